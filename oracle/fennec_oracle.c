@@ -1,0 +1,1003 @@
+/*
+ * fennec_oracle.c -- CPU restatement of fennec's per-pixel hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it -- always as the
+ * checker (or as the timed CPU baseline), never as the thing shipped.  The
+ * product path (fennec_amd/) must not import, link or fall back to it.
+ *
+ * PARITY UNPINNED: the reference (shamspias/fennec) is pure Go, there is no Go
+ * toolchain in the build image, and the reference's tests hold no golden
+ * vectors for this path -- only range/invariant assertions
+ * (fennec_test.go:82-163,510-560,612-736,802-821,1101-1115).  Those
+ * assertions are all re-run against this file by tests/test_oracle.py, and an
+ * independently written numpy restatement (tests/np_restatement.py) must
+ * agree with it bit for bit, but no Go binary has ever been compared with it.
+ *
+ * Numeric contract: IEEE fp64, evaluated left to right
+ * exactly as the Go source writes it, no FMA contraction (amd64, GOAMD64=v1).
+ * Build with -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ * Weight tables (SSIM 8x8 window, blur 1-D kernel, Lanczos taps) are computed
+ * here with glibc's exp()/sin(); Go's math.Exp/math.Sin may differ from glibc
+ * in the last ulp, which is why every kernel-level entry point takes the
+ * table as an INPUT -- the table generators are convenience, not contract.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* parallelDo (resize.go:200-239): static contiguous split over procs  */
+/* ------------------------------------------------------------------ */
+
+typedef void (*orc_range_fn)(int from, int to, void *arg);
+
+typedef struct {
+    orc_range_fn fn;
+    void *arg;
+    int from, to;
+} orc_job;
+
+static void *orc_job_main(void *p)
+{
+    orc_job *j = (orc_job *)p;
+    j->fn(j->from, j->to, j->arg);
+    return NULL;
+}
+
+/* resize.go:200-239 -- batchSize = ceil(count/procs); empty batches skipped. */
+static void parallel_do(int start, int stop, int procs, orc_range_fn fn, void *arg)
+{
+    int count = stop - start;
+    if (count <= 0) return;
+    if (procs > count) procs = count;
+    if (procs <= 1) {
+        fn(start, stop, arg);
+        return;
+    }
+    int batch = (count + procs - 1) / procs;
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)procs);
+    orc_job *jobs = (orc_job *)malloc(sizeof(orc_job) * (size_t)procs);
+    int n = 0;
+    for (int p = 0; p < procs; p++) {
+        int bs = start + p * batch, be = bs + batch;
+        if (be > stop) be = stop;
+        if (bs >= be) continue;
+        jobs[n].fn = fn; jobs[n].arg = arg; jobs[n].from = bs; jobs[n].to = be;
+        pthread_create(&tid[n], NULL, orc_job_main, &jobs[n]);
+        n++;
+    }
+    for (int i = 0; i < n; i++) pthread_join(tid[i], NULL);
+    free(tid);
+    free(jobs);
+}
+
+/* ------------------------------------------------------------------ */
+/* clampF (convert.go:149-158)                                         */
+/* ------------------------------------------------------------------ */
+
+ORC_API uint8_t orc_clampF(double x)
+{
+    /* math.Round = round half away from zero = C round() */
+    int64_t v = (int64_t)round(x);
+    if (v > 255) return 255;
+    if (v < 0) return 0;
+    return (uint8_t)v;
+}
+#define clampF orc_clampF
+
+/* ------------------------------------------------------------------ */
+/* ssim.go                                                             */
+/* ------------------------------------------------------------------ */
+
+/* ssim.go:11-17 -- Go untyped constants are exact rationals: 2.55^2, 7.65^2 */
+static const double SSIM_C1 = 6.5025;
+static const double SSIM_C2 = 58.5225;
+
+/* toLuminance (ssim.go:207-220) */
+ORC_API void orc_to_luminance(const uint8_t *pix, int stride, int w, int h, double *lum)
+{
+    for (int y = 0; y < h; y++) {
+        size_t off = (size_t)y * (size_t)stride;
+        for (int x = 0; x < w; x++) {
+            size_t i = off + (size_t)x * 4;
+            lum[(size_t)y * w + x] =
+                0.299 * (double)pix[i] + 0.587 * (double)pix[i + 1] + 0.114 * (double)pix[i + 2];
+        }
+    }
+}
+
+/* gaussianKernel (ssim.go:223-241); taps x,y in [-half, half) */
+ORC_API void orc_gaussian_kernel(int size, double sigma, double *kernel)
+{
+    int half = size / 2;
+    double sum = 0;
+    int idx = 0;
+    for (int y = -half; y < half; y++) {
+        for (int x = -half; x < half; x++) {
+            double val = exp(-(double)(x * x + y * y) / (2 * sigma * sigma));
+            kernel[idx] = val;
+            sum += val;
+            idx++;
+        }
+    }
+    for (int i = 0; i < size * size; i++) kernel[i] /= sum;
+}
+
+/* one row band of windowedSSIM's body (ssim.go:110-148) */
+static void ssim_band(const double *lumA, const double *lumB, int w, int startY, int endY,
+                      const double *kernel, double *sum_out, long *count_out)
+{
+    const int half = 4;
+    double localSum = 0;
+    long localCount = 0;
+    for (int y = startY; y < endY; y++) {
+        for (int x = half; x < w - half; x++) {
+            double muA = 0, muB = 0, sigAA = 0, sigBB = 0, sigAB = 0;
+            int ki = 0;
+            for (int wy = -half; wy < half; wy++) {
+                for (int wx = -half; wx < half; wx++) {
+                    size_t idx = (size_t)(y + wy) * w + (x + wx);
+                    double weight = kernel[ki];
+                    double va = lumA[idx], vb = lumB[idx];
+                    muA += va * weight;
+                    muB += vb * weight;
+                    ki++;
+                }
+            }
+            ki = 0;
+            for (int wy = -half; wy < half; wy++) {
+                for (int wx = -half; wx < half; wx++) {
+                    size_t idx = (size_t)(y + wy) * w + (x + wx);
+                    double weight = kernel[ki];
+                    double da = lumA[idx] - muA;
+                    double db = lumB[idx] - muB;
+                    sigAA += da * da * weight;
+                    sigBB += db * db * weight;
+                    sigAB += da * db * weight;
+                    ki++;
+                }
+            }
+            double num = (2 * muA * muB + SSIM_C1) * (2 * sigAB + SSIM_C2);
+            double den = (muA * muA + muB * muB + SSIM_C1) * (sigAA + sigBB + SSIM_C2);
+            localSum += num / den;
+            localCount++;
+        }
+    }
+    *sum_out = localSum;
+    *count_out = localCount;
+}
+
+typedef struct {
+    const double *lumA, *lumB, *kernel;
+    int w, h, rowsPerProc;
+    double *sums;
+    long *counts;
+} ssim_mt_arg;
+
+static void ssim_mt_body(int from, int to, void *p)
+{
+    ssim_mt_arg *a = (ssim_mt_arg *)p;
+    for (int proc = from; proc < to; proc++) {
+        int startY = 4 + proc * a->rowsPerProc;
+        int endY = startY + a->rowsPerProc;
+        if (endY > a->h - 4) endY = a->h - 4;
+        ssim_band(a->lumA, a->lumB, a->w, startY, endY, a->kernel, &a->sums[proc], &a->counts[proc]);
+    }
+}
+
+/*
+ * windowedSSIM (ssim.go:73-166).  `procs` plays GOMAXPROCS: the reference
+ * splits rows into `procs` bands, keeps one partial (sum,count) per band and
+ * adds the partials serially (ssim.go:84-94,155-160), so its last bits depend
+ * on GOMAXPROCS.  procs=1 is the canonical oracle order.
+ * The 8x8 window table is an input (see file header).
+ */
+ORC_API double orc_windowed_ssim(const double *lumA, const double *lumB, int w, int h,
+                                 const double *kernel, int procs)
+{
+    const int windowSize = 8;
+    int rows = h - windowSize + 1;
+    if (procs > rows) procs = rows;
+    if (procs < 1) procs = 1;
+    int rowsPerProc = (rows + procs - 1) / procs;
+    double *sums = (double *)calloc((size_t)procs, sizeof(double));
+    long *counts = (long *)calloc((size_t)procs, sizeof(long));
+    ssim_mt_arg a = {lumA, lumB, kernel, w, h, rowsPerProc, sums, counts};
+    /* one goroutine per band (ssim.go:97-152) */
+    parallel_do(0, procs, procs, ssim_mt_body, &a);
+    double totalSum = 0;
+    long totalCount = 0;
+    for (int p = 0; p < procs; p++) {
+        totalSum += sums[p];
+        totalCount += counts[p];
+    }
+    free(sums);
+    free(counts);
+    if (totalCount == 0) return 1.0;
+    return totalSum / (double)totalCount;
+}
+
+/*
+ * pixelSSIM (ssim.go:169-204).  Walks the flat Pix slices; `pix_len` is
+ * len(a.Pix) (4*w*h for a fresh image).
+ */
+ORC_API double orc_pixel_ssim(const uint8_t *a, const uint8_t *b, int w, int h, size_t pix_len)
+{
+    double n = (double)(w * h);
+    if (n == 0) return 1.0;
+    double muA = 0, muB = 0;
+    for (size_t i = 0; i < pix_len; i += 4) {
+        double la = 0.299 * (double)a[i] + 0.587 * (double)a[i + 1] + 0.114 * (double)a[i + 2];
+        double lb = 0.299 * (double)b[i] + 0.587 * (double)b[i + 1] + 0.114 * (double)b[i + 2];
+        muA += la;
+        muB += lb;
+    }
+    muA /= n;
+    muB /= n;
+    double sigAA = 0, sigBB = 0, sigAB = 0;
+    for (size_t i = 0; i < pix_len; i += 4) {
+        double la = 0.299 * (double)a[i] + 0.587 * (double)a[i + 1] + 0.114 * (double)a[i + 2];
+        double lb = 0.299 * (double)b[i] + 0.587 * (double)b[i + 1] + 0.114 * (double)b[i + 2];
+        double da = la - muA, db = lb - muB;
+        sigAA += da * da;
+        sigBB += db * db;
+        sigAB += da * db;
+    }
+    sigAA /= n;
+    sigBB /= n;
+    sigAB /= n;
+    double num = (2 * muA * muB + SSIM_C1) * (2 * sigAB + SSIM_C2);
+    double den = (muA * muA + muB * muB + SSIM_C1) * (sigAA + sigBB + SSIM_C2);
+    return num / den;
+}
+
+/* boxDownsample + averageBoxPixel (ssim.go:244-309).  dst must be zeroed by
+ * the caller (image.NewNRGBA); count==0 pixels are left untouched. */
+ORC_API void orc_box_downsample(const uint8_t *src, int sstride, int srcW, int srcH,
+                                uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return; /* 0x0 image */
+    double xRatio = (double)srcW / (double)dstW;
+    double yRatio = (double)srcH / (double)dstH;
+    for (int dy = 0; dy < dstH; dy++) {
+        int sy0 = (int)((double)dy * yRatio);
+        int sy1 = (int)((double)(dy + 1) * yRatio);
+        if (sy1 > srcH) sy1 = srcH;
+        if (sy0 >= sy1) sy0 = sy1 - 1;
+        if (sy0 < 0) sy0 = 0;
+        for (int dx = 0; dx < dstW; dx++) {
+            int sx0 = (int)((double)dx * xRatio);
+            int sx1 = (int)((double)(dx + 1) * xRatio);
+            if (sx1 > srcW) sx1 = srcW;
+            if (sx0 >= sx1) sx0 = sx1 - 1;
+            if (sx0 < 0) sx0 = 0;
+            double rS = 0, gS = 0, bS = 0, aS = 0, count = 0;
+            for (int sy = sy0; sy < sy1; sy++) {
+                for (int sx = sx0; sx < sx1; sx++) {
+                    size_t off = (size_t)sy * sstride + (size_t)sx * 4;
+                    rS += (double)src[off];
+                    gS += (double)src[off + 1];
+                    bS += (double)src[off + 2];
+                    aS += (double)src[off + 3];
+                    count++;
+                }
+            }
+            if (count > 0) {
+                double inv = 1.0 / count;
+                size_t off = (size_t)dy * dstride + (size_t)dx * 4;
+                dst[off] = clampF(rS * inv);
+                dst[off + 1] = clampF(gS * inv);
+                dst[off + 2] = clampF(bS * inv);
+                dst[off + 3] = clampF(aS * inv);
+            }
+        }
+    }
+}
+
+/* SSIMFast's target dims (ssim.go:52-56).  Returns 1 if a downsample happens. */
+ORC_API int orc_ssim_fast_dims(int w, int h, int *newW, int *newH)
+{
+    const int maxDim = 512;
+    *newW = w;
+    *newH = h;
+    if (w > maxDim || h > maxDim) {
+        double scale = (double)maxDim / fmax((double)w, (double)h);
+        *newW = (int)fmax(8, round((double)w * scale));
+        *newH = (int)fmax(8, round((double)h * scale));
+        return 1;
+    }
+    return 0;
+}
+
+/*
+ * SSIMFast (ssim.go:48-70).  Both images are assumed w x h (the reference does
+ * not check).  `procs` = GOMAXPROCS for windowedSSIM; boxDownsample and
+ * toLuminance are serial in the reference and stay serial here.
+ */
+ORC_API double orc_ssim_fast(const uint8_t *a, int astride, const uint8_t *b, int bstride,
+                             int w, int h, const double *kernel, int procs)
+{
+    uint8_t *da = NULL, *db = NULL;
+    int nw, nh;
+    if (orc_ssim_fast_dims(w, h, &nw, &nh)) {
+        da = (uint8_t *)calloc((size_t)nw * nh * 4, 1);
+        db = (uint8_t *)calloc((size_t)nw * nh * 4, 1);
+        orc_box_downsample(a, astride, w, h, da, nw * 4, nw, nh);
+        orc_box_downsample(b, bstride, w, h, db, nw * 4, nw, nh);
+        a = da; astride = nw * 4;
+        b = db; bstride = nw * 4;
+        w = nw; h = nh;
+    }
+    double r;
+    if (w < 8 || h < 8) {
+        /* len(Pix) of the image handed to pixelSSIM */
+        size_t len = (size_t)(h > 0 ? (h - 1) : 0) * (size_t)astride + (size_t)w * 4;
+        if (w <= 0 || h <= 0) len = 0;
+        r = orc_pixel_ssim(a, b, w, h, len);
+    } else {
+        double *lumA = (double *)malloc(sizeof(double) * (size_t)w * h);
+        double *lumB = (double *)malloc(sizeof(double) * (size_t)w * h);
+        orc_to_luminance(a, astride, w, h, lumA);
+        orc_to_luminance(b, bstride, w, h, lumB);
+        r = orc_windowed_ssim(lumA, lumB, w, h, kernel, procs);
+        free(lumA);
+        free(lumB);
+    }
+    free(da);
+    free(db);
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* resize.go                                                           */
+/* ------------------------------------------------------------------ */
+
+/* lanczosKernel (resize.go:57-69), a = 3 */
+ORC_API double orc_lanczos_kernel(double x)
+{
+    const double lanczosA = 3.0;
+    if (x == 0) return 1.0;
+    if (x < 0) x = -x;
+    if (x >= lanczosA) return 0.0;
+    double xpi = x * M_PI;
+    return (lanczosA * sin(xpi) * sin(xpi / lanczosA)) / (xpi * xpi);
+}
+
+/*
+ * precomputeWeights (resize.go:164-197) in CSR form: taps of output d are
+ * index[offset[d] .. offset[d+1]) / weight[...].  Call with index==NULL to
+ * size the arrays (returns total taps); offset must hold dstSize+1 ints.
+ * ratio/support are derived as resizeH/resizeV do (resize.go:81-87,125-131).
+ */
+ORC_API int orc_precompute_weights(int dstSize, int srcSize, int *offset, int *index, double *weight)
+{
+    const double lanczosA = 3.0;
+    double ratio = (double)srcSize / (double)dstSize;
+    double support = lanczosA;
+    if (ratio > 1) support = lanczosA * ratio;
+    double filterScale = fmax(ratio, 1.0);
+    int total = 0;
+    for (int d = 0; d < dstSize; d++) {
+        double center = ((double)d + 0.5) * ratio - 0.5;
+        int left = (int)ceil(center - support);
+        int right = (int)floor(center + support);
+        if (left < 0) left = 0;
+        if (right >= srcSize) right = srcSize - 1;
+        double wsum = 0;
+        int first = total;
+        if (offset) offset[d] = total;
+        for (int s = left; s <= right; s++) {
+            double w = orc_lanczos_kernel(((double)s - center) / filterScale);
+            if (w != 0) {
+                wsum += w;
+                if (index) {
+                    index[total] = s;
+                    weight[total] = w;
+                }
+                total++;
+            }
+        }
+        if (wsum != 0 && index) {
+            for (int i = first; i < total; i++) weight[i] /= wsum;
+        }
+    }
+    if (offset) offset[dstSize] = total;
+    return total;
+}
+
+typedef struct {
+    const uint8_t *src;
+    int sstride;
+    uint8_t *dst;
+    int dstride;
+    int dstW, dstH;
+    const int *offset, *index;
+    const double *weight;
+} resize_arg;
+
+/* resizeH body (resize.go:89-115): parallel over rows y */
+static void resize_h_rows(int from, int to, void *p)
+{
+    resize_arg *a = (resize_arg *)p;
+    for (int y = from; y < to; y++) {
+        for (int dx = 0; dx < a->dstW; dx++) {
+            double r = 0, g = 0, b = 0, al = 0;
+            for (int t = a->offset[dx]; t < a->offset[dx + 1]; t++) {
+                size_t off = (size_t)y * a->sstride + (size_t)a->index[t] * 4;
+                double sa = (double)a->src[off + 3];
+                double w = a->weight[t];
+                double aw = sa * w;
+                r += (double)a->src[off] * aw;
+                g += (double)a->src[off + 1] * aw;
+                b += (double)a->src[off + 2] * aw;
+                al += aw;
+            }
+            size_t dstOff = (size_t)y * a->dstride + (size_t)dx * 4;
+            if (al > 0.5) {
+                double inv = 1.0 / al;
+                a->dst[dstOff] = clampF(r * inv);
+                a->dst[dstOff + 1] = clampF(g * inv);
+                a->dst[dstOff + 2] = clampF(b * inv);
+                a->dst[dstOff + 3] = clampF(al);
+            }
+        }
+    }
+}
+
+/* resizeV body (resize.go:133-158): parallel over columns x */
+static void resize_v_cols(int from, int to, void *p)
+{
+    resize_arg *a = (resize_arg *)p;
+    for (int x = from; x < to; x++) {
+        for (int dy = 0; dy < a->dstH; dy++) {
+            double r = 0, g = 0, b = 0, al = 0;
+            for (int t = a->offset[dy]; t < a->offset[dy + 1]; t++) {
+                size_t off = (size_t)a->index[t] * a->sstride + (size_t)x * 4;
+                double sa = (double)a->src[off + 3];
+                double w = a->weight[t];
+                double aw = sa * w;
+                r += (double)a->src[off] * aw;
+                g += (double)a->src[off + 1] * aw;
+                b += (double)a->src[off + 2] * aw;
+                al += aw;
+            }
+            size_t dstOff = (size_t)dy * a->dstride + (size_t)x * 4;
+            if (al > 0.5) {
+                double inv = 1.0 / al;
+                a->dst[dstOff] = clampF(r * inv);
+                a->dst[dstOff + 1] = clampF(g * inv);
+                a->dst[dstOff + 2] = clampF(b * inv);
+                a->dst[dstOff + 3] = clampF(al);
+            }
+        }
+    }
+}
+
+/* resizeH (resize.go:77-118) with an explicit tap table; dst (dstW x srcH) must be zeroed. */
+ORC_API void orc_resize_h(const uint8_t *src, int sstride, int srcH, uint8_t *dst, int dstride,
+                          int dstW, const int *offset, const int *index, const double *weight,
+                          int procs)
+{
+    resize_arg a = {src, sstride, dst, dstride, dstW, srcH, offset, index, weight};
+    parallel_do(0, srcH, procs, resize_h_rows, &a);
+}
+
+/* resizeV (resize.go:121-161) with an explicit tap table; dst (dstW x dstH) must be zeroed. */
+ORC_API void orc_resize_v(const uint8_t *src, int sstride, uint8_t *dst, int dstride, int dstW,
+                          int dstH, const int *offset, const int *index, const double *weight,
+                          int procs)
+{
+    resize_arg a = {src, sstride, dst, dstride, dstW, dstH, offset, index, weight};
+    parallel_do(0, dstW, procs, resize_v_cols, &a);
+}
+
+/*
+ * lanczosResize (resize.go:37-53).  dst is dstW x dstH, tight or not, zeroed.
+ * Returns 0 when the reference would hand back a 0x0 image (any dim <= 0).
+ * Equal dims: flat copy of Pix (resize.go:45-49).
+ */
+ORC_API int orc_lanczos_resize(const uint8_t *src, int sstride, int srcW, int srcH, uint8_t *dst,
+                               int dstride, int dstW, int dstH, int procs)
+{
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return 0;
+    if (srcW == dstW && srcH == dstH) {
+        size_t slen = (size_t)(srcH - 1) * sstride + (size_t)srcW * 4;
+        size_t dlen = (size_t)(dstH - 1) * dstride + (size_t)dstW * 4;
+        memcpy(dst, src, slen < dlen ? slen : dlen);
+        return 1;
+    }
+    int *offH = (int *)malloc(sizeof(int) * ((size_t)dstW + 1));
+    int nH = orc_precompute_weights(dstW, srcW, offH, NULL, NULL);
+    int *idxH = (int *)malloc(sizeof(int) * (size_t)(nH > 0 ? nH : 1));
+    double *wH = (double *)malloc(sizeof(double) * (size_t)(nH > 0 ? nH : 1));
+    orc_precompute_weights(dstW, srcW, offH, idxH, wH);
+    int *offV = (int *)malloc(sizeof(int) * ((size_t)dstH + 1));
+    int nV = orc_precompute_weights(dstH, srcH, offV, NULL, NULL);
+    int *idxV = (int *)malloc(sizeof(int) * (size_t)(nV > 0 ? nV : 1));
+    double *wV = (double *)malloc(sizeof(double) * (size_t)(nV > 0 ? nV : 1));
+    orc_precompute_weights(dstH, srcH, offV, idxV, wV);
+
+    uint8_t *tmp = (uint8_t *)calloc((size_t)dstW * srcH * 4, 1);
+    orc_resize_h(src, sstride, srcH, tmp, dstW * 4, dstW, offH, idxH, wH, procs);
+    orc_resize_v(tmp, dstW * 4, dst, dstride, dstW, dstH, offV, idxV, wV, procs);
+    free(tmp);
+    free(offH); free(idxH); free(wH);
+    free(offV); free(idxV); free(wV);
+    return 1;
+}
+
+/*
+ * smartResize's target dims (resize.go:12-32).  Returns 0 when the image
+ * already fits (the reference returns the SAME pointer), 1 otherwise.
+ */
+ORC_API int orc_smart_resize_dims(int srcW, int srcH, int maxW, int maxH, int *dstW, int *dstH)
+{
+    if (maxW <= 0) maxW = srcW;
+    if (maxH <= 0) maxH = srcH;
+    *dstW = srcW;
+    *dstH = srcH;
+    if (srcW <= maxW && srcH <= maxH) return 0;
+    double ratio = fmin((double)maxW / (double)srcW, (double)maxH / (double)srcH);
+    *dstW = (int)fmax(1, round((double)srcW * ratio));
+    *dstH = (int)fmax(1, round((double)srcH * ratio));
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* SSIM / MSSSIM (need lanczosResize)                                  */
+/* ------------------------------------------------------------------ */
+
+/* SSIM (ssim.go:24-43) */
+ORC_API double orc_ssim(const uint8_t *a, int astride, int aw, int ah, const uint8_t *b,
+                        int bstride, int bw, int bh, const double *kernel, int procs)
+{
+    uint8_t *rb = NULL;
+    int w = aw, h = ah;
+    if (w != bw || h != bh) {
+        if (w > 0 && h > 0 && bw > 0 && bh > 0) {
+            rb = (uint8_t *)calloc((size_t)w * h * 4, 1);
+            orc_lanczos_resize(b, bstride, bw, bh, rb, w * 4, w, h, procs);
+            b = rb;
+            bstride = w * 4;
+        }
+    }
+    double r;
+    if (w < 8 || h < 8) {
+        size_t len = (w > 0 && h > 0) ? (size_t)(h - 1) * astride + (size_t)w * 4 : 0;
+        r = orc_pixel_ssim(a, b, w, h, len);
+    } else {
+        double *lumA = (double *)malloc(sizeof(double) * (size_t)w * h);
+        double *lumB = (double *)malloc(sizeof(double) * (size_t)w * h);
+        orc_to_luminance(a, astride, w, h, lumA);
+        orc_to_luminance(b, bstride, w, h, lumB);
+        r = orc_windowed_ssim(lumA, lumB, w, h, kernel, procs);
+        free(lumA);
+        free(lumB);
+    }
+    free(rb);
+    return r;
+}
+
+/* MSSSIM (ssim.go:313-365).  per_level (optional, 5 doubles) receives each
+ * level's SSIMFast value, NaN for levels not evaluated. */
+ORC_API double orc_msssim(const uint8_t *a, int astride, int aw, int ah, const uint8_t *b,
+                          int bstride, int bw, int bh, const double *kernel, int procs,
+                          double *per_level)
+{
+    int w = aw, h = ah;
+    uint8_t *rb = NULL;
+    if (w != bw || h != bh) {
+        rb = (uint8_t *)calloc((size_t)(w > 0 ? w : 0) * (h > 0 ? h : 0) * 4 + 4, 1);
+        orc_lanczos_resize(b, bstride, bw, bh, rb, w * 4, w, h, procs);
+        b = rb;
+        bstride = w * 4;
+    }
+    double weights[5] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    int levels = 5, nweights = 5;
+    {
+        int tw = w, th = h;
+        for (int i = 0; i < levels - 1; i++) {
+            int minDim = (int)fmin((double)tw, (double)th);
+            if (minDim < 8) {
+                nweights = i + 1;
+                double sum = 0;
+                for (int j = 0; j < nweights; j++) sum += weights[j];
+                for (int j = 0; j < nweights; j++) weights[j] /= sum;
+                break;
+            }
+            tw /= 2;
+            th /= 2;
+        }
+    }
+    /* toNRGBA copies (convert.go:12-19): tight w x h */
+    size_t n0 = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 4;
+    uint8_t *ac = (uint8_t *)malloc(n0 + 4), *bc = (uint8_t *)malloc(n0 + 4);
+    for (int y = 0; y < h; y++) {
+        memcpy(ac + (size_t)y * w * 4, a + (size_t)y * astride, (size_t)w * 4);
+        memcpy(bc + (size_t)y * w * 4, b + (size_t)y * bstride, (size_t)w * 4);
+    }
+    int cw = w, ch = h;
+    double result = 0;
+    if (per_level) for (int i = 0; i < 5; i++) per_level[i] = NAN;
+    for (int i = 0; i < nweights; i++) {
+        double ssim = orc_ssim_fast(ac, cw * 4, bc, cw * 4, cw, ch, kernel, procs);
+        if (per_level) per_level[i] = ssim;
+        result += weights[i] * log(fmax(ssim, 1e-10));
+        if (i < nweights - 1) {
+            int nw = cw / 2, nh = ch / 2;
+            if (nw < 8 || nh < 8) break;
+            uint8_t *na = (uint8_t *)calloc((size_t)nw * nh * 4, 1);
+            uint8_t *nb = (uint8_t *)calloc((size_t)nw * nh * 4, 1);
+            orc_box_downsample(ac, cw * 4, cw, ch, na, nw * 4, nw, nh);
+            orc_box_downsample(bc, cw * 4, cw, ch, nb, nw * 4, nw, nh);
+            free(ac);
+            free(bc);
+            ac = na; bc = nb; cw = nw; ch = nh;
+        }
+    }
+    free(ac);
+    free(bc);
+    free(rb);
+    return exp(result);
+}
+
+/* ------------------------------------------------------------------ */
+/* effects.go                                                          */
+/* ------------------------------------------------------------------ */
+
+/* GaussianBlur's 1-D kernel (effects.go:153-165).  Returns radius; kernel
+ * must hold 2*radius+1 doubles (call with kernel==NULL to get the radius). */
+ORC_API int orc_blur_kernel(double sigma, double *kernel)
+{
+    int radius = (int)ceil(sigma * 3);
+    if (!kernel) return radius;
+    int kernelSize = radius * 2 + 1;
+    double sum = 0;
+    for (int i = 0; i < kernelSize; i++) {
+        double x = (double)(i - radius);
+        kernel[i] = exp(-(x * x) / (2 * sigma * sigma));
+        sum += kernel[i];
+    }
+    for (int i = 0; i < kernelSize; i++) kernel[i] /= sum;
+    return radius;
+}
+
+typedef struct {
+    const uint8_t *src;   /* pass input */
+    int sstride;
+    const uint8_t *alpha; /* image alpha is copied from */
+    int astride;
+    uint8_t *dst;
+    int dstride;
+    int w, h, radius;
+    const double *kernel;
+} blur_arg;
+
+/* horizontal pass (effects.go:169-191): parallel over rows */
+static void blur_h_rows(int from, int to, void *p)
+{
+    blur_arg *a = (blur_arg *)p;
+    int kernelSize = a->radius * 2 + 1;
+    for (int y = from; y < to; y++) {
+        for (int x = 0; x < a->w; x++) {
+            double r = 0, g = 0, b = 0;
+            for (int k = 0; k < kernelSize; k++) {
+                int sx = x + k - a->radius;
+                if (sx < 0) sx = 0;
+                else if (sx >= a->w) sx = a->w - 1;
+                size_t off = (size_t)y * a->sstride + (size_t)sx * 4;
+                double wt = a->kernel[k];
+                r += (double)a->src[off] * wt;
+                g += (double)a->src[off + 1] * wt;
+                b += (double)a->src[off + 2] * wt;
+            }
+            size_t off = (size_t)y * a->dstride + (size_t)x * 4;
+            a->dst[off] = clampF(r);
+            a->dst[off + 1] = clampF(g);
+            a->dst[off + 2] = clampF(b);
+            a->dst[off + 3] = a->alpha[(size_t)y * a->astride + (size_t)x * 4 + 3];
+        }
+    }
+}
+
+/* vertical pass (effects.go:195-217): parallel over columns */
+static void blur_v_cols(int from, int to, void *p)
+{
+    blur_arg *a = (blur_arg *)p;
+    int kernelSize = a->radius * 2 + 1;
+    for (int x = from; x < to; x++) {
+        for (int y = 0; y < a->h; y++) {
+            double r = 0, g = 0, b = 0;
+            for (int k = 0; k < kernelSize; k++) {
+                int sy = y + k - a->radius;
+                if (sy < 0) sy = 0;
+                else if (sy >= a->h) sy = a->h - 1;
+                size_t off = (size_t)sy * a->sstride + (size_t)x * 4;
+                double wt = a->kernel[k];
+                r += (double)a->src[off] * wt;
+                g += (double)a->src[off + 1] * wt;
+                b += (double)a->src[off + 2] * wt;
+            }
+            size_t off = (size_t)y * a->dstride + (size_t)x * 4;
+            a->dst[off] = clampF(r);
+            a->dst[off + 1] = clampF(g);
+            a->dst[off + 2] = clampF(b);
+            a->dst[off + 3] = a->alpha[(size_t)y * a->astride + (size_t)x * 4 + 3];
+        }
+    }
+}
+
+/*
+ * GaussianBlur (effects.go:146-220) with the 1-D kernel as an input.
+ * The sigma<=0 "same pointer" guard (effects.go:147-149) belongs to the caller.
+ * The intermediate image is rounded to uint8 (effects.go:186-188).
+ */
+ORC_API void orc_gaussian_blur_k(const uint8_t *src, int sstride, int w, int h,
+                                 const double *kernel, int radius, uint8_t *dst, int dstride,
+                                 int procs)
+{
+    if (w <= 0 || h <= 0) return;
+    uint8_t *tmp = (uint8_t *)malloc((size_t)w * h * 4);
+    blur_arg ha = {src, sstride, src, sstride, tmp, w * 4, w, h, radius, kernel};
+    parallel_do(0, h, procs, blur_h_rows, &ha);
+    blur_arg va = {tmp, w * 4, src, sstride, dst, dstride, w, h, radius, kernel};
+    parallel_do(0, w, procs, blur_v_cols, &va);
+    free(tmp);
+}
+
+ORC_API void orc_gaussian_blur(const uint8_t *src, int sstride, int w, int h, double sigma,
+                               uint8_t *dst, int dstride, int procs)
+{
+    int radius = orc_blur_kernel(sigma, NULL);
+    double *kernel = (double *)malloc(sizeof(double) * (size_t)(2 * radius + 1));
+    orc_blur_kernel(sigma, kernel);
+    orc_gaussian_blur_k(src, sstride, w, h, kernel, radius, dst, dstride, procs);
+    free(kernel);
+}
+
+typedef struct {
+    const uint8_t *src;
+    int sstride;
+    const uint8_t *blur;
+    int bstride;
+    uint8_t *dst;
+    int dstride;
+    int w, h;
+    double amount;
+} fx_arg;
+
+/* gaussianBlur3x3 interior rows (effects.go:122-139) */
+static void blur3_rows(int from, int to, void *p)
+{
+    fx_arg *a = (fx_arg *)p;
+    const uint8_t *s = a->src;
+    int st = a->sstride;
+    for (int y = from; y < to; y++) {
+        for (int x = 1; x < a->w - 1; x++) {
+            for (int c = 0; c < 3; c++) {
+                double sum = 0;
+                sum += (double)s[(size_t)(y - 1) * st + (size_t)(x - 1) * 4 + c] * 1;
+                sum += (double)s[(size_t)(y - 1) * st + (size_t)(x)*4 + c] * 2;
+                sum += (double)s[(size_t)(y - 1) * st + (size_t)(x + 1) * 4 + c] * 1;
+                sum += (double)s[(size_t)(y)*st + (size_t)(x - 1) * 4 + c] * 2;
+                sum += (double)s[(size_t)(y)*st + (size_t)(x)*4 + c] * 4;
+                sum += (double)s[(size_t)(y)*st + (size_t)(x + 1) * 4 + c] * 2;
+                sum += (double)s[(size_t)(y + 1) * st + (size_t)(x - 1) * 4 + c] * 1;
+                sum += (double)s[(size_t)(y + 1) * st + (size_t)(x)*4 + c] * 2;
+                sum += (double)s[(size_t)(y + 1) * st + (size_t)(x + 1) * 4 + c] * 1;
+                a->dst[(size_t)y * a->dstride + (size_t)x * 4 + c] = clampF(sum / 16.0);
+            }
+        }
+    }
+}
+
+/* gaussianBlur3x3 (effects.go:116-141): dst = copy(src), interior blurred */
+ORC_API void orc_blur3x3(const uint8_t *src, int sstride, int w, int h, uint8_t *dst, int dstride,
+                         int procs)
+{
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * dstride, src + (size_t)y * sstride, (size_t)w * 4);
+    fx_arg a = {src, sstride, NULL, 0, dst, dstride, w, h, 0};
+    parallel_do(1, h - 1, procs, blur3_rows, &a);
+}
+
+/* Sharpen body (effects.go:28-42) */
+static void sharpen_rows(int from, int to, void *p)
+{
+    fx_arg *a = (fx_arg *)p;
+    for (int y = from; y < to; y++) {
+        for (int x = 0; x < a->w; x++) {
+            size_t so = (size_t)y * a->sstride + (size_t)x * 4;
+            size_t bo = (size_t)y * a->bstride + (size_t)x * 4;
+            size_t dof = (size_t)y * a->dstride + (size_t)x * 4;
+            for (int c = 0; c < 3; c++) {
+                double orig = (double)a->src[so + c];
+                double blur = (double)a->blur[bo + c];
+                double val = orig + a->amount * (orig - blur);
+                a->dst[dof + c] = clampF(val);
+            }
+            a->dst[dof + 3] = a->src[so + 3];
+        }
+    }
+}
+
+/*
+ * Sharpen (effects.go:10-45).  Returns 0 when the reference returns the SAME
+ * pointer (strength<=0, or w<3 || h<3) and leaves dst untouched; 1 otherwise.
+ */
+ORC_API int orc_sharpen(const uint8_t *src, int sstride, int w, int h, double strength,
+                        uint8_t *dst, int dstride, int procs)
+{
+    if (strength <= 0) return 0;
+    if (strength > 1) strength = 1;
+    if (w < 3 || h < 3) return 0;
+    uint8_t *blurred = (uint8_t *)malloc((size_t)w * h * 4);
+    orc_blur3x3(src, sstride, w, h, blurred, w * 4, procs);
+    fx_arg a = {src, sstride, blurred, w * 4, dst, dstride, w, h, 1.0 + strength * 1.5};
+    parallel_do(0, h, procs, sharpen_rows, &a);
+    free(blurred);
+    return 1;
+}
+
+/* localEdgeStrength (effects.go:93-112) */
+static double local_edge_strength(const uint8_t *pix, int stride, int x, int y)
+{
+#define LUM(px, py) \
+    (0.299 * (double)pix[(size_t)(py)*stride + (size_t)(px)*4] + \
+     0.587 * (double)pix[(size_t)(py)*stride + (size_t)(px)*4 + 1] + \
+     0.114 * (double)pix[(size_t)(py)*stride + (size_t)(px)*4 + 2])
+    double gx = -LUM(x - 1, y - 1) + LUM(x + 1, y - 1) - 2 * LUM(x - 1, y) + 2 * LUM(x + 1, y) -
+                LUM(x - 1, y + 1) + LUM(x + 1, y + 1);
+    double gy = -LUM(x - 1, y - 1) - 2 * LUM(x, y - 1) - LUM(x + 1, y - 1) + LUM(x - 1, y + 1) +
+                2 * LUM(x, y + 1) + LUM(x + 1, y + 1);
+#undef LUM
+    double mag = sqrt(gx * gx + gy * gy);
+    double normalized = mag / 400.0;
+    if (normalized > 1) normalized = 1;
+    return normalized;
+}
+
+/* AdaptiveSharpen interior rows (effects.go:70-87) */
+static void adaptive_rows(int from, int to, void *p)
+{
+    fx_arg *a = (fx_arg *)p;
+    for (int y = from; y < to; y++) {
+        for (int x = 1; x < a->w - 1; x++) {
+            size_t so = (size_t)y * a->sstride + (size_t)x * 4;
+            double edgeStr = local_edge_strength(a->src, a->sstride, x, y);
+            double localAmount = a->amount * edgeStr;
+            size_t bo = (size_t)y * a->bstride + (size_t)x * 4;
+            size_t dof = (size_t)y * a->dstride + (size_t)x * 4;
+            for (int c = 0; c < 3; c++) {
+                double orig = (double)a->src[so + c];
+                double blur = (double)a->blur[bo + c];
+                double val = orig + localAmount * (orig - blur);
+                a->dst[dof + c] = clampF(val);
+            }
+            a->dst[dof + 3] = a->src[so + 3];
+        }
+    }
+}
+
+/* AdaptiveSharpen (effects.go:49-90).  Return value as orc_sharpen. */
+ORC_API int orc_adaptive_sharpen(const uint8_t *src, int sstride, int w, int h, double strength,
+                                 uint8_t *dst, int dstride, int procs)
+{
+    if (strength <= 0) return 0;
+    if (strength > 1) strength = 1;
+    if (w < 3 || h < 3) return 0;
+    uint8_t *blurred = (uint8_t *)malloc((size_t)w * h * 4);
+    orc_blur3x3(src, sstride, w, h, blurred, w * 4, procs);
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * dstride, src + (size_t)y * sstride, (size_t)w * 4);
+    fx_arg a = {src, sstride, blurred, w * 4, dst, dstride, w, h, 1.0 + strength * 2.0};
+    parallel_do(1, h - 1, procs, adaptive_rows, &a);
+    free(blurred);
+    return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* orientation (convert.go:186-256, exif.go:178-203)                   */
+/* ------------------------------------------------------------------ */
+
+static void rot90cw(const uint8_t *s, int ss, int w, int h, uint8_t *d, int ds)
+{ /* convert.go:187-199: dst is h wide, w high */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            memcpy(d + (size_t)x * ds + (size_t)(h - 1 - y) * 4, s + (size_t)y * ss + (size_t)x * 4, 4);
+}
+static void rot180(const uint8_t *s, int ss, int w, int h, uint8_t *d, int ds)
+{ /* convert.go:202-214 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            memcpy(d + (size_t)(h - 1 - y) * ds + (size_t)(w - 1 - x) * 4, s + (size_t)y * ss + (size_t)x * 4, 4);
+}
+static void rot270cw(const uint8_t *s, int ss, int w, int h, uint8_t *d, int ds)
+{ /* convert.go:217-229: dst is h wide, w high */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            memcpy(d + (size_t)(w - 1 - x) * ds + (size_t)y * 4, s + (size_t)y * ss + (size_t)x * 4, 4);
+}
+static void flip_h(const uint8_t *s, int ss, int w, int h, uint8_t *d, int ds)
+{ /* convert.go:232-244 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            memcpy(d + (size_t)y * ds + (size_t)(w - 1 - x) * 4, s + (size_t)y * ss + (size_t)x * 4, 4);
+}
+static void flip_v(const uint8_t *s, int ss, int w, int h, uint8_t *d, int ds)
+{ /* convert.go:247-256 */
+    for (int y = 0; y < h; y++)
+        memcpy(d + (size_t)(h - 1 - y) * ds, s + (size_t)y * ss, (size_t)w * 4);
+}
+
+/*
+ * ApplyOrientation (exif.go:178-203).  Output dims: w x h for 2,3,4; h x w for
+ * 5,6,7,8.  dst is tight (stride = 4*outW).  Returns 0 for orientations the
+ * reference answers with the SAME pointer (0, 1, unknown), 1 otherwise.
+ */
+ORC_API int orc_apply_orientation(const uint8_t *src, int sstride, int w, int h, int orient,
+                                  uint8_t *dst)
+{
+    switch (orient) {
+    case 2: flip_h(src, sstride, w, h, dst, w * 4); return 1;
+    case 3: rot180(src, sstride, w, h, dst, w * 4); return 1;
+    case 4: flip_v(src, sstride, w, h, dst, w * 4); return 1;
+    case 5: { /* rotate 270 CW, then flip horizontal */
+        uint8_t *t = (uint8_t *)malloc((size_t)w * h * 4 + 4);
+        rot270cw(src, sstride, w, h, t, h * 4);
+        flip_h(t, h * 4, h, w, dst, h * 4);
+        free(t);
+        return 1;
+    }
+    case 6: rot90cw(src, sstride, w, h, dst, h * 4); return 1;
+    case 7: { /* rotate 90 CW, then flip horizontal */
+        uint8_t *t = (uint8_t *)malloc((size_t)w * h * 4 + 4);
+        rot90cw(src, sstride, w, h, t, h * 4);
+        flip_h(t, h * 4, h, w, dst, h * 4);
+        free(t);
+        return 1;
+    }
+    case 8: rot270cw(src, sstride, w, h, dst, h * 4); return 1;
+    default: return 0;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* batch.go:140-158 Summarize                                          */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Summarize (batch.go:140-158) over parallel arrays: failed[i]!=0 is r.Err!=nil,
+ * has_result[i] is r.Result!=nil.  out = {Total, Succeeded, Failed, TotalSaved};
+ * returns AvgSSIM.
+ */
+ORC_API double orc_summarize(int n, const int *failed, const int *has_result,
+                             const int64_t *original_size, const int64_t *compressed_size,
+                             const double *ssim, int64_t out[4])
+{
+    int64_t succeeded = 0, nfailed = 0, saved = 0;
+    double ssimSum = 0;
+    for (int i = 0; i < n; i++) {
+        if (failed[i]) {
+            nfailed++;
+            continue;
+        }
+        succeeded++;
+        if (has_result[i]) {
+            saved += original_size[i] - compressed_size[i];
+            ssimSum += ssim[i];
+        }
+    }
+    out[0] = n;
+    out[1] = succeeded;
+    out[2] = nfailed;
+    out[3] = saved;
+    return succeeded > 0 ? ssimSum / (double)succeeded : 0.0;
+}

@@ -1,0 +1,308 @@
+"""ctypes binding of oracle/libfennec_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import
+this module, and only as the checker / timed CPU baseline.  The product package
+(fennec_amd) never imports it.  See fennec_oracle.c for the parity statement
+("parity unpinned": no Go toolchain, no golden vectors in the reference).
+
+Images are numpy uint8 arrays of shape (h, w, 4), C-contiguous (tight stride),
+or any array whose last two axes are contiguous (stride = arr.strides[0]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfennec_oracle.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int)
+_i64p = C.POINTER(C.c_int64)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (strict fp64 flags, oracle/Makefile)."""
+    src = os.path.join(_HERE, "fennec_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libfennec_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_clampF.restype = C.c_uint8
+        L.orc_clampF.argtypes = [C.c_double]
+        L.orc_to_luminance.restype = None
+        L.orc_to_luminance.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _f64p]
+        L.orc_gaussian_kernel.restype = None
+        L.orc_gaussian_kernel.argtypes = [C.c_int, C.c_double, _f64p]
+        L.orc_windowed_ssim.restype = C.c_double
+        L.orc_windowed_ssim.argtypes = [_f64p, _f64p, C.c_int, C.c_int, _f64p, C.c_int]
+        L.orc_pixel_ssim.restype = C.c_double
+        L.orc_pixel_ssim.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_size_t]
+        L.orc_box_downsample.restype = None
+        L.orc_box_downsample.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_ssim_fast_dims.restype = C.c_int
+        L.orc_ssim_fast_dims.argtypes = [C.c_int, C.c_int, _i32p, _i32p]
+        L.orc_ssim_fast.restype = C.c_double
+        L.orc_ssim_fast.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _f64p, C.c_int]
+        L.orc_lanczos_kernel.restype = C.c_double
+        L.orc_lanczos_kernel.argtypes = [C.c_double]
+        L.orc_precompute_weights.restype = C.c_int
+        L.orc_precompute_weights.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f64p]
+        L.orc_resize_h.restype = None
+        L.orc_resize_h.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int]
+        L.orc_resize_v.restype = None
+        L.orc_resize_v.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, C.c_int]
+        L.orc_lanczos_resize.restype = C.c_int
+        L.orc_lanczos_resize.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_smart_resize_dims.restype = C.c_int
+        L.orc_smart_resize_dims.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]
+        L.orc_ssim.restype = C.c_double
+        L.orc_ssim.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _f64p, C.c_int]
+        L.orc_msssim.restype = C.c_double
+        L.orc_msssim.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, _f64p, C.c_int, _f64p]
+        L.orc_blur_kernel.restype = C.c_int
+        L.orc_blur_kernel.argtypes = [C.c_double, _f64p]
+        L.orc_gaussian_blur_k.restype = None
+        L.orc_gaussian_blur_k.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _f64p, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_gaussian_blur.restype = None
+        L.orc_gaussian_blur.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.c_int, C.c_int]
+        L.orc_blur3x3.restype = None
+        L.orc_blur3x3.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_sharpen.restype = C.c_int
+        L.orc_sharpen.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.c_int, C.c_int]
+        L.orc_adaptive_sharpen.restype = C.c_int
+        L.orc_adaptive_sharpen.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.c_int, C.c_int]
+        L.orc_apply_orientation.restype = C.c_int
+        L.orc_apply_orientation.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
+        L.orc_summarize.restype = C.c_double
+        L.orc_summarize.argtypes = [C.c_int, _i32p, _i32p, _i64p, _i64p, _f64p, _i64p]
+        _lib = L
+    return _lib
+
+
+# ---------------------------------------------------------------- helpers
+def _img(a: np.ndarray):
+    """(ptr, stride, w, h) of an (h, w, 4) uint8 image with contiguous rows."""
+    assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 4, a.shape
+    h, w = a.shape[:2]
+    if h > 0 and w > 0:
+        assert a.strides[2] == 1 and a.strides[1] == 4, "rows must be contiguous"
+    stride = a.strides[0] if h > 1 else w * 4
+    return a.ctypes.data_as(_u8p), int(stride), int(w), int(h)
+
+
+def _f64(a: np.ndarray):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_f64p)
+
+
+def _i32(a: np.ndarray):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+def new_image(w: int, h: int) -> np.ndarray:
+    """image.NewNRGBA(image.Rect(0,0,w,h)): zeroed, tight."""
+    return np.zeros((max(h, 0), max(w, 0), 4), dtype=np.uint8)
+
+
+# ---------------------------------------------------------------- API
+def clampF(x: float) -> int:
+    return int(lib().orc_clampF(float(x)))
+
+
+def gaussian_kernel(size: int = 8, sigma: float = 1.5) -> np.ndarray:
+    k = np.empty(size * size, dtype=np.float64)
+    lib().orc_gaussian_kernel(size, sigma, k.ctypes.data_as(_f64p))
+    return k
+
+
+def to_luminance(img: np.ndarray) -> np.ndarray:
+    p, s, w, h = _img(img)
+    lum = np.empty((h, w), dtype=np.float64)
+    lib().orc_to_luminance(p, s, w, h, lum.ctypes.data_as(_f64p))
+    return lum
+
+
+def windowed_ssim(lumA, lumB, kernel=None, procs: int = 1) -> float:
+    lumA, pa = _f64(lumA)
+    lumB, pb = _f64(lumB)
+    h, w = lumA.shape
+    k, pk = _f64(gaussian_kernel() if kernel is None else kernel)
+    return float(lib().orc_windowed_ssim(pa, pb, w, h, pk, procs))
+
+
+def pixel_ssim(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    pa, _, w, h = _img(a)
+    pb, _, _, _ = _img(b)
+    return float(lib().orc_pixel_ssim(pa, pb, w, h, a.size))
+
+
+def box_downsample(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    p, s, w, h = _img(img)
+    if w <= 0 or h <= 0 or dw <= 0 or dh <= 0:
+        return new_image(0, 0)
+    dst = new_image(dw, dh)
+    lib().orc_box_downsample(p, s, w, h, dst.ctypes.data_as(_u8p), dw * 4, dw, dh)
+    return dst
+
+
+def ssim_fast_dims(w: int, h: int):
+    nw, nh = C.c_int(), C.c_int()
+    ds = lib().orc_ssim_fast_dims(w, h, C.byref(nw), C.byref(nh))
+    return bool(ds), nw.value, nh.value
+
+
+def ssim_fast(a: np.ndarray, b: np.ndarray, kernel=None, procs: int = 1) -> float:
+    pa, sa, w, h = _img(a)
+    pb, sb, _, _ = _img(b)
+    k, pk = _f64(gaussian_kernel() if kernel is None else kernel)
+    return float(lib().orc_ssim_fast(pa, sa, pb, sb, w, h, pk, procs))
+
+
+def ssim(a: np.ndarray, b: np.ndarray, kernel=None, procs: int = 1) -> float:
+    pa, sa, aw, ah = _img(a)
+    pb, sb, bw, bh = _img(b)
+    k, pk = _f64(gaussian_kernel() if kernel is None else kernel)
+    return float(lib().orc_ssim(pa, sa, aw, ah, pb, sb, bw, bh, pk, procs))
+
+
+def msssim(a: np.ndarray, b: np.ndarray, kernel=None, procs: int = 1, per_level: bool = False):
+    pa, sa, aw, ah = _img(a)
+    pb, sb, bw, bh = _img(b)
+    k, pk = _f64(gaussian_kernel() if kernel is None else kernel)
+    lv = np.empty(5, dtype=np.float64)
+    r = float(lib().orc_msssim(pa, sa, aw, ah, pb, sb, bw, bh, pk, procs, lv.ctypes.data_as(_f64p)))
+    return (r, lv) if per_level else r
+
+
+def lanczos_kernel(x: float) -> float:
+    return float(lib().orc_lanczos_kernel(float(x)))
+
+
+def precompute_weights(dst_size: int, src_size: int):
+    """CSR tap table (offset[dst+1], index[n], weight[n]) of resize.go:164-197."""
+    off = np.zeros(dst_size + 1, dtype=np.int32)
+    n = lib().orc_precompute_weights(dst_size, src_size, off.ctypes.data_as(_i32p), None, None)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    wt = np.zeros(max(n, 1), dtype=np.float64)
+    lib().orc_precompute_weights(dst_size, src_size, off.ctypes.data_as(_i32p),
+                                 idx.ctypes.data_as(_i32p), wt.ctypes.data_as(_f64p))
+    return off, idx[:n], wt[:n]
+
+
+def resize_h(img: np.ndarray, dw: int, table=None, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    off, idx, wt = precompute_weights(dw, w) if table is None else table
+    off, po = _i32(off); idx, pi = _i32(idx); wt, pw = _f64(wt)
+    dst = new_image(dw, h)
+    lib().orc_resize_h(p, s, h, dst.ctypes.data_as(_u8p), dw * 4, dw, po, pi, pw, procs)
+    return dst
+
+
+def resize_v(img: np.ndarray, dh: int, table=None, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    off, idx, wt = precompute_weights(dh, h) if table is None else table
+    off, po = _i32(off); idx, pi = _i32(idx); wt, pw = _f64(wt)
+    dst = new_image(w, dh)
+    lib().orc_resize_v(p, s, dst.ctypes.data_as(_u8p), w * 4, w, dh, po, pi, pw, procs)
+    return dst
+
+
+def lanczos_resize(img: np.ndarray, dw: int, dh: int, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    if w <= 0 or h <= 0 or dw <= 0 or dh <= 0:
+        return new_image(0, 0)
+    dst = new_image(dw, dh)
+    lib().orc_lanczos_resize(p, s, w, h, dst.ctypes.data_as(_u8p), dw * 4, dw, dh, procs)
+    return dst
+
+
+def smart_resize_dims(w: int, h: int, max_w: int, max_h: int):
+    dw, dh = C.c_int(), C.c_int()
+    r = lib().orc_smart_resize_dims(w, h, max_w, max_h, C.byref(dw), C.byref(dh))
+    return bool(r), dw.value, dh.value
+
+
+def smart_resize(img: np.ndarray, max_w: int, max_h: int, procs: int = 1) -> np.ndarray:
+    h, w = img.shape[:2]
+    r, dw, dh = smart_resize_dims(w, h, max_w, max_h)
+    return lanczos_resize(img, dw, dh, procs) if r else img
+
+
+def blur_kernel(sigma: float):
+    r = lib().orc_blur_kernel(float(sigma), None)
+    k = np.empty(2 * r + 1, dtype=np.float64)
+    lib().orc_blur_kernel(float(sigma), k.ctypes.data_as(_f64p))
+    return r, k
+
+
+def gaussian_blur(img: np.ndarray, sigma: float, kernel=None, procs: int = 1) -> np.ndarray:
+    if sigma <= 0:
+        return img  # same pointer (effects.go:147-149)
+    p, s, w, h = _img(img)
+    dst = new_image(w, h)
+    if kernel is None:
+        radius, kernel = blur_kernel(sigma)
+    else:
+        radius = (len(kernel) - 1) // 2
+    k, pk = _f64(kernel)
+    lib().orc_gaussian_blur_k(p, s, w, h, pk, radius, dst.ctypes.data_as(_u8p), w * 4, procs)
+    return dst
+
+
+def blur3x3(img: np.ndarray, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    dst = new_image(w, h)
+    lib().orc_blur3x3(p, s, w, h, dst.ctypes.data_as(_u8p), w * 4, procs)
+    return dst
+
+
+def sharpen(img: np.ndarray, strength: float, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    dst = new_image(w, h)
+    r = lib().orc_sharpen(p, s, w, h, float(strength), dst.ctypes.data_as(_u8p), w * 4, procs)
+    return dst if r else img
+
+
+def adaptive_sharpen(img: np.ndarray, strength: float, procs: int = 1) -> np.ndarray:
+    p, s, w, h = _img(img)
+    dst = new_image(w, h)
+    r = lib().orc_adaptive_sharpen(p, s, w, h, float(strength), dst.ctypes.data_as(_u8p), w * 4, procs)
+    return dst if r else img
+
+
+def apply_orientation(img: np.ndarray, orient: int) -> np.ndarray:
+    p, s, w, h = _img(img)
+    ow, oh = (h, w) if orient in (5, 6, 7, 8) else (w, h)
+    dst = new_image(ow, oh)
+    r = lib().orc_apply_orientation(p, s, w, h, int(orient), dst.ctypes.data_as(_u8p))
+    return dst if r else img
+
+
+def summarize(failed, has_result, original_size, compressed_size, ssim_vals):
+    n = len(failed)
+    f, pf = _i32(np.asarray(failed)); hr, ph = _i32(np.asarray(has_result))
+    o = np.ascontiguousarray(original_size, dtype=np.int64)
+    c = np.ascontiguousarray(compressed_size, dtype=np.int64)
+    s, ps = _f64(np.asarray(ssim_vals))
+    out = np.zeros(4, dtype=np.int64)
+    avg = lib().orc_summarize(n, pf, ph, o.ctypes.data_as(_i64p), c.ctypes.data_as(_i64p), ps,
+                              out.ctypes.data_as(_i64p))
+    return dict(Total=int(out[0]), Succeeded=int(out[1]), Failed=int(out[2]),
+                TotalSaved=int(out[3]), AvgSSIM=float(avg))

@@ -1,0 +1,243 @@
+"""CPU tests of the oracle itself (no GPU).
+
+1. Every range/invariant assertion the reference's own tests make on the hot
+   path (fennec_test.go:82-163,510-560,612-736,802-821,1101-1115) holds for
+   the C oracle -- the only "fixtures" the reference has.
+2. The C oracle and the independently written numpy restatement
+   (tests/np_restatement.py) agree BIT FOR BIT.
+Parity with a Go binary is unpinned (no Go toolchain).
+"""
+import numpy as np
+import pytest
+
+import np_restatement as npr
+from fennec_amd import synth
+
+
+# ---------------------------------------------------------------- reference invariants
+def test_ssim_identical(orc):           # fennec_test.go:82-88
+    img = synth.make_test_image(100, 100)
+    assert orc.ssim(img, img) >= 0.999
+
+
+def test_ssim_different(orc):           # fennec_test.go:90-97
+    a = synth.make_solid_image(100, 100, (0, 0, 0, 255))
+    b = synth.make_solid_image(100, 100, (255, 255, 255, 255))
+    assert orc.ssim(a, b) <= 0.1
+
+
+def _minus(img, d):
+    m = img.copy()
+    r = m[..., 0]
+    r[r > d] -= d
+    return m
+
+
+def test_ssim_similar(orc):             # fennec_test.go:99-113
+    img = synth.make_test_image(100, 100)
+    s = orc.ssim(img, _minus(img, 10))
+    assert 0.85 <= s <= 0.999
+
+
+def test_ssim_fast_identical(orc):      # fennec_test.go:115-121
+    img = synth.make_test_image(500, 500)
+    assert orc.ssim_fast(img, img) >= 0.999
+
+
+def test_ssim_small_image(orc):         # fennec_test.go:123-129 (pixelSSIM path)
+    img = synth.make_test_image(4, 4)
+    assert orc.ssim(img, img) >= 0.999
+
+
+def test_msssim(orc):                   # fennec_test.go:131-163
+    img = synth.make_test_image(128, 128)
+    assert orc.msssim(img, img) >= 0.99
+    a = synth.make_solid_image(128, 128, (0, 0, 0, 255))
+    b = synth.make_solid_image(128, 128, (255, 255, 255, 255))
+    assert orc.msssim(a, b) <= 0.1
+    s = orc.msssim(img, _minus(img, 5))
+    assert 0.7 <= s < 1.0
+
+
+def test_lanczos_resize_dims_and_quality(orc):   # fennec_test.go:510-538
+    img = synth.make_test_image(100, 100)
+    assert orc.lanczos_resize(img, 50, 50).shape == (50, 50, 4)
+    assert orc.lanczos_resize(img, 200, 200).shape == (200, 200, 4)
+    same = orc.lanczos_resize(img, 100, 100)
+    assert same.shape == (100, 100, 4) and np.array_equal(same, img)
+    restored = orc.lanczos_resize(orc.lanczos_resize(img, 50, 50), 100, 100)
+    assert orc.ssim(img, restored) >= 0.5
+
+
+def test_smart_resize(orc):             # fennec_test.go:540-552
+    img = synth.make_test_image(1000, 500)
+    r = orc.smart_resize(img, 200, 200)
+    assert r.shape[1] <= 200 and r.shape[0] <= 200 and r.shape[:2] == (100, 200)
+    assert orc.smart_resize(img, 2000, 2000) is img
+
+
+def test_lanczos_resize_zero(orc):      # fennec_test.go:554-560
+    img = synth.make_test_image(100, 100)
+    assert orc.lanczos_resize(img, 0, 50).shape[:2] == (0, 0)
+
+
+def test_sharpen_invariants(orc):       # fennec_test.go:612-657
+    img = synth.make_striped_image(100, 100, 10)
+    s = orc.sharpen(img, 0.8)
+    assert s.shape == img.shape and not np.array_equal(s, img)
+    g = synth.make_test_image(100, 100)
+    assert orc.sharpen(g, 0) is g
+    assert orc.sharpen(img, 5.0).shape == img.shape
+    assert np.array_equal(orc.sharpen(img, 5.0), orc.sharpen(img, 1.0))   # clamped to 1
+    t = synth.make_test_image(2, 2)
+    assert orc.sharpen(t, 0.5) is t
+
+
+def test_adaptive_sharpen_invariants(orc):   # fennec_test.go:659-694
+    img = synth.make_striped_image(100, 100, 10)
+    s = orc.adaptive_sharpen(img, 0.5)
+    assert s.shape == img.shape and not np.array_equal(s, img)
+    g = synth.make_test_image(100, 100)
+    assert orc.adaptive_sharpen(g, 0) is g
+    t = synth.make_test_image(2, 2)
+    assert orc.adaptive_sharpen(t, 0.5) is t
+
+
+def test_gaussian_blur_invariants(orc):  # fennec_test.go:696-736
+    img = synth.make_test_image(100, 100)
+    b = orc.gaussian_blur(img, 2.0)
+    assert b.shape == img.shape
+    assert orc.ssim(img, b) >= 0.3
+    assert orc.gaussian_blur(img, 0) is img
+    assert orc.gaussian_blur(img, -1.0) is img
+    big = orc.gaussian_blur(img, 20.0)
+    assert big.shape == img.shape and orc.ssim(img, big) <= 0.999
+
+
+def test_apply_orientation_dims(orc):   # fennec_test.go:802-821
+    img = np.zeros((50, 100, 4), dtype=np.uint8)
+    img[0, 0, 0] = 255
+    img[0, 0, 3] = 255
+    assert orc.apply_orientation(img, 1) is img
+    assert orc.apply_orientation(img, 0) is img
+    assert orc.apply_orientation(img, 99) is img
+    assert orc.apply_orientation(img, 6).shape == (100, 50, 4)
+    assert orc.apply_orientation(img, 3).shape == (50, 100, 4)
+    # the marked corner pixel lands where a 90 CW rotation puts it: top-right
+    assert orc.apply_orientation(img, 6)[0, 49, 0] == 255
+
+
+def test_box_downsample_dims(orc):      # fennec_test.go:1101-1115
+    img = synth.make_test_image(100, 100)
+    assert orc.box_downsample(img, 10, 10).shape == (10, 10, 4)
+    assert orc.box_downsample(img, 0, 0).shape[:2] == (0, 0)
+
+
+def test_clampF(orc):                   # convert.go:149-158
+    for x, want in [(0.5, 1), (1.5, 2), (2.5, 3), (-0.5, 0), (254.5, 255), (255.4, 255), (300, 255),
+                    (-3, 0), (0.49999999999999994, 0), (127.49999999999999, 127)]:
+        assert orc.clampF(x) == want
+        assert int(npr.clampF(x)) == want
+
+
+# ---------------------------------------------------------------- C oracle == numpy restatement
+IMAGES = [
+    ("grad_64x48", lambda: synth.make_test_image(64, 48)),
+    ("alpha_37x29", lambda: synth.make_test_image_with_alpha(37, 29)),
+    ("photo_100x75", lambda: synth.large_photo(100, 75, 3)),
+    ("noise_53x41", lambda: synth.noise_image(53, 41, 7, alpha=True)),
+    ("stripes_40x40", lambda: synth.make_striped_image(40, 40, 5)),
+]
+
+
+@pytest.mark.parametrize("name,mk", IMAGES)
+def test_tables_match(orc, name, mk):
+    assert np.array_equal(orc.gaussian_kernel(), npr.gaussian_kernel())
+    for s in (0.5, 1.0, 2.0, 3.3):
+        r1, k1 = orc.blur_kernel(s)
+        r2, k2 = npr.blur_kernel(s)
+        assert r1 == r2 and np.array_equal(k1, k2)
+    for d, s in [(50, 100), (200, 100), (33, 100), (100, 7), (7, 100)]:
+        off, idx, wt = orc.precompute_weights(d, s)
+        tab = npr.precompute_weights(d, s)
+        for i, (ti, tw) in enumerate(tab):
+            assert list(idx[off[i]:off[i + 1]]) == ti
+            assert np.array_equal(wt[off[i]:off[i + 1]], np.array(tw))
+
+
+@pytest.mark.parametrize("name,mk", IMAGES)
+def test_effects_match(orc, name, mk):
+    img = mk()
+    assert np.array_equal(orc.gaussian_blur(img, 2.0), npr.gaussian_blur(img, 2.0))
+    assert np.array_equal(orc.gaussian_blur(img, 0.7), npr.gaussian_blur(img, 0.7))
+    assert np.array_equal(orc.blur3x3(img), npr.blur3x3(img))
+    assert np.array_equal(orc.sharpen(img, 0.8), npr.sharpen(img, 0.8))
+    assert np.array_equal(orc.adaptive_sharpen(img, 0.5), npr.adaptive_sharpen(img, 0.5))
+    for o in range(0, 10):
+        assert np.array_equal(orc.apply_orientation(img, o), npr.apply_orientation(img, o))
+
+
+@pytest.mark.parametrize("name,mk", IMAGES)
+def test_resize_match(orc, name, mk):
+    img = mk()
+    h, w = img.shape[:2]
+    for dw, dh in [(w // 2, h // 2), (w * 2, h * 2 - 1), (w - 3, h + 5), (1, 1), (w, h), (9, h)]:
+        assert np.array_equal(orc.lanczos_resize(img, dw, dh), npr.lanczos_resize(img, dw, dh)), (dw, dh)
+    for dw, dh in [(10, 10), (w // 2, h // 2), (w, h), (w + 7, h + 3), (1, 1), (8, 9)]:
+        assert np.array_equal(orc.box_downsample(img, dw, dh), npr.box_downsample(img, dw, dh)), (dw, dh)
+
+
+@pytest.mark.parametrize("name,mk", IMAGES)
+def test_ssim_family_match(orc, name, mk):
+    a = mk()
+    b = npr.gaussian_blur(a, 1.2)
+    assert orc.ssim(a, b) == npr.ssim(a, b)
+    assert orc.ssim_fast(a, b) == npr.ssim_fast(a, b)
+    assert orc.msssim(a, b) == npr.msssim(a, b)
+    assert np.array_equal(orc.to_luminance(a), npr.to_luminance(a))
+    small = a[:5, :6].copy()
+    assert orc.pixel_ssim(small, b[:5, :6].copy()) == npr.pixel_ssim(small, b[:5, :6].copy())
+    # mismatched dims -> implicit lanczos resize of b (ssim.go:31-33, 320-322)
+    half = npr.lanczos_resize(a, a.shape[1] // 2, a.shape[0] // 2)
+    assert orc.ssim(a, half) == npr.ssim(a, half)
+    assert orc.msssim(a, half) == npr.msssim(a, half)
+
+
+def test_ssim_fast_downsample_path_match(orc):
+    a = synth.large_photo(640, 480, 1)          # > 512 -> boxDownsample to 512x384
+    b = npr.gaussian_blur(a, 2.0)
+    assert orc.ssim_fast_dims(640, 480) == (True, 512, 384) == npr.ssim_fast_dims(640, 480)
+    assert orc.ssim_fast_dims(3840, 2160) == (True, 512, 288)
+    assert orc.ssim_fast_dims(7680, 4320) == (True, 512, 288)
+    assert orc.ssim_fast_dims(2000, 3) == (True, 512, 8)
+    assert orc.ssim_fast(a, b) == npr.ssim_fast(a, b)
+
+
+def test_windowed_ssim_degenerate_and_procs(orc):
+    a = synth.make_test_image(8, 8)
+    assert orc.ssim(a, a) == 1.0                 # w==8: zero windows -> 1.0 (ssim.go:162-164)
+    a = synth.large_photo(96, 64, 0)
+    b = npr.gaussian_blur(a, 1.0)
+    s1 = orc.ssim(a, b, procs=1)
+    for p in (2, 3, 8, 64):                      # GOMAXPROCS changes only the last bits
+        assert abs(orc.ssim(a, b, procs=p) - s1) < 1e-14
+        assert np.array_equal(orc.gaussian_blur(a, 2.0, procs=p), orc.gaussian_blur(a, 2.0))
+        assert np.array_equal(orc.lanczos_resize(a, 50, 31, procs=p), orc.lanczos_resize(a, 50, 31))
+        assert np.array_equal(orc.adaptive_sharpen(a, 0.5, procs=p), orc.adaptive_sharpen(a, 0.5))
+
+
+def test_strided_input(orc):
+    """Kernels index y*Stride + 4x (image.NRGBA SubImage semantics)."""
+    big = synth.noise_image(80, 60, 11, alpha=True)
+    sub = big[5:45, 8:72]                        # rows contiguous, stride = 80*4
+    tight = np.ascontiguousarray(sub)
+    assert np.array_equal(orc.gaussian_blur(sub, 1.5), orc.gaussian_blur(tight, 1.5))
+    assert np.array_equal(orc.lanczos_resize(sub, 30, 20), orc.lanczos_resize(tight, 30, 20))
+    assert np.array_equal(orc.box_downsample(sub, 16, 10), orc.box_downsample(tight, 16, 10))
+    assert orc.ssim(sub, tight) == 1.0
+
+
+def test_summarize(orc):                # batch.go:140-158
+    s = orc.summarize([0, 1, 0, 0], [1, 0, 1, 0], [100, 0, 300, 50], [40, 0, 100, 0], [0.95, 0, 0.97, 0])
+    assert s["Total"] == 4 and s["Succeeded"] == 3 and s["Failed"] == 1
+    assert s["TotalSaved"] == 260 and s["AvgSSIM"] == (0.95 + 0.97) / 3.0
