@@ -1,0 +1,542 @@
+"""fennec_amd -- fennec's per-pixel hot path on AMD Instinct MI355X (gfx950).
+
+A thin ctypes binding of ``libfennec_hip.so`` (C ABI: ``include/fennec_hip.h``):
+hand-written HIP kernels behind the reference's own function names
+(``SSIM``, ``SSIMFast``, ``MSSSIM``, ``GaussianBlur``, ``Sharpen``,
+``AdaptiveSharpen``, ``ApplyOrientation``, ``lanczosResize``, ``smartResize``,
+``boxDownsample``; shamspias/fennec ssim.go / resize.go / effects.go / exif.go).
+
+Images are ``image.NRGBA`` byte buffers:
+
+* numpy ``uint8`` arrays of shape ``(h, w, 4)`` with contiguous rows -> host space
+  (the library stages them through the GPU and returns numpy arrays);
+* torch ``uint8`` CUDA/HIP tensors of shape ``(h, w, 4)`` -> device space (results
+  are new device tensors; nothing crosses PCIe).
+
+There is NO CPU implementation in this package: without the built library or
+without a GPU every call raises.  Build with ``python -c "import __graft_entry__
+as g; g.build()"`` or ``make -C fennec_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import synth  # noqa: F401  (deterministic test/bench images)
+
+__all__ = [
+    "Context", "default_context", "load_library", "FennecError",
+    "SSIM", "SSIMFast", "MSSSIM", "GaussianBlur", "Sharpen", "AdaptiveSharpen",
+    "ApplyOrientation", "lanczosResize", "smartResize", "boxDownsample",
+    "gaussianKernel", "blurKernel", "precomputeWeights", "Summarize",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfennec_hip.so")
+
+FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
+FNX_HOST, FNX_DEVICE = 0, 1
+FNX_BLUR_FAST, FNX_BLUR_EXACT = 0, 1
+
+_u8p = C.c_void_p
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class FennecError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def _sig(L, name, restype, argtypes):
+    f = getattr(L, name)
+    f.restype = restype
+    f.argtypes = argtypes
+
+
+def load_library() -> C.CDLL:
+    """dlopen libfennec_hip.so and declare every entry point of include/fennec_hip.h."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise FennecError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(make -C fennec_amd/csrc, or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        ctx = C.c_void_p
+        i = C.c_int
+        d = C.c_double
+        img = [_u8p, i]                                   # pointer, stride
+        _sig(L, "fnx_version", C.c_char_p, [])
+        _sig(L, "fnx_device_count", i, [])
+        _sig(L, "fnx_last_error", C.c_char_p, [])
+        _sig(L, "fnx_ctx_create", i, [i, C.POINTER(ctx)])
+        _sig(L, "fnx_ctx_destroy", None, [ctx])
+        _sig(L, "fnx_ctx_device", i, [ctx])
+        _sig(L, "fnx_ctx_stream", C.c_void_p, [ctx])
+        _sig(L, "fnx_ctx_sync", i, [ctx])
+        _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
+        _sig(L, "fnx_free", i, [ctx, C.c_void_p])
+        _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
+        _sig(L, "fnx_download", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
+        _sig(L, "fnx_gaussian_blur", i, [ctx, i] + img + [i, i, _f64p, i, i] + img)
+        _sig(L, "fnx_blur3x3", i, [ctx, i] + img + [i, i] + img)
+        _sig(L, "fnx_sharpen", i, [ctx, i] + img + [i, i, d] + img)
+        _sig(L, "fnx_adaptive_sharpen", i, [ctx, i] + img + [i, i, d] + img)
+        _sig(L, "fnx_resize_h", i, [ctx, i] + img + [i, i, _i32p, _i32p, _f64p] + img + [i])
+        _sig(L, "fnx_resize_v", i, [ctx, i] + img + [i, i, _i32p, _i32p, _f64p] + img + [i])
+        _sig(L, "fnx_lanczos_resize", i, [ctx, i] + img + [i, i, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p] + img + [i, i])
+        _sig(L, "fnx_box_downsample", i, [ctx, i] + img + [i, i] + img + [i, i])
+        _sig(L, "fnx_ssim_fast", i, [ctx, i] + img + img + [i, i, _f64p, _f64p])
+        _sig(L, "fnx_ssim", i, [ctx, i] + img + img + [i, i, _f64p, _f64p])
+        _sig(L, "fnx_msssim", i, [ctx, i] + img + img + [i, i, _f64p, _f64p, _f64p])
+        _sig(L, "fnx_ssim_fast_prepare", i, [ctx, i] + img + [i, i, C.POINTER(C.c_void_p)])
+        _sig(L, "fnx_ssim_fast_against", i, [ctx, C.c_void_p, i] + img + [_f64p, _f64p])
+        _sig(L, "fnx_prepared_free", None, [ctx, C.c_void_p])
+        _sig(L, "fnx_orient", i, [ctx, i] + img + [i, i, i] + img)
+        _sig(L, "fnx_gaussian_blur_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i])
+        _sig(L, "fnx_ssim_fast_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p, _f64p])
+        _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
+        _sig(L, "fennec_blurKernel", i, [d, _f64p])
+        _sig(L, "fennec_lanczosKernel", d, [d])
+        _sig(L, "fennec_precomputeWeights", i, [i, i, _i32p, _i32p, _f64p])
+        _sig(L, "fennec_smartResizeDims", i, [i, i, i, i, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fennec_ssimFastDims", i, [i, i, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fennec_SSIM", i, [ctx, i] + img + [i, i] + img + [i, i, _f64p])
+        _sig(L, "fennec_SSIMFast", i, [ctx, i] + img + img + [i, i, _f64p])
+        _sig(L, "fennec_MSSSIM", i, [ctx, i] + img + [i, i] + img + [i, i, _f64p])
+        _sig(L, "fennec_GaussianBlur", i, [ctx, i] + img + [i, i, d] + img)
+        _sig(L, "fennec_Sharpen", i, [ctx, i] + img + [i, i, d] + img)
+        _sig(L, "fennec_AdaptiveSharpen", i, [ctx, i] + img + [i, i, d] + img)
+        _sig(L, "fennec_ApplyOrientation", i, [ctx, i] + img + [i, i, i] + img)
+        _sig(L, "fennec_lanczosResize", i, [ctx, i] + img + [i, i] + img + [i, i])
+        _sig(L, "fennec_boxDownsample", i, [ctx, i] + img + [i, i] + img + [i, i])
+        _sig(L, "fennec_Summarize", d, [i, _i32p, _i32p, _i64p, _i64p, _f64p, _i64p])
+        _lib = L
+        return L
+
+
+# names include/fennec_hip.h declares (checked by tests/test_abi.py against the header itself)
+def exported_symbols():
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "fennec_hip.h")
+    text = open(hdr).read()
+    return sorted(set(re.findall(r"\b((?:fnx|fennec)_\w+)\s*\(", text)))
+
+
+# ---------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class _Img:
+    """(space, pointer, stride, w, h) view of a numpy array or a torch device tensor."""
+
+    __slots__ = ("space", "ptr", "stride", "w", "h", "obj")
+
+    def __init__(self, x):
+        self.obj = x
+        if _is_torch(x):
+            import torch
+            if not x.is_cuda or x.dtype != torch.uint8 or x.dim() != 3 or x.shape[2] != 4:
+                raise FennecError("device images must be uint8 CUDA/HIP tensors of shape (h, w, 4)")
+            h, w = int(x.shape[0]), int(x.shape[1])
+            if h > 0 and w > 0 and (x.stride(2) != 1 or x.stride(1) != 4):
+                raise FennecError("image rows must be contiguous")
+            self.space, self.ptr = FNX_DEVICE, x.data_ptr()
+            self.stride = int(x.stride(0)) if h > 1 else w * 4
+        else:
+            a = x
+            if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 4:
+                raise FennecError("host images must be numpy uint8 arrays of shape (h, w, 4)")
+            h, w = a.shape[:2]
+            if h > 0 and w > 0 and (a.strides[2] != 1 or a.strides[1] != 4):
+                raise FennecError("image rows must be contiguous")
+            self.space, self.ptr = FNX_HOST, a.ctypes.data
+            self.stride = int(a.strides[0]) if h > 1 else w * 4
+        self.w, self.h = int(w), int(h)
+
+    def like(self, w: int, h: int):
+        """A fresh tight w x h image in the same space.  Every kernel writes every dst pixel
+        (zeros where image.NewNRGBA's zero pixel survives in the reference), so no memset --
+        a torch.zeros fill would also run on torch's stream and race with the ctx stream."""
+        if self.space == FNX_DEVICE:
+            import torch
+            return torch.empty((h, w, 4), dtype=torch.uint8, device=self.obj.device)
+        return np.empty((h, w, 4), dtype=np.uint8)
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_f64p)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+class Context:
+    """One GPU, one stream, its scratch (fnx_ctx).  Not re-entrant: one per worker thread."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.fnx_ctx_create(int(device), C.byref(h))
+        if rc < 0:
+            raise FennecError(f"fnx_ctx_create({device}): {self._err()}")
+        self._h = h
+        self.device = int(device)
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _err(self) -> str:
+        return (self._lib.fnx_last_error() or b"").decode()
+
+    def _chk(self, rc: int, what: str) -> int:
+        if rc < 0:
+            raise FennecError(f"{what} failed ({rc}): {self._err()}")
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fnx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self._lib.fnx_ctx_sync(self._h), "fnx_ctx_sync")
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.fnx_ctx_stream(self._h) or 0)
+
+    def _pair(self, a, b):
+        ia, ib = _Img(a), _Img(b)
+        if ia.space != ib.space:
+            raise FennecError("both images must live in the same space (numpy or device tensors)")
+        return ia, ib
+
+    # -- table generators (Go side of the seam) -----------------------------------------
+    def gaussianKernel(self, size: int = 8, sigma: float = 1.5) -> np.ndarray:
+        k = np.empty(size * size, dtype=np.float64)
+        self._lib.fennec_gaussianKernel(size, sigma, k.ctypes.data_as(_f64p))
+        return k
+
+    def blurKernel(self, sigma: float):
+        r = self._lib.fennec_blurKernel(float(sigma), None)
+        k = np.empty(2 * r + 1, dtype=np.float64)
+        self._lib.fennec_blurKernel(float(sigma), k.ctypes.data_as(_f64p))
+        return r, k
+
+    def precomputeWeights(self, dst_size: int, src_size: int):
+        off = np.zeros(dst_size + 1, dtype=np.int32)
+        n = self._lib.fennec_precomputeWeights(dst_size, src_size, off.ctypes.data_as(_i32p), None, None)
+        idx = np.zeros(max(n, 1), dtype=np.int32)
+        wt = np.zeros(max(n, 1), dtype=np.float64)
+        self._lib.fennec_precomputeWeights(dst_size, src_size, off.ctypes.data_as(_i32p),
+                                           idx.ctypes.data_as(_i32p), wt.ctypes.data_as(_f64p))
+        return off, idx[:max(n, 0)], wt[:max(n, 0)]
+
+    def smartResizeDims(self, w, h, max_w, max_h):
+        dw, dh = C.c_int(), C.c_int()
+        r = self._lib.fennec_smartResizeDims(w, h, max_w, max_h, C.byref(dw), C.byref(dh))
+        return bool(r), dw.value, dh.value
+
+    def ssimFastDims(self, w, h):
+        nw, nh = C.c_int(), C.c_int()
+        r = self._lib.fennec_ssimFastDims(w, h, C.byref(nw), C.byref(nh))
+        return bool(r), nw.value, nh.value
+
+    # -- ssim.go ------------------------------------------------------------------------
+    def SSIM(self, img1, img2) -> float:
+        """ssim.go:24 -- full-resolution SSIM; a differently sized img2 is Lanczos-resized."""
+        a, b = self._pair(img1, img2)
+        out = C.c_double()
+        self._chk(self._lib.fennec_SSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
+                                        b.w, b.h, C.byref(out)), "SSIM")
+        return out.value
+
+    def SSIMFast(self, img1, img2) -> float:
+        """ssim.go:48 -- SSIM on <=512 px box-downsampled copies."""
+        a, b = self._pair(img1, img2)
+        out = C.c_double()
+        self._chk(self._lib.fennec_SSIMFast(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h,
+                                            C.byref(out)), "SSIMFast")
+        return out.value
+
+    def MSSSIM(self, img1, img2) -> float:
+        """ssim.go:313 -- 5-level multi-scale SSIM."""
+        a, b = self._pair(img1, img2)
+        out = C.c_double()
+        self._chk(self._lib.fennec_MSSSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
+                                          b.w, b.h, C.byref(out)), "MSSSIM")
+        return out.value
+
+    def msssim_levels(self, img1, img2, window=None):
+        """fnx_msssim with per-level SSIMFast values (equal dims)."""
+        a, b = self._pair(img1, img2)
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        out = C.c_double()
+        lv = np.empty(5, dtype=np.float64)
+        self._chk(self._lib.fnx_msssim(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h, pk,
+                                       C.byref(out), lv.ctypes.data_as(_f64p)), "fnx_msssim")
+        return out.value, lv
+
+    def boxDownsample(self, img, dstW: int, dstH: int):
+        """ssim.go:244"""
+        s = _Img(img)
+        if s.w <= 0 or s.h <= 0 or dstW <= 0 or dstH <= 0:
+            return s.like(0, 0)
+        dst = s.like(dstW, dstH)
+        d = _Img(dst)
+        self._chk(self._lib.fennec_boxDownsample(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr,
+                                                 d.stride, dstW, dstH), "boxDownsample")
+        return dst
+
+    def ssim_fast_prepare(self, img):
+        s = _Img(img)
+        p = C.c_void_p()
+        self._chk(self._lib.fnx_ssim_fast_prepare(self._h, s.space, s.ptr, s.stride, s.w, s.h, C.byref(p)),
+                  "fnx_ssim_fast_prepare")
+        return _Prepared(self, p, s.w, s.h)
+
+    # -- effects.go ---------------------------------------------------------------------
+    def GaussianBlur(self, img, sigma: float, exact: bool = False, kernel=None):
+        """effects.go:146.  sigma <= 0 returns `img` itself (same pointer)."""
+        if sigma <= 0:
+            return img
+        s = _Img(img)
+        dst = s.like(s.w, s.h)
+        d = _Img(dst)
+        if kernel is None and not exact:
+            rc = self._lib.fennec_GaussianBlur(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(sigma),
+                                               d.ptr, d.stride)
+        else:
+            if kernel is None:
+                radius, kernel = self.blurKernel(sigma)
+            else:
+                radius = (len(kernel) - 1) // 2
+            k, pk = _f64(kernel)
+            rc = self._lib.fnx_gaussian_blur(self._h, s.space, s.ptr, s.stride, s.w, s.h, pk, radius,
+                                             FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, d.ptr, d.stride)
+        self._chk(rc, "GaussianBlur")
+        return dst
+
+    def blur3x3(self, img):
+        """effects.go:116 gaussianBlur3x3"""
+        s = _Img(img)
+        dst = s.like(s.w, s.h)
+        d = _Img(dst)
+        self._chk(self._lib.fnx_blur3x3(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr, d.stride), "blur3x3")
+        return dst
+
+    def _sharpen(self, fn, name, img, strength):
+        s = _Img(img)
+        dst = s.like(s.w, s.h)
+        d = _Img(dst)
+        rc = self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(strength), d.ptr, d.stride), name)
+        return img if rc == FNX_NOOP else dst
+
+    def Sharpen(self, img, strength: float):
+        """effects.go:10.  strength <= 0 or an image under 3x3 returns `img` itself."""
+        return self._sharpen(self._lib.fennec_Sharpen, "Sharpen", img, strength)
+
+    def AdaptiveSharpen(self, img, strength: float):
+        """effects.go:49"""
+        return self._sharpen(self._lib.fennec_AdaptiveSharpen, "AdaptiveSharpen", img, strength)
+
+    # -- resize.go ----------------------------------------------------------------------
+    def lanczosResize(self, img, dstW: int, dstH: int):
+        """resize.go:37"""
+        s = _Img(img)
+        if s.w <= 0 or s.h <= 0 or dstW <= 0 or dstH <= 0:
+            return s.like(0, 0)
+        dst = s.like(dstW, dstH)
+        d = _Img(dst)
+        self._chk(self._lib.fennec_lanczosResize(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr,
+                                                 d.stride, dstW, dstH), "lanczosResize")
+        return dst
+
+    def smartResize(self, img, maxW: int, maxH: int):
+        """resize.go:12.  Returns `img` itself when it already fits."""
+        s = _Img(img)
+        r, dw, dh = self.smartResizeDims(s.w, s.h, maxW, maxH)
+        return self.lanczosResize(img, dw, dh) if r else img
+
+    def resize_pass(self, img, dst_size: int, vertical: bool, table=None):
+        """resizeH / resizeV (resize.go:77,121) with an explicit CSR tap table."""
+        s = _Img(img)
+        src_size = s.h if vertical else s.w
+        off, idx, wt = table if table is not None else self.precomputeWeights(dst_size, src_size)
+        off, po = _i32(off); idx, pi = _i32(idx); wt, pw = _f64(wt)
+        dst = s.like(s.w, dst_size) if vertical else s.like(dst_size, s.h)
+        d = _Img(dst)
+        fn = self._lib.fnx_resize_v if vertical else self._lib.fnx_resize_h
+        self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, po, pi, pw, d.ptr, d.stride, dst_size),
+                  "resize_pass")
+        return dst
+
+    # -- exif.go ------------------------------------------------------------------------
+    def ApplyOrientation(self, img, orient: int):
+        """exif.go:178.  Orientation 0, 1 and unknown values return `img` itself."""
+        orient = int(orient)
+        if orient < 2 or orient > 8:
+            return img
+        s = _Img(img)
+        ow, oh = (s.h, s.w) if orient >= 5 else (s.w, s.h)
+        dst = s.like(ow, oh)
+        d = _Img(dst)
+        self._chk(self._lib.fennec_ApplyOrientation(self._h, s.space, s.ptr, s.stride, s.w, s.h, orient,
+                                                    d.ptr, d.stride), "ApplyOrientation")
+        return dst
+
+    # -- batched forms (device tensors) ---------------------------------------------------
+    def GaussianBlurBatch(self, imgs, sigma: float, outs=None, exact: bool = False):
+        """n same-sized device images, one launch per stage (enqueued; call sync() to wait)."""
+        if sigma <= 0:
+            return list(imgs)
+        views = [_Img(t) for t in imgs]
+        if any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("batched ops take device tensors")
+        w, h, st = views[0].w, views[0].h, views[0].stride
+        if outs is None:
+            outs = [views[0].like(w, h) for _ in views]
+        oviews = [_Img(t) for t in outs]
+        n = len(views)
+        srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+        dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
+        radius, kernel = self.blurKernel(sigma)
+        k, pk = _f64(kernel)
+        self._chk(self._lib.fnx_gaussian_blur_batch(self._h, n, srcs, st, w, h, pk, radius,
+                                                    FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, dsts,
+                                                    oviews[0].stride), "GaussianBlurBatch")
+        return outs
+
+    def SSIMFastBatch(self, imgs_a, imgs_b, window=None) -> np.ndarray:
+        va = [_Img(t) for t in imgs_a]
+        vb = [_Img(t) for t in imgs_b]
+        n = len(va)
+        if n != len(vb) or any(v.space != FNX_DEVICE for v in va + vb):
+            raise FennecError("batched ops take two equally long lists of device tensors")
+        as_ = (C.c_void_p * n)(*[v.ptr for v in va])
+        bs_ = (C.c_void_p * n)(*[v.ptr for v in vb])
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        out = np.empty(n, dtype=np.float64)
+        self._chk(self._lib.fnx_ssim_fast_batch(self._h, n, as_, va[0].stride, bs_, vb[0].stride, va[0].w,
+                                                va[0].h, pk, out.ctypes.data_as(_f64p)), "SSIMFastBatch")
+        return out
+
+
+class _Prepared:
+    """Reference side of an SSIM-guided quality search (compress.go:45-74)."""
+
+    def __init__(self, ctx: Context, handle, w, h):
+        self._ctx, self._p, self.w, self.h = ctx, handle, w, h
+
+    def against(self, img, window=None) -> float:
+        s = _Img(img)
+        if (s.w, s.h) != (self.w, self.h):
+            raise FennecError("candidate dims differ from the prepared reference")
+        k, pk = _f64(self._ctx.gaussianKernel() if window is None else window)
+        out = C.c_double()
+        self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against(self._ctx._h, self._p, s.space, s.ptr, s.stride,
+                                                            pk, C.byref(out)), "fnx_ssim_fast_against")
+        return out.value
+
+    def close(self):
+        if self._p:
+            self._ctx._lib.fnx_prepared_free(self._ctx._h, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def Summarize(failed, has_result, original_size, compressed_size, ssim) -> dict:
+    """batch.go:140-158 over parallel arrays (pure host arithmetic, index order)."""
+    L = load_library()
+    n = len(failed)
+    f, pf = _i32(np.asarray(failed)); hr, ph = _i32(np.asarray(has_result))
+    o = np.ascontiguousarray(original_size, dtype=np.int64)
+    c = np.ascontiguousarray(compressed_size, dtype=np.int64)
+    s, ps = _f64(np.asarray(ssim))
+    out = np.zeros(4, dtype=np.int64)
+    avg = L.fennec_Summarize(n, pf, ph, o.ctypes.data_as(_i64p), c.ctypes.data_as(_i64p), ps,
+                             out.ctypes.data_as(_i64p))
+    return dict(Total=int(out[0]), Succeeded=int(out[1]), Failed=int(out[2]), TotalSaved=int(out[3]),
+                AvgSSIM=float(avg))
+
+
+# ---------------------------------------------------------------------------------------
+# module-level functions with the reference's names, on a per-thread default context
+_tls = threading.local()
+
+
+def default_context(device: int | None = None) -> Context:
+    dev = int(os.environ.get("FENNEC_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if device is None else device
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    if dev not in ctxs:
+        ctxs[dev] = Context(dev)
+    return ctxs[dev]
+
+
+def _dev_of(x):
+    if _is_torch(x) and x.is_cuda:
+        return x.device.index or 0
+    return None
+
+
+def SSIM(img1, img2): return default_context(_dev_of(img1)).SSIM(img1, img2)
+def SSIMFast(img1, img2): return default_context(_dev_of(img1)).SSIMFast(img1, img2)
+def MSSSIM(img1, img2): return default_context(_dev_of(img1)).MSSSIM(img1, img2)
+def GaussianBlur(img, sigma): return default_context(_dev_of(img)).GaussianBlur(img, sigma)
+def Sharpen(img, strength): return default_context(_dev_of(img)).Sharpen(img, strength)
+def AdaptiveSharpen(img, strength): return default_context(_dev_of(img)).AdaptiveSharpen(img, strength)
+def ApplyOrientation(img, orient): return default_context(_dev_of(img)).ApplyOrientation(img, orient)
+def lanczosResize(img, dstW, dstH): return default_context(_dev_of(img)).lanczosResize(img, dstW, dstH)
+def smartResize(img, maxW, maxH): return default_context(_dev_of(img)).smartResize(img, maxW, maxH)
+def boxDownsample(img, dstW, dstH): return default_context(_dev_of(img)).boxDownsample(img, dstW, dstH)
+
+
+def gaussianKernel(size=8, sigma=1.5):
+    k = np.empty(size * size, dtype=np.float64)
+    load_library().fennec_gaussianKernel(size, sigma, k.ctypes.data_as(_f64p))
+    return k
+
+
+def blurKernel(sigma):
+    L = load_library()
+    r = L.fennec_blurKernel(float(sigma), None)
+    k = np.empty(2 * r + 1, dtype=np.float64)
+    L.fennec_blurKernel(float(sigma), k.ctypes.data_as(_f64p))
+    return r, k
+
+
+def precomputeWeights(dst_size, src_size):
+    L = load_library()
+    off = np.zeros(dst_size + 1, dtype=np.int32)
+    n = L.fennec_precomputeWeights(dst_size, src_size, off.ctypes.data_as(_i32p), None, None)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    wt = np.zeros(max(n, 1), dtype=np.float64)
+    L.fennec_precomputeWeights(dst_size, src_size, off.ctypes.data_as(_i32p), idx.ctypes.data_as(_i32p),
+                               wt.ctypes.data_as(_f64p))
+    return off, idx[:max(n, 0)], wt[:max(n, 0)]

@@ -1,0 +1,577 @@
+// fnx_* entry points: argument checks, host<->device staging, table upload, kernel launches.
+#include <cmath>
+
+#include "common.hpp"
+
+using namespace fnx;
+
+namespace {
+
+// Pix length of a w x h image with the given stride (Go: (h-1)*Stride + 4*w)
+inline size_t pix_len(int w, int h, int stride)
+{
+    return (w > 0 && h > 0) ? static_cast<size_t>(h - 1) * stride + static_cast<size_t>(w) * 4 : 0;
+}
+
+int check_img(const void *p, int stride, int w, int h, const char *what)
+{
+    if (w <= 0 || h <= 0) return FNX_OK;
+    if (!p) {
+        set_error("invalid argument: %s pixel pointer is null", what);
+        return FNX_ERR_INVALID;
+    }
+    if (stride < w * 4 || (stride & 3)) {
+        set_error("invalid argument: %s stride %d for width %d", what, stride, w);
+        return FNX_ERR_INVALID;
+    }
+    return FNX_OK;
+}
+
+int check_space(int space)
+{
+    if (space != FNX_HOST && space != FNX_DEVICE) {
+        set_error("invalid argument: space must be FNX_HOST or FNX_DEVICE");
+        return FNX_ERR_INVALID;
+    }
+    return FNX_OK;
+}
+
+// SSIMFast's dims (ssim.go:52-56)
+bool ssim_fast_dims(int w, int h, int *nw, int *nh)
+{
+    *nw = w;
+    *nh = h;
+    const int maxDim = 512;
+    if (w > maxDim || h > maxDim) {
+        double scale = double(maxDim) / std::fmax(double(w), double(h));
+        *nw = int(std::fmax(8, std::round(double(w) * scale)));
+        *nh = int(std::fmax(8, std::round(double(h) * scale)));
+        return true;
+    }
+    return false;
+}
+
+// SSIMFast of n device image pairs (single pointers or device pointer arrays) -> d_out[n].
+// Image i of the single-pointer form lives at a + i*a_img (used by MSSSIM with n == 1).
+int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const *as, int astride,
+                     const uint8_t *b, const uint8_t *const *bs, int bstride, int w, int h,
+                     const double *d_window, double *d_out)
+{
+    int nw, nh;
+    if (ssim_fast_dims(w, h, &nw, &nh)) {
+        // boxDownsample both sides (ssim.go:57-58) into tight planes: [a0..an-1][b0..bn-1]
+        const size_t plane = static_cast<size_t>(nw) * nh * 4;
+        void *t = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_TMP2, plane * 2 * n + 16, &t));
+        uint8_t *da = static_cast<uint8_t *>(t), *db = da + plane * n;
+        FNX_TRY(launch_box_downsample(ctx, n, a, as, astride, w, h, da, nw * 4, plane, nw, nh));
+        FNX_TRY(launch_box_downsample(ctx, n, b, bs, bstride, w, h, db, nw * 4, plane, nw, nh));
+        if (nw < 8 || nh < 8) {
+            for (int i = 0; i < n; i++)
+                FNX_TRY(launch_pixel_ssim(ctx, da + plane * i, db + plane * i, nw, nh, plane, d_out + i));
+            return FNX_OK;
+        }
+        return launch_windowed_ssim(ctx, n, da, nw * 4, plane, db, nw * 4, plane, nw, nh, d_window, d_out);
+    }
+    if (as || bs) {
+        set_error("batched SSIMFast needs images larger than 512 px (the downsample path)");
+        return FNX_ERR_INVALID;
+    }
+    if (w < 8 || h < 8) return launch_pixel_ssim(ctx, a, b, w, h, pix_len(w, h, astride), d_out);
+    return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, d_window, d_out);
+}
+
+int result_slot(fnx_ctx *ctx, int n, double **d)
+{
+    void *p = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_RESULT, sizeof(double) * static_cast<size_t>(n > 16 ? n : 16), &p));
+    *d = static_cast<double *>(p);
+    return FNX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                      const double *kernel, int radius, int flags, uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(kernel != nullptr && radius >= 0, "blur kernel");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_TRY(check_img(dst, dstride, w, h, "dst"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
+    FNX_TRY(launch_blur(ctx, 1, s.p, nullptr, s.stride, w, h, kernel, radius, flags, d.p, nullptr, d.stride));
+    return finish(ctx, space, &d);
+}
+
+int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w,
+                            int h, const double *kernel, int radius, int flags,
+                            uint8_t *const *dsts, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0, "batch arguments");
+    if (n == 0 || w <= 0 || h <= 0) return FNX_OK;
+    FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
+    bool al = true;
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
+        al = al && !(reinterpret_cast<uintptr_t>(srcs[i]) & 15) && !(reinterpret_cast<uintptr_t>(dsts[i]) & 15);
+    }
+    if (!al) {   // unaligned images: the scalar-load path handles them one by one
+        for (int i = 0; i < n; i++)
+            FNX_TRY(launch_blur(ctx, 1, srcs[i], nullptr, sstride, w, h, kernel, radius, flags, dsts[i], nullptr, dstride));
+        return FNX_OK;
+    }
+    const void *hosts[2] = {srcs, dsts};
+    const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+    void *dp[2];
+    FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+    return launch_blur(ctx, n, nullptr, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel,
+                       radius, flags, nullptr, static_cast<uint8_t *const *>(dp[1]), dstride);
+}
+
+int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_TRY(check_img(dst, dstride, w, h, "dst"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
+    FNX_TRY(launch_blur3x3(ctx, s.p, s.stride, w, h, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+static int sharpen_common(fnx_ctx *ctx, bool adaptive, int space, const uint8_t *src, int sstride,
+                          int w, int h, double amount, uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(w >= 3 && h >= 3, "sharpen needs w,h >= 3 (the reference returns the input below that)");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_TRY(check_img(dst, dstride, w, h, "dst"));
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
+    FNX_TRY(launch_sharpen(ctx, adaptive, s.p, s.stride, w, h, amount, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+int fnx_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                double amount, uint8_t *dst, int dstride)
+{
+    return sharpen_common(ctx, false, space, src, sstride, w, h, amount, dst, dstride);
+}
+
+int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                         double amount, uint8_t *dst, int dstride)
+{
+    return sharpen_common(ctx, true, space, src, sstride, w, h, amount, dst, dstride);
+}
+
+// ---- resize ------------------------------------------------------------------------
+static int upload_taps(fnx_ctx *ctx, Slot slot, int nout, const int32_t *off, const int32_t *idx,
+                       const double *wt, const int32_t **d_off, const int32_t **d_idx, const double **d_wt)
+{
+    FNX_REQUIRE(off && idx && wt, "tap table is null");
+    const int ntaps = off[nout];
+    FNX_REQUIRE(ntaps >= 0, "tap table offsets");
+    const void *hosts[3] = {wt, off, idx};
+    const size_t sizes[3] = {sizeof(double) * size_t(ntaps), sizeof(int32_t) * size_t(nout + 1),
+                             sizeof(int32_t) * size_t(ntaps)};
+    void *dp[3];
+    FNX_TRY(upload_tables(ctx, slot, hosts, sizes, 3, dp));
+    *d_wt = static_cast<const double *>(dp[0]);
+    *d_off = static_cast<const int32_t *>(dp[1]);
+    *d_idx = static_cast<const int32_t *>(dp[2]);
+    return FNX_OK;
+}
+
+int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                 const int32_t *offset, const int32_t *index, const double *weight,
+                 uint8_t *dst, int dstride, int dstW)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(srcW > 0 && srcH > 0 && dstW > 0, "dims");
+    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
+    FNX_TRY(check_img(dst, dstride, dstW, srcH, "dst"));
+    const int32_t *doff, *didx;
+    const double *dwt;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offset, index, weight, &doff, &didx, &dwt));
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, srcH, SLOT_OUT, &d));
+    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstW));
+    return finish(ctx, space, &d);
+}
+
+int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                 const int32_t *offset, const int32_t *index, const double *weight,
+                 uint8_t *dst, int dstride, int dstH)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(srcW > 0 && srcH > 0 && dstH > 0, "dims");
+    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
+    FNX_TRY(check_img(dst, dstride, srcW, dstH, "dst"));
+    const int32_t *doff, *didx;
+    const double *dwt;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offset, index, weight, &doff, &didx, &dwt));
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, srcW, dstH, SLOT_OUT, &d));
+    FNX_TRY(launch_resize_v(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstH));
+    return finish(ctx, space, &d);
+}
+
+int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                       int srcH, const int32_t *offH, const int32_t *idxH, const double *wH,
+                       const int32_t *offV, const int32_t *idxV, const double *wV,
+                       uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
+    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
+    FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
+    if (srcW == dstW && srcH == dstH) {   // flat copy of Pix (resize.go:45-49)
+        const size_t sl = pix_len(srcW, srcH, sstride), dl = pix_len(dstW, dstH, dstride);
+        const size_t nbytes = sl < dl ? sl : dl;
+        if (space == FNX_HOST) {
+            std::memcpy(dst, src, nbytes);
+        } else {
+            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return FNX_OK;
+    }
+    const int32_t *dOffH, *dIdxH, *dOffV, *dIdxV;
+    const double *dWH, *dWV;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offH, idxH, wH, &dOffH, &dIdxH, &dWH));
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offV, idxV, wV, &dOffV, &dIdxV, &dWV));
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, dstH, SLOT_OUT, &d));
+    // uint8 intermediate dstW x srcH (resize.go:51)
+    const int tp = pitch16(dstW);
+    void *tmp = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
+    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, dOffH, dIdxH, dWH, static_cast<uint8_t *>(tmp), tp, dstW));
+    FNX_TRY(launch_resize_v(ctx, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, dOffV, dIdxV, dWV, d.p, d.stride, dstH));
+    return finish(ctx, space, &d);
+}
+
+// ---- ssim.go -----------------------------------------------------------------------
+int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                       int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // ssim.go:246-248
+    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
+    FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, dstH, SLOT_OUT, &d));
+    FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, srcW, srcH, d.p, d.stride, 0, dstW, dstH));
+    return finish(ctx, space, &d);
+}
+
+int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+                  int bstride, int w, int h, const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && out, "window/out is null");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    if (w <= 0 || h <= 0) {   // pixelSSIM: n == 0 -> 1.0 (ssim.go:172-175)
+        *out = 1.0;
+        return FNX_OK;
+    }
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    DevImg da, db;
+    int nw, nh;
+    if (!ssim_fast_dims(w, h, &nw, &nh) && (w < 8 || h < 8)) {   // pixelSSIM on the inputs themselves
+        FNX_REQUIRE(pix_len(w, h, bstride) >= pix_len(w, h, astride), "b.Pix shorter than a.Pix (the reference would panic)");
+        FNX_TRY(stage_in_flat(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in_flat(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+    } else {
+        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+    }
+    double *dres;
+    FNX_TRY(result_slot(ctx, 1, &dres));
+    FNX_TRY(ssim_fast_device(ctx, 1, da.p, nullptr, da.stride, db.p, nullptr, db.stride, w, h,
+                             static_cast<const double *>(dwin), dres));
+    return fetch_doubles(ctx, dres, out, 1);
+}
+
+int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
+                        const uint8_t *const *bs, int bstride, int w, int h,
+                        const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(n >= 0 && as && bs && window && out, "batch arguments");
+    if (n == 0) return FNX_OK;
+    FNX_REQUIRE(w > 0 && h > 0 && astride >= 4 * w && bstride >= 4 * w, "dims");
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    double *dres;
+    FNX_TRY(result_slot(ctx, n, &dres));
+    int nw, nh;
+    bool al = !(astride & 15) && !(bstride & 15);
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(as[i] && bs[i], "null image in batch");
+        al = al && !(reinterpret_cast<uintptr_t>(as[i]) & 15) && !(reinterpret_cast<uintptr_t>(bs[i]) & 15);
+    }
+    if (ssim_fast_dims(w, h, &nw, &nh) && al) {
+        const void *hosts[2] = {as, bs};
+        const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+        void *dp[2];
+        FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+        FNX_TRY(ssim_fast_device(ctx, n, nullptr, static_cast<const uint8_t *const *>(dp[0]), astride, nullptr,
+                                 static_cast<const uint8_t *const *>(dp[1]), bstride, w, h,
+                                 static_cast<const double *>(dwin), dres));
+    } else {
+        for (int i = 0; i < n; i++)
+            FNX_TRY(ssim_fast_device(ctx, 1, as[i], nullptr, astride, bs[i], nullptr, bstride, w, h,
+                                     static_cast<const double *>(dwin), dres + i));
+    }
+    return fetch_doubles(ctx, dres, out, n);
+}
+
+int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+             int bstride, int w, int h, const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && out, "window/out is null");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    if (w <= 0 || h <= 0) {
+        *out = 1.0;
+        return FNX_OK;
+    }
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    DevImg da, db;
+    if (w < 8 || h < 8) {
+        FNX_REQUIRE(pix_len(w, h, bstride) >= pix_len(w, h, astride), "b.Pix shorter than a.Pix (the reference would panic)");
+        FNX_TRY(stage_in_flat(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in_flat(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+    } else {
+        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+    }
+    double *dres;
+    FNX_TRY(result_slot(ctx, 1, &dres));
+    if (w < 8 || h < 8) {   // ssim.go:35-37
+        FNX_TRY(launch_pixel_ssim(ctx, da.p, db.p, w, h, pix_len(w, h, da.stride), dres));
+    } else {                // toLuminance x2 + windowedSSIM at full resolution (ssim.go:39-42)
+        FNX_TRY(launch_windowed_ssim(ctx, 1, da.p, da.stride, 0, db.p, db.stride, 0, w, h,
+                                     static_cast<const double *>(dwin), dres));
+    }
+    return fetch_doubles(ctx, dres, out, 1);
+}
+
+int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+               int bstride, int w, int h, const double *window, double *out, double *per_level)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && out, "window/out is null");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    // weights, trimmed while a level's min dim < 8 (ssim.go:324-342)
+    double weights[5] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    int nweights = 5;
+    {
+        int tw = w, th = h;
+        for (int i = 0; i < 4; i++) {
+            int minDim = int(std::fmin(double(tw), double(th)));
+            if (minDim < 8) {
+                nweights = i + 1;
+                double sum = 0;
+                for (int j = 0; j < nweights; j++) sum += weights[j];
+                for (int j = 0; j < nweights; j++) weights[j] /= sum;
+                break;
+            }
+            tw /= 2;
+            th /= 2;
+        }
+    }
+    double lv[5];
+    for (double &v : lv) v = NAN;
+    int nlev = 0;
+    if (w <= 0 || h <= 0) {
+        // SSIMFast of empty images: pixelSSIM n==0 -> 1.0; the halving loop then breaks (nw < 8)
+        lv[0] = 1.0;
+        nlev = 1;
+    } else {
+        void *dwin = nullptr;
+        FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+        DevImg da, db;
+        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+        double *dres;
+        FNX_TRY(result_slot(ctx, 5, &dres));
+        // pyramid storage: levels 1.. of both images, ping-ponged in two slots per side
+        const uint8_t *ca = da.p, *cb = db.p;
+        int cas = da.stride, cbs = db.stride, cw = w, ch = h;
+        size_t lvl_bytes = static_cast<size_t>(w / 2) * (h / 2) * 4 + 16;
+        void *pa = nullptr, *pb = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 2, &pa));   // level k at offset (k&1)*lvl_bytes
+        FNX_TRY(scratch(ctx, SLOT_TMP1, lvl_bytes * 2, &pb));
+        for (int i = 0; i < nweights; i++) {
+            FNX_TRY(ssim_fast_device(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch,
+                                     static_cast<const double *>(dwin), dres + i));
+            nlev = i + 1;
+            if (i < nweights - 1) {
+                const int nw = cw / 2, nh = ch / 2;
+                if (nw < 8 || nh < 8) break;              // ssim.go:354-358
+                uint8_t *na = static_cast<uint8_t *>(pa) + (i & 1) * lvl_bytes;
+                uint8_t *nb = static_cast<uint8_t *>(pb) + (i & 1) * lvl_bytes;
+                FNX_TRY(launch_box_downsample(ctx, 1, ca, nullptr, cas, cw, ch, na, nw * 4, 0, nw, nh));
+                FNX_TRY(launch_box_downsample(ctx, 1, cb, nullptr, cbs, cw, ch, nb, nw * 4, 0, nw, nh));
+                ca = na; cb = nb; cas = cbs = nw * 4; cw = nw; ch = nh;
+            }
+        }
+        FNX_TRY(fetch_doubles(ctx, dres, lv, nlev));
+    }
+    double result = 0;
+    for (int i = 0; i < nlev; i++) result += weights[i] * std::log(std::fmax(lv[i], 1e-10));   // ssim.go:351
+    *out = std::exp(result);
+    if (per_level)
+        for (int i = 0; i < 5; i++) per_level[i] = i < nlev ? lv[i] : NAN;
+    return FNX_OK;
+}
+
+// ---- prepared reference ------------------------------------------------------------------
+int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int w, int h,
+                          fnx_prepared **out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(out != nullptr && w > 0 && h > 0, "prepare arguments");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    *out = nullptr;
+    fnx_prepared *p = new fnx_prepared();
+    p->w = w;
+    p->h = h;
+    const bool ds = ssim_fast_dims(w, h, &p->pw, &p->ph);
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, static_cast<size_t>(p->pw) * p->ph * 4 + 16);
+    if (e != hipSuccess) {
+        delete p;
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        return FNX_ERR_OOM;
+    }
+    p->pix = static_cast<uint8_t *>(d);
+    DevImg da;
+    int rc = stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da);
+    if (rc >= 0) {
+        if (ds) {
+            rc = launch_box_downsample(ctx, 1, da.p, nullptr, da.stride, w, h, p->pix, p->pw * 4, 0, p->pw, p->ph);
+        } else if (hipMemcpy2DAsync(p->pix, size_t(w) * 4, da.p, da.stride, size_t(w) * 4, h,
+                                    hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            set_error("hipMemcpy2DAsync failed");
+            rc = FNX_ERR_HIP;
+        }
+    }
+    if (rc >= 0 && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = FNX_ERR_HIP;
+    if (rc < 0) {
+        (void)hipFree(p->pix);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return FNX_OK;
+}
+
+int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
+                          int bstride, const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(ref && window && out, "against arguments");
+    const int w = ref->w, h = ref->h, pw = ref->pw, ph = ref->ph;
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    DevImg db;
+    FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+    double *dres;
+    FNX_TRY(result_slot(ctx, 1, &dres));
+    const uint8_t *cb = db.p;
+    int cbs = db.stride;
+    if (pw != w || ph != h) {
+        void *t = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_TMP2, static_cast<size_t>(pw) * ph * 4 + 16, &t));
+        FNX_TRY(launch_box_downsample(ctx, 1, db.p, nullptr, db.stride, w, h, static_cast<uint8_t *>(t), pw * 4, 0, pw, ph));
+        cb = static_cast<const uint8_t *>(t);
+        cbs = pw * 4;
+    }
+    if (pw < 8 || ph < 8) {
+        // pixelSSIM walks both flat Pix slices; the prepared side is tight, so b must be too
+        if (cbs != pw * 4) {
+            void *t = nullptr;
+            FNX_TRY(scratch(ctx, SLOT_TMP3, static_cast<size_t>(pw) * ph * 4 + 16, &t));
+            FNX_HIP(hipMemcpy2DAsync(t, size_t(pw) * 4, cb, cbs, size_t(pw) * 4, ph, hipMemcpyDeviceToDevice, ctx->stream));
+            cb = static_cast<const uint8_t *>(t);
+        }
+        FNX_TRY(launch_pixel_ssim(ctx, ref->pix, cb, pw, ph, static_cast<size_t>(pw) * ph * 4, dres));
+    } else {
+        FNX_TRY(launch_windowed_ssim(ctx, 1, ref->pix, pw * 4, 0, cb, cbs, 0, pw, ph,
+                                     static_cast<const double *>(dwin), dres));
+    }
+    return fetch_doubles(ctx, dres, out, 1);
+}
+
+void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
+{
+    if (!p) return;
+    if (ctx && bind(ctx) == FNX_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (p->pix) (void)hipFree(p->pix);
+    }
+    delete p;
+}
+
+// ---- orientation -------------------------------------------------------------------------
+int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int orient,
+               uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    if (orient < 2 || orient > 8) return FNX_NOOP;   // exif.go:180-181,200-201
+    const bool swap = orient >= 5;
+    const int ow = swap ? h : w, oh = swap ? w : h;
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_TRY(check_img(dst, dstride, ow, oh, "dst"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, ow, oh, SLOT_OUT, &d));
+    FNX_TRY(launch_orient(ctx, s.p, s.stride, w, h, orient, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+}  // extern "C"

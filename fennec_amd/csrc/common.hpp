@@ -1,0 +1,168 @@
+// Internal header of libfennec_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/fennec_hip.h"
+
+namespace fnx {
+
+void set_error(const char *fmt, ...);
+
+#define FNX_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            fnx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                           __LINE__);                                                      \
+            return e__ == hipErrorOutOfMemory ? FNX_ERR_OOM : FNX_ERR_HIP;                 \
+        }                                                                                  \
+    } while (0)
+
+#define FNX_TRY(expr)            \
+    do {                         \
+        int r__ = (expr);        \
+        if (r__ < 0) return r__; \
+    } while (0)
+
+#define FNX_REQUIRE(cond, msg)                  \
+    do {                                        \
+        if (!(cond)) {                          \
+            fnx::set_error("invalid argument: %s", msg); \
+            return FNX_ERR_INVALID;             \
+        }                                       \
+    } while (0)
+
+// Scratch slots of a ctx (device memory, grown on demand, reused across calls).
+enum Slot {
+    SLOT_IN_A = 0,   // staged host input a / src
+    SLOT_IN_B,       // staged host input b
+    SLOT_OUT,        // staged host output
+    SLOT_TMP0,       // op intermediates (blur/resize uint8 tmp, downsampled planes ...)
+    SLOT_TMP1,
+    SLOT_TMP2,
+    SLOT_TMP3,
+    SLOT_TABLE0,     // weight tables
+    SLOT_TABLE1,
+    SLOT_PARTIAL,    // reduction partials
+    SLOT_RESULT,     // scalar results
+    SLOT_PTRS,       // pointer arrays of batched ops
+    SLOT_COUNT
+};
+
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Cached copy of the last table uploaded into a table slot.
+struct TableCache {
+    std::vector<unsigned char> host;
+};
+
+}  // namespace fnx
+
+struct fnx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fnx::Scratch slot[fnx::SLOT_COUNT];
+    fnx::TableCache tcache[fnx::SLOT_COUNT];
+    // pinned host ring: tables going up, scalars coming down
+    unsigned char *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_off = 0;
+    int num_cus = 256;
+};
+
+struct fnx_prepared {
+    int w = 0, h = 0;      // original dims
+    int pw = 0, ph = 0;    // dims SSIMFast compares at
+    uint8_t *pix = nullptr;  // device, tight pw x ph NRGBA (downsampled or copied reference side)
+};
+
+namespace fnx {
+
+int bind(fnx_ctx *ctx);
+// Device scratch of at least `bytes` in `slot` (contents undefined).
+int scratch(fnx_ctx *ctx, Slot slot, size_t bytes, void **out);
+// Pinned host bytes valid until the next fnx call on this ctx wraps the ring.
+int pinned_alloc(fnx_ctx *ctx, size_t bytes, void **out);
+// Upload a small host table into a table slot (skipped when identical to the cached one).
+int upload_table(fnx_ctx *ctx, Slot slot, const void *host, size_t bytes, void **dptr);
+// Upload several host arrays back to back into one slot (each 16-byte aligned).
+int upload_tables(fnx_ctx *ctx, Slot slot, const void *const *hosts, const size_t *sizes, int n,
+                  void **dptrs);
+
+// staged / intermediate images are TIGHT (stride = 4*w), like image.NewNRGBA; 16-byte vector
+// access is then available whenever w % 4 == 0 (every size the benchmarks and codecs produce).
+inline int pitch16(int w) { return w * 4; }
+
+// An input image resolved to device memory.
+struct DevImg {
+    const uint8_t *p = nullptr;
+    int stride = 0;
+};
+struct DevOut {
+    uint8_t *p = nullptr;
+    int stride = 0;
+    uint8_t *host = nullptr;  // non-null: copy back to here (hstride) at finish
+    int hstride = 0, w = 0, h = 0;
+};
+
+int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
+             DevImg *out);
+// Same, but keeps the caller's stride and copies the flat Pix slice ((h-1)*stride + 4*w bytes):
+// pixelSSIM walks the flat slice, row padding included (ssim.go:178).
+int stage_in_flat(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
+                  DevImg *out);
+int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, Slot slot,
+              DevOut *out);
+// Copy a staged output back (if host) and synchronise when `space` is host.
+int finish(fnx_ctx *ctx, int space, DevOut *out);
+// Fetch n doubles from device memory into host memory (synchronises).
+int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n);
+
+inline bool aligned16(const void *p, int stride)
+{
+    return ((reinterpret_cast<uintptr_t>(p) | static_cast<uintptr_t>(stride)) & 15u) == 0;
+}
+
+// ---- kernel launchers (each enqueues on ctx->stream; device pointers only) ----
+struct BatchPtrs {            // either one image (p) or an array of n device pointers (pp)
+    const uint8_t *p = nullptr;
+    const uint8_t *const *pp = nullptr;
+};
+
+int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride,
+                int w, int h, const double *kernel, int radius, int flags, uint8_t *dst,
+                uint8_t *const *dsts, int dstride);
+int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *dst,
+                   int dstride);
+int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,
+                   double amount, uint8_t *dst, int dstride);
+int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
+                    const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
+                    int dstride, int dstW);
+int launch_resize_v(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
+                    const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
+                    int dstride, int dstH);
+// n images: src either one pointer or device array; dst images are tight dstW x dstH, image i at
+// dst + i*dst_image_bytes.
+int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
+                          int sstride, int srcW, int srcH, uint8_t *dst, int dstride,
+                          size_t dst_image_bytes, int dstW, int dstH);
+// Windowed SSIM of n image pairs (tight or strided NRGBA, w x h >= 8): image i of a at
+// a + i*a_image_bytes (same for b); writes n doubles to d_out.
+int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
+                         const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
+                         const double *d_window, double *d_out);
+int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
+                      size_t pix_len, double *d_out);
+int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
+                  uint8_t *dst, int dstride);
+
+}  // namespace fnx

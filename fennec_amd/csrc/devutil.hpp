@@ -1,0 +1,63 @@
+// Device-side helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fnx {
+
+// explicit global-address-space views: pointers fetched from pointer tables are generic to
+// the compiler and would otherwise be accessed with flat_load/flat_store
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4 g_u32x4;
+typedef __attribute__((address_space(1))) u32x4 g_u32x4w;
+typedef __attribute__((address_space(1))) const uint32_t g_u32;
+typedef __attribute__((address_space(1))) uint32_t g_u32w;
+
+// clampF (convert.go:149-158): math.Round (ties away from zero) then clamp to [0,255].
+__device__ __forceinline__ uint32_t clampF_dev(double x)
+{
+    long long v = static_cast<long long>(round(x));
+    if (v > 255) return 255u;
+    if (v < 0) return 0u;
+    return static_cast<uint32_t>(v);
+}
+
+// fast-mode rounding of an fp32 accumulator into byte `sel` of `old`:
+// floor(x+0.5) then saturating u8 convert + pack (v_cvt_pk_u8_f32).
+__device__ __forceinline__ uint32_t pack_u8(float x, uint32_t sel, uint32_t old)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(x + 0.5f), sel, old);
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ uint32_t ld_px(const uint8_t *row, int x)
+{
+    return *(g_u32 *)(row + 4 * static_cast<size_t>(x));
+}
+
+// BT.601 luminance exactly as the reference writes it (ssim.go:216, effects.go:96):
+// (0.299*R + 0.587*G) + 0.114*B in fp64, no contraction (TU built with -ffp-contract=off).
+__device__ __forceinline__ double lum601(uint32_t p)
+{
+    double r = static_cast<double>(p & 0xffu);
+    double g = static_cast<double>((p >> 8) & 0xffu);
+    double b = static_cast<double>((p >> 16) & 0xffu);
+    return 0.299 * r + 0.587 * g + 0.114 * b;
+}
+
+// XCD-aware work-item remap: consecutive workgroup ids land on different XCDs
+// (b % 8, MI355X_MICROARCH "Workgroup dispatch"), so hand each XCD a CONTIGUOUS range of
+// tiles -- neighbouring tiles share halo rows/columns and then hit the same 4 MiB L2.
+// grid must be launched with 8*ceil(total/8) blocks; returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_tile(int bid, int total)
+{
+    int per = (total + 7) >> 3;
+    int t = (bid & 7) * per + (bid >> 3);
+    return ((bid >> 3) < per && t < total) ? t : -1;
+}
+
+}  // namespace fnx

@@ -1,0 +1,297 @@
+// fennec_*: the reference's function set (ssim.go, resize.go, effects.go, exif.go, batch.go)
+// mirrored in C++ above the fnx_* kernel layer -- guards, control flow and weight-table
+// generation, i.e. everything the Go side of a cgo shim keeps.  No pixel arithmetic happens
+// here: every image operation is a fnx_* call (HIP kernels); there is no CPU path.
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace fnx;
+
+namespace {
+
+struct Taps {
+    std::vector<int32_t> off, idx;
+    std::vector<double> wt;
+};
+
+void make_taps(int dstSize, int srcSize, Taps &t)
+{
+    t.off.assign(static_cast<size_t>(dstSize) + 1, 0);
+    int n = fennec_precomputeWeights(dstSize, srcSize, t.off.data(), nullptr, nullptr);
+    t.idx.assign(static_cast<size_t>(n > 0 ? n : 1), 0);
+    t.wt.assign(static_cast<size_t>(n > 0 ? n : 1), 0.0);
+    fennec_precomputeWeights(dstSize, srcSize, t.off.data(), t.idx.data(), t.wt.data());
+}
+
+// The 8x8 window never changes (windowSize 8, sigma 1.5: ssim.go:74-77).
+const double *ssim_window()
+{
+    static double k[64];
+    static bool init = false;
+    if (!init) {
+        fennec_gaussianKernel(8, 1.5, k);
+        init = true;
+    }
+    return k;
+}
+
+// b resized to a's dims on the device when dims differ (ssim.go:31-33, 320-322).
+// Returns device pointer/stride of the image to compare against.
+int resize_b_to(fnx_ctx *ctx, int space, const uint8_t *b, int bstride, int bw, int bh, int w, int h,
+                const uint8_t **out, int *ostride)
+{
+    Taps th, tv;
+    make_taps(w, bw, th);
+    make_taps(h, bh, tv);
+    void *d = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP3, static_cast<size_t>(w) * h * 4 + 16, &d));
+    const uint8_t *src = b;
+    int sstride = bstride;
+    if (space == FNX_HOST) {   // stage b ourselves; the resize then runs device -> device
+        DevImg s;
+        FNX_TRY(stage_in(ctx, FNX_HOST, b, bstride, bw, bh, SLOT_IN_B, &s));
+        src = s.p;
+        sstride = s.stride;
+    }
+    int rc = fnx_lanczos_resize(ctx, FNX_DEVICE, src, sstride, bw, bh, th.off.data(), th.idx.data(),
+                                th.wt.data(), tv.off.data(), tv.idx.data(), tv.wt.data(),
+                                static_cast<uint8_t *>(d), w * 4, w, h);
+    if (rc < 0) return rc;
+    *out = static_cast<const uint8_t *>(d);
+    *ostride = w * 4;
+    return FNX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fennec_gaussianKernel(int size, double sigma, double *kernel)
+{   // ssim.go:223-241
+    const int half = size / 2;
+    double sum = 0;
+    int idx = 0;
+    for (int y = -half; y < half; y++)
+        for (int x = -half; x < half; x++) {
+            double val = std::exp(-double(x * x + y * y) / (2 * sigma * sigma));
+            kernel[idx++] = val;
+            sum += val;
+        }
+    for (int i = 0; i < size * size; i++) kernel[i] /= sum;
+}
+
+int fennec_blurKernel(double sigma, double *kernel)
+{   // effects.go:153-165
+    const int radius = int(std::ceil(sigma * 3));
+    if (!kernel) return radius;
+    const int n = radius * 2 + 1;
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = double(i - radius);
+        kernel[i] = std::exp(-(x * x) / (2 * sigma * sigma));
+        sum += kernel[i];
+    }
+    for (int i = 0; i < n; i++) kernel[i] /= sum;
+    return radius;
+}
+
+double fennec_lanczosKernel(double x)
+{   // resize.go:57-69
+    const double lanczosA = 3.0;
+    if (x == 0) return 1.0;
+    if (x < 0) x = -x;
+    if (x >= lanczosA) return 0.0;
+    double xpi = x * M_PI;
+    return (lanczosA * std::sin(xpi) * std::sin(xpi / lanczosA)) / (xpi * xpi);
+}
+
+int fennec_precomputeWeights(int dstSize, int srcSize, int32_t *offset, int32_t *index, double *weight)
+{   // resize.go:164-197, ratio/support as resize.go:81-87
+    const double ratio = double(srcSize) / double(dstSize);
+    double support = 3.0;
+    if (ratio > 1) support = 3.0 * ratio;
+    const double filterScale = std::fmax(ratio, 1.0);
+    int total = 0;
+    for (int d = 0; d < dstSize; d++) {
+        double center = (double(d) + 0.5) * ratio - 0.5;
+        int left = int(std::ceil(center - support));
+        int right = int(std::floor(center + support));
+        if (left < 0) left = 0;
+        if (right >= srcSize) right = srcSize - 1;
+        double wsum = 0;
+        const int first = total;
+        if (offset) offset[d] = total;
+        for (int s = left; s <= right; s++) {
+            double w = fennec_lanczosKernel((double(s) - center) / filterScale);
+            if (w != 0) {
+                wsum += w;
+                if (index) {
+                    index[total] = s;
+                    weight[total] = w;
+                }
+                total++;
+            }
+        }
+        if (wsum != 0 && index)
+            for (int i = first; i < total; i++) weight[i] /= wsum;
+    }
+    if (offset) offset[dstSize] = total;
+    return total;
+}
+
+int fennec_smartResizeDims(int srcW, int srcH, int maxW, int maxH, int *dstW, int *dstH)
+{   // resize.go:12-32
+    if (maxW <= 0) maxW = srcW;
+    if (maxH <= 0) maxH = srcH;
+    *dstW = srcW;
+    *dstH = srcH;
+    if (srcW <= maxW && srcH <= maxH) return 0;
+    double ratio = std::fmin(double(maxW) / double(srcW), double(maxH) / double(srcH));
+    *dstW = int(std::fmax(1, std::round(double(srcW) * ratio)));
+    *dstH = int(std::fmax(1, std::round(double(srcH) * ratio)));
+    return 1;
+}
+
+int fennec_ssimFastDims(int w, int h, int *newW, int *newH)
+{   // ssim.go:52-56
+    *newW = w;
+    *newH = h;
+    if (w > 512 || h > 512) {
+        double scale = 512.0 / std::fmax(double(w), double(h));
+        *newW = int(std::fmax(8, std::round(double(w) * scale)));
+        *newH = int(std::fmax(8, std::round(double(h) * scale)));
+        return 1;
+    }
+    return 0;
+}
+
+int fennec_SSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
+                const uint8_t *b, int bstride, int bw, int bh, double *out)
+{
+    if (aw == bw && ah == bh) return fnx_ssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out);
+    FNX_TRY(bind(ctx));
+    if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
+        // lanczosResize hands back a 0x0 image; pixelSSIM then indexes past it for a non-empty
+        // `a` (the reference panics) or returns 1.0 for an empty `a`.
+        if (aw <= 0 || ah <= 0) { *out = 1.0; return FNX_OK; }
+        set_error("SSIM: second image is empty (the reference panics)");
+        return FNX_ERR_INVALID;
+    }
+    const uint8_t *rb;
+    int rbs;
+    FNX_TRY(resize_b_to(ctx, space, b, bstride, bw, bh, aw, ah, &rb, &rbs));
+    if (space == FNX_DEVICE) return fnx_ssim(ctx, FNX_DEVICE, a, astride, rb, rbs, aw, ah, ssim_window(), out);
+    DevImg da;
+    FNX_TRY(stage_in(ctx, FNX_HOST, a, astride, aw, ah, SLOT_IN_A, &da));
+    return fnx_ssim(ctx, FNX_DEVICE, da.p, da.stride, rb, rbs, aw, ah, ssim_window(), out);
+}
+
+int fennec_SSIMFast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+                    int bstride, int w, int h, double *out)
+{
+    return fnx_ssim_fast(ctx, space, a, astride, b, bstride, w, h, ssim_window(), out);
+}
+
+int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
+                  const uint8_t *b, int bstride, int bw, int bh, double *out)
+{
+    if (aw == bw && ah == bh)
+        return fnx_msssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out, nullptr);
+    FNX_TRY(bind(ctx));
+    if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
+        if (aw <= 0 || ah <= 0) return fnx_msssim(ctx, space, a, astride, a, astride, aw, ah, ssim_window(), out, nullptr);
+        set_error("MSSSIM: second image is empty (the reference panics)");
+        return FNX_ERR_INVALID;
+    }
+    const uint8_t *rb;
+    int rbs;
+    FNX_TRY(resize_b_to(ctx, space, b, bstride, bw, bh, aw, ah, &rb, &rbs));
+    if (space == FNX_DEVICE)
+        return fnx_msssim(ctx, FNX_DEVICE, a, astride, rb, rbs, aw, ah, ssim_window(), out, nullptr);
+    DevImg da;
+    FNX_TRY(stage_in(ctx, FNX_HOST, a, astride, aw, ah, SLOT_IN_A, &da));
+    return fnx_msssim(ctx, FNX_DEVICE, da.p, da.stride, rb, rbs, aw, ah, ssim_window(), out, nullptr);
+}
+
+int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                        double sigma, uint8_t *dst, int dstride)
+{
+    if (sigma <= 0) return FNX_NOOP;   // effects.go:147-149: same pointer
+    const int radius = fennec_blurKernel(sigma, nullptr);
+    std::vector<double> k(static_cast<size_t>(2 * radius + 1));
+    fennec_blurKernel(sigma, k.data());
+    return fnx_gaussian_blur(ctx, space, src, sstride, w, h, k.data(), radius, FNX_BLUR_FAST, dst, dstride);
+}
+
+int fennec_Sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                   double strength, uint8_t *dst, int dstride)
+{
+    if (strength <= 0) return FNX_NOOP;   // effects.go:11-13
+    if (strength > 1) strength = 1;
+    if (w < 3 || h < 3) return FNX_NOOP;  // effects.go:20-22
+    return fnx_sharpen(ctx, space, src, sstride, w, h, 1.0 + strength * 1.5, dst, dstride);
+}
+
+int fennec_AdaptiveSharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                           double strength, uint8_t *dst, int dstride)
+{
+    if (strength <= 0) return FNX_NOOP;   // effects.go:50-52
+    if (strength > 1) strength = 1;
+    if (w < 3 || h < 3) return FNX_NOOP;  // effects.go:59-61
+    return fnx_adaptive_sharpen(ctx, space, src, sstride, w, h, 1.0 + strength * 2.0, dst, dstride);
+}
+
+int fennec_ApplyOrientation(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
+                            int h, int orient, uint8_t *dst, int dstride)
+{
+    return fnx_orient(ctx, space, src, sstride, w, h, orient, dst, dstride);
+}
+
+int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                         int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;
+    if (srcW == dstW && srcH == dstH)
+        return fnx_lanczos_resize(ctx, space, src, sstride, srcW, srcH, nullptr, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, dst, dstride, dstW, dstH);
+    Taps th, tv;
+    make_taps(dstW, srcW, th);
+    make_taps(dstH, srcH, tv);
+    return fnx_lanczos_resize(ctx, space, src, sstride, srcW, srcH, th.off.data(), th.idx.data(),
+                              th.wt.data(), tv.off.data(), tv.idx.data(), tv.wt.data(), dst, dstride,
+                              dstW, dstH);
+}
+
+int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                         int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    return fnx_box_downsample(ctx, space, src, sstride, srcW, srcH, dst, dstride, dstW, dstH);
+}
+
+double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
+                        const int64_t *original_size, const int64_t *compressed_size,
+                        const double *ssim, int64_t out4[4])
+{   // batch.go:140-158
+    int64_t succeeded = 0, nfailed = 0, saved = 0;
+    double ssimSum = 0;
+    for (int i = 0; i < n; i++) {
+        if (failed[i]) {
+            nfailed++;
+            continue;
+        }
+        succeeded++;
+        if (has_result[i]) {
+            saved += original_size[i] - compressed_size[i];
+            ssimSum += ssim[i];
+        }
+    }
+    out4[0] = n;
+    out4[1] = succeeded;
+    out4[2] = nfailed;
+    out4[3] = saved;
+    return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
+}
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// SSIM family kernels (ssim.go) on gfx950: boxDownsample, windowedSSIM (+toLuminance
+// fused into the tile load), pixelSSIM.  All fp64, unfused, reference operation order
+// (TU built with -ffp-contract=off); only the final mean's summation tree differs from
+// the reference's running sum (which itself depends on GOMAXPROCS, ssim.go:84-94,155-160).
+#include "common.hpp"
+#include "devutil.hpp"
+
+namespace fnx {
+
+// ------------------------------------------------------------------------------------
+// boxDownsample (ssim.go:244-309)
+// ------------------------------------------------------------------------------------
+struct BoxArgs {
+    const uint8_t *src;
+    const uint8_t *const *srcs;
+    uint8_t *dst;
+    size_t dst_image_bytes;
+    int sstride, srcW, srcH, dstride, dstW, dstH;
+    double xRatio, yRatio;
+    int seg;      // output columns per workgroup (tiled kernel)
+    int vec_in;
+};
+
+// box edges exactly as ssim.go:255-278
+__device__ __forceinline__ void box_edge(int d, double ratio, int srcN, int &s0, int &s1)
+{
+    s0 = static_cast<int>(static_cast<double>(d) * ratio);
+    s1 = static_cast<int>(static_cast<double>(d + 1) * ratio);
+    if (s1 > srcN) s1 = srcN;
+    if (s0 >= s1) s0 = s1 - 1;
+    if (s0 < 0) s0 = 0;
+}
+
+__device__ __forceinline__ uint32_t box_finish(uint32_t r, uint32_t g, uint32_t b, uint32_t al, int count)
+{
+    // sums are exact integers; inv := 1.0/count; clampF(sum*inv)  (ssim.go:301-308)
+    const double inv = 1.0 / static_cast<double>(count);
+    return clampF_dev(static_cast<double>(r) * inv) | (clampF_dev(static_cast<double>(g) * inv) << 8) |
+           (clampF_dev(static_cast<double>(b) * inv) << 16) | (clampF_dev(static_cast<double>(al) * inv) << 24);
+}
+
+// Any ratio (also upscaling, where boxes overlap / repeat): one thread per output pixel.
+__global__ __launch_bounds__(256) void box_generic_kernel(BoxArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.dstW || dy >= a.dstH) return;
+    const int z = blockIdx.z;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    int sx0, sx1, sy0, sy1;
+    box_edge(dx, a.xRatio, a.srcW, sx0, sx1);
+    box_edge(dy, a.yRatio, a.srcH, sy0, sy1);
+    unsigned long long r = 0, g = 0, b = 0, al = 0;
+    for (int sy = sy0; sy < sy1; sy++) {
+        const uint8_t *row = src + static_cast<size_t>(sy) * a.sstride;
+        for (int sx = sx0; sx < sx1; sx++) {
+            const uint32_t p = ld_px(row, sx);
+            r += p & 0xffu; g += (p >> 8) & 0xffu; b += (p >> 16) & 0xffu; al += p >> 24;
+        }
+    }
+    const long long count = static_cast<long long>(sy1 - sy0) * (sx1 - sx0);
+    // count == 0 (possible when upscaling: sx1 == 0) leaves the fresh image's zero pixel (ssim.go:301)
+    uint32_t o = 0;
+    if (count > 0) {
+        const double inv = 1.0 / static_cast<double>(count);
+        o = clampF_dev(static_cast<double>(r) * inv) | (clampF_dev(static_cast<double>(g) * inv) << 8) |
+            (clampF_dev(static_cast<double>(b) * inv) << 16) | (clampF_dev(static_cast<double>(al) * inv) << 24);
+    }
+    uint8_t *dimg = a.dst + a.dst_image_bytes * z;
+    *reinterpret_cast<uint32_t *>(dimg + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) = o;
+}
+
+// Downscaling fast path (ratio >= 1 on both axes => boxes tile the source exactly, each
+// source byte is read ONCE): workgroup = (segment of output columns, one output row).
+// Every thread streams one 16-byte column chunk down the box rows (all loads independent),
+// accumulating per-source-column sums as packed 2x16-bit lanes ((R,B) and (G,A)); the column
+// sums go through LDS and one thread per output pixel adds its box columns.
+constexpr int BOX_CHUNKS = 256;          // 16-byte chunks (4 px) per workgroup row segment
+constexpr int BOX_MAXROWS = 257;         // 257*255 < 65536: packed 16-bit sums cannot overflow
+
+__global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
+    const int z = blockIdx.z;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    const int dy = blockIdx.y;
+    const int dx_lo = blockIdx.x * a.seg;
+    const int dx_hi = min(dx_lo + a.seg, a.dstW);
+    int sy0, sy1, sxa, sxb, t0, t1;
+    box_edge(dy, a.yRatio, a.srcH, sy0, sy1);
+    box_edge(dx_lo, a.xRatio, a.srcW, sxa, t1);
+    box_edge(dx_hi - 1, a.xRatio, a.srcW, t0, sxb);
+    const int c0 = sxa >> 2;                       // first chunk of the segment
+    const int nchunk = ((sxb + 3) >> 2) - c0;      // <= BOX_CHUNKS by construction of seg
+    const int tid = threadIdx.x;
+
+    if (tid < nchunk) {
+        const int x = 4 * (c0 + tid);
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        const uint8_t *p = src + static_cast<size_t>(sy0) * a.sstride;
+        const bool vec = a.vec_in && (x + 3 < a.srcW);
+        int sy = sy0;
+        // 8 rows per trip: 8 independent 16-byte loads in flight per lane
+        for (; sy + 8 <= sy1; sy += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint8_t *row = p + static_cast<size_t>(u) * a.sstride;
+                if (vec) {
+                    v[u] = *reinterpret_cast<const uint4 *>(row + 4 * static_cast<size_t>(x));
+                } else {
+                    v[u].x = ld_px(row, min(x, a.srcW - 1));
+                    v[u].y = ld_px(row, min(x + 1, a.srcW - 1));
+                    v[u].z = ld_px(row, min(x + 2, a.srcW - 1));
+                    v[u].w = ld_px(row, min(x + 3, a.srcW - 1));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                lo[0] += v[u].x & 0x00ff00ffu; hi[0] += (v[u].x >> 8) & 0x00ff00ffu;
+                lo[1] += v[u].y & 0x00ff00ffu; hi[1] += (v[u].y >> 8) & 0x00ff00ffu;
+                lo[2] += v[u].z & 0x00ff00ffu; hi[2] += (v[u].z >> 8) & 0x00ff00ffu;
+                lo[3] += v[u].w & 0x00ff00ffu; hi[3] += (v[u].w >> 8) & 0x00ff00ffu;
+            }
+            p += static_cast<size_t>(8) * a.sstride;
+        }
+        {   // remainder rows (< 8): issue all loads, then accumulate
+            uint4 v[7];
+            const int rem = sy1 - sy;
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                if (u < rem) {
+                    const uint8_t *row = p + static_cast<size_t>(u) * a.sstride;
+                    if (vec) {
+                        v[u] = *reinterpret_cast<const uint4 *>(row + 4 * static_cast<size_t>(x));
+                    } else {
+                        v[u].x = ld_px(row, min(x, a.srcW - 1));
+                        v[u].y = ld_px(row, min(x + 1, a.srcW - 1));
+                        v[u].z = ld_px(row, min(x + 2, a.srcW - 1));
+                        v[u].w = ld_px(row, min(x + 3, a.srcW - 1));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 7; u++) {
+                if (u < rem) {
+                    lo[0] += v[u].x & 0x00ff00ffu; hi[0] += (v[u].x >> 8) & 0x00ff00ffu;
+                    lo[1] += v[u].y & 0x00ff00ffu; hi[1] += (v[u].y >> 8) & 0x00ff00ffu;
+                    lo[2] += v[u].z & 0x00ff00ffu; hi[2] += (v[u].z >> 8) & 0x00ff00ffu;
+                    lo[3] += v[u].w & 0x00ff00ffu; hi[3] += (v[u].w >> 8) & 0x00ff00ffu;
+                }
+            }
+        }
+        // s_col[px] = {lo, hi}: two 16-byte stores per lane
+        uint4 *sp = reinterpret_cast<uint4 *>(s_col + tid * 8);
+        sp[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+        sp[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+    }
+    __syncthreads();
+
+    const int dx = dx_lo + tid;
+    if (dx < dx_hi) {
+        int sx0, sx1;
+        box_edge(dx, a.xRatio, a.srcW, sx0, sx1);
+        uint32_t r = 0, g = 0, b = 0, al = 0;
+        for (int sx = sx0; sx < sx1; sx++) {
+            const uint2 c = *reinterpret_cast<const uint2 *>(s_col + (sx - 4 * c0) * 2);
+            r += c.x & 0xffffu; b += c.x >> 16;
+            g += c.y & 0xffffu; al += c.y >> 16;
+        }
+        const int count = (sy1 - sy0) * (sx1 - sx0);
+        uint8_t *dimg = a.dst + a.dst_image_bytes * z;
+        *reinterpret_cast<uint32_t *>(dimg + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) =
+            box_finish(r, g, b, al, count);
+    }
+}
+
+int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
+                          int sstride, int srcW, int srcH, uint8_t *dst, int dstride,
+                          size_t dst_image_bytes, int dstW, int dstH)
+{
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0 || n <= 0) return FNX_OK;
+    BoxArgs a{};
+    a.src = src; a.srcs = srcs; a.dst = dst; a.dst_image_bytes = dst_image_bytes;
+    a.sstride = sstride; a.srcW = srcW; a.srcH = srcH; a.dstride = dstride; a.dstW = dstW; a.dstH = dstH;
+    a.xRatio = static_cast<double>(srcW) / static_cast<double>(dstW);   // ssim.go:251-252
+    a.yRatio = static_cast<double>(srcH) / static_cast<double>(dstH);
+    a.vec_in = srcs ? ((sstride & 15) == 0) : aligned16(src, sstride);
+    const bool tiled = srcW >= dstW && srcH >= dstH && a.yRatio + 1.0 < BOX_MAXROWS &&
+                       a.xRatio + 1.0 < BOX_MAXROWS && a.xRatio * 2 + 8 < 4 * BOX_CHUNKS;
+    if (tiled) {
+        // seg output columns span < seg*xRatio + 1 source px, plus < 4 px of chunk alignment each side
+        int seg = static_cast<int>((4 * BOX_CHUNKS - 8) / a.xRatio);
+        if (seg > 256) seg = 256;
+        if (seg < 1) seg = 1;
+        a.seg = seg;
+        dim3 grid((dstW + seg - 1) / seg, dstH, n);
+        hipLaunchKernelGGL(box_tiled_kernel, grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        dim3 grid((dstW + 63) / 64, (dstH + 3) / 4, n);
+        hipLaunchKernelGGL(box_generic_kernel, grid, dim3(256), 0, ctx->stream, a);
+    }
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// windowedSSIM (ssim.go:73-166) with toLuminance (ssim.go:207-220) fused into the tile load
+// ------------------------------------------------------------------------------------
+constexpr int WS_TX = 32, WS_TY = 8;   // windows per workgroup (one per thread)
+
+struct WinArgs {
+    const uint8_t *a;
+    const uint8_t *b;
+    size_t a_image_bytes, b_image_bytes;
+    int astride, bstride, w, h;
+    int tiles_x, tiles;    // per image pair
+    const double *window;  // 64 weights, row-major wy,wx in [-4,4)
+    double *partial;       // [n][tiles]
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double *s_red)
+{
+    // fixed-shape tree => bit-reproducible from run to run
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
+{
+    constexpr int LW = WS_TX + 7, LH = WS_TY + 7;
+    __shared__ double s_a[LH * LW], s_b[LH * LW], s_k[64], s_red[4];
+    const int z = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    // window (wx0+i, wy0+j) covers pixels [wx0+i, wx0+i+8) x [wy0+j, wy0+j+8): centre (x,y)=(wx+4,wy+4)
+    const int wx0 = tx * WS_TX, wy0 = ty * WS_TY;
+    const uint8_t *A = a.a + a.a_image_bytes * z;
+    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const int tid = threadIdx.x;
+    if (tid < 64) s_k[tid] = a.window[tid];
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
+        s_a[i] = lum601(ld_px(A + static_cast<size_t>(y) * a.astride, x));
+        s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
+    }
+    __syncthreads();
+    const int lx = tid & (WS_TX - 1), ly = tid / WS_TX;
+    const int wx = wx0 + lx, wy = wy0 + ly;
+    double val = 0;
+    if (wx < a.w - 8 && wy < a.h - 8) {     // (w-8)*(h-8) windows (ssim.go:110-111)
+        double muA = 0, muB = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double wt = s_k[j * 8 + i];
+                muA += s_a[(ly + j) * LW + lx + i] * wt;
+                muB += s_b[(ly + j) * LW + lx + i] * wt;
+            }
+        double sAA = 0, sBB = 0, sAB = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double wt = s_k[j * 8 + i];
+                const double da = s_a[(ly + j) * LW + lx + i] - muA;
+                const double db = s_b[(ly + j) * LW + lx + i] - muB;
+                sAA += da * da * wt;
+                sBB += db * db * wt;
+                sAB += da * db * wt;
+            }
+        const double num = (2 * muA * muB + 6.5025) * (2 * sAB + 58.5225);
+        const double den = (muA * muA + muB * muB + 6.5025) * (sAA + sBB + 58.5225);
+        val = num / den;
+    }
+    const double t = block_sum_256(val, s_red);
+    if (tid == 0) a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
+}
+
+// one workgroup per image pair: fixed-order sum of the tile partials, then / count
+__global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
+{
+    __shared__ double s_red[4];
+    const double *p = partial + static_cast<size_t>(blockIdx.x) * tiles;
+    double v = 0;
+    for (int i = threadIdx.x; i < tiles; i += 256) v += p[i];
+    const double t = block_sum_256(v, s_red);
+    if (threadIdx.x == 0) out[blockIdx.x] = count > 0 ? t / count : 1.0;   // totalCount==0 -> 1.0 (ssim.go:162-164)
+}
+
+int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
+                         const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
+                         const double *d_window, double *d_out)
+{
+    const int ww = w - 8, wh = h - 8;     // window grid
+    WinArgs wa{};
+    wa.a = a; wa.b = b; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
+    wa.astride = astride; wa.bstride = bstride; wa.w = w; wa.h = h; wa.window = d_window;
+    int tiles = 0;
+    if (ww > 0 && wh > 0) {
+        wa.tiles_x = (ww + WS_TX - 1) / WS_TX;
+        tiles = wa.tiles_x * ((wh + WS_TY - 1) / WS_TY);
+    }
+    wa.tiles = tiles;
+    void *part = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
+    wa.partial = static_cast<double *>(part);
+    if (tiles > 0) {
+        hipLaunchKernelGGL(windowed_ssim_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, wa);
+        FNX_HIP(hipGetLastError());
+    }
+    const double count = (ww > 0 && wh > 0) ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(n), dim3(256), 0, ctx->stream,
+                       static_cast<const double *>(part), tiles, count, d_out);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// pixelSSIM (ssim.go:169-204): images with a dimension < 8.  One lane, the reference's
+// exact running-sum order over the flat Pix slices.
+// ------------------------------------------------------------------------------------
+__global__ void pixel_ssim_kernel(const uint8_t *a, const uint8_t *b, int w, int h, size_t pix_len, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double n = static_cast<double>(w * h);
+    if (n == 0) { *out = 1.0; return; }
+    double muA = 0, muB = 0;
+    for (size_t i = 0; i < pix_len; i += 4) {
+        muA += lum601(*reinterpret_cast<const uint32_t *>(a + i));
+        muB += lum601(*reinterpret_cast<const uint32_t *>(b + i));
+    }
+    muA /= n; muB /= n;
+    double sAA = 0, sBB = 0, sAB = 0;
+    for (size_t i = 0; i < pix_len; i += 4) {
+        const double da = lum601(*reinterpret_cast<const uint32_t *>(a + i)) - muA;
+        const double db = lum601(*reinterpret_cast<const uint32_t *>(b + i)) - muB;
+        sAA += da * da; sBB += db * db; sAB += da * db;
+    }
+    sAA /= n; sBB /= n; sAB /= n;
+    const double num = (2 * muA * muB + 6.5025) * (2 * sAB + 58.5225);
+    const double den = (muA * muA + muB * muB + 6.5025) * (sAA + sBB + 58.5225);
+    *out = num / den;
+}
+
+int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
+                      size_t pix_len, double *d_out)
+{
+    hipLaunchKernelGGL(pixel_ssim_kernel, dim3(1), dim3(64), 0, ctx->stream, a, b, w, h, pix_len, d_out);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+}  // namespace fnx

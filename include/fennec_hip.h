@@ -1,0 +1,226 @@
+/*
+ * fennec_hip.h -- C ABI of libfennec_hip.so: fennec's per-pixel hot path on
+ * AMD Instinct MI355X (gfx950 / CDNA4), hand-written HIP kernels.
+ *
+ * The reference (shamspias/fennec, pure Go) has no FFI seam; the seam is the set
+ * of Go functions whose BODIES a cgo shim replaces.  Every
+ * entry point below names the reference function it replaces (file:line).
+ * INTEGRATION.md shows the cgo binding.
+ *
+ * Two layers, both exported:
+ *
+ *   fnx_*     kernel level.  Takes weight tables (SSIM 8x8 window, blur 1-D
+ *             kernel, Lanczos CSR taps) as INPUTS, so a Go caller passes tables
+ *             computed with Go's own math.Exp / math.Sin and gets results
+ *             identical to the reference's.  This is what cgo binds.
+ *   fennec_*  the reference's exported/unexported function set mirrored in C++
+ *             above fnx_* (guards, control flow, table generation with libm) --
+ *             the host side as it exists where no Go toolchain is available;
+ *             also what the Python test/bench harness binds.
+ *
+ * Conventions
+ *   - Images are 8-bit non-premultiplied R,G,B,A ("NRGBA", Go image.NRGBA.Pix):
+ *     pixel (x,y) lives at pix[y*stride + 4*x]; stride is in BYTES; Rect.Min is
+ *     ignored exactly as the reference's kernels ignore it.
+ *   - `space` says where image pointers live: FNX_HOST (the library stages
+ *     through its own pinned/device buffers; call returns when dst is filled)
+ *     or FNX_DEVICE (HIP device pointers of the ctx's device; the op is enqueued
+ *     on the ctx stream and returns immediately unless it has a host scalar
+ *     output).  Tables and scalar outputs are always HOST pointers.
+ *   - Inputs are never written; C never retains a caller pointer past return
+ *     (cgo rule), except device pointers of in-flight FNX_DEVICE ops until
+ *     fnx_ctx_sync().
+ *   - A fnx_ctx owns one device, one stream and its scratch.  It is NOT
+ *     re-entrant: one ctx per worker thread (HIP's current device is per OS
+ *     thread and goroutines migrate, so every call binds the ctx's device).
+ *   - Return codes: FNX_OK; FNX_NOOP = the reference returns the SAME image
+ *     (dst untouched); FNX_EMPTY = the reference returns a 0x0 image (dst
+ *     untouched); negative = error, text via fnx_last_error().  There is NO
+ *     CPU fallback inside this library: without a usable GPU every op fails
+ *     with FNX_ERR_NO_DEVICE.
+ */
+#ifndef FENNEC_HIP_H
+#define FENNEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library itself is built with -fvisibility=hidden */
+#endif
+
+#define FNX_OK 0
+#define FNX_NOOP 1
+#define FNX_EMPTY 2
+#define FNX_ERR_INVALID (-1)
+#define FNX_ERR_NO_DEVICE (-2)
+#define FNX_ERR_HIP (-3)
+#define FNX_ERR_OOM (-4)
+
+#define FNX_HOST 0
+#define FNX_DEVICE 1
+
+/* fnx_gaussian_blur flags */
+#define FNX_BLUR_FAST 0  /* fp32 FMA accumulation: <=1 LSB off the reference on <=0.1% of samples */
+#define FNX_BLUR_EXACT 1 /* fp64, unfused, reference tap order: bit-exact */
+
+typedef struct fnx_ctx fnx_ctx;
+typedef struct fnx_prepared fnx_prepared;
+
+/* ---- runtime ---------------------------------------------------------- */
+const char *fnx_version(void);
+/* Number of usable HIP devices (0 when there is none / no driver). */
+int fnx_device_count(void);
+/* Thread-local text of the last error returned on this thread. */
+const char *fnx_last_error(void);
+int fnx_ctx_create(int device, fnx_ctx **out);
+void fnx_ctx_destroy(fnx_ctx *ctx);
+int fnx_ctx_device(const fnx_ctx *ctx);
+/* The ctx's hipStream_t (as void*), for callers that time or order work. */
+void *fnx_ctx_stream(fnx_ctx *ctx);
+/* Block until everything enqueued on the ctx has finished. */
+int fnx_ctx_sync(fnx_ctx *ctx);
+
+/* Device memory on the ctx's device (for FNX_DEVICE callers). */
+int fnx_malloc(fnx_ctx *ctx, size_t bytes, void **dptr);
+int fnx_free(fnx_ctx *ctx, void *dptr);
+/* 2-D copies host<->device, stream-ordered; both return after completion. */
+int fnx_upload(fnx_ctx *ctx, void *dptr, int dstride, const void *host, int hstride, int w, int h);
+int fnx_download(fnx_ctx *ctx, void *host, int hstride, const void *dptr, int dstride, int w, int h);
+
+/* ---- effects.go ------------------------------------------------------- */
+/* GaussianBlur body (effects.go:167-219): separable, clamp-to-edge, RGB only,
+ * uint8 intermediate, alpha from the source.  kernel[2*radius+1] is the
+ * normalised 1-D kernel of effects.go:153-165.  The sigma<=0 guard
+ * (effects.go:147-149) belongs to the caller. */
+int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                      const double *kernel, int radius, int flags, uint8_t *dst, int dstride);
+/* gaussianBlur3x3 (effects.go:116-141). */
+int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                uint8_t *dst, int dstride);
+/* Sharpen body (effects.go:24-44), amount = 1+1.5*strength; requires w,h >= 3. */
+int fnx_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                double amount, uint8_t *dst, int dstride);
+/* AdaptiveSharpen body (effects.go:63-89) incl. localEdgeStrength
+ * (effects.go:93-112), amount = 1+2*strength; requires w,h >= 3. */
+int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                         double amount, uint8_t *dst, int dstride);
+
+/* ---- resize.go -------------------------------------------------------- */
+/* Lanczos tap table in CSR form: taps of output d are
+ * index[offset[d] .. offset[d+1]) with weight[...] (precomputeWeights,
+ * resize.go:164-197).  offset has dst+1 entries. */
+/* resizeH (resize.go:77-118): src srcW x srcH -> dst dstW x srcH. */
+int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                 const int32_t *offset, const int32_t *index, const double *weight,
+                 uint8_t *dst, int dstride, int dstW);
+/* resizeV (resize.go:121-161): src srcW x srcH -> dst srcW x dstH. */
+int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                 const int32_t *offset, const int32_t *index, const double *weight,
+                 uint8_t *dst, int dstride, int dstH);
+/* lanczosResize (resize.go:37-53): guards, equal-dims flat copy, H then V
+ * through a uint8 intermediate.  Tables may be NULL when dims are equal. */
+int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                       int srcH, const int32_t *offH, const int32_t *idxH, const double *wH,
+                       const int32_t *offV, const int32_t *idxV, const double *wV,
+                       uint8_t *dst, int dstride, int dstW, int dstH);
+
+/* ---- ssim.go ---------------------------------------------------------- */
+/* boxDownsample (ssim.go:244-309). */
+int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                       int srcH, uint8_t *dst, int dstride, int dstW, int dstH);
+/* SSIMFast (ssim.go:48-70); window = gaussianKernel(8,1.5) (ssim.go:223-241),
+ * 64 doubles.  Both images are w x h (the reference does not check). */
+int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+                  int bstride, int w, int h, const double *window, double *out);
+/* SSIM (ssim.go:24-43) for equal dims (the dims-differ resize is composed by
+ * the caller, as fennec_SSIM does). */
+int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+             int bstride, int w, int h, const double *window, double *out);
+/* MSSSIM (ssim.go:313-365) for equal dims; per_level (NULL or 5 doubles)
+ * receives each level's SSIMFast, NaN where the reference stops early. */
+int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+               int bstride, int w, int h, const double *window, double *out, double *per_level);
+
+/* Binary-search form of SSIMFast (compress.go:45-74 calls SSIMFast(src, decoded)
+ * with the same src every iteration): downsample + luminance of the reference
+ * side once, then compare candidates against it. */
+int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int w, int h,
+                          fnx_prepared **out);
+int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
+                          int bstride, const double *window, double *out);
+void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p);
+
+/* ---- convert.go / exif.go --------------------------------------------- */
+/* ApplyOrientation (exif.go:178-203 over convert.go:186-256).  orient 2..8;
+ * dst is w x h for 2,3,4 and h x w for 5,6,7,8.  0, 1 and unknown values
+ * return FNX_NOOP. */
+int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int orient,
+               uint8_t *dst, int dstride);
+
+/* ---- batched forms (FNX_DEVICE only) ------------------------------------ */
+/* n independent images of identical geometry in ONE launch per stage
+ * (CompressBatch items never interact, batch.go:88-122).  srcs/dsts/as/bs are
+ * HOST arrays of n device pointers. */
+int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w,
+                            int h, const double *kernel, int radius, int flags,
+                            uint8_t *const *dsts, int dstride);
+int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
+                        const uint8_t *const *bs, int bstride, int w, int h,
+                        const double *window, double *out /* n, host */);
+
+/* ======================================================================= */
+/* fennec_* : the reference's function set (names and argument meaning as in
+ * the Go source), mirrored above fnx_*.                                     */
+/* ======================================================================= */
+
+/* gaussianKernel(size, sigma) (ssim.go:223-241): size*size doubles. */
+void fennec_gaussianKernel(int size, double sigma, double *kernel);
+/* GaussianBlur's radius/kernel (effects.go:153-165); kernel may be NULL. */
+int fennec_blurKernel(double sigma, double *kernel);
+/* lanczosKernel (resize.go:57-69). */
+double fennec_lanczosKernel(double x);
+/* precomputeWeights (resize.go:164-197) with ratio/support derived as
+ * resizeH/resizeV do; returns the tap count; index/weight may be NULL to size. */
+int fennec_precomputeWeights(int dstSize, int srcSize, int32_t *offset, int32_t *index,
+                             double *weight);
+/* smartResize's dims (resize.go:12-32): returns 0 if the image already fits. */
+int fennec_smartResizeDims(int srcW, int srcH, int maxW, int maxH, int *dstW, int *dstH);
+/* SSIMFast's downsample dims (ssim.go:52-56): returns 1 if it downsamples. */
+int fennec_ssimFastDims(int w, int h, int *newW, int *newH);
+
+int fennec_SSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
+                const uint8_t *b, int bstride, int bw, int bh, double *out);     /* ssim.go:24 */
+int fennec_SSIMFast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+                    int bstride, int w, int h, double *out);                      /* ssim.go:48 */
+int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
+                  const uint8_t *b, int bstride, int bw, int bh, double *out);   /* ssim.go:313 */
+int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                        double sigma, uint8_t *dst, int dstride);                 /* effects.go:146 */
+int fennec_Sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                   double strength, uint8_t *dst, int dstride);                   /* effects.go:10 */
+int fennec_AdaptiveSharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                           double strength, uint8_t *dst, int dstride);           /* effects.go:49 */
+int fennec_ApplyOrientation(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
+                            int h, int orient, uint8_t *dst, int dstride);        /* exif.go:178 */
+int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                         int srcH, uint8_t *dst, int dstride, int dstW, int dstH); /* resize.go:37 */
+int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
+                         int srcH, uint8_t *dst, int dstride, int dstW, int dstH); /* ssim.go:244 */
+
+/* Summarize (batch.go:140-158) over parallel arrays; out4 = {Total, Succeeded,
+ * Failed, TotalSaved}; returns AvgSSIM.  Pure host arithmetic in index order. */
+double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
+                        const int64_t *original_size, const int64_t *compressed_size,
+                        const double *ssim, int64_t out4[4]);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* FENNEC_HIP_H */

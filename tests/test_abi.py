@@ -1,0 +1,88 @@
+"""CPU tests of the C-ABI library: it builds, loads, exports every symbol that
+include/fennec_hip.h declares, and fails loudly without a GPU (no CPU fallback).
+Also the host-side table generators (fennec_* layer) against the oracle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import fennec_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(fennec_amd.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "fennec_amd", "csrc")])
+    return fennec_amd.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = fennec_amd.exported_symbols()
+    assert len(names) >= 40
+    raw = ctypes.CDLL(fennec_amd.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+    assert b"gfx950" in lib.fnx_version()
+
+
+def test_only_abi_symbols_are_exported():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", fennec_amd.LIB_PATH]).decode()
+    syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    stray = [s for s in syms if not (s.startswith("fnx_") or s.startswith("fennec_") or s in ("_init", "_fini"))]
+    assert not stray, stray
+
+
+def test_no_device_fails_loudly(lib):
+    if lib.fnx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(fennec_amd.FennecError, match="no HIP device"):
+        fennec_amd.Context(0)
+    with pytest.raises(fennec_amd.FennecError):
+        fennec_amd.GaussianBlur(fennec_amd.synth.make_test_image(16, 16), 2.0)
+
+
+def test_product_does_not_import_oracle():
+    """The product package must not reach into oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "fennec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.replace("no CPU", ""), os.path.join(dirpath, f)
+
+
+def test_table_generators_match_oracle(lib, orc):
+    assert np.array_equal(fennec_amd.gaussianKernel(), orc.gaussian_kernel())
+    for s in (0.3, 1.0, 2.0, 2.5, 20.0):
+        r, k = fennec_amd.blurKernel(s)
+        ro, ko = orc.blur_kernel(s)
+        assert r == ro and np.array_equal(k, ko)
+    for d, s in [(1920, 3840), (3840, 1920), (512, 3840), (50, 100), (7, 100), (100, 7), (1, 1)]:
+        off, idx, wt = fennec_amd.precomputeWeights(d, s)
+        o2, i2, w2 = orc.precompute_weights(d, s)
+        assert np.array_equal(off, o2) and np.array_equal(idx, i2) and np.array_equal(wt, w2)
+    for x in (0.0, 0.5, -1.25, 2.999, 3.0, 7.0):
+        assert lib.fennec_lanczosKernel(x) == orc.lanczos_kernel(x)
+
+
+def test_dims_helpers_match_oracle(lib, orc):
+    nw, nh = ctypes.c_int(), ctypes.c_int()
+    for w, h in [(3840, 2160), (7680, 4320), (640, 480), (512, 512), (513, 3), (100, 100), (2000, 3)]:
+        r = lib.fennec_ssimFastDims(w, h, ctypes.byref(nw), ctypes.byref(nh))
+        assert (bool(r), nw.value, nh.value) == orc.ssim_fast_dims(w, h)
+    for args in [(1000, 500, 200, 200), (1000, 500, 2000, 2000), (1000, 500, 0, 100), (3, 1000, 2, 2)]:
+        r = lib.fennec_smartResizeDims(*args, ctypes.byref(nw), ctypes.byref(nh))
+        assert (bool(r), nw.value, nh.value) == orc.smart_resize_dims(*args)
+
+
+def test_summarize_matches_oracle(orc):
+    rng = np.random.default_rng(3)
+    n = 257
+    failed = (rng.random(n) < 0.1).astype(np.int32)
+    has = (rng.random(n) < 0.95).astype(np.int32)
+    o = rng.integers(1000, 10**7, n); c = rng.integers(100, 10**6, n); s = rng.random(n)
+    assert fennec_amd.Summarize(failed, has, o, c, s) == orc.summarize(failed, has, o, c, s)

@@ -1,0 +1,306 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs.
+
+Bars (SURVEY.md Appendix A "stated tolerances"):
+  * orient, boxDownsample, blur3x3, Sharpen, AdaptiveSharpen, lanczosResize, GaussianBlur
+    in EXACT mode: bit-exact.
+  * GaussianBlur FAST mode (fp32 FMA): max |delta| <= 1 LSB on <= 0.1 % of samples.
+  * SSIM / SSIMFast / MSSSIM (fp64 moments): |delta| <= 1e-9.
+"""
+import numpy as np
+import pytest
+
+import fennec_amd
+from fennec_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SSIM_TOL = 1e-9
+BLUR_FAST_MAX_LSB = 1
+BLUR_FAST_MAX_FRAC = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return fennec_amd.Context(0)
+
+
+IMAGES = {
+    "grad_64x48": lambda: synth.make_test_image(64, 48),
+    "alpha_37x29": lambda: synth.make_test_image_with_alpha(37, 29),
+    "photo_200x150": lambda: synth.large_photo(200, 150, 3),
+    "noise_131x77": lambda: synth.noise_image(131, 77, 7, alpha=True),
+    "stripes_100x100": lambda: synth.make_striped_image(100, 100, 10),
+    "photo_640x480": lambda: synth.large_photo(640, 480, 0),
+    "noise_3x5": lambda: synth.noise_image(3, 5, 1, alpha=True),
+    "noise_1x1": lambda: synth.noise_image(1, 1, 2, alpha=True),
+    "noise_300x2": lambda: synth.noise_image(300, 2, 4, alpha=True),
+}
+
+
+def assert_blur_close(got, want):
+    diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert diff.max() <= BLUR_FAST_MAX_LSB, f"max diff {diff.max()}"
+    frac = float((diff[..., :3] != 0).mean())
+    assert frac <= BLUR_FAST_MAX_FRAC, f"mismatch fraction {frac}"
+    assert np.array_equal(got[..., 3], want[..., 3])
+
+
+# ------------------------------------------------------------------ effects.go
+@pytest.mark.parametrize("name", list(IMAGES))
+@pytest.mark.parametrize("sigma", [0.3, 1.0, 2.0, 2.6])
+def test_gaussian_blur(ctx, orc, name, sigma):
+    img = IMAGES[name]()
+    want = orc.gaussian_blur(img, sigma)
+    assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want)
+    assert_blur_close(ctx.GaussianBlur(img, sigma), want)
+
+
+def test_gaussian_blur_large_sigma_generic_path(ctx, orc):
+    img = synth.large_photo(160, 120, 5)
+    for sigma in (3.5, 20.0):          # radius 11 / 60: beyond the fused kernel
+        want = orc.gaussian_blur(img, sigma)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want)
+        assert_blur_close(ctx.GaussianBlur(img, sigma), want)
+
+
+def test_gaussian_blur_guards(ctx):
+    img = synth.make_test_image(100, 100)
+    assert ctx.GaussianBlur(img, 0) is img            # fennec_test.go:708-723
+    assert ctx.GaussianBlur(img, -1.0) is img
+
+
+def test_gaussian_blur_arbitrary_kernel_saturates(ctx, orc):
+    """The 1-D kernel is an input: negative taps / gain > 1 must clamp like clampF."""
+    img = synth.noise_image(96, 64, 9)
+    for k in ([-0.5, 2.0, -0.5], [0.25, 0.5, 0.25], [0.7, 0.7, 0.7], [-1.0, 0.5, -1.0]):
+        k = np.array(k)
+        want = orc.gaussian_blur(img, 1.0, kernel=k)
+        assert np.array_equal(ctx.GaussianBlur(img, 1.0, exact=True, kernel=k), want)
+        assert_blur_close(ctx.GaussianBlur(img, 1.0, kernel=k), want)
+
+
+@pytest.mark.parametrize("name", list(IMAGES))
+def test_blur3x3_sharpen_adaptive(ctx, orc, name):
+    img = IMAGES[name]()
+    assert np.array_equal(ctx.blur3x3(img), orc.blur3x3(img))
+    for s in (0.3, 0.8, 1.0, 5.0):
+        assert np.array_equal(ctx.Sharpen(img, s), orc.sharpen(img, s)), s
+        assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), s
+
+
+def test_sharpen_guards(ctx):
+    img = synth.make_test_image(100, 100)
+    tiny = synth.make_test_image(2, 2)
+    assert ctx.Sharpen(img, 0) is img and ctx.AdaptiveSharpen(img, 0) is img     # fennec_test.go:632-694
+    assert ctx.Sharpen(tiny, 0.5) is tiny and ctx.AdaptiveSharpen(tiny, 0.5) is tiny
+
+
+# ------------------------------------------------------------------ resize.go
+@pytest.mark.parametrize("name", ["grad_64x48", "alpha_37x29", "photo_200x150", "noise_131x77", "noise_3x5", "noise_1x1"])
+def test_lanczos_resize(ctx, orc, name):
+    img = IMAGES[name]()
+    h, w = img.shape[:2]
+    for dw, dh in [(max(w // 2, 1), max(h // 2, 1)), (w * 2, h * 2 - 1), (w + 5, max(h - 3, 1)), (1, 1), (w, h), (9, h), (w, 7)]:
+        assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh)), (dw, dh)
+    assert ctx.lanczosResize(img, 0, 50).shape[:2] == (0, 0)       # fennec_test.go:554-560
+
+
+def test_resize_passes_with_explicit_tables(ctx, orc):
+    img = synth.make_test_image_with_alpha(120, 90)
+    tab = orc.precompute_weights(50, 120)
+    assert np.array_equal(ctx.resize_pass(img, 50, False, tab), orc.resize_h(img, 50, tab))
+    tab = orc.precompute_weights(200, 90)
+    assert np.array_equal(ctx.resize_pass(img, 200, True, tab), orc.resize_v(img, 200, tab))
+
+
+def test_smart_resize(ctx, orc):
+    img = synth.make_test_image(1000, 500)
+    r = ctx.smartResize(img, 200, 200)
+    assert r.shape[:2] == (100, 200) and np.array_equal(r, orc.smart_resize(img, 200, 200))
+    assert ctx.smartResize(img, 2000, 2000) is img                  # fennec_test.go:540-552
+
+
+# ------------------------------------------------------------------ ssim.go
+@pytest.mark.parametrize("name", ["grad_64x48", "alpha_37x29", "photo_200x150", "noise_131x77", "photo_640x480"])
+def test_box_downsample(ctx, orc, name):
+    img = IMAGES[name]()
+    h, w = img.shape[:2]
+    for dw, dh in [(10, 10), (w // 2, h // 2), (w, h), (w + 7, h + 3), (1, 1), (8, 9), (w - 1, h - 1), (3 * w, 2 * h)]:
+        assert np.array_equal(ctx.boxDownsample(img, dw, dh), orc.box_downsample(img, dw, dh)), (dw, dh)
+    assert ctx.boxDownsample(img, 0, 0).shape[:2] == (0, 0)          # fennec_test.go:1109-1115
+
+
+@pytest.mark.parametrize("name", list(IMAGES))
+def test_ssim_family(ctx, orc, name):
+    a = IMAGES[name]()
+    b = orc.gaussian_blur(a, 1.2)
+    assert abs(ctx.SSIM(a, b) - orc.ssim(a, b)) <= SSIM_TOL
+    assert abs(ctx.SSIMFast(a, b) - orc.ssim_fast(a, b)) <= SSIM_TOL
+    assert abs(ctx.MSSSIM(a, b) - orc.msssim(a, b)) <= SSIM_TOL
+    assert abs(ctx.SSIM(a, a) - 1.0) <= 1e-12
+
+
+def test_ssim_reference_assertions(ctx):
+    """The reference's own assertions, on the HIP path (fennec_test.go:82-163)."""
+    img = synth.make_test_image(100, 100)
+    assert ctx.SSIM(img, img) >= 0.999
+    black = synth.make_solid_image(100, 100, (0, 0, 0, 255))
+    white = synth.make_solid_image(100, 100, (255, 255, 255, 255))
+    assert ctx.SSIM(black, white) <= 0.1
+    mod = img.copy(); r = mod[..., 0]; r[r > 10] -= 10
+    assert 0.85 <= ctx.SSIM(img, mod) <= 0.999
+    big = synth.make_test_image(500, 500)
+    assert ctx.SSIMFast(big, big) >= 0.999
+    small = synth.make_test_image(4, 4)
+    assert ctx.SSIM(small, small) >= 0.999
+    m = synth.make_test_image(128, 128)
+    assert ctx.MSSSIM(m, m) >= 0.99
+    assert ctx.MSSSIM(synth.make_solid_image(128, 128, (0, 0, 0, 255)), synth.make_solid_image(128, 128, (255, 255, 255, 255))) <= 0.1
+
+
+def test_ssim_mismatched_dims(ctx, orc):
+    a = synth.large_photo(200, 150, 2)
+    half = orc.lanczos_resize(a, 100, 75)
+    assert abs(ctx.SSIM(a, half) - orc.ssim(a, half)) <= SSIM_TOL      # ssim.go:31-33
+    assert abs(ctx.MSSSIM(a, half) - orc.msssim(a, half)) <= SSIM_TOL  # ssim.go:320-322
+
+
+def test_ssim_degenerate(ctx, orc):
+    a = synth.make_test_image(8, 8)
+    assert ctx.SSIM(a, a) == 1.0                      # zero windows -> 1.0 (ssim.go:162-164)
+    a = synth.noise_image(2000, 3, 5)
+    b = synth.noise_image(2000, 3, 6)
+    assert abs(ctx.SSIMFast(a, b) - orc.ssim_fast(a, b)) <= SSIM_TOL   # downsample to 512x8 -> windowed with h == 8
+    a = synth.noise_image(9, 700, 5)
+    b = synth.noise_image(9, 700, 6)
+    assert abs(ctx.SSIMFast(a, b) - orc.ssim_fast(a, b)) <= SSIM_TOL
+    assert abs(ctx.MSSSIM(a, b) - orc.msssim(a, b)) <= SSIM_TOL
+
+
+def test_msssim_levels(ctx, orc):
+    a = synth.large_photo(300, 200, 1)
+    b = orc.gaussian_blur(a, 1.5)
+    got, lv = ctx.msssim_levels(a, b)
+    want, wl = orc.msssim(a, b, per_level=True)
+    assert abs(got - want) <= SSIM_TOL
+    assert np.array_equal(np.isnan(lv), np.isnan(wl))
+    assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL
+
+
+def test_ssim_fast_prepared(ctx, orc):
+    a = synth.large_photo(640, 480, 4)
+    p = ctx.ssim_fast_prepare(a)
+    for sigma in (0.5, 1.0, 2.0):
+        b = orc.gaussian_blur(a, sigma)
+        assert abs(p.against(b) - orc.ssim_fast(a, b)) <= SSIM_TOL
+    p.close()
+    a = synth.large_photo(100, 80, 4)
+    p = ctx.ssim_fast_prepare(a)
+    assert abs(p.against(a) - 1.0) <= 1e-12
+    p.close()
+
+
+# ------------------------------------------------------------------ orientation
+@pytest.mark.parametrize("name", ["grad_64x48", "alpha_37x29", "noise_131x77", "noise_3x5", "noise_1x1", "noise_300x2"])
+def test_apply_orientation(ctx, orc, name):
+    img = IMAGES[name]()
+    for o in range(0, 10):
+        got = ctx.ApplyOrientation(img, o)
+        want = orc.apply_orientation(img, o)
+        if o < 2 or o > 8:
+            assert got is img
+        else:
+            assert np.array_equal(got, want), o
+
+
+# ------------------------------------------------------------------ spaces / strides / batches
+def test_strided_host_input(ctx, orc):
+    big = synth.noise_image(160, 120, 11, alpha=True)
+    sub = big[5:85, 8:136]
+    assert np.array_equal(ctx.GaussianBlur(sub, 1.5, exact=True), orc.gaussian_blur(sub, 1.5))
+    assert np.array_equal(ctx.lanczosResize(sub, 30, 20), orc.lanczos_resize(sub, 30, 20))
+    assert np.array_equal(ctx.boxDownsample(sub, 16, 10), orc.box_downsample(sub, 16, 10))
+    assert np.array_equal(ctx.AdaptiveSharpen(sub, 0.5), orc.adaptive_sharpen(sub, 0.5))
+    assert abs(ctx.SSIM(sub, np.ascontiguousarray(sub)) - 1.0) <= 1e-12
+
+
+def test_device_space_equals_host_space(ctx, orc):
+    import torch
+    img = synth.large_photo(644, 483, 7)          # width not a multiple of 4 pixels x 16 bytes
+    d = torch.from_numpy(img).cuda()
+    torch.cuda.synchronize()
+    fast = ctx.GaussianBlur(d, 2.0); ctx.sync()
+    assert np.array_equal(fast.cpu().numpy(), ctx.GaussianBlur(img, 2.0))
+    sh = ctx.AdaptiveSharpen(d, 0.5); ctx.sync()
+    assert np.array_equal(sh.cpu().numpy(), orc.adaptive_sharpen(img, 0.5))
+    rs = ctx.lanczosResize(d, 322, 241); ctx.sync()
+    assert np.array_equal(rs.cpu().numpy(), orc.lanczos_resize(img, 322, 241))
+    assert abs(ctx.SSIMFast(d, fast) - orc.ssim_fast(img, fast.cpu().numpy())) <= SSIM_TOL
+    assert abs(ctx.MSSSIM(d, rs) - orc.msssim(img, rs.cpu().numpy())) <= SSIM_TOL
+    # strided device view (rows contiguous, stride != 4*w)
+    sub = d[3:403, 4:604]
+    bl = ctx.GaussianBlur(sub, 1.0, exact=True); ctx.sync()
+    assert np.array_equal(bl.cpu().numpy(), orc.gaussian_blur(img[3:403, 4:604], 1.0))
+
+
+def test_batched_forms_equal_single(ctx, orc):
+    import torch
+    imgs = [synth.large_photo(1280, 720, k) for k in range(5)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs = ctx.GaussianBlurBatch(d, 2.0)
+    ss = ctx.SSIMFastBatch(d, outs)
+    for k in range(5):
+        single = ctx.GaussianBlur(imgs[k], 2.0)
+        assert np.array_equal(outs[k].cpu().numpy(), single)
+        assert ss[k] == ctx.SSIMFast(imgs[k], single)
+        assert abs(ss[k] - orc.ssim_fast(imgs[k], single)) <= SSIM_TOL
+    outs = ctx.GaussianBlurBatch(d, 2.0, exact=True); ctx.sync()
+    assert np.array_equal(outs[2].cpu().numpy(), orc.gaussian_blur(imgs[2], 2.0, procs=8))
+
+
+def test_determinism(ctx):
+    a = synth.large_photo(1920, 1080, 1)
+    b = ctx.GaussianBlur(a, 2.0)
+    vals = {ctx.SSIMFast(a, b) for _ in range(5)} | {ctx.SSIM(a, b) for _ in range(3)}
+    assert len(vals) == 2          # fixed reduction trees: bit-identical from run to run
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes
+def test_config2_4k_blur_ssimfast(ctx, orc):
+    """4K: GaussianBlur sigma=2 + SSIMFast vs original, against the oracle (threaded)."""
+    img = synth.large_photo(3840, 2160, 0)
+    want = orc.gaussian_blur(img, 2.0, procs=16)
+    assert np.array_equal(ctx.GaussianBlur(img, 2.0, exact=True), want)
+    fast = ctx.GaussianBlur(img, 2.0)
+    assert_blur_close(fast, want)
+    assert abs(ctx.SSIMFast(img, want) - orc.ssim_fast(img, want)) <= SSIM_TOL
+    assert np.array_equal(ctx.boxDownsample(img, 512, 288), orc.box_downsample(img, 512, 288))
+    # size-independent properties
+    solid = synth.make_solid_image(3840, 2160, (13, 200, 77, 128))
+    assert np.array_equal(ctx.GaussianBlur(solid, 2.0), solid)     # blur of a constant is the constant
+    assert ctx.SSIMFast(img, img) == 1.0
+
+
+def test_config3_4k_lanczos_msssim(ctx, orc):
+    img = synth.large_photo(3840, 2160, 1)
+    small = ctx.lanczosResize(img, 1920, 1080)
+    assert np.array_equal(small, orc.lanczos_resize(img, 1920, 1080, procs=16))
+    got = ctx.MSSSIM(img, small)
+    want = orc.msssim(img, small, procs=16)
+    assert abs(got - want) <= SSIM_TOL
+
+
+def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
+    img = synth.large_photo(7680, 4320, 2)
+    sharp = ctx.AdaptiveSharpen(img, 0.5)
+    assert np.array_equal(sharp, orc.adaptive_sharpen(img, 0.5, procs=16))
+    # orientation round trips at full size (pure permutations)
+    assert np.array_equal(ctx.ApplyOrientation(ctx.ApplyOrientation(img, 6), 8), img)
+    assert np.array_equal(ctx.ApplyOrientation(ctx.ApplyOrientation(img, 5), 5), img)
+    # full-resolution SSIM against the oracle on a 2K crop, by property at 8K
+    crop, scrop = np.ascontiguousarray(img[:1080, :2048]), np.ascontiguousarray(sharp[:1080, :2048])
+    assert abs(ctx.SSIM(crop, scrop) - orc.ssim(crop, scrop, procs=16)) <= SSIM_TOL
+    s = ctx.SSIM(img, sharp)
+    assert 0.0 < s < 1.0 and ctx.SSIM(img, img) == 1.0
