@@ -71,6 +71,14 @@ def load_library() -> C.CDLL:
             raise FennecError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(make -C fennec_amd/csrc, or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch wheels bundle their own HIP runtime and link it by file name, so it is not
+        # deduplicated against /opt/rocm's copy by soname: if our library pulled the system
+        # runtime in first, torch would later load a SECOND runtime that sees no GPUs.  Let
+        # torch (when present) load its runtime first; ours then binds to the same one.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         ctx = C.c_void_p
         i = C.c_int

@@ -55,7 +55,7 @@ bool ssim_fast_dims(int w, int h, int *nw, int *nh)
 // Image i of the single-pointer form lives at a + i*a_img (used by MSSSIM with n == 1).
 int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const *as, int astride,
                      const uint8_t *b, const uint8_t *const *bs, int bstride, int w, int h,
-                     const double *d_window, double *d_out)
+                     const double *h_window, const double *d_window, double *d_out)
 {
     int nw, nh;
     if (ssim_fast_dims(w, h, &nw, &nh)) {
@@ -71,14 +71,14 @@ int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const
                 FNX_TRY(launch_pixel_ssim(ctx, da + plane * i, db + plane * i, nw, nh, plane, d_out + i));
             return FNX_OK;
         }
-        return launch_windowed_ssim(ctx, n, da, nw * 4, plane, db, nw * 4, plane, nw, nh, d_window, d_out);
+        return launch_windowed_ssim(ctx, n, da, nw * 4, plane, db, nw * 4, plane, nw, nh, h_window, d_window, d_out);
     }
     if (as || bs) {
         set_error("batched SSIMFast needs images larger than 512 px (the downsample path)");
         return FNX_ERR_INVALID;
     }
     if (w < 8 || h < 8) return launch_pixel_ssim(ctx, a, b, w, h, pix_len(w, h, astride), d_out);
-    return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, d_window, d_out);
+    return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, h_window, d_window, d_out);
 }
 
 int result_slot(fnx_ctx *ctx, int n, double **d)
@@ -318,7 +318,7 @@ int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const 
     }
     double *dres;
     FNX_TRY(result_slot(ctx, 1, &dres));
-    FNX_TRY(ssim_fast_device(ctx, 1, da.p, nullptr, da.stride, db.p, nullptr, db.stride, w, h,
+    FNX_TRY(ssim_fast_device(ctx, 1, da.p, nullptr, da.stride, db.p, nullptr, db.stride, w, h, window,
                              static_cast<const double *>(dwin), dres));
     return fetch_doubles(ctx, dres, out, 1);
 }
@@ -347,11 +347,11 @@ int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astri
         void *dp[2];
         FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
         FNX_TRY(ssim_fast_device(ctx, n, nullptr, static_cast<const uint8_t *const *>(dp[0]), astride, nullptr,
-                                 static_cast<const uint8_t *const *>(dp[1]), bstride, w, h,
+                                 static_cast<const uint8_t *const *>(dp[1]), bstride, w, h, window,
                                  static_cast<const double *>(dwin), dres));
     } else {
         for (int i = 0; i < n; i++)
-            FNX_TRY(ssim_fast_device(ctx, 1, as[i], nullptr, astride, bs[i], nullptr, bstride, w, h,
+            FNX_TRY(ssim_fast_device(ctx, 1, as[i], nullptr, astride, bs[i], nullptr, bstride, w, h, window,
                                      static_cast<const double *>(dwin), dres + i));
     }
     return fetch_doubles(ctx, dres, out, n);
@@ -385,7 +385,7 @@ int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8
     if (w < 8 || h < 8) {   // ssim.go:35-37
         FNX_TRY(launch_pixel_ssim(ctx, da.p, db.p, w, h, pix_len(w, h, da.stride), dres));
     } else {                // toLuminance x2 + windowedSSIM at full resolution (ssim.go:39-42)
-        FNX_TRY(launch_windowed_ssim(ctx, 1, da.p, da.stride, 0, db.p, db.stride, 0, w, h,
+        FNX_TRY(launch_windowed_ssim(ctx, 1, da.p, da.stride, 0, db.p, db.stride, 0, w, h, window,
                                      static_cast<const double *>(dwin), dres));
     }
     return fetch_doubles(ctx, dres, out, 1);
@@ -440,7 +440,7 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 2, &pa));   // level k at offset (k&1)*lvl_bytes
         FNX_TRY(scratch(ctx, SLOT_TMP1, lvl_bytes * 2, &pb));
         for (int i = 0; i < nweights; i++) {
-            FNX_TRY(ssim_fast_device(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch,
+            FNX_TRY(ssim_fast_device(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch, window,
                                      static_cast<const double *>(dwin), dres + i));
             nlev = i + 1;
             if (i < nweights - 1) {
@@ -538,7 +538,7 @@ int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, cons
         }
         FNX_TRY(launch_pixel_ssim(ctx, ref->pix, cb, pw, ph, static_cast<size_t>(pw) * ph * 4, dres));
     } else {
-        FNX_TRY(launch_windowed_ssim(ctx, 1, ref->pix, pw * 4, 0, cb, cbs, 0, pw, ph,
+        FNX_TRY(launch_windowed_ssim(ctx, 1, ref->pix, pw * 4, 0, cb, cbs, 0, pw, ph, window,
                                      static_cast<const double *>(dwin), dres));
     }
     return fetch_doubles(ctx, dres, out, 1);

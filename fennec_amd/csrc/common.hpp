@@ -159,7 +159,7 @@ int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
 // a + i*a_image_bytes (same for b); writes n doubles to d_out.
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
-                         const double *d_window, double *d_out);
+                         const double *h_window, const double *d_window, double *d_out);
 int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
                       size_t pix_len, double *d_out);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,

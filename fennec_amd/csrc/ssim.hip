@@ -285,6 +285,109 @@ __global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
     if (tid == 0) a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
 }
 
+// Separable form.  gaussianKernel(8,1.5) is rank-1: k[j][i] = r[j]*c[i] (ssim.go:231, exp of a
+// sum), so the five window moments E[a], E[b], E[a^2], E[b^2], E[ab] are two 8-tap passes instead
+// of 64 taps x 2 sweeps, and sigma = E[x^2] - mu^2.  Algebraically identical to the reference's
+// two-sweep form; in fp64 the results differ by ~1e-13 (inside the 1e-9 bar).  The host checks
+// that the caller's table really is rank-1 and otherwise uses windowed_ssim_kernel above.
+constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup: 2 per thread
+
+struct WinSepArgs {
+    const uint8_t *a;
+    const uint8_t *b;
+    size_t a_image_bytes, b_image_bytes;
+    int astride, bstride, w, h;
+    int tiles_x, tiles;
+    double *partial;
+    double col[8], row[8];   // k[j][i] ~= row[j] * col[i]
+};
+
+__global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
+{
+    constexpr int LW = WSS_TX + 7, LH = WSS_TY + 7;
+    __shared__ double s_a[LH * LW], s_b[LH * LW];
+    __shared__ double s_h[5][LH * WSS_TX];
+    __shared__ double s_red[4];
+    const int z = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int wx0 = tx * WSS_TX, wy0 = ty * WSS_TY;
+    const uint8_t *A = a.a + a.a_image_bytes * z;
+    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
+        s_a[i] = lum601(ld_px(A + static_cast<size_t>(y) * a.astride, x));
+        s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
+    }
+    __syncthreads();
+    // horizontal 8-tap pass of the five moments
+    for (int i = tid; i < LH * WSS_TX; i += 256) {
+        const int r = i / WSS_TX, x = i - r * WSS_TX;
+        double ha = 0, hb = 0, haa = 0, hbb = 0, hab = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const double va = s_a[r * LW + x + t], vb = s_b[r * LW + x + t], c = a.col[t];
+            ha = fma(va, c, ha);
+            hb = fma(vb, c, hb);
+            haa = fma(va * va, c, haa);
+            hbb = fma(vb * vb, c, hbb);
+            hab = fma(va * vb, c, hab);
+        }
+        s_h[0][i] = ha; s_h[1][i] = hb; s_h[2][i] = haa; s_h[3][i] = hbb; s_h[4][i] = hab;
+    }
+    __syncthreads();
+    // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); 2 windows per thread
+    double val = 0;
+#pragma unroll
+    for (int rep = 0; rep < (WSS_TX * WSS_TY) / 256; rep++) {
+        const int wi = tid + rep * 256;
+        const int ly = wi / WSS_TX, lx = wi - ly * WSS_TX;
+        const int wx = wx0 + lx, wy = wy0 + ly;
+        if (wx < a.w - 8 && wy < a.h - 8) {
+            double m[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double rj = a.row[j];
+#pragma unroll
+                for (int q = 0; q < 5; q++) m[q] = fma(s_h[q][(ly + j) * WSS_TX + lx], rj, m[q]);
+            }
+            const double muA = m[0], muB = m[1];
+            const double sAA = m[2] - muA * muA, sBB = m[3] - muB * muB, sAB = m[4] - muA * muB;
+            const double num = (2 * muA * muB + 6.5025) * (2 * sAB + 58.5225);
+            const double den = (muA * muA + muB * muB + 6.5025) * (sAA + sBB + 58.5225);
+            val += num / den;
+        }
+    }
+    const double t = block_sum_256(val, s_red);
+    if (tid == 0) a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
+}
+
+// rank-1 factorisation of the 8x8 table: col[i] = sum_j k[j][i], row[j] = sum_i k[j][i] / sum(k).
+// Accepted when every entry is reproduced to 1e-13 relative (the Gaussian is, to ~3e-16).
+static bool window_rank1(const double *k, double *col, double *row)
+{
+    double total = 0;
+    for (int i = 0; i < 8; i++) col[i] = row[i] = 0;
+    for (int j = 0; j < 8; j++)
+        for (int i = 0; i < 8; i++) {
+            col[i] += k[j * 8 + i];
+            row[j] += k[j * 8 + i];
+            total += k[j * 8 + i];
+        }
+    if (!(total > 0)) return false;
+    double kmax = 0;
+    for (int i = 0; i < 64; i++) kmax = k[i] > kmax ? k[i] : kmax;
+    for (int j = 0; j < 8; j++) row[j] /= total;
+    for (int j = 0; j < 8; j++)
+        for (int i = 0; i < 8; i++) {
+            const double d = k[j * 8 + i] - row[j] * col[i];
+            if (!(d <= 1e-13 * kmax && d >= -1e-13 * kmax)) return false;
+        }
+    return true;
+}
+
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
 {
@@ -298,26 +401,35 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial,
 
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
-                         const double *d_window, double *d_out)
+                         const double *h_window, const double *d_window, double *d_out)
 {
     const int ww = w - 8, wh = h - 8;     // window grid
-    WinArgs wa{};
-    wa.a = a; wa.b = b; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
-    wa.astride = astride; wa.bstride = bstride; wa.w = w; wa.h = h; wa.window = d_window;
-    int tiles = 0;
-    if (ww > 0 && wh > 0) {
-        wa.tiles_x = (ww + WS_TX - 1) / WS_TX;
-        tiles = wa.tiles_x * ((wh + WS_TY - 1) / WS_TY);
+    const bool have = ww > 0 && wh > 0;
+    WinSepArgs sa{};
+    const bool sep = have && window_rank1(h_window, sa.col, sa.row);
+    const int TX = sep ? WSS_TX : WS_TX, TY = sep ? WSS_TY : WS_TY;
+    int tiles_x = 0, tiles = 0;
+    if (have) {
+        tiles_x = (ww + TX - 1) / TX;
+        tiles = tiles_x * ((wh + TY - 1) / TY);
     }
-    wa.tiles = tiles;
     void *part = nullptr;
     FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
-    wa.partial = static_cast<double *>(part);
-    if (tiles > 0) {
+    if (sep) {
+        sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
+        sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
+        sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
+        hipLaunchKernelGGL(windowed_ssim_sep_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
+        FNX_HIP(hipGetLastError());
+    } else if (have) {
+        WinArgs wa{};
+        wa.a = a; wa.b = b; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
+        wa.astride = astride; wa.bstride = bstride; wa.w = w; wa.h = h; wa.window = d_window;
+        wa.tiles_x = tiles_x; wa.tiles = tiles; wa.partial = static_cast<double *>(part);
         hipLaunchKernelGGL(windowed_ssim_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, wa);
         FNX_HIP(hipGetLastError());
     }
-    const double count = (ww > 0 && wh > 0) ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
+    const double count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(n), dim3(256), 0, ctx->stream,
                        static_cast<const double *>(part), tiles, count, d_out);
     FNX_HIP(hipGetLastError());

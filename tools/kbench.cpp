@@ -1,0 +1,91 @@
+// kbench: kernel-level timing of the batched C-ABI entry points with HIP events on the ctx
+// stream (development tool; bench.py is the contract benchmark).
+//   kbench [what] [batch] [iters]     what = blur | ssim | both | single
+// Variants are selected inside the library with FNX_* environment variables.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/fennec_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#define FK(x) do { int r = (x); if (r < 0) { fprintf(stderr, "%s: %s\n", #x, fnx_last_error()); exit(1); } } while (0)
+
+int main(int argc, char **argv)
+{
+    std::string what = argc > 1 ? argv[1] : "both";
+    int B = argc > 2 ? atoi(argv[2]) : 32;
+    int iters = argc > 3 ? atoi(argv[3]) : 20;
+    int W = argc > 4 ? atoi(argv[4]) : 3840, H = argc > 5 ? atoi(argv[5]) : 2160;
+    fnx_ctx *ctx;
+    FK(fnx_ctx_create(0, &ctx));
+    hipStream_t st = (hipStream_t)fnx_ctx_stream(ctx);
+    size_t S = (size_t)W * H * 4;
+    std::vector<uint8_t> host(S);
+    std::vector<const uint8_t *> srcs(B);
+    std::vector<uint8_t *> dsts(B);
+    for (int k = 0; k < B; k++) {
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                uint8_t *p = &host[((size_t)y * W + x) * 4];
+                p[0] = (uint8_t)((x * y + 3 * x + 17 * k) & 255);
+                p[1] = (uint8_t)((x * y + 7 * y + 31 * k) & 255);
+                p[2] = (uint8_t)((x + 11 * y + 5 * k) & 255);
+                p[3] = 255;
+            }
+        void *d, *o;
+        FK(fnx_malloc(ctx, S, &d));
+        FK(fnx_malloc(ctx, S, &o));
+        FK(fnx_upload(ctx, d, W * 4, host.data(), W * 4, W, H));
+        srcs[k] = (const uint8_t *)d;
+        dsts[k] = (uint8_t *)o;
+    }
+    double sigma = 2.0;
+    int radius = fennec_blurKernel(sigma, nullptr);
+    std::vector<double> kern(2 * radius + 1);
+    fennec_blurKernel(sigma, kern.data());
+    double win[64];
+    fennec_gaussianKernel(8, 1.5, win);
+    std::vector<double> out(B);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double mp = (double)W * H / 1e6;
+
+    auto time_it = [&](const char *name, auto &&fn, double bytes_per_image) {
+        for (int i = 0; i < 3; i++) fn();
+        FK(fnx_ctx_sync(ctx));
+        float tot = 0, best = 1e30f;
+        for (int i = 0; i < iters; i++) {
+            CK(hipEventRecord(e0, st));
+            fn();
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            tot += ms;
+            if (ms < best) best = ms;
+        }
+        double avg = tot / iters;
+        printf("%-28s B=%d avg %.3f ms (%.2f us/img, %.0f MP/s, %.0f GB/s algorithmic)  best %.3f ms (%.2f us/img)\n", name, B,
+               avg, avg * 1e3 / B, mp * B / (avg * 1e-3), bytes_per_image * B / (avg * 1e-3) / 1e9, best, best * 1e3 / B);
+    };
+
+    if (what == "blur" || what == "both")
+        time_it("gaussian_blur_batch", [&] { FK(fnx_gaussian_blur_batch(ctx, B, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4)); }, 2.0 * S);
+    if (what == "ssim" || what == "both")
+        time_it("ssim_fast_batch", [&] { FK(fnx_ssim_fast_batch(ctx, B, srcs.data(), W * 4, dsts.data(), W * 4, W, H, win, out.data())); }, 2.0 * S);
+    if (what == "single" || what == "both") {
+        int k = 0;
+        time_it("gaussian_blur x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_gaussian_blur(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts[i], W * 4)); }, 2.0 * S);
+        time_it("ssim_fast x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_ssim_fast(ctx, FNX_DEVICE, srcs[i], W * 4, dsts[i], W * 4, W, H, win, &out[i])); }, 2.0 * S);
+        (void)k;
+    }
+    printf("ssim[0]=%.12f\n", out[0]);
+    fnx_ctx_destroy(ctx);
+    return 0;
+}
