@@ -12,6 +12,8 @@
 #include "common.hpp"
 #include "devutil.hpp"
 
+#include <cstdlib>
+
 namespace fnx {
 
 // ------------------------------------------------------------------------------------

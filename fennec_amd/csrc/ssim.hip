@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void box_generic_kernel(BoxArgs a)
 constexpr int BOX_CHUNKS = 256;          // 16-byte chunks (4 px) per workgroup row segment
 constexpr int BOX_MAXROWS = 257;         // 257*255 < 65536: packed 16-bit sums cannot overflow
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
@@ -98,57 +99,38 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
         const int x = 4 * (c0 + tid);
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         const uint8_t *p = src + static_cast<size_t>(sy0) * a.sstride;
-        const bool vec = a.vec_in && (x + 3 < a.srcW);
-        int sy = sy0;
-        // 8 rows per trip: 8 independent 16-byte loads in flight per lane
-        for (; sy + 8 <= sy1; sy += 8) {
-            uint4 v[8];
+        // a chunk that sticks out of the row (srcW % 4 != 0) is read pixel by pixel, clamped;
+        // the surplus columns belong to no box
+        const bool whole = x + 3 < a.srcW;
+        if (VEC && whole) {
+            // 8 rows per trip: 8 independent 16-byte streaming loads in flight per lane (rows
+            // beyond the box are a workgroup-uniform skip and contribute zeros)
+            for (int sy = sy0; sy < sy1; sy += 8) {
+                u32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint8_t *row = p + static_cast<size_t>(u) * a.sstride;
-                if (vec) {
-                    v[u] = *reinterpret_cast<const uint4 *>(row + 4 * static_cast<size_t>(x));
-                } else {
-                    v[u].x = ld_px(row, min(x, a.srcW - 1));
-                    v[u].y = ld_px(row, min(x + 1, a.srcW - 1));
-                    v[u].z = ld_px(row, min(x + 2, a.srcW - 1));
-                    v[u].w = ld_px(row, min(x + 3, a.srcW - 1));
+                for (int u = 0; u < 8; u++) {
+                    v[u] = (u32x4){0, 0, 0, 0};
+                    if (sy + u < sy1) v[u] = ld16_stream(p + static_cast<size_t>(u) * a.sstride + 4 * static_cast<size_t>(x));
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                lo[0] += v[u].x & 0x00ff00ffu; hi[0] += (v[u].x >> 8) & 0x00ff00ffu;
-                lo[1] += v[u].y & 0x00ff00ffu; hi[1] += (v[u].y >> 8) & 0x00ff00ffu;
-                lo[2] += v[u].z & 0x00ff00ffu; hi[2] += (v[u].z >> 8) & 0x00ff00ffu;
-                lo[3] += v[u].w & 0x00ff00ffu; hi[3] += (v[u].w >> 8) & 0x00ff00ffu;
-            }
-            p += static_cast<size_t>(8) * a.sstride;
-        }
-        {   // remainder rows (< 8): issue all loads, then accumulate
-            uint4 v[7];
-            const int rem = sy1 - sy;
-#pragma unroll
-            for (int u = 0; u < 7; u++) {
-                if (u < rem) {
-                    const uint8_t *row = p + static_cast<size_t>(u) * a.sstride;
-                    if (vec) {
-                        v[u] = *reinterpret_cast<const uint4 *>(row + 4 * static_cast<size_t>(x));
-                    } else {
-                        v[u].x = ld_px(row, min(x, a.srcW - 1));
-                        v[u].y = ld_px(row, min(x + 1, a.srcW - 1));
-                        v[u].z = ld_px(row, min(x + 2, a.srcW - 1));
-                        v[u].w = ld_px(row, min(x + 3, a.srcW - 1));
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 7; u++) {
-                if (u < rem) {
+                for (int u = 0; u < 8; u++) {
                     lo[0] += v[u].x & 0x00ff00ffu; hi[0] += (v[u].x >> 8) & 0x00ff00ffu;
                     lo[1] += v[u].y & 0x00ff00ffu; hi[1] += (v[u].y >> 8) & 0x00ff00ffu;
                     lo[2] += v[u].z & 0x00ff00ffu; hi[2] += (v[u].z >> 8) & 0x00ff00ffu;
                     lo[3] += v[u].w & 0x00ff00ffu; hi[3] += (v[u].w >> 8) & 0x00ff00ffu;
                 }
+                p += static_cast<size_t>(8) * a.sstride;
+            }
+        } else {
+            // unaligned image, or the one chunk that sticks out of the row: pixel by pixel, clamped
+#pragma unroll 1
+            for (int sy = sy0; sy < sy1; sy++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t q = ld_px(p, min(x + e, a.srcW - 1));
+                    lo[e] += q & 0x00ff00ffu; hi[e] += (q >> 8) & 0x00ff00ffu;
+                }
+                p += a.sstride;
             }
         }
         // s_col[px] = {lo, hi}: two 16-byte stores per lane
@@ -195,7 +177,8 @@ int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
         if (seg < 1) seg = 1;
         a.seg = seg;
         dim3 grid((dstW + seg - 1) / seg, dstH, n);
-        hipLaunchKernelGGL(box_tiled_kernel, grid, dim3(256), 0, ctx->stream, a);
+        if (a.vec_in) hipLaunchKernelGGL(box_tiled_kernel<true>, grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(box_tiled_kernel<false>, grid, dim3(256), 0, ctx->stream, a);
     } else {
         dim3 grid((dstW + 63) / 64, (dstH + 3) / 4, n);
         hipLaunchKernelGGL(box_generic_kernel, grid, dim3(256), 0, ctx->stream, a);

@@ -304,3 +304,17 @@ def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
     assert abs(ctx.SSIM(crop, scrop) - orc.ssim(crop, scrop, procs=16)) <= SSIM_TOL
     s = ctx.SSIM(img, sharp)
     assert 0.0 < s < 1.0 and ctx.SSIM(img, img) == 1.0
+
+
+# ------------------------------------------------------------------ fused blur kernel: every radius, odd shapes
+@pytest.mark.parametrize("name", ["photo_640x480", "noise_131x77", "alpha_37x29", "noise_3x5", "noise_300x2"])
+def test_blur_fast_all_radii(ctx, orc, name):
+    img = IMAGES[name]()
+    for sigma in (0.3, 0.6, 1.0, 1.3, 1.6, 2.0, 2.3, 2.6):     # radius 1..8
+        assert_blur_close(ctx.GaussianBlur(img, sigma), orc.gaussian_blur(img, sigma))
+
+
+def test_blur_fast_shapes(ctx, orc):
+    for (w, h) in [(1030, 300), (513, 64), (2049, 33), (1281, 721)]:
+        img = synth.noise_image(w, h, w + h, alpha=True)
+        assert_blur_close(ctx.GaussianBlur(img, 2.0), orc.gaussian_blur(img, 2.0, procs=8))
