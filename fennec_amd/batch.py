@@ -1,0 +1,191 @@
+"""CompressBatch semantics around the GPU hot path (batch.go:58-158, compress.go:21-87).
+
+What the reference does with goroutines in one process, done here with one process per GPU:
+
+* items are independent (batch.go:88-122), so rank r of W takes items r, r+W, r+2W, ... --
+  no data-path collective; inside a rank a small thread pool (one fennec_amd.Context each)
+  plays the reference's worker pool so host codec work overlaps device work;
+* results are written by index (batch.go:71,108), so order is preserved;
+* the only reduction is Summarize (batch.go:140-158): per-rank partial
+  {Succeeded, Failed, TotalSaved, ssimSum} -> one all-reduce (RCCL over xGMI on GPUs, gloo in
+  the CPU tests).  Integer fields are reduced as int64 (exact); ssimSum as float64, whose
+  cross-rank summation order differs from the reference's index order by <= 1 ulp per add.
+
+`compress_jpeg_optimal` restates the SSIM-guided quality binary search (compress.go:21-87)
+with the JPEG codec as a pluggable pair of callables (Pillow/libjpeg-turbo by default; Go's
+image/jpeg is not available here, so the chosen quality is "parity unpinned") and SSIMFast
+evaluated on the GPU against a prepared reference (the search compares every candidate with
+the same source image).
+"""
+from __future__ import annotations
+
+import io
+import queue
+import threading
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+# Quality presets -> target SSIM (types.go:74-91)
+TARGET_SSIM = {"Lossless": 1.0, "Ultra": 0.99, "High": 0.97, "Balanced": 0.94, "Aggressive": 0.90,
+               "Maximum": 0.85}
+
+
+def search_lower_bound(target_ssim: float) -> int:
+    """compress.go:35-43: where the binary search starts."""
+    if target_ssim >= 0.99:
+        return 75
+    if target_ssim >= 0.97:
+        return 50
+    if target_ssim >= 0.94:
+        return 30
+    if target_ssim >= 0.90:
+        return 15
+    return 1
+
+
+def pillow_encode(rgba: np.ndarray, quality: int) -> bytes:
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(rgba[..., :3]), "RGB").save(buf, "JPEG", quality=int(quality), subsampling=2)
+    return buf.getvalue()
+
+
+def pillow_decode(data: bytes) -> np.ndarray:
+    from PIL import Image
+    rgb = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+    out = np.empty(rgb.shape[:2] + (4,), dtype=np.uint8)
+    out[..., :3] = rgb
+    out[..., 3] = 255
+    return out
+
+
+def compress_jpeg_optimal(ssim_against: Callable[[np.ndarray], float], src: np.ndarray, target_ssim: float,
+                          encode: Callable[[np.ndarray, int], bytes] = pillow_encode,
+                          decode: Callable[[bytes], np.ndarray] = pillow_decode):
+    """compress.go:21-87.  `ssim_against(decoded)` is SSIMFast(src, decoded) (compress.go:62).
+    Returns (quality, ssim, data, steps)."""
+    if target_ssim >= 1.0:
+        target_ssim = 0.999                       # compress.go:24-26
+    lo, hi = search_lower_bound(target_ssim), 100
+    best_q, best_ssim, best_data = hi, 1.0, None
+    steps = 0
+    while lo <= hi:
+        mid = (lo + hi) // 2
+        data = encode(src, mid)
+        s = ssim_against(decode(data))
+        steps += 1
+        if s >= target_ssim:
+            best_q, best_ssim, best_data = mid, s, data
+            hi = mid - 1
+        else:
+            lo = mid + 1
+    if best_data is None:                          # compress.go:82-86 fallback
+        best_data = encode(src, best_q)
+    return best_q, best_ssim, best_data, steps
+
+
+@dataclass
+class BatchResult:
+    """batch.go:20-30 (Result reduced to the fields Summarize reads, types.go:221-297)."""
+    Index: int
+    Err: Optional[str] = None
+    OriginalSize: int = 0
+    CompressedSize: int = 0
+    SSIM: float = 0.0
+    Quality: int = 0
+    has_result: bool = True
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Items of rank `rank`: r, r+W, ... (independent units, batch.go:88-122)."""
+    return list(range(rank, n_items, world))
+
+
+def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], make_worker_state: Callable[[int], object],
+                   workers: int = 1, rank: int = 0, world: int = 1,
+                   on_item: Optional[Callable[[int, int], None]] = None) -> List[BatchResult]:
+    """CompressBatch (batch.go:58-128) for this rank's shard: a closed queue of indices drained
+    by `workers` threads, results stored by index, `on_item(completed, total)` under a lock."""
+    mine = shard_indices(n_items, rank, world)
+    if not mine:
+        return []
+    workers = max(1, min(workers, len(mine)))       # batch.go:63-69
+    q: "queue.Queue[int]" = queue.Queue()
+    for i in mine:
+        q.put(i)
+    results: dict = {}
+    lock = threading.Lock()
+    done = [0]
+
+    def run(wid: int):
+        state = make_worker_state(wid)
+        while True:
+            try:
+                idx = q.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                r = work(idx, state)
+            except Exception as e:                   # per-item error capture (batch.go:108-113)
+                r = BatchResult(Index=idx, Err=f"{type(e).__name__}: {e}", has_result=False)
+            results[idx] = r
+            if on_item:
+                with lock:
+                    done[0] += 1
+                    c = done[0]
+                on_item(c, len(mine))
+
+    threads = [threading.Thread(target=run, args=(w,)) for w in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return [results[i] for i in mine]
+
+
+@dataclass
+class BatchSummary:
+    """batch.go:131-138"""
+    Total: int = 0
+    Succeeded: int = 0
+    Failed: int = 0
+    TotalSaved: int = 0
+    AvgSSIM: float = 0.0
+    ssim_sum: float = field(default=0.0, repr=False)
+
+
+def summarize_local(results: Sequence[BatchResult]) -> BatchSummary:
+    """Summarize (batch.go:140-158) over this rank's results, index order."""
+    s = BatchSummary(Total=len(results))
+    for r in results:
+        if r.Err is not None:
+            s.Failed += 1
+            continue
+        s.Succeeded += 1
+        if r.has_result:
+            s.TotalSaved += r.OriginalSize - r.CompressedSize
+            s.ssim_sum += r.SSIM
+    if s.Succeeded > 0:
+        s.AvgSSIM = s.ssim_sum / float(s.Succeeded)
+    return s
+
+
+def summarize_distributed(results: Sequence[BatchResult], device=None, group=None) -> BatchSummary:
+    """Summarize across all ranks: the path's one collective (two tiny all-reduces)."""
+    import torch
+    import torch.distributed as dist
+
+    s = summarize_local(results)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return s
+    ints = torch.tensor([s.Total, s.Succeeded, s.Failed, s.TotalSaved], dtype=torch.int64, device=device)
+    flt = torch.tensor([s.ssim_sum], dtype=torch.float64, device=device)
+    dist.all_reduce(ints, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(flt, op=dist.ReduceOp.SUM, group=group)
+    t, ok, bad, saved = (int(v) for v in ints.tolist())
+    out = BatchSummary(Total=t, Succeeded=ok, Failed=bad, TotalSaved=saved, ssim_sum=float(flt.item()))
+    if ok > 0:
+        out.AvgSSIM = out.ssim_sum / float(ok)
+    return out

@@ -1,0 +1,342 @@
+//go:build cgo && fennec_hip
+
+// Package fennec -- cgo shim that swaps the BODIES of the per-pixel hot-path functions
+// (ssim.go, resize.go, effects.go, exif.go) for calls into libfennec_hip.so (MI355X / gfx950).
+//
+// Drop this file into the reference tree next to the files it shadows and build with
+//
+//	CGO_CFLAGS="-I$FENNEC_HIP/include" CGO_LDFLAGS="-L$FENNEC_HIP/fennec_amd -lfennec_hip" \
+//	    go build -tags fennec_hip ./...
+//
+// after renaming each shadowed function in the reference to its `...Go` twin (one-line edits,
+// listed in INTEGRATION.md) and giving the originals a `//go:build !fennec_hip` twin file.
+// Everything above these functions -- CompressFile/CompressBytes/CompressBatch, the JPEG
+// quality search, target-size mode, the CLI -- is untouched.
+//
+// NOTE: there is no Go toolchain in the image this repository is developed in, so this file
+// has never been compiled.  It is the binding a maintainer would add; the C ABI it calls is
+// exercised by the Python/ctypes harness and the C++ tools in this repository.
+//
+// Contract kept from the reference (SURVEY.md 8(b)):
+//   - none of these functions returns an error, so on ANY non-zero status the shim runs the
+//     pure-Go implementation (GPU absent, out of memory, ...);
+//   - pointer-identity guards (sigma<=0, strength<=0, dims<3, orientation<=1, already-fits)
+//     stay in Go, before the boundary;
+//   - weight tables are computed in Go with Go's math.Exp/math.Sin and passed in, so kernels
+//     see bit-for-bit the reference's tables;
+//   - outputs are Go-allocated (image.NewNRGBA) and filled by C; C retains no Go pointer.
+package fennec
+
+/*
+#include <stdint.h>
+#include "fennec_hip.h"
+*/
+import "C"
+
+import (
+	"image"
+	"math"
+	"runtime"
+	"sync"
+	"unsafe"
+)
+
+// ---- context pool --------------------------------------------------------------------------
+// A fnx_ctx is not re-entrant and HIP's current device is per OS thread, while goroutines
+// migrate between threads: every call borrows a context (which binds its device itself).
+type hipPool struct {
+	mu   sync.Mutex
+	free []*C.fnx_ctx
+	next int
+	ndev int
+}
+
+var pool = func() *hipPool {
+	return &hipPool{ndev: int(C.fnx_device_count())}
+}()
+
+func (p *hipPool) get() *C.fnx_ctx {
+	if p.ndev == 0 {
+		return nil
+	}
+	p.mu.Lock()
+	if n := len(p.free); n > 0 {
+		c := p.free[n-1]
+		p.free = p.free[:n-1]
+		p.mu.Unlock()
+		return c
+	}
+	dev := p.next % p.ndev // CompressBatch workers spread round-robin over the node's GPUs
+	p.next++
+	p.mu.Unlock()
+	var c *C.fnx_ctx
+	if C.fnx_ctx_create(C.int(dev), &c) != C.FNX_OK {
+		return nil
+	}
+	return c
+}
+
+func (p *hipPool) put(c *C.fnx_ctx) {
+	p.mu.Lock()
+	p.free = append(p.free, c)
+	p.mu.Unlock()
+}
+
+func pix(img *image.NRGBA) *C.uint8_t {
+	if len(img.Pix) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&img.Pix[0]))
+}
+
+var ssimWindow = gaussianKernel(8, 1.5) // ssim.go:77, Go's own math.Exp
+
+// ---- ssim.go -------------------------------------------------------------------------------
+
+// SSIMFast replaces ssim.go:48.
+func SSIMFast(img1, img2 *image.NRGBA) float64 {
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		var out C.double
+		w, h := img1.Bounds().Dx(), img1.Bounds().Dy()
+		st := C.fnx_ssim_fast(c, C.FNX_HOST, pix(img1), C.int(img1.Stride), pix(img2), C.int(img2.Stride),
+			C.int(w), C.int(h), (*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		runtime.KeepAlive(img1)
+		runtime.KeepAlive(img2)
+		if st == C.FNX_OK {
+			return float64(out)
+		}
+	}
+	return ssimFastGo(img1, img2)
+}
+
+// SSIM replaces ssim.go:24.
+func SSIM(img1, img2 image.Image) float64 {
+	a, b := toNRGBARef(img1), toNRGBARef(img2)
+	w, h := a.Bounds().Dx(), a.Bounds().Dy()
+	if w != b.Bounds().Dx() || h != b.Bounds().Dy() {
+		b = lanczosResize(b, w, h) // ssim.go:31-33 (itself on the GPU)
+	}
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		var out C.double
+		st := C.fnx_ssim(c, C.FNX_HOST, pix(a), C.int(a.Stride), pix(b), C.int(b.Stride), C.int(w), C.int(h),
+			(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		runtime.KeepAlive(a)
+		runtime.KeepAlive(b)
+		if st == C.FNX_OK {
+			return float64(out)
+		}
+	}
+	return ssimGo(a, b)
+}
+
+// MSSSIM replaces ssim.go:313.
+func MSSSIM(img1, img2 image.Image) float64 {
+	a, b := toNRGBARef(img1), toNRGBARef(img2)
+	w, h := a.Bounds().Dx(), a.Bounds().Dy()
+	if w != b.Bounds().Dx() || h != b.Bounds().Dy() {
+		b = lanczosResize(b, w, h) // ssim.go:320-322
+	}
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		var out C.double
+		st := C.fnx_msssim(c, C.FNX_HOST, pix(a), C.int(a.Stride), pix(b), C.int(b.Stride), C.int(w), C.int(h),
+			(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out, nil)
+		runtime.KeepAlive(a)
+		runtime.KeepAlive(b)
+		if st == C.FNX_OK {
+			return float64(out)
+		}
+	}
+	return msssimGo(a, b)
+}
+
+// boxDownsample replaces ssim.go:244.
+func boxDownsample(img *image.NRGBA, dstW, dstH int) *image.NRGBA {
+	srcW, srcH := img.Bounds().Dx(), img.Bounds().Dy()
+	if srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0 {
+		return image.NewNRGBA(image.Rect(0, 0, 0, 0))
+	}
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		dst := image.NewNRGBA(image.Rect(0, 0, dstW, dstH))
+		st := C.fnx_box_downsample(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(srcW), C.int(srcH),
+			pix(dst), C.int(dst.Stride), C.int(dstW), C.int(dstH))
+		runtime.KeepAlive(img)
+		if st == C.FNX_OK {
+			return dst
+		}
+	}
+	return boxDownsampleGo(img, dstW, dstH)
+}
+
+// ---- resize.go -----------------------------------------------------------------------------
+
+// csr flattens precomputeWeights' [][]weightEntry (resize.go:164-197) for the C ABI.
+func csr(weights [][]weightEntry) (off, idx []C.int32_t, wt []C.double) {
+	off = make([]C.int32_t, len(weights)+1)
+	n := 0
+	for d, e := range weights {
+		off[d] = C.int32_t(n)
+		n += len(e)
+	}
+	off[len(weights)] = C.int32_t(n)
+	idx = make([]C.int32_t, n+1)
+	wt = make([]C.double, n+1)
+	k := 0
+	for _, e := range weights {
+		for _, t := range e {
+			idx[k], wt[k] = C.int32_t(t.index), C.double(t.weight)
+			k++
+		}
+	}
+	return
+}
+
+func lanczosTable(dst, src int) ([]C.int32_t, []C.int32_t, []C.double) {
+	ratio := float64(src) / float64(dst) // resize.go:81-87
+	support := lanczosA
+	if ratio > 1 {
+		support = lanczosA * ratio
+	}
+	return csr(precomputeWeights(dst, src, ratio, support))
+}
+
+// lanczosResize replaces resize.go:37 (smartResize, resize.go:12, calls it unchanged).
+func lanczosResize(img *image.NRGBA, dstW, dstH int) *image.NRGBA {
+	srcW, srcH := img.Bounds().Dx(), img.Bounds().Dy()
+	if srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0 {
+		return image.NewNRGBA(image.Rect(0, 0, 0, 0))
+	}
+	if srcW == dstW && srcH == dstH {
+		return lanczosResizeGo(img, dstW, dstH) // flat copy, no reason to cross the bus
+	}
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		offH, idxH, wH := lanczosTable(dstW, srcW)
+		offV, idxV, wV := lanczosTable(dstH, srcH)
+		dst := image.NewNRGBA(image.Rect(0, 0, dstW, dstH))
+		st := C.fnx_lanczos_resize(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(srcW), C.int(srcH),
+			&offH[0], &idxH[0], &wH[0], &offV[0], &idxV[0], &wV[0],
+			pix(dst), C.int(dst.Stride), C.int(dstW), C.int(dstH))
+		runtime.KeepAlive(img)
+		if st == C.FNX_OK {
+			return dst
+		}
+	}
+	return lanczosResizeGo(img, dstW, dstH)
+}
+
+// ---- effects.go ----------------------------------------------------------------------------
+
+// GaussianBlur replaces effects.go:146.
+func GaussianBlur(img *image.NRGBA, sigma float64) *image.NRGBA {
+	if sigma <= 0 {
+		return img // same pointer (effects.go:147-149)
+	}
+	w, h := img.Bounds().Dx(), img.Bounds().Dy()
+	radius := int(math.Ceil(sigma * 3))
+	kernel := make([]float64, radius*2+1) // effects.go:155-165, Go's math.Exp
+	var sum float64
+	for i := range kernel {
+		x := float64(i - radius)
+		kernel[i] = math.Exp(-(x * x) / (2 * sigma * sigma))
+		sum += kernel[i]
+	}
+	for i := range kernel {
+		kernel[i] /= sum
+	}
+	if c := pool.get(); c != nil && w > 0 && h > 0 {
+		defer pool.put(c)
+		dst := image.NewNRGBA(image.Rect(0, 0, w, h))
+		// FNX_BLUR_EXACT reproduces the reference bit for bit; FNX_BLUR_FAST is ~3x faster and
+		// differs by at most 1 LSB on <= 0.1 % of samples.
+		st := C.fnx_gaussian_blur(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h),
+			(*C.double)(unsafe.Pointer(&kernel[0])), C.int(radius), C.FNX_BLUR_FAST, pix(dst), C.int(dst.Stride))
+		runtime.KeepAlive(img)
+		if st == C.FNX_OK {
+			return dst
+		}
+	}
+	return gaussianBlurGo(img, sigma)
+}
+
+func sharpenHIP(img *image.NRGBA, amount float64, adaptive bool) *image.NRGBA {
+	c := pool.get()
+	if c == nil {
+		return nil
+	}
+	defer pool.put(c)
+	w, h := img.Bounds().Dx(), img.Bounds().Dy()
+	dst := image.NewNRGBA(image.Rect(0, 0, w, h))
+	var st C.int
+	if adaptive {
+		st = C.fnx_adaptive_sharpen(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h), C.double(amount), pix(dst), C.int(dst.Stride))
+	} else {
+		st = C.fnx_sharpen(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h), C.double(amount), pix(dst), C.int(dst.Stride))
+	}
+	runtime.KeepAlive(img)
+	if st != C.FNX_OK {
+		return nil
+	}
+	return dst
+}
+
+// Sharpen replaces effects.go:10.
+func Sharpen(img *image.NRGBA, strength float64) *image.NRGBA {
+	if strength <= 0 {
+		return img
+	}
+	if strength > 1 {
+		strength = 1
+	}
+	if img.Bounds().Dx() < 3 || img.Bounds().Dy() < 3 {
+		return img
+	}
+	if dst := sharpenHIP(img, 1.0+strength*1.5, false); dst != nil {
+		return dst
+	}
+	return sharpenGo(img, strength)
+}
+
+// AdaptiveSharpen replaces effects.go:49.
+func AdaptiveSharpen(img *image.NRGBA, strength float64) *image.NRGBA {
+	if strength <= 0 {
+		return img
+	}
+	if strength > 1 {
+		strength = 1
+	}
+	if img.Bounds().Dx() < 3 || img.Bounds().Dy() < 3 {
+		return img
+	}
+	if dst := sharpenHIP(img, 1.0+strength*2.0, true); dst != nil {
+		return dst
+	}
+	return adaptiveSharpenGo(img, strength)
+}
+
+// ---- exif.go -------------------------------------------------------------------------------
+
+// ApplyOrientation replaces exif.go:178.
+func ApplyOrientation(img *image.NRGBA, orient Orientation) *image.NRGBA {
+	if orient < 2 || orient > 8 {
+		return img // exif.go:180-181,200-201
+	}
+	w, h := img.Bounds().Dx(), img.Bounds().Dy()
+	if c := pool.get(); c != nil && w > 0 && h > 0 {
+		defer pool.put(c)
+		ow, oh := w, h
+		if orient >= 5 {
+			ow, oh = h, w
+		}
+		dst := image.NewNRGBA(image.Rect(0, 0, ow, oh))
+		st := C.fnx_orient(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h), C.int(orient), pix(dst), C.int(dst.Stride))
+		runtime.KeepAlive(img)
+		if st == C.FNX_OK {
+			return dst
+		}
+	}
+	return applyOrientationGo(img, orient)
+}

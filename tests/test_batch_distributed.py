@@ -1,0 +1,97 @@
+"""CompressBatch semantics (batch.go / compress.go) -- host logic on CPU, incl. the N>1 path
+with world_size 2 over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from fennec_amd import batch
+
+
+def test_search_lower_bound_and_presets():       # compress.go:35-43, types.go:74-91
+    assert [batch.search_lower_bound(t) for t in (0.999, 0.99, 0.97, 0.94, 0.90, 0.85)] == [75, 75, 50, 30, 15, 1]
+    assert batch.TARGET_SSIM["Balanced"] == 0.94 and batch.TARGET_SSIM["Lossless"] == 1.0
+
+
+def test_compress_jpeg_optimal_binary_search():
+    """compress.go:45-74 with a synthetic monotone quality->SSIM codec."""
+    curve = lambda q: 0.80 + 0.002 * q              # SSIM as a function of quality
+    enc = lambda img, q: bytes([q])
+    dec = lambda data: data[0]
+    for target, want in [(0.94, 70), (0.97, 85), (0.90, 50), (0.85, 25), (1.0, 100)]:
+        q, s, data, steps = batch.compress_jpeg_optimal(lambda d: curve(d), None, target, enc, dec)
+        lo = batch.search_lower_bound(min(target, 0.999))
+        brute = next((k for k in range(lo, 101) if curve(k) >= min(target, 0.999)), 100)
+        assert q == brute and data == bytes([q]) and steps <= 7, (target, q, brute)
+        if brute == want:
+            assert q == want
+    # nothing reaches the target: bestQuality stays 100, fallback encode (compress.go:82-86)
+    q, s, data, _ = batch.compress_jpeg_optimal(lambda d: 0.5, None, 0.94, enc, dec)
+    assert q == 100 and s == 1.0 and data == bytes([100])
+
+
+def test_pillow_codec_roundtrip():
+    from fennec_amd import synth
+    img = synth.make_test_image(64, 48)
+    dec = batch.pillow_decode(batch.pillow_encode(img, 90))
+    assert dec.shape == img.shape and dec.dtype == np.uint8 and (dec[..., 3] == 255).all()
+    assert np.abs(dec[..., :3].astype(int) - img[..., :3].astype(int)).mean() < 6
+
+
+def _fake_work(idx, state):
+    if idx % 7 == 3:
+        raise RuntimeError("decode failed")
+    return batch.BatchResult(Index=idx, OriginalSize=1000 + 13 * idx, CompressedSize=400 + 5 * idx,
+                             SSIM=0.9 + (idx % 10) * 0.007, Quality=50 + idx % 40)
+
+
+def test_compress_batch_order_errors_progress(orc):
+    seen = []
+    res = batch.compress_batch(50, _fake_work, lambda w: None, workers=4, on_item=lambda c, t: seen.append((c, t)))
+    assert [r.Index for r in res] == list(range(50))            # results by index (batch.go:71)
+    assert sorted(c for c, _ in seen) == list(range(1, 51)) and all(t == 50 for _, t in seen)
+    assert all((r.Err is not None) == (r.Index % 7 == 3) for r in res)
+    s = batch.summarize_local(res)
+    want = orc.summarize([r.Err is not None for r in res], [r.has_result for r in res],
+                         [r.OriginalSize for r in res], [r.CompressedSize for r in res], [r.SSIM for r in res])
+    assert (s.Total, s.Succeeded, s.Failed, s.TotalSaved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
+    assert s.AvgSSIM == want["AvgSSIM"]
+    assert batch.compress_batch(0, _fake_work, lambda w: None) == []     # batch.go:59-61
+
+
+def _rank_main(rank, world, port, n_items, out_q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = batch.compress_batch(n_items, _fake_work, lambda w: None, workers=2, rank=rank, world=world)
+    s = batch.summarize_distributed(res)
+    out_q.put((rank, [r.Index for r in res], (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM)))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(orc):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_items, world = 37, 2
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shards = {r: idx for r, idx, _ in got}
+    assert sorted(shards[0] + shards[1]) == list(range(n_items))         # every item exactly once
+    assert shards[0] == list(range(0, n_items, 2)) and shards[1] == list(range(1, n_items, 2))
+    allres = [(_fake_work(i, None) if i % 7 != 3 else batch.BatchResult(Index=i, Err="x", has_result=False)) for i in range(n_items)]
+    want = orc.summarize([r.Err is not None for r in allres], [r.has_result for r in allres],
+                         [r.OriginalSize for r in allres], [r.CompressedSize for r in allres], [r.SSIM for r in allres])
+    for _, _, (t, ok, bad, saved, avg) in got:                             # identical on every rank
+        assert (t, ok, bad, saved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
+        assert abs(avg - want["AvgSSIM"]) <= 1e-15 * 4
