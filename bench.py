@@ -215,7 +215,7 @@ def cpu_baseline(img: np.ndarray) -> dict:
         oracle.ssim_fast(img, b, procs=cores)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 16:
+        if dt > 12.0 or (n >= 16 and dt > 3.0) or n >= 256:
             break
     return {
         "value": round(n * W4K * H4K / 1e6 / dt, 2),
