@@ -19,10 +19,14 @@ typedef __attribute__((address_space(1))) uint32_t g_u32w;
 // clampF (convert.go:149-158): math.Round (ties away from zero) then clamp to [0,255].
 __device__ __forceinline__ uint32_t clampF_dev(double x)
 {
-    long long v = static_cast<long long>(round(x));
-    if (v > 255) return 255u;
-    if (v < 0) return 0u;
-    return static_cast<uint32_t>(v);
+    // Same value as int64(math.Round(x)) clamped, without the f64->i64 conversion and libm round():
+    // t = trunc(x); x - t is exact; ties (|x - t| == 0.5) and beyond go away from zero.
+    double t = trunc(x);
+    if (fabs(x - t) >= 0.5) t += copysign(1.0, x);
+    // int64(NaN) and int64(|x| >= 2^63) are 0x8000000000000000 on amd64 -> negative -> 0
+    if (!(fabs(t) < 9223372036854775808.0)) return 0u;
+    t = fmin(fmax(t, 0.0), 255.0);
+    return static_cast<uint32_t>(static_cast<int>(t));
 }
 
 // fast-mode rounding of an fp32 accumulator into byte `sel` of `old`:

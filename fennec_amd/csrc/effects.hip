@@ -17,55 +17,80 @@ struct FxArgs {
     double amount;
 };
 
+// Workgroup = 64 x 8 output pixels (2 per lane).  The 66 x 10 source tile is loaded once into
+// LDS (raw pixel + its BT.601 luminance), so every pixel's luminance is computed once instead of
+// once per Sobel neighbour (8x) and the 3x3 neighbourhood costs LDS reads, not global loads.
+constexpr int FX_TW = 64, FX_TH = 8;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.w || y >= a.h) return;
-    const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
-    const uint32_t c = ld_px(row, x);
-    uint32_t out = c;   // borders and alpha are copies of the source (effects.go:68,120)
-    if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
-        const uint8_t *up = row - a.sstride, *dn = row + a.sstride;
-        const uint32_t p00 = ld_px(up, x - 1), p01 = ld_px(up, x), p02 = ld_px(up, x + 1);
-        const uint32_t p10 = ld_px(row, x - 1), p12 = ld_px(row, x + 1);
-        const uint32_t p20 = ld_px(dn, x - 1), p21 = ld_px(dn, x), p22 = ld_px(dn, x + 1);
-        uint32_t blur[3];
+    constexpr int LW = FX_TW + 2, LH = FX_TH + 2;
+    __shared__ uint32_t s_px[LH * LW];
+    __shared__ double s_lum[MODE == FX_ADAPTIVE ? LH * LW : 1];
+    const int x0 = blockIdx.x * FX_TW, y0 = blockIdx.y * FX_TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        // clamped reads: out-of-image tile cells are only ever neighbours of border pixels, which
+        // are copies of the source and never look at them
+        const int x = clampi(x0 + lx - 1, 0, a.w - 1), y = clampi(y0 + ly - 1, 0, a.h - 1);
+        const uint32_t p = ld_px(a.src + static_cast<size_t>(y) * a.sstride, x);
+        s_px[i] = p;
+        if (MODE == FX_ADAPTIVE) s_lum[i] = lum601(p);
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    const int x = x0 + lx;
+    if (x >= a.w) return;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const int s = 8 * ch;
-            const uint32_t sum = ((p00 >> s) & 0xffu) + 2 * ((p01 >> s) & 0xffu) + ((p02 >> s) & 0xffu) +
-                                 2 * ((p10 >> s) & 0xffu) + 4 * ((c >> s) & 0xffu) + 2 * ((p12 >> s) & 0xffu) +
-                                 ((p20 >> s) & 0xffu) + 2 * ((p21 >> s) & 0xffu) + ((p22 >> s) & 0xffu);
-            blur[ch] = (sum + 8) >> 4;                       // effects.go:125-135
-        }
-        if (MODE == FX_BLUR3) {
-            out = blur[0] | (blur[1] << 8) | (blur[2] << 16) | (c & 0xff000000u);
-        } else {
-            double amt = a.amount;
-            if (MODE == FX_ADAPTIVE) {                       // localEdgeStrength, effects.go:93-112
-                const double l00 = lum601(p00), l01 = lum601(p01), l02 = lum601(p02);
-                const double l10 = lum601(p10), l12 = lum601(p12);
-                const double l20 = lum601(p20), l21 = lum601(p21), l22 = lum601(p22);
-                const double gx = -l00 + l02 - 2 * l10 + 2 * l12 - l20 + l22;
-                const double gy = -l00 - 2 * l01 - l02 + l20 + 2 * l21 + l22;
-                const double mag = sqrt(gx * gx + gy * gy);
-                double normalized = mag / 400.0;
-                if (normalized > 1) normalized = 1;
-                amt = a.amount * normalized;                 // localAmount (effects.go:74)
-            }
-            out = c & 0xff000000u;
+    for (int rep = 0; rep < 2; rep++) {
+        const int ly = (tid >> 6) + 4 * rep;
+        const int y = y0 + ly;
+        if (y >= a.h) continue;
+        const int ci = (ly + 1) * LW + lx + 1;          // tile cell of (x, y)
+        const uint32_t c = s_px[ci];
+        uint32_t out = c;   // borders and alpha are copies of the source (effects.go:68,120)
+        if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
+            const uint32_t p00 = s_px[ci - LW - 1], p01 = s_px[ci - LW], p02 = s_px[ci - LW + 1];
+            const uint32_t p10 = s_px[ci - 1], p12 = s_px[ci + 1];
+            const uint32_t p20 = s_px[ci + LW - 1], p21 = s_px[ci + LW], p22 = s_px[ci + LW + 1];
+            uint32_t blur[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const double orig = static_cast<double>((c >> (8 * ch)) & 0xffu);
-                const double bl = static_cast<double>(blur[ch]);
-                const double val = orig + amt * (orig - bl); // effects.go:37,82
-                out |= clampF_dev(val) << (8 * ch);
+                const int s = 8 * ch;
+                const uint32_t sum = ((p00 >> s) & 0xffu) + 2 * ((p01 >> s) & 0xffu) + ((p02 >> s) & 0xffu) +
+                                     2 * ((p10 >> s) & 0xffu) + 4 * ((c >> s) & 0xffu) + 2 * ((p12 >> s) & 0xffu) +
+                                     ((p20 >> s) & 0xffu) + 2 * ((p21 >> s) & 0xffu) + ((p22 >> s) & 0xffu);
+                blur[ch] = (sum + 8) >> 4;                       // effects.go:125-135
+            }
+            if (MODE == FX_BLUR3) {
+                out = blur[0] | (blur[1] << 8) | (blur[2] << 16) | (c & 0xff000000u);
+            } else {
+                double amt = a.amount;
+                if (MODE == FX_ADAPTIVE) {                       // localEdgeStrength, effects.go:93-112
+                    const double l00 = s_lum[ci - LW - 1], l01 = s_lum[ci - LW], l02 = s_lum[ci - LW + 1];
+                    const double l10 = s_lum[ci - 1], l12 = s_lum[ci + 1];
+                    const double l20 = s_lum[ci + LW - 1], l21 = s_lum[ci + LW], l22 = s_lum[ci + LW + 1];
+                    const double gx = -l00 + l02 - 2 * l10 + 2 * l12 - l20 + l22;
+                    const double gy = -l00 - 2 * l01 - l02 + l20 + 2 * l21 + l22;
+                    const double mag = sqrt(gx * gx + gy * gy);
+                    double normalized = mag / 400.0;
+                    if (normalized > 1) normalized = 1;
+                    amt = a.amount * normalized;                 // localAmount (effects.go:74)
+                }
+                out = c & 0xff000000u;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const double orig = static_cast<double>((c >> (8 * ch)) & 0xffu);
+                    const double bl = static_cast<double>(blur[ch]);
+                    const double val = orig + amt * (orig - bl); // effects.go:37,82
+                    out |= clampF_dev(val) << (8 * ch);
+                }
             }
         }
+        *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
     }
-    *reinterpret_cast<uint32_t *>(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
 }
 
 template <int MODE>
@@ -74,7 +99,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
 {
     if (w <= 0 || h <= 0) return FNX_OK;
     FxArgs a{src, dst, sstride, dstride, w, h, amount};
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
     hipLaunchKernelGGL((fx_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
     FNX_HIP(hipGetLastError());
     return FNX_OK;

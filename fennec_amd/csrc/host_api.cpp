@@ -3,6 +3,9 @@
 // generation, i.e. everything the Go side of a cgo shim keeps.  No pixel arithmetic happens
 // here: every image operation is a fnx_* call (HIP kernels); there is no CPU path.
 #include <cmath>
+#include <memory>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -16,13 +19,35 @@ struct Taps {
     std::vector<double> wt;
 };
 
-void make_taps(int dstSize, int srcSize, Taps &t)
+void build_taps(int dstSize, int srcSize, Taps &t)
 {
     t.off.assign(static_cast<size_t>(dstSize) + 1, 0);
     int n = fennec_precomputeWeights(dstSize, srcSize, t.off.data(), nullptr, nullptr);
     t.idx.assign(static_cast<size_t>(n > 0 ? n : 1), 0);
     t.wt.assign(static_cast<size_t>(n > 0 ? n : 1), 0.0);
     fennec_precomputeWeights(dstSize, srcSize, t.off.data(), t.idx.data(), t.wt.data());
+}
+
+// precomputeWeights costs two sin() per tap (tens of thousands for a 4K axis): far more than the
+// resize kernels themselves, and callers resize to the same few geometries over and over
+// (SSIM's implicit resize, smartResize to a fixed box, the target-size scale search).  Keep the
+// most recent tables; entries are immutable once built and shared by pointer.
+std::shared_ptr<const Taps> make_taps(int dstSize, int srcSize)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, int>, std::shared_ptr<const Taps>>> cache;
+    const std::pair<int, int> key(dstSize, srcSize);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : cache)
+            if (e.first == key) return e.second;
+    }
+    auto t = std::make_shared<Taps>();
+    build_taps(dstSize, srcSize, *t);
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 32) cache.erase(cache.begin());
+    cache.emplace_back(key, t);
+    return t;
 }
 
 // The 8x8 window never changes (windowSize 8, sigma 1.5: ssim.go:74-77).
@@ -42,9 +67,8 @@ const double *ssim_window()
 int resize_b_to(fnx_ctx *ctx, int space, const uint8_t *b, int bstride, int bw, int bh, int w, int h,
                 const uint8_t **out, int *ostride)
 {
-    Taps th, tv;
-    make_taps(w, bw, th);
-    make_taps(h, bh, tv);
+    const auto pth = make_taps(w, bw), ptv = make_taps(h, bh);
+    const Taps &th = *pth, &tv = *ptv;
     void *d = nullptr;
     FNX_TRY(scratch(ctx, SLOT_TMP3, static_cast<size_t>(w) * h * 4 + 16, &d));
     const uint8_t *src = b;
@@ -256,9 +280,8 @@ int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
     if (srcW == dstW && srcH == dstH)
         return fnx_lanczos_resize(ctx, space, src, sstride, srcW, srcH, nullptr, nullptr, nullptr, nullptr,
                                   nullptr, nullptr, dst, dstride, dstW, dstH);
-    Taps th, tv;
-    make_taps(dstW, srcW, th);
-    make_taps(dstH, srcH, tv);
+    const auto pth = make_taps(dstW, srcW), ptv = make_taps(dstH, srcH);
+    const Taps &th = *pth, &tv = *ptv;
     return fnx_lanczos_resize(ctx, space, src, sstride, srcW, srcH, th.off.data(), th.idx.data(),
                               th.wt.data(), tv.off.data(), tv.idx.data(), tv.wt.data(), dst, dstride,
                               dstW, dstH);

@@ -85,6 +85,27 @@ int main(int argc, char **argv)
         time_it("ssim_fast x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_ssim_fast(ctx, FNX_DEVICE, srcs[i], W * 4, dsts[i], W * 4, W, H, win, &out[i])); }, 2.0 * S);
         (void)k;
     }
+    if (what == "cfg3" || what == "all") {      // BASELINE config 3 pieces (4K -> 1080p Lanczos, MSSSIM)
+        void *small, *up;
+        FK(fnx_malloc(ctx, (size_t)(W / 2) * (H / 2) * 4, &small));
+        FK(fnx_malloc(ctx, S, &up));
+        double res = 0;
+        time_it("lanczosResize 1/2", [&] { for (int i = 0; i < B; i++) FK(fennec_lanczosResize(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, (uint8_t *)small, W / 2 * 4, W / 2, H / 2)); }, 1.25 * S);
+        time_it("lanczosResize x2 (back up)", [&] { for (int i = 0; i < B; i++) FK(fennec_lanczosResize(ctx, FNX_DEVICE, (uint8_t *)small, W / 2 * 4, W / 2, H / 2, (uint8_t *)up, W * 4, W, H)); }, 1.25 * S);
+        time_it("MSSSIM (equal dims)", [&] { for (int i = 0; i < B; i++) FK(fennec_MSSSIM(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, (uint8_t *)up, W * 4, W, H, &res)); }, 3.33 * S);
+        time_it("MSSSIM (vs half size: cfg3)", [&] { for (int i = 0; i < B; i++) FK(fennec_MSSSIM(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, (uint8_t *)small, W / 2 * 4, W / 2, H / 2, &res)); }, 4.58 * S);
+        printf("msssim=%.12f\n", res);
+    }
+    if (what == "cfg4" || what == "all") {      // BASELINE config 4 pieces (AdaptiveSharpen, full SSIM)
+        double res = 0;
+        time_it("AdaptiveSharpen", [&] { for (int i = 0; i < B; i++) FK(fennec_AdaptiveSharpen(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, 0.5, dsts[i], W * 4)); }, 2.0 * S);
+        time_it("Sharpen", [&] { for (int i = 0; i < B; i++) FK(fennec_Sharpen(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, 0.5, dsts[i], W * 4)); }, 2.0 * S);
+        time_it("SSIM (full res)", [&] { for (int i = 0; i < B; i++) FK(fennec_SSIM(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, dsts[i], W * 4, W, H, &res)); }, 2.0 * S);
+        time_it("ApplyOrientation 6", [&] { for (int i = 0; i < B; i++) FK(fennec_ApplyOrientation(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, 6, dsts[i], H * 4)); }, 2.0 * S);
+        time_it("ApplyOrientation 3", [&] { for (int i = 0; i < B; i++) FK(fennec_ApplyOrientation(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, 3, dsts[i], W * 4)); }, 2.0 * S);
+        time_it("GaussianBlur exact", [&] { for (int i = 0; i < B; i++) FK(fnx_gaussian_blur(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, kern.data(), radius, FNX_BLUR_EXACT, dsts[i], W * 4)); }, 2.0 * S);
+        printf("ssim=%.12f\n", res);
+    }
     printf("ssim[0]=%.12f\n", out[0]);
     fnx_ctx_destroy(ctx);
     return 0;
