@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 
 // Work decomposition of one TW x TH output tile (256 threads):
 //   stage : (TH+2R) rows x (TW+2RA) px of NRGBA, 16-byte global loads, into LDS s_in
-//   H pass: item = 2 staged rows x 4 output px.  The 2 rows x RGB = 6 accumulators per output
+//   H pass: item = 2 staged rows x 8 output px.  The 2 rows x RGB = 6 accumulators per output
 //           are three float2 lanes, so every tap is 3 v_pk_fma_f32 for 2 pixels; input pixels
 //           are converted once and scattered into the (<=4) outputs they feed, taps ascending.
 //           Results are rounded to uint8 into LDS s_tmp (the reference's uint8 intermediate).
@@ -118,13 +118,14 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
     constexpr int D = RA - R;               // px the LDS image is shifted against global chunks
     constexpr int NT = 2 * R + 1;
     constexpr int IH = TH + 2 * R;          // staged rows
-    constexpr int NPX = 4 + 2 * R;          // input px one H item (4 outputs) needs per row
+    constexpr int HO = 8;                   // outputs per H item and row: each px converted (HO+2R)/HO times
+    constexpr int NPX = HO + 2 * R;         // input px one H item needs per row
     constexpr int NV = (NPX + 3) / 4;       // ... as 16-byte LDS reads
     constexpr int GC = (TW + 2 * RA) / 4;   // global 16-byte chunks per staged row
     constexpr int NLOAD = (IH * GC + 255) / 256;
-    constexpr int GROUPS = TW / 4;
-    static_assert(TH % Q == 0 && TW % 4 == 0 && IH % 2 == 0, "tile shape");
-    static_assert(IWP % 4 == 0 && IWP >= TW - 4 + 4 * NV, "LDS pitch");
+    constexpr int GROUPS = TW / 4, HGROUPS = TW / HO;
+    static_assert(TH % Q == 0 && TW % HO == 0 && IH % 2 == 0, "tile shape");
+    static_assert(IWP % 4 == 0 && IWP >= TW - HO + 4 * NV, "LDS pitch");
 
     // s_in[r][i]  <-> src(x0 - R + i, clamp(y0 - R + r));  s_tmp[r][x] <-> H-pass of that row.
     __shared__ __attribute__((aligned(16))) uint32_t smem[IH * IWP + IH * TW];
@@ -182,47 +183,51 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
     }
     __syncthreads();
 
-    // ---- horizontal pass (effects.go:169-191) ----
-    for (int item = tid; item < (IH / 2) * GROUPS; item += 256) {
-        const int rp = item / GROUPS, g = item - rp * GROUPS;
-        const uint32_t *row0 = s_in + (2 * rp) * IWP + 4 * g;
+    // ---- horizontal pass (effects.go:169-191): item = 2 staged rows x HO outputs ----
+    for (int item = tid; item < (IH / 2) * HGROUPS; item += 256) {
+        const int rp = item / HGROUPS, g = item - rp * HGROUPS;
+        const uint32_t *row0 = s_in + (2 * rp) * IWP + HO * g;
         const uint32_t *row1 = row0 + IWP;
-        uint32_t p0[4 * NV], p1[4 * NV];
+        v2f acc[HO][3];
+#pragma unroll
+        for (int j = 0; j < HO; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){0.5f, 0.5f};
 #pragma unroll
         for (int q = 0; q < NV; q++) {
             const u32x4 t0 = *reinterpret_cast<const u32x4 *>(row0 + 4 * q);
             const u32x4 t1 = *reinterpret_cast<const u32x4 *>(row1 + 4 * q);
-            p0[4 * q] = t0.x; p0[4 * q + 1] = t0.y; p0[4 * q + 2] = t0.z; p0[4 * q + 3] = t0.w;
-            p1[4 * q] = t1.x; p1[4 * q + 1] = t1.y; p1[4 * q + 2] = t1.z; p1[4 * q + 3] = t1.w;
-        }
-        v2f acc[4][3];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){0.5f, 0.5f};
+            for (int e = 0; e < 4; e++) {
+                const int i = 4 * q + e;
+                if (i < NPX) {
+                    const uint32_t p0 = t0[e], p1 = t1[e];
+                    const v2f f0 = {static_cast<float>(p0 & 0xffu), static_cast<float>((p0 >> 8) & 0xffu)};
+                    const v2f f1 = {static_cast<float>((p0 >> 16) & 0xffu), static_cast<float>(p1 & 0xffu)};
+                    const v2f f2 = {static_cast<float>((p1 >> 8) & 0xffu), static_cast<float>((p1 >> 16) & 0xffu)};
 #pragma unroll
-        for (int i = 0; i < NPX; i++) {
-            const v2f f0 = {static_cast<float>(p0[i] & 0xffu), static_cast<float>((p0[i] >> 8) & 0xffu)};
-            const v2f f1 = {static_cast<float>((p0[i] >> 16) & 0xffu), static_cast<float>(p1[i] & 0xffu)};
-            const v2f f2 = {static_cast<float>((p1[i] >> 8) & 0xffu), static_cast<float>((p1[i] >> 16) & 0xffu)};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = i - j;
-                if (k >= 0 && k < NT) {
-                    acc[j][0] = fma2(f0, a.wt[k], acc[j][0]);
-                    acc[j][1] = fma2(f1, a.wt[k], acc[j][1]);
-                    acc[j][2] = fma2(f2, a.wt[k], acc[j][2]);
+                    for (int j = 0; j < HO; j++) {
+                        const int k = i - j;
+                        if (k >= 0 && k < NT) {
+                            acc[j][0] = fma2(f0, a.wt[k], acc[j][0]);
+                            acc[j][1] = fma2(f1, a.wt[k], acc[j][1]);
+                            acc[j][2] = fma2(f2, a.wt[k], acc[j][2]);
+                        }
+                    }
+                    // keep the converts next to their FMAs: hoisting all of them costs 6 VGPRs per px
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // keep the converts next to their FMAs: hoisting all of them costs 6 VGPRs per px
-            __builtin_amdgcn_sched_barrier(0);
         }
-        u32x4 o0, o1;
+        uint32_t o0[HO], o1[HO];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < HO; j++) {
             o0[j] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, 0)));
             o1[j] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, 0)));
         }
-        *reinterpret_cast<u32x4 *>(s_tmp + (2 * rp) * TW + 4 * g) = o0;
-        *reinterpret_cast<u32x4 *>(s_tmp + (2 * rp + 1) * TW + 4 * g) = o1;
+#pragma unroll
+        for (int b = 0; b < HO / 4; b++) {
+            *reinterpret_cast<u32x4 *>(s_tmp + (2 * rp) * TW + HO * g + 4 * b) = (u32x4){o0[4 * b], o0[4 * b + 1], o0[4 * b + 2], o0[4 * b + 3]};
+            *reinterpret_cast<u32x4 *>(s_tmp + (2 * rp + 1) * TW + HO * g + 4 * b) = (u32x4){o1[4 * b], o1[4 * b + 1], o1[4 * b + 2], o1[4 * b + 3]};
+        }
     }
     __syncthreads();
 
@@ -293,8 +298,8 @@ template <int R>
 static int launch_fused(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
     constexpr int TW = 64, TH = ((64 - 2 * R) / 4) * 4, Q = 4;   // TH + 2R <= 64 staged rows
-    constexpr int NV = (4 + 2 * R + 3) / 4;
-    constexpr int IWP = ((TW - 4 + 4 * NV) + 31) / 32 * 32;   // pitch = 0 mod 128 B: conflict-free b128 reads
+    constexpr int NV = (8 + 2 * R + 3) / 4;
+    constexpr int IWP = ((TW - 8 + 4 * NV) + 31) / 32 * 32;   // pitch = 0 mod 128 B
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);

@@ -9,6 +9,7 @@ namespace fnx {
 // explicit global-address-space views: pointers fetched from pointer tables are generic to
 // the compiler and would otherwise be accessed with flat_load/flat_store
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const u32x4 g_u32x4;
