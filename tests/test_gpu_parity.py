@@ -318,3 +318,44 @@ def test_blur_fast_shapes(ctx, orc):
     for (w, h) in [(1030, 300), (513, 64), (2049, 33), (1281, 721)]:
         img = synth.noise_image(w, h, w + h, alpha=True)
         assert_blur_close(ctx.GaussianBlur(img, 2.0), orc.gaussian_blur(img, 2.0, procs=8))
+
+
+# ------------------------------------------------------------------ concurrency (CompressBatch workers)
+def test_concurrent_contexts_threads(orc):
+    """batch.go:84-123: workers call the hot path concurrently; one fnx_ctx per worker thread."""
+    import threading
+    imgs = [synth.large_photo(800, 600, k) for k in range(8)]
+    want = [(orc.gaussian_blur(i, 2.0, procs=4), None) for i in imgs]
+    want = [(b, orc.ssim_fast(i, b)) for i, (b, _) in zip(imgs, want)]
+    errs = []
+
+    def worker(wid):
+        try:
+            c = fennec_amd.Context(0)
+            for rep in range(6):
+                for k in range(wid, 8, 4):
+                    b = c.GaussianBlur(imgs[k], 2.0, exact=True)
+                    assert np.array_equal(b, want[k][0])
+                    assert abs(c.SSIMFast(imgs[k], b) - want[k][1]) <= SSIM_TOL
+                    assert np.array_equal(c.ApplyOrientation(imgs[k], 6), orc.apply_orientation(imgs[k], 6))
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+def test_jpeg_quality_search_on_gpu(ctx, orc):
+    """compress.go:21-87 harness: GPU SSIMFast (prepared reference) drives the same binary search
+    as the oracle's SSIMFast; same quality, same SSIM to 1e-9."""
+    from fennec_amd import batch
+    src = synth.make_test_image(640, 480)
+    prep = ctx.ssim_fast_prepare(src)
+    q1, s1, d1, n1 = batch.compress_jpeg_optimal(lambda dec: prep.against(dec), src, 0.94)
+    q2, s2, d2, n2 = batch.compress_jpeg_optimal(lambda dec: orc.ssim_fast(src, dec), src, 0.94)
+    prep.close()
+    assert (q1, n1) == (q2, n2) and d1 == d2 and abs(s1 - s2) <= SSIM_TOL
+    assert 30 <= q1 <= 100 and s1 >= 0.94
