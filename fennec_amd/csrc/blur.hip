@@ -96,11 +96,16 @@ __device__ __forceinline__ v2f fma2(v2f f, float w, v2f acc)
 {
     return __builtin_elementwise_fma(f, (v2f){w, w}, acc);
 }
-// floor(x) -> saturated u8 into byte `sel` of `old`; accumulators start at 0.5, so this is
-// floor(sum + 0.5) = round-half-up of a non-negative sum, i.e. clampF for every in-range value
+// clampF of a fast-mode accumulator in ONE instruction.  v_cvt_pk_u8_f32 saturates to [0,255] and
+// rounds per the wave's FP32 round mode (probed on gfx950: nearest-even by default, truncation
+// under round-toward-zero).  Accumulators are seeded with 0.5, so truncation is floor(sum + 0.5)
+// = clampF's round-half-up; the mode is flipped (one SALU s_setreg each way) only around the
+// packing instructions, the FMAs all run in round-to-nearest-even.
+__device__ __forceinline__ void fp32_round_toward_zero() { __builtin_amdgcn_s_setreg(0x801, 3); }   // hwreg(MODE, 0, 2)
+__device__ __forceinline__ void fp32_round_nearest() { __builtin_amdgcn_s_setreg(0x801, 0); }
 __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 {
-    return __builtin_amdgcn_cvt_pk_u8_f32(floorf(x), sel, old);
+    return __builtin_amdgcn_cvt_pk_u8_f32(x, sel, old);
 }
 
 // Work decomposition of one TW x TH output tile (256 threads):
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
     constexpr int NPX = HO + 2 * R;         // input px one H item needs per row
     constexpr int NV = (NPX + 3) / 4;       // ... as 16-byte LDS reads
     constexpr int GC = (TW + 2 * RA) / 4;   // global 16-byte chunks per staged row
-    constexpr int NLOAD = (IH * GC + 255) / 256;
+    constexpr int RPP = 256 / GC;           // staged rows per pass of the 256 lanes
+    constexpr int NLOAD = (IH + RPP - 1) / RPP;
     constexpr int GROUPS = TW / 4, HGROUPS = TW / HO;
     static_assert(TH % Q == 0 && TW % HO == 0 && IH % 2 == 0, "tile shape");
     static_assert(IWP % 4 == 0 && IWP >= TW - HO + 4 * NV, "LDS pitch");
@@ -142,42 +148,54 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
     const int tid = threadIdx.x;
 
     // ---- stage the tile + halo: all global loads first (memory-level parallelism) ----
+    // lane -> (chunk column gc, row lane r0), rows r0, r0+RPP, ...: one division per lane, every
+    // further address is a constant stride away (the staging used to cost 18 VALU ops per output
+    // pixel in index arithmetic -- on a VALU-bound kernel that was 15 % of the run time)
+    const int r0 = tid / GC, gc = tid - r0 * GC;
+    const bool stager = r0 < RPP;
+    const int xs = x0 - RA + 4 * gc;                     // first px of this lane's chunks
+    const bool interior = a.vec_in && x0 - RA >= 0 && x0 + TW + RA <= a.w && y0 - R >= 0 && y0 + TH + R <= a.h;
     u32x4 v[NLOAD];
+    if (interior) {                                      // workgroup-uniform: no clamps, no per-load tests
+        const uint8_t *p = src + static_cast<size_t>(y0 - R + r0) * a.sstride + 4 * static_cast<size_t>(xs);
 #pragma unroll
-    for (int it = 0; it < NLOAD; it++) {
-        const int c = tid + it * 256;
-        if (c < IH * GC) {
-            const int r = c / GC, gc = c - r * GC;
-            const int y = clampi(y0 - R + r, 0, a.h - 1);
-            const int x = x0 - RA + 4 * gc;
-            const uint8_t *row = src + static_cast<size_t>(y) * a.sstride;
-            if (a.vec_in && x >= 0 && x + 3 < a.w) {
-                v[it] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(x));
-            } else {   // image border (clamp-to-edge, effects.go:174-178) or unaligned input
-                v[it].x = ld_px(row, clampi(x, 0, a.w - 1));
-                v[it].y = ld_px(row, clampi(x + 1, 0, a.w - 1));
-                v[it].z = ld_px(row, clampi(x + 2, 0, a.w - 1));
-                v[it].w = ld_px(row, clampi(x + 3, 0, a.w - 1));
+        for (int it = 0; it < NLOAD; it++)
+            if (stager && r0 + it * RPP < IH) v[it] = *(g_u32x4 *)(p + static_cast<size_t>(it * RPP) * a.sstride);
+    } else {
+#pragma unroll
+        for (int it = 0; it < NLOAD; it++) {
+            const int r = r0 + it * RPP;
+            if (stager && r < IH) {
+                const uint8_t *row = src + static_cast<size_t>(clampi(y0 - R + r, 0, a.h - 1)) * a.sstride;
+                if (a.vec_in && xs >= 0 && xs + 3 < a.w) {
+                    v[it] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(xs));
+                } else {   // image border (clamp-to-edge, effects.go:174-178) or unaligned input
+                    v[it].x = ld_px(row, clampi(xs, 0, a.w - 1));
+                    v[it].y = ld_px(row, clampi(xs + 1, 0, a.w - 1));
+                    v[it].z = ld_px(row, clampi(xs + 2, 0, a.w - 1));
+                    v[it].w = ld_px(row, clampi(xs + 3, 0, a.w - 1));
+                }
             }
         }
     }
+    {
+        const int i0 = 4 * gc - D;                       // LDS column of the chunk's first px
+        uint32_t *colp = s_in + r0 * IWP + i0;
 #pragma unroll
-    for (int it = 0; it < NLOAD; it++) {
-        const int c = tid + it * 256;
-        if (c < IH * GC) {
-            const int r = c / GC, gc = c - r * GC;
-            const int i0 = 4 * gc - D;   // LDS column of the chunk's first px
-            uint32_t *rowp = s_in + r * IWP;
-            if constexpr (D == 0) {
-                if (i0 + 3 < IWP) *reinterpret_cast<u32x4 *>(rowp + i0) = v[it];
-            } else if constexpr (D == 2) {
-                if (i0 >= 0 && i0 + 1 < IWP) *reinterpret_cast<u32x2 *>(rowp + i0) = (u32x2){v[it].x, v[it].y};
-                if (i0 + 3 < IWP) *reinterpret_cast<u32x2 *>(rowp + i0 + 2) = (u32x2){v[it].z, v[it].w};
-            } else {
-                if (i0 >= 0 && i0 < IWP) rowp[i0] = v[it].x;
-                if (i0 + 1 >= 0 && i0 + 1 < IWP) rowp[i0 + 1] = v[it].y;
-                if (i0 + 2 >= 0 && i0 + 2 < IWP) rowp[i0 + 2] = v[it].z;
-                if (i0 + 3 >= 0 && i0 + 3 < IWP) rowp[i0 + 3] = v[it].w;
+        for (int it = 0; it < NLOAD; it++) {
+            if (stager && r0 + it * RPP < IH) {
+                uint32_t *rowp = colp + it * RPP * IWP;
+                if constexpr (D == 0) {
+                    if (i0 + 3 < IWP) *reinterpret_cast<u32x4 *>(rowp) = v[it];
+                } else if constexpr (D == 2) {
+                    if (i0 >= 0 && i0 + 1 < IWP) *reinterpret_cast<u32x2 *>(rowp) = (u32x2){v[it].x, v[it].y};
+                    if (i0 + 3 < IWP) *reinterpret_cast<u32x2 *>(rowp + 2) = (u32x2){v[it].z, v[it].w};
+                } else {
+                    if (i0 >= 0 && i0 < IWP) rowp[0] = v[it].x;
+                    if (i0 + 1 >= 0 && i0 + 1 < IWP) rowp[1] = v[it].y;
+                    if (i0 + 2 >= 0 && i0 + 2 < IWP) rowp[2] = v[it].z;
+                    if (i0 + 3 >= 0 && i0 + 3 < IWP) rowp[3] = v[it].w;
+                }
             }
         }
     }
@@ -218,11 +236,13 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
             }
         }
         uint32_t o0[HO], o1[HO];
+        fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < HO; j++) {
             o0[j] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, 0)));
             o1[j] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, 0)));
         }
+        fp32_round_nearest();
 #pragma unroll
         for (int b = 0; b < HO / 4; b++) {
             *reinterpret_cast<u32x4 *>(s_tmp + (2 * rp) * TW + HO * g + 4 * b) = (u32x4){o0[4 * b], o0[4 * b + 1], o0[4 * b + 2], o0[4 * b + 3]};
@@ -267,6 +287,7 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
         // round + pack every output row first, pinned with an empty asm: otherwise LLVM sinks the
         // whole accumulation into the `y < h` store branches and the live ranges explode
         u32x4 o[Q];
+        fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < Q; j++) {
             // alpha from the ORIGINAL image (effects.go:215), still in the staged tile
@@ -277,6 +298,7 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
             o[j].w = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, ap[3] & 0xff000000u)));
             asm volatile("" : "+v"(o[j].x), "+v"(o[j].y), "+v"(o[j].z), "+v"(o[j].w));
         }
+        fp32_round_nearest();
 #pragma unroll
         for (int j = 0; j < Q; j++) {
             const int y = y0 + q * Q + j;

@@ -132,11 +132,6 @@ inline bool aligned16(const void *p, int stride)
 }
 
 // ---- kernel launchers (each enqueues on ctx->stream; device pointers only) ----
-struct BatchPtrs {            // either one image (p) or an array of n device pointers (pp)
-    const uint8_t *p = nullptr;
-    const uint8_t *const *pp = nullptr;
-};
-
 int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride,
                 int w, int h, const double *kernel, int radius, int flags, uint8_t *dst,
                 uint8_t *const *dsts, int dstride);
