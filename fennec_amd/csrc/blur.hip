@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256, 4) void blur_fused_kernel(FusedArgs a)
         fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < Q; j++) {
-            // alpha from the ORIGINAL image (effects.go:215), still in the staged tile
+            // alpha from the ORIGINAL image (effects.go:215), still in the staged tile: the source
+            // pixel seeds the pack chain, bytes 0..2 are overwritten, byte 3 (alpha) survives
             const uint32_t *ap = s_in + (q * Q + j + R) * IWP + 4 * g + R;
-            o[j].x = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, ap[0] & 0xff000000u)));
-            o[j].y = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, ap[1] & 0xff000000u)));
-            o[j].z = pk8(acc[j][4].x, 2, pk8(acc[j][3].y, 1, pk8(acc[j][3].x, 0, ap[2] & 0xff000000u)));
-            o[j].w = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, ap[3] & 0xff000000u)));
+            o[j].x = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, ap[0])));
+            o[j].y = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, ap[1])));
+            o[j].z = pk8(acc[j][4].x, 2, pk8(acc[j][3].y, 1, pk8(acc[j][3].x, 0, ap[2])));
+            o[j].w = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, ap[3])));
             asm volatile("" : "+v"(o[j].x), "+v"(o[j].y), "+v"(o[j].z), "+v"(o[j].w));
         }
         fp32_round_nearest();
