@@ -417,6 +417,13 @@ class Context:
         """n same-sized device images, one launch per stage (enqueued; call sync() to wait)."""
         if sigma <= 0:
             return list(imgs)
+        plan = self.plan_blur_batch(imgs, sigma, outs=outs, exact=exact)
+        plan.run()
+        return plan.outs
+
+    def plan_blur_batch(self, imgs, sigma: float, outs=None, exact: bool = False):
+        """Pre-marshal a batched blur (pointer tables, kernel) so that run() is one C call --
+        lets a caller bracket the launch tightly with events."""
         views = [_Img(t) for t in imgs]
         if any(v.space != FNX_DEVICE for v in views):
             raise FennecError("batched ops take device tensors")
@@ -429,12 +436,21 @@ class Context:
         dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
         radius, kernel = self.blurKernel(sigma)
         k, pk = _f64(kernel)
-        self._chk(self._lib.fnx_gaussian_blur_batch(self._h, n, srcs, st, w, h, pk, radius,
-                                                    FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, dsts,
-                                                    oviews[0].stride), "GaussianBlurBatch")
-        return outs
+        flags = FNX_BLUR_EXACT if exact else FNX_BLUR_FAST
+        ctx, lib, ost = self, self._lib, oviews[0].stride
 
-    def SSIMFastBatch(self, imgs_a, imgs_b, window=None) -> np.ndarray:
+        class _Plan:
+            def __init__(p):
+                p.outs = outs
+                p._keep = (imgs, outs, srcs, dsts, k)
+
+            def run(p):
+                ctx._chk(lib.fnx_gaussian_blur_batch(ctx._h, n, srcs, st, w, h, pk, radius, flags, dsts, ost),
+                         "GaussianBlurBatch")
+        return _Plan()
+
+    def plan_ssim_fast_batch(self, imgs_a, imgs_b, window=None):
+        """Pre-marshalled SSIMFastBatch: run() -> numpy array of n SSIM values (synchronises)."""
         va = [_Img(t) for t in imgs_a]
         vb = [_Img(t) for t in imgs_b]
         n = len(va)
@@ -444,9 +460,21 @@ class Context:
         bs_ = (C.c_void_p * n)(*[v.ptr for v in vb])
         k, pk = _f64(self.gaussianKernel() if window is None else window)
         out = np.empty(n, dtype=np.float64)
-        self._chk(self._lib.fnx_ssim_fast_batch(self._h, n, as_, va[0].stride, bs_, vb[0].stride, va[0].w,
-                                                va[0].h, pk, out.ctypes.data_as(_f64p)), "SSIMFastBatch")
-        return out
+        po = out.ctypes.data_as(_f64p)
+        ctx, lib = self, self._lib
+        sa, sb, w, h = va[0].stride, vb[0].stride, va[0].w, va[0].h
+
+        class _Plan:
+            def __init__(p):
+                p._keep = (imgs_a, imgs_b, as_, bs_, k, out)
+
+            def run(p):
+                ctx._chk(lib.fnx_ssim_fast_batch(ctx._h, n, as_, sa, bs_, sb, w, h, pk, po), "SSIMFastBatch")
+                return out
+        return _Plan()
+
+    def SSIMFastBatch(self, imgs_a, imgs_b, window=None) -> np.ndarray:
+        return self.plan_ssim_fast_batch(imgs_a, imgs_b, window).run().copy()
 
 
 class _Prepared:
