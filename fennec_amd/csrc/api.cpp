@@ -118,16 +118,7 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
     FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0, "batch arguments");
     if (n == 0 || w <= 0 || h <= 0) return FNX_OK;
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
-    bool al = true;
-    for (int i = 0; i < n; i++) {
-        FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
-        al = al && !(reinterpret_cast<uintptr_t>(srcs[i]) & 15) && !(reinterpret_cast<uintptr_t>(dsts[i]) & 15);
-    }
-    if (!al) {   // unaligned images: the scalar-load path handles them one by one
-        for (int i = 0; i < n; i++)
-            FNX_TRY(launch_blur(ctx, 1, srcs[i], nullptr, sstride, w, h, kernel, radius, flags, dsts[i], nullptr, dstride));
-        return FNX_OK;
-    }
+    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
     const void *hosts[2] = {srcs, dsts};
     const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
     void *dp[2];

@@ -119,12 +119,13 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 //   * 128-lane workgroups, 64 x TH output tile (TH = 64-2R rounded down to a multiple of 4): an H item is 2 rows x 8 outputs (2 per lane), a V item is 2 columns x
 //     TH/4 output rows (1 per lane): each intermediate pixel is converted (Q+2R)/Q ~ 1.9 times
 //     instead of 4, all lanes busy in both passes.
-template <int R>
-__global__ __launch_bounds__(128) void blur_direct_kernel(FusedArgs a)
+template <int R, int NTH, int IH>
+__global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
 {
-    constexpr int TW = 64, IH = 64;
-    constexpr int TH = ((IH - 2 * R) / 4) * 4;      // output rows per tile
-    constexpr int Q = TH / 4;                       // output rows per V item (4 row groups)
+    constexpr int TW = 64;
+    constexpr int RG = NTH / 32;                    // row groups of the V pass (32 column pairs each)
+    constexpr int TH = ((IH - 2 * R) / RG) * RG;    // output rows per tile
+    constexpr int Q = TH / RG;                      // output rows per V item
     constexpr int SR = TH + 2 * R;                  // staged (H-filtered) rows actually needed
     constexpr int NT = 2 * R + 1;
     constexpr int HO = 8;
@@ -132,9 +133,9 @@ __global__ __launch_bounds__(128) void blur_direct_kernel(FusedArgs a)
     constexpr int NV = (NPX + 3) / 4;
     constexpr int HGROUPS = TW / HO;                // 8
     constexpr int HITEMS = ((SR + 1) / 2) * HGROUPS;
-    static_assert(Q * 4 == TH && SR <= IH, "tile shape");
+    static_assert(Q * RG == TH && SR <= IH && SR % 2 == 0, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) uint32_t s_tmp[IH * TW];   // H pass: R,G,B rounded + source alpha
+    __shared__ __attribute__((aligned(16))) uint32_t s_tmp[SR * TW];   // H pass: R,G,B rounded + source alpha
 
     const int tile = xcd_tile(blockIdx.x, a.tiles);
     if (tile < 0) return;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(128) void blur_direct_kernel(FusedArgs a)
     const bool interior = x0 - R >= 0 && x0 + TW + R + 3 < a.w && y0 - R >= 0 && y0 + TH + R <= a.h;
 
     // ---- horizontal pass (effects.go:169-191): item = 2 rows x 8 outputs, window from global ----
-    for (int item = tid; item < HITEMS; item += 128) {
+    for (int item = tid; item < HITEMS; item += NTH) {
         const int rp = item / HGROUPS, g = item - rp * HGROUPS;
         const int xs = x0 + HO * g - R;                          // first px of the window
         u32x4 t0[NV], t1[NV];
@@ -279,16 +280,24 @@ __global__ __launch_bounds__(128) void blur_direct_kernel(FusedArgs a)
     }
 }
 
-template <int R>
-static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa)
+template <int R, int NTH, int IH>
+static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
-    constexpr int TW = 64, TH = ((64 - 2 * R) / 4) * 4;
+    constexpr int TW = 64, RG = NTH / 32, TH = ((IH - 2 * R) / RG) * RG;
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
-    hipLaunchKernelGGL((blur_direct_kernel<R>), grid, dim3(128), 0, ctx->stream, fa);
+    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH>), grid, dim3(NTH), 0, ctx->stream, fa);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
+}
+
+// 128 lanes, 64 intermediate rows: measured best on MI355X (256 lanes x 124 rows trims the H-pass
+// row halo from 1.23x to 1.11x but runs 4 % slower: 2 spilled VGPRs and 8 waves in lockstep).
+template <int R>
+static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa)
+{
+    return launch_direct_cfg<R, 128, 64>(ctx, n, fa);
 }
 
 template <typename T>

@@ -54,12 +54,19 @@ __device__ __forceinline__ u32x4 ld16_stream(const uint8_t *p)
 
 // BT.601 luminance exactly as the reference writes it (ssim.go:216, effects.go:96):
 // (0.299*R + 0.587*G) + 0.114*B in fp64, no contraction (TU built with -ffp-contract=off).
+__device__ __forceinline__ double u8_to_f64(uint32_t v);
 __device__ __forceinline__ double lum601(uint32_t p)
 {
-    double r = static_cast<double>(p & 0xffu);
-    double g = static_cast<double>((p >> 8) & 0xffu);
-    double b = static_cast<double>((p >> 16) & 0xffu);
+    double r = u8_to_f64(p & 0xffu);
+    double g = u8_to_f64((p >> 8) & 0xffu);
+    double b = u8_to_f64((p >> 16) & 0xffu);
     return 0.299 * r + 0.587 * g + 0.114 * b;
+}
+
+// u8 (any v < 2^32) -> f64 without v_cvt_f64_u32: 2^52 + v is exact, so (2^52 | v) - 2^52 == v
+__device__ __forceinline__ double u8_to_f64(uint32_t v)
+{
+    return __hiloint2double(0x43300000, static_cast<int>(v)) - 4503599627370496.0;
 }
 
 // XCD-aware work-item remap: consecutive workgroup ids land on different XCDs

@@ -2,6 +2,7 @@
 // mirrored in C++ above the fnx_* kernel layer -- guards, control flow and weight-table
 // generation, i.e. everything the Go side of a cgo shim keeps.  No pixel arithmetic happens
 // here: every image operation is a fnx_* call (HIP kernels); there is no CPU path.
+#include <array>
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -50,16 +51,15 @@ std::shared_ptr<const Taps> make_taps(int dstSize, int srcSize)
     return t;
 }
 
-// The 8x8 window never changes (windowSize 8, sigma 1.5: ssim.go:74-77).
+// The 8x8 window never changes (windowSize 8, sigma 1.5: ssim.go:74-77); built once, thread-safely.
 const double *ssim_window()
 {
-    static double k[64];
-    static bool init = false;
-    if (!init) {
-        fennec_gaussianKernel(8, 1.5, k);
-        init = true;
-    }
-    return k;
+    static const std::array<double, 64> k = [] {
+        std::array<double, 64> t{};
+        fennec_gaussianKernel(8, 1.5, t.data());
+        return t;
+    }();
+    return k.data();
 }
 
 // b resized to a's dims on the device when dims differ (ssim.go:31-33, 320-322).

@@ -18,12 +18,6 @@ struct ResizeArgs {
     const double *wt;
 };
 
-// u8 -> f64 without v_cvt_f64_u32: 2^52 + v is exact for v < 2^32, so (2^52 | v) - 2^52 == v
-__device__ __forceinline__ double u8_to_f64(uint32_t v)
-{
-    return __hiloint2double(0x43300000, static_cast<int>(v)) - 4503599627370496.0;
-}
-
 // one tap: aw = sa*w; r += R*aw; g += G*aw; b += B*aw; a += aw   (resize.go:95-103)
 __device__ __forceinline__ void resize_tap(uint32_t p, double w, double &r, double &g, double &b, double &al)
 {

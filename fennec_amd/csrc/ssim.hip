@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
 // of 64 taps x 2 sweeps, and sigma = E[x^2] - mu^2.  Algebraically identical to the reference's
 // two-sweep form; in fp64 the results differ by ~1e-13 (inside the 1e-9 bar).  The host checks
 // that the caller's table really is rank-1 and otherwise uses windowed_ssim_kernel above.
-constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup: 2 per thread
+constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup: 2 per lane (256 lanes)
 
 struct WinSepArgs {
     const uint8_t *a;
@@ -305,42 +305,71 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
         s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
     }
     __syncthreads();
-    // horizontal 8-tap pass of the five moments
-    for (int i = tid; i < LH * WSS_TX; i += 256) {
-        const int r = i / WSS_TX, x = i - r * WSS_TX;
-        double ha = 0, hb = 0, haa = 0, hbb = 0, hab = 0;
+    // horizontal 8-tap pass of the five moments; item = (row, 2 adjacent outputs): the 9-value
+    // window is read once for both (the kernel is LDS-bandwidth bound, not fp64 bound)
+    for (int i = tid; i < LH * (WSS_TX / 2); i += 256) {
+        const int r = i / (WSS_TX / 2), x = 2 * (i - r * (WSS_TX / 2));
+        double va[9], vb[9];
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const double va = s_a[r * LW + x + t], vb = s_b[r * LW + x + t], c = a.col[t];
-            ha = fma(va, c, ha);
-            hb = fma(vb, c, hb);
-            haa = fma(va * va, c, haa);
-            hbb = fma(vb * vb, c, hbb);
-            hab = fma(va * vb, c, hab);
+        for (int t = 0; t < 9; t++) {
+            va[t] = s_a[r * LW + x + t];
+            vb[t] = s_b[r * LW + x + t];
         }
-        s_h[0][i] = ha; s_h[1][i] = hb; s_h[2][i] = haa; s_h[3][i] = hbb; s_h[4][i] = hab;
+        double h[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const double aa = va[t] * va[t], bb = vb[t] * vb[t], ab = va[t] * vb[t];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const int k = t - o;
+                if (k >= 0 && k < 8) {
+                    const double c = a.col[k];
+                    h[o][0] = fma(va[t], c, h[o][0]);
+                    h[o][1] = fma(vb[t], c, h[o][1]);
+                    h[o][2] = fma(aa, c, h[o][2]);
+                    h[o][3] = fma(bb, c, h[o][3]);
+                    h[o][4] = fma(ab, c, h[o][4]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            s_h[q][r * WSS_TX + x] = h[0][q];
+            s_h[q][r * WSS_TX + x + 1] = h[1][q];
+        }
     }
     __syncthreads();
-    // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); 2 windows per thread
+    // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); a lane owns 2 vertically
+    // adjacent windows and reads their 9 rows once
     double val = 0;
+    {
+        const int lx = tid & (WSS_TX - 1), ly = 2 * (tid / WSS_TX);
+        const int wx = wx0 + lx;
+        double m[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
 #pragma unroll
-    for (int rep = 0; rep < (WSS_TX * WSS_TY) / 256; rep++) {
-        const int wi = tid + rep * 256;
-        const int ly = wi / WSS_TX, lx = wi - ly * WSS_TX;
-        const int wx = wx0 + lx, wy = wy0 + ly;
-        if (wx < a.w - 8 && wy < a.h - 8) {
-            double m[5] = {0, 0, 0, 0, 0};
+        for (int j = 0; j < 9; j++) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const double rj = a.row[j];
-#pragma unroll
-                for (int q = 0; q < 5; q++) m[q] = fma(s_h[q][(ly + j) * WSS_TX + lx], rj, m[q]);
+            for (int q = 0; q < 5; q++) {
+                const double hv = s_h[q][(ly + j) * WSS_TX + lx];
+                if (j < 8) m[0][q] = fma(hv, a.row[j], m[0][q]);
+                if (j >= 1) m[1][q] = fma(hv, a.row[j - 1], m[1][q]);
             }
-            const double muA = m[0], muB = m[1];
-            const double sAA = m[2] - muA * muA, sBB = m[3] - muB * muB, sAB = m[4] - muA * muB;
-            const double num = (2 * muA * muB + 6.5025) * (2 * sAB + 58.5225);
-            const double den = (muA * muA + muB * muB + 6.5025) * (sAA + sBB + 58.5225);
-            val += num / den;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const int wy = wy0 + ly + o;
+            if (wx < a.w - 8 && wy < a.h - 8) {
+                const double muA = m[o][0], muB = m[o][1];
+                const double sAA = m[o][2] - muA * muA, sBB = m[o][3] - muB * muB, sAB = m[o][4] - muA * muB;
+                const double num = (2 * muA * muB + 6.5025) * (2 * sAB + 58.5225);
+                const double den = (muA * muA + muB * muB + 6.5025) * (sAA + sBB + 58.5225);
+                // den >= C1*C2 > 0 and far from the subnormal range: reciprocal + 2 Newton steps
+                // is accurate to ~1 ulp without the IEEE division's scale/fixup sequence
+                double rc = __builtin_amdgcn_rcp(den);
+                rc = fma(fma(-den, rc, 1.0), rc, rc);
+                rc = fma(fma(-den, rc, 1.0), rc, rc);
+                val += num * rc;
+            }
         }
     }
     const double t = block_sum_256(val, s_red);
