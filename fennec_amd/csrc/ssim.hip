@@ -19,6 +19,7 @@ struct BoxArgs {
     double xRatio, yRatio;
     int seg;      // output columns per workgroup (tiled kernel)
     int vec_in;
+    int packed_ok;  // rows*cols*255 of the largest box < 65536
 };
 
 // box edges exactly as ssim.go:255-278
@@ -35,8 +36,8 @@ __device__ __forceinline__ uint32_t box_finish(uint32_t r, uint32_t g, uint32_t 
 {
     // sums are exact integers; inv := 1.0/count; clampF(sum*inv)  (ssim.go:301-308)
     const double inv = 1.0 / static_cast<double>(count);
-    return clampF_dev(static_cast<double>(r) * inv) | (clampF_dev(static_cast<double>(g) * inv) << 8) |
-           (clampF_dev(static_cast<double>(b) * inv) << 16) | (clampF_dev(static_cast<double>(al) * inv) << 24);
+    return clampF_dev(u8_to_f64(r) * inv) | (clampF_dev(u8_to_f64(g) * inv) << 8) |
+           (clampF_dev(u8_to_f64(b) * inv) << 16) | (clampF_dev(u8_to_f64(al) * inv) << 24);
 }
 
 // Any ratio (also upscaling, where boxes overlap / repeat): one thread per output pixel.
@@ -78,6 +79,24 @@ __global__ __launch_bounds__(256) void box_generic_kernel(BoxArgs a)
 constexpr int BOX_CHUNKS = 256;          // 16-byte chunks (4 px) per workgroup row segment
 constexpr int BOX_MAXROWS = 257;         // 257*255 < 65536: packed 16-bit sums cannot overflow
 
+// N rows of one 4-px chunk: per pixel (R,B) = p & 0x00ff00ff and (G,A) = bytes 1,3 moved to the
+// 16-bit lanes by one v_perm_b32; the per-column sums stay packed 2 x 16 bit (<= 257 rows)
+template <int N>
+__device__ __forceinline__ void box_trip(const uint8_t *q, int sstride, uint32_t (&lo)[4], uint32_t (&hi)[4])
+{
+    u32x4 v[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) v[u] = ld16_stream(q + static_cast<size_t>(u) * sstride);
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            lo[e] += v[u][e] & 0x00ff00ffu;
+            hi[e] += __builtin_amdgcn_perm(0u, v[u][e], 0x0c030c01u);   // (G, 0, A, 0)
+        }
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
 {
@@ -103,23 +122,20 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
         // the surplus columns belong to no box
         const bool whole = x + 3 < a.srcW;
         if (VEC && whole) {
-            // 8 rows per trip: 8 independent 16-byte streaming loads in flight per lane (rows
-            // beyond the box are a workgroup-uniform skip and contribute zeros)
-            for (int sy = sy0; sy < sy1; sy += 8) {
-                u32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    v[u] = (u32x4){0, 0, 0, 0};
-                    if (sy + u < sy1) v[u] = ld16_stream(p + static_cast<size_t>(u) * a.sstride + 4 * static_cast<size_t>(x));
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    lo[0] += v[u].x & 0x00ff00ffu; hi[0] += (v[u].x >> 8) & 0x00ff00ffu;
-                    lo[1] += v[u].y & 0x00ff00ffu; hi[1] += (v[u].y >> 8) & 0x00ff00ffu;
-                    lo[2] += v[u].z & 0x00ff00ffu; hi[2] += (v[u].z >> 8) & 0x00ff00ffu;
-                    lo[3] += v[u].w & 0x00ff00ffu; hi[3] += (v[u].w >> 8) & 0x00ff00ffu;
-                }
-                p += static_cast<size_t>(8) * a.sstride;
+            // 8 rows per trip, all 16-byte streaming loads in flight before the first use; the
+            // last (short) trip is its own fully unrolled body -- no per-row predication
+            const uint8_t *q = p + 4 * static_cast<size_t>(x);
+            int left = sy1 - sy0;
+            for (; left >= 8; left -= 8, q += static_cast<size_t>(8) * a.sstride) box_trip<8>(q, a.sstride, lo, hi);
+            switch (left) {
+            case 7: box_trip<7>(q, a.sstride, lo, hi); break;
+            case 6: box_trip<6>(q, a.sstride, lo, hi); break;
+            case 5: box_trip<5>(q, a.sstride, lo, hi); break;
+            case 4: box_trip<4>(q, a.sstride, lo, hi); break;
+            case 3: box_trip<3>(q, a.sstride, lo, hi); break;
+            case 2: box_trip<2>(q, a.sstride, lo, hi); break;
+            case 1: box_trip<1>(q, a.sstride, lo, hi); break;
+            default: break;
             }
         } else {
             // unaligned image, or the one chunk that sticks out of the row: pixel by pixel, clamped
@@ -145,10 +161,19 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
         int sx0, sx1;
         box_edge(dx, a.xRatio, a.srcW, sx0, sx1);
         uint32_t r = 0, g = 0, b = 0, al = 0;
-        for (int sx = sx0; sx < sx1; sx++) {
-            const uint2 c = *reinterpret_cast<const uint2 *>(s_col + (sx - 4 * c0) * 2);
-            r += c.x & 0xffffu; b += c.x >> 16;
-            g += c.y & 0xffffu; al += c.y >> 16;
+        if (a.packed_ok) {     // whole box fits 16-bit lanes: add the columns packed, unpack once
+            uint32_t plo = 0, phi = 0;
+            for (int sx = sx0; sx < sx1; sx++) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(s_col + (sx - 4 * c0) * 2);
+                plo += c.x; phi += c.y;
+            }
+            r = plo & 0xffffu; b = plo >> 16; g = phi & 0xffffu; al = phi >> 16;
+        } else {
+            for (int sx = sx0; sx < sx1; sx++) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(s_col + (sx - 4 * c0) * 2);
+                r += c.x & 0xffffu; b += c.x >> 16;
+                g += c.y & 0xffffu; al += c.y >> 16;
+            }
         }
         const int count = (sy1 - sy0) * (sx1 - sx0);
         uint8_t *dimg = a.dst + a.dst_image_bytes * z;
@@ -170,6 +195,7 @@ int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
     a.vec_in = srcs ? ((sstride & 15) == 0) : aligned16(src, sstride);
     const bool tiled = srcW >= dstW && srcH >= dstH && a.yRatio + 1.0 < BOX_MAXROWS &&
                        a.xRatio + 1.0 < BOX_MAXROWS && a.xRatio * 2 + 8 < 4 * BOX_CHUNKS;
+    a.packed_ok = (static_cast<double>(static_cast<long>(a.yRatio) + 2) * static_cast<double>(static_cast<long>(a.xRatio) + 2) * 255.0) < 65536.0;
     if (tiled) {
         // seg output columns span < seg*xRatio + 1 source px, plus < 4 px of chunk alignment each side
         int seg = static_cast<int>((4 * BOX_CHUNKS - 8) / a.xRatio);

@@ -4,6 +4,7 @@
 // Variants are selected inside the library with FNX_* environment variables.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,6 +85,25 @@ int main(int argc, char **argv)
         time_it("gaussian_blur x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_gaussian_blur(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts[i], W * 4)); }, 2.0 * S);
         time_it("ssim_fast x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_ssim_fast(ctx, FNX_DEVICE, srcs[i], W * 4, dsts[i], W * 4, W, H, win, &out[i])); }, 2.0 * S);
         (void)k;
+    }
+    if (what == "host" || what == "all") {      // FNX_HOST entry points: pageable host buffers, PCIe both ways
+        std::vector<uint8_t> hdst(S);
+        double res = 0;
+        int nb = B < 4 ? B : 4;
+        auto time_host = [&](const char *name, auto &&fn, double bytes) {
+            fn();
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < nb; i++) fn();
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nb;
+            printf("%-28s host-space %.3f ms/img (%.0f MP/s, %.1f GB/s over PCIe+kernel)\n", name, ms, mp / (ms * 1e-3), bytes / (ms * 1e-3) / 1e9);
+        };
+        time_host("gaussian_blur FNX_HOST", [&] { FK(fnx_gaussian_blur(ctx, FNX_HOST, host.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, hdst.data(), W * 4)); }, 2.0 * S);
+        time_host("ssim_fast FNX_HOST", [&] { FK(fnx_ssim_fast(ctx, FNX_HOST, host.data(), W * 4, hdst.data(), W * 4, W, H, win, &res)); }, 2.0 * S);
+        fnx_prepared *pr = nullptr;
+        FK(fnx_ssim_fast_prepare(ctx, FNX_HOST, host.data(), W * 4, W, H, &pr));
+        time_host("ssim_fast_against FNX_HOST", [&] { FK(fnx_ssim_fast_against(ctx, pr, FNX_HOST, hdst.data(), W * 4, win, &res)); }, 1.0 * S);
+        fnx_prepared_free(ctx, pr);
+        printf("ssim=%.12f\n", res);
     }
     if (what == "cfg3" || what == "all") {      // BASELINE config 3 pieces (4K -> 1080p Lanczos, MSSSIM)
         void *small, *up;
