@@ -64,8 +64,7 @@ int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const
         void *t = nullptr;
         FNX_TRY(scratch(ctx, SLOT_TMP2, plane * 2 * n + 16, &t));
         uint8_t *da = static_cast<uint8_t *>(t), *db = da + plane * n;
-        FNX_TRY(launch_box_downsample(ctx, n, a, as, astride, w, h, da, nw * 4, plane, nw, nh));
-        FNX_TRY(launch_box_downsample(ctx, n, b, bs, bstride, w, h, db, nw * 4, plane, nw, nh));
+        FNX_TRY(launch_box_downsample_pair(ctx, n, a, as, astride, b, bs, bstride, w, h, da, nw * 4, plane, nw, nh));
         if (nw < 8 || nh < 8) {
             for (int i = 0; i < n; i++)
                 FNX_TRY(launch_pixel_ssim(ctx, da + plane * i, db + plane * i, nw, nh, plane, d_out + i));
@@ -427,9 +426,8 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         const uint8_t *ca = da.p, *cb = db.p;
         int cas = da.stride, cbs = db.stride, cw = w, ch = h;
         size_t lvl_bytes = static_cast<size_t>(w / 2) * (h / 2) * 4 + 16;
-        void *pa = nullptr, *pb = nullptr;
-        FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 2, &pa));   // level k at offset (k&1)*lvl_bytes
-        FNX_TRY(scratch(ctx, SLOT_TMP1, lvl_bytes * 2, &pb));
+        void *pyr = nullptr;   // level k lives at (k&1)*2*lvl_bytes: [a][b]
+        FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 4, &pyr));
         for (int i = 0; i < nweights; i++) {
             FNX_TRY(ssim_fast_device(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch, window,
                                      static_cast<const double *>(dwin), dres + i));
@@ -437,10 +435,10 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
             if (i < nweights - 1) {
                 const int nw = cw / 2, nh = ch / 2;
                 if (nw < 8 || nh < 8) break;              // ssim.go:354-358
-                uint8_t *na = static_cast<uint8_t *>(pa) + (i & 1) * lvl_bytes;
-                uint8_t *nb = static_cast<uint8_t *>(pb) + (i & 1) * lvl_bytes;
-                FNX_TRY(launch_box_downsample(ctx, 1, ca, nullptr, cas, cw, ch, na, nw * 4, 0, nw, nh));
-                FNX_TRY(launch_box_downsample(ctx, 1, cb, nullptr, cbs, cw, ch, nb, nw * 4, 0, nw, nh));
+                uint8_t *na = static_cast<uint8_t *>(pyr) + (i & 1) * 2 * lvl_bytes;
+                uint8_t *nb = na + lvl_bytes;
+                FNX_TRY(launch_box_downsample_pair(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch, na, nw * 4,
+                                                   lvl_bytes, nw, nh));
                 ca = na; cb = nb; cas = cbs = nw * 4; cw = nw; ch = nh;
             }
         }

@@ -150,6 +150,10 @@ int launch_resize_v(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int
 int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
                           int sstride, int srcW, int srcH, uint8_t *dst, int dstride,
                           size_t dst_image_bytes, int dstW, int dstH);
+int launch_box_downsample_pair(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
+                               int sstride, const uint8_t *src_b, const uint8_t *const *srcs_b, int sstride_b,
+                               int srcW, int srcH, uint8_t *dst, int dstride, size_t dst_image_bytes,
+                               int dstW, int dstH);
 // Windowed SSIM of n image pairs (tight or strided NRGBA, w x h >= 8): image i of a at
 // a + i*a_image_bytes (same for b); writes n doubles to d_out.
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,

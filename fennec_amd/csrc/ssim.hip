@@ -13,6 +13,9 @@ namespace fnx {
 struct BoxArgs {
     const uint8_t *src;
     const uint8_t *const *srcs;
+    const uint8_t *src_b;            // optional second image set: z in [n, 2n) reads these,
+    const uint8_t *const *srcs_b;    // dst image index stays z (layout [a0..an-1][b0..bn-1])
+    int sstride_b, nimg;
     uint8_t *dst;
     size_t dst_image_bytes;
     int sstride, srcW, srcH, dstride, dstW, dstH;
@@ -47,13 +50,16 @@ __global__ __launch_bounds__(256) void box_generic_kernel(BoxArgs a)
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= a.dstW || dy >= a.dstH) return;
     const int z = blockIdx.z;
-    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    const bool second = z >= a.nimg;
+    const int zi = second ? z - a.nimg : z;
+    const uint8_t *src = second ? (a.srcs_b ? a.srcs_b[zi] : a.src_b) : (a.srcs ? a.srcs[zi] : a.src);
+    const int sstride = second ? a.sstride_b : a.sstride;
     int sx0, sx1, sy0, sy1;
     box_edge(dx, a.xRatio, a.srcW, sx0, sx1);
     box_edge(dy, a.yRatio, a.srcH, sy0, sy1);
     unsigned long long r = 0, g = 0, b = 0, al = 0;
     for (int sy = sy0; sy < sy1; sy++) {
-        const uint8_t *row = src + static_cast<size_t>(sy) * a.sstride;
+        const uint8_t *row = src + static_cast<size_t>(sy) * sstride;
         for (int sx = sx0; sx < sx1; sx++) {
             const uint32_t p = ld_px(row, sx);
             r += p & 0xffu; g += (p >> 8) & 0xffu; b += (p >> 16) & 0xffu; al += p >> 24;
@@ -102,7 +108,10 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
     const int z = blockIdx.z;
-    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    const bool second = z >= a.nimg;
+    const int zi = second ? z - a.nimg : z;
+    const uint8_t *src = second ? (a.srcs_b ? a.srcs_b[zi] : a.src_b) : (a.srcs ? a.srcs[zi] : a.src);
+    const int sstride = second ? a.sstride_b : a.sstride;
     const int dy = blockIdx.y;
     const int dx_lo = blockIdx.x * a.seg;
     const int dx_hi = min(dx_lo + a.seg, a.dstW);
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
     if (tid < nchunk) {
         const int x = 4 * (c0 + tid);
         uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
-        const uint8_t *p = src + static_cast<size_t>(sy0) * a.sstride;
+        const uint8_t *p = src + static_cast<size_t>(sy0) * sstride;
         // a chunk that sticks out of the row (srcW % 4 != 0) is read pixel by pixel, clamped;
         // the surplus columns belong to no box
         const bool whole = x + 3 < a.srcW;
@@ -126,15 +135,15 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
             // last (short) trip is its own fully unrolled body -- no per-row predication
             const uint8_t *q = p + 4 * static_cast<size_t>(x);
             int left = sy1 - sy0;
-            for (; left >= 8; left -= 8, q += static_cast<size_t>(8) * a.sstride) box_trip<8>(q, a.sstride, lo, hi);
+            for (; left >= 8; left -= 8, q += static_cast<size_t>(8) * sstride) box_trip<8>(q, sstride, lo, hi);
             switch (left) {
-            case 7: box_trip<7>(q, a.sstride, lo, hi); break;
-            case 6: box_trip<6>(q, a.sstride, lo, hi); break;
-            case 5: box_trip<5>(q, a.sstride, lo, hi); break;
-            case 4: box_trip<4>(q, a.sstride, lo, hi); break;
-            case 3: box_trip<3>(q, a.sstride, lo, hi); break;
-            case 2: box_trip<2>(q, a.sstride, lo, hi); break;
-            case 1: box_trip<1>(q, a.sstride, lo, hi); break;
+            case 7: box_trip<7>(q, sstride, lo, hi); break;
+            case 6: box_trip<6>(q, sstride, lo, hi); break;
+            case 5: box_trip<5>(q, sstride, lo, hi); break;
+            case 4: box_trip<4>(q, sstride, lo, hi); break;
+            case 3: box_trip<3>(q, sstride, lo, hi); break;
+            case 2: box_trip<2>(q, sstride, lo, hi); break;
+            case 1: box_trip<1>(q, sstride, lo, hi); break;
             default: break;
             }
         } else {
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
                     const uint32_t q = ld_px(p, min(x + e, a.srcW - 1));
                     lo[e] += q & 0x00ff00ffu; hi[e] += (q >> 8) & 0x00ff00ffu;
                 }
-                p += a.sstride;
+                p += sstride;
             }
         }
         // s_col[px] = {lo, hi}: two 16-byte stores per lane
@@ -186,13 +195,28 @@ int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
                           int sstride, int srcW, int srcH, uint8_t *dst, int dstride,
                           size_t dst_image_bytes, int dstW, int dstH)
 {
+    return launch_box_downsample_pair(ctx, n, src, srcs, sstride, nullptr, nullptr, 0, srcW, srcH, dst, dstride,
+                                      dst_image_bytes, dstW, dstH);
+}
+
+// Both sides of an SSIM comparison in ONE launch: images a (z < n) and b (z >= n), same geometry;
+// dst image z lives at dst + z*dst_image_bytes.  b == bs == nullptr: a only.
+int launch_box_downsample_pair(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
+                               int sstride, const uint8_t *src_b, const uint8_t *const *srcs_b, int sstride_b,
+                               int srcW, int srcH, uint8_t *dst, int dstride, size_t dst_image_bytes,
+                               int dstW, int dstH)
+{
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0 || n <= 0) return FNX_OK;
+    const bool pair = src_b || srcs_b;
     BoxArgs a{};
     a.src = src; a.srcs = srcs; a.dst = dst; a.dst_image_bytes = dst_image_bytes;
+    a.src_b = src_b; a.srcs_b = srcs_b; a.sstride_b = sstride_b; a.nimg = n;
     a.sstride = sstride; a.srcW = srcW; a.srcH = srcH; a.dstride = dstride; a.dstW = dstW; a.dstH = dstH;
     a.xRatio = static_cast<double>(srcW) / static_cast<double>(dstW);   // ssim.go:251-252
     a.yRatio = static_cast<double>(srcH) / static_cast<double>(dstH);
     a.vec_in = srcs ? ((sstride & 15) == 0) : aligned16(src, sstride);
+    if (pair) a.vec_in = a.vec_in && (srcs_b ? ((sstride_b & 15) == 0) : aligned16(src_b, sstride_b));
+    const int nz = pair ? 2 * n : n;
     const bool tiled = srcW >= dstW && srcH >= dstH && a.yRatio + 1.0 < BOX_MAXROWS &&
                        a.xRatio + 1.0 < BOX_MAXROWS && a.xRatio * 2 + 8 < 4 * BOX_CHUNKS;
     a.packed_ok = (static_cast<double>(static_cast<long>(a.yRatio) + 2) * static_cast<double>(static_cast<long>(a.xRatio) + 2) * 255.0) < 65536.0;
@@ -202,11 +226,11 @@ int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
         if (seg > 256) seg = 256;
         if (seg < 1) seg = 1;
         a.seg = seg;
-        dim3 grid((dstW + seg - 1) / seg, dstH, n);
+        dim3 grid((dstW + seg - 1) / seg, dstH, nz);
         if (a.vec_in) hipLaunchKernelGGL(box_tiled_kernel<true>, grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(box_tiled_kernel<false>, grid, dim3(256), 0, ctx->stream, a);
     } else {
-        dim3 grid((dstW + 63) / 64, (dstH + 3) / 4, n);
+        dim3 grid((dstW + 63) / 64, (dstH + 3) / 4, nz);
         hipLaunchKernelGGL(box_generic_kernel, grid, dim3(256), 0, ctx->stream, a);
     }
     FNX_HIP(hipGetLastError());
