@@ -113,6 +113,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_orient", i, [ctx, i] + img + [i, i, i] + img)
         _sig(L, "fnx_gaussian_blur_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i])
         _sig(L, "fnx_ssim_fast_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p, _f64p])
+        _sig(L, "fnx_ssim_fast_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
+        _sig(L, "fnx_results_fetch", i, [ctx, i, _f64p])
         _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
         _sig(L, "fennec_blurKernel", i, [d, _f64p])
         _sig(L, "fennec_lanczosKernel", d, [d])
@@ -470,6 +472,14 @@ class Context:
 
             def run(p):
                 ctx._chk(lib.fnx_ssim_fast_batch(ctx._h, n, as_, sa, bs_, sb, w, h, pk, po), "SSIMFastBatch")
+                return out
+
+            def enqueue(p):
+                """Queue the kernels only; results stay on the device until fetch()."""
+                ctx._chk(lib.fnx_ssim_fast_batch_enqueue(ctx._h, n, as_, sa, bs_, sb, w, h, pk), "SSIMFastBatch")
+
+            def fetch(p):
+                ctx._chk(lib.fnx_results_fetch(ctx._h, n, po), "fnx_results_fetch")
                 return out
         return _Plan()
 

@@ -317,8 +317,28 @@ int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astri
                         const uint8_t *const *bs, int bstride, int w, int h,
                         const double *window, double *out)
 {
+    FNX_REQUIRE(out != nullptr, "out is null");
+    FNX_TRY(fnx_ssim_fast_batch_enqueue(ctx, n, as, astride, bs, bstride, w, h, window));
+    return fnx_results_fetch(ctx, n, out);
+}
+
+int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
+{
     FNX_TRY(bind(ctx));
-    FNX_REQUIRE(n >= 0 && as && bs && window && out, "batch arguments");
+    FNX_REQUIRE(n >= 0 && out, "fetch arguments");
+    if (n == 0) return FNX_OK;
+    FNX_REQUIRE(ctx->res_pinned && ctx->res_event && n <= ctx->res_n, "no enqueued results of that size on this ctx");
+    FNX_HIP(hipEventSynchronize(ctx->res_event));
+    std::memcpy(out, ctx->res_pinned, sizeof(double) * size_t(n));
+    return FNX_OK;
+}
+
+int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
+                                const uint8_t *const *bs, int bstride, int w, int h,
+                                const double *window)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(n >= 0 && as && bs && window, "batch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0 && astride >= 4 * w && bstride >= 4 * w, "dims");
     void *dwin = nullptr;
@@ -344,7 +364,16 @@ int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astri
             FNX_TRY(ssim_fast_device(ctx, 1, as[i], nullptr, astride, bs[i], nullptr, bstride, w, h, window,
                                      static_cast<const double *>(dwin), dres + i));
     }
-    return fetch_doubles(ctx, dres, out, n);
+    // results -> pinned host memory right behind the kernels + an event: fnx_results_fetch then
+    // never waits for work that was queued on this stream after the batch
+    void *pin = nullptr;
+    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n), &pin));
+    FNX_HIP(hipMemcpyAsync(pin, dres, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
+    FNX_HIP(hipEventRecord(ctx->res_event, ctx->stream));
+    ctx->res_pinned = static_cast<const double *>(pin);
+    ctx->res_n = n;
+    return FNX_OK;
 }
 
 int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,

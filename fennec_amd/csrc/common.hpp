@@ -76,6 +76,11 @@ struct fnx_ctx {
     unsigned char *pinned = nullptr;
     size_t pinned_cap = 0, pinned_off = 0;
     int num_cus = 256;
+    // results of the last *_enqueue call: copied to pinned memory right behind the kernels, so a
+    // later fetch waits for THIS event only, not for work queued on the stream afterwards
+    hipEvent_t res_event = nullptr;
+    const double *res_pinned = nullptr;
+    int res_n = 0;
 };
 
 struct fnx_prepared {

@@ -235,6 +235,7 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
         for (auto &s : ctx->slot)
             if (s.p) (void)hipFree(s.p);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        if (ctx->res_event) (void)hipEventDestroy(ctx->res_event);
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;

@@ -171,6 +171,14 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
 int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
                         const uint8_t *const *bs, int bstride, int w, int h,
                         const double *window, double *out /* n, host */);
+/* The same split in two so that several contexts (= streams) can be kept busy by one host
+ * thread: _enqueue only queues the kernels, the n results stay on the device until
+ * fnx_results_fetch (which synchronises the ctx).  Fetch before enqueuing the next batch on the
+ * SAME ctx. */
+int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
+                                const uint8_t *const *bs, int bstride, int w, int h,
+                                const double *window);
+int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
 
 /* ======================================================================= */
 /* fennec_* : the reference's function set (names and argument meaning as in

@@ -359,3 +359,44 @@ def test_jpeg_quality_search_on_gpu(ctx, orc):
     prep.close()
     assert (q1, n1) == (q2, n2) and d1 == d2 and abs(s1 - s2) <= SSIM_TOL
     assert 30 <= q1 <= 100 and s1 >= 0.94
+
+
+# ------------------------------------------------------------------ randomized shapes
+def test_fuzz_random_shapes(ctx, orc):
+    """Seeded random geometry sweep: every op against the oracle on odd sizes, thin images,
+    sizes around the tile edges (64, 52, 128 ...) and random parameters."""
+    rng = np.random.default_rng(20260928)
+    special = [1, 2, 3, 7, 8, 9, 31, 51, 52, 53, 63, 64, 65, 103, 104, 105, 127, 128, 129, 191, 257]
+    for it in range(36):
+        w = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(1, 300))
+        h = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(1, 300))
+        img = synth.noise_image(w, h, 1000 + it, alpha=True)
+        sigma = float(rng.choice([0.3, 0.7, 1.0, 1.4, 2.0, 2.5, 3.1]))
+        want = orc.gaussian_blur(img, sigma)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want), (w, h, sigma)
+        assert_blur_close(ctx.GaussianBlur(img, sigma), want)
+        s = float(rng.uniform(0.05, 1.0))
+        assert np.array_equal(ctx.Sharpen(img, s), orc.sharpen(img, s)), (w, h, s)
+        assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), (w, h, s)
+        dw, dh = int(rng.integers(1, 2 * w + 2)), int(rng.integers(1, 2 * h + 2))
+        assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh)), (w, h, dw, dh)
+        assert np.array_equal(ctx.boxDownsample(img, dw, dh), orc.box_downsample(img, dw, dh)), (w, h, dw, dh)
+        o = int(rng.integers(2, 9))
+        assert np.array_equal(ctx.ApplyOrientation(img, o), orc.apply_orientation(img, o)), (w, h, o)
+        other = synth.noise_image(w, h, 5000 + it, alpha=True)
+        assert abs(ctx.SSIM(img, other) - orc.ssim(img, other)) <= SSIM_TOL, (w, h)
+        assert abs(ctx.SSIMFast(img, want) - orc.ssim_fast(img, want)) <= SSIM_TOL, (w, h)
+        assert abs(ctx.MSSSIM(img, want) - orc.msssim(img, want)) <= SSIM_TOL, (w, h)
+
+
+def test_fuzz_large_downsample_shapes(ctx, orc):
+    """SSIMFast's >512 path (tiled box kernel) on awkward sizes and strides."""
+    rng = np.random.default_rng(7)
+    for (w, h) in [(513, 9), (9, 513), (1000, 1000), (1023, 517), (2047, 64), (777, 1555), (4001, 13)]:
+        a = synth.noise_image(w, h, w * 7 + h, alpha=True)
+        b = synth.noise_image(w, h, w * 11 + h, alpha=True)
+        assert abs(ctx.SSIMFast(a, b) - orc.ssim_fast(a, b)) <= SSIM_TOL, (w, h)
+        _, nw, nh = orc.ssim_fast_dims(w, h)
+        assert np.array_equal(ctx.boxDownsample(a, nw, nh), orc.box_downsample(a, nw, nh)), (w, h)
+        assert np.array_equal(ctx.boxDownsample(a, max(w // 300, 1), max(h // 300, 1)),
+                              orc.box_downsample(a, max(w // 300, 1), max(h // 300, 1))), (w, h)   # boxes > 257 rows

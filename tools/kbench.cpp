@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,44 @@ int main(int argc, char **argv)
         time_it("gaussian_blur x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_gaussian_blur(ctx, FNX_DEVICE, srcs[i], W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts[i], W * 4)); }, 2.0 * S);
         time_it("ssim_fast x B (per call)", [&] { for (int i = 0; i < B; i++) FK(fnx_ssim_fast(ctx, FNX_DEVICE, srcs[i], W * 4, dsts[i], W * 4, W, H, win, &out[i])); }, 2.0 * S);
         (void)k;
+    }
+    if (what == "overlap") {    // two contexts, half a batch each, staggered: blur (VALU bound) of one
+                                // overlaps SSIMFast (load bound) of the other
+        fnx_ctx *c2;
+        FK(fnx_ctx_create(0, &c2));
+        int hB = B / 2;
+        std::vector<double> o2(B);
+        auto seq = [&] {
+            FK(fnx_gaussian_blur_batch(ctx, B, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4));
+            FK(fnx_ssim_fast_batch(ctx, B, srcs.data(), W * 4, dsts.data(), W * 4, W, H, win, out.data()));
+        };
+        auto ovl = [&] {
+            // ctx: half A, c2: half B
+            FK(fnx_gaussian_blur_batch(ctx, hB, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4));
+            FK(fnx_ssim_fast_batch_enqueue(ctx, hB, srcs.data(), W * 4, dsts.data(), W * 4, W, H, win));
+            FK(fnx_gaussian_blur_batch(c2, hB, srcs.data() + hB, W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data() + hB, W * 4));
+            FK(fnx_ssim_fast_batch_enqueue(c2, hB, srcs.data() + hB, W * 4, dsts.data() + hB, W * 4, W, H, win));
+            FK(fnx_results_fetch(ctx, hB, o2.data()));
+            FK(fnx_results_fetch(c2, hB, o2.data() + hB));
+        };
+        auto stag = [&] {   // complementary phases: ctx blurs then scores, c2 scores (last iteration's blur) then blurs
+            FK(fnx_gaussian_blur_batch(ctx, hB, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4));
+            FK(fnx_ssim_fast_batch_enqueue(c2, hB, srcs.data() + hB, W * 4, dsts.data() + hB, W * 4, W, H, win));
+            FK(fnx_ssim_fast_batch_enqueue(ctx, hB, srcs.data(), W * 4, dsts.data(), W * 4, W, H, win));
+            FK(fnx_gaussian_blur_batch(c2, hB, srcs.data() + hB, W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data() + hB, W * 4));
+            FK(fnx_results_fetch(ctx, hB, o2.data()));
+            FK(fnx_results_fetch(c2, hB, o2.data() + hB));
+        };
+        for (const char *nm : {"sequential 1 ctx", "2 ctx half batches", "x staggered 2 ctx"}) {
+            auto &fn = (nm[0] == 's') ? (std::function<void()> &)*new std::function<void()>(seq) : (nm[0] == 'x') ? (std::function<void()> &)*new std::function<void()>(stag) : (std::function<void()> &)*new std::function<void()>(ovl);
+            for (int i = 0; i < 3; i++) fn();
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < iters; i++) fn();
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+            printf("%-24s %.3f ms per %d images (%.2f us/img, %.0f MP/s)\n", nm, ms, B, ms * 1e3 / B, mp * B / (ms * 1e-3));
+        }
+        for (int i = 0; i < B; i++) if (out[i] != o2[i]) { printf("MISMATCH %d\n", i); break; }
+        fnx_ctx_destroy(c2);
     }
     if (what == "host" || what == "all") {      // FNX_HOST entry points: pageable host buffers, PCIe both ways
         std::vector<uint8_t> hdst(S);
