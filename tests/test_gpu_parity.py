@@ -400,3 +400,28 @@ def test_fuzz_large_downsample_shapes(ctx, orc):
         assert np.array_equal(ctx.boxDownsample(a, nw, nh), orc.box_downsample(a, nw, nh)), (w, h)
         assert np.array_equal(ctx.boxDownsample(a, max(w // 300, 1), max(h // 300, 1)),
                               orc.box_downsample(a, max(w // 300, 1), max(h // 300, 1))), (w, h)   # boxes > 257 rows
+
+
+def test_async_batch_enqueue_fetch_two_contexts(orc):
+    """fnx_ssim_fast_batch_enqueue / fnx_results_fetch: two contexts driven by one host thread,
+    work queued on a stream AFTER the batch must not delay or corrupt the fetched results."""
+    import torch
+    c0, c1 = fennec_amd.Context(0), fennec_amd.Context(0)
+    imgs = [synth.large_photo(1024, 768, k) for k in range(6)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    o = [torch.empty_like(t) for t in d]
+    torch.cuda.synchronize()
+    pb0 = c0.plan_blur_batch(d[:3], 2.0, outs=o[:3]); pb1 = c1.plan_blur_batch(d[3:], 2.0, outs=o[3:])
+    ps0 = c0.plan_ssim_fast_batch(d[:3], o[:3]); ps1 = c1.plan_ssim_fast_batch(d[3:], o[3:])
+    pb0.run(); pb1.run()
+    for rep in range(3):
+        ps0.enqueue(); ps1.enqueue()
+        pb0.run(); pb1.run()                      # queued behind the scoring, overwrites the same outputs with the same values
+        got = np.concatenate([ps0.fetch().copy(), ps1.fetch().copy()])
+        c0.sync(); c1.sync()
+        for k in range(6):
+            want_blur = c0.GaussianBlur(imgs[k], 2.0)
+            assert np.array_equal(o[k].cpu().numpy(), want_blur)
+            assert abs(got[k] - orc.ssim_fast(imgs[k], want_blur)) <= SSIM_TOL
+    with pytest.raises(fennec_amd.FennecError):
+        fennec_amd.Context(0).plan_ssim_fast_batch(d[:1], o[:1]).fetch()     # nothing enqueued on that ctx
