@@ -292,11 +292,20 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     return FNX_OK;
 }
 
-// 128 lanes, 64 intermediate rows: measured best on MI355X (256 lanes x 124 rows trims the H-pass
-// row halo from 1.23x to 1.11x but runs 4 % slower: 2 spilled VGPRs and 8 waves in lockstep).
+// Two tile shapes (measured on MI355X, 4K: 23.6 vs 22.9 us; 1080p: 5.6 vs 6.0 us per image):
+//   128 lanes x 64 intermediate rows  (TH = 52 at R=6, H-pass row halo 1.23x)
+//   256 lanes x (2*TH+2R) rows         (TH = 104,      halo 1.12x) -- wins when the image height
+//     does not leave a mostly empty last tile row and there are enough tiles to fill the chip.
+// Cost model: H work ~ staged rows, V work ~ output rows (about 55 : 45 of the instructions).
 template <int R>
 static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
+    constexpr int TH0 = ((64 - 2 * R) / 4) * 4, TH1 = 2 * TH0;
+    const long ty0 = (fa.h + TH0 - 1) / TH0, ty1 = (fa.h + TH1 - 1) / TH1;
+    const double cost0 = ty0 * (0.55 * (TH0 + 2 * R) + 0.45 * TH0);
+    const double cost1 = ty1 * (0.55 * (TH1 + 2 * R) + 0.45 * TH1);
+    const long tiles1 = ty1 * ((fa.w + 63) / 64) * n;
+    if (cost1 < 0.95 * cost0 && tiles1 >= 4L * ctx->num_cus) return launch_direct_cfg<R, 256, TH1 + 2 * R>(ctx, n, fa);
     return launch_direct_cfg<R, 128, 64>(ctx, n, fa);
 }
 
