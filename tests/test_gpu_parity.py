@@ -425,3 +425,24 @@ def test_async_batch_enqueue_fetch_two_contexts(orc):
             assert abs(got[k] - orc.ssim_fast(imgs[k], want_blur)) <= SSIM_TOL
     with pytest.raises(fennec_amd.FennecError):
         fennec_amd.Context(0).plan_ssim_fast_batch(d[:1], o[:1]).fetch()     # nothing enqueued on that ctx
+
+
+def test_device_views_at_4_byte_alignment(ctx, orc):
+    """Device sub-views whose rows start only 4-byte aligned (odd x offset, odd width): the blur's
+    16-byte window loads and the box kernel's vector path must both cope."""
+    import torch
+    big = synth.noise_image(1301, 700, 99, alpha=True)
+    d = torch.from_numpy(big).cuda()
+    torch.cuda.synchronize()
+    for (y0, y1, x0, x1) in [(0, 700, 1, 1300), (3, 650, 5, 1234), (10, 80, 7, 72)]:
+        sub_h = np.ascontiguousarray(big[y0:y1, x0:x1])
+        sub_d = d[y0:y1, x0:x1]
+        out = ctx.GaussianBlur(sub_d, 2.0); ctx.sync()
+        assert_blur_close(out.cpu().numpy(), orc.gaussian_blur(sub_h, 2.0, procs=8))
+        out = ctx.AdaptiveSharpen(sub_d, 0.7); ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), orc.adaptive_sharpen(sub_h, 0.7, procs=8))
+        assert abs(ctx.SSIMFast(sub_d, sub_d.flip(1).contiguous()) - orc.ssim_fast(sub_h, np.ascontiguousarray(sub_h[:, ::-1]))) <= SSIM_TOL
+        sm = ctx.boxDownsample(sub_d, max((x1 - x0) // 3, 1), max((y1 - y0) // 3, 1)); ctx.sync()
+        assert np.array_equal(sm.cpu().numpy(), orc.box_downsample(sub_h, max((x1 - x0) // 3, 1), max((y1 - y0) // 3, 1)))
+        rs = ctx.lanczosResize(sub_d, 200, 100); ctx.sync()
+        assert np.array_equal(rs.cpu().numpy(), orc.lanczos_resize(sub_h, 200, 100, procs=8))
