@@ -125,6 +125,32 @@ int main(int argc, char **argv)
         for (int i = 0; i < B; i++) if (out[i] != o2[i]) { printf("MISMATCH %d\n", i); break; }
         fnx_ctx_destroy(c2);
     }
+    if (what == "overlap2") {   // fine-grained: stream A blurs chunk k+1 while stream B scores chunk k
+        fnx_ctx *c2;
+        FK(fnx_ctx_create(0, &c2));
+        hipStream_t s2 = (hipStream_t)fnx_ctx_stream(c2);
+        for (int chunk : {2, 4, 8, 16}) {
+            int nch = B / chunk;
+            std::vector<hipEvent_t> evs(nch);
+            for (size_t ei = 0; ei < evs.size(); ei++) CK(hipEventCreateWithFlags(&evs[ei], hipEventDisableTiming));
+            auto run = [&] {
+                for (int c = 0; c < nch; c++) {
+                    FK(fnx_gaussian_blur_batch(ctx, chunk, srcs.data() + c * chunk, W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data() + c * chunk, W * 4));
+                    CK(hipEventRecord(evs[c], st));
+                    CK(hipStreamWaitEvent(s2, evs[c], 0));
+                    FK(fnx_ssim_fast_batch_enqueue(c2, chunk, srcs.data() + c * chunk, W * 4, dsts.data() + c * chunk, W * 4, W, H, win));
+                }
+                FK(fnx_ctx_sync(ctx));
+                FK(fnx_ctx_sync(c2));
+            };
+            for (int i = 0; i < 3; i++) run();
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < iters; i++) run();
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+            printf("chunk %2d: %.3f ms per %d images (%.2f us/img, %.0f MP/s)\n", chunk, ms, B, ms * 1e3 / B, mp * B / (ms * 1e-3));
+        }
+        fnx_ctx_destroy(c2);
+    }
     if (what == "host" || what == "all") {      // FNX_HOST entry points: pageable host buffers, PCIe both ways
         std::vector<uint8_t> hdst(S);
         double res = 0;
