@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
 // sigma_ab) are two 8-tap passes instead of 64 taps x 2 sweeps, and sigma = E[x^2] - mu^2.  Algebraically identical to the reference's
 // two-sweep form; in fp64 the results differ by ~1e-13 (inside the 1e-9 bar).  The host checks
 // that the caller's table really is rank-1 and otherwise uses windowed_ssim_kernel above.
-constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup: 2 per lane (256 lanes)
+constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup (256 lanes, 2 per lane)
 
 struct WinSepArgs {
     const uint8_t *a;
@@ -335,16 +335,23 @@ struct WinSepArgs {
     double col[8], row[8];   // k[j][i] ~= row[j] * col[i]
 };
 
+// TY = 16 rows of windows per workgroup (a 32-row tile trims the halos from 1.75x / 1.44x to 1.49x /
+// 1.22x but needs 70 KB of LDS: 2 workgroups per CU, measured 7 % slower at 8K).  The kernel is fp64-issue bound (fp64 runs at
+// half rate), so everything is cut for fp64 instructions per window: four moments, 2 horizontally
+// adjacent H outputs and TY/8 vertically adjacent windows per lane.  (A 3 x 256 LDS table of the
+// luminance products saved 6 fp64 ops per pixel and cost 20 %: dependent, bank-conflicting reads.)
+template <int TY>
 __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
 {
-    constexpr int LW = WSS_TX + 7, LH = WSS_TY + 7;
+    constexpr int LW = WSS_TX + 7, LH = TY + 7;
+    constexpr int WPT = WSS_TX * TY / 256;       // vertically adjacent windows per lane
     __shared__ double s_a[LH * LW], s_b[LH * LW];
     __shared__ double s_h[4][LH * WSS_TX];   // E[a], E[b], E[a^2 + b^2], E[ab] after the H pass
     __shared__ double s_red[4];
     const int z = blockIdx.y;
     const int tile = blockIdx.x;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int wx0 = tx * WSS_TX, wy0 = ty * WSS_TY;
+    const int wx0 = tx * WSS_TX, wy0 = ty * TY;
     const uint8_t *A = a.a + a.a_image_bytes * z;
     const uint8_t *B = a.b + a.b_image_bytes * z;
     const int tid = threadIdx.x;
@@ -355,8 +362,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
         s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
     }
     __syncthreads();
-    // horizontal 8-tap pass of the five moments; item = (row, 2 adjacent outputs): the 9-value
-    // window is read once for both (the kernel is LDS-bandwidth bound, not fp64 bound)
+    // horizontal 8-tap pass; item = (row, 2 adjacent outputs): the 9-value window is read once
     for (int i = tid; i < LH * (WSS_TX / 2); i += 256) {
         const int r = i / (WSS_TX / 2), x = 2 * (i - r * (WSS_TX / 2));
         double va[9], vb[9];
@@ -390,24 +396,29 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
         }
     }
     __syncthreads();
-    // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); a lane owns 2 vertically
-    // adjacent windows and reads their 9 rows once
+    // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); a lane owns WPT vertically
+    // adjacent windows and reads their WPT+7 rows once
     double val = 0;
     {
-        const int lx = tid & (WSS_TX - 1), ly = 2 * (tid / WSS_TX);
+        const int lx = tid & (WSS_TX - 1), ly = WPT * (tid / WSS_TX);
         const int wx = wx0 + lx;
-        double m[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        double m[WPT][4];
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
+        for (int o = 0; o < WPT; o++) m[o][0] = m[o][1] = m[o][2] = m[o][3] = 0;
+#pragma unroll
+        for (int j = 0; j < WPT + 7; j++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const double hv = s_h[q][(ly + j) * WSS_TX + lx];
-                if (j < 8) m[0][q] = fma(hv, a.row[j], m[0][q]);
-                if (j >= 1) m[1][q] = fma(hv, a.row[j - 1], m[1][q]);
+#pragma unroll
+                for (int o = 0; o < WPT; o++) {
+                    const int k = j - o;
+                    if (k >= 0 && k < 8) m[o][q] = fma(hv, a.row[k], m[o][q]);
+                }
             }
         }
 #pragma unroll
-        for (int o = 0; o < 2; o++) {
+        for (int o = 0; o < WPT; o++) {
             const int wy = wy0 + ly + o;
             if (wx < a.w - 8 && wy < a.h - 8) {
                 const double muA = m[o][0], muB = m[o][1];
@@ -483,7 +494,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
-        hipLaunchKernelGGL(windowed_ssim_sep_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
+        hipLaunchKernelGGL(windowed_ssim_sep_kernel<WSS_TY>, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         FNX_HIP(hipGetLastError());
     } else if (have) {
         WinArgs wa{};
