@@ -92,6 +92,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ctx_device", i, [ctx])
         _sig(L, "fnx_ctx_stream", C.c_void_p, [ctx])
         _sig(L, "fnx_ctx_sync", i, [ctx])
+        _sig(L, "fnx_ctx_profile", i, [ctx, i])
+        _sig(L, "fnx_ctx_kernel_ms", i, [ctx, C.POINTER(C.c_float)])
         _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
         _sig(L, "fnx_free", i, [ctx, C.c_void_p])
         _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
@@ -115,6 +117,10 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ssim_fast_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p, _f64p])
         _sig(L, "fnx_ssim_fast_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
         _sig(L, "fnx_results_fetch", i, [ctx, i, _f64p])
+        _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
+             [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
+        _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
+             [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p])
         _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
         _sig(L, "fennec_blurKernel", i, [d, _f64p])
         _sig(L, "fennec_lanczosKernel", d, [d])
@@ -229,6 +235,16 @@ class Context:
 
     def sync(self):
         self._chk(self._lib.fnx_ctx_sync(self._h), "fnx_ctx_sync")
+
+    def profile(self, enable: bool = True):
+        """Bracket every blur_direct_kernel launch with HIP events (fnx_ctx_profile)."""
+        self._chk(self._lib.fnx_ctx_profile(self._h, 1 if enable else 0), "fnx_ctx_profile")
+
+    def kernel_ms(self) -> float:
+        """Duration of the last bracketed blur_direct_kernel launch, in ms (waits for it)."""
+        ms = C.c_float(0.0)
+        self._chk(self._lib.fnx_ctx_kernel_ms(self._h, C.byref(ms)), "fnx_ctx_kernel_ms")
+        return float(ms.value)
 
     @property
     def stream(self) -> int:
@@ -485,6 +501,55 @@ class Context:
 
     def SSIMFastBatch(self, imgs_a, imgs_b, window=None) -> np.ndarray:
         return self.plan_ssim_fast_batch(imgs_a, imgs_b, window).run().copy()
+
+    def plan_blur_ssim_fast_batch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None):
+        """Pre-marshalled `outs[i] = GaussianBlur(imgs[i], sigma); ssim[i] = SSIMFast(imgs[i], outs[i])`
+        in one pass over the pixels (fnx_gaussian_blur_ssim_fast_batch).  run() -> numpy array of n
+        SSIM values (synchronises); enqueue()/fetch() split it."""
+        if sigma <= 0:
+            raise FennecError("sigma <= 0 returns the source itself (effects.go:147): nothing to plan")
+        views = [_Img(t) for t in imgs]
+        if any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("batched ops take device tensors")
+        w, h, st = views[0].w, views[0].h, views[0].stride
+        if outs is None:
+            outs = [views[0].like(w, h) for _ in views]
+        oviews = [_Img(t) for t in outs]
+        n = len(views)
+        srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+        dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
+        radius, kernel = self.blurKernel(sigma)
+        k, pk = _f64(kernel)
+        kw, pw = _f64(self.gaussianKernel() if window is None else window)
+        flags = FNX_BLUR_EXACT if exact else FNX_BLUR_FAST
+        out = np.empty(n, dtype=np.float64)
+        po = out.ctypes.data_as(_f64p)
+        ctx, lib, ost = self, self._lib, oviews[0].stride
+
+        class _Plan:
+            def __init__(p):
+                p.outs = outs
+                p._keep = (imgs, outs, srcs, dsts, k, kw, out)
+
+            def run(p):
+                ctx._chk(lib.fnx_gaussian_blur_ssim_fast_batch(ctx._h, n, srcs, st, w, h, pk, radius, flags,
+                                                               dsts, ost, pw, po), "GaussianBlur+SSIMFast batch")
+                return out
+
+            def enqueue(p):
+                ctx._chk(lib.fnx_gaussian_blur_ssim_fast_batch_enqueue(ctx._h, n, srcs, st, w, h, pk, radius,
+                                                                       flags, dsts, ost, pw),
+                         "GaussianBlur+SSIMFast batch")
+
+            def fetch(p):
+                ctx._chk(lib.fnx_results_fetch(ctx._h, n, po), "fnx_results_fetch")
+                return out
+        return _Plan()
+
+    def GaussianBlurSSIMFastBatch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None):
+        """-> (blurred images, numpy array of SSIMFast(imgs[i], blurred[i]))."""
+        plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window)
+        return plan.outs, plan.run().copy()
 
 
 class _Prepared:

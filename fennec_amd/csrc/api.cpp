@@ -88,6 +88,20 @@ int result_slot(fnx_ctx *ctx, int n, double **d)
     return FNX_OK;
 }
 
+// results -> pinned host memory right behind the kernels + an event: fnx_results_fetch then
+// never waits for work that was queued on this stream after the batch
+int publish_results(fnx_ctx *ctx, const double *dres, int n)
+{
+    void *pin = nullptr;
+    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n), &pin));
+    FNX_HIP(hipMemcpyAsync(pin, dres, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
+    FNX_HIP(hipEventRecord(ctx->res_event, ctx->stream));
+    ctx->res_pinned = static_cast<const double *>(pin);
+    ctx->res_n = n;
+    return FNX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -364,16 +378,57 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
             FNX_TRY(ssim_fast_device(ctx, 1, as[i], nullptr, astride, bs[i], nullptr, bstride, w, h, window,
                                      static_cast<const double *>(dwin), dres + i));
     }
-    // results -> pinned host memory right behind the kernels + an event: fnx_results_fetch then
-    // never waits for work that was queued on this stream after the batch
-    void *pin = nullptr;
-    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n), &pin));
-    FNX_HIP(hipMemcpyAsync(pin, dres, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
-    if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
-    FNX_HIP(hipEventRecord(ctx->res_event, ctx->stream));
-    ctx->res_pinned = static_cast<const double *>(pin);
-    ctx->res_n = n;
-    return FNX_OK;
+    return publish_results(ctx, dres, n);
+}
+
+int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride,
+                                              int w, int h, const double *kernel, int radius, int flags,
+                                              uint8_t *const *dsts, int dstride, const double *window)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0 && window, "batch arguments");
+    if (n == 0) return FNX_OK;
+    FNX_REQUIRE(w > 0 && h > 0, "dims");
+    FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
+    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
+    int nw, nh;
+    const bool down = ssim_fast_dims(w, h, &nw, &nh);
+    if (down && nw >= 8 && nh >= 8 && !(flags & FNX_BLUR_EXACT)) {
+        // one pass: the blur kernel also accumulates both boxDownsample planes
+        const void *hosts[2] = {srcs, dsts};
+        const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+        void *dp[2];
+        FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+        const size_t plane = static_cast<size_t>(nw) * nh * 4;
+        void *t = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_TMP2, plane * 2 * n + 16, &t));
+        uint8_t *planes = static_cast<uint8_t *>(t);
+        const int st = launch_blur_scored(ctx, n, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel,
+                                          radius, static_cast<uint8_t *const *>(dp[1]), dstride, planes, plane, nw, nh);
+        if (st < 0) return st;
+        if (st == FNX_OK) {
+            void *dwin = nullptr;
+            FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+            double *dres;
+            FNX_TRY(result_slot(ctx, n, &dres));
+            FNX_TRY(launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
+                                         window, static_cast<const double *>(dwin), dres));
+            return publish_results(ctx, dres, n);
+        }
+    }
+    // shapes the one-pass kernel is not built for: the two ops back to back
+    FNX_TRY(fnx_gaussian_blur_batch(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride));
+    return fnx_ssim_fast_batch_enqueue(ctx, n, srcs, sstride, const_cast<const uint8_t *const *>(dsts), dstride, w, h, window);
+}
+
+int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w,
+                                      int h, const double *kernel, int radius, int flags,
+                                      uint8_t *const *dsts, int dstride, const double *window, double *out)
+{
+    FNX_REQUIRE(out != nullptr, "out is null");
+    FNX_TRY(fnx_gaussian_blur_ssim_fast_batch_enqueue(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts,
+                                                      dstride, window));
+    return fnx_results_fetch(ctx, n, out);
 }
 
 int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,

@@ -12,6 +12,8 @@
 #include "common.hpp"
 #include "devutil.hpp"
 
+#include <algorithm>
+
 namespace fnx {
 
 // ------------------------------------------------------------------------------------
@@ -86,7 +88,25 @@ struct FusedArgs {
     int sstride, dstride, w, h;
     int tiles_x, tiles;   // per image
     float wt[2 * FUSED_RMAX + 1];
+    // SCORE variant only (launch_blur_scored): boxDownsample partial sums of src and dst
+    const int32_t *bx, *by;       // box column / row of each source column / row (-1: in no box)
+    unsigned long long *slabs;    // [image][tile][2][slabn] packed 4 x u16 channel sums
+    int nbx, nby;                 // most box columns / rows any tile touches
 };
+
+// capacity of the per-tile box table, entries per image: (nbx+1) * (nby+1) <= SCORE_NBOX
+constexpr int SCORE_NBOX = 192;
+
+// channel sums of one pixel into the box table entry at byte offset `off`: the entry is
+// R | G<<16 | B<<32 | A<<48, a box of <= 256 px cannot carry out of a 16-bit field
+__device__ __forceinline__ void box_add(unsigned long long *table, uint32_t off, uint32_t px)
+{
+    const uint32_t rg = __builtin_amdgcn_perm(0u, px, 0x0c010c00u);
+    const uint32_t ba = __builtin_amdgcn_perm(0u, px, 0x0c030c02u);
+    unsigned long long *e = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(table) + off);
+    __hip_atomic_fetch_add(e, (static_cast<unsigned long long>(ba) << 32) | rg, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // acc += f * w on two lanes at once (v_pk_fma_f32)
 __device__ __forceinline__ v2f fma2(v2f f, float w, v2f acc)
@@ -119,7 +139,12 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 //   * 128-lane workgroups, 64 x TH output tile (TH = 64-2R rounded down to a multiple of 4): an H item is 2 rows x 8 outputs (2 per lane), a V item is 2 columns x
 //     TH/4 output rows (1 per lane): each intermediate pixel is converted (Q+2R)/Q ~ 1.9 times
 //     instead of 4, all lanes busy in both passes.
-template <int R, int NTH, int IH>
+//
+// SCORE = true additionally accumulates, per tile, the boxDownsample (ssim.go:244-309) channel
+// sums of the source pixels (H pass: each item holds its 16 centre pixels) and of the blurred
+// pixels (V pass: the packed outputs) with LDS atomics, and writes them to the tile's slab:
+// SSIMFast(src, blurred) then needs no second pass over either image (launch_blur_scored).
+template <int R, int NTH, int IH, bool SCORE>
 __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
 {
     constexpr int TW = 64;
@@ -136,6 +161,9 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     static_assert(Q * RG == TH && SR <= IH && SR % 2 == 0, "tile shape");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_tmp[SR * TW];   // H pass: R,G,B rounded + source alpha
+    __shared__ unsigned long long s_box[SCORE ? 2 * SCORE_NBOX : 1];   // [src | blurred] box tables
+    __shared__ __attribute__((aligned(16))) uint32_t s_coloff[SCORE ? TW : 4];   // byte offset of a tile column's box
+    __shared__ uint32_t s_rowoff[SCORE ? TH : 1];                      // ... of a tile row's box row
 
     const int tile = xcd_tile(blockIdx.x, a.tiles);
     if (tile < 0) return;
@@ -147,6 +175,22 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     const int tid = threadIdx.x;
     // a window may over-read up to 3 px past its last tap: interior = no clamp needed anywhere
     const bool interior = x0 - R >= 0 && x0 + TW + R + 3 < a.w && y0 - R >= 0 && y0 + TH + R <= a.h;
+
+    if constexpr (SCORE) {
+        // table layout: (nby+1) rows of (nbx+1) entries; the last column / row collect pixels that
+        // belong to no box (outside the image, or the source's unboxed tail columns / rows)
+        const int slabn = (a.nbx + 1) * (a.nby + 1);
+        for (int e = tid; e < slabn; e += NTH) s_box[e] = s_box[SCORE_NBOX + e] = 0;
+        if (tid < TW) {
+            const int b0 = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
+            s_coloff[tid] = (v >= 0 && b0 >= 0) ? 8u * (v - b0) : 8u * a.nbx;
+        }
+        for (int r = tid; r < TH; r += NTH) {
+            const int b0 = a.by[y0], v = y0 + r < a.h ? a.by[y0 + r] : -1;
+            s_rowoff[r] = 8u * (a.nbx + 1) * ((v >= 0 && b0 >= 0) ? v - b0 : a.nby);
+        }
+        __syncthreads();
+    }
 
     // ---- horizontal pass (effects.go:169-191): item = 2 rows x 8 outputs, window from global ----
     for (int item = tid; item < HITEMS; item += NTH) {
@@ -178,6 +222,21 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
                         t1[q][e] = ld_px(p1, xc);
                     }
                 }
+            }
+        }
+        if constexpr (SCORE) {   // source side of the box sums: this item's 2 x 8 centre pixels
+            const int r0 = 2 * rp - R;
+            const u32x4 ca = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g);
+            const u32x4 cb = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g + 4);
+            if (r0 >= 0 && r0 < TH) {
+                const uint32_t ro = s_rowoff[r0];
+#pragma unroll
+                for (int j = 0; j < HO; j++) box_add(s_box, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t0[(j + R) / 4][(j + R) % 4]);
+            }
+            if (r0 + 1 >= 0 && r0 + 1 < TH) {
+                const uint32_t ro = s_rowoff[r0 + 1];
+#pragma unroll
+                for (int j = 0; j < HO; j++) box_add(s_box, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t1[(j + R) / 4][(j + R) % 4]);
             }
         }
         v2f acc[HO][3];
@@ -263,6 +322,15 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
             asm volatile("" : "+v"(o[j].x), "+v"(o[j].y));   // keep the accumulation out of the store branches
         }
         fp32_round_nearest();
+        if constexpr (SCORE) {   // blurred side of the box sums (columns / rows outside the image -> spare entries)
+            const u32x2 co = *reinterpret_cast<const u32x2 *>(s_coloff + 2 * cp);
+#pragma unroll
+            for (int j = 0; j < Q; j++) {
+                const uint32_t ro = s_rowoff[rg * Q + j];
+                box_add(s_box + SCORE_NBOX, ro + co.x, o[j].x);
+                box_add(s_box + SCORE_NBOX, ro + co.y, o[j].y);
+            }
+        }
         if (x < a.w) {
 #pragma unroll
             for (int j = 0; j < Q; j++) {
@@ -278,17 +346,108 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
             }
         }
     }
+    if constexpr (SCORE) {
+        __syncthreads();
+        const int slabn = (a.nbx + 1) * (a.nby + 1);
+        unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
+        for (int e = tid; e < slabn; e += NTH) {
+            slab[e] = s_box[e];
+            slab[slabn + e] = s_box[SCORE_NBOX + e];
+        }
+    }
 }
 
-template <int R, int NTH, int IH>
+// ------------------------------------------------------------------------------------
+// box tables from the slabs of a SCORE launch: the boxDownsample'd source (z < n) and blurred
+// (z >= n) images, identical to box_tiled_kernel's output (integer sums are order-free)
+// ------------------------------------------------------------------------------------
+struct BoxRef {           // where one output column (or row) finds its partial sums
+    int32_t part0, part1; // slab offsets of the (at most two) tiles the box spans; part1 < 0: one tile
+    int32_t len, pad;     // box width (height) in source px
+};
+
+struct SlabArgs {
+    const unsigned long long *slabs;
+    const double *inv;        // inv[c] = 1.0 / c, c <= 256 (the reference's division, done once on the host)
+    const BoxRef *xref, *yref;
+    uint8_t *dst;             // [src 0..n-1][blurred 0..n-1] tight dstW x dstH planes
+    size_t plane, image_slabs;  // entries per image: tiles * 2 * slabn
+    int n, dstW, dstH, slabn;
+};
+
+// clampF of a value known to lie in [0, 256): trunc + round-half-up, as clampF_dev without its guards
+__device__ __forceinline__ uint32_t round_u8_small(double x)
+{
+    double t = trunc(x);
+    if (x - t >= 0.5) t += 1.0;
+    return min(static_cast<uint32_t>(static_cast<int>(t)), 255u);
+}
+
+// One thread per box, both images.  The index arithmetic (box_edge, tile and entry of each part)
+// is per column / per row and comes from host tables: what is left is <= 8 slab loads and the
+// fp64 finish.  Alpha is not produced: both planes only feed toLuminance (ssim.go:207-220).
+__global__ __launch_bounds__(256) void box_from_slabs_kernel(SlabArgs a)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= a.dstW || dy >= a.dstH) return;
+    const int i = blockIdx.z;
+    const BoxRef xr = a.xref[dx], yr = a.yref[dy];
+    const double inv = a.inv[xr.len * yr.len];
+    const unsigned long long *base = a.slabs + a.image_slabs * i;
+    // 2 x u16 per word: the whole box is <= 256 px, so no field overflows.  [0]: source, [1]: blurred
+    uint32_t rg[2], b[2];
+#pragma unroll
+    for (int img = 0; img < 2; img++) {
+        const unsigned long long v = base[yr.part0 + xr.part0 + img * a.slabn];
+        rg[img] = static_cast<uint32_t>(v);
+        b[img] = static_cast<uint32_t>(v >> 32);
+    }
+    if (xr.part1 >= 0) {
+#pragma unroll
+        for (int img = 0; img < 2; img++) {
+            const unsigned long long v = base[yr.part0 + xr.part1 + img * a.slabn];
+            rg[img] += static_cast<uint32_t>(v);
+            b[img] += static_cast<uint32_t>(v >> 32);
+        }
+    }
+    if (yr.part1 >= 0) {
+#pragma unroll
+        for (int img = 0; img < 2; img++) {
+            unsigned long long v = base[yr.part1 + xr.part0 + img * a.slabn];
+            rg[img] += static_cast<uint32_t>(v);
+            b[img] += static_cast<uint32_t>(v >> 32);
+            if (xr.part1 >= 0) {
+                v = base[yr.part1 + xr.part1 + img * a.slabn];
+                rg[img] += static_cast<uint32_t>(v);
+                b[img] += static_cast<uint32_t>(v >> 32);
+            }
+        }
+    }
+    // clampF(sum * (1.0 / count)) per channel (ssim.go:301-308)
+#pragma unroll
+    for (int img = 0; img < 2; img++) {
+        const uint32_t o = round_u8_small(u8_to_f64(rg[img] & 0xffffu) * inv) | (round_u8_small(u8_to_f64(rg[img] >> 16) * inv) << 8) |
+                           (round_u8_small(u8_to_f64(b[img] & 0xffffu) * inv) << 16);
+        *reinterpret_cast<uint32_t *>(a.dst + a.plane * (static_cast<size_t>(img) * a.n + i) +
+                                      (static_cast<size_t>(dy) * a.dstW + dx) * 4) = o;
+    }
+}
+
+template <int R, int NTH, int IH, bool SCORE>
 static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
     constexpr int TW = 64, RG = NTH / 32, TH = ((IH - 2 * R) / RG) * RG;
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
-    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH>), grid, dim3(NTH), 0, ctx->stream, fa);
+    if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
+    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), 0, ctx->stream, fa);
     FNX_HIP(hipGetLastError());
+    if (ctx->prof) {
+        FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
+        ctx->prof_valid = true;
+    }
     return FNX_OK;
 }
 
@@ -297,16 +456,179 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 //   256 lanes x (2*TH+2R) rows         (TH = 104,      halo 1.12x) -- wins when the image height
 //     does not leave a mostly empty last tile row and there are enough tiles to fill the chip.
 // Cost model: H work ~ staged rows, V work ~ output rows (about 55 : 45 of the instructions).
-template <int R>
-static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa)
+static int direct_tile_rows(int R, bool tall)
 {
-    constexpr int TH0 = ((64 - 2 * R) / 4) * 4, TH1 = 2 * TH0;
-    const long ty0 = (fa.h + TH0 - 1) / TH0, ty1 = (fa.h + TH1 - 1) / TH1;
+    const int th0 = ((64 - 2 * R) / 4) * 4;
+    return tall ? 2 * th0 : th0;
+}
+static bool direct_tall(const fnx_ctx *ctx, int R, int n, int w, int h)
+{
+    const int TH0 = direct_tile_rows(R, false), TH1 = direct_tile_rows(R, true);
+    const long ty0 = (h + TH0 - 1) / TH0, ty1 = (h + TH1 - 1) / TH1;
     const double cost0 = ty0 * (0.55 * (TH0 + 2 * R) + 0.45 * TH0);
     const double cost1 = ty1 * (0.55 * (TH1 + 2 * R) + 0.45 * TH1);
-    const long tiles1 = ty1 * ((fa.w + 63) / 64) * n;
-    if (cost1 < 0.95 * cost0 && tiles1 >= 4L * ctx->num_cus) return launch_direct_cfg<R, 256, TH1 + 2 * R>(ctx, n, fa);
-    return launch_direct_cfg<R, 128, 64>(ctx, n, fa);
+    const long tiles1 = ty1 * ((w + 63) / 64) * n;
+    return cost1 < 0.95 * cost0 && tiles1 >= 4L * ctx->num_cus;
+}
+
+template <int R, bool SCORE>
+static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa, bool tall)
+{
+    constexpr int TH0 = ((64 - 2 * R) / 4) * 4;
+    if (tall) return launch_direct_cfg<R, 256, 2 * TH0 + 2 * R, SCORE>(ctx, n, fa);
+    return launch_direct_cfg<R, 128, 64, SCORE>(ctx, n, fa);
+}
+
+template <bool SCORE>
+static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, bool tall)
+{
+    switch (radius) {
+    case 1: return launch_direct<1, SCORE>(ctx, n, fa, tall);
+    case 2: return launch_direct<2, SCORE>(ctx, n, fa, tall);
+    case 3: return launch_direct<3, SCORE>(ctx, n, fa, tall);
+    case 4: return launch_direct<4, SCORE>(ctx, n, fa, tall);
+    case 5: return launch_direct<5, SCORE>(ctx, n, fa, tall);
+    case 6: return launch_direct<6, SCORE>(ctx, n, fa, tall);
+    case 7: return launch_direct<7, SCORE>(ctx, n, fa, tall);
+    case 8: return launch_direct<8, SCORE>(ctx, n, fa, tall);
+    }
+    return FNX_ERR_INVALID;
+}
+
+// GaussianBlur (fast mode) of n images AND the boxDownsample'd dstW x dstH planes of every
+// source and blurred image, for SSIMFast(src, blurred) (ssim.go:48-70), in one pass over the
+// pixels.  Returns FNX_NOOP without launching anything when the shape is outside what the
+// SCORE kernel is built for (the caller then runs the two ops separately).
+// Geometry of a one-pass launch: tile shape, box tables.  Cached on the ctx (batches repeat it).
+constexpr int NINV = 258;   // doubles at the head of the table blob: 1/c, c in [0, 256]
+static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH)
+{
+    if (radius < 1 || radius > FUSED_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
+        h >= (1 << 24))
+        return false;
+    const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
+    const double yr = static_cast<double>(h) / static_cast<double>(dstH);
+    // source column / row -> box index (boxes of a downscale are disjoint and ascending)
+    // one table blob: 1/c for c in [0, 256] (doubles) | BoxRef per output column, per output row |
+    // box index of every source column, every source row
+    const size_t ref_words = 4 * (static_cast<size_t>(dstW) + dstH);
+    std::vector<int32_t> &map = g.map;
+    map.assign(2 * NINV + ref_words + static_cast<size_t>(w) + h, -1);
+    double *inv = reinterpret_cast<double *>(map.data());
+    inv[0] = inv[257] = 0.0;
+    for (int c = 1; c <= 256; c++) inv[c] = 1.0 / static_cast<double>(c);
+    BoxRef *xref = reinterpret_cast<BoxRef *>(map.data() + 2 * NINV), *yref = xref + dstW;
+    int32_t *bx = map.data() + 2 * NINV + ref_words, *by = bx + w;
+    int maxbw = 0, maxbh = 0;
+    for (int d = 0; d < dstW; d++) {
+        int s0, s1;
+        box_edge(d, xr, w, s0, s1);
+        if (d + 1 < dstW) { int n0, n1; box_edge(d + 1, xr, w, n0, n1); if (n0 < s1) return false; }
+        for (int x = s0; x < s1; x++) bx[x] = d;
+        if (s1 - s0 > maxbw) maxbw = s1 - s0;
+    }
+    for (int d = 0; d < dstH; d++) {
+        int s0, s1;
+        box_edge(d, yr, h, s0, s1);
+        if (d + 1 < dstH) { int n0, n1; box_edge(d + 1, yr, h, n0, n1); if (n0 < s1) return false; }
+        for (int y = s0; y < s1; y++) by[y] = d;
+        if (s1 - s0 > maxbh) maxbh = s1 - s0;
+    }
+    if (static_cast<long>(maxbw) * maxbh > 256) return false;   // 16-bit sum fields
+    // most boxes a tile touches, for the preferred tile shape and then the other one
+    bool tall = g.tall_pref;
+    int th = 0, nbx = 0, nby = 0;
+    for (int attempt = 0; attempt < 2; attempt++, tall = !tall) {
+        th = direct_tile_rows(radius, tall);
+        nbx = nby = 1;
+        auto span = [](const int32_t *m, int lo, int hi) {   // boxes touched by [lo, hi)
+            int first = -1, last = -1;
+            for (int i = lo; i < hi; i++)
+                if (m[i] >= 0) { if (first < 0) first = m[i]; last = m[i]; }
+            return first < 0 ? 0 : last - first + 1;
+        };
+        for (int x0 = 0; x0 < w; x0 += 64) nbx = std::max(nbx, span(bx, x0, std::min(w, x0 + 64)));
+        for (int y0 = 0; y0 < h; y0 += th) nby = std::max(nby, span(by, y0, std::min(h, y0 + th)));
+        if ((nbx + 1) * (nby + 1) <= SCORE_NBOX) break;
+        th = 0;
+    }
+    if (!th) return false;
+    tall = th == direct_tile_rows(radius, true);
+    // a tile whose first column / row is in no box must not hold boxed pixels (kernel uses bx[x0])
+    for (int x0 = 0; x0 < w; x0 += 64)
+        if (bx[x0] < 0) for (int x = x0; x < std::min(w, x0 + 64); x++) if (bx[x] >= 0) return false;
+    for (int y0 = 0; y0 < h; y0 += th)
+        if (by[y0] < 0) for (int y = y0; y < std::min(h, y0 + th); y++) if (by[y] >= 0) return false;
+
+    const int slabn = (nbx + 1) * (nby + 1);
+    const int tiles_x = (w + 63) / 64, tiles = tiles_x * ((h + th - 1) / th);
+    if (static_cast<size_t>(tiles) * 2 * slabn >= (1u << 30)) return false;   // 32-bit slab offsets
+    for (int d = 0; d < dstW; d++) {
+        int s0, s1;
+        box_edge(d, xr, w, s0, s1);
+        const int t0 = s0 >> 6, t1 = (s1 - 1) >> 6;
+        if (t1 > t0 + 1) return false;
+        xref[d].part0 = t0 * 2 * slabn + (d - bx[t0 << 6]);
+        xref[d].part1 = t1 > t0 ? t1 * 2 * slabn + (d - bx[t1 << 6]) : -1;
+        xref[d].len = s1 - s0; xref[d].pad = 0;
+    }
+    for (int d = 0; d < dstH; d++) {
+        int s0, s1;
+        box_edge(d, yr, h, s0, s1);
+        const int t0 = s0 / th, t1 = (s1 - 1) / th;
+        if (t1 > t0 + 1) return false;
+        yref[d].part0 = t0 * tiles_x * 2 * slabn + (d - by[t0 * th]) * (nbx + 1);
+        yref[d].part1 = t1 > t0 ? t1 * tiles_x * 2 * slabn + (d - by[t1 * th]) * (nbx + 1) : -1;
+        yref[d].len = s1 - s0; yref[d].pad = 0;
+    }
+
+    g.th = th; g.nbx = nbx; g.nby = nby; g.tall = tall;
+    return true;
+}
+
+int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
+                       const double *kernel, int radius, uint8_t *const *dsts, int dstride,
+                       uint8_t *planes, size_t plane, int dstW, int dstH)
+{
+    if (n > 65535) return FNX_NOOP;   // grid.z
+    const bool tall_pref = direct_tall(ctx, radius, n, w, h);
+    ScoreGeom &g = ctx->score_geom;
+    if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref)) {
+        g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref;
+        g.ok = build_score_geom(g, w, h, radius, dstW, dstH);
+    }
+    if (!g.ok) return FNX_NOOP;
+    const std::vector<int32_t> &map = g.map;
+    const int th = g.th, nbx = g.nbx, nby = g.nby;
+    const bool tall = g.tall;
+    const size_t ref_words = 4 * (static_cast<size_t>(dstW) + dstH);
+    const int slabn = (nbx + 1) * (nby + 1);
+    const int tiles_x = (w + 63) / 64, tiles = tiles_x * ((h + th - 1) / th);
+
+    void *dmap = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_BOXMAP, map.data(), sizeof(int32_t) * map.size(), &dmap));
+    FusedArgs fa{};
+    fa.srcs = srcs; fa.dsts = dsts;
+    fa.sstride = sstride; fa.dstride = dstride; fa.w = w; fa.h = h;
+    for (int i = 0; i < 2 * radius + 1; i++) fa.wt[i] = static_cast<float>(kernel[i]);
+    fa.bx = static_cast<const int32_t *>(dmap) + 2 * NINV + ref_words; fa.by = fa.bx + w;
+    fa.nbx = nbx; fa.nby = nby;
+    void *slabs = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
+    fa.slabs = static_cast<unsigned long long *>(slabs);
+    FNX_TRY(launch_direct_radius<true>(ctx, radius, n, fa, tall));
+
+    SlabArgs sa{};
+    sa.slabs = fa.slabs; sa.dst = planes; sa.plane = plane;
+    sa.inv = static_cast<const double *>(dmap);
+    sa.xref = reinterpret_cast<const BoxRef *>(static_cast<const int32_t *>(dmap) + 2 * NINV);
+    sa.yref = sa.xref + dstW;
+    sa.image_slabs = static_cast<size_t>(tiles) * 2 * slabn;
+    sa.n = n; sa.dstW = dstW; sa.dstH = dstH; sa.slabn = slabn;
+    hipLaunchKernelGGL(box_from_slabs_kernel, dim3((dstW + 63) / 64, (dstH + 3) / 4, n), dim3(256), 0,
+                       ctx->stream, sa);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
 }
 
 template <typename T>
@@ -361,17 +683,7 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
     fa.src = src; fa.srcs = srcs; fa.dst = dst; fa.dsts = dsts;
     fa.sstride = sstride; fa.dstride = dstride; fa.w = w; fa.h = h;
     for (int i = 0; i < 2 * radius + 1; i++) fa.wt[i] = static_cast<float>(kernel[i]);
-    switch (radius) {
-    case 1: return launch_direct<1>(ctx, n, fa);
-    case 2: return launch_direct<2>(ctx, n, fa);
-    case 3: return launch_direct<3>(ctx, n, fa);
-    case 4: return launch_direct<4>(ctx, n, fa);
-    case 5: return launch_direct<5>(ctx, n, fa);
-    case 6: return launch_direct<6>(ctx, n, fa);
-    case 7: return launch_direct<7>(ctx, n, fa);
-    case 8: return launch_direct<8>(ctx, n, fa);
-    }
-    return FNX_ERR_INVALID;
+    return launch_direct_radius<false>(ctx, radius, n, fa, direct_tall(ctx, radius, n, w, h));
 }
 
 }  // namespace fnx

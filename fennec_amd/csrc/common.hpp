@@ -52,6 +52,8 @@ enum Slot {
     SLOT_PARTIAL,    // reduction partials
     SLOT_RESULT,     // scalar results
     SLOT_PTRS,       // pointer arrays of batched ops
+    SLOT_BOXMAP,     // source column/row -> box index tables (blur + SSIMFast in one pass)
+    SLOT_SLABS,      // per-tile box partial sums of that pass
     SLOT_COUNT
 };
 
@@ -63,6 +65,14 @@ struct Scratch {
 // Cached copy of the last table uploaded into a table slot.
 struct TableCache {
     std::vector<unsigned char> host;
+};
+
+// Cached geometry of the one-pass blur + SSIMFast launch (blur.hip: launch_blur_scored)
+struct ScoreGeom {
+    int w = 0, h = 0, dstW = 0, dstH = 0, radius = 0;
+    bool tall_pref = false, tall = false, ok = false;
+    int th = 0, nbx = 0, nby = 0;
+    std::vector<int32_t> map;   // the table blob uploaded to SLOT_BOXMAP
 };
 
 }  // namespace fnx
@@ -79,6 +89,10 @@ struct fnx_ctx {
     // results of the last *_enqueue call: copied to pinned memory right behind the kernels, so a
     // later fetch waits for THIS event only, not for work queued on the stream afterwards
     hipEvent_t res_event = nullptr;
+    // fnx_ctx_profile: events around the last blur_direct_kernel launch
+    fnx::ScoreGeom score_geom;
+    bool prof = false, prof_valid = false;
+    hipEvent_t prof_ev[2] = {nullptr, nullptr};
     const double *res_pinned = nullptr;
     int res_n = 0;
 };
@@ -140,6 +154,11 @@ inline bool aligned16(const void *p, int stride)
 int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride,
                 int w, int h, const double *kernel, int radius, int flags, uint8_t *dst,
                 uint8_t *const *dsts, int dstride);
+// fast-mode blur + both boxDownsample'd planes ([src 0..n-1][blurred 0..n-1], tight dstW x dstH)
+// in one pass; FNX_NOOP (nothing launched) when the shape is not covered.  srcs/dsts: device arrays.
+int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
+                       const double *kernel, int radius, uint8_t *const *dsts, int dstride,
+                       uint8_t *planes, size_t plane, int dstW, int dstH);
 int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *dst,
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,

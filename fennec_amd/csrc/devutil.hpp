@@ -69,6 +69,24 @@ __device__ __forceinline__ double u8_to_f64(uint32_t v)
     return __hiloint2double(0x43300000, static_cast<int>(v)) - 4503599627370496.0;
 }
 
+// boxDownsample's source range of output index d (ssim.go:262-275)
+__host__ __device__ __forceinline__ void box_edge(int d, double ratio, int srcN, int &s0, int &s1)
+{
+    s0 = static_cast<int>(static_cast<double>(d) * ratio);
+    s1 = static_cast<int>(static_cast<double>(d + 1) * ratio);
+    if (s1 > srcN) s1 = srcN;
+    if (s0 >= s1) s0 = s1 - 1;
+    if (s0 < 0) s0 = 0;
+}
+
+__device__ __forceinline__ uint32_t box_finish(uint32_t r, uint32_t g, uint32_t b, uint32_t al, int count)
+{
+    // sums are exact integers; inv := 1.0/count; clampF(sum*inv)  (ssim.go:301-308)
+    const double inv = 1.0 / static_cast<double>(count);
+    return clampF_dev(u8_to_f64(r) * inv) | (clampF_dev(u8_to_f64(g) * inv) << 8) |
+           (clampF_dev(u8_to_f64(b) * inv) << 16) | (clampF_dev(u8_to_f64(al) * inv) << 24);
+}
+
 // XCD-aware work-item remap: consecutive workgroup ids land on different XCDs
 // (b % 8, MI355X_MICROARCH "Workgroup dispatch"), so hand each XCD a CONTIGUOUS range of
 // tiles -- neighbouring tiles share halo rows/columns and then hit the same 4 MiB L2.

@@ -236,12 +236,34 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
             if (s.p) (void)hipFree(s.p);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         if (ctx->res_event) (void)hipEventDestroy(ctx->res_event);
+        for (auto &e : ctx->prof_ev)
+            if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
 }
 
 int fnx_ctx_device(const fnx_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int fnx_ctx_profile(fnx_ctx *ctx, int enable)
+{
+    FNX_TRY(bind(ctx));
+    if (enable)
+        for (auto &e : ctx->prof_ev)
+            if (!e) FNX_HIP(hipEventCreate(&e));
+    ctx->prof = enable != 0;
+    ctx->prof_valid = false;
+    return FNX_OK;
+}
+
+int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(ms != nullptr && ctx->prof_valid, "no profiled kernel launch on this ctx");
+    FNX_HIP(hipEventSynchronize(ctx->prof_ev[1]));
+    FNX_HIP(hipEventElapsedTime(ms, ctx->prof_ev[0], ctx->prof_ev[1]));
+    return FNX_OK;
+}
 
 void *fnx_ctx_stream(fnx_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 

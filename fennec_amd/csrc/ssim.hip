@@ -26,23 +26,6 @@ struct BoxArgs {
 };
 
 // box edges exactly as ssim.go:255-278
-__device__ __forceinline__ void box_edge(int d, double ratio, int srcN, int &s0, int &s1)
-{
-    s0 = static_cast<int>(static_cast<double>(d) * ratio);
-    s1 = static_cast<int>(static_cast<double>(d + 1) * ratio);
-    if (s1 > srcN) s1 = srcN;
-    if (s0 >= s1) s0 = s1 - 1;
-    if (s0 < 0) s0 = 0;
-}
-
-__device__ __forceinline__ uint32_t box_finish(uint32_t r, uint32_t g, uint32_t b, uint32_t al, int count)
-{
-    // sums are exact integers; inv := 1.0/count; clampF(sum*inv)  (ssim.go:301-308)
-    const double inv = 1.0 / static_cast<double>(count);
-    return clampF_dev(u8_to_f64(r) * inv) | (clampF_dev(u8_to_f64(g) * inv) << 8) |
-           (clampF_dev(u8_to_f64(b) * inv) << 16) | (clampF_dev(u8_to_f64(al) * inv) << 24);
-}
-
 // Any ratio (also upscaling, where boxes overlap / repeat): one thread per output pixel.
 __global__ __launch_bounds__(256) void box_generic_kernel(BoxArgs a)
 {

@@ -83,6 +83,12 @@ int fnx_ctx_device(const fnx_ctx *ctx);
 void *fnx_ctx_stream(fnx_ctx *ctx);
 /* Block until everything enqueued on the ctx has finished. */
 int fnx_ctx_sync(fnx_ctx *ctx);
+/* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of its
+ * GaussianBlur fast-path kernel (blur_direct_kernel, the path's dominant kernel) with a pair
+ * of HIP events on its stream.  fnx_ctx_kernel_ms waits for the last bracketed launch and
+ * returns its duration in milliseconds (FNX_ERR_INVALID if none was recorded). */
+int fnx_ctx_profile(fnx_ctx *ctx, int enable);
+int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
 
 /* Device memory on the ctx's device (for FNX_DEVICE callers). */
 int fnx_malloc(fnx_ctx *ctx, size_t bytes, void **dptr);
@@ -179,6 +185,24 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
                                 const uint8_t *const *bs, int bstride, int w, int h,
                                 const double *window);
 int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
+
+/* dsts[i] = GaussianBlur(srcs[i]) AND out[i] = SSIMFast(srcs[i], dsts[i]) -- the pair of calls
+ * the reference makes whenever it scores a processed image against its source (effects.go:146
+ * then ssim.go:48; the headline benchmark's step) -- with ONE pass over the pixels: the blur
+ * kernel already holds every source and every blurred pixel, so it also accumulates the integer
+ * channel sums of boxDownsample (ssim.go:244-309) for both, and SSIMFast never re-reads either
+ * full-size image (HBM traffic 2*S instead of 4*S).  Results are identical to the two separate
+ * calls: the box sums are integers, everything after them is the same code.  Shapes the one-pass
+ * kernel is not built for (FNX_BLUR_EXACT, radius > 8, no downsample, boxes > 256 px or < ~5 px
+ * wide) run the two ops back to back.  The _enqueue form pairs with fnx_results_fetch. */
+int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride,
+                                      int w, int h, const double *kernel, int radius, int flags,
+                                      uint8_t *const *dsts, int dstride, const double *window,
+                                      double *out /* n, host */);
+int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *srcs,
+                                              int sstride, int w, int h, const double *kernel,
+                                              int radius, int flags, uint8_t *const *dsts,
+                                              int dstride, const double *window);
 
 /* ======================================================================= */
 /* fennec_* : the reference's function set (names and argument meaning as in

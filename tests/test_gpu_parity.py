@@ -260,6 +260,46 @@ def test_batched_forms_equal_single(ctx, orc):
     assert np.array_equal(outs[2].cpu().numpy(), orc.gaussian_blur(imgs[2], 2.0, procs=8))
 
 
+def _one_pass_case(ctx, orc, imgs, sigma, exact=False, check_oracle=(0,)):
+    """fnx_gaussian_blur_ssim_fast_batch == the two ops run separately (bit for bit), and the
+    score is SSIMFast of (source, the blurred image it returned) per the oracle."""
+    import torch
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=exact)
+    ref = ctx.GaussianBlurBatch(d, sigma, exact=exact)
+    ref_ss = ctx.SSIMFastBatch(d, ref) if max(imgs[0].shape[:2]) > 512 else \
+        np.array([ctx.SSIMFast(a, b) for a, b in zip(d, ref)])
+    for k in range(len(imgs)):
+        assert torch.equal(outs[k], ref[k])
+        assert ss[k] == ref_ss[k]
+    for k in check_oracle:
+        assert abs(ss[k] - orc.ssim_fast(imgs[k], outs[k].cpu().numpy())) <= SSIM_TOL
+
+
+def test_blur_ssimfast_one_pass_4k(ctx, orc):
+    imgs = [synth.large_photo(3840, 2160, 3), synth.noise_image(3840, 2160, 9, alpha=True),
+            synth.make_test_image_with_alpha(3840, 2160)]
+    _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0, 1, 2))
+    _one_pass_case(ctx, orc, imgs[:2], 2.0, exact=True, check_oracle=())     # exact mode: two-op route
+
+
+@pytest.mark.parametrize("w,h", [(3001, 2005), (4099, 2817), (2900, 700), (640, 3333), (7680, 4320),
+                                 (2817, 2816), (5000, 64)])
+def test_blur_ssimfast_one_pass_shapes(ctx, orc, w, h):
+    imgs = [synth.noise_image(w, h, w ^ h, alpha=True), synth.large_photo(w, h, 1)]
+    _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0,))
+
+
+def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
+    imgs = [synth.noise_image(3000, 2000, 5, alpha=True)]
+    for sigma in (0.3, 0.6, 1.0, 1.3, 1.6, 2.3, 2.6, 4.0):      # radius 1..8, then 12 (generic kernels)
+        _one_pass_case(ctx, orc, imgs, sigma, check_oracle=())
+    # boxes too small for the one-pass tables / no downsample at all
+    _one_pass_case(ctx, orc, [synth.large_photo(1280, 720, 2), synth.large_photo(1280, 720, 4)], 2.0)
+    _one_pass_case(ctx, orc, [synth.large_photo(500, 300, 2)], 2.0)
+
+
 def test_determinism(ctx):
     a = synth.large_photo(1920, 1080, 1)
     b = ctx.GaussianBlur(a, 2.0)
