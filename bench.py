@@ -14,6 +14,11 @@ N > 1 is launched by torch.distributed.run (one rank per GPU): images are indepe
 images -- weak scaling, no data-path collective; the only reduction is Summarize's
 (count, ssim-sum) all-reduce over RCCL after the timed region is closed.
 
+Two ways through the C ABI, bit-identical results (tests/test_gpu_parity.py::test_blur_ssimfast_one_pass_*):
+--pipeline one-pass (default) calls fnx_gaussian_blur_ssim_fast_batch, whose blur kernel also
+accumulates SSIMFast's boxDownsample sums, so neither full-size image is read a second time;
+--pipeline two-call calls fnx_gaussian_blur_batch then fnx_ssim_fast_batch, as the reference does.
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events on the stream the
 kernel runs on) and, at N == 1, `cpu_baseline` (the oracle -- a C restatement of the Go
 reference with its threading model -- on a bounded sample of the same workload).
@@ -45,9 +50,10 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=32, help="4K images per step per GPU")
     ap.add_argument("--contexts", type=int, default=1,
                     help="worker contexts (HIP streams) per GPU; >1 runs them in complementary phases")
-    ap.add_argument("--pipeline", default="two-call", choices=["two-call", "one-pass"],
-                    help="two-call: fnx_gaussian_blur_batch then fnx_ssim_fast_batch; one-pass: "
-                         "fnx_gaussian_blur_ssim_fast_batch (same results, each image read once)")
+    ap.add_argument("--pipeline", default="one-pass", choices=["one-pass", "two-call"],
+                    help="one-pass (default): fnx_gaussian_blur_ssim_fast_batch, the blur kernel also gathers "
+                         "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
+                         "fnx_gaussian_blur_batch then fnx_ssim_fast_batch (bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")

@@ -51,6 +51,7 @@ for k in sorted(set(fetch) | set(write)):
     traffic["kernels"][k] = {"FETCH_SIZE_KB": fkb, "WRITE_SIZE_KB": wkb,
                              "hbm_bytes_per_launch": (2 * fkb + wkb) * 1024.0,
                              "launches_averaged": fetch.get(k, (0, 0))[1]}
+traffic["images_per_launch"] = int(sys.argv[2]) if len(sys.argv) > 2 else 32   # bench.py --batch of the profiled run
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 
 with open(os.path.join(dst, f"{tag}_sq_counters.txt"), "w") as fo:
