@@ -47,6 +47,22 @@ _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 
 
+class Analysis(C.Structure):
+    """fnx_analysis (include/fennec_hip.h): what the device computes for Analyze."""
+    _fields_ = [("histogram", C.c_uint64 * 256), ("bright_sum", C.c_double), ("variance_sum", C.c_double),
+                ("sample_count", C.c_int64), ("edge_count", C.c_int64), ("edge_total", C.c_int64),
+                ("unique_colors", C.c_int32), ("has_alpha", C.c_int32), ("is_grayscale", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+class ImageStats(C.Structure):
+    """fennec_ImageStats = ImageStats (analyze.go:9-22)."""
+    _fields_ = [("Width", C.c_int32), ("Height", C.c_int32), ("HasAlpha", C.c_int32), ("IsGrayscale", C.c_int32),
+                ("UniqueColors", C.c_int32), ("RecommendedFormat", C.c_int32), ("RecommendedQuality", C.c_int32),
+                ("pad", C.c_int32), ("Entropy", C.c_double), ("EdgeDensity", C.c_double),
+                ("MeanBrightness", C.c_double), ("Contrast", C.c_double), ("EstimatedCompression", C.c_double)]
+
+
 class FennecError(RuntimeError):
     pass
 
@@ -121,6 +137,13 @@ def load_library() -> C.CDLL:
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p])
+        _sig(L, "fnx_analyze", i, [ctx, i] + img + [i, i, C.POINTER(Analysis)])
+        _sig(L, "fnx_analyze_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.POINTER(Analysis)])
+        _sig(L, "fnx_scan_flags", i, [ctx, i, _u8p, C.c_size_t, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fennec_Analyze", i, [ctx, i] + img + [i, i, C.POINTER(ImageStats)])
+        _sig(L, "fennec_statsFromAnalysis", None, [C.POINTER(Analysis), i, i, C.POINTER(ImageStats)])
+        _sig(L, "fennec_isOpaque", i, [ctx, i] + img + [i, i, C.POINTER(i)])
+        _sig(L, "fennec_isGrayscale", i, [ctx, i] + img + [i, i, C.POINTER(i)])
         _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
         _sig(L, "fennec_blurKernel", i, [d, _f64p])
         _sig(L, "fennec_lanczosKernel", d, [d])
@@ -430,6 +453,76 @@ class Context:
                                                     d.ptr, d.stride), "ApplyOrientation")
         return dst
 
+    # -- Analyze (analyze.go) ---------------------------------------------------------------
+    @staticmethod
+    def _stats_dict(st: ImageStats) -> dict:
+        return {name: getattr(st, name) for name, _ in ImageStats._fields_ if name != "pad"}
+
+    @staticmethod
+    def _analysis_dict(a: Analysis) -> dict:
+        d = {name: getattr(a, name) for name, _ in Analysis._fields_ if name not in ("pad", "histogram")}
+        d["histogram"] = np.array(a.histogram[:], dtype=np.uint64)
+        return d
+
+    def Analyze(self, img) -> dict:
+        """Analyze (analyze.go:26-124) -> dict with the ImageStats field names."""
+        v = _Img(img)
+        st = ImageStats()
+        self._chk(self._lib.fennec_Analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(st)), "Analyze")
+        return self._stats_dict(st)
+
+    def analyze_raw(self, img) -> dict:
+        """fnx_analyze: the device-side accumulators (histogram, sums, counts)."""
+        v = _Img(img)
+        a = Analysis()
+        self._chk(self._lib.fnx_analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(a)), "fnx_analyze")
+        return self._analysis_dict(a)
+
+    def plan_analyze_batch(self, imgs):
+        """Pre-marshalled fnx_analyze_batch over n same-sized device images: run() -> list of ImageStats dicts."""
+        views = [_Img(t) for t in imgs]
+        if any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("batched ops take device tensors")
+        n, w, h, st = len(views), views[0].w, views[0].h, views[0].stride
+        srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+        res = (Analysis * n)()
+        ctx, lib = self, self._lib
+
+        class _Plan:
+            def __init__(p):
+                p._keep = (imgs, srcs, res)
+                p.raw = res
+
+            def run(p):
+                ctx._chk(lib.fnx_analyze_batch(ctx._h, n, srcs, st, w, h, res), "AnalyzeBatch")
+                return res
+
+            def stats(p):
+                out = []
+                for k in range(n):
+                    s = ImageStats()
+                    lib.fennec_statsFromAnalysis(C.byref(res[k]), w, h, C.byref(s))
+                    out.append(ctx._stats_dict(s))
+                return out
+        return _Plan()
+
+    def AnalyzeBatch(self, imgs):
+        plan = self.plan_analyze_batch(imgs)
+        plan.run()
+        return plan.stats()
+
+    def isOpaque(self, img) -> bool:
+        v = _Img(img)
+        o = C.c_int(0)
+        self._chk(self._lib.fennec_isOpaque(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isOpaque")
+        return bool(o.value)
+
+    def isGrayscale(self, img) -> bool:
+        v = _Img(img)
+        o = C.c_int(0)
+        self._chk(self._lib.fennec_isGrayscale(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isGrayscale")
+        return bool(o.value)
+
     # -- batched forms (device tensors) ---------------------------------------------------
     def GaussianBlurBatch(self, imgs, sigma: float, outs=None, exact: bool = False):
         """n same-sized device images, one launch per stage (enqueued; call sync() to wait)."""
@@ -626,6 +719,7 @@ def ApplyOrientation(img, orient): return default_context(_dev_of(img)).ApplyOri
 def lanczosResize(img, dstW, dstH): return default_context(_dev_of(img)).lanczosResize(img, dstW, dstH)
 def smartResize(img, maxW, maxH): return default_context(_dev_of(img)).smartResize(img, maxW, maxH)
 def boxDownsample(img, dstW, dstH): return default_context(_dev_of(img)).boxDownsample(img, dstW, dstH)
+def Analyze(img): return default_context(_dev_of(img)).Analyze(img)
 
 
 def gaussianKernel(size=8, sigma=1.5):

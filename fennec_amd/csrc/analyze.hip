@@ -1,0 +1,320 @@
+// Analyze (analyze.go:26-124) and the flat scans isOpaque / isGrayscale (convert.go:66-84) on gfx950.
+// SURVEY 8(f) item 3 -- the first row widened after the hot path proper.
+//
+//  * analyze_pass_kernel: THE full-image pass (analyze.go:53-80): luminance histogram
+//    (bin int(lum + 0.5)), luminance sum, has-alpha and all-grey flags.  One 16-byte
+//    non-temporal load = 4 px per lane; fp64 luminance in the reference's operation order
+//    (so every bin is exact); histogram in LDS, one copy per wave; per-workgroup partials
+//    (no global atomics: 1024 workgroups hammering 256 addresses serialise).
+//  * analyze_finish_kernel: column sums of the histogram partials (exact integers), the
+//    brightness partials in a fixed order (bit-reproducible; the reference's own sum is one long
+//    serial fp64 chain, so its last bits are an accident of order -- tolerance 1e-12 relative).
+//  * analyze_sampled_kernel: the three sampled statistics -- distinct colours among every
+//    step-th pixel (device hash set, order-free: the reference only reads len() capped at 1024),
+//    contrast on the <=100x100 grid (needs the mean: runs after the finish), Sobel edge count on
+//    the <=~200x200 grid (integer count; fp64 Sobel + IEEE sqrt in the reference's order: exact).
+#include "common.hpp"
+#include "devutil.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace fnx {
+
+constexpr int AN_WG = 1024;            // workgroups of the full pass per image (4 per CU)
+constexpr int AN_HASH_CAP = 1 << 17;   // >= 2x the 50 000 + colour samples
+
+struct PassArgs2 {
+    const uint8_t *src;
+    const uint8_t *const *srcs;
+    int sstride, w, h;
+    int upr;                 // 4-px units per row (tight images: ONE row of w*h px)
+    uint32_t upr_magic;      // ceil(2^32 / upr)
+    int rows, row_px;        // iteration space: rows x row_px pixels
+    int vec;                 // 16-byte loads allowed
+    long long units;
+    uint32_t *hist_part;     // [n][AN_WG][256]
+    double *bright_part;     // [n][AN_WG]
+    uint32_t *flag_part;     // [n][AN_WG]   bit 0: some alpha < 255, bit 1: some r != g || g != b
+};
+
+__device__ __forceinline__ void an_pixel(uint32_t p, uint32_t *hist, double &bright, uint32_t &flags)
+{
+    const double lum = lum601(p);                              // analyze.go:62
+    bright += lum;
+    atomicAdd(&hist[static_cast<int>(lum + 0.5)], 1u);        // analyze.go:64 (LDS)
+    const uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu;
+    flags |= ((p >> 24) < 255u ? 1u : 0u) | ((r != g || g != b) ? 2u : 0u);
+}
+
+__global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
+{
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ double s_red[4];
+    __shared__ uint32_t s_flag[4];
+    const int tid = threadIdx.x, wave = tid >> 6, z = blockIdx.y;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    for (int i = tid; i < 4 * 256; i += 256) (&s_hist[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t *hist = s_hist[wave];
+    double bright = 0.0;
+    uint32_t flags = 0;
+    for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < a.units; u += static_cast<long long>(AN_WG) * 256) {
+        int y = 0;
+        long long c = u;
+        if (a.rows > 1) {
+            y = __umulhi(static_cast<uint32_t>(u), a.upr_magic);   // u < 2^32 / upr is checked by the host
+            c = u - static_cast<long long>(y) * a.upr;
+        }
+        const long long x = 4 * c;
+        const uint8_t *p = src + static_cast<size_t>(y) * a.sstride + 4 * x;
+        const long long left = a.row_px - x;
+        if (a.vec && left >= 4) {
+            const u32x4 v = ld16_stream(p);
+            an_pixel(v.x, hist, bright, flags);
+            an_pixel(v.y, hist, bright, flags);
+            an_pixel(v.z, hist, bright, flags);
+            an_pixel(v.w, hist, bright, flags);
+        } else {
+            for (int e = 0; e < 4 && e < left; e++) an_pixel(*(g_u32 *)(p + 4 * e), hist, bright, flags);
+        }
+    }
+    // brightness: fixed tree (lane order inside the wave, then waves 0..3)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bright += __shfl_down(bright, off, 64);
+        flags |= __shfl_down(flags, off, 64);
+    }
+    if ((tid & 63) == 0) { s_red[wave] = bright; s_flag[wave] = flags; }
+    __syncthreads();
+    const size_t part = static_cast<size_t>(z) * AN_WG + blockIdx.x;
+    a.hist_part[part * 256 + tid] = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+    if (tid == 0) {
+        a.bright_part[part] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        a.flag_part[part] = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void analyze_finish_kernel(const uint32_t *hist_part, const double *bright_part,
+                                                             const uint32_t *flag_part, fnx_analysis *res)
+{
+    __shared__ double s_b[256];
+    __shared__ uint32_t s_f;
+    const int tid = threadIdx.x, z = blockIdx.x;
+    if (tid == 0) s_f = 0;
+    __syncthreads();
+    unsigned long long cnt = 0;
+    double b = 0.0;
+    uint32_t f = 0;
+    for (int g = 0; g < AN_WG; g++) cnt += hist_part[(static_cast<size_t>(z) * AN_WG + g) * 256 + tid];
+    for (int g = tid; g < AN_WG; g += 256) {
+        b += bright_part[static_cast<size_t>(z) * AN_WG + g];
+        f |= flag_part[static_cast<size_t>(z) * AN_WG + g];
+    }
+    s_b[tid] = b;
+    atomicOr(&s_f, f);
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) s_b[tid] += s_b[tid + off];
+        __syncthreads();
+    }
+    fnx_analysis *r = res + z;
+    r->histogram[tid] = cnt;
+    if (tid == 0) {
+        r->bright_sum = s_b[0];
+        r->has_alpha = s_f & 1u;
+        r->is_grayscale = (s_f & 2u) ? 0 : 1;
+        r->variance_sum = 0.0;
+        r->sample_count = 0;
+        r->edge_count = 0;
+        r->edge_total = 0;
+        r->unique_colors = 0;
+        r->pad = 0;
+    }
+}
+
+struct SampArgs {
+    const uint8_t *src;
+    const uint8_t *const *srcs;
+    int sstride, w, h;
+    long long color_samples, color_step;       // analyze.go:46-50,73-77
+    int color_blocks;
+    int cstep_x, cstep_y, cnx, cny;            // contrast grid (analyze.go:93-109)
+    int estep_x, estep_y, enx, eny;            // edge grid (analyze.go:150-156)
+    unsigned long long *hash;                  // [n][AN_HASH_CAP], zeroed
+    fnx_analysis *res;
+};
+
+__device__ __forceinline__ double sobel_lum(const uint8_t *src, int stride, int x, int y)   // analyze.go:186-189
+{
+    return lum601(*(g_u32 *)(src + static_cast<size_t>(y) * stride + 4 * static_cast<size_t>(x)));
+}
+
+__global__ __launch_bounds__(256) void analyze_sampled_kernel(SampArgs a)
+{
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, z = blockIdx.y, b = blockIdx.x;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    fnx_analysis *r = a.res + z;
+    if (b < a.color_blocks) {                  // ---- sampled colour set
+        const long long k = static_cast<long long>(b) * 256 + tid;
+        if (k >= a.color_samples) return;
+        const long long idx = k * a.color_step;
+        const int y = static_cast<int>(idx / a.w), x = static_cast<int>(idx - static_cast<long long>(y) * a.w);
+        const uint32_t p = *(g_u32 *)(src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x));
+        const unsigned long long key = (1ull << 32) | p;     // any bijection of (r,g,b,a) counts the same
+        unsigned long long *tab = a.hash + static_cast<size_t>(z) * AN_HASH_CAP;
+        uint32_t slot = (p * 2654435761u) >> (32 - 17);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&tab[slot], 0ull, key);
+            if (old == 0ull) { atomicAdd(&r->unique_colors, 1); break; }
+            if (old == key) break;
+            slot = (slot + 1) & (AN_HASH_CAP - 1);
+        }
+    } else if (b == a.color_blocks) {          // ---- contrast: sum (lum - mean)^2 on the fixed grid
+        const double mean = r->bright_sum / static_cast<double>(static_cast<long long>(a.w) * a.h);
+        double v = 0.0;
+        const int total = a.cnx * a.cny;
+        for (int s = tid; s < total; s += 256) {
+            const int iy = s / a.cnx, ix = s - iy * a.cnx;
+            const double d = sobel_lum(src, a.sstride, ix * a.cstep_x, iy * a.cstep_y) - mean;
+            v += d * d;
+        }
+        const double t = block_sum_256(v, s_red);
+        if (tid == 0) {
+            r->variance_sum = t;
+            r->sample_count = total;
+        }
+    } else {                                   // ---- Sobel edge count (analyze.go:158-177)
+        const int s = (b - a.color_blocks - 1) * 256 + tid;
+        bool edge = false;
+        if (s < a.enx * a.eny) {
+            const int iy = s / a.enx, ix = s - iy * a.enx;
+            const int x = 1 + ix * a.estep_x, y = 1 + iy * a.estep_y;
+            const int st = a.sstride;
+            const double gx = sobel_lum(src, st, x + 1, y - 1) - sobel_lum(src, st, x - 1, y - 1) +
+                              2 * sobel_lum(src, st, x + 1, y) - 2 * sobel_lum(src, st, x - 1, y) +
+                              sobel_lum(src, st, x + 1, y + 1) - sobel_lum(src, st, x - 1, y + 1);
+            const double gy = sobel_lum(src, st, x - 1, y + 1) - sobel_lum(src, st, x - 1, y - 1) +
+                              2 * sobel_lum(src, st, x, y + 1) - 2 * sobel_lum(src, st, x, y - 1) +
+                              sobel_lum(src, st, x + 1, y + 1) - sobel_lum(src, st, x + 1, y - 1);
+            edge = sqrt(gx * gx + gy * gy) > 30.0;
+        }
+        const unsigned long long m = __ballot(edge);
+        if ((tid & 63) == 0 && m) atomicAdd(reinterpret_cast<unsigned long long *>(&r->edge_count), static_cast<unsigned long long>(__popcll(m)));
+        if (b == a.color_blocks + 1 && tid == 0) r->edge_total = static_cast<long long>(a.enx) * a.eny;
+    }
+}
+
+// n images (one pointer, or a device pointer array) -> d_res[n] (device).
+int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
+                   bool aligned16_ok, fnx_analysis *d_res)
+{
+    if (n <= 0) return FNX_OK;
+    void *hp = nullptr, *bp = nullptr, *hash = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP0, sizeof(uint32_t) * 256 * AN_WG * static_cast<size_t>(n), &hp));
+    FNX_TRY(scratch(ctx, SLOT_TMP1, (sizeof(double) + sizeof(uint32_t)) * AN_WG * static_cast<size_t>(n) + 16, &bp));
+    FNX_TRY(scratch(ctx, SLOT_TMP3, sizeof(unsigned long long) * AN_HASH_CAP * static_cast<size_t>(n), &hash));
+    FNX_HIP(hipMemsetAsync(hash, 0, sizeof(unsigned long long) * AN_HASH_CAP * static_cast<size_t>(n), ctx->stream));
+
+    PassArgs2 pa{};
+    pa.src = src; pa.srcs = srcs; pa.sstride = sstride; pa.w = w; pa.h = h;
+    pa.hist_part = static_cast<uint32_t *>(hp);
+    pa.bright_part = static_cast<double *>(bp);
+    pa.flag_part = reinterpret_cast<uint32_t *>(pa.bright_part + static_cast<size_t>(AN_WG) * n);
+    if (sstride == 4 * w) {      // tight: one long row
+        pa.rows = 1;
+        pa.row_px = 0;           // set below (64-bit)
+        pa.upr = 1;
+        pa.units = (static_cast<long long>(w) * h + 3) / 4;
+        pa.vec = aligned16_ok;
+    } else {
+        pa.rows = h;
+        pa.upr = (w + 3) / 4;
+        pa.units = static_cast<long long>(pa.upr) * h;
+        pa.vec = aligned16_ok && (sstride & 15) == 0;
+    }
+    pa.upr_magic = static_cast<uint32_t>((0x100000000ull + pa.upr - 1) / pa.upr);
+    if (pa.rows > 1 && pa.units >= (0x100000000ll / pa.upr)) {
+        set_error("image too large for the strided Analyze pass");
+        return FNX_ERR_INVALID;
+    }
+    const long long row_px = pa.rows == 1 ? static_cast<long long>(w) * h : w;
+    if (row_px > 0x7fffffffll) {
+        set_error("image too large for Analyze");
+        return FNX_ERR_INVALID;
+    }
+    pa.row_px = static_cast<int>(row_px);
+    hipLaunchKernelGGL(analyze_pass_kernel, dim3(AN_WG, n), dim3(256), 0, ctx->stream, pa);
+    FNX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(analyze_finish_kernel, dim3(n), dim3(256), 0, ctx->stream, pa.hist_part, pa.bright_part,
+                       pa.flag_part, d_res);
+    FNX_HIP(hipGetLastError());
+
+    SampArgs sa{};
+    sa.src = src; sa.srcs = srcs; sa.sstride = sstride; sa.w = w; sa.h = h;
+    const long long total = static_cast<long long>(w) * h;
+    sa.color_step = total > 50000 ? total / 50000 : 1;                 // analyze.go:46-50
+    sa.color_samples = (total + sa.color_step - 1) / sa.color_step;    // idx % step == 0, idx < total
+    sa.color_blocks = static_cast<int>((sa.color_samples + 255) / 256);
+    sa.cstep_y = static_cast<int>(std::fmax(1.0, std::ceil(static_cast<double>(h) / 100)));   // analyze.go:93-94
+    sa.cstep_x = static_cast<int>(std::fmax(1.0, std::ceil(static_cast<double>(w) / 100)));
+    sa.cny = (h + sa.cstep_y - 1) / sa.cstep_y;
+    sa.cnx = (w + sa.cstep_x - 1) / sa.cstep_x;
+    int eblocks = 0;
+    if (w >= 3 && h >= 3) {                                            // analyze.go:146-151
+        sa.estep_x = static_cast<int>(std::fmax(1.0, static_cast<double>(w) / 200));
+        sa.estep_y = static_cast<int>(std::fmax(1.0, static_cast<double>(h) / 200));
+        sa.enx = (w - 2 + sa.estep_x - 1) / sa.estep_x;
+        sa.eny = (h - 2 + sa.estep_y - 1) / sa.estep_y;
+        eblocks = (sa.enx * sa.eny + 255) / 256;
+    }
+    sa.hash = static_cast<unsigned long long *>(hash);
+    sa.res = d_res;
+    hipLaunchKernelGGL(analyze_sampled_kernel, dim3(sa.color_blocks + 1 + eblocks, n), dim3(256), 0, ctx->stream, sa);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// isOpaque / isGrayscale (convert.go:66-84): flat scans of Pix, row padding included
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_flags_kernel(const uint8_t *pix, long long npx, int vec, uint32_t *out)
+{
+    uint32_t flags = 0;
+    const long long units = (npx + 3) / 4;
+    for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+        const long long x = 4 * u;
+        const uint8_t *p = pix + 4 * x;
+        uint32_t v[4];
+        int cnt = npx - x >= 4 ? 4 : static_cast<int>(npx - x);
+        if (vec && cnt == 4) {
+            const u32x4 q = ld16_stream(p);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (int e = 0; e < cnt; e++) v[e] = *(g_u32 *)(p + 4 * e);
+        }
+        for (int e = 0; e < cnt; e++) {
+            const uint32_t r = v[e] & 0xffu, g = (v[e] >> 8) & 0xffu, b = (v[e] >> 16) & 0xffu;
+            flags |= ((v[e] >> 24) != 0xffu ? 1u : 0u) | ((r != g || g != b) ? 2u : 0u);
+        }
+    }
+    if (__ballot(flags & 1u) && (threadIdx.x & 63) == 0) atomicOr(out, 1u);
+    if (__ballot(flags & 2u) && (threadIdx.x & 63) == 0) atomicOr(out, 2u);
+}
+
+// d_flags (device, one uint32): bit 0 = some alpha != 255, bit 1 = some pixel not grey
+int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags)
+{
+    FNX_HIP(hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
+    const long long npx = static_cast<long long>(pix_len / 4);
+    if (npx == 0) return FNX_OK;
+    const long long units = (npx + 3) / 4;
+    const int blocks = static_cast<int>(std::min<long long>((units + 255) / 256, 4LL * ctx->num_cus));
+    hipLaunchKernelGGL(scan_flags_kernel, dim3(blocks), dim3(256), 0, ctx->stream, pix, npx,
+                       (reinterpret_cast<uintptr_t>(pix) & 15u) == 0 ? 1 : 0, d_flags);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+}  // namespace fnx

@@ -627,6 +627,79 @@ void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
     delete p;
 }
 
+// ---- Analyze (analyze.go:26-124) and the flat scans (convert.go:66-84) --------------------
+static void clamp_unique(fnx_analysis *a, int n)
+{
+    for (int i = 0; i < n; i++)
+        if (a[i].unique_colors > 1024) a[i].unique_colors = 1024;   // len(colorSet) < 1024 gate, analyze.go:73
+}
+
+int fnx_analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, fnx_analysis *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(out != nullptr, "out is null");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    std::memset(out, 0, sizeof(*out));
+    if (w <= 0 || h <= 0) return FNX_EMPTY;      // Analyze returns the zero ImageStats (analyze.go:37-39)
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    void *dres = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_RESULT, sizeof(fnx_analysis), &dres));
+    FNX_TRY(launch_analyze(ctx, 1, s.p, nullptr, s.stride, w, h, (reinterpret_cast<uintptr_t>(s.p) & 15u) == 0,
+                           static_cast<fnx_analysis *>(dres)));
+    FNX_TRY(fetch_bytes(ctx, dres, out, sizeof(fnx_analysis)));
+    clamp_unique(out, 1);
+    return FNX_OK;
+}
+
+int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
+                      fnx_analysis *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(n >= 0 && srcs && out, "batch arguments");
+    if (n == 0) return FNX_OK;
+    FNX_REQUIRE(w > 0 && h > 0 && sstride >= 4 * w && !(sstride & 3), "dims");
+    bool al = true;
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(srcs[i], "null image in batch");
+        al = al && !(reinterpret_cast<uintptr_t>(srcs[i]) & 15);
+    }
+    void *dp = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_PTRS, srcs, sizeof(void *) * size_t(n), &dp));
+    void *dres = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_RESULT, sizeof(fnx_analysis) * size_t(n), &dres));
+    FNX_TRY(launch_analyze(ctx, n, nullptr, static_cast<const uint8_t *const *>(dp), sstride, w, h, al,
+                           static_cast<fnx_analysis *>(dres)));
+    FNX_TRY(fetch_bytes(ctx, dres, out, sizeof(fnx_analysis) * size_t(n)));
+    clamp_unique(out, n);
+    return FNX_OK;
+}
+
+int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, int *is_opaque, int *is_grayscale)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(pix != nullptr || pix_len == 0, "pix is null");
+    uint32_t flags = 0;
+    if (pix_len >= 4) {
+        const uint8_t *d = pix;
+        if (space == FNX_HOST) {
+            void *t = nullptr;
+            FNX_TRY(scratch(ctx, SLOT_IN_A, pix_len + 16, &t));
+            FNX_HIP(hipMemcpyAsync(t, pix, pix_len, hipMemcpyHostToDevice, ctx->stream));
+            d = static_cast<const uint8_t *>(t);
+        }
+        void *df = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_RESULT, 16, &df));
+        FNX_TRY(launch_scan_flags(ctx, d, pix_len, static_cast<uint32_t *>(df)));
+        FNX_TRY(fetch_bytes(ctx, df, &flags, sizeof(flags)));
+    }
+    if (is_opaque) *is_opaque = (flags & 1u) ? 0 : 1;
+    if (is_grayscale) *is_grayscale = (flags & 2u) ? 0 : 1;
+    return FNX_OK;
+}
+
 // ---- orientation -------------------------------------------------------------------------
 int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int orient,
                uint8_t *dst, int dstride)

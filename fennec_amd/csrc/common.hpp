@@ -144,6 +144,7 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
 int finish(fnx_ctx *ctx, int space, DevOut *out);
 // Fetch n doubles from device memory into host memory (synchronises).
 int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n);
+int fetch_bytes(fnx_ctx *ctx, const void *dptr, void *host, size_t bytes);
 
 inline bool aligned16(const void *p, int stride)
 {
@@ -185,6 +186,11 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
                          const double *h_window, const double *d_window, double *d_out);
 int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
                       size_t pix_len, double *d_out);
+// Analyze's device side (analyze.hip): n images -> d_res[n]; aligned16_ok: every base pointer is 16-byte aligned
+int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
+                   bool aligned16_ok, fnx_analysis *d_res);
+// flat Pix scan: *d_flags bit 0 = some alpha != 255, bit 1 = some pixel with r != g or g != b
+int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
                   uint8_t *dst, int dstride);
 

@@ -69,6 +69,20 @@ __device__ __forceinline__ double u8_to_f64(uint32_t v)
     return __hiloint2double(0x43300000, static_cast<int>(v)) - 4503599627370496.0;
 }
 
+// sum over a 256-lane workgroup, result valid in thread 0 (s_red: 4 doubles of LDS)
+__device__ __forceinline__ double block_sum_256(double v, double *s_red)
+{
+    // fixed-shape tree => bit-reproducible from run to run
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    return t;
+}
+
 // boxDownsample's source range of output index d (ssim.go:262-275)
 __host__ __device__ __forceinline__ void box_edge(int d, double ratio, int srcN, int &s0, int &s1)
 {

@@ -4,6 +4,7 @@
 // here: every image operation is a fnx_* call (HIP kernels); there is no CPU path.
 #include <array>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <utility>
@@ -315,6 +316,79 @@ double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
     out4[2] = nfailed;
     out4[3] = saved;
     return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
+}
+
+// ---- Analyze (analyze.go:26-230) -----------------------------------------------------------
+void fennec_statsFromAnalysis(const fnx_analysis *a, int w, int h, fennec_ImageStats *st)
+{
+    std::memset(st, 0, sizeof(*st));
+    st->Width = w;
+    st->Height = h;
+    if (w <= 0 || h <= 0 || !a) return;
+    const double n = double(static_cast<long long>(w) * h);
+    st->HasAlpha = a->has_alpha;
+    st->IsGrayscale = a->is_grayscale;
+    st->UniqueColors = a->unique_colors;
+    st->MeanBrightness = a->bright_sum / n;                                   // analyze.go:90
+    if (a->sample_count > 0) st->Contrast = std::sqrt(a->variance_sum / double(a->sample_count));   // :111-113
+    double entropy = 0;                                                       // computeEntropy, :127-139
+    for (int i = 0; i < 256; i++) {
+        const double count = double(a->histogram[i]);
+        if (count > 0) {
+            const double p = count / n;
+            entropy -= p * std::log2(p);
+        }
+    }
+    st->Entropy = entropy;
+    if (a->edge_total > 0) st->EdgeDensity = double(a->edge_count) / double(a->edge_total);   // :180-183
+    // recommendFormat (:191-202)
+    if (st->HasAlpha) st->RecommendedFormat = 2;
+    else if (st->UniqueColors <= 256) st->RecommendedFormat = 2;
+    else if (st->EdgeDensity > 0.3 && st->UniqueColors < 1000) st->RecommendedFormat = 2;
+    else st->RecommendedFormat = 1;
+    // recommendQuality (:204-215)
+    if (st->Entropy > 6 && st->EdgeDensity < 0.15) st->RecommendedQuality = 0;
+    else if (st->Entropy < 4) st->RecommendedQuality = 4;
+    else if (st->EdgeDensity > 0.25) st->RecommendedQuality = 3;
+    else st->RecommendedQuality = 0;
+    // estimateCompression (:217-230)
+    if (st->RecommendedFormat == 2) {
+        if (st->UniqueColors <= 256) st->EstimatedCompression = 5.0 + (256 - double(st->UniqueColors)) / 50;
+        else if (st->IsGrayscale) st->EstimatedCompression = 3.0;
+        else st->EstimatedCompression = 2.0;
+    } else {
+        double base = 10.0;
+        if (st->Entropy > 7) base = 5.0;
+        else if (st->Entropy > 5) base = 8.0;
+        if (st->EdgeDensity > 0.2) base *= 0.7;
+        st->EstimatedCompression = base;
+    }
+}
+
+int fennec_Analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, fennec_ImageStats *out)
+{
+    if (!out) return FNX_ERR_INVALID;
+    fnx_analysis a;
+    const int rc = fnx_analyze(ctx, space, src, sstride, w, h, &a);
+    if (rc < 0) return rc;
+    fennec_statsFromAnalysis(&a, w, h, out);
+    return rc;
+}
+
+static int flat_scan(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int *opaque, int *gray)
+{
+    const size_t len = (w > 0 && h > 0) ? size_t(h - 1) * size_t(sstride) + size_t(w) * 4 : 0;   // image.NRGBA Pix of a (sub)image
+    return fnx_scan_flags(ctx, space, src, len, opaque, gray);
+}
+
+int fennec_isOpaque(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int *out)
+{
+    return flat_scan(ctx, space, src, sstride, w, h, out, nullptr);
+}
+
+int fennec_isGrayscale(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int *out)
+{
+    return flat_scan(ctx, space, src, sstride, w, h, nullptr, out);
 }
 
 }  // extern "C"

@@ -172,14 +172,19 @@ int finish(fnx_ctx *ctx, int space, DevOut *out)
     return FNX_OK;
 }
 
-int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n)
+int fetch_bytes(fnx_ctx *ctx, const void *dptr, void *host, size_t bytes)
 {
     void *pin = nullptr;
-    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n), &pin));
-    FNX_HIP(hipMemcpyAsync(pin, dptr, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
+    FNX_TRY(pinned_alloc(ctx, bytes, &pin));
+    FNX_HIP(hipMemcpyAsync(pin, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     FNX_HIP(hipStreamSynchronize(ctx->stream));
-    std::memcpy(host, pin, sizeof(double) * size_t(n));
+    std::memcpy(host, pin, bytes);
     return FNX_OK;
+}
+
+int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n)
+{
+    return fetch_bytes(ctx, dptr, host, sizeof(double) * size_t(n));
 }
 
 }  // namespace fnx

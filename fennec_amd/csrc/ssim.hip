@@ -235,19 +235,6 @@ struct WinArgs {
     double *partial;       // [n][tiles]
 };
 
-__device__ __forceinline__ double block_sum_256(double v, double *s_red)
-{
-    // fixed-shape tree => bit-reproducible from run to run
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) s_red[wave] = v;
-    __syncthreads();
-    double t = 0;
-    if (threadIdx.x == 0) t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-    return t;
-}
-
 __global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
 {
     constexpr int LW = WS_TX + 7, LH = WS_TY + 7;

@@ -204,10 +204,56 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
                                               int radius, int flags, uint8_t *const *dsts,
                                               int dstride, const double *window);
 
+/* ---- Analyze (analyze.go:26-124), SURVEY 8(f) item 3 ---------------------- */
+/* What the device computes: every statistic that needs the pixels.  The float
+ * epilogue (computeEntropy, sqrt, the recommend* rules, analyze.go:87-230) is a
+ * few hundred flops on these numbers and stays with the caller -- Go computes it
+ * with its own math.Log2, fennec_Analyze below with libm. */
+typedef struct fnx_analysis {
+    uint64_t histogram[256]; /* luminance histogram, bin int(lum + 0.5), all pixels: exact */
+    double bright_sum;       /* sum of luminance over all pixels (summation order differs from
+                                the reference's serial loop: <= 1e-12 relative) */
+    double variance_sum;     /* sum (lum - mean)^2 over the <=100x100 contrast grid (same remark) */
+    int64_t sample_count;    /* points of that grid */
+    int64_t edge_count;      /* Sobel magnitude > 30 on the sampled grid: exact */
+    int64_t edge_total;
+    int32_t unique_colors;   /* len(colorSet): distinct colours among every step-th pixel, capped 1024 */
+    int32_t has_alpha;       /* some alpha < 255 */
+    int32_t is_grayscale;    /* every pixel r == g == b */
+    int32_t pad;
+} fnx_analysis;
+int fnx_analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                fnx_analysis *out /* host */);
+/* n same-sized device images (HOST array of device pointers), one launch per stage. */
+int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
+                      fnx_analysis *out /* n, host */);
+/* isOpaque / isGrayscale (convert.go:66-84): both walk the FLAT Pix slice (pix_len bytes, row
+ * padding included), one pass answers both. */
+int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, int *is_opaque,
+                   int *is_grayscale);
+
 /* ======================================================================= */
 /* fennec_* : the reference's function set (names and argument meaning as in
  * the Go source), mirrored above fnx_*.                                     */
 /* ======================================================================= */
+
+/* ImageStats (analyze.go:9-22); Format: 1 JPEG, 2 PNG (types.go:35-42); Quality: 0 Balanced,
+ * 3 High, 4 Aggressive (types.go:59-72). */
+typedef struct fennec_ImageStats {
+    int32_t Width, Height;
+    int32_t HasAlpha, IsGrayscale, UniqueColors;
+    int32_t RecommendedFormat, RecommendedQuality, pad;
+    double Entropy, EdgeDensity, MeanBrightness, Contrast, EstimatedCompression;
+} fennec_ImageStats;
+/* Analyze (analyze.go:26-124). */
+int fennec_Analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                   fennec_ImageStats *out);
+/* The float epilogue alone: computeEntropy, contrast, edge density, recommendFormat,
+ * recommendQuality, estimateCompression (analyze.go:87-230) from the device's numbers. */
+void fennec_statsFromAnalysis(const fnx_analysis *a, int w, int h, fennec_ImageStats *out);
+/* isOpaque / isGrayscale (convert.go:66-84) of an image (flat Pix: (h-1)*stride + 4*w bytes). */
+int fennec_isOpaque(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int *out);
+int fennec_isGrayscale(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int *out);
 
 /* gaussianKernel(size, sigma) (ssim.go:223-241): size*size doubles. */
 void fennec_gaussianKernel(int size, double sigma, double *kernel);

@@ -1001,3 +1001,234 @@ ORC_API double orc_summarize(int n, const int *failed, const int *has_result,
     out[3] = saved;
     return succeeded > 0 ? ssimSum / (double)succeeded : 0.0;
 }
+
+/* ================================================================== */
+/* Analyze (analyze.go:26-176) and the scans of convert.go:66-146      */
+/* the first row widened after (a)-(e).            */
+/* ================================================================== */
+
+/* Insertion-only set of uint32 keys, standing in for Go's map[uint32]struct{}:
+ * only len() is observable (analyze.go:73-76, convert.go:121-133). */
+typedef struct {
+    uint64_t *slot; /* 0 = empty, else key + 1 */
+    int cap, len;
+} orc_set;
+
+static int orc_set_init(orc_set *s, int cap)
+{
+    s->slot = (uint64_t *)calloc((size_t)cap, sizeof(uint64_t));
+    s->cap = cap;
+    s->len = 0;
+    return s->slot != NULL;
+}
+
+static void orc_set_add(orc_set *s, uint32_t key)
+{
+    uint32_t h = (key * 2654435761u) & (uint32_t)(s->cap - 1);
+    while (s->slot[h]) {
+        if (s->slot[h] == (uint64_t)key + 1) return;
+        h = (h + 1) & (uint32_t)(s->cap - 1);
+    }
+    s->slot[h] = (uint64_t)key + 1;
+    s->len++;
+}
+
+typedef struct {
+    int32_t width, height;
+    int32_t has_alpha, is_grayscale, unique_colors;
+    int32_t recommended_format;   /* types.go:35-42: 0 Auto, 1 JPEG, 2 PNG */
+    int32_t recommended_quality;  /* types.go:59-72: 0 Balanced, 1 Lossless, 2 Ultra, 3 High, 4 Aggressive, 5 Maximum */
+    int32_t pad;
+    double entropy, edge_density, mean_brightness, contrast, estimated_compression;
+    /* raw accumulators, exposed so that tests can compare the device's integer outputs exactly */
+    double histogram[256];
+    double bright_sum, variance_sum;
+    int64_t sample_count, edge_count, edge_total;
+} orc_image_stats;
+
+/* sobelLum (analyze.go:186-189) */
+static double sobel_lum(const uint8_t *pix, int stride, int x, int y)
+{
+    const uint8_t *p = pix + (size_t)y * stride + (size_t)x * 4;
+    return 0.299 * (double)p[0] + 0.587 * (double)p[1] + 0.114 * (double)p[2];
+}
+
+/* computeEntropy (analyze.go:127-139); log2 is libm's (Go: math.Log2) */
+ORC_API double orc_compute_entropy(const double *histogram, int n, double total)
+{
+    if (total == 0) return 0;
+    double entropy = 0;
+    for (int i = 0; i < n; i++) {
+        double count = histogram[i];
+        if (count > 0) {
+            double p = count / total;
+            entropy -= p * log2(p);
+        }
+    }
+    return entropy;
+}
+
+/* recommendFormat / recommendQuality / estimateCompression (analyze.go:191-230) */
+ORC_API void orc_recommend(orc_image_stats *s)
+{
+    if (s->has_alpha) s->recommended_format = 2;
+    else if (s->unique_colors <= 256) s->recommended_format = 2;
+    else if (s->edge_density > 0.3 && s->unique_colors < 1000) s->recommended_format = 2;
+    else s->recommended_format = 1;
+
+    if (s->entropy > 6 && s->edge_density < 0.15) s->recommended_quality = 0;
+    else if (s->entropy < 4) s->recommended_quality = 4;
+    else if (s->edge_density > 0.25) s->recommended_quality = 3;
+    else s->recommended_quality = 0;
+
+    if (s->recommended_format == 2) {
+        if (s->unique_colors <= 256) s->estimated_compression = 5.0 + (256 - (double)s->unique_colors) / 50;
+        else if (s->is_grayscale) s->estimated_compression = 3.0;
+        else s->estimated_compression = 2.0;
+    } else {
+        double base = 10.0;
+        if (s->entropy > 7) base = 5.0;
+        else if (s->entropy > 5) base = 8.0;
+        if (s->edge_density > 0.2) base *= 0.7;
+        s->estimated_compression = base;
+    }
+}
+
+/* Analyze (analyze.go:26-124), computeEdgeDensity (analyze.go:142-184) */
+ORC_API int orc_analyze(const uint8_t *pix, int stride, int w, int h, orc_image_stats *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->width = w;
+    st->height = h;
+    if (w == 0 || h == 0) return 0;
+
+    /* single pass: colour info, brightness, alpha (analyze.go:41-85) */
+    double brightSum = 0;
+    orc_set colors;
+    if (!orc_set_init(&colors, 4096)) return -1;
+    int maxSample = 50000, step = 1;
+    if ((long long)w * h > maxSample) step = (int)((long long)w * h / maxSample);
+    int allGray = 1, hasAlpha = 0;
+    long long idx = 0;
+    for (int y = 0; y < h; y++) {
+        size_t off = (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            size_t i = off + (size_t)x * 4;
+            uint8_t r = pix[i], g = pix[i + 1], b = pix[i + 2], a = pix[i + 3];
+            double lum = 0.299 * (double)r + 0.587 * (double)g + 0.114 * (double)b;
+            brightSum += lum;
+            st->histogram[(int)(lum + 0.5)]++;
+            if (a < 255) hasAlpha = 1;
+            if (r != g || g != b) allGray = 0;
+            if (idx % step == 0 && colors.len < 1024) {
+                uint32_t key = (uint32_t)r << 24 | (uint32_t)g << 16 | (uint32_t)b << 8 | (uint32_t)a;
+                orc_set_add(&colors, key);
+            }
+            idx++;
+        }
+    }
+    double n = (double)((long long)w * h);
+    st->has_alpha = hasAlpha;
+    st->is_grayscale = allGray;
+    st->unique_colors = colors.len;
+    free(colors.slot);
+    st->bright_sum = brightSum;
+    st->mean_brightness = brightSum / n;
+
+    /* contrast on a fixed grid (analyze.go:93-113) */
+    int stepY = (int)fmax(1, ceil((double)h / 100));
+    int stepX = (int)fmax(1, ceil((double)w / 100));
+    double varianceSum = 0, mean = st->mean_brightness;
+    int64_t sampleCount = 0;
+    for (int y = 0; y < h; y += stepY) {
+        size_t off = (size_t)y * stride;
+        for (int x = 0; x < w; x += stepX) {
+            size_t i = off + (size_t)x * 4;
+            double lum = 0.299 * (double)pix[i] + 0.587 * (double)pix[i + 1] + 0.114 * (double)pix[i + 2];
+            double d = lum - mean;
+            varianceSum += d * d;
+            sampleCount++;
+        }
+    }
+    st->variance_sum = varianceSum;
+    st->sample_count = sampleCount;
+    if (sampleCount > 0) st->contrast = sqrt(varianceSum / (double)sampleCount);
+
+    st->entropy = orc_compute_entropy(st->histogram, 256, n);
+
+    /* computeEdgeDensity (analyze.go:142-184) */
+    if (w >= 3 && h >= 3) {
+        int sX = (int)fmax(1, (double)w / 200), sY = (int)fmax(1, (double)h / 200);
+        int64_t edgeCount = 0, totalCount = 0;
+        double threshold = 30.0;
+        for (int y = 1; y < h - 1; y += sY) {
+            for (int x = 1; x < w - 1; x += sX) {
+                double gx = sobel_lum(pix, stride, x + 1, y - 1) - sobel_lum(pix, stride, x - 1, y - 1) +
+                            2 * sobel_lum(pix, stride, x + 1, y) - 2 * sobel_lum(pix, stride, x - 1, y) +
+                            sobel_lum(pix, stride, x + 1, y + 1) - sobel_lum(pix, stride, x - 1, y + 1);
+                double gy = sobel_lum(pix, stride, x - 1, y + 1) - sobel_lum(pix, stride, x - 1, y - 1) +
+                            2 * sobel_lum(pix, stride, x, y + 1) - 2 * sobel_lum(pix, stride, x, y - 1) +
+                            sobel_lum(pix, stride, x + 1, y + 1) - sobel_lum(pix, stride, x + 1, y - 1);
+                double mag = sqrt(gx * gx + gy * gy);
+                if (mag > threshold) edgeCount++;
+                totalCount++;
+            }
+        }
+        st->edge_count = edgeCount;
+        st->edge_total = totalCount;
+        if (totalCount > 0) st->edge_density = (double)edgeCount / (double)totalCount;
+    }
+    orc_recommend(st);
+    return 0;
+}
+
+/* isOpaque (convert.go:66-74): walks the FLAT Pix slice, row padding included */
+ORC_API int orc_is_opaque(const uint8_t *pix, size_t pix_len)
+{
+    for (size_t i = 3; i < pix_len; i += 4)
+        if (pix[i] != 0xff) return 0;
+    return 1;
+}
+
+/* isGrayscale (convert.go:76-84): flat Pix as well */
+ORC_API int orc_is_grayscale(const uint8_t *pix, size_t pix_len)
+{
+    for (size_t i = 0; i + 2 < pix_len; i += 4)
+        if (pix[i] != pix[i + 1] || pix[i + 1] != pix[i + 2]) return 0;
+    return 1;
+}
+
+/* analyzeFormat (convert.go:105-146): 1 JPEG, 2 PNG.  The scan stops once 512 distinct sampled
+ * colours were seen, so has-alpha only covers the samples before that point. */
+ORC_API int orc_analyze_format(const uint8_t *pix, int stride, int w, int h)
+{
+    int hasAlpha = 0;
+    orc_set colors;
+    if (!orc_set_init(&colors, 2048)) return -1;
+    int maxSamples = 10000, step = 1;
+    long long total = (long long)w * h;
+    if (total > maxSamples) {
+        step = (int)(total / maxSamples);
+        if (step < 1) step = 1;
+    }
+    long long idx = 0;
+    for (int y = 0; y < h && colors.len < 512; y++) {
+        for (int x = 0; x < w && colors.len < 512; x++) {
+            if (idx % step != 0) {
+                idx++;
+                continue;
+            }
+            size_t off = (size_t)y * stride + (size_t)x * 4;
+            uint8_t a = pix[off + 3];
+            if (a < 255) hasAlpha = 1;
+            uint32_t key = (uint32_t)pix[off] << 24 | (uint32_t)pix[off + 1] << 16 | (uint32_t)pix[off + 2] << 8 | a;
+            orc_set_add(&colors, key);
+            idx++;
+        }
+    }
+    int ncolors = colors.len;
+    free(colors.slot);
+    if (hasAlpha) return 2;
+    if (ncolors < 256) return 2;
+    return 1;
+}

@@ -89,8 +89,29 @@ def lib() -> C.CDLL:
         L.orc_apply_orientation.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p]
         L.orc_summarize.restype = C.c_double
         L.orc_summarize.argtypes = [C.c_int, _i32p, _i32p, _i64p, _i64p, _f64p, _i64p]
+        L.orc_analyze.restype = C.c_int
+        L.orc_analyze.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(ImageStats)]
+        L.orc_compute_entropy.restype = C.c_double
+        L.orc_compute_entropy.argtypes = [_f64p, C.c_int, C.c_double]
+        L.orc_is_opaque.restype = C.c_int
+        L.orc_is_opaque.argtypes = [_u8p, C.c_size_t]
+        L.orc_is_grayscale.restype = C.c_int
+        L.orc_is_grayscale.argtypes = [_u8p, C.c_size_t]
+        L.orc_analyze_format.restype = C.c_int
+        L.orc_analyze_format.argtypes = [_u8p, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
+
+
+class ImageStats(C.Structure):
+    """orc_image_stats: ImageStats (analyze.go:9-22) plus the raw accumulators."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("has_alpha", C.c_int32),
+                ("is_grayscale", C.c_int32), ("unique_colors", C.c_int32),
+                ("recommended_format", C.c_int32), ("recommended_quality", C.c_int32), ("pad", C.c_int32),
+                ("entropy", C.c_double), ("edge_density", C.c_double), ("mean_brightness", C.c_double),
+                ("contrast", C.c_double), ("estimated_compression", C.c_double),
+                ("histogram", C.c_double * 256), ("bright_sum", C.c_double), ("variance_sum", C.c_double),
+                ("sample_count", C.c_int64), ("edge_count", C.c_int64), ("edge_total", C.c_int64)]
 
 
 # ---------------------------------------------------------------- helpers
@@ -306,3 +327,37 @@ def summarize(failed, has_result, original_size, compressed_size, ssim_vals):
                               out.ctypes.data_as(_i64p))
     return dict(Total=int(out[0]), Succeeded=int(out[1]), Failed=int(out[2]),
                 TotalSaved=int(out[3]), AvgSSIM=float(avg))
+
+
+def analyze(img: np.ndarray) -> dict:
+    """Analyze (analyze.go:26-124) -> dict of ImageStats fields + raw accumulators."""
+    p, s, w, h = _img(img)
+    st = ImageStats()
+    if lib().orc_analyze(p, s, w, h, C.byref(st)) != 0:
+        raise MemoryError("orc_analyze")
+    d = {name: getattr(st, name) for name, _ in ImageStats._fields_ if name not in ("pad", "histogram")}
+    d["histogram"] = np.array(st.histogram[:], dtype=np.float64)
+    return d
+
+
+def _flat(img: np.ndarray):
+    """the flat Pix slice: (h-1)*stride + 4*w bytes for a strided view, all of it when tight"""
+    p, s, w, h = _img(img)
+    n = (h - 1) * s + 4 * w if h > 0 and w > 0 else 0
+    return p, n
+
+
+def is_opaque(img: np.ndarray) -> bool:
+    p, n = _flat(img)
+    return bool(lib().orc_is_opaque(p, n))
+
+
+def is_grayscale(img: np.ndarray) -> bool:
+    p, n = _flat(img)
+    return bool(lib().orc_is_grayscale(p, n))
+
+
+def analyze_format(img: np.ndarray) -> int:
+    """analyzeFormat (convert.go:105-146): 1 = JPEG, 2 = PNG."""
+    p, s, w, h = _img(img)
+    return int(lib().orc_analyze_format(p, s, w, h))

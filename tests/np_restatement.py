@@ -425,3 +425,84 @@ def apply_orientation(img, orient):
     if orient == 8:
         return rot270(img)
     return img
+
+
+# ------------------------------------------------------------------ analyze.go / convert.go scans
+def analyze(img):
+    """Analyze (analyze.go:26-124) + computeEdgeDensity (analyze.go:142-184): dict of the
+    ImageStats fields and raw accumulators (entropy / recommendations left to the caller)."""
+    h, w = img.shape[:2]
+    out = dict(width=w, height=h)
+    if w == 0 or h == 0:
+        return out
+    px = img.reshape(-1, 4)
+    r, g, b, a = (px[:, k] for k in range(4))
+    lum = (0.299 * r.astype(np.float64) + 0.587 * g.astype(np.float64)) + 0.114 * b.astype(np.float64)
+    out["bright_sum"] = seq_sum(lum)                       # brightSum += lum, raster order
+    out["histogram"] = np.bincount((lum + 0.5).astype(np.int64), minlength=256).astype(np.float64)
+    out["has_alpha"] = int(np.any(a < 255))
+    out["is_grayscale"] = int(np.all((r == g) & (g == b)))
+    step = 1
+    if w * h > 50000:
+        step = w * h // 50000
+    keys = (px[::step].astype(np.uint32) << np.array([24, 16, 8, 0], dtype=np.uint32)).sum(axis=1, dtype=np.uint32)
+    # the set stops growing at 1024 entries; before that it holds every distinct sampled key
+    out["unique_colors"] = min(1024, len(np.unique(keys)))
+    n = float(w * h)
+    mean = out["bright_sum"] / n
+    out["mean_brightness"] = mean
+    step_y = int(max(1, math.ceil(h / 100)))
+    step_x = int(max(1, math.ceil(w / 100)))
+    grid = img[::step_y, ::step_x].astype(np.float64)
+    glum = (0.299 * grid[..., 0] + 0.587 * grid[..., 1]) + 0.114 * grid[..., 2]
+    d = glum - mean
+    out["variance_sum"] = seq_sum(d * d)
+    out["sample_count"] = int(d.size)
+    out["contrast"] = math.sqrt(out["variance_sum"] / d.size)
+    out["edge_count"] = out["edge_total"] = 0
+    out["edge_density"] = 0.0
+    if w >= 3 and h >= 3:
+        sx = int(max(1, w / 200))
+        sy = int(max(1, h / 200))
+        L = to_luminance(img)
+        ys = np.arange(1, h - 1, sy)[:, None]
+        xs = np.arange(1, w - 1, sx)[None, :]
+        gx = ((((L[ys - 1, xs + 1] - L[ys - 1, xs - 1]) + 2 * L[ys, xs + 1]) - 2 * L[ys, xs - 1]) +
+              L[ys + 1, xs + 1]) - L[ys + 1, xs - 1]
+        gy = ((((L[ys + 1, xs - 1] - L[ys - 1, xs - 1]) + 2 * L[ys + 1, xs]) - 2 * L[ys - 1, xs]) +
+              L[ys + 1, xs + 1]) - L[ys - 1, xs + 1]
+        mag = np.sqrt(gx * gx + gy * gy)
+        out["edge_count"] = int(np.count_nonzero(mag > 30.0))
+        out["edge_total"] = int(mag.size)
+        out["edge_density"] = out["edge_count"] / out["edge_total"]
+    return out
+
+
+def is_opaque(img):
+    """convert.go:66-74 on a tight image"""
+    return bool(np.all(img[..., 3] == 255))
+
+
+def is_grayscale(img):
+    """convert.go:76-84 on a tight image"""
+    return bool(np.all((img[..., 0] == img[..., 1]) & (img[..., 1] == img[..., 2])))
+
+
+def analyze_format(img):
+    """analyzeFormat (convert.go:105-146): 1 JPEG, 2 PNG"""
+    h, w = img.shape[:2]
+    step = 1
+    if w * h > 10000:
+        step = max(1, w * h // 10000)
+    px = img.reshape(-1, 4)[::step]
+    seen = set()
+    has_alpha = False
+    for p in px:                       # order matters: the scan stops at 512 distinct colours
+        if len(seen) >= 512:
+            break
+        if p[3] < 255:
+            has_alpha = True
+        seen.add(bytes(p))
+    if has_alpha or len(seen) < 256:
+        return 2
+    return 1

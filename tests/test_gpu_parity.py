@@ -486,3 +486,90 @@ def test_device_views_at_4_byte_alignment(ctx, orc):
         assert np.array_equal(sm.cpu().numpy(), orc.box_downsample(sub_h, max((x1 - x0) // 3, 1), max((y1 - y0) // 3, 1)))
         rs = ctx.lanczosResize(sub_d, 200, 100); ctx.sync()
         assert np.array_equal(rs.cpu().numpy(), orc.lanczos_resize(sub_h, 200, 100, procs=8))
+
+
+# ------------------------------------------------------------------ Analyze (analyze.go), SURVEY 8(f).3
+ANALYZE_REL = 1e-12        # sums whose order differs from the reference's serial loop
+
+
+def _check_analysis(raw, st, want):
+    """raw = fnx_analyze's accumulators, st = ImageStats dict, want = oracle."""
+    assert np.array_equal(raw["histogram"].astype(np.float64), want["histogram"])      # exact
+    for k in ("has_alpha", "is_grayscale", "unique_colors", "sample_count", "edge_count", "edge_total"):
+        assert raw[k] == want[k], k
+    assert abs(raw["bright_sum"] - want["bright_sum"]) <= ANALYZE_REL * abs(want["bright_sum"])
+    # (lum - mean)^2 terms inherit the mean's last-bit difference: absolute floor for flat images
+    assert abs(raw["variance_sum"] - want["variance_sum"]) <= 1e-9 * abs(want["variance_sum"]) + 1e-6
+    assert (st["Width"], st["Height"]) == (want["width"], want["height"])
+    assert (st["HasAlpha"], st["IsGrayscale"], st["UniqueColors"]) == (want["has_alpha"], want["is_grayscale"], want["unique_colors"])
+    assert abs(st["Entropy"] - want["entropy"]) <= 1e-12
+    assert st["EdgeDensity"] == want["edge_density"]
+    assert abs(st["MeanBrightness"] - want["mean_brightness"]) <= ANALYZE_REL * max(1.0, want["mean_brightness"])
+    assert abs(st["Contrast"] - want["contrast"]) <= 1e-9
+    assert (st["RecommendedFormat"], st["RecommendedQuality"]) == (want["recommended_format"], want["recommended_quality"])
+    assert st["EstimatedCompression"] == want["estimated_compression"]
+
+
+ANALYZE_IMAGES = dict(IMAGES)
+ANALYZE_IMAGES.update({
+    "grey_100x100": lambda: synth.make_solid_image(100, 100, (128, 128, 128, 255)),       # fennec_test.go:579
+    "grad_200x200": lambda: synth.make_test_image(200, 200),                               # fennec_test.go:566
+    "alpha_100x100": lambda: synth.make_test_image_with_alpha(100, 100),                   # fennec_test.go:591
+    "greyramp_333x77": lambda: np.repeat((np.arange(333 * 77, dtype=np.uint32) % 256).astype(np.uint8).reshape(77, 333, 1), 4, axis=2) | np.array([0, 0, 0, 255], dtype=np.uint8),
+    "photo_1000x1000": lambda: synth.large_photo(1000, 1000, 2),                           # BenchmarkAnalyze's size
+    "noise_1921x1081": lambda: synth.noise_image(1921, 1081, 3, alpha=True),
+    "fewcolors_640x480": lambda: (synth.large_photo(640, 480, 1) & 0xC0) | np.array([0, 0, 0, 255], dtype=np.uint8),
+})
+
+
+@pytest.mark.parametrize("name", list(ANALYZE_IMAGES))
+def test_analyze(ctx, orc, name):
+    img = np.ascontiguousarray(ANALYZE_IMAGES[name]())
+    _check_analysis(ctx.analyze_raw(img), ctx.Analyze(img), orc.analyze(img))
+    assert ctx.isOpaque(img) == orc.is_opaque(img)
+    assert ctx.isGrayscale(img) == orc.is_grayscale(img)
+
+
+def test_analyze_4k_device_batch_and_views(ctx, orc):
+    import torch
+    imgs = [synth.large_photo(3840, 2160, 0), synth.noise_image(3840, 2160, 1, alpha=True),
+            synth.make_test_image(3840, 2160)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    plan = ctx.plan_analyze_batch(d)
+    raw = plan.run()
+    stats = plan.stats()
+    for k, img in enumerate(imgs):
+        want = orc.analyze(img)
+        _check_analysis(ctx._analysis_dict(raw[k]), stats[k], want)
+        single = ctx.analyze_raw(d[k])                       # device, single
+        assert np.array_equal(single["histogram"], np.array(raw[k].histogram[:], dtype=np.uint64))
+        assert single["bright_sum"] == raw[k].bright_sum     # same partial layout -> same bits
+    # strided views: device (16-byte aligned or not) and host
+    sub = d[1][5:1005, 8:1508]
+    _check_analysis(ctx.analyze_raw(sub), ctx.Analyze(sub), orc.analyze(np.ascontiguousarray(imgs[1][5:1005, 8:1508])))
+    sub = d[1][5:1005, 3:1500]
+    _check_analysis(ctx.analyze_raw(sub), ctx.Analyze(sub), orc.analyze(np.ascontiguousarray(imgs[1][5:1005, 3:1500])))
+    hv = imgs[0][7:507, 9:1209]
+    _check_analysis(ctx.analyze_raw(hv), ctx.Analyze(hv), orc.analyze(np.ascontiguousarray(hv)))
+    # determinism: fixed reduction trees
+    assert len({ctx.analyze_raw(d[0])["bright_sum"] for _ in range(4)}) == 1
+    # empty image (fennec_test.go:602-608)
+    st = ctx.Analyze(np.zeros((0, 0, 4), dtype=np.uint8))
+    assert (st["Width"], st["Height"], st["Entropy"]) == (0, 0, 0.0)
+
+
+def test_flat_scans_see_row_padding(ctx, orc):
+    """isOpaque / isGrayscale walk the flat Pix slice (convert.go:66-84): padding counts."""
+    base = synth.make_solid_image(64, 32, (9, 9, 9, 255))
+    base[:, 63] = (1, 2, 3, 0)                  # last column: transparent and coloured
+    view = base[:, :63]                          # SubImage-like: stride 256, width 63
+    assert orc.is_opaque(view) is False and orc.is_grayscale(view) is False
+    assert ctx.isOpaque(view) is False and ctx.isGrayscale(view) is False
+    one_row = base[:1, :63]                      # a single row ends before the padding
+    assert ctx.isOpaque(one_row) is True and ctx.isGrayscale(one_row) is True
+    assert orc.is_opaque(one_row) is True
+    big = synth.large_photo(3840, 2160, 4)
+    assert ctx.isOpaque(big) is True and ctx.isGrayscale(big) is False
+    big[2159, 3839, 3] = 254
+    assert ctx.isOpaque(big) is False

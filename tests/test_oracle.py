@@ -241,3 +241,40 @@ def test_summarize(orc):                # batch.go:140-158
     s = orc.summarize([0, 1, 0, 0], [1, 0, 1, 0], [100, 0, 300, 50], [40, 0, 100, 0], [0.95, 0, 0.97, 0])
     assert s["Total"] == 4 and s["Succeeded"] == 3 and s["Failed"] == 1
     assert s["TotalSaved"] == 260 and s["AvgSSIM"] == (0.95 + 0.97) / 3.0
+
+
+# ---------------------------------------------------------------- Analyze
+def test_analyze_reference_invariants(orc):      # fennec_test.go:564-610
+    st = orc.analyze(synth.make_test_image(200, 200))
+    assert (st["width"], st["height"]) == (200, 200) and not st["has_alpha"] and st["entropy"] >= 1
+    st = orc.analyze(synth.make_solid_image(100, 100, (128, 128, 128, 255)))
+    assert st["is_grayscale"] and st["entropy"] <= 0.01
+    st = orc.analyze(synth.make_test_image_with_alpha(100, 100))
+    assert st["has_alpha"] and st["recommended_format"] == 2          # PNG
+    st = orc.analyze(np.zeros((0, 0, 4), dtype=np.uint8))
+    assert (st["width"], st["height"]) == (0, 0)
+
+
+def test_format_scans_reference_invariants(orc):  # fennec_test.go:738-768
+    few = synth.make_solid_image(50, 50, (10, 20, 30, 255))
+    assert orc.analyze_format(few) == 2
+    assert orc.analyze_format(synth.make_test_image(200, 200)) == 1
+    assert orc.analyze_format(synth.make_test_image_with_alpha(50, 50)) == 2
+    assert orc.is_opaque(synth.make_test_image(10, 10))
+    assert not orc.is_opaque(synth.make_test_image_with_alpha(10, 10))
+
+
+@pytest.mark.parametrize("name,mk", IMAGES + [("photo_400x300", lambda: synth.large_photo(400, 300, 1)),
+                                              ("grey_90x70", lambda: synth.make_solid_image(90, 70, (77, 77, 77, 255))),
+                                              ("noise_2x2", lambda: synth.noise_image(2, 2, 1, alpha=True))])
+def test_analyze_match(orc, name, mk):
+    img = mk()
+    got, want = orc.analyze(img), npr.analyze(img)
+    for k, v in want.items():
+        if k == "histogram":
+            assert np.array_equal(got[k], v)
+        else:
+            assert got[k] == v, k                      # same op order -> bit-equal, floats included
+    assert orc.is_opaque(img) == npr.is_opaque(img)
+    assert orc.is_grayscale(img) == npr.is_grayscale(img)
+    assert orc.analyze_format(img) == npr.analyze_format(img)
