@@ -55,7 +55,7 @@ def main() -> int:
                          "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
                          "fnx_gaussian_blur_batch then fnx_ssim_fast_batch (bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
     if args.workload != "config2":
@@ -322,6 +322,21 @@ def other_workloads(args) -> int:
             return out
         metric, unit, units_per_step = "megapixels/sec: 8K AdaptiveSharpen + SSIM", "MP/s", B * W * H / 1e6
         name = "config4: 8K AdaptiveSharpen(0.5) + full-resolution SSIM"
+    elif wl == "analyze":     # Analyze (analyze.go:26-124), BenchmarkAnalyze's op at 4K
+        W, H, B = 3840, 2160, args.batch
+        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        torch.cuda.synchronize()
+        alg = 4.0 * W * H           # every pixel read once; the sampled passes touch < 1 % more
+        plan = ctx.plan_analyze_batch(imgs)
+        ctx.profile(True)            # the library brackets analyze_pass_kernel with HIP events
+        pass_ms = []
+
+        def step():
+            plan.run()                                   # fnx_analyze_batch: results on the host at return
+            pass_ms.append(ctx.kernel_ms())
+            return [s["Entropy"] for s in plan.stats()]  # + the float epilogue (fennec_statsFromAnalysis)
+        metric, unit, units_per_step = "megapixels/sec: 4K Analyze", "MP/s", B * W * H / 1e6
+        name = "analyze: Analyze() of 4K images (histogram, brightness, flags, sampled colours / contrast / Sobel)"
     else:   # config5: CompressBatch semantics, host JPEG codec (Pillow) + GPU SSIMFast
         W, H, B = 3840, 2160, min(args.batch, 16)
         srcs = [synth.large_photo(W, H, rank * B + i) for i in range(B)]
@@ -380,6 +395,27 @@ def other_workloads(args) -> int:
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None},
         "result_sample": float(vals[0]),
     }
+    if wl == "analyze":
+        ms = float(np.mean(pass_ms[-args.steps:]))
+        g = alg * B / (ms * 1e-3) / 1e9
+        out["config"]["inputs"] = "device-resident, one batched C-ABI call per step (fnx_analyze_batch)"
+        out["roofline_step"] = out["roofline"]
+        out["roofline"] = {"kernel": f"analyze_pass_kernel (histogram + brightness + flags, one launch of {B} images)",
+                           "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(g / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": alg * B, "avg_launch_ms": round(ms, 4)}
+    if wl == "analyze" and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        img = imgs[0].cpu().numpy()
+        orc.analyze(img)
+        t1 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t1 < 5.0:
+            orc.analyze(img)
+            reps += 1
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(reps * W * H / 1e6 / dt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} x Analyze(4K) in {dt:.1f} s, oracle/fennec_oracle.c (serial, as the reference)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

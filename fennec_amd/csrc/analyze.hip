@@ -5,7 +5,7 @@
 //    (bin int(lum + 0.5)), luminance sum, has-alpha and all-grey flags.  One 16-byte
 //    non-temporal load = 4 px per lane; fp64 luminance in the reference's operation order
 //    (so every bin is exact); histogram in LDS, one copy per wave; per-workgroup partials
-//    (no global atomics: 1024 workgroups hammering 256 addresses serialise).
+//    (no global atomics: a thousand workgroups hammering 256 addresses serialise).
 //  * analyze_finish_kernel: column sums of the histogram partials (exact integers), the
 //    brightness partials in a fixed order (bit-reproducible; the reference's own sum is one long
 //    serial fp64 chain, so its last bits are an accident of order -- tolerance 1e-12 relative).
@@ -21,7 +21,8 @@
 
 namespace fnx {
 
-constexpr int AN_WG = 1024;            // workgroups of the full pass per image (4 per CU)
+constexpr int AN_WG_MAX = 1024;        // workgroups of the full pass per image: 4 per CU for one image, fewer in a batch
+constexpr int AN_CBLOCKS = 8;          // workgroups of the contrast grid per image (each one is latency-bound)
 constexpr int AN_HASH_CAP = 1 << 17;   // >= 2x the 50 000 + colour samples
 
 struct PassArgs2 {
@@ -33,9 +34,10 @@ struct PassArgs2 {
     int rows, row_px;        // iteration space: rows x row_px pixels
     int vec;                 // 16-byte loads allowed
     long long units;
-    uint32_t *hist_part;     // [n][AN_WG][256]
-    double *bright_part;     // [n][AN_WG]
-    uint32_t *flag_part;     // [n][AN_WG]   bit 0: some alpha < 255, bit 1: some r != g || g != b
+    int G;                   // workgroups per image
+    uint32_t *hist_part;     // [n][G][256]
+    double *bright_part;     // [n][G]
+    uint32_t *flag_part;     // [n][G]   bit 0: some alpha < 255, bit 1: some r != g || g != b
 };
 
 __device__ __forceinline__ void an_pixel(uint32_t p, uint32_t *hist, double &bright, uint32_t &flags)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
     uint32_t *hist = s_hist[wave];
     double bright = 0.0;
     uint32_t flags = 0;
-    for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < a.units; u += static_cast<long long>(AN_WG) * 256) {
+    for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < a.units; u += static_cast<long long>(a.G) * 256) {
         int y = 0;
         long long c = u;
         if (a.rows > 1) {
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
     }
     if ((tid & 63) == 0) { s_red[wave] = bright; s_flag[wave] = flags; }
     __syncthreads();
-    const size_t part = static_cast<size_t>(z) * AN_WG + blockIdx.x;
+    const size_t part = static_cast<size_t>(z) * a.G + blockIdx.x;
     a.hist_part[part * 256 + tid] = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     if (tid == 0) {
         a.bright_part[part] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
@@ -95,21 +97,33 @@ __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
     }
 }
 
+// grid (16, n): workgroup j sums bins [16j, 16j+16) over the G partial histograms (thread = bin x 16-way
+// split of g, LDS tree); workgroup 0 also sums the brightness partials (fixed order) and the flags.
 __global__ __launch_bounds__(256) void analyze_finish_kernel(const uint32_t *hist_part, const double *bright_part,
-                                                             const uint32_t *flag_part, fnx_analysis *res)
+                                                             const uint32_t *flag_part, int G, fnx_analysis *res)
 {
+    __shared__ unsigned long long s_c[16][17];
     __shared__ double s_b[256];
     __shared__ uint32_t s_f;
-    const int tid = threadIdx.x, z = blockIdx.x;
+    const int tid = threadIdx.x, z = blockIdx.y, bin = blockIdx.x * 16 + (tid & 15), lane = tid >> 4;
+    fnx_analysis *r = res + z;
+    unsigned long long cnt = 0;
+    for (int g = lane; g < G; g += 16) cnt += hist_part[(static_cast<size_t>(z) * G + g) * 256 + bin];
+    s_c[lane][tid & 15] = cnt;
+    __syncthreads();
+    if (tid < 16) {
+        unsigned long long t = 0;
+        for (int l = 0; l < 16; l++) t += s_c[l][tid];
+        r->histogram[blockIdx.x * 16 + tid] = t;
+    }
+    if (blockIdx.x != 0) return;
     if (tid == 0) s_f = 0;
     __syncthreads();
-    unsigned long long cnt = 0;
     double b = 0.0;
     uint32_t f = 0;
-    for (int g = 0; g < AN_WG; g++) cnt += hist_part[(static_cast<size_t>(z) * AN_WG + g) * 256 + tid];
-    for (int g = tid; g < AN_WG; g += 256) {
-        b += bright_part[static_cast<size_t>(z) * AN_WG + g];
-        f |= flag_part[static_cast<size_t>(z) * AN_WG + g];
+    for (int g = tid; g < G; g += 256) {
+        b += bright_part[static_cast<size_t>(z) * G + g];
+        f |= flag_part[static_cast<size_t>(z) * G + g];
     }
     s_b[tid] = b;
     atomicOr(&s_f, f);
@@ -118,8 +132,6 @@ __global__ __launch_bounds__(256) void analyze_finish_kernel(const uint32_t *his
         if (tid < off) s_b[tid] += s_b[tid + off];
         __syncthreads();
     }
-    fnx_analysis *r = res + z;
-    r->histogram[tid] = cnt;
     if (tid == 0) {
         r->bright_sum = s_b[0];
         r->has_alpha = s_f & 1u;
@@ -138,10 +150,14 @@ struct SampArgs {
     const uint8_t *const *srcs;
     int sstride, w, h;
     long long color_samples, color_step;       // analyze.go:46-50,73-77
+    long long color_k0;                        // first sample of this launch
     int color_blocks;
+    int colors_only;                           // second colour launch: skip images that already hold 1024
     int cstep_x, cstep_y, cnx, cny;            // contrast grid (analyze.go:93-109)
     int estep_x, estep_y, enx, eny;            // edge grid (analyze.go:150-156)
     unsigned long long *hash;                  // [n][AN_HASH_CAP], zeroed
+    uint32_t *count_part;                      // [n][gridDim.x]: per-workgroup counts (new colours / edges)
+    double *var_part;                          // [n][AN_CBLOCKS]: per-workgroup sums of (lum - mean)^2
     fnx_analysis *res;
 };
 
@@ -157,36 +173,61 @@ __global__ __launch_bounds__(256) void analyze_sampled_kernel(SampArgs a)
     const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
     fnx_analysis *r = a.res + z;
     if (b < a.color_blocks) {                  // ---- sampled colour set
-        const long long k = static_cast<long long>(b) * 256 + tid;
-        if (k >= a.color_samples) return;
-        const long long idx = k * a.color_step;
-        const int y = static_cast<int>(idx / a.w), x = static_cast<int>(idx - static_cast<long long>(y) * a.w);
-        const uint32_t p = *(g_u32 *)(src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x));
-        const unsigned long long key = (1ull << 32) | p;     // any bijection of (r,g,b,a) counts the same
-        unsigned long long *tab = a.hash + static_cast<size_t>(z) * AN_HASH_CAP;
-        uint32_t slot = (p * 2654435761u) >> (32 - 17);
-        for (;;) {
-            const unsigned long long old = atomicCAS(&tab[slot], 0ull, key);
-            if (old == 0ull) { atomicAdd(&r->unique_colors, 1); break; }
-            if (old == key) break;
-            slot = (slot + 1) & (AN_HASH_CAP - 1);
+        const long long k = a.color_k0 + static_cast<long long>(b) * 256 + tid;
+        bool fresh = false;
+        // the reference stops inserting at 1024 entries (analyze.go:73) and only len() is read: the first
+        // launch hashes the first 2048 samples, the second one the rest -- unless the fold in between
+        // already counted 1024 (photographs: always), which spares ~48 000 device-scope CAS per image
+        const bool skip = a.colors_only && r->unique_colors >= 1024;
+        if (!skip && k < a.color_samples) {
+            const long long idx = k * a.color_step;
+            const int y = static_cast<int>(idx / a.w), x = static_cast<int>(idx - static_cast<long long>(y) * a.w);
+            const uint32_t p = *(g_u32 *)(src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x));
+            const unsigned long long key = (1ull << 32) | p;     // any bijection of (r,g,b,a) counts the same
+            unsigned long long *tab = a.hash + static_cast<size_t>(z) * AN_HASH_CAP;
+            uint32_t slot = (p * 2654435761u) >> (32 - 17);
+            for (;;) {
+                // a slot only ever goes 0 -> key: a (possibly stale) plain read that already shows this
+                // key settles a duplicate without an atomic; anything else is decided by the CAS
+                unsigned long long old = tab[slot];
+                if (old == key) break;
+                if (old == 0ull) {
+                    old = atomicCAS(&tab[slot], 0ull, key);
+                    if (old == 0ull) { fresh = true; break; }
+                    if (old == key) break;
+                }
+                slot = (slot + 1) & (AN_HASH_CAP - 1);
+            }
         }
-    } else if (b == a.color_blocks) {          // ---- contrast: sum (lum - mean)^2 on the fixed grid
+        // counts go to a per-workgroup slot and are folded afterwards: hundreds of device-scope atomics on
+        // ONE word cost ~80 ns each when every XCD contends for it (measured: they were 2/3 of this kernel)
+        const int c = __syncthreads_count(fresh);
+        if (tid == 0) a.count_part[static_cast<size_t>(z) * gridDim.x + b] = c;
+    } else if (b < a.color_blocks + AN_CBLOCKS) {   // ---- contrast: sum (lum - mean)^2 on the fixed grid
         const double mean = r->bright_sum / static_cast<double>(static_cast<long long>(a.w) * a.h);
         double v = 0.0;
-        const int total = a.cnx * a.cny;
-        for (int s = tid; s < total; s += 256) {
-            const int iy = s / a.cnx, ix = s - iy * a.cnx;
-            const double d = sobel_lum(src, a.sstride, ix * a.cstep_x, iy * a.cstep_y) - mean;
-            v += d * d;
+        const int total = a.cnx * a.cny, cb = b - a.color_blocks;
+        const int per = (total + AN_CBLOCKS - 1) / AN_CBLOCKS, lo = cb * per, hi = min(total, lo + per);
+        for (int s0 = lo + tid; s0 < hi; s0 += 8 * 256) {        // 8 independent loads in flight per lane
+            uint32_t px[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int s = s0 + e * 256;
+                const int iy = s < hi ? s / a.cnx : 0, ix = s < hi ? s - iy * a.cnx : 0;
+                px[e] = *(g_u32 *)(src + static_cast<size_t>(iy * a.cstep_y) * a.sstride + 4 * static_cast<size_t>(ix * a.cstep_x));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (s0 + e * 256 < hi) {
+                    const double d = lum601(px[e]) - mean;
+                    v += d * d;
+                }
+            }
         }
         const double t = block_sum_256(v, s_red);
-        if (tid == 0) {
-            r->variance_sum = t;
-            r->sample_count = total;
-        }
+        if (tid == 0) a.var_part[static_cast<size_t>(z) * AN_CBLOCKS + cb] = t;
     } else {                                   // ---- Sobel edge count (analyze.go:158-177)
-        const int s = (b - a.color_blocks - 1) * 256 + tid;
+        const int s = (b - a.color_blocks - AN_CBLOCKS) * 256 + tid;
         bool edge = false;
         if (s < a.enx * a.eny) {
             const int iy = s / a.enx, ix = s - iy * a.enx;
@@ -200,9 +241,41 @@ __global__ __launch_bounds__(256) void analyze_sampled_kernel(SampArgs a)
                               sobel_lum(src, st, x + 1, y + 1) - sobel_lum(src, st, x + 1, y - 1);
             edge = sqrt(gx * gx + gy * gy) > 30.0;
         }
-        const unsigned long long m = __ballot(edge);
-        if ((tid & 63) == 0 && m) atomicAdd(reinterpret_cast<unsigned long long *>(&r->edge_count), static_cast<unsigned long long>(__popcll(m)));
-        if (b == a.color_blocks + 1 && tid == 0) r->edge_total = static_cast<long long>(a.enx) * a.eny;
+        const int c = __syncthreads_count(edge);
+        if (tid == 0) a.count_part[static_cast<size_t>(z) * gridDim.x + b] = c;
+    }
+}
+
+// one workgroup per image: fold the per-workgroup counts of analyze_sampled_kernel
+__global__ __launch_bounds__(256) void analyze_fold_kernel(const uint32_t *count_part, int blocks, int color_blocks,
+                                                           const double *var_part, long long grid_samples,
+                                                           long long edge_total, int colors_only, fnx_analysis *res)
+{
+    __shared__ int s_c[2];
+    const int tid = threadIdx.x, z = blockIdx.x;
+    if (tid < 2) s_c[tid] = 0;
+    __syncthreads();
+    int colors = 0, edges = 0;
+    for (int b = tid; b < blocks; b += 256) {
+        const int c = static_cast<int>(count_part[static_cast<size_t>(z) * blocks + b]);
+        if (b < color_blocks) colors += c;
+        else if (b >= color_blocks + AN_CBLOCKS) edges += c;
+    }
+    atomicAdd(&s_c[0], colors);
+    atomicAdd(&s_c[1], edges);
+    __syncthreads();
+    if (tid == 0) {
+        if (colors_only) {
+            res[z].unique_colors += s_c[0];
+        } else {
+            res[z].unique_colors = s_c[0];
+            res[z].edge_count = s_c[1];
+            res[z].edge_total = edge_total;
+            double v = 0.0;                                   // fixed order: bit-reproducible
+            for (int k = 0; k < AN_CBLOCKS; k++) v += var_part[static_cast<size_t>(z) * AN_CBLOCKS + k];
+            res[z].variance_sum = v;
+            res[z].sample_count = grid_samples;
+        }
     }
 }
 
@@ -212,8 +285,10 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
 {
     if (n <= 0) return FNX_OK;
     void *hp = nullptr, *bp = nullptr, *hash = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_TMP0, sizeof(uint32_t) * 256 * AN_WG * static_cast<size_t>(n), &hp));
-    FNX_TRY(scratch(ctx, SLOT_TMP1, (sizeof(double) + sizeof(uint32_t)) * AN_WG * static_cast<size_t>(n) + 16, &bp));
+    // workgroups per image: fill the chip ~4 deep whatever the batch size
+    const int G = std::max(128, std::min(AN_WG_MAX, (4 * ctx->num_cus + n - 1) / n));
+    FNX_TRY(scratch(ctx, SLOT_TMP0, sizeof(uint32_t) * 256 * G * static_cast<size_t>(n), &hp));
+    FNX_TRY(scratch(ctx, SLOT_TMP1, (sizeof(double) + sizeof(uint32_t)) * G * static_cast<size_t>(n) + 16, &bp));
     FNX_TRY(scratch(ctx, SLOT_TMP3, sizeof(unsigned long long) * AN_HASH_CAP * static_cast<size_t>(n), &hash));
     FNX_HIP(hipMemsetAsync(hash, 0, sizeof(unsigned long long) * AN_HASH_CAP * static_cast<size_t>(n), ctx->stream));
 
@@ -221,7 +296,8 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
     pa.src = src; pa.srcs = srcs; pa.sstride = sstride; pa.w = w; pa.h = h;
     pa.hist_part = static_cast<uint32_t *>(hp);
     pa.bright_part = static_cast<double *>(bp);
-    pa.flag_part = reinterpret_cast<uint32_t *>(pa.bright_part + static_cast<size_t>(AN_WG) * n);
+    pa.flag_part = reinterpret_cast<uint32_t *>(pa.bright_part + static_cast<size_t>(G) * n);
+    pa.G = G;
     if (sstride == 4 * w) {      // tight: one long row
         pa.rows = 1;
         pa.row_px = 0;           // set below (64-bit)
@@ -245,10 +321,15 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
         return FNX_ERR_INVALID;
     }
     pa.row_px = static_cast<int>(row_px);
-    hipLaunchKernelGGL(analyze_pass_kernel, dim3(AN_WG, n), dim3(256), 0, ctx->stream, pa);
+    if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
+    hipLaunchKernelGGL(analyze_pass_kernel, dim3(G, n), dim3(256), 0, ctx->stream, pa);
     FNX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(analyze_finish_kernel, dim3(n), dim3(256), 0, ctx->stream, pa.hist_part, pa.bright_part,
-                       pa.flag_part, d_res);
+    if (ctx->prof) {
+        FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
+        ctx->prof_valid = true;
+    }
+    hipLaunchKernelGGL(analyze_finish_kernel, dim3(16, n), dim3(256), 0, ctx->stream, pa.hist_part, pa.bright_part,
+                       pa.flag_part, G, d_res);
     FNX_HIP(hipGetLastError());
 
     SampArgs sa{};
@@ -271,8 +352,30 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
     }
     sa.hash = static_cast<unsigned long long *>(hash);
     sa.res = d_res;
-    hipLaunchKernelGGL(analyze_sampled_kernel, dim3(sa.color_blocks + 1 + eblocks, n), dim3(256), 0, ctx->stream, sa);
+    const int all_color_blocks = sa.color_blocks;
+    constexpr int FIRST_COLOR_BLOCKS = 8;      // 2048 samples
+    sa.color_blocks = std::min(all_color_blocks, FIRST_COLOR_BLOCKS);
+    const int sblocks = sa.color_blocks + AN_CBLOCKS + eblocks;
+    void *cp = nullptr;
+    const size_t counts = (sizeof(uint32_t) * std::max(sblocks, all_color_blocks) * static_cast<size_t>(n) + 15) & ~size_t(15);
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, counts + sizeof(double) * AN_CBLOCKS * static_cast<size_t>(n), &cp));
+    sa.count_part = static_cast<uint32_t *>(cp);
+    sa.var_part = reinterpret_cast<double *>(static_cast<char *>(cp) + counts);
+    hipLaunchKernelGGL(analyze_sampled_kernel, dim3(sblocks, n), dim3(256), 0, ctx->stream, sa);
     FNX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(analyze_fold_kernel, dim3(n), dim3(256), 0, ctx->stream, sa.count_part, sblocks, sa.color_blocks,
+                       sa.var_part, static_cast<long long>(sa.cnx) * sa.cny, static_cast<long long>(sa.enx) * sa.eny, 0, d_res);
+    FNX_HIP(hipGetLastError());
+    if (all_color_blocks > FIRST_COLOR_BLOCKS) {
+        sa.color_k0 = static_cast<long long>(FIRST_COLOR_BLOCKS) * 256;
+        sa.color_blocks = all_color_blocks - FIRST_COLOR_BLOCKS;
+        sa.colors_only = 1;
+        hipLaunchKernelGGL(analyze_sampled_kernel, dim3(sa.color_blocks, n), dim3(256), 0, ctx->stream, sa);
+        FNX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(analyze_fold_kernel, dim3(n), dim3(256), 0, ctx->stream, sa.count_part, sa.color_blocks,
+                           sa.color_blocks, sa.var_part, 0LL, 0LL, 1, d_res);
+        FNX_HIP(hipGetLastError());
+    }
     return FNX_OK;
 }
 

@@ -83,10 +83,11 @@ int fnx_ctx_device(const fnx_ctx *ctx);
 void *fnx_ctx_stream(fnx_ctx *ctx);
 /* Block until everything enqueued on the ctx has finished. */
 int fnx_ctx_sync(fnx_ctx *ctx);
-/* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of its
- * GaussianBlur fast-path kernel (blur_direct_kernel, the path's dominant kernel) with a pair
- * of HIP events on its stream.  fnx_ctx_kernel_ms waits for the last bracketed launch and
- * returns its duration in milliseconds (FNX_ERR_INVALID if none was recorded). */
+/* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of a
+ * call's dominant kernel (GaussianBlur fast path: blur_direct_kernel; Analyze:
+ * analyze_pass_kernel) with a pair of HIP events on its stream.  fnx_ctx_kernel_ms waits for
+ * the last bracketed launch and returns its duration in milliseconds (FNX_ERR_INVALID if none
+ * was recorded). */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
 

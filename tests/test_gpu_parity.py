@@ -489,7 +489,12 @@ def test_device_views_at_4_byte_alignment(ctx, orc):
 
 
 # ------------------------------------------------------------------ Analyze (analyze.go), SURVEY 8(f).3
-ANALYZE_REL = 1e-12        # sums whose order differs from the reference's serial loop
+def _serial_sum_tol(n):
+    """brightSum is ONE serial fp64 chain over all n pixels in the reference (analyze.go:63): its
+    own rounding error is bounded by (n-1)*2^-53 relative (1.1e-12 observed at 4K, against the
+    exact sum); the device's fixed-tree sum is closer to exact, so the bar is the chain's bound."""
+    return max(1e-12, n * 2.0 ** -53)
+
 
 
 def _check_analysis(raw, st, want):
@@ -497,14 +502,15 @@ def _check_analysis(raw, st, want):
     assert np.array_equal(raw["histogram"].astype(np.float64), want["histogram"])      # exact
     for k in ("has_alpha", "is_grayscale", "unique_colors", "sample_count", "edge_count", "edge_total"):
         assert raw[k] == want[k], k
-    assert abs(raw["bright_sum"] - want["bright_sum"]) <= ANALYZE_REL * abs(want["bright_sum"])
+    rel = _serial_sum_tol(want["width"] * want["height"])
+    assert abs(raw["bright_sum"] - want["bright_sum"]) <= rel * abs(want["bright_sum"])
     # (lum - mean)^2 terms inherit the mean's last-bit difference: absolute floor for flat images
     assert abs(raw["variance_sum"] - want["variance_sum"]) <= 1e-9 * abs(want["variance_sum"]) + 1e-6
     assert (st["Width"], st["Height"]) == (want["width"], want["height"])
     assert (st["HasAlpha"], st["IsGrayscale"], st["UniqueColors"]) == (want["has_alpha"], want["is_grayscale"], want["unique_colors"])
     assert abs(st["Entropy"] - want["entropy"]) <= 1e-12
     assert st["EdgeDensity"] == want["edge_density"]
-    assert abs(st["MeanBrightness"] - want["mean_brightness"]) <= ANALYZE_REL * max(1.0, want["mean_brightness"])
+    assert abs(st["MeanBrightness"] - want["mean_brightness"]) <= rel * max(1.0, want["mean_brightness"])
     assert abs(st["Contrast"] - want["contrast"]) <= 1e-9
     assert (st["RecommendedFormat"], st["RecommendedQuality"]) == (want["recommended_format"], want["recommended_quality"])
     assert st["EstimatedCompression"] == want["estimated_compression"]
@@ -518,6 +524,13 @@ ANALYZE_IMAGES.update({
     "greyramp_333x77": lambda: np.repeat((np.arange(333 * 77, dtype=np.uint32) % 256).astype(np.uint8).reshape(77, 333, 1), 4, axis=2) | np.array([0, 0, 0, 255], dtype=np.uint8),
     "photo_1000x1000": lambda: synth.large_photo(1000, 1000, 2),                           # BenchmarkAnalyze's size
     "noise_1921x1081": lambda: synth.noise_image(1921, 1081, 3, alpha=True),
+    # many colours, but only far into the sampled sequence (second colour launch must run)
+    "late_noise_1000x800": lambda: np.concatenate([synth.make_solid_image(1000, 500, (5, 6, 7, 255)),
+                                                   synth.noise_image(1000, 300, 11)], axis=0),
+    # fewer than 1024 distinct colours in total, spread over the whole image
+    "palette_900x700": lambda: np.stack([(np.arange(900 * 700, dtype=np.uint32) * 7919 % 700 % 256).astype(np.uint8).reshape(700, 900),
+                                         (np.arange(900 * 700, dtype=np.uint32) * 7919 % 700 // 256).astype(np.uint8).reshape(700, 900),
+                                         np.zeros((700, 900), np.uint8), np.full((700, 900), 255, np.uint8)], axis=2),
     "fewcolors_640x480": lambda: (synth.large_photo(640, 480, 1) & 0xC0) | np.array([0, 0, 0, 255], dtype=np.uint8),
 })
 
@@ -544,7 +557,7 @@ def test_analyze_4k_device_batch_and_views(ctx, orc):
         _check_analysis(ctx._analysis_dict(raw[k]), stats[k], want)
         single = ctx.analyze_raw(d[k])                       # device, single
         assert np.array_equal(single["histogram"], np.array(raw[k].histogram[:], dtype=np.uint64))
-        assert single["bright_sum"] == raw[k].bright_sum     # same partial layout -> same bits
+        assert abs(single["bright_sum"] - raw[k].bright_sum) <= 1e-13 * raw[k].bright_sum   # partial layout depends on n
     # strided views: device (16-byte aligned or not) and host
     sub = d[1][5:1005, 8:1508]
     _check_analysis(ctx.analyze_raw(sub), ctx.Analyze(sub), orc.analyze(np.ascontiguousarray(imgs[1][5:1005, 8:1508])))
