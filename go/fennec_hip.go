@@ -340,3 +340,55 @@ func ApplyOrientation(img *image.NRGBA, orient Orientation) *image.NRGBA {
 	}
 	return applyOrientationGo(img, orient)
 }
+
+// ---- analyze.go ----------------------------------------------------------------------------
+
+// Analyze replaces analyze.go:26: the device gathers every statistic that needs the pixels
+// (fnx_analysis); the float epilogue is the reference's own code on those numbers, so entropy
+// and the recommend* rules are computed with Go's math package exactly as before.
+func Analyze(img image.Image) ImageStats {
+	src := toNRGBARef(img)
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	if w == 0 || h == 0 {
+		return ImageStats{Width: w, Height: h} // analyze.go:37-39
+	}
+	if c := pool.get(); c != nil {
+		defer pool.put(c)
+		var a C.fnx_analysis
+		st := C.fnx_analyze(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), &a)
+		runtime.KeepAlive(src)
+		if st == C.FNX_OK {
+			n := float64(w * h)
+			stats := ImageStats{Width: w, Height: h}
+			stats.HasAlpha = a.has_alpha != 0
+			stats.IsGrayscale = a.is_grayscale != 0
+			stats.UniqueColors = int(a.unique_colors)
+			stats.MeanBrightness = float64(a.bright_sum) / n // analyze.go:90
+			if a.sample_count > 0 {
+				stats.Contrast = math.Sqrt(float64(a.variance_sum) / float64(a.sample_count)) // :111-113
+			}
+			var histogram [256]float64
+			for i := range histogram {
+				histogram[i] = float64(a.histogram[i])
+			}
+			stats.Entropy = computeEntropy(histogram[:], n) // :116
+			if a.edge_total > 0 {
+				stats.EdgeDensity = float64(a.edge_count) / float64(a.edge_total) // :180-183
+			}
+			stats.RecommendedFormat = recommendFormat(stats)
+			stats.RecommendedQuality = recommendQuality(stats)
+			stats.EstimatedCompression = estimateCompression(stats)
+			return stats
+		}
+	}
+	return analyzeGo(img)
+}
+
+// GaussianBlurScored is an addition, not a replacement: GaussianBlur (effects.go:146) and
+// SSIMFast(img, blurred) (ssim.go:48) in one pass over the pixels -- the blur kernel gathers
+// SSIMFast's boxDownsample sums while it has the pixels in registers.  Device-resident images
+// only (fnx_gaussian_blur_ssim_fast_batch takes device pointers); shown for the batch form a
+// GPU-side pipeline would call:
+//
+//	C.fnx_gaussian_blur_ssim_fast_batch(c, n, &srcs[0], stride, w, h, &kernel[0], radius,
+//	        C.FNX_BLUR_FAST, &dsts[0], stride, &ssimWindow[0], &scores[0])
