@@ -55,7 +55,7 @@ def main() -> int:
                          "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
                          "fnx_gaussian_blur_batch then fnx_ssim_fast_batch (bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
     if args.workload != "config2":
@@ -337,6 +337,22 @@ def other_workloads(args) -> int:
             return [s["Entropy"] for s in plan.stats()]  # + the float epilogue (fennec_statsFromAnalysis)
         metric, unit, units_per_step = "megapixels/sec: 4K Analyze", "MP/s", B * W * H / 1e6
         name = "analyze: Analyze() of 4K images (histogram, brightness, flags, sampled colours / contrast / Sobel)"
+    elif wl == "palette":     # applyPalette + palettedToNRGBA (targetsize.go:488-546), 256 colours
+        W, H, B = 3840, 2160, min(args.batch, 16)
+        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        pal = np.random.default_rng(1).integers(0, 256, size=(256, 4), dtype=np.uint8)
+        pal[:, 3] = 255
+        torch.cuda.synchronize()
+        alg = 4.0 * W * H + 1.0 * W * H + 4.0 * W * H      # read src, write indices, write quantized NRGBA
+
+        def step():
+            last = None
+            for a in imgs:
+                last = ctx.applyPalette(a, pal)
+            ctx.sync()
+            return [float(last[0][0, 0].item())]
+        metric, unit, units_per_step = "megapixels/sec: 4K applyPalette (256 colours) + palettedToNRGBA", "MP/s", B * W * H / 1e6
+        name = "palette: nearest of 256 palette colours per pixel, indices + quantized NRGBA out"
     else:   # config5: CompressBatch semantics, host JPEG codec (Pillow) + GPU SSIMFast
         W, H, B = 3840, 2160, min(args.batch, 16)
         srcs = [synth.large_photo(W, H, rank * B + i) for i in range(B)]

@@ -144,6 +144,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fennec_statsFromAnalysis", None, [C.POINTER(Analysis), i, i, C.POINTER(ImageStats)])
         _sig(L, "fennec_isOpaque", i, [ctx, i] + img + [i, i, C.POINTER(i)])
         _sig(L, "fennec_isGrayscale", i, [ctx, i] + img + [i, i, C.POINTER(i)])
+        _sig(L, "fnx_apply_palette", i, [ctx, i] + img + [i, i, _u8p, i, _u8p, i, _u8p, i])
         _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
         _sig(L, "fennec_blurKernel", i, [d, _f64p])
         _sig(L, "fennec_lanczosKernel", d, [d])
@@ -522,6 +523,25 @@ class Context:
         o = C.c_int(0)
         self._chk(self._lib.fennec_isGrayscale(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isGrayscale")
         return bool(o.value)
+
+    def applyPalette(self, img, palette, want_quantized: bool = True):
+        """applyPalette (targetsize.go:488-527) [+ palettedToNRGBA]: -> (indices (h, w) uint8,
+        quantized (h, w, 4) or None).  palette: (n, 4) uint8, opaque."""
+        v = _Img(img)
+        pal = np.ascontiguousarray(palette, dtype=np.uint8).reshape(-1, 4)
+        if v.space == FNX_DEVICE:
+            import torch
+            idx = torch.empty((v.h, v.w), dtype=torch.uint8, device=img.device)
+            iptr, istride = idx.data_ptr(), v.w
+        else:
+            idx = np.empty((v.h, v.w), dtype=np.uint8)
+            iptr, istride = idx.ctypes.data, v.w
+        q = v.like(v.w, v.h) if want_quantized else None
+        qv = _Img(q) if want_quantized else None
+        self._chk(self._lib.fnx_apply_palette(self._h, v.space, v.ptr, v.stride, v.w, v.h, pal.ctypes.data, len(pal),
+                                              iptr, istride, qv.ptr if qv else None, qv.stride if qv else 0),
+                  "applyPalette")
+        return idx, q
 
     # -- batched forms (device tensors) ---------------------------------------------------
     def GaussianBlurBatch(self, imgs, sigma: float, outs=None, exact: bool = False):

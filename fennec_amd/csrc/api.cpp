@@ -700,6 +700,42 @@ int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, 
     return FNX_OK;
 }
 
+// ---- applyPalette + palettedToNRGBA (targetsize.go:488-546) ---------------------------------
+int fnx_apply_palette(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                      const uint8_t *palette, int ncolors, uint8_t *indices, int istride,
+                      uint8_t *quantized, int qstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(palette != nullptr && ncolors >= 1 && ncolors <= 256, "palette: 1..256 colours (image.Paletted indices are uint8)");
+    for (int i = 0; i < ncolors; i++)
+        FNX_REQUIRE(palette[4 * i + 3] == 255, "palette entries must be opaque (medianCut only emits A = 255, targetsize.go:407-410)");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_REQUIRE(indices != nullptr || quantized != nullptr, "no output requested");
+    if (indices) FNX_REQUIRE(istride >= w, "index stride");
+    if (quantized) FNX_TRY(check_img(quantized, qstride, w, h, "quantized"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    DevOut q;
+    if (quantized) FNX_TRY(stage_out(ctx, space, quantized, qstride, w, h, SLOT_OUT, &q));
+    uint8_t *didx = indices;
+    int dpitch = istride;
+    if (indices && space == FNX_HOST) {
+        dpitch = (w + 3) & ~3;
+        void *t = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(dpitch) * h + 16, &t));
+        didx = static_cast<uint8_t *>(t);
+    }
+    FNX_TRY(launch_apply_palette(ctx, s.p, s.stride, w, h, palette, ncolors, didx, dpitch,
+                                 quantized ? q.p : nullptr, quantized ? q.stride : 0));
+    if (indices && space == FNX_HOST)
+        FNX_HIP(hipMemcpy2DAsync(indices, istride, didx, dpitch, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    if (quantized) return finish(ctx, space, &q);
+    if (space == FNX_HOST) FNX_HIP(hipStreamSynchronize(ctx->stream));
+    return FNX_OK;
+}
+
 // ---- orientation -------------------------------------------------------------------------
 int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int orient,
                uint8_t *dst, int dstride)

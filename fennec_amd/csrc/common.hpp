@@ -191,6 +191,9 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
                    bool aligned16_ok, fnx_analysis *d_res);
 // flat Pix scan: *d_flags bit 0 = some alpha != 255, bit 1 = some pixel with r != g or g != b
 int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags);
+// applyPalette (+ palettedToNRGBA): palette = n x 4 host bytes (opaque); idx and/or quant may be null
+int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, const uint8_t *palette, int n,
+                         uint8_t *idx, int istride, uint8_t *quant, int qstride);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
                   uint8_t *dst, int dstride);
 

@@ -233,6 +233,16 @@ int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstri
 int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, int *is_opaque,
                    int *is_grayscale);
 
+/* ---- applyPalette + palettedToNRGBA (targetsize.go:488-546), SURVEY 8(f) item 4 ---------- */
+/* Nearest palette entry per pixel by squared RGB distance, first minimum wins (targetsize.go:
+ * 505-517); `indices` = image.Paletted.Pix (w x h bytes, stride istride), `quantized` =
+ * palettedToNRGBA of it (NRGBA, alpha 255).  Either output may be NULL.  palette: ncolors x 4
+ * HOST bytes r,g,b,a with a == 255 (what medianCut emits; medianCut itself stays with the
+ * caller).  Integer arithmetic: bit-exact. */
+int fnx_apply_palette(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                      const uint8_t *palette, int ncolors, uint8_t *indices, int istride,
+                      uint8_t *quantized, int qstride);
+
 /* ======================================================================= */
 /* fennec_* : the reference's function set (names and argument meaning as in
  * the Go source), mirrored above fnx_*.                                     */

@@ -1232,3 +1232,42 @@ ORC_API int orc_analyze_format(const uint8_t *pix, int stride, int w, int h)
     if (ncolors < 256) return 2;
     return 1;
 }
+
+/* ================================================================== */
+/* applyPalette + palettedToNRGBA (targetsize.go:488-546)              */
+/* ================================================================== */
+
+/*
+ * applyPalette (targetsize.go:488-527).  palette: n x 4 bytes r,g,b,a, every a == 255 (the only
+ * palettes medianCut builds, targetsize.go:407-410), so c.RGBA()>>8 is the stored byte.  The
+ * reference memoises the answer per (r,g,b) in a map; the memo cannot change a result.
+ * idx: w x h bytes (image.Paletted.Pix, stride istride); quant (may be NULL): palettedToNRGBA
+ * (targetsize.go:529-546) of it.
+ */
+ORC_API void orc_apply_palette(const uint8_t *pix, int stride, int w, int h, const uint8_t *palette, int n,
+                               uint8_t *idx, int istride, uint8_t *quant, int qstride)
+{
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            size_t off = (size_t)y * stride + (size_t)x * 4;
+            int r = pix[off], g = pix[off + 1], b = pix[off + 2];
+            int bestIdx = 0, bestDist = 2147483647; /* math.MaxInt32 */
+            for (int i = 0; i < n; i++) {
+                int dr = r - (int)palette[4 * i], dg = g - (int)palette[4 * i + 1], db = b - (int)palette[4 * i + 2];
+                int dist = dr * dr + dg * dg + db * db;
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdx = i;
+                }
+            }
+            idx[(size_t)y * istride + x] = (uint8_t)bestIdx;
+            if (quant) {
+                uint8_t *q = quant + (size_t)y * qstride + (size_t)x * 4;
+                q[0] = palette[4 * bestIdx];
+                q[1] = palette[4 * bestIdx + 1];
+                q[2] = palette[4 * bestIdx + 2];
+                q[3] = 255;
+            }
+        }
+    }
+}

@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
         L.orc_is_grayscale.argtypes = [_u8p, C.c_size_t]
         L.orc_analyze_format.restype = C.c_int
         L.orc_analyze_format.argtypes = [_u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_apply_palette.restype = None
+        L.orc_apply_palette.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -361,3 +363,15 @@ def analyze_format(img: np.ndarray) -> int:
     """analyzeFormat (convert.go:105-146): 1 = JPEG, 2 = PNG."""
     p, s, w, h = _img(img)
     return int(lib().orc_analyze_format(p, s, w, h))
+
+
+def apply_palette(img: np.ndarray, palette: np.ndarray):
+    """applyPalette + palettedToNRGBA (targetsize.go:488-546) -> (indices (h, w), quantized (h, w, 4))."""
+    p, s, w, h = _img(img)
+    pal = np.ascontiguousarray(palette, dtype=np.uint8).reshape(-1, 4)
+    assert np.all(pal[:, 3] == 255)
+    idx = np.zeros((h, w), dtype=np.uint8)
+    q = new_image(w, h)
+    lib().orc_apply_palette(p, s, w, h, pal.ctypes.data_as(_u8p), len(pal), idx.ctypes.data_as(_u8p), w,
+                            q.ctypes.data_as(_u8p), 4 * w)
+    return idx, q

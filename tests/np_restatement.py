@@ -506,3 +506,13 @@ def analyze_format(img):
     if has_alpha or len(seen) < 256:
         return 2
     return 1
+
+
+def apply_palette(img, palette):
+    """applyPalette + palettedToNRGBA (targetsize.go:488-546); opaque palette"""
+    pal = np.asarray(palette, dtype=np.int64).reshape(-1, 4)
+    rgb = img[..., :3].astype(np.int64)
+    dist = ((rgb[:, :, None, :] - pal[None, None, :, :3]) ** 2).sum(axis=3)
+    idx = np.argmin(dist, axis=2).astype(np.uint8)          # first minimum, like the strict `<`
+    q = np.asarray(palette, dtype=np.uint8).reshape(-1, 4)[idx]
+    return idx, q

@@ -586,3 +586,43 @@ def test_flat_scans_see_row_padding(ctx, orc):
     assert ctx.isOpaque(big) is True and ctx.isGrayscale(big) is False
     big[2159, 3839, 3] = 254
     assert ctx.isOpaque(big) is False
+
+
+# ------------------------------------------------------------------ applyPalette (targetsize.go:488-546), SURVEY 8(f).4
+def _palette(n, seed):
+    rng = np.random.default_rng(seed)
+    pal = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    pal[:, 3] = 255
+    if n > 3:
+        pal[n // 2] = pal[1]                # duplicates: the lower index wins (strict <)
+    return pal
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 16, 64, 255, 256])
+@pytest.mark.parametrize("name", ["noise_131x77", "photo_640x480", "noise_3x5", "alpha_37x29"])
+def test_apply_palette(ctx, orc, name, n):
+    img = IMAGES[name]()
+    pal = _palette(n, n)
+    wi, wq = orc.apply_palette(img, pal)
+    gi, gq = ctx.applyPalette(img, pal)
+    assert np.array_equal(gi, wi) and np.array_equal(gq, wq)
+
+
+def test_apply_palette_device_and_extremes(ctx, orc):
+    import torch
+    img = synth.noise_image(1921, 1081, 5, alpha=True)
+    pal = _palette(256, 9)
+    wi, wq = orc.apply_palette(img, pal)
+    d = torch.from_numpy(img).cuda()
+    gi, gq = ctx.applyPalette(d, pal); ctx.sync()
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gq.cpu().numpy(), wq)
+    sub = d[3:900, 5:1500]                                   # strided device view, odd width
+    gi, gq = ctx.applyPalette(sub, pal); ctx.sync()
+    wi, wq = orc.apply_palette(np.ascontiguousarray(img[3:900, 5:1500]), pal)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gq.cpu().numpy(), wq)
+    # extreme entries: black/white palette, all-equal distances
+    bw = np.array([[0, 0, 0, 255], [255, 255, 255, 255], [0, 0, 0, 255]], dtype=np.uint8)
+    gi, _ = ctx.applyPalette(img, bw)
+    assert np.array_equal(gi, orc.apply_palette(img, bw)[0]) and gi.max() <= 1
+    with pytest.raises(fennec_amd.FennecError):
+        ctx.applyPalette(img, np.array([[1, 2, 3, 200]], dtype=np.uint8))      # translucent palette entry

@@ -278,3 +278,24 @@ def test_analyze_match(orc, name, mk):
     assert orc.is_opaque(img) == npr.is_opaque(img)
     assert orc.is_grayscale(img) == npr.is_grayscale(img)
     assert orc.analyze_format(img) == npr.analyze_format(img)
+
+
+def _test_palette(n, seed):
+    rng = np.random.default_rng(seed)
+    pal = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    pal[:, 3] = 255
+    if n > 3:
+        pal[n // 2] = pal[1]                # duplicate entries: the lower index must win
+    return pal
+
+
+@pytest.mark.parametrize("n", [1, 2, 16, 100, 256])
+def test_apply_palette_match(orc, n):      # targetsize.go:488-546
+    img = synth.noise_image(61, 47, n, alpha=True)
+    pal = _test_palette(n, n + 1)
+    i1, q1 = orc.apply_palette(img, pal)
+    i2, q2 = npr.apply_palette(img, pal)
+    assert np.array_equal(i1, i2) and np.array_equal(q1, q2)
+    assert np.all(q1[..., 3] == 255)
+    exact = pal[[0]].repeat(4, axis=0).reshape(2, 2, 4)     # a pixel that IS a palette colour maps to it
+    assert np.array_equal(orc.apply_palette(exact, pal)[1], exact)
