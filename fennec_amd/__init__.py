@@ -144,6 +144,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fennec_statsFromAnalysis", None, [C.POINTER(Analysis), i, i, C.POINTER(ImageStats)])
         _sig(L, "fennec_isOpaque", i, [ctx, i] + img + [i, i, C.POINTER(i)])
         _sig(L, "fennec_isGrayscale", i, [ctx, i] + img + [i, i, C.POINTER(i)])
+        _sig(L, "fnx_ycbcr_to_nrgba", i, [ctx, i, _u8p, i, _u8p, _u8p, i, i, i, i] + img)
+        _sig(L, "fnx_ssim_fast_against_ycbcr", i, [ctx, C.c_void_p, i, _u8p, i, _u8p, _u8p, i, i, _f64p, _f64p])
         _sig(L, "fnx_apply_palette", i, [ctx, i] + img + [i, i, _u8p, i, _u8p, i, _u8p, i])
         _sig(L, "fennec_gaussianKernel", None, [i, d, _f64p])
         _sig(L, "fennec_blurKernel", i, [d, _f64p])
@@ -524,6 +526,35 @@ class Context:
         self._chk(self._lib.fennec_isGrayscale(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isGrayscale")
         return bool(o.value)
 
+    @staticmethod
+    def _planes(y, cb, cr):
+        """(space, y ptr/stride, cb ptr, cr ptr, cstride, w, h) of numpy or torch uint8 planes."""
+        def view(p):
+            if p is None:
+                return None, 0, 0
+            if _is_torch(p):
+                return p.data_ptr(), int(p.stride(0)) if p.shape[0] > 1 else int(p.shape[1]), FNX_DEVICE
+            return p.ctypes.data, int(p.strides[0]) if p.shape[0] > 1 else int(p.shape[1]), FNX_HOST
+        yp, ys, space = view(y)
+        cbp, cs, _ = view(cb)
+        crp, cs2, _ = view(cr)
+        if cb is not None and cs != cs2:
+            raise FennecError("Cb and Cr must share a stride (image.YCbCr.CStride)")
+        return space, yp, ys, cbp, crp, cs, int(y.shape[1]), int(y.shape[0])
+
+    def ycbcrToNRGBA(self, y, cb, cr, ratio: int):
+        """toNRGBARef of an image.YCbCr (convert.go:22-64); cb = cr = None: image.Gray.  Planes: 2-D uint8."""
+        space, yp, ys, cbp, crp, cs, w, h = self._planes(y, cb, cr)
+        if space == FNX_DEVICE:
+            import torch
+            dst = torch.empty((h, w, 4), dtype=torch.uint8, device=y.device)
+        else:
+            dst = np.empty((h, w, 4), dtype=np.uint8)
+        d = _Img(dst)
+        self._chk(self._lib.fnx_ycbcr_to_nrgba(self._h, space, yp, ys, cbp, crp, cs, int(ratio), w, h, d.ptr, d.stride),
+                  "ycbcrToNRGBA")
+        return dst
+
     def applyPalette(self, img, palette, want_quantized: bool = True):
         """applyPalette (targetsize.go:488-527) [+ palettedToNRGBA]: -> (indices (h, w) uint8,
         quantized (h, w, 4) or None).  palette: (n, 4) uint8, opaque."""
@@ -680,6 +711,17 @@ class _Prepared:
         self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against(self._ctx._h, self._p, s.space, s.ptr, s.stride,
                                                             pk, C.byref(out)), "fnx_ssim_fast_against")
         return out.value
+
+    def against_ycbcr(self, y, cb, cr, ratio: int, window=None) -> float:
+        """SSIMFast(reference, toNRGBARef(decoded planes)) -- fnx_ssim_fast_against_ycbcr."""
+        space, yp, ys, cbp, crp, cs, w, h = Context._planes(y, cb, cr)
+        if (w, h) != (self.w, self.h):
+            raise FennecError("candidate dims differ from the prepared reference")
+        k, pk = _f64(self._ctx.gaussianKernel() if window is None else window)
+        out = C.c_double(0.0)
+        self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against_ycbcr(self._ctx._h, self._p, space, yp, ys, cbp, crp, cs,
+                                                                  int(ratio), pk, C.byref(out)), "against_ycbcr")
+        return float(out.value)
 
     def close(self):
         if self._p:

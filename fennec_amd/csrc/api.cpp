@@ -578,26 +578,21 @@ int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride
     return FNX_OK;
 }
 
-int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
-                          int bstride, const double *window, double *out)
+// SSIMFast(prepared reference, device-resident candidate)
+static int against_device(fnx_ctx *ctx, const fnx_prepared *ref, const uint8_t *b, int bstride, const double *window,
+                          double *out)
 {
-    FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
-    FNX_REQUIRE(ref && window && out, "against arguments");
     const int w = ref->w, h = ref->h, pw = ref->pw, ph = ref->ph;
-    FNX_TRY(check_img(b, bstride, w, h, "b"));
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
-    DevImg db;
-    FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
     double *dres;
     FNX_TRY(result_slot(ctx, 1, &dres));
-    const uint8_t *cb = db.p;
-    int cbs = db.stride;
+    const uint8_t *cb = b;
+    int cbs = bstride;
     if (pw != w || ph != h) {
         void *t = nullptr;
         FNX_TRY(scratch(ctx, SLOT_TMP2, static_cast<size_t>(pw) * ph * 4 + 16, &t));
-        FNX_TRY(launch_box_downsample(ctx, 1, db.p, nullptr, db.stride, w, h, static_cast<uint8_t *>(t), pw * 4, 0, pw, ph));
+        FNX_TRY(launch_box_downsample(ctx, 1, b, nullptr, bstride, w, h, static_cast<uint8_t *>(t), pw * 4, 0, pw, ph));
         cb = static_cast<const uint8_t *>(t);
         cbs = pw * 4;
     }
@@ -615,6 +610,95 @@ int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, cons
                                      static_cast<const double *>(dwin), dres));
     }
     return fetch_doubles(ctx, dres, out, 1);
+}
+
+int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
+                          int bstride, const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(ref && window && out, "against arguments");
+    FNX_TRY(check_img(b, bstride, ref->w, ref->h, "b"));
+    DevImg db;
+    FNX_TRY(stage_in(ctx, space, b, bstride, ref->w, ref->h, SLOT_IN_B, &db));
+    return against_device(ctx, ref, db.p, db.stride, window, out);
+}
+
+// ---- decoded JPEG planes (image.YCbCr / image.Gray) -> NRGBA: convert.go:22-64 ----------------
+static int chroma_dims(int ratio, int w, int h, int *cw, int *ch)
+{
+    switch (ratio) {   // image.NewYCbCr's plane sizes for Rect.Min == (0,0)
+    case 0: *cw = w; *ch = h; break;
+    case 1: *cw = (w + 1) / 2; *ch = h; break;
+    case 2: *cw = (w + 1) / 2; *ch = (h + 1) / 2; break;
+    case 3: *cw = w; *ch = (h + 1) / 2; break;
+    case 4: *cw = (w + 3) / 4; *ch = h; break;
+    case 5: *cw = (w + 3) / 4; *ch = (h + 1) / 2; break;
+    default: set_error("invalid argument: subsample ratio"); return FNX_ERR_INVALID;
+    }
+    return FNX_OK;
+}
+
+// planes -> tight device NRGBA in `slot`
+static int ycbcr_stage_convert(fnx_ctx *ctx, int space, const uint8_t *y, int ystride, const uint8_t *cb,
+                               const uint8_t *cr, int cstride, int ratio, int w, int h, uint8_t *dst, int dstride)
+{
+    const bool gray = !cb && !cr;
+    FNX_REQUIRE(y != nullptr && ystride >= w, "Y plane");
+    FNX_REQUIRE(gray || (cb && cr), "Cb and Cr must both be given (or both NULL for image.Gray)");
+    int cw = 0, ch = 0;
+    if (!gray) {
+        FNX_TRY(chroma_dims(ratio, w, h, &cw, &ch));
+        FNX_REQUIRE(cstride >= cw, "chroma stride");
+    }
+    const uint8_t *dy = y, *dcb = cb, *dcr = cr;
+    int dys = ystride, dcs = cstride;
+    if (space == FNX_HOST) {
+        dys = (w + 15) & ~15;
+        dcs = (cw + 15) & ~15;
+        void *t = nullptr;
+        const size_t ybytes = static_cast<size_t>(dys) * h, cbytes = gray ? 0 : static_cast<size_t>(dcs) * ch;
+        FNX_TRY(scratch(ctx, SLOT_TMP1, ybytes + 2 * cbytes + 16, &t));
+        uint8_t *base = static_cast<uint8_t *>(t);
+        FNX_HIP(hipMemcpy2DAsync(base, dys, y, ystride, w, h, hipMemcpyHostToDevice, ctx->stream));
+        dy = base;
+        if (!gray) {
+            FNX_HIP(hipMemcpy2DAsync(base + ybytes, dcs, cb, cstride, cw, ch, hipMemcpyHostToDevice, ctx->stream));
+            FNX_HIP(hipMemcpy2DAsync(base + ybytes + cbytes, dcs, cr, cstride, cw, ch, hipMemcpyHostToDevice, ctx->stream));
+            dcb = base + ybytes;
+            dcr = base + ybytes + cbytes;
+        }
+    }
+    return launch_ycbcr_to_nrgba(ctx, dy, dys, gray ? nullptr : dcb, gray ? nullptr : dcr, dcs, gray ? 0 : ratio, w, h, dst,
+                                 dstride);
+}
+
+int fnx_ycbcr_to_nrgba(fnx_ctx *ctx, int space, const uint8_t *y, int ystride, const uint8_t *cb,
+                       const uint8_t *cr, int cstride, int ratio, int w, int h, uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_TRY(check_img(dst, dstride, w, h, "dst"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevOut d;
+    FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
+    FNX_TRY(ycbcr_stage_convert(ctx, space, y, ystride, cb, cr, cstride, ratio, w, h, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+int fnx_ssim_fast_against_ycbcr(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *y, int ystride,
+                                const uint8_t *cb, const uint8_t *cr, int cstride, int ratio,
+                                const double *window, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(ref && window && out, "against arguments");
+    const int w = ref->w, h = ref->h;
+    FNX_REQUIRE(w > 0 && h > 0, "empty reference");
+    void *t = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_IN_B, static_cast<size_t>(w) * h * 4 + 16, &t));
+    FNX_TRY(ycbcr_stage_convert(ctx, space, y, ystride, cb, cr, cstride, ratio, w, h, static_cast<uint8_t *>(t), w * 4));
+    return against_device(ctx, ref, static_cast<const uint8_t *>(t), w * 4, window, out);
 }
 
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)

@@ -194,6 +194,9 @@ int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t
 // applyPalette (+ palettedToNRGBA): palette = n x 4 host bytes (opaque); idx and/or quant may be null
 int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, const uint8_t *palette, int n,
                          uint8_t *idx, int istride, uint8_t *quant, int qstride);
+// image.YCbCr / image.Gray planes -> NRGBA (convert.hip); device pointers; cb == cr == nullptr: Gray
+int launch_ycbcr_to_nrgba(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr,
+                          int cstride, int ratio, int w, int h, uint8_t *dst, int dstride);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
                   uint8_t *dst, int dstride);
 

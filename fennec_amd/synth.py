@@ -74,3 +74,34 @@ def noise_image(w: int, h: int, seed: int, alpha: bool = False) -> np.ndarray:
     if not alpha:
         img[..., 3] = 255
     return img
+
+
+def ycbcr_planes(w: int, h: int, ratio: int, seed: int):
+    """Seeded image.YCbCr planes as image.NewYCbCr lays them out (Rect.Min = 0,0).
+    ratio: image.YCbCrSubsampleRatio (0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0, 4 4:1:1, 5 4:1:0).
+    Full-range noise, so the saturating branches of color.YCbCr.RGBA() are exercised."""
+    rng = np.random.default_rng(seed)
+    cw = [w, (w + 1) // 2, (w + 1) // 2, w, (w + 3) // 4, (w + 3) // 4][ratio]
+    ch = [h, h, (h + 1) // 2, (h + 1) // 2, h, (h + 1) // 2][ratio]
+    y = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    cb = rng.integers(0, 256, size=(ch, cw), dtype=np.uint8)
+    cr = rng.integers(0, 256, size=(ch, cw), dtype=np.uint8)
+    return y, cb, cr
+
+
+def rgb_to_ycbcr_planes(img: np.ndarray, ratio: int = 2):
+    """A plausible decoder output for an NRGBA image (JFIF forward transform, chroma box-averaged):
+    only used to get photograph-like planes for tests -- not a restatement of any encoder."""
+    r, g, b = (img[..., k].astype(np.float64) for k in range(3))
+    y = np.clip(np.rint(0.299 * r + 0.587 * g + 0.114 * b), 0, 255).astype(np.uint8)
+    cbf = 128 - 0.168736 * r - 0.331264 * g + 0.5 * b
+    crf = 128 + 0.5 * r - 0.418688 * g - 0.081312 * b
+    h, w = y.shape
+    fx = [1, 2, 2, 1, 4, 4][ratio]
+    fy = [1, 1, 2, 2, 1, 2][ratio]
+    cw, ch = (w + fx - 1) // fx, (h + fy - 1) // fy
+
+    def sub(p):
+        pad = np.pad(p, ((0, ch * fy - h), (0, cw * fx - w)), mode="edge")
+        return np.clip(np.rint(pad.reshape(ch, fy, cw, fx).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
+    return y, sub(cbf), sub(crf)

@@ -233,6 +233,24 @@ int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstri
 int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, int *is_opaque,
                    int *is_grayscale);
 
+/* ---- toNRGBARef of a decoded JPEG (convert.go:22-64), SURVEY 8(f) item 1 ------------------- */
+/* Go's image/jpeg returns *image.YCbCr (or *image.Gray): the reference converts it with a
+ * per-pixel At().RGBA() loop on the host (convertToNRGBA, convert.go:34-64) and SSIMFast then
+ * uploads 4 bytes per pixel.  These take the decoder's planes as they are (Rect.Min == (0,0)):
+ * Y: w x h, stride ystride; Cb, Cr: the subsampled planes of image.NewYCbCr, stride cstride;
+ * ratio = image.YCbCrSubsampleRatio (0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0, 4 4:1:1, 5 4:1:0);
+ * cb == cr == NULL: image.Gray.  Arithmetic: image.YCbCr.COffset + color.YCbCr.RGBA() of the Go
+ * standard library (go.mod:3 pins go 1.25.5), then convert.go:48-53's uint8(c >> 8) -- integer,
+ * bit-exact against the restatement in oracle/ (which states its provenance). */
+int fnx_ycbcr_to_nrgba(fnx_ctx *ctx, int space, const uint8_t *y, int ystride, const uint8_t *cb,
+                       const uint8_t *cr, int cstride, int ratio, int w, int h, uint8_t *dst,
+                       int dstride);
+/* SSIMFast(prepared reference, toNRGBARef(decoded planes)) for the quality binary search
+ * (compress.go:45-74): 1.5 bytes per pixel cross PCIe at 4:2:0 instead of 4. */
+int fnx_ssim_fast_against_ycbcr(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *y,
+                                int ystride, const uint8_t *cb, const uint8_t *cr, int cstride,
+                                int ratio, const double *window, double *out);
+
 /* ---- applyPalette + palettedToNRGBA (targetsize.go:488-546), SURVEY 8(f) item 4 ---------- */
 /* Nearest palette entry per pixel by squared RGB distance, first minimum wins (targetsize.go:
  * 505-517); `indices` = image.Paletted.Pix (w x h bytes, stride istride), `quantized` =

@@ -1271,3 +1271,68 @@ ORC_API void orc_apply_palette(const uint8_t *pix, int stride, int w, int h, con
         }
     }
 }
+
+/* ================================================================== */
+/* toNRGBARef of a decoded JPEG (convert.go:22-64) -- SURVEY 8(f).1     */
+/* ================================================================== */
+
+/*
+ * convertToNRGBA (convert.go:34-64) applied to what Go's image/jpeg decoder returns: an
+ * *image.YCbCr (or *image.Gray when cb == cr == NULL) with Rect.Min == (0,0).
+ *
+ * THIRD-PARTY ARITHMETIC, RESTATED: img.At(x,y).RGBA() is Go's standard library --
+ * image.YCbCr.COffset (image/ycbcr.go) for the chroma sample of (x,y), then
+ * color.YCbCr.RGBA() (image/color/ycbcr.go) -- toolchain pinned by go.mod:3 (go 1.25.5),
+ * source not under /root/reference.  The published algorithm: yy1 = Y*0x10101,
+ * cb1 = Cb-128, cr1 = Cr-128; r = yy1 + 91881*cr1, g = yy1 - 22554*cb1 - 46802*cr1,
+ * b = yy1 + 116130*cb1; each channel: if (uint32(v) & 0xff000000) == 0 then v >>= 8 else
+ * v = ^(v >> 31) & 0xffff  (saturate to 0 / 0xffff); alpha 0xffff.  convertToNRGBA then takes
+ * the a == 0xffff branch: uint8(c >> 8) (convert.go:48-53).  color.Gray.RGBA() is y * 0x101.
+ * PARITY UNPINNED like the rest of this file, and additionally a restatement from the published
+ * source of a dependency rather than from files under /root/reference.
+ *
+ * ratio: image.YCbCrSubsampleRatio -- 0: 4:4:4, 1: 4:2:2, 2: 4:2:0, 3: 4:4:0, 4: 4:1:1, 5: 4:1:0.
+ */
+static int32_t ycc_channel(int32_t v)
+{
+    if (((uint32_t)v & 0xff000000u) == 0) return v >> 8;
+    return ~(v >> 31) & 0xffff;
+}
+
+ORC_API int orc_ycbcr_coffset(int ratio, int x, int y, int cstride)
+{
+    switch (ratio) {
+    case 1: return y * cstride + x / 2;
+    case 2: return (y / 2) * cstride + x / 2;
+    case 3: return (y / 2) * cstride + x;
+    case 4: return y * cstride + x / 4;
+    case 5: return (y / 2) * cstride + x / 4;
+    default: return y * cstride + x;
+    }
+}
+
+ORC_API void orc_ycbcr_to_nrgba(const uint8_t *yp, int ystride, const uint8_t *cb, const uint8_t *cr, int cstride,
+                                int ratio, int w, int h, uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            uint32_t r, g, b;
+            int32_t yy = yp[(size_t)y * ystride + x];
+            if (!cb || !cr) {
+                r = g = b = (uint32_t)yy * 0x101u; /* color.Gray.RGBA() */
+            } else {
+                int co = orc_ycbcr_coffset(ratio, x, y, cstride);
+                int32_t yy1 = yy * 0x10101;
+                int32_t cb1 = (int32_t)cb[co] - 128, cr1 = (int32_t)cr[co] - 128;
+                r = (uint32_t)ycc_channel(yy1 + 91881 * cr1);
+                g = (uint32_t)ycc_channel(yy1 - 22554 * cb1 - 46802 * cr1);
+                b = (uint32_t)ycc_channel(yy1 + 116130 * cb1);
+            }
+            uint8_t *o = dst + (size_t)y * dstride + (size_t)x * 4;
+            o[0] = (uint8_t)(r >> 8); /* a == 0xffff branch, convert.go:48-53 */
+            o[1] = (uint8_t)(g >> 8);
+            o[2] = (uint8_t)(b >> 8);
+            o[3] = 0xff;
+        }
+    }
+}

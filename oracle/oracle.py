@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         L.orc_analyze_format.argtypes = [_u8p, C.c_int, C.c_int, C.c_int]
         L.orc_apply_palette.restype = None
         L.orc_apply_palette.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int, _u8p, C.c_int]
+        L.orc_ycbcr_to_nrgba.restype = None
+        L.orc_ycbcr_to_nrgba.argtypes = [_u8p, C.c_int, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -375,3 +377,17 @@ def apply_palette(img: np.ndarray, palette: np.ndarray):
     lib().orc_apply_palette(p, s, w, h, pal.ctypes.data_as(_u8p), len(pal), idx.ctypes.data_as(_u8p), w,
                             q.ctypes.data_as(_u8p), 4 * w)
     return idx, q
+
+
+def ycbcr_to_nrgba(y: np.ndarray, cb, cr, ratio: int) -> np.ndarray:
+    """toNRGBARef of an image.YCbCr / image.Gray (convert.go:22-64 + Go's color.YCbCr.RGBA)."""
+    h, w = y.shape
+    y = np.ascontiguousarray(y)
+    dst = new_image(w, h)
+    if cb is None:
+        lib().orc_ycbcr_to_nrgba(y.ctypes.data_as(_u8p), w, None, None, 0, 0, w, h, dst.ctypes.data_as(_u8p), 4 * w)
+    else:
+        cb, cr = np.ascontiguousarray(cb), np.ascontiguousarray(cr)
+        lib().orc_ycbcr_to_nrgba(y.ctypes.data_as(_u8p), w, cb.ctypes.data_as(_u8p), cr.ctypes.data_as(_u8p),
+                                 cb.shape[1], int(ratio), w, h, dst.ctypes.data_as(_u8p), 4 * w)
+    return dst

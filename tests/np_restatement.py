@@ -516,3 +516,23 @@ def apply_palette(img, palette):
     idx = np.argmin(dist, axis=2).astype(np.uint8)          # first minimum, like the strict `<`
     q = np.asarray(palette, dtype=np.uint8).reshape(-1, 4)[idx]
     return idx, q
+
+
+def ycbcr_to_nrgba(y, cb, cr, ratio):
+    """convertToNRGBA (convert.go:34-64) of an image.YCbCr: COffset + color.YCbCr.RGBA() of Go's
+    standard library (published algorithm), opaque branch uint8(c >> 8)."""
+    h, w = y.shape
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    out[..., 3] = 255
+    if cb is None:
+        out[..., 0] = out[..., 1] = out[..., 2] = (y.astype(np.uint32) * 0x101) >> 8
+        return out
+    xs = np.arange(w) >> [0, 1, 1, 0, 2, 2][ratio]
+    ys = np.arange(h) >> [0, 0, 1, 1, 0, 1][ratio]
+    cb1 = cb[ys[:, None], xs[None, :]].astype(np.int64) - 128
+    cr1 = cr[ys[:, None], xs[None, :]].astype(np.int64) - 128
+    yy1 = y.astype(np.int64) * 0x10101
+    for k, v in enumerate((yy1 + 91881 * cr1, yy1 - 22554 * cb1 - 46802 * cr1, yy1 + 116130 * cb1)):
+        c16 = np.where(v < 0, 0, np.where(v >= (1 << 24), 0xffff, v >> 8))
+        out[..., k] = c16 >> 8
+    return out

@@ -626,3 +626,32 @@ def test_apply_palette_device_and_extremes(ctx, orc):
     assert np.array_equal(gi, orc.apply_palette(img, bw)[0]) and gi.max() <= 1
     with pytest.raises(fennec_amd.FennecError):
         ctx.applyPalette(img, np.array([[1, 2, 3, 200]], dtype=np.uint8))      # translucent palette entry
+
+
+# ------------------------------------------------------------------ decoded JPEG planes -> NRGBA, SURVEY 8(f).1
+@pytest.mark.parametrize("ratio", [0, 1, 2, 3, 4, 5])
+def test_ycbcr_to_nrgba(ctx, orc, ratio):
+    import torch
+    for (w, h) in [(640, 480), (37, 29), (1, 1), (5, 2), (1283, 719)]:
+        y, cb, cr = synth.ycbcr_planes(w, h, ratio, 7 * ratio + w)
+        want = orc.ycbcr_to_nrgba(y, cb, cr, ratio)
+        assert np.array_equal(ctx.ycbcrToNRGBA(y, cb, cr, ratio), want)
+        got = ctx.ycbcrToNRGBA(torch.from_numpy(y).cuda(), torch.from_numpy(cb).cuda(), torch.from_numpy(cr).cuda(), ratio)
+        ctx.sync()
+        assert np.array_equal(got.cpu().numpy(), want)
+    y = synth.ycbcr_planes(301, 200, 0, 5)[0]
+    assert np.array_equal(ctx.ycbcrToNRGBA(y, None, None, 0), orc.ycbcr_to_nrgba(y, None, None, 0))   # image.Gray
+
+
+def test_ssim_fast_against_ycbcr_4k(ctx, orc):
+    """compress.go:45-74 with the decoder's planes: SSIMFast(src, toNRGBARef(decoded YCbCr))."""
+    src = synth.large_photo(3840, 2160, 6)
+    prep = ctx.ssim_fast_prepare(src)
+    for ratio in (2, 0, 1):
+        y, cb, cr = synth.rgb_to_ycbcr_planes(src, ratio)
+        dec = orc.ycbcr_to_nrgba(y, cb, cr, ratio)
+        want = orc.ssim_fast(src, dec, procs=16)
+        assert abs(prep.against_ycbcr(y, cb, cr, ratio) - want) <= SSIM_TOL
+        assert prep.against_ycbcr(y, cb, cr, ratio) == prep.against(dec)      # same kernels after the conversion
+        assert 0.5 < want < 1.0
+    prep.close()

@@ -299,3 +299,18 @@ def test_apply_palette_match(orc, n):      # targetsize.go:488-546
     assert np.all(q1[..., 3] == 255)
     exact = pal[[0]].repeat(4, axis=0).reshape(2, 2, 4)     # a pixel that IS a palette colour maps to it
     assert np.array_equal(orc.apply_palette(exact, pal)[1], exact)
+
+
+@pytest.mark.parametrize("ratio", [0, 1, 2, 3, 4, 5])
+def test_ycbcr_to_nrgba_match(orc, ratio):        # convert.go:34-64 over image.YCbCr (Go stdlib arithmetic)
+    for (w, h) in [(64, 48), (37, 29), (1, 1), (5, 2)]:
+        y, cb, cr = synth.ycbcr_planes(w, h, ratio, 10 * ratio + w)
+        assert np.array_equal(orc.ycbcr_to_nrgba(y, cb, cr, ratio), npr.ycbcr_to_nrgba(y, cb, cr, ratio))
+    y = synth.ycbcr_planes(40, 30, 0, 3)[0]
+    g = orc.ycbcr_to_nrgba(y, None, None, 0)               # image.Gray
+    assert np.array_equal(g, npr.ycbcr_to_nrgba(y, None, None, 0))
+    assert np.array_equal(g[..., 0], y) and np.all(g[..., 3] == 255)
+    # neutral chroma is grey, white stays white, black stays black (color.YCbCr.RGBA invariants)
+    y = np.array([[0, 255, 17]], dtype=np.uint8)
+    n = np.full((1, 3), 128, dtype=np.uint8)
+    assert np.array_equal(orc.ycbcr_to_nrgba(y, n, n, 0)[0, :, :3], np.array([[0] * 3, [255] * 3, [17] * 3]))
