@@ -13,6 +13,7 @@
 #include "devutil.hpp"
 
 #include <algorithm>
+#include <cmath>
 
 namespace fnx {
 
@@ -94,8 +95,9 @@ struct FusedArgs {
     int nbx, nby;                 // most box columns / rows any tile touches
 };
 
-// capacity of the per-tile box table, entries per image: (nbx+1) * (nby+1) <= SCORE_NBOX
-constexpr int SCORE_NBOX = 192;
+// most entries of a per-tile box table, (nbx+1) * (nby+1): the two tables live in dynamic LDS sized
+// per launch (4K: 2 x 176 x 8 B = 2.8 KB); the cap keeps the kernel at >= 3 workgroups per CU
+constexpr int SCORE_NBOX = 512;
 
 // channel sums of one pixel into the box table entry at byte offset `off`: the entry is
 // R | G<<16 | B<<32 | A<<48, a box of <= 256 px cannot carry out of a 16-bit field
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     static_assert(Q * RG == TH && SR <= IH && SR % 2 == 0, "tile shape");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_tmp[SR * TW];   // H pass: R,G,B rounded + source alpha
-    __shared__ unsigned long long s_box[SCORE ? 2 * SCORE_NBOX : 1];   // [src | blurred] box tables
+    extern __shared__ unsigned long long s_box[];                      // SCORE: [src | blurred] box tables, 2 * slabn
     __shared__ __attribute__((aligned(16))) uint32_t s_coloff[SCORE ? TW : 4];   // byte offset of a tile column's box
     __shared__ uint32_t s_rowoff[SCORE ? TH : 1];                      // ... of a tile row's box row
 
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         // table layout: (nby+1) rows of (nbx+1) entries; the last column / row collect pixels that
         // belong to no box (outside the image, or the source's unboxed tail columns / rows)
         const int slabn = (a.nbx + 1) * (a.nby + 1);
-        for (int e = tid; e < slabn; e += NTH) s_box[e] = s_box[SCORE_NBOX + e] = 0;
+        for (int e = tid; e < 2 * slabn; e += NTH) s_box[e] = 0;
         if (tid < TW) {
             const int b0 = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
             s_coloff[tid] = (v >= 0 && b0 >= 0) ? 8u * (v - b0) : 8u * a.nbx;
@@ -323,12 +325,13 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         fp32_round_nearest();
         if constexpr (SCORE) {   // blurred side of the box sums (columns / rows outside the image -> spare entries)
+            unsigned long long *s_box_b = s_box + (a.nbx + 1) * (a.nby + 1);
             const u32x2 co = *reinterpret_cast<const u32x2 *>(s_coloff + 2 * cp);
 #pragma unroll
             for (int j = 0; j < Q; j++) {
                 const uint32_t ro = s_rowoff[rg * Q + j];
-                box_add(s_box + SCORE_NBOX, ro + co.x, o[j].x);
-                box_add(s_box + SCORE_NBOX, ro + co.y, o[j].y);
+                box_add(s_box_b, ro + co.x, o[j].x);
+                box_add(s_box_b, ro + co.y, o[j].y);
             }
         }
         if (x < a.w) {
@@ -350,10 +353,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         __syncthreads();
         const int slabn = (a.nbx + 1) * (a.nby + 1);
         unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
-        for (int e = tid; e < slabn; e += NTH) {
-            slab[e] = s_box[e];
-            slab[slabn + e] = s_box[SCORE_NBOX + e];
-        }
+        for (int e = tid; e < 2 * slabn; e += NTH) slab[e] = s_box[e];
     }
 }
 
@@ -442,7 +442,8 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
     if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
-    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), 0, ctx->stream, fa);
+    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * 2 * (fa.nbx + 1) * (fa.nby + 1) : 0;
+    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), dyn_lds, ctx->stream, fa);
     FNX_HIP(hipGetLastError());
     if (ctx->prof) {
         FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
@@ -508,6 +509,11 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
         return false;
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
     const double yr = static_cast<double>(h) / static_cast<double>(dstH);
+    // Where the one-pass kernel wins (measured, tools/time_onepass.py, us per image one-pass / two-call):
+    // ratio 3.1 (1600x1200) 11.0 / 10.2, 3.75 (1080p) 10.2 / 9.8, 5 (1440p) 15.4 / 15.6, 7.5 (4K) 30.2 / 32.8,
+    // 15 (8K) 129.5 / 122.0 -- small boxes mean many table entries per tile to zero and store, large
+    // boxes mean 8 lanes adding into one LDS word.  Outside [5, 12] the two ops run back to back.
+    if (std::fmin(xr, yr) < 5.0 || std::fmax(xr, yr) > 12.0) return false;
     // source column / row -> box index (boxes of a downscale are disjoint and ascending)
     // one table blob: 1/c for c in [0, 256] (doubles) | BoxRef per output column, per output row |
     // box index of every source column, every source row
