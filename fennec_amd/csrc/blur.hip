@@ -509,11 +509,12 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
         return false;
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
     const double yr = static_cast<double>(h) / static_cast<double>(dstH);
-    // Where the one-pass kernel wins (measured, tools/time_onepass.py, us per image one-pass / two-call):
-    // ratio 3.1 (1600x1200) 11.0 / 10.2, 3.75 (1080p) 10.2 / 9.8, 5 (1440p) 15.4 / 15.6, 7.5 (4K) 30.2 / 32.8,
-    // 15 (8K) 129.5 / 122.0 -- small boxes mean many table entries per tile to zero and store, large
-    // boxes mean 8 lanes adding into one LDS word.  Outside [5, 12] the two ops run back to back.
-    if (std::fmin(xr, yr) < 5.0 || std::fmax(xr, yr) > 12.0) return false;
+    // Where the one-pass kernel wins (measured at steady clocks, tools/time_onepass.py, us per image
+    // one-pass / two-call): ratio 3.1 (1600x1200) 13.2 / 9.8, 3.75 (1080p) 9.0 / 9.3, 5 (1440p) 13.4 / 15.3,
+    // 7.5 (4K) 26.8 / 32.1, 10 (5K) 49.2 / 54.9, 15 (8K) 121.4 / 117.8 -- small boxes mean many table
+    // entries per tile to zero and store, large boxes mean 8 lanes adding into one LDS word (and the
+    // two-call box kernel streams long columns well).  Outside [3.6, 12] the two ops run back to back.
+    if (std::fmin(xr, yr) < 3.6 || std::fmax(xr, yr) > 12.0) return false;
     // source column / row -> box index (boxes of a downscale are disjoint and ascending)
     // one table blob: 1/c for c in [0, 256] (doubles) | BoxRef per output column, per output row |
     // box index of every source column, every source row
