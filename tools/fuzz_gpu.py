@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Randomised HIP-vs-oracle sweep (run on a GPU box): python tools/fuzz_gpu.py [seconds] [seed].
+Not part of the test suite (time-boxed, random); every failure prints the reproducing seed/case."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fennec_amd  # noqa: E402
+from fennec_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = fennec_amd.Context(0)
+SSIM_TOL = 1e-9
+fails, runs = [], {}
+
+
+def rand_image(w, h):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return synth.noise_image(w, h, int(rng.integers(1 << 30)), alpha=bool(rng.integers(2)))
+    if kind == 1:
+        return synth.large_photo(w, h, int(rng.integers(100)))
+    if kind == 2:
+        return synth.make_test_image_with_alpha(w, h)
+    img = synth.noise_image(w, h, int(rng.integers(1 << 30)), alpha=True)
+    img[..., :3] &= 0xF0                       # few colours, ties in the filters
+    return img
+
+
+def blur_close(got, want):
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    return d.max() <= 1 and float((d[..., :3] != 0).mean()) <= 1e-3 and np.array_equal(got[..., 3], want[..., 3])
+
+
+def case(name, ok, desc):
+    runs[name] = runs.get(name, 0) + 1
+    if not ok:
+        fails.append((name, desc))
+        print("FAIL", name, desc, flush=True)
+
+
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    it += 1
+    w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+    if rng.integers(8) == 0:
+        w, h = int(rng.integers(500, 2300)), int(rng.integers(300, 1300))
+    img = rand_image(w, h)
+    desc = f"seed={seed} it={it} {w}x{h}"
+    sigma = float(rng.choice([0.3, 0.7, 1.0, 1.5, 2.0, 2.6, 3.4]))
+    want = orc.gaussian_blur(img, sigma, procs=8)
+    case("blur_exact", np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want), desc + f" sigma={sigma}")
+    case("blur_fast", blur_close(ctx.GaussianBlur(img, sigma), want), desc + f" sigma={sigma}")
+    st = float(rng.uniform(0.05, 1.3))
+    case("sharpen", np.array_equal(ctx.Sharpen(img, st), orc.sharpen(img, st, procs=4)), desc + f" s={st}")
+    case("adaptive", np.array_equal(ctx.AdaptiveSharpen(img, st), orc.adaptive_sharpen(img, st, procs=4)), desc + f" s={st}")
+    dw, dh = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+    case("resize", np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh, procs=8)), desc + f" -> {dw}x{dh}")
+    bw, bh = int(rng.integers(1, max(2, w + 3))), int(rng.integers(1, max(2, h + 3)))
+    case("box", np.array_equal(ctx.boxDownsample(img, bw, bh), orc.box_downsample(img, bw, bh)), desc + f" -> {bw}x{bh}")
+    o = int(rng.integers(2, 9))
+    case("orient", np.array_equal(ctx.ApplyOrientation(img, o), orc.apply_orientation(img, o)), desc + f" o={o}")
+    other = ctx.GaussianBlur(img, 1.0) if rng.integers(2) else rand_image(w, h)
+    case("ssim", abs(ctx.SSIM(img, other) - orc.ssim(img, other, procs=8)) <= SSIM_TOL, desc)
+    case("ssim_fast", abs(ctx.SSIMFast(img, other) - orc.ssim_fast(img, other, procs=8)) <= SSIM_TOL, desc)
+    case("msssim", abs(ctx.MSSSIM(img, other) - orc.msssim(img, other, procs=8)) <= SSIM_TOL, desc)
+    a, wa = ctx.analyze_raw(img), orc.analyze(img)
+    ok = (np.array_equal(a["histogram"].astype(np.float64), wa["histogram"]) and
+          all(a[k] == wa[k] for k in ("has_alpha", "is_grayscale", "unique_colors", "sample_count", "edge_count", "edge_total")) and
+          abs(a["bright_sum"] - wa["bright_sum"]) <= max(1e-12, w * h * 2.0 ** -53) * max(1.0, abs(wa["bright_sum"])) and
+          abs(a["variance_sum"] - wa["variance_sum"]) <= 1e-9 * abs(wa["variance_sum"]) + 1e-6)
+    case("analyze", ok, desc)
+    n = int(rng.integers(1, 257))
+    pal = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    pal[:, 3] = 255
+    gi, gq = ctx.applyPalette(img, pal)
+    wi, wq = orc.apply_palette(img, pal)
+    case("palette", np.array_equal(gi, wi) and np.array_equal(gq, wq), desc + f" n={n}")
+    ratio = int(rng.integers(0, 6))
+    y, cb, cr = synth.ycbcr_planes(w, h, ratio, int(rng.integers(1 << 30)))
+    case("ycbcr", np.array_equal(ctx.ycbcrToNRGBA(y, cb, cr, ratio), orc.ycbcr_to_nrgba(y, cb, cr, ratio)), desc + f" ratio={ratio}")
+    if it % 6 == 0:                         # one-pass kernel: sizes inside its gate, odd dims, all radii
+        import torch
+        w2, h2 = int(rng.integers(1850, 4300)), int(rng.integers(1100, 2600))
+        imgs = [rand_image(w2, h2) for _ in range(2)]
+        d = [torch.from_numpy(i).cuda() for i in imgs]
+        torch.cuda.synchronize()
+        outs, ss = ctx.GaussianBlurSSIMFastBatch(d, sigma)
+        ref = ctx.GaussianBlurBatch(d, sigma)
+        rs = ctx.SSIMFastBatch(d, ref)
+        ok = all(torch.equal(x, y_) for x, y_ in zip(outs, ref)) and np.array_equal(ss, rs)
+        ok = ok and abs(ss[0] - orc.ssim_fast(imgs[0], outs[0].cpu().numpy(), procs=16)) <= SSIM_TOL
+        ok = ok and blur_close(outs[1].cpu().numpy(), orc.gaussian_blur(imgs[1], sigma, procs=16))
+        case("one_pass", ok, f"seed={seed} it={it} {w2}x{h2} sigma={sigma}")
+print("runs:", runs)
+print("FAILURES:", len(fails))
+for f in fails[:20]:
+    print("  ", f)
+sys.exit(1 if fails else 0)
