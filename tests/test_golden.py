@@ -35,6 +35,8 @@ def test_oracle_reproduces_golden(orc, name):
     for cid, kind, val in mg.cases(name, img):
         if kind == "image":
             assert list(val.shape) == exp[cid]["shape"] and sha(val) == exp[cid]["sha256"], (name, cid)
+        elif kind == "stats":
+            assert val == exp[cid]["stats"], (name, cid)
         else:
             assert float(val).hex() == exp[cid]["hex"], (name, cid)
     for key in SMALL.files:
@@ -70,7 +72,32 @@ def _hip_case(ctx, img, blurred, cid):
         return ctx.SSIMFast(img, blurred)
     if op == "msssim":
         return ctx.MSSSIM(img, blurred)
+    if op == "apply_palette":
+        idx, quant = ctx.applyPalette(img, mg.golden_palette(int(arg)))
+        return idx if cid.endswith(".indices") else quant
+    if op == "ycbcr_to_nrgba":
+        from fennec_amd import synth
+        h, w = img.shape[:2]
+        y, cb, cr = synth.ycbcr_planes(w, h, int(arg), 1000 + w)
+        return ctx.ycbcrToNRGBA(y, cb, cr, int(arg))
     raise KeyError(cid)
+
+
+def _check_stats(ctx, img, want):
+    """fnx_analyze against the stored Analyze accumulators: integers exact, the two order-dependent
+    sums within the serial chain's own error bound (see tests/test_gpu_parity.py)."""
+    a = ctx.analyze_raw(img)
+    h, w = img.shape[:2]
+    assert sha(a["histogram"].astype(np.uint64)) == want["histogram_sha256"]
+    for k in ("has_alpha", "is_grayscale", "unique_colors", "sample_count", "edge_count", "edge_total"):
+        assert a[k] == want[k], k
+    bs, vs = float.fromhex(want["bright_sum"]), float.fromhex(want["variance_sum"])
+    assert abs(a["bright_sum"] - bs) <= max(1e-12, w * h * 2.0 ** -53) * abs(bs)
+    assert abs(a["variance_sum"] - vs) <= 1e-9 * abs(vs) + 1e-6
+    st = ctx.Analyze(img)
+    assert abs(st["Entropy"] - float.fromhex(want["entropy"])) <= 1e-12
+    assert st["EdgeDensity"] == float.fromhex(want["edge_density"])
+    assert (st["RecommendedFormat"], st["RecommendedQuality"]) == (want["recommended_format"], want["recommended_quality"])
 
 
 @pytest.mark.gpu
@@ -83,6 +110,9 @@ def test_hip_reproduces_golden(name):
     blurred = ctx.GaussianBlur(img, 1.2, exact=True)      # bit-exact stand-in for the oracle's blur
     for cid, e in exp.items():
         if cid == "input_sha256":
+            continue
+        if "stats" in e:
+            _check_stats(ctx, img, e["stats"])
             continue
         got = _hip_case(ctx, img, blurred, cid)
         if "sha256" in e:
