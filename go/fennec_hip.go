@@ -35,6 +35,7 @@ import "C"
 
 import (
 	"image"
+	"image/color"
 	"math"
 	"runtime"
 	"sync"
@@ -392,3 +393,100 @@ func Analyze(img image.Image) ImageStats {
 //
 //	C.fnx_gaussian_blur_ssim_fast_batch(c, n, &srcs[0], stride, w, h, &kernel[0], radius,
 //	        C.FNX_BLUR_FAST, &dsts[0], stride, &ssimWindow[0], &scores[0])
+
+// ---- compress.go: the quality binary search (compress.go:45-74) ----------------------------
+
+// ssimAgainst scores decoded candidates against ONE prepared source: the source's downsampled
+// side is computed once per search instead of once per step, and a candidate that the decoder
+// returned as *image.YCbCr / *image.Gray crosses PCIe as planes (1.5 bytes per pixel at 4:2:0)
+// and is converted on the device (the arithmetic of color.YCbCr.RGBA + convert.go:48-53).
+// compressJPEGOptimal's loop body changes from
+//
+//	decoded, _ := jpeg.Decode(...); ssim := SSIMFast(src, toNRGBARef(decoded))
+//
+// to `ssim := ref.against(decoded)`, with `ref := prepareSSIM(src); defer ref.close()` before it.
+type ssimRef struct {
+	c   *C.fnx_ctx
+	p   *C.fnx_prepared
+	src *image.NRGBA
+}
+
+func prepareSSIM(src *image.NRGBA) *ssimRef {
+	r := &ssimRef{src: src}
+	if c := pool.get(); c != nil {
+		var p *C.fnx_prepared
+		if C.fnx_ssim_fast_prepare(c, C.FNX_HOST, pix(src), C.int(src.Stride),
+			C.int(src.Bounds().Dx()), C.int(src.Bounds().Dy()), &p) == C.FNX_OK {
+			r.c, r.p = c, p
+		} else {
+			pool.put(c)
+		}
+	}
+	return r
+}
+
+func (r *ssimRef) close() {
+	if r.p != nil {
+		C.fnx_prepared_free(r.c, r.p)
+		pool.put(r.c)
+		r.p = nil
+	}
+}
+
+func (r *ssimRef) against(decoded image.Image) float64 {
+	if r.p != nil {
+		var out C.double
+		st := C.int(-1)
+		switch d := decoded.(type) {
+		case *image.YCbCr:
+			if d.Rect.Min == (image.Point{}) && d.Rect.Dx() == r.src.Bounds().Dx() && d.Rect.Dy() == r.src.Bounds().Dy() {
+				st = C.fnx_ssim_fast_against_ycbcr(r.c, r.p, C.FNX_HOST,
+					(*C.uint8_t)(unsafe.Pointer(&d.Y[0])), C.int(d.YStride),
+					(*C.uint8_t)(unsafe.Pointer(&d.Cb[0])), (*C.uint8_t)(unsafe.Pointer(&d.Cr[0])), C.int(d.CStride),
+					C.int(d.SubsampleRatio), (*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+			}
+		case *image.Gray:
+			if d.Rect.Min == (image.Point{}) && d.Rect.Dx() == r.src.Bounds().Dx() && d.Rect.Dy() == r.src.Bounds().Dy() {
+				st = C.fnx_ssim_fast_against_ycbcr(r.c, r.p, C.FNX_HOST,
+					(*C.uint8_t)(unsafe.Pointer(&d.Pix[0])), C.int(d.Stride), nil, nil, 0, 0,
+					(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+			}
+		case *image.NRGBA:
+			st = C.fnx_ssim_fast_against(r.c, r.p, C.FNX_HOST, pix(d), C.int(d.Stride),
+				(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		}
+		runtime.KeepAlive(decoded)
+		if st == C.FNX_OK {
+			return float64(out)
+		}
+	}
+	return ssimFastGo(r.src, toNRGBARef(decoded)) // anything else: the reference's own path
+}
+
+// ---- targetsize.go: applyPalette (targetsize.go:488) ----------------------------------------
+
+// applyPalette replaces targetsize.go:488 for opaque palettes (what medianCut builds).
+func applyPalette(src *image.NRGBA, palette color.Palette) *image.Paletted {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	pal := make([]C.uint8_t, 0, 4*len(palette))
+	ok := len(palette) >= 1 && len(palette) <= 256 && w > 0 && h > 0
+	for _, c := range palette {
+		n, isN := c.(color.NRGBA)
+		if !isN || n.A != 255 {
+			ok = false
+			break
+		}
+		pal = append(pal, C.uint8_t(n.R), C.uint8_t(n.G), C.uint8_t(n.B), 255)
+	}
+	if c := pool.get(); ok && c != nil {
+		defer pool.put(c)
+		indexed := image.NewPaletted(src.Bounds(), palette)
+		st := C.fnx_apply_palette(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h),
+			&pal[0], C.int(len(palette)), (*C.uint8_t)(unsafe.Pointer(&indexed.Pix[0])), C.int(indexed.Stride), nil, 0)
+		runtime.KeepAlive(src)
+		if st == C.FNX_OK {
+			return indexed
+		}
+	}
+	return applyPaletteGo(src, palette)
+}
