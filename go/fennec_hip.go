@@ -478,7 +478,10 @@ func applyPalette(src *image.NRGBA, palette color.Palette) *image.Paletted {
 		}
 		pal = append(pal, C.uint8_t(n.R), C.uint8_t(n.G), C.uint8_t(n.B), 255)
 	}
-	if c := pool.get(); ok && c != nil {
+	if !ok {
+		return applyPaletteGo(src, palette)
+	}
+	if c := pool.get(); c != nil {
 		defer pool.put(c)
 		indexed := image.NewPaletted(src.Bounds(), palette)
 		st := C.fnx_apply_palette(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h),
