@@ -18,15 +18,17 @@ struct FxArgs {
 };
 
 // Workgroup = 64 x 8 output pixels (2 per lane).  The 66 x 10 source tile is loaded once into
-// LDS (raw pixel + its BT.601 luminance), so every pixel's luminance is computed once instead of
-// once per Sobel neighbour (8x) and the 3x3 neighbourhood costs LDS reads, not global loads.
+// LDS -- as two words per pixel with the channels spread into 16-bit fields (R|B<<16, G|A<<16),
+// plus its BT.601 luminance -- so every pixel's luminance is computed once instead of once per
+// Sobel neighbour (8x), the 3x3 neighbourhood costs LDS reads, not global loads, and the binomial
+// sum (max 16*255 per field) runs on two channels per add.
 constexpr int FX_TW = 64, FX_TH = 8;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
 {
     constexpr int LW = FX_TW + 2, LH = FX_TH + 2;
-    __shared__ uint32_t s_px[LH * LW];
+    __shared__ uint32_t s_rb[LH * LW], s_ga[LH * LW];
     __shared__ double s_lum[MODE == FX_ADAPTIVE ? LH * LW : 1];
     const int x0 = blockIdx.x * FX_TW, y0 = blockIdx.y * FX_TH;
     const int tid = threadIdx.x;
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
         // are copies of the source and never look at them
         const int x = clampi(x0 + lx - 1, 0, a.w - 1), y = clampi(y0 + ly - 1, 0, a.h - 1);
         const uint32_t p = ld_px(a.src + static_cast<size_t>(y) * a.sstride, x);
-        s_px[i] = p;
+        s_rb[i] = p & 0x00ff00ffu;
+        s_ga[i] = (p >> 8) & 0x00ff00ffu;
         if (MODE == FX_ADAPTIVE) s_lum[i] = lum601(p);
     }
     __syncthreads();
@@ -49,21 +52,16 @@ __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
         const int y = y0 + ly;
         if (y >= a.h) continue;
         const int ci = (ly + 1) * LW + lx + 1;          // tile cell of (x, y)
-        const uint32_t c = s_px[ci];
+        const uint32_t crb = s_rb[ci], cga = s_ga[ci];
+        const uint32_t c = crb | (cga << 8);
         uint32_t out = c;   // borders and alpha are copies of the source (effects.go:68,120)
         if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
-            const uint32_t p00 = s_px[ci - LW - 1], p01 = s_px[ci - LW], p02 = s_px[ci - LW + 1];
-            const uint32_t p10 = s_px[ci - 1], p12 = s_px[ci + 1];
-            const uint32_t p20 = s_px[ci + LW - 1], p21 = s_px[ci + LW], p22 = s_px[ci + LW + 1];
-            uint32_t blur[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int s = 8 * ch;
-                const uint32_t sum = ((p00 >> s) & 0xffu) + 2 * ((p01 >> s) & 0xffu) + ((p02 >> s) & 0xffu) +
-                                     2 * ((p10 >> s) & 0xffu) + 4 * ((c >> s) & 0xffu) + 2 * ((p12 >> s) & 0xffu) +
-                                     ((p20 >> s) & 0xffu) + 2 * ((p21 >> s) & 0xffu) + ((p22 >> s) & 0xffu);
-                blur[ch] = (sum + 8) >> 4;                       // effects.go:125-135
-            }
+            // [1 2 1; 2 4 2; 1 2 1] on two channels per word; (sum + 8) >> 4 per field (effects.go:125-135)
+            const uint32_t srb = (s_rb[ci - LW - 1] + s_rb[ci - LW + 1] + s_rb[ci + LW - 1] + s_rb[ci + LW + 1]) +
+                                 2 * (s_rb[ci - LW] + s_rb[ci - 1] + s_rb[ci + 1] + s_rb[ci + LW]) + 4 * crb + 0x00080008u;
+            const uint32_t sga = (s_ga[ci - LW - 1] + s_ga[ci - LW + 1] + s_ga[ci + LW - 1] + s_ga[ci + LW + 1]) +
+                                 2 * (s_ga[ci - LW] + s_ga[ci - 1] + s_ga[ci + 1] + s_ga[ci + LW]) + 4 * cga + 0x00080008u;
+            const uint32_t blur[3] = {(srb >> 4) & 0xffu, (sga >> 4) & 0xffu, (srb >> 20) & 0xffu};
             if (MODE == FX_BLUR3) {
                 out = blur[0] | (blur[1] << 8) | (blur[2] << 16) | (c & 0xff000000u);
             } else {

@@ -438,8 +438,17 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial,
 {
     __shared__ double s_red[4];
     const double *p = partial + static_cast<size_t>(blockIdx.x) * tiles;
-    double v = 0;
-    for (int i = threadIdx.x; i < tiles; i += 256) v += p[i];
+    // 8 independent partial sums per lane keep 8 loads in flight (a single chain waits out every load:
+    // 60 us for the 65 k tiles of an 8K SSIM); the combination order is fixed, so results stay
+    // bit-reproducible from run to run
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < tiles; i += 8 * 256) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += p[i + e * 256];
+    }
+    for (int e = 0; i < tiles; i += 256, e++) acc[e] += p[i];
+    const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     const double t = block_sum_256(v, s_red);
     if (threadIdx.x == 0) out[blockIdx.x] = count > 0 ? t / count : 1.0;   // totalCount==0 -> 1.0 (ssim.go:162-164)
 }
