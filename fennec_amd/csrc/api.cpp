@@ -131,7 +131,7 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
     FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0, "batch arguments");
     if (n == 0 || w <= 0 || h <= 0) return FNX_OK;
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
-    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
+    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i] && srcs[i] != dsts[i], "null image in batch, or dst aliases src (the blur is not in-place)");
     const void *hosts[2] = {srcs, dsts};
     const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
     void *dp[2];
@@ -390,7 +390,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0, "dims");
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
-    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
+    for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i] && srcs[i] != dsts[i], "null image in batch, or dst aliases src (the blur is not in-place)");
     int nw, nh;
     const bool down = ssim_fast_dims(w, h, &nw, &nh);
     if (down && nw >= 8 && nh >= 8 && !(flags & FNX_BLUR_EXACT)) {
