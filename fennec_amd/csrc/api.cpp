@@ -88,16 +88,23 @@ int result_slot(fnx_ctx *ctx, int n, double **d)
     return FNX_OK;
 }
 
-// results -> pinned host memory right behind the kernels + an event: fnx_results_fetch then
-// never waits for work that was queued on this stream after the batch
-int publish_results(fnx_ctx *ctx, const double *dres, int n)
+// an event right behind the result kernels: fnx_results_fetch then never waits for work that was
+// queued on this stream after the batch
+// The result kernels of the *_enqueue entry points write their n doubles straight into pinned host
+// memory (mapped into the device's address space by hipHostMalloc): no D2H copy to launch.
+int pinned_results(fnx_ctx *ctx, int n, double **out)
 {
     void *pin = nullptr;
-    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n), &pin));
-    FNX_HIP(hipMemcpyAsync(pin, dres, sizeof(double) * size_t(n), hipMemcpyDeviceToHost, ctx->stream));
+    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n > 16 ? n : 16), &pin));
+    *out = static_cast<double *>(pin);
+    return FNX_OK;
+}
+
+int publish_results(fnx_ctx *ctx, const double *pinned, int n)
+{
     if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
     FNX_HIP(hipEventRecord(ctx->res_event, ctx->stream));
-    ctx->res_pinned = static_cast<const double *>(pin);
+    ctx->res_pinned = pinned;
     ctx->res_n = n;
     return FNX_OK;
 }
@@ -358,7 +365,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
-    FNX_TRY(result_slot(ctx, n, &dres));
+    FNX_TRY(pinned_results(ctx, n, &dres));
     int nw, nh;
     bool al = !(astride & 15) && !(bstride & 15);
     for (int i = 0; i < n; i++) {
@@ -410,7 +417,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
             void *dwin = nullptr;
             FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
             double *dres;
-            FNX_TRY(result_slot(ctx, n, &dres));
+            FNX_TRY(pinned_results(ctx, n, &dres));
             FNX_TRY(launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
                                          window, static_cast<const double *>(dwin), dres));
             return publish_results(ctx, dres, n);
