@@ -251,10 +251,12 @@ func GaussianBlur(img *image.NRGBA, sigma float64) *image.NRGBA {
 	if c := pool.get(); c != nil && w > 0 && h > 0 {
 		defer pool.put(c)
 		dst := image.NewNRGBA(image.Rect(0, 0, w, h))
-		// FNX_BLUR_EXACT reproduces the reference bit for bit; FNX_BLUR_FAST is ~3x faster and
-		// differs by at most 1 LSB on <= 0.1 % of samples.
+		// FNX_BLUR_EXACT reproduces the reference bit for bit.  A host-space call is PCIe-bound
+		// (1.2 ms per 4K image, of which the exact kernels are ~60 us and the fast one ~20 us), so
+		// the drop-in takes the exact mode; FNX_BLUR_FAST (<= 1 LSB on <= 0.1 % of samples) is for
+		// device-resident pipelines that ask for it.
 		st := C.fnx_gaussian_blur(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h),
-			(*C.double)(unsafe.Pointer(&kernel[0])), C.int(radius), C.FNX_BLUR_FAST, pix(dst), C.int(dst.Stride))
+			(*C.double)(unsafe.Pointer(&kernel[0])), C.int(radius), C.FNX_BLUR_EXACT, pix(dst), C.int(dst.Stride))
 		runtime.KeepAlive(img)
 		if st == C.FNX_OK {
 			return dst
