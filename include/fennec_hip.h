@@ -307,7 +307,9 @@ int fennec_SSIMFast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, cons
 int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
                   const uint8_t *b, int bstride, int bw, int bh, double *out);   /* ssim.go:313 */
 int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
-                        double sigma, uint8_t *dst, int dstride);                 /* effects.go:146 */
+                        double sigma, uint8_t *dst, int dstride);                 /* effects.go:146;
+                        FNX_HOST: FNX_BLUR_EXACT (bit-exact; the call is PCIe-bound anyway),
+                        FNX_DEVICE: FNX_BLUR_FAST */
 int fennec_Sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                    double strength, uint8_t *dst, int dstride);                   /* effects.go:10 */
 int fennec_AdaptiveSharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,

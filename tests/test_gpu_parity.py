@@ -300,6 +300,17 @@ def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
     _one_pass_case(ctx, orc, [synth.large_photo(500, 300, 2)], 2.0)
 
 
+def test_reference_named_blur_is_exact_for_host_images(orc):
+    """fennec_GaussianBlur (the drop-in mirror): bit-exact for host images, fast kernel for device tensors."""
+    import torch
+    img = synth.noise_image(333, 217, 8, alpha=True)
+    want = orc.gaussian_blur(img, 2.0)
+    assert np.array_equal(fennec_amd.GaussianBlur(img, 2.0), want)
+    dev = fennec_amd.GaussianBlur(torch.from_numpy(img).cuda(), 2.0)
+    fennec_amd.default_context(0).sync()
+    assert_blur_close(dev.cpu().numpy(), want)
+
+
 def test_determinism(ctx):
     a = synth.large_photo(1920, 1080, 1)
     b = ctx.GaussianBlur(a, 2.0)
