@@ -193,7 +193,8 @@ int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
 
 // ---- resize ------------------------------------------------------------------------
 static int upload_taps(fnx_ctx *ctx, Slot slot, int nout, const int32_t *off, const int32_t *idx,
-                       const double *wt, const int32_t **d_off, const int32_t **d_idx, const double **d_wt)
+                       const double *wt, const int32_t **d_off, const int32_t **d_idx, const double **d_wt,
+                       int *contig_taps = nullptr)
 {
     FNX_REQUIRE(off && idx && wt, "tap table is null");
     const int ntaps = off[nout];
@@ -206,6 +207,11 @@ static int upload_taps(fnx_ctx *ctx, Slot slot, int nout, const int32_t *off, co
     *d_wt = static_cast<const double *>(dp[0]);
     *d_off = static_cast<const int32_t *>(dp[1]);
     *d_idx = static_cast<const int32_t *>(dp[2]);
+    if (contig_taps) {      // scanned once per distinct table (the slot's cache says whether it changed)
+        TableCache &tc = ctx->tcache[slot];
+        if (tc.fresh) tc.contig_taps = resize_contiguous_taps(off, idx, nout);
+        *contig_taps = tc.contig_taps;
+    }
     return FNX_OK;
 }
 
@@ -220,12 +226,13 @@ int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_TRY(check_img(dst, dstride, dstW, srcH, "dst"));
     const int32_t *doff, *didx;
     const double *dwt;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offset, index, weight, &doff, &didx, &dwt));
+    int contig = 0;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offset, index, weight, &doff, &didx, &dwt, &contig));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, srcH, SLOT_OUT, &d));
-    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstW));
+    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstW, contig));
     return finish(ctx, space, &d);
 }
 
@@ -271,7 +278,8 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     }
     const int32_t *dOffH, *dIdxH, *dOffV, *dIdxV;
     const double *dWH, *dWV;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offH, idxH, wH, &dOffH, &dIdxH, &dWH));
+    int contig = 0;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offH, idxH, wH, &dOffH, &dIdxH, &dWH, &contig));
     FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offV, idxV, wV, &dOffV, &dIdxV, &dWV));
     DevImg s;
     DevOut d;
@@ -281,7 +289,7 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     const int tp = pitch16(dstW);
     void *tmp = nullptr;
     FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
-    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, dOffH, dIdxH, dWH, static_cast<uint8_t *>(tmp), tp, dstW));
+    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, dOffH, dIdxH, dWH, static_cast<uint8_t *>(tmp), tp, dstW, contig));
     FNX_TRY(launch_resize_v(ctx, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, dOffV, dIdxV, dWV, d.p, d.stride, dstH));
     return finish(ctx, space, &d);
 }

@@ -65,6 +65,8 @@ struct Scratch {
 // Cached copy of the last table uploaded into a table slot.
 struct TableCache {
     std::vector<unsigned char> host;
+    bool fresh = false;      // the last upload_tables() into this slot really uploaded (contents changed)
+    int contig_taps = 0;     // resize tap tables: resize_contiguous_taps() of the cached table
 };
 
 // Cached geometry of the one-pass blur + SSIMFast launch (blur.hip: launch_blur_scored)
@@ -164,9 +166,12 @@ int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, 
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,
                    double amount, uint8_t *dst, int dstride);
+// contig_taps: resize_contiguous_taps() of the (host) H table -- most taps of any output when every
+// output's tap indices are consecutive, else 0
 int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
                     const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
-                    int dstride, int dstW);
+                    int dstride, int dstW, int contig_taps);
+int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout);
 int launch_resize_v(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
                     const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
                     int dstride, int dstH);

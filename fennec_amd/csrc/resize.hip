@@ -65,12 +65,95 @@ __global__ __launch_bounds__(256) void resize_pass_kernel(ResizeArgs a)
     *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = o;
 }
 
+// H pass with the tap table in registers.  Every row of the image uses the SAME taps for output
+// column x (resize.go:82: weights are per column), so a lane owns one column, loads its <= 4*NV taps
+// once and walks down RH_ROWS rows: per output pixel that is NV 16-byte loads of the (contiguous)
+// source window instead of one index + one weight + one pixel load per tap.  Arithmetic per tap and
+// tap order are resize_tap's; columns with fewer taps are padded with zero weights, which add +0.0
+// to the accumulators and cannot change a clampF result.  Requires contiguous tap indices (the host
+// checks; zero-weight taps dropped by precomputeWeights can leave gaps -> generic kernel).
+constexpr int RH_ROWS = 16;
+
+struct ResizeRowsArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int sstride, dstride;
+    int outW, rows, srcW;
+    const int32_t *off;
+    const int32_t *idx;
+    const double *wt;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void resize_h_rows_kernel(ResizeRowsArgs a)
+{
+    constexpr int NT = 4 * NV;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RH_ROWS;
+    if (x >= a.outW || y0 >= a.rows) return;
+    const int t0 = a.off[x], n = a.off[x + 1] - t0;
+    const int s0 = n > 0 ? a.idx[t0] : 0;                       // first source column of the window
+    double w[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) w[k] = k < n ? a.wt[t0 + k] : 0.0;
+    const bool vec = s0 + NT <= a.srcW;                         // whole window inside the row
+    const int y1 = min(a.rows, y0 + RH_ROWS);
+    auto load_row = [&](int y, u32x4 (&v)[NV]) {
+        const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; q++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[q][e] = ld_px(row, min(s0 + 4 * q + e, a.srcW - 1));
+        }
+    };
+    for (int y = y0; y < y1; y++) {
+        u32x4 v[NV];
+        load_row(y, v);
+        double r = 0, g = 0, b = 0, al = 0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) resize_tap(v[k / 4][k % 4], w[k], r, g, b, al);
+        uint32_t o = 0;                                         // zero-initialised dst pixel
+        if (al > 0.5) {                                         // resize.go:107-113
+            const double inv = 1.0 / al;
+            o = clampF_dev(r * inv) | (clampF_dev(g * inv) << 8) | (clampF_dev(b * inv) << 16) |
+                (clampF_dev(al) << 24);
+        }
+        *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = o;
+    }
+}
+
+// max taps of any output (0: indices not contiguous somewhere) -- host tables
+int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout)
+{
+    int maxn = 0;
+    for (int d = 0; d < nout; d++) {
+        const int n = off[d + 1] - off[d];
+        for (int k = 1; k < n; k++)
+            if (idx[off[d] + k] != idx[off[d]] + k) return 0;
+        if (n > maxn) maxn = n;
+    }
+    return maxn;
+}
+
+// contig_taps: resize_contiguous_taps() of the H table (0: unknown / not contiguous)
 int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
                     const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
-                    int dstride, int dstW)
+                    int dstride, int dstW, int contig_taps)
 {
-    (void)srcW;
     if (dstW <= 0 || srcH <= 0) return FNX_OK;
+    if (contig_taps > 0 && contig_taps <= 16 && srcW >= 4) {
+        ResizeRowsArgs ra{src, dst, sstride, dstride, dstW, srcH, srcW, d_off, d_idx, d_wt};
+        dim3 grid((dstW + 63) / 64, (srcH + 4 * RH_ROWS - 1) / (4 * RH_ROWS));
+        if (contig_taps <= 8) hipLaunchKernelGGL((resize_h_rows_kernel<2>), grid, dim3(256), 0, ctx->stream, ra);
+        else if (contig_taps <= 12) hipLaunchKernelGGL((resize_h_rows_kernel<3>), grid, dim3(256), 0, ctx->stream, ra);
+        else hipLaunchKernelGGL((resize_h_rows_kernel<4>), grid, dim3(256), 0, ctx->stream, ra);
+        FNX_HIP(hipGetLastError());
+        return FNX_OK;
+    }
     ResizeArgs a{src, dst, sstride, dstride, dstW, srcH, d_off, d_idx, d_wt};
     dim3 grid((dstW + 63) / 64, (srcH + 3) / 4);
     hipLaunchKernelGGL((resize_pass_kernel<false>), grid, dim3(256), 0, ctx->stream, a);

@@ -86,6 +86,7 @@ int upload_tables(fnx_ctx *ctx, Slot slot, const void *const *hosts, const size_
         dptrs[i] = static_cast<unsigned char *>(d) + off;
         off += (sizes[i] + 15) & ~size_t(15);
     }
+    tc.fresh = !same;
     if (same) return FNX_OK;
     void *pin = nullptr;
     FNX_TRY(pinned_alloc(ctx, total ? total : 16, &pin));
