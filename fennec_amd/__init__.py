@@ -35,7 +35,7 @@ __all__ = [
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfennec_hip.so")
+LIB_PATH = os.environ.get("FENNEC_HIP_LIB") or os.path.join(_HERE, "libfennec_hip.so")   # override: A/B builds
 
 FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
 FNX_HOST, FNX_DEVICE = 0, 1

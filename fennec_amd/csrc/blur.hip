@@ -100,7 +100,10 @@ struct FusedArgs {
 constexpr int SCORE_NBOX = 512;
 
 // channel sums of one pixel into the box table entry at byte offset `off`: the entry is
-// R | G<<16 | B<<32 | A<<48, a box of <= 256 px cannot carry out of a 16-bit field
+// R | G<<16 | B<<32 | A<<48, a box of <= 256 px cannot carry out of a 16-bit field.  (Two
+// v_perm_b32 at 4 clocks each; `px & 0x00ff00ff`, `(px >> 8) & 0x00ff00ff` -- three 2-clock
+// instructions by experiments/valurate.hip -- measured 2 % SLOWER in this kernel: with 4 waves per
+// SIMD it is the instruction count that matters, not the per-class issue cost.)
 __device__ __forceinline__ void box_add(unsigned long long *table, uint32_t off, uint32_t px)
 {
     const uint32_t rg = __builtin_amdgcn_perm(0u, px, 0x0c010c00u);
