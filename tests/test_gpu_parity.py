@@ -112,6 +112,20 @@ def test_resize_passes_with_explicit_tables(ctx, orc):
     assert np.array_equal(ctx.resize_pass(img, 50, False, tab), orc.resize_h(img, 50, tab))
     tab = orc.precompute_weights(200, 90)
     assert np.array_equal(ctx.resize_pass(img, 200, True, tab), orc.resize_v(img, 200, tab))
+    # hand-made tables: taps with gaps (precomputeWeights drops w == 0 taps, resize.go:186-188) take the
+    # generic H kernel; contiguous taps at the right image edge, 1..16 taps, take the in-register one
+    rng = np.random.default_rng(5)
+    for gap in (True, False):
+        off, idx, wt = [0], [], []
+        for d in range(70):
+            n = int(rng.integers(1, 17))
+            s0 = int(rng.integers(0, 120 - (2 * n if gap else n) + 1)) if d % 7 else 120 - (2 * n - 1 if gap else n)
+            idx += [s0 + (2 * k if gap else k) for k in range(n)]
+            w = rng.uniform(-0.3, 1.0, size=n)
+            wt += list(w / w.sum()) if abs(w.sum()) > 0.2 else list(w)
+            off.append(len(idx))
+        tab = (np.array(off, np.int32), np.array(idx, np.int32), np.array(wt, np.float64))
+        assert np.array_equal(ctx.resize_pass(img, 70, False, tab), orc.resize_h(img, 70, tab)), gap
 
 
 def test_smart_resize(ctx, orc):
