@@ -305,6 +305,19 @@ def test_blur_ssimfast_one_pass_shapes(ctx, orc, w, h):
     _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0,))
 
 
+def test_blur_ssimfast_one_pass_strided_views(ctx, orc):
+    """sources that are sub-rectangles of larger device images (stride != 4*w), 4-byte aligned only"""
+    import torch
+    big = torch.from_numpy(synth.noise_image(4000, 2300, 21, alpha=True)).cuda()
+    torch.cuda.synchronize()
+    views = [big[10:10 + 2160, 16:16 + 3840], big[33:33 + 2160, 101:101 + 3840]]
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(views, 2.0)
+    for v, o, s_ in zip(views, outs, ss):
+        host = np.ascontiguousarray(v.cpu().numpy())
+        assert_blur_close(o.cpu().numpy(), orc.gaussian_blur(host, 2.0, procs=16))
+        assert abs(s_ - orc.ssim_fast(host, o.cpu().numpy(), procs=16)) <= SSIM_TOL
+
+
 def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
     imgs = [synth.noise_image(3000, 2000, 5, alpha=True)]
     for sigma in (0.3, 0.6, 1.0, 1.3, 1.6, 2.3, 2.6, 4.0):      # radius 1..8, then 12 (generic kernels)
