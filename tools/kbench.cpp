@@ -1,6 +1,6 @@
 // kbench: kernel-level timing of the batched C-ABI entry points with HIP events on the ctx
 // stream (development tool; bench.py is the contract benchmark).
-//   kbench [what] [batch] [iters]     what = blur | ssim | both | single
+//   kbench [what] [batch] [iters] [W] [H]   what = blur | ssim | both | single | onepass | overlap ...
 // Variants are selected inside the library with FNX_* environment variables.
 #include <hip/hip_runtime.h>
 
@@ -77,6 +77,17 @@ int main(int argc, char **argv)
                avg, avg * 1e3 / B, mp * B / (avg * 1e-3), bytes_per_image * B / (avg * 1e-3) / 1e9, best, best * 1e3 / B);
     };
 
+    if (what == "onepass") {   // config 2 from a C++ host: wall clock over `iters` blocking calls after a clock pre-warm
+        auto fn = [&] { FK(fnx_gaussian_blur_ssim_fast_batch(ctx, B, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST,
+                                                             dsts.data(), W * 4, win, out.data())); };
+        auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.3) fn();
+        t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; i++) fn();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("gaussian_blur_ssim_fast_batch  B=%d %dx%d: %.3f ms per call, %.2f us/img, %.0f MP/s (wall clock, %d calls), ssim[0]=%.9f\n", B, W, H,
+               dt / iters * 1e3, dt / iters / B * 1e6, mp * B * iters / dt, iters, out[0]);
+    }
     if (what == "blur" || what == "both")
         time_it("gaussian_blur_batch", [&] { FK(fnx_gaussian_blur_batch(ctx, B, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4)); }, 2.0 * S);
     if (what == "ssim" || what == "both")
