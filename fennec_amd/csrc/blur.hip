@@ -166,7 +166,13 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     static_assert(Q * RG == TH && SR <= IH && SR % 2 == 0, "tile shape");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_tmp[SR * TW];   // H pass: R,G,B rounded + source alpha
-    extern __shared__ unsigned long long s_box[];                      // SCORE: [src | blurred] box tables, 2 * slabn
+    // SCORE: box tables in dynamic LDS, RA copies for the source side then RB for the blurred side, each
+    // slabn entries.  Lanes that add into the same box in the same instruction -- row pairs of one
+    // column group in the H pass, neighbouring column pairs in the V pass -- are spread over the
+    // copies: same-address LDS atomics serialise (PMC: the LDS data FIFO was full 18 % of the time
+    // and address conflicts cost 8 cycles per atomic with single tables).
+    constexpr int RA = NTH == 256 ? 2 : 1, RB = NTH == 256 ? 4 : 2;
+    extern __shared__ unsigned long long s_box[];
     __shared__ __attribute__((aligned(16))) uint32_t s_coloff[SCORE ? TW : 4];   // byte offset of a tile column's box
     __shared__ uint32_t s_rowoff[SCORE ? TH : 1];                      // ... of a tile row's box row
 
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         // table layout: (nby+1) rows of (nbx+1) entries; the last column / row collect pixels that
         // belong to no box (outside the image, or the source's unboxed tail columns / rows)
         const int slabn = (a.nbx + 1) * (a.nby + 1);
-        for (int e = tid; e < 2 * slabn; e += NTH) s_box[e] = 0;
+        for (int e = tid; e < (RA + RB) * slabn; e += NTH) s_box[e] = 0;
         if (tid < TW) {
             const int b0 = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
             s_coloff[tid] = (v >= 0 && b0 >= 0) ? 8u * (v - b0) : 8u * a.nbx;
@@ -231,17 +237,18 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         if constexpr (SCORE) {   // source side of the box sums: this item's 2 x 8 centre pixels
             const int r0 = 2 * rp - R;
+            unsigned long long *s_box_a = s_box + (rp & (RA - 1)) * ((a.nbx + 1) * (a.nby + 1));
             const u32x4 ca = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g);
             const u32x4 cb = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g + 4);
             if (r0 >= 0 && r0 < TH) {
                 const uint32_t ro = s_rowoff[r0];
 #pragma unroll
-                for (int j = 0; j < HO; j++) box_add(s_box, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t0[(j + R) / 4][(j + R) % 4]);
+                for (int j = 0; j < HO; j++) box_add(s_box_a, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t0[(j + R) / 4][(j + R) % 4]);
             }
             if (r0 + 1 >= 0 && r0 + 1 < TH) {
                 const uint32_t ro = s_rowoff[r0 + 1];
 #pragma unroll
-                for (int j = 0; j < HO; j++) box_add(s_box, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t1[(j + R) / 4][(j + R) % 4]);
+                for (int j = 0; j < HO; j++) box_add(s_box_a, ro + (j < 4 ? ca[j & 3] : cb[j & 3]), t1[(j + R) / 4][(j + R) % 4]);
             }
         }
         v2f acc[HO][3];
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         fp32_round_nearest();
         if constexpr (SCORE) {   // blurred side of the box sums (columns / rows outside the image -> spare entries)
-            unsigned long long *s_box_b = s_box + (a.nbx + 1) * (a.nby + 1);
+            unsigned long long *s_box_b = s_box + (RA + (cp & (RB - 1))) * ((a.nbx + 1) * (a.nby + 1));
             const u32x2 co = *reinterpret_cast<const u32x2 *>(s_coloff + 2 * cp);
 #pragma unroll
             for (int j = 0; j < Q; j++) {
@@ -356,7 +363,13 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         __syncthreads();
         const int slabn = (a.nbx + 1) * (a.nby + 1);
         unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
-        for (int e = tid; e < 2 * slabn; e += NTH) slab[e] = s_box[e];
+        for (int e = tid; e < 2 * slabn; e += NTH) {      // fold the copies: [0, slabn) source, [slabn, 2 slabn) blurred
+            const bool src_side = e < slabn;
+            const int ent = src_side ? e : e - slabn, first = src_side ? 0 : RA, copies = src_side ? RA : RB;
+            unsigned long long v = 0;
+            for (int c = 0; c < copies; c++) v += s_box[(first + c) * slabn + ent];
+            slab[e] = v;
+        }
     }
 }
 
@@ -445,7 +458,8 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
     if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
-    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * 2 * (fa.nbx + 1) * (fa.nby + 1) : 0;
+    constexpr int COPIES = NTH == 256 ? 6 : 3;      // RA + RB of the kernel
+    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * COPIES * (fa.nbx + 1) * (fa.nby + 1) : 0;
     hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), dyn_lds, ctx->stream, fa);
     FNX_HIP(hipGetLastError());
     if (ctx->prof) {
