@@ -93,6 +93,8 @@ struct FusedArgs {
     const int32_t *bx, *by;       // box column / row of each source column / row (-1: in no box)
     unsigned long long *slabs;    // [image][tile][2][slabn] packed 4 x u16 channel sums
     int nbx, nby;                 // most box columns / rows any tile touches
+    int cstride;                  // entries between the LDS copies of a box table: >= (nbx+1)(nby+1) and
+                                  // = 4 mod 16, so that copy c of an entry sits 8c banks away (32 x 4-byte banks)
 };
 
 // most entries of a per-tile box table, (nbx+1) * (nby+1): the two tables live in dynamic LDS sized
@@ -190,8 +192,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     if constexpr (SCORE) {
         // table layout: (nby+1) rows of (nbx+1) entries; the last column / row collect pixels that
         // belong to no box (outside the image, or the source's unboxed tail columns / rows)
-        const int slabn = (a.nbx + 1) * (a.nby + 1);
-        for (int e = tid; e < (RA + RB) * slabn; e += NTH) s_box[e] = 0;
+        for (int e = tid; e < (RA + RB) * a.cstride; e += NTH) s_box[e] = 0;
         if (tid < TW) {
             const int b0 = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
             s_coloff[tid] = (v >= 0 && b0 >= 0) ? 8u * (v - b0) : 8u * a.nbx;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         if constexpr (SCORE) {   // source side of the box sums: this item's 2 x 8 centre pixels
             const int r0 = 2 * rp - R;
-            unsigned long long *s_box_a = s_box + (rp & (RA - 1)) * ((a.nbx + 1) * (a.nby + 1));
+            unsigned long long *s_box_a = s_box + (rp & (RA - 1)) * a.cstride;
             const u32x4 ca = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g);
             const u32x4 cb = *reinterpret_cast<const u32x4 *>(s_coloff + HO * g + 4);
             if (r0 >= 0 && r0 < TH) {
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         fp32_round_nearest();
         if constexpr (SCORE) {   // blurred side of the box sums (columns / rows outside the image -> spare entries)
-            unsigned long long *s_box_b = s_box + (RA + (cp & (RB - 1))) * ((a.nbx + 1) * (a.nby + 1));
+            unsigned long long *s_box_b = s_box + (RA + (cp & (RB - 1))) * a.cstride;
             const u32x2 co = *reinterpret_cast<const u32x2 *>(s_coloff + 2 * cp);
 #pragma unroll
             for (int j = 0; j < Q; j++) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
             const bool src_side = e < slabn;
             const int ent = src_side ? e : e - slabn, first = src_side ? 0 : RA, copies = src_side ? RA : RB;
             unsigned long long v = 0;
-            for (int c = 0; c < copies; c++) v += s_box[(first + c) * slabn + ent];
+            for (int c = 0; c < copies; c++) v += s_box[(first + c) * a.cstride + ent];
             slab[e] = v;
         }
     }
@@ -459,7 +460,8 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
     if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
     constexpr int COPIES = NTH == 256 ? 6 : 3;      // RA + RB of the kernel
-    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * COPIES * (fa.nbx + 1) * (fa.nby + 1) : 0;
+    if (SCORE) fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
+    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * COPIES * fa.cstride : 0;
     hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), dyn_lds, ctx->stream, fa);
     FNX_HIP(hipGetLastError());
     if (ctx->prof) {
