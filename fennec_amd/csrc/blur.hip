@@ -151,7 +151,7 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 // sums of the source pixels (H pass: each item holds its 16 centre pixels) and of the blurred
 // pixels (V pass: the packed outputs) with LDS atomics, and writes them to the tile's slab:
 // SSIMFast(src, blurred) then needs no second pass over either image (launch_blur_scored).
-template <int R, int NTH, int IH, bool SCORE>
+template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1>
 __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
 {
     constexpr int TW = 64;
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     // column group in the H pass, neighbouring column pairs in the V pass -- are spread over the
     // copies: same-address LDS atomics serialise (PMC: the LDS data FIFO was full 18 % of the time
     // and address conflicts cost 8 cycles per atomic with single tables).
-    constexpr int RA = NTH == 256 ? 2 : 1, RB = NTH == 256 ? 4 : 2;
+    // As many copies as fit without costing a resident workgroup (launch_direct_cfg picks RA, RB; they are
+    // template parameters because run-time counts cost 3.5 % in SGPR pressure).
     extern __shared__ unsigned long long s_box[];
     __shared__ __attribute__((aligned(16))) uint32_t s_coloff[SCORE ? TW : 4];   // byte offset of a tile column's box
     __shared__ uint32_t s_rowoff[SCORE ? TH : 1];                      // ... of a tile row's box row
@@ -459,10 +460,20 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
     if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
-    constexpr int COPIES = NTH == 256 ? 6 : 3;      // RA + RB of the kernel
-    if (SCORE) fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
-    const size_t dyn_lds = SCORE ? sizeof(unsigned long long) * COPIES * fa.cstride : 0;
-    hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, SCORE>), grid, dim3(NTH), dyn_lds, ctx->stream, fa);
+    if constexpr (SCORE) {
+        fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
+        // LDS left per workgroup at 4 (256 lanes) / 7 (128 lanes) workgroups per CU, next to the uint8
+        // intermediate: as many table copies as fit in it
+        const size_t budget = NTH == 256 ? 9600 : 6000, per_copy = sizeof(unsigned long long) * fa.cstride;
+        if (6 * per_copy <= budget)
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 2, 4>), grid, dim3(NTH), 6 * per_copy, ctx->stream, fa);
+        else if (3 * per_copy <= budget)
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 2>), grid, dim3(NTH), 3 * per_copy, ctx->stream, fa);
+        else
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1>), grid, dim3(NTH), 2 * per_copy, ctx->stream, fa);
+    } else {
+        hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false>), grid, dim3(NTH), 0, ctx->stream, fa);
+    }
     FNX_HIP(hipGetLastError());
     if (ctx->prof) {
         FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
@@ -529,11 +540,11 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
     const double yr = static_cast<double>(h) / static_cast<double>(dstH);
     // Where the one-pass kernel wins (measured at steady clocks, tools/time_onepass.py, us per image
-    // one-pass / two-call): ratio 3.1 (1600x1200) 13.2 / 9.8, 3.75 (1080p) 9.0 / 9.3, 5 (1440p) 13.4 / 15.3,
-    // 7.5 (4K) 26.8 / 32.1, 10 (5K) 49.2 / 54.9, 15 (8K) 121.4 / 117.8 -- small boxes mean many table
-    // entries per tile to zero and store, large boxes mean 8 lanes adding into one LDS word (and the
-    // two-call box kernel streams long columns well).  Outside [3.6, 12] the two ops run back to back.
-    if (std::fmin(xr, yr) < 3.6 || std::fmax(xr, yr) > 12.0) return false;
+    // one-pass / two-call): ratio 3.1 (1600x1200) 10.1 / 9.6, 3.75 (1080p) 9.1 / 9.3, 4.3 (2200 px)
+    // 11.5 / 12.1, 5 (1440p) 13.8 / 15.2, 7.5 (4K) 26.9 / 31.9, 15 (8K) 98.3 / 120.1.  Small boxes mean
+    // many table entries per tile to zero, store and (no room for copies) contend on; below 3.6 the
+    // two ops run back to back.  Upwards the limit is the 16-bit sum fields (boxes of <= 256 px).
+    if (std::fmin(xr, yr) < 3.6) return false;
     // source column / row -> box index (boxes of a downscale are disjoint and ascending)
     // one table blob: 1/c for c in [0, 256] (doubles) | BoxRef per output column, per output row |
     // box index of every source column, every source row

@@ -195,7 +195,7 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
  * full-size image (HBM traffic 2*S instead of 4*S).  Results are identical to the two separate
  * calls: the box sums are integers, everything after them is the same code.  Shapes the one-pass
  * kernel is not built for or does not win on (FNX_BLUR_EXACT, radius > 8, no downsample, a
- * box-downsample ratio outside [3.6, 12]: below ~1850 px or above 6144 px on the long side) run the
+ * box-downsample ratio below 3.6 or boxes above 256 px: long side under ~1850 px or over 8192 px) run the
  * two ops back to back.  The _enqueue form pairs with fnx_results_fetch. */
 int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride,
                                       int w, int h, const double *kernel, int radius, int flags,

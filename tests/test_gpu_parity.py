@@ -299,7 +299,7 @@ def test_blur_ssimfast_one_pass_4k(ctx, orc):
 
 
 @pytest.mark.parametrize("w,h", [(3001, 2005), (4099, 2817), (2900, 700), (640, 3333), (7680, 4320),
-                                 (2817, 2816), (5000, 64), (6100, 3000), (2560, 1440), (1920, 1080)])
+                                 (2817, 2816), (5000, 64), (6100, 3000), (2560, 1440), (1920, 1080), (8190, 4607), (8200, 120)])
 def test_blur_ssimfast_one_pass_shapes(ctx, orc, w, h):
     imgs = [synth.noise_image(w, h, w ^ h, alpha=True), synth.large_photo(w, h, 1)]
     _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0,))
