@@ -219,7 +219,7 @@ def main() -> int:
             "avg_launch_ms": round(blur_ms, 4),
         }
         rest = {
-            "kernels": "box_from_slabs_kernel + windowed_ssim_sep_kernel + ssim_finish_kernel (+ D2H of results)",
+            "kernels": "box_from_slabs_kernel + windowed_ssim_sep_kernel + ssim_finish_kernel (results land in pinned host memory)",
             "avg_ms": round(rest_ms, 4),
         }
     else:
