@@ -40,25 +40,40 @@ struct PassArgs2 {
     uint32_t *flag_part;     // [n][G]   bit 0: some alpha < 255, bit 1: some r != g || g != b
 };
 
-__device__ __forceinline__ void an_pixel(uint32_t p, uint32_t *hist, double &bright, uint32_t &flags)
+// luminance bin, brightness and flags of one pixel (analyze.go:57-72)
+__device__ __forceinline__ int an_pixel(uint32_t p, double &bright, uint32_t &flags)
 {
     const double lum = lum601(p);                              // analyze.go:62
     bright += lum;
-    atomicAdd(&hist[static_cast<int>(lum + 0.5)], 1u);        // analyze.go:64 (LDS)
     const uint32_t r = p & 0xffu, g = (p >> 8) & 0xffu, b = (p >> 16) & 0xffu;
     flags |= ((p >> 24) < 255u ? 1u : 0u) | ((r != g || g != b) ? 2u : 0u);
+    return static_cast<int>(lum + 0.5);                        // analyze.go:64
 }
+
+// two histogram increments; equal bins (flat image areas) become ONE atomic of 2
+__device__ __forceinline__ void an_count2(uint32_t *hist, int b0, int b1)
+{
+    atomicAdd(&hist[b0], b0 == b1 ? 2u : 1u);
+    if (b0 != b1) atomicAdd(&hist[b1], 1u);
+}
+
+// LDS histograms: AN_COPIES per wave, picked by lane parity.  Same-address LDS atomics serialise, and
+// in flat image areas every lane of a wave hits the same bin: with one histogram per wave and one
+// atomic per pixel a solid-colour 4K image took 27.9 us against 6.9 us for a noisy one.  Merging
+// equal neighbours (an_count2) and 2 copies give 8.6 us solid / 7.3 us noisy; 4 and 8 copies were no
+// better on solid and cost the noisy case occupancy (7.4 / 8.5 us).
+constexpr int AN_COPIES = 2;
 
 __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
 {
-    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_hist[4 * AN_COPIES][256];
     __shared__ double s_red[4];
     __shared__ uint32_t s_flag[4];
     const int tid = threadIdx.x, wave = tid >> 6, z = blockIdx.y;
     const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
-    for (int i = tid; i < 4 * 256; i += 256) (&s_hist[0][0])[i] = 0;
+    for (int i = tid; i < 4 * AN_COPIES * 256; i += 256) (&s_hist[0][0])[i] = 0;
     __syncthreads();
-    uint32_t *hist = s_hist[wave];
+    uint32_t *hist = s_hist[wave * AN_COPIES + (tid & (AN_COPIES - 1))];
     double bright = 0.0;
     uint32_t flags = 0;
     for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < a.units; u += static_cast<long long>(a.G) * 256) {
@@ -73,12 +88,12 @@ __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
         const long long left = a.row_px - x;
         if (a.vec && left >= 4) {
             const u32x4 v = ld16_stream(p);
-            an_pixel(v.x, hist, bright, flags);
-            an_pixel(v.y, hist, bright, flags);
-            an_pixel(v.z, hist, bright, flags);
-            an_pixel(v.w, hist, bright, flags);
+            const int b0 = an_pixel(v.x, bright, flags), b1 = an_pixel(v.y, bright, flags);
+            const int b2 = an_pixel(v.z, bright, flags), b3 = an_pixel(v.w, bright, flags);
+            an_count2(hist, b0, b1);
+            an_count2(hist, b2, b3);
         } else {
-            for (int e = 0; e < 4 && e < left; e++) an_pixel(*(g_u32 *)(p + 4 * e), hist, bright, flags);
+            for (int e = 0; e < 4 && e < left; e++) atomicAdd(&hist[an_pixel(*(g_u32 *)(p + 4 * e), bright, flags)], 1u);
         }
     }
     // brightness: fixed tree (lane order inside the wave, then waves 0..3)
@@ -90,7 +105,10 @@ __global__ __launch_bounds__(256) void analyze_pass_kernel(PassArgs2 a)
     if ((tid & 63) == 0) { s_red[wave] = bright; s_flag[wave] = flags; }
     __syncthreads();
     const size_t part = static_cast<size_t>(z) * a.G + blockIdx.x;
-    a.hist_part[part * 256 + tid] = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+    uint32_t cnt = 0;
+#pragma unroll 8
+    for (int k = 0; k < 4 * AN_COPIES; k++) cnt += s_hist[k][tid];
+    a.hist_part[part * 256 + tid] = cnt;
     if (tid == 0) {
         a.bright_part[part] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
         a.flag_part[part] = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3];
