@@ -86,3 +86,31 @@ def test_summarize_matches_oracle(orc):
     has = (rng.random(n) < 0.95).astype(np.int32)
     o = rng.integers(1000, 10**7, n); c = rng.integers(100, 10**6, n); s = rng.random(n)
     assert fennec_amd.Summarize(failed, has, o, c, s) == orc.summarize(failed, has, o, c, s)
+
+
+def test_stats_epilogue_matches_oracle_on_cpu(orc):
+    """fennec_statsFromAnalysis is host arithmetic (computeEntropy, sqrt, recommend*, analyze.go:87-230):
+    fed with the oracle's own accumulators it must reproduce the oracle's ImageStats -- no GPU involved."""
+    import ctypes as C
+    import numpy as np
+    import fennec_amd
+    from fennec_amd import synth
+    lib = fennec_amd.load_library()
+    for img in (synth.make_test_image(200, 200), synth.make_test_image_with_alpha(100, 100),
+                synth.make_solid_image(100, 100, (128, 128, 128, 255)), synth.large_photo(320, 240, 2)):
+        want = orc.analyze(img)
+        a = fennec_amd.Analysis()
+        for i in range(256):
+            a.histogram[i] = int(want["histogram"][i])
+        for k in ("bright_sum", "variance_sum", "sample_count", "edge_count", "edge_total", "unique_colors",
+                  "has_alpha", "is_grayscale"):
+            setattr(a, k, want[k])
+        st = fennec_amd.ImageStats()
+        h, w = img.shape[:2]
+        lib.fennec_statsFromAnalysis(C.byref(a), w, h, C.byref(st))
+        assert (st.Width, st.Height, st.HasAlpha, st.IsGrayscale, st.UniqueColors) == \
+            (w, h, want["has_alpha"], want["is_grayscale"], want["unique_colors"])
+        assert st.Entropy == want["entropy"] and st.EdgeDensity == want["edge_density"]
+        assert st.MeanBrightness == want["mean_brightness"] and st.Contrast == want["contrast"]
+        assert (st.RecommendedFormat, st.RecommendedQuality, st.EstimatedCompression) == \
+            (want["recommended_format"], want["recommended_quality"], want["estimated_compression"])

@@ -693,3 +693,23 @@ def test_ssim_fast_against_ycbcr_4k(ctx, orc):
         assert prep.against_ycbcr(y, cb, cr, ratio) == prep.against(dec)      # same kernels after the conversion
         assert 0.5 < want < 1.0
     prep.close()
+
+
+def test_ctx_profile_hook(ctx):
+    """fnx_ctx_profile / fnx_ctx_kernel_ms: the library's own HIP events around its dominant kernel."""
+    import torch
+    c = fennec_amd.Context(0)
+    with pytest.raises(fennec_amd.FennecError):
+        c.kernel_ms()                                         # nothing recorded yet
+    d = [torch.from_numpy(synth.large_photo(3840, 2160, k)).cuda() for k in range(2)]
+    torch.cuda.synchronize()
+    c.profile(True)
+    c.GaussianBlurSSIMFastBatch(d, 2.0)
+    ms_score = c.kernel_ms()
+    c.GaussianBlurBatch(d, 2.0); c.sync()
+    ms_plain = c.kernel_ms()
+    c.plan_analyze_batch(d).run()
+    ms_an = c.kernel_ms()
+    assert 0.005 < ms_plain < ms_score < 5.0 and 0.001 < ms_an < 5.0
+    c.profile(False)
+    c.close()
