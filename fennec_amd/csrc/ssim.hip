@@ -313,10 +313,10 @@ struct WinSepArgs {
 template <int TY>
 __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
 {
-    constexpr int LW = WSS_TX + 7, LH = TY + 7;
+    constexpr int LW = WSS_TX + 8, LH = TY + 7;   // 39 columns are used; an even pitch keeps row starts 16-byte aligned
     constexpr int WPT = WSS_TX * TY / 256;       // vertically adjacent windows per lane
-    __shared__ double s_a[LH * LW], s_b[LH * LW];
-    __shared__ double s_h[4][LH * WSS_TX];   // E[a], E[b], E[a^2 + b^2], E[ab] after the H pass
+    __shared__ __attribute__((aligned(16))) double s_a[LH * LW], s_b[LH * LW];
+    __shared__ __attribute__((aligned(16))) double s_h[4][LH * WSS_TX];   // E[a], E[b], E[a^2 + b^2], E[ab] after the H pass
     __shared__ double s_red[4];
     const int z = blockIdx.y;
     const int tile = blockIdx.x;
@@ -335,11 +335,16 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
     // horizontal 8-tap pass; item = (row, 2 adjacent outputs): the 9-value window is read once
     for (int i = tid; i < LH * (WSS_TX / 2); i += 256) {
         const int r = i / (WSS_TX / 2), x = 2 * (i - r * (WSS_TX / 2));
-        double va[9], vb[9];
+        // 16-byte reads of value pairs: lanes step by 2 doubles, so 8-byte reads of x+t hit every other
+        // bank pair (PMC at 8K: LDS busy 68 % of the kernel, two thirds of it bank conflicts); pairs
+        // make the access linear across the wave
+        double va[10], vb[10];
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            va[t] = s_a[r * LW + x + t];
-            vb[t] = s_b[r * LW + x + t];
+        for (int t = 0; t < 10; t += 2) {
+            const double2 pa = *reinterpret_cast<const double2 *>(&s_a[r * LW + x + t]);
+            const double2 pb = *reinterpret_cast<const double2 *>(&s_b[r * LW + x + t]);
+            va[t] = pa.x; va[t + 1] = pa.y;
+            vb[t] = pb.x; vb[t + 1] = pb.y;
         }
         // SSIM needs sigma_aa + sigma_bb and sigma_ab only, so four moments suffice:
         // E[a], E[b], E[a^2 + b^2], E[ab]
@@ -360,10 +365,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_kernel(WinSepArgs a)
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            s_h[q][r * WSS_TX + x] = h[0][q];
-            s_h[q][r * WSS_TX + x + 1] = h[1][q];
-        }
+        for (int q = 0; q < 4; q++) *reinterpret_cast<double2 *>(&s_h[q][r * WSS_TX + x]) = make_double2(h[0][q], h[1][q]);
     }
     __syncthreads();
     // vertical 8-tap pass + the SSIM formula (ssim.go:142-145); a lane owns WPT vertically
