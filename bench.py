@@ -482,7 +482,7 @@ def committed_traffic(kernel_substr: str, batch: int, scored: bool = False):
         try:
             t = json.load(open(p))
             for k, v in t["kernels"].items():
-                if kernel_substr in k and ("true>" in k) == scored and batch == int(t.get("images_per_launch", 32)):
+                if kernel_substr in k and (", true" in k) == scored and batch == int(t.get("images_per_launch", 32)):
                     return float(v["hbm_bytes_per_launch"])
         except Exception:
             continue
