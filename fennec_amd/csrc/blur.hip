@@ -5,10 +5,13 @@
 //    (this TU is built with -ffp-contract=off), so H(tmp uint8) then V is bit-exact.
 //    T=float is the generic fast mode for radii the fused kernel is not built for.
 //  * blur_direct_kernel<R>: the fast path for radii <= 8 (sigma=2 -> R=6): one launch, both
-//    passes in one 64 x ~52 tile, horizontal pass fed straight from global memory into a
-//    uint8 LDS intermediate (the reference rounds the intermediate to uint8,
-//    effects.go:186-188), vertical pass from LDS.  HBM traffic is read-once/write-once
+//    passes in one 64 x 52 (128 lanes) or 64 x 104 (256 lanes) tile, horizontal pass fed straight
+//    from global memory into a uint8 LDS intermediate (the reference rounds the intermediate to
+//    uint8, effects.go:186-188), vertical pass from LDS.  HBM traffic is read-once/write-once
 //    (2*S, halo re-reads hit L2); fp32 FMA accumulation (<=1 LSB off on <=0.1% samples).
+//  * blur_direct_kernel<R, ..., SCORE=true> + box_from_slabs_kernel: the same blur that also
+//    gathers SSIMFast's boxDownsample sums of the source and of the blurred image, so
+//    SSIMFast(src, blurred) needs no second pass over either (launch_blur_scored).
 #include "common.hpp"
 #include "devutil.hpp"
 
@@ -143,9 +146,9 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 //     global memory (16-byte loads at 4-byte alignment; neighbours' overlaps hit L1/L2), so LDS
 //     holds only the uint8 intermediate (16 KB per 64x64 tile) and there is ONE barrier;
 //   * the source alpha rides in byte 3 of the intermediate, so the V pass needs nothing else;
-//   * 128-lane workgroups, 64 x TH output tile (TH = 64-2R rounded down to a multiple of 4): an H item is 2 rows x 8 outputs (2 per lane), a V item is 2 columns x
-//     TH/4 output rows (1 per lane): each intermediate pixel is converted (Q+2R)/Q ~ 1.9 times
-//     instead of 4, all lanes busy in both passes.
+//   * 128- or 256-lane workgroups, 64 x TH output tile (TH = 52 or 104 at R = 6): an H item is
+//     2 rows x 8 outputs (~2 per lane), a V item is 2 columns x Q = TH/(lanes/32) = 13 output rows
+//     (1 per lane): each intermediate pixel is converted (Q+2R)/Q ~ 1.9 times instead of 4.
 //
 // SCORE = true additionally accumulates, per tile, the boxDownsample (ssim.go:244-309) channel
 // sums of the source pixels (H pass: each item holds its 16 centre pixels) and of the blurred
