@@ -1,7 +1,9 @@
-// SSIM family kernels (ssim.go) on gfx950: boxDownsample, windowedSSIM (+toLuminance
-// fused into the tile load), pixelSSIM.  All fp64, unfused, reference operation order
-// (TU built with -ffp-contract=off); only the final mean's summation tree differs from
-// the reference's running sum (which itself depends on GOMAXPROCS, ssim.go:84-94,155-160).
+// SSIM family kernels (ssim.go) on gfx950: boxDownsample (integer sums, bit-exact), windowedSSIM
+// (+toLuminance fused into the tile load), pixelSSIM.  fp64 throughout (TU built with
+// -ffp-contract=off).  windowed_ssim_kernel follows the reference's operation order with unfused
+// arithmetic; windowed_ssim_sep_kernel (rank-1 windows: the reference's own Gaussian) computes
+// separable moments with explicit fma -- both within 1e-9 of the reference's mean, whose own
+// summation order depends on GOMAXPROCS (ssim.go:84-94,155-160).
 #include "common.hpp"
 #include "devutil.hpp"
 
