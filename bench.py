@@ -43,6 +43,23 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 PREWARM_S = 0.3            # untimed: clocks ramp under load before the W warm-up steps
 
 
+def _dist_setup(torch, dist, local_rank, world):
+    """One process per GPU over RCCL.  Test hook: FENNEC_BENCH_BACKEND=gloo with
+    FENNEC_BENCH_SINGLE_DEVICE=1 runs the N > 1 control flow (barriers, MAX / SUM reductions, rank-0
+    JSON) with every rank on GPU 0 -- RCCL cannot share a device -- so that the multi-rank path can be
+    exercised on a 1-GPU box.  Returns (device index, device for reduction tensors)."""
+    backend = os.environ.get("FENNEC_BENCH_BACKEND", "nccl")
+    dev = 0 if os.environ.get("FENNEC_BENCH_SINGLE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    return dev, ("cuda" if backend == "nccl" else "cpu")
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,10 +95,7 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    local_rank, red_dev = _dist_setup(torch, dist, local_rank, world)
 
     import fennec_amd
     from fennec_amd import synth
@@ -177,11 +191,11 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # Summarize (batch.go:140-158) across ranks: the path's only reduction
-        red = torch.tensor([float(len(vals)), float(np.sum(vals))], dtype=torch.float64, device="cuda")
+        red = torch.tensor([float(len(vals)), float(np.sum(vals))], dtype=torch.float64, device=red_dev)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
         n_items, ssim_sum = int(red[0].item()), float(red[1].item())
     else:
@@ -300,10 +314,7 @@ def other_workloads(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    local_rank, red_dev = _dist_setup(torch, dist, local_rank, world)
     import fennec_amd
     from fennec_amd import batch as fbatch
     from fennec_amd import synth
@@ -425,7 +436,7 @@ def other_workloads(args) -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = units_per_step * world * args.steps / elapsed
