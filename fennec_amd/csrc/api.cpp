@@ -80,26 +80,25 @@ int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const
     return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, h_window, d_window, d_out);
 }
 
+// n doubles the result kernels write into: pinned host memory mapped into the device's address
+// space, so that a blocking entry point only has to wait for the stream (result_wait) -- no D2H copy
 int result_slot(fnx_ctx *ctx, int n, double **d)
 {
     void *p = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_RESULT, sizeof(double) * static_cast<size_t>(n > 16 ? n : 16), &p));
+    FNX_TRY(pinned_alloc(ctx, sizeof(double) * static_cast<size_t>(n > 16 ? n : 16), &p));
     *d = static_cast<double *>(p);
+    return FNX_OK;
+}
+
+int result_wait(fnx_ctx *ctx, const double *pinned, double *out, int n)
+{
+    FNX_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, pinned, sizeof(double) * size_t(n));
     return FNX_OK;
 }
 
 // an event right behind the result kernels: fnx_results_fetch then never waits for work that was
 // queued on this stream after the batch
-// The result kernels of the *_enqueue entry points write their n doubles straight into pinned host
-// memory (mapped into the device's address space by hipHostMalloc): no D2H copy to launch.
-int pinned_results(fnx_ctx *ctx, int n, double **out)
-{
-    void *pin = nullptr;
-    FNX_TRY(pinned_alloc(ctx, sizeof(double) * size_t(n > 16 ? n : 16), &pin));
-    *out = static_cast<double *>(pin);
-    return FNX_OK;
-}
-
 int publish_results(fnx_ctx *ctx, const double *pinned, int n)
 {
     if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
@@ -339,7 +338,7 @@ int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const 
     FNX_TRY(result_slot(ctx, 1, &dres));
     FNX_TRY(ssim_fast_device(ctx, 1, da.p, nullptr, da.stride, db.p, nullptr, db.stride, w, h, window,
                              static_cast<const double *>(dwin), dres));
-    return fetch_doubles(ctx, dres, out, 1);
+    return result_wait(ctx, dres, out, 1);
 }
 
 int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
@@ -373,7 +372,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
-    FNX_TRY(pinned_results(ctx, n, &dres));
+    FNX_TRY(result_slot(ctx, n, &dres));
     int nw, nh;
     bool al = !(astride & 15) && !(bstride & 15);
     for (int i = 0; i < n; i++) {
@@ -425,7 +424,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
             void *dwin = nullptr;
             FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
             double *dres;
-            FNX_TRY(pinned_results(ctx, n, &dres));
+            FNX_TRY(result_slot(ctx, n, &dres));
             FNX_TRY(launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
                                          window, static_cast<const double *>(dwin), dres));
             return publish_results(ctx, dres, n);
@@ -477,7 +476,7 @@ int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8
         FNX_TRY(launch_windowed_ssim(ctx, 1, da.p, da.stride, 0, db.p, db.stride, 0, w, h, window,
                                      static_cast<const double *>(dwin), dres));
     }
-    return fetch_doubles(ctx, dres, out, 1);
+    return result_wait(ctx, dres, out, 1);
 }
 
 int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
@@ -541,7 +540,7 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
                 ca = na; cb = nb; cas = cbs = nw * 4; cw = nw; ch = nh;
             }
         }
-        FNX_TRY(fetch_doubles(ctx, dres, lv, nlev));
+        FNX_TRY(result_wait(ctx, dres, lv, nlev));
     }
     double result = 0;
     for (int i = 0; i < nlev; i++) result += weights[i] * std::log(std::fmax(lv[i], 1e-10));   // ssim.go:351
@@ -624,7 +623,7 @@ static int against_device(fnx_ctx *ctx, const fnx_prepared *ref, const uint8_t *
         FNX_TRY(launch_windowed_ssim(ctx, 1, ref->pix, pw * 4, 0, cb, cbs, 0, pw, ph, window,
                                      static_cast<const double *>(dwin), dres));
     }
-    return fetch_doubles(ctx, dres, out, 1);
+    return result_wait(ctx, dres, out, 1);
 }
 
 int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
