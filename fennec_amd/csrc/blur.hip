@@ -38,7 +38,7 @@ struct PassArgs {
 template <typename T> __device__ __forceinline__ T acc_tap(T acc, uint32_t v, T wt);
 template <> __device__ __forceinline__ double acc_tap<double>(double acc, uint32_t v, double wt)
 {
-    return acc + static_cast<double>(v) * wt;   // r += float64(pix) * wt  (effects.go:181)
+    return acc + u8_to_f64(v) * wt;   // r += float64(pix) * wt  (effects.go:181); the convert as 2^52-trick: v_cvt_f64_u32 is slow
 }
 template <> __device__ __forceinline__ float acc_tap<float>(float acc, uint32_t v, float wt)
 {

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
                 out = c & 0xff000000u;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const double orig = static_cast<double>((c >> (8 * ch)) & 0xffu);
-                    const double bl = static_cast<double>(blur[ch]);
+                    const double orig = u8_to_f64((c >> (8 * ch)) & 0xffu);
+                    const double bl = u8_to_f64(blur[ch]);
                     const double val = orig + amt * (orig - bl); // effects.go:37,82
                     out |= clampF_dev(val) << (8 * ch);
                 }
