@@ -1,9 +1,11 @@
 // GaussianBlur (effects.go:146-220) on gfx950.
 //
 //  * blur_pass_kernel<T,VERT>: one separable pass, any radius, thread per pixel.
-//    T=double is the EXACT mode: fp64, unfused mul+add in the reference's tap order
+//    T=double is the EXACT mode for radii > 8: fp64, unfused mul+add in the reference's tap order
 //    (this TU is built with -ffp-contract=off), so H(tmp uint8) then V is bit-exact.
 //    T=float is the generic fast mode for radii the fused kernel is not built for.
+//  * blur_exact_kernel<R>: the EXACT mode for radii <= 8, one launch, the direct kernel's tile
+//    scheme with double accumulators.
 //  * blur_direct_kernel<R>: the fast path for radii <= 8 (sigma=2 -> R=6): one launch, both
 //    passes in one 64 x 52 (128 lanes) or 64 x 104 (256 lanes) tile, horizontal pass fed straight
 //    from global memory into a uint8 LDS intermediate (the reference rounds the intermediate to
@@ -710,13 +712,177 @@ static int launch_generic(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
     return FNX_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// exact mode for radii <= 8: the direct kernel's shape in fp64
+// ------------------------------------------------------------------------------------
+// Same tile scheme as blur_direct_kernel (H pass fed from global memory into the uint8 LDS
+// intermediate with the source alpha in byte 3, one barrier, V pass from LDS), but every
+// accumulator is a double updated with an UNFUSED multiply and add, taps in ascending order, and the
+// rounding is clampF_dev -- the reference's arithmetic (effects.go:169-217), so the output is
+// bit-exact.  An H item is 2 rows x 4 outputs, a V item 1 column x Q rows: the register budget
+// (2 VGPRs per accumulator) halves the fast kernel's item sizes.  256 lanes, 64 x 4Q tile.
+struct ExactArgs {
+    const uint8_t *src;
+    const uint8_t *const *srcs;
+    uint8_t *dst;
+    uint8_t *const *dsts;
+    int sstride, dstride, w, h;
+    int tiles_x, tiles;
+    double wt[2 * FUSED_RMAX + 1];
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_exact_kernel(ExactArgs a)
+{
+    constexpr int TW = 64, NTH = 256, RG = 4;
+    constexpr int Q = (64 - 2 * R) / RG;            // output rows per V item
+    constexpr int TH = Q * RG, SR = TH + 2 * R;     // SR <= 64
+    constexpr int NT = 2 * R + 1;
+    constexpr int HO = 4, NPX = HO + 2 * R, NV = (NPX + 3) / 4;
+    constexpr int HGROUPS = TW / HO;                // 16
+    constexpr int HITEMS = ((SR + 1) / 2) * HGROUPS;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tmp[(SR + 1) * TW];
+
+    const int tile = xcd_tile(blockIdx.x, a.tiles);
+    if (tile < 0) return;
+    const int z = blockIdx.y;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    uint8_t *dst = a.dsts ? a.dsts[z] : a.dst;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int tid = threadIdx.x;
+
+    // ---- horizontal pass (effects.go:169-191) ----
+    for (int item = tid; item < HITEMS; item += NTH) {
+        const int rp = item / HGROUPS, g = item - rp * HGROUPS;
+        const int xs = x0 + HO * g - R;
+        const uint8_t *p0 = src + static_cast<size_t>(clampi(y0 - R + 2 * rp, 0, a.h - 1)) * a.sstride;
+        const uint8_t *p1 = src + static_cast<size_t>(clampi(y0 - R + 2 * rp + 1, 0, a.h - 1)) * a.sstride;
+        u32x4 t0[NV], t1[NV];
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
+            const int x = xs + 4 * q;
+            if (x >= 0 && x + 3 < a.w) {
+                t0[q] = *(g_u32x4 *)(p0 + 4 * static_cast<size_t>(x));
+                t1[q] = *(g_u32x4 *)(p1 + 4 * static_cast<size_t>(x));
+            } else {   // clamp-to-edge (effects.go:174-178)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int xc = clampi(x + e, 0, a.w - 1);
+                    t0[q][e] = ld_px(p0, xc);
+                    t1[q][e] = ld_px(p1, xc);
+                }
+            }
+        }
+        double acc0[HO][3], acc1[HO][3];
+#pragma unroll
+        for (int j = 0; j < HO; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc0[j][c] = acc1[j][c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPX; i++) {
+            const uint32_t q0 = t0[i / 4][i % 4], q1 = t1[i / 4][i % 4];
+            double f0[3], f1[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                f0[c] = u8_to_f64((q0 >> (8 * c)) & 0xffu);
+                f1[c] = u8_to_f64((q1 >> (8 * c)) & 0xffu);
+            }
+#pragma unroll
+            for (int j = 0; j < HO; j++) {
+                const int k = i - j;
+                if (k >= 0 && k < NT) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        acc0[j][c] = acc0[j][c] + f0[c] * a.wt[k];   // r += float64(pix) * wt, unfused (TU: -ffp-contract=off)
+                        acc1[j][c] = acc1[j][c] + f1[c] * a.wt[k];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < HO; j++) {
+            const int c = j + R;
+            const uint32_t s0 = t0[c / 4][c % 4], s1 = t1[c / 4][c % 4];
+            s_tmp[(2 * rp) * TW + HO * g + j] = clampF_dev(acc0[j][0]) | (clampF_dev(acc0[j][1]) << 8) |
+                                                (clampF_dev(acc0[j][2]) << 16) | (s0 & 0xff000000u);
+            s_tmp[(2 * rp + 1) * TW + HO * g + j] = clampF_dev(acc1[j][0]) | (clampF_dev(acc1[j][1]) << 8) |
+                                                    (clampF_dev(acc1[j][2]) << 16) | (s1 & 0xff000000u);
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass (effects.go:195-217): item = 1 column x Q output rows ----
+    {
+        const int col = tid & 63, rg = tid >> 6;
+        const int x = x0 + col;
+        const uint32_t *colp = s_tmp + (rg * Q) * TW + col;
+        double acc[Q][3];
+#pragma unroll
+        for (int j = 0; j < Q; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
+        uint32_t al[Q];
+#pragma unroll
+        for (int i = 0; i < Q + 2 * R; i++) {
+            const uint32_t t = colp[i * TW];
+            if (i >= R && i < R + Q) al[i - R] = t;
+            double f[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) f[c] = u8_to_f64((t >> (8 * c)) & 0xffu);
+#pragma unroll
+            for (int j = 0; j < Q; j++) {
+                const int k = i - j;
+                if (k >= 0 && k < NT) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[j][c] = acc[j][c] + f[c] * a.wt[k];
+                }
+            }
+        }
+        if (x < a.w) {
+#pragma unroll
+            for (int j = 0; j < Q; j++) {
+                const int y = y0 + rg * Q + j;
+                if (y < a.h)
+                    *(g_u32w *)(dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) =
+                        clampF_dev(acc[j][0]) | (clampF_dev(acc[j][1]) << 8) | (clampF_dev(acc[j][2]) << 16) | (al[j] & 0xff000000u);
+            }
+        }
+    }
+}
+
+template <int R>
+static int launch_exact(fnx_ctx *ctx, int n, ExactArgs &ea)
+{
+    constexpr int TH = ((64 - 2 * R) / 4) * 4;
+    ea.tiles_x = (ea.w + 63) / 64;
+    ea.tiles = ea.tiles_x * ((ea.h + TH - 1) / TH);
+    hipLaunchKernelGGL((blur_exact_kernel<R>), dim3(8 * ((ea.tiles + 7) / 8), n), dim3(256), 0, ctx->stream, ea);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
 int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride,
                 int w, int h, const double *kernel, int radius, int flags, uint8_t *dst,
                 uint8_t *const *dsts, int dstride)
 {
     if (w <= 0 || h <= 0 || n <= 0) return FNX_OK;
-    if (flags & FNX_BLUR_EXACT)
-        return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
+    if (flags & FNX_BLUR_EXACT) {
+        if (radius < 1 || radius > FUSED_RMAX)
+            return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
+        ExactArgs ea{};
+        ea.src = src; ea.srcs = srcs; ea.dst = dst; ea.dsts = dsts;
+        ea.sstride = sstride; ea.dstride = dstride; ea.w = w; ea.h = h;
+        for (int i = 0; i < 2 * radius + 1; i++) ea.wt[i] = kernel[i];
+        switch (radius) {
+        case 1: return launch_exact<1>(ctx, n, ea);
+        case 2: return launch_exact<2>(ctx, n, ea);
+        case 3: return launch_exact<3>(ctx, n, ea);
+        case 4: return launch_exact<4>(ctx, n, ea);
+        case 5: return launch_exact<5>(ctx, n, ea);
+        case 6: return launch_exact<6>(ctx, n, ea);
+        case 7: return launch_exact<7>(ctx, n, ea);
+        case 8: return launch_exact<8>(ctx, n, ea);
+        }
+    }
     if (radius < 1 || radius > FUSED_RMAX)
         return launch_generic<float>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
     FusedArgs fa{};
