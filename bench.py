@@ -296,6 +296,22 @@ def main() -> int:
         "summarize": {"items": n_items, "avg_ssim": ssim_sum / max(n_items, 1)},
     }
 
+    # kernel-only rate (HIP-event kernel time of the step) and the PCIe-inclusive
+    # rate of the same two ops called with HOST buffers (what the cgo shim's FNX_HOST calls see) -- the
+    # latter measured after the timed region on one image, never part of `value`
+    step_kernel_ms = blur_ms + (rest_ms if one_pass else ssim_ms)
+    out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
+                          "ms_per_step": round(step_kernel_ms, 4)}
+    if rank == 0:
+        host = srcs[0].cpu().numpy()
+        ctx.GaussianBlur(host, SIGMA, exact=None)
+        t_h = time.perf_counter()
+        for _ in range(3):
+            hb = ctx.GaussianBlur(host, SIGMA, exact=None)       # the drop-in mirror: exact mode for host images
+            ctx.SSIMFast(host, hb)
+        t_h = (time.perf_counter() - t_h) / 3
+        out["pcie_inclusive"] = {"value": round(mp_per_image / t_h, 1), "unit": "MP/s", "ms_per_image": round(t_h * 1e3, 3),
+                                 "note": "one context, pageable host buffers: 3 uploads + 1 download of 33 MB per image"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(srcs[0].cpu().numpy())
     if rank == 0:
@@ -515,12 +531,19 @@ def cpu_baseline(img: np.ndarray) -> dict:
         dt = time.perf_counter() - t0
         if dt > 12.0 or (n >= 16 and dt > 3.0) or n >= 256:
             break
+    t1 = time.perf_counter()                     # also at T = 1
+    b = oracle.gaussian_blur(img, SIGMA, procs=1)
+    oracle.ssim_fast(img, b, procs=1)
+    dt1 = time.perf_counter() - t1
+    import shutil
     return {
         "value": round(n * W4K * H4K / 1e6 / dt, 2),
         "unit": "MP/s",
         "cores": cores,
         "kind": "port",
         "sample": f"{n} x (4K GaussianBlur sigma=2 + SSIMFast) in {dt:.1f} s, oracle/fennec_oracle.c with procs={cores}",
+        "value_1_thread": round(W4K * H4K / 1e6 / dt1, 2),
+        "go_toolchain": "present (not used)" if shutil.which("go") else "absent: the Go reference itself cannot be timed",
     }
 
 
