@@ -713,3 +713,31 @@ def test_ctx_profile_hook(ctx):
     assert 0.005 < ms_plain < ms_score < 5.0 and 0.001 < ms_an < 5.0
     c.profile(False)
     c.close()
+
+
+def test_full_size_properties(ctx):
+    """size-independent properties at BASELINE.json's full sizes, no oracle involved"""
+    import torch
+    a = synth.large_photo(3840, 2160, 5)
+    b = ctx.GaussianBlur(a, 2.0)
+    # symmetry of the SSIM family (the separable kernel fuses a^2+b^2 one way round: last-bit differences)
+    assert abs(ctx.SSIM(a, b) - ctx.SSIM(b, a)) <= 1e-12
+    assert abs(ctx.SSIMFast(a, b) - ctx.SSIMFast(b, a)) <= 1e-12
+    assert abs(ctx.MSSSIM(a, b) - ctx.MSSSIM(b, a)) <= 1e-12
+    # orientation round trips and permutation property at 8K
+    big = synth.large_photo(7680, 4320, 1)
+    for o, inv in ((2, 2), (3, 3), (4, 4), (5, 5), (6, 8), (7, 7), (8, 6)):
+        assert np.array_equal(ctx.ApplyOrientation(ctx.ApplyOrientation(big, o), inv), big)
+    # constant images are fixed points of every filter; resizing to the same size is a copy
+    solid = synth.make_solid_image(3840, 2160, (201, 17, 99, 255))
+    for out in (ctx.GaussianBlur(solid, 2.0), ctx.GaussianBlur(solid, 2.0, exact=True), ctx.blur3x3(solid),
+                ctx.Sharpen(solid, 0.8), ctx.AdaptiveSharpen(solid, 0.8), ctx.lanczosResize(solid, 3840, 2160)):
+        assert np.array_equal(out, solid)
+    assert np.array_equal(ctx.boxDownsample(solid, 512, 288), synth.make_solid_image(512, 288, (201, 17, 99, 255)))
+    assert np.array_equal(ctx.lanczosResize(solid, 1920, 1080), synth.make_solid_image(1920, 1080, (201, 17, 99, 255)))
+    # one-pass == its parts on a device batch (checksum of checksums)
+    d = [torch.from_numpy(synth.large_photo(3840, 2160, k)).cuda() for k in range(4)]
+    torch.cuda.synchronize()
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, 2.0)
+    assert all(torch.equal(o, r) for o, r in zip(outs, ctx.GaussianBlurBatch(d, 2.0)))
+    assert np.array_equal(ss, ctx.SSIMFastBatch(d, outs))
