@@ -741,3 +741,40 @@ def test_full_size_properties(ctx):
     outs, ss = ctx.GaussianBlurSSIMFastBatch(d, 2.0)
     assert all(torch.equal(o, r) for o, r in zip(outs, ctx.GaussianBlurBatch(d, 2.0)))
     assert np.array_equal(ss, ctx.SSIMFastBatch(d, outs))
+
+
+def test_argument_errors_and_context_lifecycle(orc):
+    """bad arguments come back as FennecError with the library's message (never a crash, never a silent
+    fallback); contexts can be created and destroyed in a loop without leaking device memory"""
+    import ctypes as C
+    import torch
+    lib = fennec_amd.load_library()
+    c = fennec_amd.Context(0)
+    img = synth.large_photo(64, 48, 1)
+    k = np.array([0.25, 0.5, 0.25])
+    out = np.empty_like(img)
+    # stride smaller than a row, null source, negative radius, translucent palette, mismatched batch
+    assert lib.fnx_gaussian_blur(c._h, 0, img.ctypes.data, 4 * 64 - 4, 64, 48, k.ctypes.data_as(C.POINTER(C.c_double)), 1, 0,
+                                 out.ctypes.data, 4 * 64) < 0
+    assert b"stride" in lib.fnx_last_error() or b"invalid" in lib.fnx_last_error()
+    assert lib.fnx_gaussian_blur(c._h, 0, None, 4 * 64, 64, 48, k.ctypes.data_as(C.POINTER(C.c_double)), 1, 0,
+                                 out.ctypes.data, 4 * 64) < 0
+    assert lib.fnx_gaussian_blur(c._h, 7, img.ctypes.data, 4 * 64, 64, 48, k.ctypes.data_as(C.POINTER(C.c_double)), 1, 0,
+                                 out.ctypes.data, 4 * 64) < 0          # unknown space
+    with pytest.raises(fennec_amd.FennecError):
+        c.plan_ssim_fast_batch([torch.from_numpy(img).cuda()], [])
+    with pytest.raises(fennec_amd.FennecError):
+        c.GaussianBlurBatch([img], 2.0)                               # host arrays in a device batch
+    # a failed call leaves the ctx usable
+    assert np.array_equal(c.GaussianBlur(img, 2.0, exact=True), orc.gaussian_blur(img, 2.0))
+    c.close()
+    free0 = torch.cuda.mem_get_info()[0]
+    big = synth.large_photo(1920, 1080, 2)
+    for _ in range(12):
+        cc = fennec_amd.Context(0)
+        cc.GaussianBlur(big, 2.0)
+        cc.SSIMFast(big, big)
+        cc.Analyze(big)
+        cc.close()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20            # nothing accumulates across contexts
