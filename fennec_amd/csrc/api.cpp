@@ -53,9 +53,12 @@ bool ssim_fast_dims(int w, int h, int *nw, int *nh)
 
 // SSIMFast of n device image pairs (single pointers or device pointer arrays) -> d_out[n].
 // Image i of the single-pointer form lives at a + i*a_img (used by MSSSIM with n == 1).
+// defer (n == 1 only): windowed paths leave their final mean to launch_ssim_finish_deferred, which writes
+// d_out_base[defer_index]; d_out is then d_out_base + defer_index
 int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const *as, int astride,
                      const uint8_t *b, const uint8_t *const *bs, int bstride, int w, int h,
-                     const double *h_window, const double *d_window, double *d_out)
+                     const double *h_window, const double *d_window, double *d_out,
+                     SsimDeferred *defer = nullptr, int defer_index = 0)
 {
     int nw, nh;
     if (ssim_fast_dims(w, h, &nw, &nh)) {
@@ -70,14 +73,16 @@ int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const
                 FNX_TRY(launch_pixel_ssim(ctx, da + plane * i, db + plane * i, nw, nh, plane, d_out + i));
             return FNX_OK;
         }
-        return launch_windowed_ssim(ctx, n, da, nw * 4, plane, db, nw * 4, plane, nw, nh, h_window, d_window, d_out);
+        return launch_windowed_ssim(ctx, n, da, nw * 4, plane, db, nw * 4, plane, nw, nh, h_window, d_window,
+                                    defer ? d_out - defer_index : d_out, defer, defer_index);
     }
     if (as || bs) {
         set_error("batched SSIMFast needs images larger than 512 px (the downsample path)");
         return FNX_ERR_INVALID;
     }
     if (w < 8 || h < 8) return launch_pixel_ssim(ctx, a, b, w, h, pix_len(w, h, astride), d_out);
-    return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, h_window, d_window, d_out);
+    return launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, h_window, d_window,
+                                defer ? d_out - defer_index : d_out, defer, defer_index);
 }
 
 // n doubles the result kernels write into: pinned host memory mapped into the device's address
@@ -526,9 +531,13 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         size_t lvl_bytes = static_cast<size_t>(w / 2) * (h / 2) * 4 + 16;
         void *pyr = nullptr;   // level k lives at (k&1)*2*lvl_bytes: [a][b]
         FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 4, &pyr));
+        // the five levels' final means are taken by one launch at the end
+        SsimDeferred defer;
+        void *reserve = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &reserve));
         for (int i = 0; i < nweights; i++) {
             FNX_TRY(ssim_fast_device(ctx, 1, ca, nullptr, cas, cb, nullptr, cbs, cw, ch, window,
-                                     static_cast<const double *>(dwin), dres + i));
+                                     static_cast<const double *>(dwin), dres + i, &defer, i));
             nlev = i + 1;
             if (i < nweights - 1) {
                 const int nw = cw / 2, nh = ch / 2;
@@ -540,6 +549,7 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
                 ca = na; cb = nb; cas = cbs = nw * 4; cw = nw; ch = nh;
             }
         }
+        FNX_TRY(launch_ssim_finish_deferred(ctx, defer, dres));
         FNX_TRY(result_wait(ctx, dres, lv, nlev));
     }
     double result = 0;

@@ -186,9 +186,22 @@ int launch_box_downsample_pair(fnx_ctx *ctx, int n, const uint8_t *src, const ui
                                int dstW, int dstH);
 // Windowed SSIM of n image pairs (tight or strided NRGBA, w x h >= 8): image i of a at
 // a + i*a_image_bytes (same for b); writes n doubles to d_out.
+// Windowed-SSIM launches whose final means are taken later by ONE finish launch (MSSSIM: five levels,
+// each finish is ~4.5 us of latency for a few hundred additions).  The caller reserves SLOT_PARTIAL
+// for all of them first (SSIM_DEFER_DOUBLES) so that the partial pointers stay valid.
+constexpr size_t SSIM_DEFER_DOUBLES = 8 * 1024;
+struct SsimDeferred {
+    int count = 0;
+    size_t used = 0;                       // doubles of SLOT_PARTIAL handed out
+    struct Item { size_t offset; int tiles; double windows; int out_index; } item[8];
+};
+// defer != nullptr (n must be 1): no finish launch; the result goes to d_out[defer_out_index] when
+// launch_ssim_finish_deferred runs
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
-                         const double *h_window, const double *d_window, double *d_out);
+                         const double *h_window, const double *d_window, double *d_out,
+                         SsimDeferred *defer = nullptr, int defer_out_index = 0);
+int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out);
 int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
                       size_t pix_len, double *d_out);
 // Analyze's device side (analyze.hip): n images -> d_res[n]; aligned16_ok: every base pointer is 16-byte aligned

@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial,
 
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
-                         const double *h_window, const double *d_window, double *d_out)
+                         const double *h_window, const double *d_window, double *d_out,
+                         SsimDeferred *defer, int defer_out_index)
 {
     const int ww = w - 8, wh = h - 8;     // window grid
     const bool have = ww > 0 && wh > 0;
@@ -472,7 +473,13 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         tiles = tiles_x * ((wh + TY - 1) / TY);
     }
     void *part = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
+    if (defer && (n != 1 || defer->count >= 8 || defer->used + tiles + 2 > SSIM_DEFER_DOUBLES)) defer = nullptr;
+    if (defer) {
+        FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));   // reserved by the caller: no growth
+        part = static_cast<double *>(part) + defer->used;
+    } else {
+        FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
+    }
     if (sep) {
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
@@ -488,8 +495,57 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         FNX_HIP(hipGetLastError());
     }
     const double count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
+    if (defer) {
+        defer->item[defer->count++] = {defer->used, tiles, count, defer_out_index};
+        defer->used += static_cast<size_t>(tiles) + 2;
+        return FNX_OK;
+    }
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(n), dim3(256), 0, ctx->stream,
                        static_cast<const double *>(part), tiles, count, d_out);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+struct FinishMulti {
+    const double *partial[8];
+    int tiles[8], out_index[8];
+    double windows[8];
+    double *out;
+};
+
+// ssim_finish_kernel for several independent reductions: workgroup z finishes item z
+__global__ __launch_bounds__(256) void ssim_finish_multi_kernel(FinishMulti f)
+{
+    __shared__ double s_red[4];
+    const int z = blockIdx.x;
+    const double *p = f.partial[z];
+    const int tiles = f.tiles[z];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < tiles; i += 8 * 256) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += p[i + e * 256];
+    }
+    for (int e = 0; i < tiles; i += 256, e++) acc[e] += p[i];
+    const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const double t = block_sum_256(v, s_red);
+    if (threadIdx.x == 0) f.out[f.out_index[z]] = f.windows[z] > 0 ? t / f.windows[z] : 1.0;
+}
+
+int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out)
+{
+    if (d.count == 0) return FNX_OK;
+    void *part = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));
+    FinishMulti f{};
+    for (int i = 0; i < d.count; i++) {
+        f.partial[i] = static_cast<const double *>(part) + d.item[i].offset;
+        f.tiles[i] = d.item[i].tiles;
+        f.out_index[i] = d.item[i].out_index;
+        f.windows[i] = d.item[i].windows;
+    }
+    f.out = d_out;
+    hipLaunchKernelGGL(ssim_finish_multi_kernel, dim3(d.count), dim3(256), 0, ctx->stream, f);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
 }
