@@ -171,7 +171,9 @@ int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, 
 /* ---- batched forms (FNX_DEVICE only) ------------------------------------ */
 /* n independent images of identical geometry in ONE launch per stage
  * (CompressBatch items never interact, batch.go:88-122).  srcs/dsts/as/bs are
- * HOST arrays of n device pointers. */
+ * HOST arrays of n device pointers.  Image outputs are bit-identical to the per-image calls; SSIM
+ * scalars may differ from them in the last bits (the window statistics are tiled differently when
+ * there are many windows in flight) -- both stay within the 1e-9 bar and are run-to-run reproducible. */
 int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w,
                             int h, const double *kernel, int radius, int flags,
                             uint8_t *const *dsts, int dstride);
