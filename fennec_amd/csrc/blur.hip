@@ -94,6 +94,7 @@ struct FusedArgs {
     int sstride, dstride, w, h;
     int tiles_x, tiles;   // per image
     float wt[2 * FUSED_RMAX + 1];
+    double wd[2 * FUSED_RMAX + 1];   // GUARD variant only: the caller's fp64 weights for the exact fix-ups
     // SCORE variant only (launch_blur_scored): boxDownsample partial sums of src and dst
     const int32_t *bx, *by;       // box column / row of each source column / row (-1: in no box)
     unsigned long long *slabs;    // [image][tile][2][slabn] packed 4 x u16 channel sums
@@ -156,9 +157,23 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 // sums of the source pixels (H pass: each item holds its 16 centre pixels) and of the blurred
 // pixels (V pass: the packed outputs) with LDS atomics, and writes them to the tile's slab:
 // SSIMFast(src, blurred) then needs no second pass over either image (launch_blur_scored).
-template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1>
-__global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
+//
+// GUARD = true makes the fp32 kernel BIT-EXACT.  Its accumulator is within E = 255*2^-24 + (2R+1)*2^-17
+// (<= 1.45e-4 at R = 8) of the exact sum plus the seed, while the reference's fp64 chain is within 4e-13
+// of it.  Seeded with 0.5 - G (G = 2e-4 > E + the slack of one more fp32 add), a sample is packed twice,
+// as floor(acc) and as floor(acc + 2G): when the two agree no integer lies within G of the true
+// sum + 0.5, so floor() of it is that same number and so is the reference's clampF -- proven, not
+// sampled.  The ~0.1 % of pixels where they differ are pushed onto an LDS list and recomputed in fp64
+// in the reference's order after the pass (H: patched in the intermediate; V: stored again); doing it
+// in place would run the fp64 code in almost every wave.  A list overflow recomputes the whole tile.
+constexpr float GUARD_G = 2.0e-4f;
+constexpr int FIX_CAP = 2048;
+
+template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1, bool GUARD = false>
+__global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
 {
+    static_assert(!(GUARD && SCORE), "the guarded kernel does not gather box sums yet");
+    constexpr float SEED = GUARD ? 0.5f - GUARD_G : 0.5f;
     constexpr int TW = 64;
     constexpr int RG = NTH / 32;                    // row groups of the V pass (32 column pairs each)
     constexpr int TH = ((IH - 2 * R) / RG) * RG;    // output rows per tile
@@ -183,6 +198,8 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     extern __shared__ unsigned long long s_box[];
     __shared__ __attribute__((aligned(16))) uint32_t s_coloff[SCORE ? TW : 4];   // byte offset of a tile column's box
     __shared__ uint32_t s_rowoff[SCORE ? TH : 1];                      // ... of a tile row's box row
+    __shared__ uint32_t s_fix[GUARD ? FIX_CAP : 1];                    // GUARD: (row << 8 | column) of pixels to recompute
+    __shared__ int s_nfix[2];
 
     const int tile = xcd_tile(blockIdx.x, a.tiles);
     if (tile < 0) return;
@@ -194,6 +211,10 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
     const int tid = threadIdx.x;
     // a window may over-read up to 3 px past its last tap: interior = no clamp needed anywhere
     const bool interior = x0 - R >= 0 && x0 + TW + R + 3 < a.w && y0 - R >= 0 && y0 + TH + R <= a.h;
+    if constexpr (GUARD) {
+        if (tid < 2) s_nfix[tid] = 0;
+        __syncthreads();
+    }
 
     if constexpr (SCORE) {
         // table layout: (nby+1) rows of (nbx+1) entries; the last column / row collect pixels that
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
         v2f acc[HO][3];
 #pragma unroll
-        for (int j = 0; j < HO; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){0.5f, 0.5f};
+        for (int j = 0; j < HO; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){SEED, SEED};
 #pragma unroll
         for (int q = 0; q < NV; q++) {
 #pragma unroll
@@ -293,6 +314,20 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
             const int c = j + R;
             o0[j] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, t0[c / 4][c % 4])));
             o1[j] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, t1[c / 4][c % 4])));
+            if constexpr (GUARD) {   // second pack at acc + 2G: a differing pixel is within G of a rounding boundary
+                const v2f g2 = {2.0f * GUARD_G, 2.0f * GUARD_G};
+                const v2f h0 = acc[j][0] + g2, h1 = acc[j][1] + g2, h2 = acc[j][2] + g2;
+                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, t0[c / 4][c % 4])));
+                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, t1[c / 4][c % 4])));
+                if (p0 != o0[j]) {
+                    const int e = atomicAdd(&s_nfix[0], 1);
+                    if (e < FIX_CAP) s_fix[e] = ((2 * rp) << 8) | (HO * g + j);
+                }
+                if (p1 != o1[j]) {
+                    const int e = atomicAdd(&s_nfix[0], 1);
+                    if (e < FIX_CAP) s_fix[e] = ((2 * rp + 1) << 8) | (HO * g + j);
+                }
+            }
         }
         fp32_round_nearest();
 #pragma unroll
@@ -302,6 +337,26 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         }
     }
     __syncthreads();
+    if constexpr (GUARD) {   // exact H results for the flagged pixels (effects.go:169-191, fp64, taps ascending)
+        const int nfix = s_nfix[0];
+        const int total = nfix > FIX_CAP ? SR * TW : nfix;
+        for (int e = tid; e < total; e += NTH) {
+            const int row = nfix > FIX_CAP ? e / TW : static_cast<int>(s_fix[e] >> 8);
+            const int col = nfix > FIX_CAP ? e - row * TW : static_cast<int>(s_fix[e] & 0xffu);
+            const uint8_t *prow = src + static_cast<size_t>(clampi(y0 - R + row, 0, a.h - 1)) * a.sstride;
+            double r = 0, g = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const uint32_t p = ld_px(prow, clampi(x0 + col + k - R, 0, a.w - 1));
+                r = r + u8_to_f64(p & 0xffu) * a.wd[k];
+                g = g + u8_to_f64((p >> 8) & 0xffu) * a.wd[k];
+                b = b + u8_to_f64((p >> 16) & 0xffu) * a.wd[k];
+            }
+            s_tmp[row * TW + col] = clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) |
+                                    (s_tmp[row * TW + col] & 0xff000000u);
+        }
+        __syncthreads();
+    }
 
     // ---- vertical pass (effects.go:195-217): item = 2 columns x Q output rows ----
     {
@@ -310,7 +365,7 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         const uint32_t *colp = s_tmp + (rg * Q) * TW + 2 * cp;
         v2f acc[Q][3];                                           // (r0,g0) (b0,r1) (g1,b1)
 #pragma unroll
-        for (int j = 0; j < Q; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){0.5f, 0.5f};
+        for (int j = 0; j < Q; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){SEED, SEED};
         uint32_t al0[Q], al1[Q];
         u32x2 tn = *reinterpret_cast<const u32x2 *>(colp);
 #pragma unroll
@@ -338,6 +393,20 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
         for (int j = 0; j < Q; j++) {
             o[j].x = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al0[j])));
             o[j].y = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al1[j])));
+            if constexpr (GUARD) {
+                const v2f g2 = {2.0f * GUARD_G, 2.0f * GUARD_G};
+                const v2f h0 = acc[j][0] + g2, h1 = acc[j][1] + g2, h2 = acc[j][2] + g2;
+                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, al0[j])));
+                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, al1[j])));
+                if (p0 != o[j].x) {
+                    const int e = atomicAdd(&s_nfix[1], 1);
+                    if (e < FIX_CAP) s_fix[e] = ((rg * Q + j) << 8) | (2 * cp);
+                }
+                if (p1 != o[j].y) {
+                    const int e = atomicAdd(&s_nfix[1], 1);
+                    if (e < FIX_CAP) s_fix[e] = ((rg * Q + j) << 8) | (2 * cp + 1);
+                }
+            }
             asm volatile("" : "+v"(o[j].x), "+v"(o[j].y));   // keep the accumulation out of the store branches
         }
         fp32_round_nearest();
@@ -364,6 +433,28 @@ __global__ __launch_bounds__(NTH, 4) void blur_direct_kernel(FusedArgs a)
                     }
                 }
             }
+        }
+    }
+    if constexpr (GUARD) {   // exact V results for the flagged pixels, stored over the provisional ones: the
+                             // barrier's vmcnt(0) has the first stores acknowledged before these are issued
+        __syncthreads();
+        const int nfix = s_nfix[1];
+        const int total = nfix > FIX_CAP ? TH * TW : nfix;
+        for (int e = tid; e < total; e += NTH) {
+            const int row = nfix > FIX_CAP ? e / TW : static_cast<int>(s_fix[e] >> 8);
+            const int col = nfix > FIX_CAP ? e - row * TW : static_cast<int>(s_fix[e] & 0xffu);
+            const int x = x0 + col, y = y0 + row;
+            if (x >= a.w || y >= a.h) continue;
+            double r = 0, g = 0, b = 0;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const uint32_t p = s_tmp[(row + k) * TW + col];
+                r = r + u8_to_f64(p & 0xffu) * a.wd[k];
+                g = g + u8_to_f64((p >> 8) & 0xffu) * a.wd[k];
+                b = b + u8_to_f64((p >> 16) & 0xffu) * a.wd[k];
+            }
+            *(g_u32w *)(dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) =
+                clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) | (s_tmp[(row + R) * TW + col] & 0xff000000u);
         }
     }
     if constexpr (SCORE) {
@@ -457,7 +548,7 @@ __global__ __launch_bounds__(256) void box_from_slabs_kernel(SlabArgs a)
     }
 }
 
-template <int R, int NTH, int IH, bool SCORE>
+template <int R, int NTH, int IH, bool SCORE, bool GUARD = false>
 static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
     constexpr int TW = 64, RG = NTH / 32, TH = ((IH - 2 * R) / RG) * RG;
@@ -477,7 +568,7 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
         else
             hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1>), grid, dim3(NTH), 2 * per_copy, ctx->stream, fa);
     } else {
-        hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false>), grid, dim3(NTH), 0, ctx->stream, fa);
+        hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false, 1, 1, GUARD>), grid, dim3(NTH), 0, ctx->stream, fa);
     }
     FNX_HIP(hipGetLastError());
     if (ctx->prof) {
@@ -507,26 +598,26 @@ static bool direct_tall(const fnx_ctx *ctx, int R, int n, int w, int h)
     return cost1 < 0.95 * cost0 && tiles1 >= 4L * ctx->num_cus;
 }
 
-template <int R, bool SCORE>
+template <int R, bool SCORE, bool GUARD = false>
 static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa, bool tall)
 {
     constexpr int TH0 = ((64 - 2 * R) / 4) * 4;
-    if (tall) return launch_direct_cfg<R, 256, 2 * TH0 + 2 * R, SCORE>(ctx, n, fa);
-    return launch_direct_cfg<R, 128, 64, SCORE>(ctx, n, fa);
+    if (tall) return launch_direct_cfg<R, 256, 2 * TH0 + 2 * R, SCORE, GUARD>(ctx, n, fa);
+    return launch_direct_cfg<R, 128, 64, SCORE, GUARD>(ctx, n, fa);
 }
 
-template <bool SCORE>
+template <bool SCORE, bool GUARD = false>
 static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, bool tall)
 {
     switch (radius) {
-    case 1: return launch_direct<1, SCORE>(ctx, n, fa, tall);
-    case 2: return launch_direct<2, SCORE>(ctx, n, fa, tall);
-    case 3: return launch_direct<3, SCORE>(ctx, n, fa, tall);
-    case 4: return launch_direct<4, SCORE>(ctx, n, fa, tall);
-    case 5: return launch_direct<5, SCORE>(ctx, n, fa, tall);
-    case 6: return launch_direct<6, SCORE>(ctx, n, fa, tall);
-    case 7: return launch_direct<7, SCORE>(ctx, n, fa, tall);
-    case 8: return launch_direct<8, SCORE>(ctx, n, fa, tall);
+    case 1: return launch_direct<1, SCORE, GUARD>(ctx, n, fa, tall);
+    case 2: return launch_direct<2, SCORE, GUARD>(ctx, n, fa, tall);
+    case 3: return launch_direct<3, SCORE, GUARD>(ctx, n, fa, tall);
+    case 4: return launch_direct<4, SCORE, GUARD>(ctx, n, fa, tall);
+    case 5: return launch_direct<5, SCORE, GUARD>(ctx, n, fa, tall);
+    case 6: return launch_direct<6, SCORE, GUARD>(ctx, n, fa, tall);
+    case 7: return launch_direct<7, SCORE, GUARD>(ctx, n, fa, tall);
+    case 8: return launch_direct<8, SCORE, GUARD>(ctx, n, fa, tall);
     }
     return FNX_ERR_INVALID;
 }
@@ -868,6 +959,25 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
     if (flags & FNX_BLUR_EXACT) {
         if (radius < 1 || radius > FUSED_RMAX)
             return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
+        // The guarded fp32 kernel's error bound assumes what GaussianBlur's own kernel guarantees
+        // (effects.go:155-165): weights >= 0 that sum to 1, so accumulators stay below 256.  Any other
+        // caller-supplied table takes the fp64 kernel.
+        double sum = 0;
+        bool nonneg = true;
+        for (int i = 0; i < 2 * radius + 1; i++) {
+            sum += kernel[i];
+            nonneg = nonneg && kernel[i] >= 0;
+        }
+        if (nonneg && sum <= 1.0 + 1e-9) {
+            FusedArgs ga{};
+            ga.src = src; ga.srcs = srcs; ga.dst = dst; ga.dsts = dsts;
+            ga.sstride = sstride; ga.dstride = dstride; ga.w = w; ga.h = h;
+            for (int i = 0; i < 2 * radius + 1; i++) {
+                ga.wt[i] = static_cast<float>(kernel[i]);
+                ga.wd[i] = kernel[i];
+            }
+            return launch_direct_radius<false, true>(ctx, radius, n, ga, direct_tall(ctx, radius, n, w, h));
+        }
         ExactArgs ea{};
         ea.src = src; ea.srcs = srcs; ea.dst = dst; ea.dsts = dsts;
         ea.sstride = sstride; ea.dstride = dstride; ea.w = w; ea.h = h;

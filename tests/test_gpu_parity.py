@@ -80,6 +80,39 @@ def test_gaussian_blur_arbitrary_kernel_saturates(ctx, orc):
         assert_blur_close(ctx.GaussianBlur(img, 1.0, kernel=k), want)
 
 
+def _binomial(radius):
+    k = np.array([1.0])
+    for _ in range(2 * radius):
+        k = np.convolve(k, [0.5, 0.5])
+    return k            # dyadic weights summing to exactly 1: sums land on exact .5 ties
+
+
+@pytest.mark.parametrize("radius", range(1, 9))
+def test_gaussian_blur_exact_ties(ctx, orc, radius):
+    """EXACT mode on inputs built to sit on clampF's rounding boundary (convert.go:149-158).
+
+    Dyadic kernels make every weighted sum a multiple of 2^-2R, so a large share of samples is an
+    exact x.5 tie -- the case an fp32 accumulator cannot decide -- and the stripe images flag every
+    pixel of a tile at once (the tile-wide recompute branch) in the horizontal or the vertical pass.
+    """
+    k = _binomial(radius)
+    w, h = 300, 150
+    cols = np.zeros((h, w, 4), np.uint8); cols[:, 1::2, :3] = 1; cols[..., 3] = 255
+    rows = np.zeros((h, w, 4), np.uint8); rows[1::2, :, :3] = 1; rows[..., 3] = 255
+    lowbits = synth.noise_image(w, h, 40 + radius, alpha=True) & 3
+    for img in (synth.noise_image(w, h, radius, alpha=True), cols, rows, lowbits):
+        want = orc.gaussian_blur(img, 1.0, kernel=k)
+        got = ctx.GaussianBlur(img, 1.0, exact=True, kernel=k)
+        assert np.array_equal(got, want), radius
+
+
+def test_gaussian_blur_exact_all_sigmas(ctx, orc):
+    """EXACT mode over every radius GaussianBlur's own kernel produces up to the fused limit and past it."""
+    img = synth.noise_image(257, 131, 77, alpha=True)
+    for sigma in (0.3, 0.5, 0.7, 1.0, 1.3, 1.7, 2.0, 2.3, 2.6, 2.9, 3.4):
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), orc.gaussian_blur(img, sigma)), sigma
+
+
 @pytest.mark.parametrize("name", list(IMAGES))
 def test_blur3x3_sharpen_adaptive(ctx, orc, name):
     img = IMAGES[name]()
