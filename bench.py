@@ -72,6 +72,9 @@ def main() -> int:
                     help="one-pass (default): fnx_gaussian_blur_ssim_fast_batch, the blur kernel also gathers "
                          "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
                          "fnx_gaussian_blur_batch then fnx_ssim_fast_batch (bit-identical results)")
+    ap.add_argument("--blur-mode", default="fast", choices=["fast", "exact"],
+                    help="fast (default): fp32 FMA blur, <= 1 LSB on <= 0.1 %% of samples (the tolerance north_star "
+                         "allows); exact: the guarded kernel, blurred images bit-identical to the reference's")
     ap.add_argument("--prewarm", type=float, default=PREWARM_S,
                     help="seconds of untimed steps before the warm-up steps (GPU clock ramp; setup, not measurement)")
     ap.add_argument("--workers", type=int, default=0, help="config5: host worker threads per GPU (0 = min(8, cores))")
@@ -126,9 +129,11 @@ def main() -> int:
     nctx = max(1, min(args.contexts, B))
     ctxs = [ctx] + [fennec_amd.Context(local_rank) for _ in range(nctx - 1)]
     halves = [list(range(k, B, nctx)) for k in range(nctx)]
-    blur_plans = [c.plan_blur_batch([srcs[i] for i in hv], SIGMA, outs=[dsts[i] for i in hv]) for c, hv in zip(ctxs, halves)]
+    exact = args.blur_mode == "exact"
+    blur_plans = [c.plan_blur_batch([srcs[i] for i in hv], SIGMA, outs=[dsts[i] for i in hv], exact=exact)
+                  for c, hv in zip(ctxs, halves)]
     ssim_plans = [c.plan_ssim_fast_batch([srcs[i] for i in hv], [dsts[i] for i in hv]) for c, hv in zip(ctxs, halves)]
-    fused_plans = [c.plan_blur_ssim_fast_batch([srcs[i] for i in hv], SIGMA, outs=[dsts[i] for i in hv])
+    fused_plans = [c.plan_blur_ssim_fast_batch([srcs[i] for i in hv], SIGMA, outs=[dsts[i] for i in hv], exact=exact)
                    for c, hv in zip(ctxs, halves)] if one_pass else None
     kernel_ms = []
     if one_pass:
@@ -282,7 +287,8 @@ def main() -> int:
             "workload": "config2: 4K (3840x2160) NRGBA GaussianBlur sigma=2.0 + SSIMFast(orig, blurred)",
             "images_per_step_per_gpu": B,
             "width": W4K, "height": H4K, "sigma": SIGMA,
-            "blur_mode": "fast (fp32 FMA, <=1 LSB on <=0.1% samples)",
+            "blur_mode": "exact (guarded fp32 kernel + fp64 fix-ups: bit-identical to the reference)" if exact else
+                         "fast (fp32 FMA, <=1 LSB on <=0.1% samples)",
             "inputs": "device-resident (HBM), batched C-ABI entry points",
             "pipeline": args.pipeline + (" (fnx_gaussian_blur_ssim_fast_batch)" if one_pass else
                                          " (fnx_gaussian_blur_batch, fnx_ssim_fast_batch)"),
@@ -302,6 +308,20 @@ def main() -> int:
     step_kernel_ms = blur_ms + (rest_ms if one_pass else ssim_ms)
     out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
                           "ms_per_step": round(step_kernel_ms, 4)}
+    if rank == 0 and one_pass and not exact and nctx == 1:
+        # the same step with bit-exact blurred images (FNX_BLUR_EXACT), after the timed region; never `value`
+        ctx.profile(False)
+        xplan = ctx.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=dsts, exact=True)
+        t_x = time.perf_counter()
+        while time.perf_counter() - t_x < 0.1:
+            xplan.run()
+        t_x = time.perf_counter()
+        for _ in range(10):
+            xplan.run()
+        t_x = (time.perf_counter() - t_x) / 10
+        out["exact_mode"] = {"value": round(mp_per_image * B / t_x, 1), "unit": "MP/s", "ms_per_step": round(t_x * 1e3, 4),
+                             "note": "same step with FNX_BLUR_EXACT: blurred images bit-identical to the reference's "
+                                     "GaussianBlur, scores from exactly those images; 10 steps after the timed region"}
     if rank == 0:
         host = srcs[0].cpu().numpy()
         ctx.GaussianBlur(host, SIGMA, exact=None)

@@ -648,10 +648,13 @@ class Context:
     def SSIMFastBatch(self, imgs_a, imgs_b, window=None) -> np.ndarray:
         return self.plan_ssim_fast_batch(imgs_a, imgs_b, window).run().copy()
 
-    def plan_blur_ssim_fast_batch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None):
+    def plan_blur_ssim_fast_batch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None,
+                                  kernel=None):
         """Pre-marshalled `outs[i] = GaussianBlur(imgs[i], sigma); ssim[i] = SSIMFast(imgs[i], outs[i])`
         in one pass over the pixels (fnx_gaussian_blur_ssim_fast_batch).  run() -> numpy array of n
-        SSIM values (synchronises); enqueue()/fetch() split it."""
+        SSIM values (synchronises); enqueue()/fetch() split it.  exact=True: the blurred images are
+        bit-exact (guarded kernel) and so are the planes the score is computed from.  `kernel` replaces
+        blurKernel(sigma) with a caller-supplied odd-length 1-D kernel."""
         if sigma <= 0:
             raise FennecError("sigma <= 0 returns the source itself (effects.go:147): nothing to plan")
         views = [_Img(t) for t in imgs]
@@ -664,7 +667,13 @@ class Context:
         n = len(views)
         srcs = (C.c_void_p * n)(*[v.ptr for v in views])
         dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
-        radius, kernel = self.blurKernel(sigma)
+        if kernel is None:
+            radius, kernel = self.blurKernel(sigma)
+        else:
+            kernel = np.asarray(kernel, dtype=np.float64)
+            if kernel.ndim != 1 or len(kernel) % 2 == 0:
+                raise FennecError("kernel must be a 1-D array of odd length")
+            radius = len(kernel) // 2
         k, pk = _f64(kernel)
         kw, pw = _f64(self.gaussianKernel() if window is None else window)
         flags = FNX_BLUR_EXACT if exact else FNX_BLUR_FAST
@@ -692,9 +701,10 @@ class Context:
                 return out
         return _Plan()
 
-    def GaussianBlurSSIMFastBatch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None):
+    def GaussianBlurSSIMFastBatch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None,
+                                  kernel=None):
         """-> (blurred images, numpy array of SSIMFast(imgs[i], blurred[i]))."""
-        plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window)
+        plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window, kernel=kernel)
         return plan.outs, plan.run().copy()
 
 

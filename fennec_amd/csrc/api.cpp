@@ -412,7 +412,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
     for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i] && srcs[i] != dsts[i], "null image in batch, or dst aliases src (the blur is not in-place)");
     int nw, nh;
     const bool down = ssim_fast_dims(w, h, &nw, &nh);
-    if (down && nw >= 8 && nh >= 8 && !(flags & FNX_BLUR_EXACT)) {
+    if (down && nw >= 8 && nh >= 8) {
         // one pass: the blur kernel also accumulates both boxDownsample planes
         const void *hosts[2] = {srcs, dsts};
         const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
@@ -423,7 +423,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
         FNX_TRY(scratch(ctx, SLOT_TMP2, plane * 2 * n + 16, &t));
         uint8_t *planes = static_cast<uint8_t *>(t);
         const int st = launch_blur_scored(ctx, n, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel,
-                                          radius, static_cast<uint8_t *const *>(dp[1]), dstride, planes, plane, nw, nh);
+                                          radius, flags, static_cast<uint8_t *const *>(dp[1]), dstride, planes, plane, nw, nh);
         if (st < 0) return st;
         if (st == FNX_OK) {
             void *dwin = nullptr;

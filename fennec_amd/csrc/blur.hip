@@ -166,13 +166,15 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 // sampled.  The ~0.1 % of pixels where they differ are pushed onto an LDS list and recomputed in fp64
 // in the reference's order after the pass (H: patched in the intermediate; V: stored again); doing it
 // in place would run the fp64 code in almost every wave.  A list overflow recomputes the whole tile.
+// With SCORE the flagged blurred pixels add into a spare table entry in the V pass and into their box
+// after the recompute, so the box sums are those of the exact image (an overflow clears and rebuilds them).
 constexpr float GUARD_G = 2.0e-4f;
-constexpr int FIX_CAP = 2048;
+constexpr int guard_fix_cap(bool score) { return score ? 512 : 2048; }   // SCORE: LDS is shared with the tables
 
 template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1, bool GUARD = false>
 __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
 {
-    static_assert(!(GUARD && SCORE), "the guarded kernel does not gather box sums yet");
+    constexpr int FIX_CAP = guard_fix_cap(SCORE);
     constexpr float SEED = GUARD ? 0.5f - GUARD_G : 0.5f;
     constexpr int TW = 64;
     constexpr int RG = NTH / 32;                    // row groups of the V pass (32 column pairs each)
@@ -388,6 +390,8 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
             __builtin_amdgcn_sched_barrier(0);
         }
         u32x2 o[Q];
+        uint32_t flagged = 0;                                    // GUARD && SCORE: bit 2j / 2j+1 = o[j].x / .y awaits its recompute
+        static_assert(2 * Q <= 32, "flag bits");
         fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < Q; j++) {
@@ -401,10 +405,12 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
                 if (p0 != o[j].x) {
                     const int e = atomicAdd(&s_nfix[1], 1);
                     if (e < FIX_CAP) s_fix[e] = ((rg * Q + j) << 8) | (2 * cp);
+                    if constexpr (SCORE) flagged |= 1u << (2 * j);
                 }
                 if (p1 != o[j].y) {
                     const int e = atomicAdd(&s_nfix[1], 1);
                     if (e < FIX_CAP) s_fix[e] = ((rg * Q + j) << 8) | (2 * cp + 1);
+                    if constexpr (SCORE) flagged |= 2u << (2 * j);
                 }
             }
             asm volatile("" : "+v"(o[j].x), "+v"(o[j].y));   // keep the accumulation out of the store branches
@@ -416,8 +422,14 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
 #pragma unroll
             for (int j = 0; j < Q; j++) {
                 const uint32_t ro = s_rowoff[rg * Q + j];
-                box_add(s_box_b, ro + co.x, o[j].x);
-                box_add(s_box_b, ro + co.y, o[j].y);
+                if constexpr (GUARD) {   // provisional values of flagged pixels go to the spare corner entry
+                    const uint32_t spare = 8u * ((a.nbx + 1) * a.nby + a.nbx);
+                    box_add(s_box_b, (flagged >> (2 * j)) & 1u ? spare : ro + co.x, o[j].x);
+                    box_add(s_box_b, (flagged >> (2 * j)) & 2u ? spare : ro + co.y, o[j].y);
+                } else {
+                    box_add(s_box_b, ro + co.x, o[j].x);
+                    box_add(s_box_b, ro + co.y, o[j].y);
+                }
             }
         }
         if (x < a.w) {
@@ -440,6 +452,12 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         __syncthreads();
         const int nfix = s_nfix[1];
         const int total = nfix > FIX_CAP ? TH * TW : nfix;
+        if constexpr (SCORE) {   // list overflow: every pixel is recomputed, so the blurred-side tables start over
+            if (nfix > FIX_CAP) {
+                for (int e = tid; e < RB * a.cstride; e += NTH) s_box[RA * a.cstride + e] = 0;
+                __syncthreads();
+            }
+        }
         for (int e = tid; e < total; e += NTH) {
             const int row = nfix > FIX_CAP ? e / TW : static_cast<int>(s_fix[e] >> 8);
             const int col = nfix > FIX_CAP ? e - row * TW : static_cast<int>(s_fix[e] & 0xffu);
@@ -453,8 +471,10 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
                 g = g + u8_to_f64((p >> 8) & 0xffu) * a.wd[k];
                 b = b + u8_to_f64((p >> 16) & 0xffu) * a.wd[k];
             }
-            *(g_u32w *)(dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) =
-                clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) | (s_tmp[(row + R) * TW + col] & 0xff000000u);
+            const uint32_t px = clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) |
+                                (s_tmp[(row + R) * TW + col] & 0xff000000u);
+            *(g_u32w *)(dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = px;
+            if constexpr (SCORE) box_add(s_box + (RA + (e & (RB - 1))) * a.cstride, s_rowoff[row] + s_coloff[col], px);
         }
     }
     if constexpr (SCORE) {
@@ -560,13 +580,14 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
         fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
         // LDS left per workgroup at 4 (256 lanes) / 7 (128 lanes) workgroups per CU, next to the uint8
         // intermediate: as many table copies as fit in it
-        const size_t budget = NTH == 256 ? 9600 : 6000, per_copy = sizeof(unsigned long long) * fa.cstride;
+        const size_t budget = (NTH == 256 ? 9600 : 6000) - (GUARD ? sizeof(uint32_t) * guard_fix_cap(true) : 0);
+        const size_t per_copy = sizeof(unsigned long long) * fa.cstride;
         if (6 * per_copy <= budget)
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 2, 4>), grid, dim3(NTH), 6 * per_copy, ctx->stream, fa);
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 2, 4, GUARD>), grid, dim3(NTH), 6 * per_copy, ctx->stream, fa);
         else if (3 * per_copy <= budget)
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 2>), grid, dim3(NTH), 3 * per_copy, ctx->stream, fa);
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 2, GUARD>), grid, dim3(NTH), 3 * per_copy, ctx->stream, fa);
         else
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1>), grid, dim3(NTH), 2 * per_copy, ctx->stream, fa);
+            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1, GUARD>), grid, dim3(NTH), 2 * per_copy, ctx->stream, fa);
     } else {
         hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false, 1, 1, GUARD>), grid, dim3(NTH), 0, ctx->stream, fa);
     }
@@ -596,6 +617,18 @@ static bool direct_tall(const fnx_ctx *ctx, int R, int n, int w, int h)
     const double cost1 = ty1 * (0.55 * (TH1 + 2 * R) + 0.45 * TH1);
     const long tiles1 = ty1 * ((w + 63) / 64) * n;
     return cost1 < 0.95 * cost0 && tiles1 >= 4L * ctx->num_cus;
+}
+
+// The guarded kernel's error bound assumes what GaussianBlur's own kernel guarantees (effects.go:155-165):
+// weights >= 0 that sum to 1, so accumulators stay below 256.
+static bool guard_kernel_ok(const double *kernel, int radius)
+{
+    double sum = 0;
+    for (int i = 0; i < 2 * radius + 1; i++) {
+        if (!(kernel[i] >= 0)) return false;
+        sum += kernel[i];
+    }
+    return sum <= 1.0 + 1e-9;
 }
 
 template <int R, bool SCORE, bool GUARD = false>
@@ -720,10 +753,12 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
 }
 
 int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
-                       const double *kernel, int radius, uint8_t *const *dsts, int dstride,
+                       const double *kernel, int radius, int flags, uint8_t *const *dsts, int dstride,
                        uint8_t *planes, size_t plane, int dstW, int dstH)
 {
     if (n > 65535) return FNX_NOOP;   // grid.z
+    const bool exact = flags & FNX_BLUR_EXACT;
+    if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);
     ScoreGeom &g = ctx->score_geom;
     if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref)) {
@@ -743,13 +778,18 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     FusedArgs fa{};
     fa.srcs = srcs; fa.dsts = dsts;
     fa.sstride = sstride; fa.dstride = dstride; fa.w = w; fa.h = h;
-    for (int i = 0; i < 2 * radius + 1; i++) fa.wt[i] = static_cast<float>(kernel[i]);
+    for (int i = 0; i < 2 * radius + 1; i++) {
+        fa.wt[i] = static_cast<float>(kernel[i]);
+        fa.wd[i] = kernel[i];
+    }
     fa.bx = static_cast<const int32_t *>(dmap) + 2 * NINV + ref_words; fa.by = fa.bx + w;
     fa.nbx = nbx; fa.nby = nby;
     void *slabs = nullptr;
     FNX_TRY(scratch(ctx, SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
     fa.slabs = static_cast<unsigned long long *>(slabs);
-    FNX_TRY(launch_direct_radius<true>(ctx, radius, n, fa, tall));
+    const int st = exact ? launch_direct_radius<true, true>(ctx, radius, n, fa, tall)
+                         : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
+    if (st < 0) return st;
 
     SlabArgs sa{};
     sa.slabs = fa.slabs; sa.dst = planes; sa.plane = plane;
@@ -959,16 +999,8 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
     if (flags & FNX_BLUR_EXACT) {
         if (radius < 1 || radius > FUSED_RMAX)
             return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
-        // The guarded fp32 kernel's error bound assumes what GaussianBlur's own kernel guarantees
-        // (effects.go:155-165): weights >= 0 that sum to 1, so accumulators stay below 256.  Any other
-        // caller-supplied table takes the fp64 kernel.
-        double sum = 0;
-        bool nonneg = true;
-        for (int i = 0; i < 2 * radius + 1; i++) {
-            sum += kernel[i];
-            nonneg = nonneg && kernel[i] >= 0;
-        }
-        if (nonneg && sum <= 1.0 + 1e-9) {
+        // any caller-supplied table the guarded kernel's bound does not cover takes the fp64 kernel
+        if (guard_kernel_ok(kernel, radius)) {
             FusedArgs ga{};
             ga.src = src; ga.srcs = srcs; ga.dst = dst; ga.dsts = dsts;
             ga.sstride = sstride; ga.dstride = dstride; ga.w = w; ga.h = h;

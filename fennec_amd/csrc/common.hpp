@@ -157,10 +157,11 @@ inline bool aligned16(const void *p, int stride)
 int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride,
                 int w, int h, const double *kernel, int radius, int flags, uint8_t *dst,
                 uint8_t *const *dsts, int dstride);
-// fast-mode blur + both boxDownsample'd planes ([src 0..n-1][blurred 0..n-1], tight dstW x dstH)
-// in one pass; FNX_NOOP (nothing launched) when the shape is not covered.  srcs/dsts: device arrays.
+// blur (fast, or with FNX_BLUR_EXACT the guarded bit-exact kernel) + both boxDownsample'd planes
+// ([src 0..n-1][blurred 0..n-1], tight dstW x dstH) in one pass; FNX_NOOP (nothing launched) when the
+// shape or the kernel is not covered.  srcs/dsts: device arrays.
 int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
-                       const double *kernel, int radius, uint8_t *const *dsts, int dstride,
+                       const double *kernel, int radius, int flags, uint8_t *const *dsts, int dstride,
                        uint8_t *planes, size_t plane, int dstW, int dstH);
 int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *dst,
                    int dstride);

@@ -328,7 +328,7 @@ def test_blur_ssimfast_one_pass_4k(ctx, orc):
     imgs = [synth.large_photo(3840, 2160, 3), synth.noise_image(3840, 2160, 9, alpha=True),
             synth.make_test_image_with_alpha(3840, 2160)]
     _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0, 1, 2))
-    _one_pass_case(ctx, orc, imgs[:2], 2.0, exact=True, check_oracle=())     # exact mode: two-op route
+    _one_pass_case(ctx, orc, imgs, 2.0, exact=True, check_oracle=(0, 1, 2))
 
 
 @pytest.mark.parametrize("w,h", [(3001, 2005), (4099, 2817), (2900, 700), (640, 3333), (7680, 4320),
@@ -336,6 +336,52 @@ def test_blur_ssimfast_one_pass_4k(ctx, orc):
 def test_blur_ssimfast_one_pass_shapes(ctx, orc, w, h):
     imgs = [synth.noise_image(w, h, w ^ h, alpha=True), synth.large_photo(w, h, 1)]
     _one_pass_case(ctx, orc, imgs, 2.0, check_oracle=(0,))
+
+
+def test_blur_ssimfast_one_pass_exact_is_the_reference(ctx, orc):
+    """exact=True: the blurred images ARE the oracle's GaussianBlur, bit for bit, in the one-pass kernel too,
+    and the score is the oracle's SSIMFast of that pair."""
+    import torch
+    imgs = [synth.noise_image(3840, 2160, 31, alpha=True), synth.large_photo(3840, 2160, 8)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, 2.0, exact=True)
+    for k, img in enumerate(imgs):
+        want = orc.gaussian_blur(img, 2.0, procs=16)
+        assert np.array_equal(outs[k].cpu().numpy(), want)
+        assert abs(ss[k] - orc.ssim_fast(img, want, procs=16)) <= SSIM_TOL
+    for w, h in ((3001, 2005), (2560, 1440), (8190, 4607), (1920, 1080)):
+        _one_pass_case(ctx, orc, [synth.noise_image(w, h, w + h, alpha=True), synth.large_photo(w, h, 2)], 2.0,
+                       exact=True, check_oracle=())
+    one = [synth.noise_image(3000, 2000, 5, alpha=True)]
+    for sigma in (0.3, 0.6, 1.0, 1.3, 1.6, 2.3, 2.6, 4.0):      # radius 1..8, then 12 (two-op route)
+        _one_pass_case(ctx, orc, one, sigma, exact=True, check_oracle=())
+
+
+@pytest.mark.parametrize("radius", (1, 3, 6, 8))
+def test_blur_ssimfast_one_pass_exact_ties(ctx, orc, radius):
+    """The guarded one-pass kernel where every pixel of a tile sits on a rounding boundary (dyadic kernel,
+    stripe images): the tile-wide recompute must also rebuild the blurred-side box sums."""
+    import torch
+    k = _binomial(radius)
+    w, h = 2048, 1200
+    cols = np.zeros((h, w, 4), np.uint8); cols[:, 1::2, :3] = 1; cols[..., 3] = 255
+    rows = np.zeros((h, w, 4), np.uint8); rows[1::2, :, :3] = 3; rows[..., 3] = 255
+    mixed = synth.noise_image(w, h, radius, alpha=True); mixed[300:900, 500:1500, :3] &= 1
+    imgs = [cols, rows, mixed]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, 1.0, exact=True, kernel=k)
+    for i, img in enumerate(imgs):
+        want = orc.gaussian_blur(img, 1.0, kernel=k, procs=8)
+        assert np.array_equal(outs[i].cpu().numpy(), want), (radius, i)
+        assert abs(ss[i] - orc.ssim_fast(img, want, procs=8)) <= SSIM_TOL, (radius, i)
+    # a kernel outside the guarded kernel's bound (gain > 1) takes the two-op route and still matches
+    k2 = np.array([0.7, 0.7, 0.7])
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d[2:], 1.0, exact=True, kernel=k2)
+    want = orc.gaussian_blur(mixed, 1.0, kernel=k2, procs=8)
+    assert np.array_equal(outs[0].cpu().numpy(), want)
+    assert abs(ss[0] - orc.ssim_fast(mixed, want, procs=8)) <= SSIM_TOL
 
 
 def test_blur_ssimfast_one_pass_strided_views(ctx, orc):

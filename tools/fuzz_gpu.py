@@ -100,6 +100,15 @@ while time.time() < t_end:
         ok = ok and abs(ss[0] - orc.ssim_fast(imgs[0], outs[0].cpu().numpy(), procs=16)) <= SSIM_TOL
         ok = ok and blur_close(outs[1].cpu().numpy(), orc.gaussian_blur(imgs[1], sigma, procs=16))
         case("one_pass", ok, f"seed={seed} it={it} {w2}x{h2} sigma={sigma}")
+        outs, ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=True)      # guarded kernel: bit-exact images
+        want = orc.gaussian_blur(imgs[0], sigma, procs=16)
+        ref = ctx.GaussianBlurBatch(d, sigma, exact=True)
+        rs = ctx.SSIMFastBatch(d, ref)
+        checks = (np.array_equal(outs[0].cpu().numpy(), want),
+                  abs(ss[0] - orc.ssim_fast(imgs[0], want, procs=16)) <= SSIM_TOL,
+                  torch.equal(outs[1], ref[1]), ss[1] == rs[1])
+        ok = all(checks)
+        case("one_pass_exact", ok, f"seed={seed} it={it} {w2}x{h2} sigma={sigma} checks={checks} ss={ss} rs={rs}")
 print("runs:", runs)
 print("FAILURES:", len(fails))
 for f in fails[:20]:

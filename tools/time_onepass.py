@@ -19,6 +19,7 @@ srcs = [torch.from_numpy(synth.large_photo(W, H, k)).cuda() for k in range(B)]
 dsts = [torch.empty_like(s) for s in srcs]
 torch.cuda.synchronize()
 one = ctx.plan_blur_ssim_fast_batch(srcs, sigma, outs=dsts)
+onex = ctx.plan_blur_ssim_fast_batch(srcs, sigma, outs=dsts, exact=True)
 pb = ctx.plan_blur_batch(srcs, sigma, outs=dsts)
 ps = ctx.plan_ssim_fast_batch(srcs, dsts)
 
@@ -28,7 +29,8 @@ def two():
     return ps.run()
 
 
-for name, fn in (("one-pass", one.run), ("two-call", two), ("one-pass", one.run), ("two-call", two)):
+for name, fn in (("one-pass", one.run), ("two-call", two), ("one-pass", one.run), ("two-call", two),
+                 ("1p-exact", onex.run), ("1p-exact", onex.run)):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.3:      # clock ramp (see bench.py PREWARM_S)
         v = fn().copy()
