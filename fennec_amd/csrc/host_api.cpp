@@ -248,7 +248,7 @@ int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride
     std::vector<double> k(static_cast<size_t>(2 * radius + 1));
     fennec_blurKernel(sigma, k.data());
     // The drop-in is bit-exact where that is free: a host-space call is PCIe-bound (1.2 ms per 4K image,
-    // the exact kernel 0.08 ms of it).  Device-resident callers get the fast kernel (<= 1 LSB on
+    // the exact kernel 0.03 ms of it).  Device-resident callers get the fast kernel (<= 1 LSB on
     // <= 0.1 % of samples) and can ask fnx_gaussian_blur for FNX_BLUR_EXACT themselves.
     const int mode = space == FNX_HOST ? FNX_BLUR_EXACT : FNX_BLUR_FAST;
     return fnx_gaussian_blur(ctx, space, src, sstride, w, h, k.data(), radius, mode, dst, dstride);

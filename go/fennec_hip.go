@@ -252,7 +252,7 @@ func GaussianBlur(img *image.NRGBA, sigma float64) *image.NRGBA {
 		defer pool.put(c)
 		dst := image.NewNRGBA(image.Rect(0, 0, w, h))
 		// FNX_BLUR_EXACT reproduces the reference bit for bit.  A host-space call is PCIe-bound
-		// (1.2 ms per 4K image, of which the exact kernel is ~0.08 ms and the fast one ~0.02 ms), so
+		// (1.2 ms per 4K image, of which the exact kernel is ~0.03 ms and the fast one ~0.03 ms), so
 		// the drop-in takes the exact mode; FNX_BLUR_FAST (<= 1 LSB on <= 0.1 % of samples) is for
 		// device-resident pipelines that ask for it.
 		st := C.fnx_gaussian_blur(c, C.FNX_HOST, pix(img), C.int(img.Stride), C.int(w), C.int(h),

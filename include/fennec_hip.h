@@ -65,7 +65,8 @@ extern "C" {
 
 /* fnx_gaussian_blur flags */
 #define FNX_BLUR_FAST 0  /* fp32 FMA accumulation: <=1 LSB off the reference on <=0.1% of samples */
-#define FNX_BLUR_EXACT 1 /* fp64, unfused, reference tap order: bit-exact */
+#define FNX_BLUR_EXACT 1 /* bit-exact: fp32 with a rounding guard, fp64 in the reference's tap order for every
+                            sample the guard cannot decide (and for kernels with negative taps or gain > 1) */
 
 typedef struct fnx_ctx fnx_ctx;
 typedef struct fnx_prepared fnx_prepared;
@@ -196,9 +197,10 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
  * channel sums of boxDownsample (ssim.go:244-309) for both, and SSIMFast never re-reads either
  * full-size image (HBM traffic 2*S instead of 4*S).  Results are identical to the two separate
  * calls: the box sums are integers, everything after them is the same code.  Shapes the one-pass
- * kernel is not built for or does not win on (FNX_BLUR_EXACT, radius > 8, no downsample, a
- * box-downsample ratio below 3.6 or boxes above 256 px: long side under ~1850 px or over 8192 px) run the
- * two ops back to back.  The _enqueue form pairs with fnx_results_fetch. */
+ * kernel is not built for or does not win on (radius > 8, no downsample, a box-downsample ratio below
+ * 3.6 or boxes above 256 px: long side under ~1850 px or over 8192 px; with FNX_BLUR_EXACT also a kernel
+ * with negative taps or gain > 1) run the two ops back to back.  With FNX_BLUR_EXACT the blurred images
+ * are bit-exact and the scores are computed from exactly those images.  The _enqueue form pairs with fnx_results_fetch. */
 int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride,
                                       int w, int h, const double *kernel, int radius, int flags,
                                       uint8_t *const *dsts, int dstride, const double *window,
