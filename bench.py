@@ -79,7 +79,7 @@ def main() -> int:
                     help="seconds of untimed steps before the warm-up steps (GPU clock ramp; setup, not measurement)")
     ap.add_argument("--workers", type=int, default=0, help="config5: host worker threads per GPU (0 = min(8, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
     if args.workload != "config2":
@@ -414,6 +414,29 @@ def other_workloads(args) -> int:
             return [float(last[0][0, 0].item())]
         metric, unit, units_per_step = "megapixels/sec: 4K applyPalette (256 colours) + palettedToNRGBA", "MP/s", B * W * H / 1e6
         name = "palette: nearest of 256 palette colours per pixel, indices + quantized NRGBA out"
+    elif wl == "scale-search":   # scaleSearch's data movement (targetsize.go:286-313)
+        W, H, B = 3840, 2160, min(args.batch, 16)
+        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        torch.cuda.synchronize()
+        # the bisection's 12 scales when the encoder says "fits" below 0.3 (a stand-in for testScaleFits: the
+        # codec stays on the host and is not part of this line)
+        scales, lo, hi = [], 0.05, 1.0
+        for _ in range(12):
+            mid = (lo + hi) / 2
+            scales.append(mid)
+            lo, hi = (mid, hi) if mid <= 0.3 else (lo, mid)
+        dims = [(int(W * sc), int(H * sc)) for sc in scales]
+        alg = sum(4.0 * W * H + 4.0 * dw * dh for dw, dh in dims) / len(dims)   # per downsample: read src, write dst
+
+        def step():
+            last = None
+            for a in imgs:
+                for dw, dh in dims:
+                    last = ctx.boxDownsample(a, dw, dh, to_host=True)    # FNX_DEVICE_SRC: resident source, host result
+            return [float(last[0, 0, 0])]
+        metric, unit, units_per_step = "megapixels/sec: 4K scaleSearch boxDownsample x12 (source pixels)", "MP/s", B * len(dims) * W * H / 1e6
+        name = ("scale-search: 12 boxDownsamples per resident 4K source at scaleSearch's bisection scales, every result "
+                "copied to host memory (FNX_DEVICE_SRC)")
     else:   # config5: CompressBatch semantics, host JPEG codec (Pillow) + GPU SSIMFast
         W, H, B = 3840, 2160, min(args.batch, 16)
         srcs = [synth.large_photo(W, H, rank * B + i) for i in range(B)]
@@ -476,7 +499,7 @@ def other_workloads(args) -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     value = units_per_step * world * args.steps / elapsed
-    gbs = alg * (B if unit == "MP/s" else B) * args.steps / elapsed / 1e9
+    gbs = alg * (B * 12 if wl == "scale-search" else B) * args.steps / elapsed / 1e9
     out = {
         "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,

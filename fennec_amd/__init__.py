@@ -38,7 +38,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FENNEC_HIP_LIB") or os.path.join(_HERE, "libfennec_hip.so")   # override: A/B builds
 
 FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
-FNX_HOST, FNX_DEVICE = 0, 1
+FNX_HOST, FNX_DEVICE, FNX_DEVICE_SRC = 0, 1, 2
 FNX_BLUR_FAST, FNX_BLUR_EXACT = 0, 1
 
 _u8p = C.c_void_p
@@ -348,16 +348,25 @@ class Context:
                                        C.byref(out), lv.ctypes.data_as(_f64p)), "fnx_msssim")
         return out.value, lv
 
-    def boxDownsample(self, img, dstW: int, dstH: int):
-        """ssim.go:244"""
+    def boxDownsample(self, img, dstW: int, dstH: int, to_host: bool = False):
+        """ssim.go:244.  to_host=True with a device image (FNX_DEVICE_SRC): the result is a numpy array and the
+        call returns when it is filled -- the scale searches of targetsize.go:240-313 keep ONE source
+        resident and fetch a small downsample per iteration."""
         s = _Img(img)
         if s.w <= 0 or s.h <= 0 or dstW <= 0 or dstH <= 0:
-            return s.like(0, 0)
-        dst = s.like(dstW, dstH)
+            return self._out_for(s, 0, 0, to_host)[1]
+        space, dst = self._out_for(s, dstW, dstH, to_host)
         d = _Img(dst)
-        self._chk(self._lib.fennec_boxDownsample(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr,
+        self._chk(self._lib.fennec_boxDownsample(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
                                                  d.stride, dstW, dstH), "boxDownsample")
         return dst
+
+    @staticmethod
+    def _out_for(s: "_Img", w: int, h: int, to_host: bool):
+        """(space, fresh destination) for an image -> image op on `s`."""
+        if to_host and s.space == FNX_DEVICE:
+            return FNX_DEVICE_SRC, np.empty((h, w, 4), dtype=np.uint8)
+        return s.space, s.like(w, h)
 
     def ssim_fast_prepare(self, img):
         s = _Img(img)
@@ -414,14 +423,14 @@ class Context:
         return self._sharpen(self._lib.fennec_AdaptiveSharpen, "AdaptiveSharpen", img, strength)
 
     # -- resize.go ----------------------------------------------------------------------
-    def lanczosResize(self, img, dstW: int, dstH: int):
-        """resize.go:37"""
+    def lanczosResize(self, img, dstW: int, dstH: int, to_host: bool = False):
+        """resize.go:37.  to_host: see boxDownsample."""
         s = _Img(img)
         if s.w <= 0 or s.h <= 0 or dstW <= 0 or dstH <= 0:
-            return s.like(0, 0)
-        dst = s.like(dstW, dstH)
+            return self._out_for(s, 0, 0, to_host)[1]
+        space, dst = self._out_for(s, dstW, dstH, to_host)
         d = _Img(dst)
-        self._chk(self._lib.fennec_lanczosResize(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr,
+        self._chk(self._lib.fennec_lanczosResize(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
                                                  d.stride, dstW, dstH), "lanczosResize")
         return dst
 

@@ -36,6 +36,16 @@ int check_space(int space)
     return FNX_OK;
 }
 
+// image -> image ops also take FNX_DEVICE_SRC: device-resident source, host destination
+int check_space_io(int space)
+{
+    if (space != FNX_HOST && space != FNX_DEVICE && space != FNX_DEVICE_SRC) {
+        set_error("invalid argument: space must be FNX_HOST, FNX_DEVICE or FNX_DEVICE_SRC");
+        return FNX_ERR_INVALID;
+    }
+    return FNX_OK;
+}
+
 // SSIMFast's dims (ssim.go:52-56)
 bool ssim_fast_dims(int w, int h, int *nw, int *nh)
 {
@@ -121,7 +131,7 @@ int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
                       const double *kernel, int radius, int flags, uint8_t *dst, int dstride)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     FNX_REQUIRE(kernel != nullptr && radius >= 0, "blur kernel");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
@@ -155,7 +165,7 @@ int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
                 uint8_t *dst, int dstride)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     if (w <= 0 || h <= 0) return FNX_OK;
@@ -171,7 +181,7 @@ static int sharpen_common(fnx_ctx *ctx, bool adaptive, int space, const uint8_t 
                           int w, int h, double amount, uint8_t *dst, int dstride)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     FNX_REQUIRE(w >= 3 && h >= 3, "sharpen needs w,h >= 3 (the reference returns the input below that)");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
@@ -224,7 +234,7 @@ int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
                  uint8_t *dst, int dstride, int dstW)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstW > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, srcH, "dst"));
@@ -245,7 +255,7 @@ int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
                  uint8_t *dst, int dstride, int dstH)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstH > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, srcW, dstH, "dst"));
@@ -266,7 +276,7 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
                        uint8_t *dst, int dstride, int dstW, int dstH)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
@@ -275,6 +285,9 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
         const size_t nbytes = sl < dl ? sl : dl;
         if (space == FNX_HOST) {
             std::memcpy(dst, src, nbytes);
+        } else if (space == FNX_DEVICE_SRC) {
+            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+            FNX_HIP(hipStreamSynchronize(ctx->stream));
         } else {
             FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
         }
@@ -303,7 +316,7 @@ int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
                        int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // ssim.go:246-248
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
@@ -849,7 +862,7 @@ int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, 
                uint8_t *dst, int dstride)
 {
     FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
+    FNX_TRY(check_space_io(space));
     if (orient < 2 || orient > 8) return FNX_NOOP;   // exif.go:180-181,200-201
     const bool swap = orient >= 5;
     const int ow = swap ? h : w, oh = swap ? w : h;

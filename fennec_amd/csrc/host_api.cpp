@@ -197,6 +197,10 @@ int fennec_SSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, 
 {
     if (aw == bw && ah == bh) return fnx_ssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out);
     FNX_TRY(bind(ctx));
+    if (space != FNX_HOST && space != FNX_DEVICE) {
+        set_error("invalid argument: space must be FNX_HOST or FNX_DEVICE");
+        return FNX_ERR_INVALID;
+    }
     if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
         // lanczosResize hands back a 0x0 image; pixelSSIM then indexes past it for a non-empty
         // `a` (the reference panics) or returns 1.0 for an empty `a`.
@@ -225,6 +229,10 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
     if (aw == bw && ah == bh)
         return fnx_msssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out, nullptr);
     FNX_TRY(bind(ctx));
+    if (space != FNX_HOST && space != FNX_DEVICE) {
+        set_error("invalid argument: space must be FNX_HOST or FNX_DEVICE");
+        return FNX_ERR_INVALID;
+    }
     if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
         if (aw <= 0 || ah <= 0) return fnx_msssim(ctx, space, a, astride, a, astride, aw, ah, ssim_window(), out, nullptr);
         set_error("MSSSIM: second image is empty (the reference panics)");
@@ -250,7 +258,7 @@ int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride
     // The drop-in is bit-exact where that is free: a host-space call is PCIe-bound (1.2 ms per 4K image,
     // the exact kernel 0.03 ms of it).  Device-resident callers get the fast kernel (<= 1 LSB on
     // <= 0.1 % of samples) and can ask fnx_gaussian_blur for FNX_BLUR_EXACT themselves.
-    const int mode = space == FNX_HOST ? FNX_BLUR_EXACT : FNX_BLUR_FAST;
+    const int mode = space == FNX_DEVICE ? FNX_BLUR_FAST : FNX_BLUR_EXACT;
     return fnx_gaussian_blur(ctx, space, src, sstride, w, h, k.data(), radius, mode, dst, dstride);
 }
 

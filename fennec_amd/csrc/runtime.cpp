@@ -109,7 +109,7 @@ int upload_table(fnx_ctx *ctx, Slot slot, const void *host, size_t bytes, void *
 int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
              DevImg *out)
 {
-    if (space == FNX_DEVICE) {
+    if (space != FNX_HOST) {   // FNX_DEVICE, FNX_DEVICE_SRC: inputs are device memory
         out->p = src;
         out->stride = sstride;
         return FNX_OK;
@@ -127,7 +127,7 @@ int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, in
 int stage_in_flat(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
                   DevImg *out)
 {
-    if (space == FNX_DEVICE) {
+    if (space != FNX_HOST) {   // FNX_DEVICE, FNX_DEVICE_SRC: inputs are device memory
         out->p = src;
         out->stride = sstride;
         return FNX_OK;
@@ -164,7 +164,7 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
 
 int finish(fnx_ctx *ctx, int space, DevOut *out)
 {
-    if (space != FNX_HOST) return FNX_OK;
+    if (space == FNX_DEVICE) return FNX_OK;
     if (out && out->host && out->w > 0 && out->h > 0) {
         FNX_HIP(hipMemcpy2DAsync(out->host, out->hstride, out->p, out->stride, size_t(out->w) * 4,
                                  out->h, hipMemcpyDeviceToHost, ctx->stream));

@@ -62,6 +62,12 @@ extern "C" {
 
 #define FNX_HOST 0
 #define FNX_DEVICE 1
+/* image -> image ops only (blur, blur3x3, sharpen, resize, box downsample, orient): the source is device
+ * memory (fnx_malloc + fnx_upload, or an earlier device result), the destination is host memory and the
+ * call returns when it is filled.  For search loops over ONE resident source -- the scale searches of
+ * targetsize.go:240-313 call boxDownsample(src, w, h) 10-12 times and encode each result on the host --
+ * so that the source crosses PCIe once. */
+#define FNX_DEVICE_SRC 2
 
 /* fnx_gaussian_blur flags */
 #define FNX_BLUR_FAST 0  /* fp32 FMA accumulation: <=1 LSB off the reference on <=0.1% of samples */

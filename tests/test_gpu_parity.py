@@ -822,6 +822,50 @@ def test_full_size_properties(ctx):
     assert np.array_equal(ss, ctx.SSIMFastBatch(d, outs))
 
 
+def test_device_source_host_destination(orc):
+    """FNX_DEVICE_SRC: one resident source, image results straight into host memory -- scaleSearch's loop
+    (targetsize.go:286-313: boxDownsample(src, w, h) at 12 bisection scales, each encoded on the host)."""
+    import ctypes as C
+    import torch
+    lib = fennec_amd.load_library()
+    c = fennec_amd.Context(0)
+    img = synth.large_photo(1900, 1068, 6)
+    d = torch.from_numpy(img).cuda()
+    torch.cuda.synchronize()
+    lo, hi = 0.05, 1.0
+    for i in range(12):
+        mid = (lo + hi) / 2
+        nw, nh = int(1900 * mid), int(1068 * mid)
+        got = c.boxDownsample(d, nw, nh, to_host=True)
+        assert isinstance(got, np.ndarray) and np.array_equal(got, orc.box_downsample(img, nw, nh)), (i, nw, nh)
+        lo, hi = (mid, hi) if i % 3 else (lo, mid)
+    assert np.array_equal(c.lanczosResize(d, 713, 401, to_host=True), orc.lanczos_resize(img, 713, 401))
+    assert np.array_equal(c.lanczosResize(d, 1900, 1068, to_host=True), img)                  # same-size copy branch
+    assert c.boxDownsample(d, 0, 5, to_host=True).shape == (0, 0, 4)
+    # the other image -> image entry points, through the raw ABI
+    SRC = fennec_amd.FNX_DEVICE_SRC
+    small = synth.noise_image(301, 203, 8, alpha=True)
+    ds = torch.from_numpy(small).cuda()
+    torch.cuda.synchronize()
+    h, w = small.shape[:2]
+    out = np.empty_like(small)
+    args = (ds.data_ptr(), 4 * w, w, h)
+    dst = (out.ctypes.data, 4 * w)
+    assert lib.fnx_blur3x3(c._h, SRC, *args, *dst) == 0 and np.array_equal(out, orc.blur3x3(small))
+    assert lib.fennec_Sharpen(c._h, SRC, *args, 0.8, *dst) == 0 and np.array_equal(out, orc.sharpen(small, 0.8))
+    assert lib.fennec_AdaptiveSharpen(c._h, SRC, *args, 0.8, *dst) == 0 and np.array_equal(out, orc.adaptive_sharpen(small, 0.8))
+    r, k = c.blurKernel(1.3)
+    assert lib.fnx_gaussian_blur(c._h, SRC, *args, k.ctypes.data_as(C.POINTER(C.c_double)), r, 1, *dst) == 0
+    assert np.array_equal(out, orc.gaussian_blur(small, 1.3))
+    rot = np.empty((w, h, 4), np.uint8)
+    assert lib.fnx_orient(c._h, SRC, *args, 6, rot.ctypes.data, 4 * h) == 0 and np.array_equal(rot, orc.apply_orientation(small, 6))
+    # scalar-result ops have no host destination: the space is rejected, not misread
+    val = C.c_double()
+    win = c.gaussianKernel()
+    assert lib.fnx_ssim_fast(c._h, SRC, *args[:2], *args[:2], w, h, win.ctypes.data_as(C.POINTER(C.c_double)), C.byref(val)) < 0
+    c.close()
+
+
 def test_argument_errors_and_context_lifecycle(orc):
     """bad arguments come back as FennecError with the library's message (never a crash, never a silent
     fallback); contexts can be created and destroyed in a loop without leaking device memory"""
