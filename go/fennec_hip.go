@@ -465,6 +465,62 @@ func (r *ssimRef) against(decoded image.Image) float64 {
 	return ssimFastGo(r.src, toNRGBARef(decoded)) // anything else: the reference's own path
 }
 
+// ---- targetsize.go: scale searches over one source (targetsize.go:240-313) ------------------
+
+// residentSrc keeps ONE source image in device memory for the scale searches: findBestScaleBinary,
+// findBestScaleFixed and scaleSearch call boxDownsample(src, w, h) 10-12 times on the same `src` and
+// encode every result on the host.  Their loop bodies change from `boxDownsample(src, newW, newH)` to
+// `rs.boxDownsample(newW, newH)`, with `rs := uploadSrc(src); defer rs.close()` before the loop: the
+// 33 MB source crosses PCIe once, each iteration is the box kernel plus the D2H copy of the small result
+// (FNX_DEVICE_SRC).
+type residentSrc struct {
+	c      *C.fnx_ctx
+	d      unsafe.Pointer
+	src    *image.NRGBA
+	w, h   int
+	stride int
+}
+
+func uploadSrc(src *image.NRGBA) *residentSrc {
+	r := &residentSrc{src: src, w: src.Bounds().Dx(), h: src.Bounds().Dy()}
+	if r.w <= 0 || r.h <= 0 {
+		return r
+	}
+	if c := pool.get(); c != nil {
+		r.stride = 4 * r.w
+		if C.fnx_malloc(c, C.size_t(r.stride*r.h), &r.d) == C.FNX_OK &&
+			C.fnx_upload(c, r.d, C.int(r.stride), unsafe.Pointer(pix(src)), C.int(src.Stride), C.int(r.w), C.int(r.h)) == C.FNX_OK {
+			r.c = c
+		} else {
+			if r.d != nil {
+				C.fnx_free(c, r.d)
+				r.d = nil
+			}
+			pool.put(c)
+		}
+	}
+	return r
+}
+
+func (r *residentSrc) close() {
+	if r.c != nil {
+		C.fnx_free(r.c, r.d)
+		pool.put(r.c)
+		r.c, r.d = nil, nil
+	}
+}
+
+func (r *residentSrc) boxDownsample(dstW, dstH int) *image.NRGBA {
+	if r.c != nil && dstW > 0 && dstH > 0 {
+		dst := image.NewNRGBA(image.Rect(0, 0, dstW, dstH))
+		if C.fnx_box_downsample(r.c, C.FNX_DEVICE_SRC, (*C.uint8_t)(r.d), C.int(r.stride), C.int(r.w), C.int(r.h),
+			pix(dst), C.int(dst.Stride), C.int(dstW), C.int(dstH)) == C.FNX_OK {
+			return dst
+		}
+	}
+	return boxDownsample(r.src, dstW, dstH) // per-call path (and through it the reference's own body)
+}
+
 // ---- targetsize.go: applyPalette (targetsize.go:488) ----------------------------------------
 
 // applyPalette replaces targetsize.go:488 for opaque palettes (what medianCut builds).
