@@ -308,7 +308,7 @@ def main() -> int:
     step_kernel_ms = blur_ms + (rest_ms if one_pass else ssim_ms)
     out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
                           "ms_per_step": round(step_kernel_ms, 4)}
-    if rank == 0 and one_pass and not exact and nctx == 1:
+    if rank == 0 and world == 1 and one_pass and not exact and nctx == 1:
         # the same step with bit-exact blurred images (FNX_BLUR_EXACT), after the timed region; never `value`
         ctx.profile(False)
         xplan = ctx.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=dsts, exact=True)

@@ -42,6 +42,20 @@ __global__ __launch_bounds__(256) void k(double *out, double seed, unsigned usee
             if (KIND == 17) { unsigned t; asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %2" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
             if (KIND == 18) { float t; asm volatile("v_add_f32 %0, 1.0, %1" : "=v"(t) : "v"(f[i])); f[i] = t; }
             if (KIND == 19) { float t; asm volatile("v_floor_f32 %0, %1" : "=v"(t) : "v"(f[i])); f[i] = t; }
+            if (KIND == 20) { float t; asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(t) : "v"(u[i])); u[i] = __float_as_uint(t); }
+            if (KIND == 21) { float t; asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(t) : "v"(u[i])); u[i] = __float_as_uint(t); }
+            if (KIND == 22) { float t; asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(t) : "v"(u[i])); u[i] = __float_as_uint(t); }
+            if (KIND == 23) { unsigned t; asm volatile("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 24) { unsigned t; asm volatile("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 25) { float t = f[i]; asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(t) : "v"(f[i]), "v"(1.0000001f)); f[i] = t; }
+            if (KIND == 26) { float t; asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(t) : "v"(u[i])); u[i] = __float_as_uint(t); }
+            if (KIND == 27) { unsigned t; asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 28) { float t; asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(t) : "v"(u[i])); u[i] = __float_as_uint(t); }
+            if (KIND == 29) { unsigned t; asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 30) { unsigned t; asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 31) { unsigned t; asm volatile("v_mad_u32_u16 %0, %1, %2, %1" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 32) { unsigned t; asm volatile("v_pk_mad_u16 %0, %1, %2, %1" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
+            if (KIND == 33) { unsigned t; asm volatile("v_dot2_u32_u16 %0, %1, %2, %1" : "=v"(t) : "v"(u[i]), "v"(useed)); u[i] = t; }
         }
     }
     double s = 0;
@@ -93,6 +107,20 @@ int main()
     run<17, 16>("v_cvt_pk_u8_f32", 1);
     run<18, 16>("v_add_f32", 1);
     run<19, 16>("v_floor_f32", 1);
+    run<20, 16>("v_cvt_f32_u32", 1);
+    run<21, 16>("v_cvt_f32_u32_sdwa BYTE_1", 1);
+    run<22, 16>("v_cvt_f32_ubyte0", 1);
+    run<26, 16>("v_cvt_f32_ubyte3", 1);
+    run<28, 16>("v_cvt_f32_i32", 1);
+    run<23, 16>("v_mad_u32_u24", 1);
+    run<24, 16>("v_mul_u32_u24_sdwa BYTE_1", 1);
+    run<29, 16>("v_mul_u32_u24", 1);
+    run<30, 16>("v_mul_lo_u32", 1);
+    run<25, 16>("v_fmac_f32", 1);
+    run<27, 16>("v_add_u32_sdwa BYTE_2", 1);
+    run<31, 16>("v_mad_u32_u16", 1);
+    run<32, 16>("v_pk_mad_u16", 1);
+    run<33, 16>("v_dot2_u32_u16", 1);
     // dependent chains: 256-thread blocks, 4096 blocks -> 16 waves per SIMD resident; x1 = every
     // instruction of a wave depends on the previous one
     run<3, 1>("v_fma_f32 dependent", 1);
