@@ -230,7 +230,7 @@ def main() -> int:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
-            "traffic": committed_traffic("blur_direct_kernel", nb0, scored=True),
+            "traffic": committed_traffic("blur_direct_kernel", nb0, scored=True, exact=exact),
             "algorithmic_bytes_per_launch": blur_bytes,
             "algorithmic_bytes_note": "SURVEY 8(d): 4*S per image for GaussianBlur+SSIMFast; the one-pass kernel "
                                       "needs only 2*S of HBM traffic for it (see traffic)",
@@ -256,7 +256,7 @@ def main() -> int:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
-            "traffic": committed_traffic("blur_direct_kernel", nb0),
+            "traffic": committed_traffic("blur_direct_kernel", nb0, exact=exact),
             "algorithmic_bytes_per_launch": blur_bytes,
             "avg_launch_ms": round(blur_ms, 4),
         }
@@ -543,7 +543,16 @@ def other_workloads(args) -> int:
     return 0
 
 
-def committed_traffic(kernel_substr: str, batch: int, scored: bool = False):
+def _template_flags(kernel_name: str):
+    """(SCORE, GUARD) of a blur_direct_kernel<R, NTH, IH, SCORE, RA, RB, GUARD> instantiation name."""
+    try:
+        args = [a.strip() for a in kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].split(",")]
+        return args[3] == "true", (len(args) > 6 and args[6] == "true")
+    except (ValueError, IndexError):
+        return False, False
+
+
+def committed_traffic(kernel_substr: str, batch: int, scored: bool = False, exact: bool = False):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH doubled per the gfx950
     correction).  None when no profile of this batch size has been committed."""
@@ -552,7 +561,7 @@ def committed_traffic(kernel_substr: str, batch: int, scored: bool = False):
         try:
             t = json.load(open(p))
             for k, v in t["kernels"].items():
-                if kernel_substr in k and (", true" in k) == scored and batch == int(t.get("images_per_launch", 32)):
+                if kernel_substr in k and _template_flags(k) == (scored, exact) and batch == int(t.get("images_per_launch", 32)):
                     return float(v["hbm_bytes_per_launch"])
         except Exception:
             continue
