@@ -312,6 +312,7 @@ struct WinSepArgs {
 // half rate), so everything is cut for fp64 instructions per window: four moments, 2 horizontally
 // adjacent H outputs and TY/8 vertically adjacent windows per lane.  (A 3 x 256 LDS table of the
 // luminance products saved 6 fp64 ops per pixel and cost 20 %: dependent, bank-conflicting reads.)
+// Big planes take windowed_ssim_sep24_kernel below; this one serves planes with too few windows for it.
 template <int TY, int NTHR>
 __global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
 {
@@ -446,6 +447,134 @@ static bool window_rank1(const double *k, double *col, double *row)
     return true;
 }
 
+// The same two passes on a 32 x 24-window tile and 256 lanes, for big planes.  Shape: (24 + 7) rows x 16
+// two-output H items = 496 items = 2 rounds of 256 lanes at 97 % (the 32 x 32 / 512-lane shape fills 61 % of
+// its second round: PMC counted 213 VALU wave-instructions per window, a quarter of them on idle lanes),
+// 3 vertically adjacent windows per lane in the V pass.  LDS: the H results of rows 0..15 (round 1) get
+// their own 16 KB; those of rows 16..30 (round 2) are held in registers across a barrier and then
+// overwrite the luminance tile, which nobody reads any more -- 36 KB per workgroup = 16 waves per CU, where
+// separate arrays (52 KB, 12 waves per CU) measured no faster than the old shape.
+constexpr int W24_TY = 24, W24_LH = W24_TY + 7, W24_LW = WSS_TX + 8, W24_R1 = 16;
+__global__ __launch_bounds__(256) void windowed_ssim_sep24_kernel(WinSepArgs a)
+{
+    constexpr int LH = W24_LH, LW = W24_LW, TX = WSS_TX, NTHR = 256, WPT = 3;
+    constexpr int LUM = LH * LW;                              // doubles per luminance tile
+    constexpr int ROWH = 4 * TX;                              // doubles per row of H results: [moment][x]
+    static_assert((LH - W24_R1) * ROWH <= 2 * LUM, "round-2 results must fit over the luminance tiles");
+    __shared__ __attribute__((aligned(16))) double s_lds[2 * LUM + W24_R1 * ROWH];
+    __shared__ double s_red[NTHR / 64];
+    double *s_a = s_lds, *s_b = s_lds + LUM;
+    double *s_h1 = s_lds + 2 * LUM;                           // rows 0..15
+    double *s_h2 = s_lds;                                     // rows 16..30, over s_a / s_b
+    const int z = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int wx0 = tx * TX, wy0 = ty * W24_TY;
+    const uint8_t *A = a.a + a.a_image_bytes * z;
+    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < LUM; i += NTHR) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
+        s_a[i] = lum601(ld_px(A + static_cast<size_t>(y) * a.astride, x));
+        s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
+    }
+    __syncthreads();
+    // horizontal pass: item = (row, 2 adjacent outputs), as in windowed_ssim_sep_kernel
+    auto h_item = [&](int r, int x, double (&h)[2][4]) {
+        double va[10], vb[10];
+#pragma unroll
+        for (int t = 0; t < 10; t += 2) {
+            const double2 pa = *reinterpret_cast<const double2 *>(&s_a[r * LW + x + t]);
+            const double2 pb = *reinterpret_cast<const double2 *>(&s_b[r * LW + x + t]);
+            va[t] = pa.x; va[t + 1] = pa.y;
+            vb[t] = pb.x; vb[t + 1] = pb.y;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; o++) h[o][0] = h[o][1] = h[o][2] = h[o][3] = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const double sq = fma(vb[t], vb[t], va[t] * va[t]), ab = va[t] * vb[t];
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const int k = t - o;
+                if (k >= 0 && k < 8) {
+                    const double c = a.col[k];
+                    h[o][0] = fma(va[t], c, h[o][0]);
+                    h[o][1] = fma(vb[t], c, h[o][1]);
+                    h[o][2] = fma(sq, c, h[o][2]);
+                    h[o][3] = fma(ab, c, h[o][3]);
+                }
+            }
+        }
+    };
+    const int hr = tid / (TX / 2), hx = 2 * (tid - hr * (TX / 2));      // this lane's item within a round
+    {
+        double h[2][4];
+        h_item(hr, hx, h);                                              // round 1: rows 0..15
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<double2 *>(&s_h1[hr * ROWH + q * TX + hx]) = make_double2(h[0][q], h[1][q]);
+    }
+    {
+        double h[2][4];
+        const bool live = W24_R1 + hr < LH;                             // round 2: rows 16..30
+        if (live) h_item(W24_R1 + hr, hx, h);
+        __syncthreads();                                                // every read of the luminance tiles is done
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<double2 *>(&s_h2[hr * ROWH + q * TX + hx]) = make_double2(h[0][q], h[1][q]);
+        }
+    }
+    __syncthreads();
+    double val = 0;
+    {
+        const int lx = tid & (TX - 1), ly = WPT * (tid / TX);
+        const int wx = wx0 + lx;
+        double m[WPT][4];
+#pragma unroll
+        for (int o = 0; o < WPT; o++) m[o][0] = m[o][1] = m[o][2] = m[o][3] = 0;
+#pragma unroll
+        for (int j = 0; j < WPT + 7; j++) {
+            const int r = ly + j;
+            const double *hrow = (r < W24_R1 ? s_h1 + r * ROWH : s_h2 + (r - W24_R1) * ROWH) + lx;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double hv = hrow[q * TX];
+#pragma unroll
+                for (int o = 0; o < WPT; o++) {
+                    const int k = j - o;
+                    if (k >= 0 && k < 8) m[o][q] = fma(hv, a.row[k], m[o][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < WPT; o++) {
+            const int wy = wy0 + ly + o;
+            if (wx < a.w - 8 && wy < a.h - 8) {
+                const double muA = m[o][0], muB = m[o][1];
+                const double mu2 = muA * muA + muB * muB, muAB = muA * muB;
+                const double sSum = m[o][2] - mu2, sAB = m[o][3] - muAB;
+                const double num = (2 * muAB + 6.5025) * (2 * sAB + 58.5225);
+                const double den = (mu2 + 6.5025) * (sSum + 58.5225);
+                double rc = __builtin_amdgcn_rcp(den);                  // see windowed_ssim_sep_kernel
+                rc = fma(fma(-den, rc, 1.0), rc, rc);
+                rc = fma(fma(-den, rc, 1.0), rc, rc);
+                val += num * rc;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = val;
+    __syncthreads();
+    if (tid == 0) {
+        double t = s_red[0];
+#pragma unroll
+        for (int wv = 1; wv < NTHR / 64; wv++) t += s_red[wv];
+        a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
+    }
+}
+
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
 {
@@ -475,10 +604,10 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     const bool have = ww > 0 && wh > 0;
     WinSepArgs sa{};
     const bool sep = have && window_rank1(h_window, sa.col, sa.row);
-    // big images: 32 x 32-window tiles on 512 lanes (halo 1.49x / 1.22x instead of 1.75x / 1.44x at the same
-    // 16 waves per CU); small ones keep 32 x 16 on 256 lanes for the tile count
+    // big images: 32 x 24-window tiles (windowed_ssim_sep24_kernel: halo 1.61x instead of 1.80x, full lanes in
+    // the H pass, 16 waves per CU); small ones keep 32 x 16 for the tile count
     const bool big = sep && static_cast<long>(ww) * wh * n >= 4L * 1024 * ctx->num_cus;
-    const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? 32 : WSS_TY) : WS_TY;
+    const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? W24_TY : WSS_TY) : WS_TY;
     int tiles_x = 0, tiles = 0;
     if (have) {
         tiles_x = (ww + TX - 1) / TX;
@@ -496,7 +625,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
-        if (big) hipLaunchKernelGGL((windowed_ssim_sep_kernel<32, 512>), dim3(tiles, n), dim3(512), 0, ctx->stream, sa);
+        if (big) hipLaunchKernelGGL(windowed_ssim_sep24_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         else hipLaunchKernelGGL((windowed_ssim_sep_kernel<WSS_TY, 256>), dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         FNX_HIP(hipGetLastError());
     } else if (have) {
