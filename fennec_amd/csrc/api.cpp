@@ -261,12 +261,13 @@ int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_TRY(check_img(dst, dstride, srcW, dstH, "dst"));
     const int32_t *doff, *didx;
     const double *dwt;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offset, index, weight, &doff, &didx, &dwt));
+    int contig = 0;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offset, index, weight, &doff, &didx, &dwt, &contig));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, srcW, dstH, SLOT_OUT, &d));
-    FNX_TRY(launch_resize_v(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstH));
+    FNX_TRY(launch_resize_v(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstH, contig));
     return finish(ctx, space, &d);
 }
 
@@ -297,7 +298,8 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     const double *dWH, *dWV;
     int contig = 0;
     FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offH, idxH, wH, &dOffH, &dIdxH, &dWH, &contig));
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offV, idxV, wV, &dOffV, &dIdxV, &dWV));
+    int contigV = 0;
+    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offV, idxV, wV, &dOffV, &dIdxV, &dWV, &contigV));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
@@ -307,7 +309,7 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     void *tmp = nullptr;
     FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
     FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, dOffH, dIdxH, dWH, static_cast<uint8_t *>(tmp), tp, dstW, contig));
-    FNX_TRY(launch_resize_v(ctx, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, dOffV, dIdxV, dWV, d.p, d.stride, dstH));
+    FNX_TRY(launch_resize_v(ctx, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, dOffV, dIdxV, dWV, d.p, d.stride, dstH, contigV));
     return finish(ctx, space, &d);
 }
 

@@ -175,7 +175,7 @@ int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int
 int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout);
 int launch_resize_v(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
                     const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
-                    int dstride, int dstH);
+                    int dstride, int dstH, int contig_taps);
 // n images: src either one pointer or device array; dst images are tight dstW x dstH, image i at
 // dst + i*dst_image_bytes.
 int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,

@@ -152,6 +152,107 @@ __global__ __launch_bounds__(256) void resize_h_rows_kernel(ResizeRowsArgs a)
     }
 }
 
+// V pass for contiguous tap lists.  A workgroup owns 256 columns x RV_G consecutive output rows and walks
+// DOWN the source rows those outputs use, once: every source pixel is loaded and converted one time and
+// feeds each output row whose window holds it (at a 2x downscale a source row serves 6 output rows, and
+// the thread-per-output kernel converted it 6 times: PMC counted 24-31 VALU instructions per tap, 16 of
+// them conversions and addressing).  Taps are row-uniform, so the window tests are scalar branches and the
+// weights come from a small LDS table (one broadcast read per use).  Per output the arithmetic is
+// resize_tap's, in ascending tap order (= ascending source row, the lists being contiguous).
+constexpr int RV_G = 4, RV_NT = 32;
+
+struct ResizeColsArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int sstride, dstride;
+    int w, outH;
+    const int32_t *off;
+    const int32_t *idx;
+    const double *wt;
+};
+
+__global__ __launch_bounds__(256) void resize_v_cols_kernel(ResizeColsArgs a)
+{
+    __shared__ double s_w[RV_G][RV_NT];
+    __shared__ int s_s0[RV_G], s_n[RV_G];
+    const int tid = threadIdx.x;
+    const int y0 = blockIdx.y * RV_G;
+    if (tid < RV_G) {
+        const int y = y0 + tid;
+        int n = 0, s0 = 0;
+        if (y < a.outH) {
+            const int t0 = a.off[y];
+            n = a.off[y + 1] - t0;
+            s0 = n > 0 ? a.idx[t0] : 0;
+        }
+        s_s0[tid] = s0;
+        s_n[tid] = n;
+    }
+    if (tid < RV_G * RV_NT) {
+        const int g = tid / RV_NT, k = tid - g * RV_NT, y = y0 + g;
+        double w = 0.0;
+        if (y < a.outH) {
+            const int t0 = a.off[y];
+            if (k < a.off[y + 1] - t0) w = a.wt[t0 + k];
+        }
+        s_w[g][k] = w;
+    }
+    __syncthreads();
+    const int x = blockIdx.x * 256 + tid;
+    if (x >= a.w) return;
+    int s0[RV_G], n[RV_G];
+    int smin = 0x7fffffff, smax = 0;
+#pragma unroll
+    for (int g = 0; g < RV_G; g++) {
+        s0[g] = __builtin_amdgcn_readfirstlane(s_s0[g]);
+        n[g] = __builtin_amdgcn_readfirstlane(s_n[g]);
+        if (n[g] > 0) {
+            smin = min(smin, s0[g]);
+            smax = max(smax, s0[g] + n[g]);
+        }
+    }
+    double r[RV_G], gg[RV_G], b[RV_G], al[RV_G];
+#pragma unroll
+    for (int g = 0; g < RV_G; g++) r[g] = gg[g] = b[g] = al[g] = 0;
+    const uint8_t *col = a.src + 4 * static_cast<size_t>(x);
+    // software pipeline: the next row's pixel is in flight while this row is used, and the RV_G weights
+    // of a row are read together (clamped index; unused ones are simply not applied) -- one LDS wait per
+    // row instead of one per use
+    uint32_t pn = smin < smax ? *(g_u32 *)(col + static_cast<size_t>(smin) * a.sstride) : 0u;
+    for (int s = smin; s < smax; s++) {
+        const uint32_t p = pn;
+        if (s + 1 < smax) pn = *(g_u32 *)(col + static_cast<size_t>(s + 1) * a.sstride);
+        double w[RV_G];
+#pragma unroll
+        for (int g = 0; g < RV_G; g++) w[g] = s_w[g][min(max(s - s0[g], 0), RV_NT - 1)];
+        const double cr = u8_to_f64(p & 0xffu), cg = u8_to_f64((p >> 8) & 0xffu), cb = u8_to_f64((p >> 16) & 0xffu);
+        const double ca = u8_to_f64(p >> 24);
+#pragma unroll
+        for (int g = 0; g < RV_G; g++) {
+            if (static_cast<unsigned>(s - s0[g]) < static_cast<unsigned>(n[g])) {
+                const double aw = ca * w[g];                    // resize.go:95-103, as resize_tap
+                r[g] += cr * aw;
+                gg[g] += cg * aw;
+                b[g] += cb * aw;
+                al[g] += aw;
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < RV_G; g++) {
+        const int y = y0 + g;
+        if (y < a.outH) {
+            uint32_t o = 0;
+            if (al[g] > 0.5) {                                  // resize.go:107-113
+                const double inv = 1.0 / al[g];
+                o = clampF_dev(r[g] * inv) | (clampF_dev(gg[g] * inv) << 8) | (clampF_dev(b[g] * inv) << 16) |
+                    (clampF_dev(al[g]) << 24);
+            }
+            *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = o;
+        }
+    }
+}
+
 // max taps of any output (0: indices not contiguous somewhere) -- host tables
 int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout)
 {
@@ -189,10 +290,17 @@ int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int
 
 int launch_resize_v(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,
                     const int32_t *d_off, const int32_t *d_idx, const double *d_wt, uint8_t *dst,
-                    int dstride, int dstH)
+                    int dstride, int dstH, int contig_taps)
 {
     (void)srcH;
     if (srcW <= 0 || dstH <= 0) return FNX_OK;
+    if (contig_taps > 0 && contig_taps <= RV_NT) {
+        ResizeColsArgs ca{src, dst, sstride, dstride, srcW, dstH, d_off, d_idx, d_wt};
+        hipLaunchKernelGGL(resize_v_cols_kernel, dim3((srcW + 255) / 256, (dstH + RV_G - 1) / RV_G), dim3(256), 0,
+                           ctx->stream, ca);
+        FNX_HIP(hipGetLastError());
+        return FNX_OK;
+    }
     ResizeArgs a{src, dst, sstride, dstride, srcW, dstH, d_off, d_idx, d_wt};
     dim3 grid((srcW + 63) / 64, (dstH + 3) / 4);
     hipLaunchKernelGGL((resize_pass_kernel<true>), grid, dim3(256), 0, ctx->stream, a);
