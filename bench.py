@@ -154,10 +154,10 @@ def main() -> int:
                     if events and k == 0:
                         events[s][1].record(ext)
                         events[s][2].record(ext)
-                if events:
-                    kernel_ms.append(ctx.kernel_ms())          # waits for the blur kernel only; the tail kernels keep running
                 for k in range(nctx):
-                    vals[halves[k]] = fused_plans[k].fetch()
+                    vals[halves[k]] = fused_plans[k].fetch()   # fnx_results_fetch: the step's only host wait
+                if events:
+                    kernel_ms.append(ctx.kernel_ms())          # the library's HIP events around the blur kernel: complete by now
             return
         for k in range(1, nctx):
             blur_plans[k].run()                                # prologue: belongs to the first step
