@@ -19,6 +19,14 @@ Two ways through the C ABI, bit-identical results (tests/test_gpu_parity.py::tes
 accumulates SSIMFast's boxDownsample sums, so neither full-size image is read a second time;
 --pipeline two-call calls fnx_gaussian_blur_batch then fnx_ssim_fast_batch, as the reference does.
 
+--depth 1 (default): one step at a time -- the blur kernel has the GPU to itself, which is what `roofline`
+describes.  --depth 2: two steps in flight; step s+1 is enqueued -- on a second context (= HIP stream), into a
+second set of destination images -- before step s's B scores are fetched, the way a CompressBatch worker pool
+keeps the queue full (batch.go:84-123).  Every step still blurs and scores all B images and fetches its
+results inside the timed region; two blur kernels then share the GPU (each launch takes twice as long, the
+pair finishes 7 % sooner than back to back: their phases decorrelate and a step's small tail kernels run
+underneath).  The default line reports that rate too (`pipelined`), measured after the timed region.
+
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP events on the stream the
 kernel runs on) and, at N == 1, `cpu_baseline` (the oracle -- a C restatement of the Go
 reference with its threading model -- on a bounded sample of the same workload).
@@ -72,6 +80,11 @@ def main() -> int:
                     help="one-pass (default): fnx_gaussian_blur_ssim_fast_batch, the blur kernel also gathers "
                          "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
                          "fnx_gaussian_blur_batch then fnx_ssim_fast_batch (bit-identical results)")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="one-pass pipeline: steps in flight.  1 (default): one step at a time, so the blur kernel runs "
+                         "alone and `roofline` describes it; 2: step s+1 is enqueued (on a second context = stream, into "
+                         "a second set of destinations) before step s's results are fetched (+7 %%; the default line "
+                         "reports that rate as `pipelined`)")
     ap.add_argument("--blur-mode", default="fast", choices=["fast", "exact"],
                     help="fast (default): fp32 FMA blur, <= 1 LSB on <= 0.1 %% of samples (the tolerance north_star "
                          "allows); exact: the guarded kernel, blurred images bit-identical to the reference's")
@@ -139,12 +152,42 @@ def main() -> int:
     if one_pass:
         ctx.profile(True)      # the library brackets its blur_direct_kernel launches with HIP events
     ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", local_rank))
+    # ---- depth-D software pipeline over whole steps (one-pass, one context per step in flight): every step
+    # still blurs and scores all B images and its B results are fetched inside the timed region; what
+    # overlaps is step s's tail (box_from_slabs, windowed SSIM, finish: small grids) with step s+1's blur
+    depth = max(1, args.depth) if one_pass and nctx == 1 else 1
+    pipe_ctx = [ctx] + [fennec_amd.Context(local_rank) for _ in range(depth - 1)]
+    pipe_dsts = [dsts] + [[torch.empty_like(d) for d in dsts] for _ in range(depth - 1)]
+    torch.cuda.synchronize()
+    pipe_plans = ([fused_plans[0]] + [c.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=o, exact=exact)
+                                      for c, o in zip(pipe_ctx[1:], pipe_dsts[1:])]) if depth > 1 else None
+    pipe_ext = [ext] + [torch.cuda.ExternalStream(c.stream, device=torch.device("cuda", local_rank)) for c in pipe_ctx[1:]]
+    for c in pipe_ctx[1:]:
+        c.profile(True)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     vals = np.zeros(B)
+
+    def run_pipelined(nsteps, events=None):
+        """nsteps full passes, `depth` of them in flight: enqueue step s, then fetch step s - depth + 1."""
+        for s in range(nsteps + depth - 1):
+            if s < nsteps:
+                d = s % depth
+                if events:
+                    events[s][0].record(pipe_ext[d])
+                pipe_plans[d].enqueue()                        # fnx_gaussian_blur_ssim_fast_batch_enqueue
+                if events:
+                    events[s][1].record(pipe_ext[d])
+            if s >= depth - 1:
+                d = (s - depth + 1) % depth
+                vals[:] = pipe_plans[d].fetch()                # fnx_results_fetch: that step's B scores
+                if events:
+                    kernel_ms.append(pipe_ctx[d].kernel_ms())  # its blur kernel's HIP events (complete by now)
 
     def run_steps(nsteps, events=None):
         """nsteps full passes.  Context 0 blurs then scores; the others score (their blur was queued
         at the end of the previous step, or in the prologue) and then blur for the next step."""
+        if depth > 1:
+            return run_pipelined(nsteps, events)
         if one_pass:
             for s in range(nsteps):
                 if events:
@@ -237,10 +280,15 @@ def main() -> int:
             "achieved_on_2S": round(blur_gbs / 2, 1),
             "avg_launch_ms": round(blur_ms, 4),
         }
+        if depth > 1:
+            roofline["note"] = (f"measured live in the timed region, where the kernel shares the GPU with the previous "
+                                f"step's tail kernels (pipeline depth {depth}); `serial` has the kernel running alone")
         rest = {
-            "kernels": "box_from_slabs_kernel + windowed_ssim_sep_kernel + ssim_finish_kernel (results land in pinned host memory)",
+            "kernels": "box_from_slabs_kernel + windowed_ssim_sep24_kernel + ssim_finish_kernel (results land in pinned host memory)",
             "avg_ms": round(rest_ms, 4),
         }
+        if depth > 1:
+            rest["note"] = "enqueue-to-last-kernel latency of a step minus its blur kernel; overlaps the next step's blur"
     else:
         blur_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(args.steps)]))
         ssim_ms = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(args.steps)]))
@@ -292,7 +340,8 @@ def main() -> int:
             "inputs": "device-resident (HBM), batched C-ABI entry points",
             "pipeline": args.pipeline + (" (fnx_gaussian_blur_ssim_fast_batch)" if one_pass else
                                          " (fnx_gaussian_blur_batch, fnx_ssim_fast_batch)"),
-            "contexts_per_gpu": nctx,
+            "contexts_per_gpu": nctx if depth == 1 else depth,
+            "pipeline_depth": depth,
             "prewarm": f"{args.prewarm} s of untimed steps before the {args.warmup} warm-up steps (GPU clock ramp)",
             "parallelism": f"independent images sharded over {world} GPU(s)",
         },
@@ -306,8 +355,60 @@ def main() -> int:
     # rate of the same two ops called with HOST buffers (what the cgo shim's FNX_HOST calls see) -- the
     # latter measured after the timed region on one image, never part of `value`
     step_kernel_ms = blur_ms + (rest_ms if one_pass else ssim_ms)
-    out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
-                          "ms_per_step": round(step_kernel_ms, 4)}
+    if depth == 1:
+        out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
+                              "ms_per_step": round(step_kernel_ms, 4)}
+        if rank == 0 and world == 1 and one_pass and nctx == 1:
+            # the same steps two in flight (--depth 2), after the timed region; never `value`
+            ctx.profile(False)
+            c2 = fennec_amd.Context(local_rank)
+            d2 = [torch.empty_like(d) for d in dsts]
+            torch.cuda.synchronize()
+            pl = [fused_plans[0], c2.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=d2, exact=exact)]
+
+            def two_in_flight(n):
+                for s_ in range(n + 1):
+                    if s_ < n:
+                        pl[s_ & 1].enqueue()
+                    if s_ >= 1:
+                        pl[(s_ - 1) & 1].fetch()
+            t_p = time.perf_counter()
+            while time.perf_counter() - t_p < 0.1:
+                two_in_flight(4)
+            t_p = time.perf_counter()
+            two_in_flight(20)
+            t_p = (time.perf_counter() - t_p) / 20
+            out["pipelined"] = {"value": round(mp_per_image * B / t_p, 1), "unit": "MP/s", "ms_per_step": round(t_p * 1e3, 4),
+                                "depth": 2, "note": "--depth 2: step s+1 enqueued on a second context before step s is "
+                                                    "fetched; 20 steps after the timed region"}
+            ctx.profile(True)
+            del pl, d2
+            c2.close()
+    elif rank == 0 and world == 1:
+        # the same step one at a time (depth 1), after the timed region: the blur kernel alone on the GPU
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.1:
+            pipe_plans[0].enqueue()
+            pipe_plans[0].fetch()
+        ks, ls = [], []
+        t_s = time.perf_counter()
+        for _ in range(10):
+            e0.record(ext)
+            pipe_plans[0].enqueue()
+            e1.record(ext)
+            pipe_plans[0].fetch()
+            ks.append(ctx.kernel_ms())
+            e1.synchronize()
+            ls.append(e0.elapsed_time(e1))
+        t_s = (time.perf_counter() - t_s) / 10
+        k_ms, l_ms = float(np.mean(ks)), float(np.mean(ls))
+        out["serial"] = {"value": round(mp_per_image * B / t_s, 1), "unit": "MP/s", "ms_per_step": round(t_s * 1e3, 4),
+                         "blur_kernel_ms": round(k_ms, 4),
+                         "roofline_frac": round(4.0 * S * B / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "--depth 1: one step at a time, 10 steps after the timed region"}
+        out["kernel_only"] = {"value": round(mp_per_image * B / (l_ms * 1e-3), 1), "unit": "MP/s", "ms_per_step": round(l_ms, 4),
+                              "note": "HIP-event time of one serial step's kernels"}
     if rank == 0 and world == 1 and one_pass and not exact and nctx == 1:
         # the same step with bit-exact blurred images (FNX_BLUR_EXACT), after the timed region; never `value`
         ctx.profile(False)
