@@ -92,6 +92,9 @@ def main() -> int:
                     help="seconds of untimed steps before the warm-up steps (GPU clock ramp; setup, not measurement)")
     ap.add_argument("--workers", type=int, default=0, help="config5: host worker threads per GPU (0 = min(8, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the measurements made after the timed region (pipelined, exact_mode, pcie_inclusive): "
+                         "profiler runs use it so that kernel statistics cover the timed configuration only")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
@@ -358,7 +361,7 @@ def main() -> int:
     if depth == 1:
         out["kernel_only"] = {"value": round(mp_per_image * nb0 / (step_kernel_ms * 1e-3), 1), "unit": "MP/s",
                               "ms_per_step": round(step_kernel_ms, 4)}
-        if rank == 0 and world == 1 and one_pass and nctx == 1:
+        if rank == 0 and world == 1 and one_pass and nctx == 1 and not args.no_extras:
             # the same steps two in flight (--depth 2), after the timed region; never `value`
             ctx.profile(False)
             c2 = fennec_amd.Context(local_rank)
@@ -384,7 +387,7 @@ def main() -> int:
             ctx.profile(True)
             del pl, d2
             c2.close()
-    elif rank == 0 and world == 1:
+    elif rank == 0 and world == 1 and not args.no_extras:
         # the same step one at a time (depth 1), after the timed region: the blur kernel alone on the GPU
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t_s = time.perf_counter()
@@ -409,7 +412,7 @@ def main() -> int:
                          "note": "--depth 1: one step at a time, 10 steps after the timed region"}
         out["kernel_only"] = {"value": round(mp_per_image * B / (l_ms * 1e-3), 1), "unit": "MP/s", "ms_per_step": round(l_ms, 4),
                               "note": "HIP-event time of one serial step's kernels"}
-    if rank == 0 and world == 1 and one_pass and not exact and nctx == 1:
+    if rank == 0 and world == 1 and one_pass and not exact and nctx == 1 and not args.no_extras:
         # the same step with bit-exact blurred images (FNX_BLUR_EXACT), after the timed region; never `value`
         ctx.profile(False)
         xplan = ctx.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=dsts, exact=True)
@@ -423,7 +426,7 @@ def main() -> int:
         out["exact_mode"] = {"value": round(mp_per_image * B / t_x, 1), "unit": "MP/s", "ms_per_step": round(t_x * 1e3, 4),
                              "note": "same step with FNX_BLUR_EXACT: blurred images bit-identical to the reference's "
                                      "GaussianBlur, scores from exactly those images; 10 steps after the timed region"}
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         host = srcs[0].cpu().numpy()
         ctx.GaussianBlur(host, SIGMA, exact=None)
         t_h = time.perf_counter()
