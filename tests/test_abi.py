@@ -114,3 +114,36 @@ def test_stats_epilogue_matches_oracle_on_cpu(orc):
         assert st.MeanBrightness == want["mean_brightness"] and st.Contrast == want["contrast"]
         assert (st.RecommendedFormat, st.RecommendedQuality, st.EstimatedCompression) == \
             (want["recommended_format"], want["recommended_quality"], want["estimated_compression"])
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    """include/fennec_hip.h is what cgo sees: it must compile as C (no C++ in the signatures) and a C
+    program must link against libfennec_hip.so and call it.  Host-only entry points here (no GPU)."""
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "fennec_hip.h"
+int main(void) {
+    double k[64], b[40];
+    int32_t w = 0, h = 0;
+    if (!strstr(fnx_version(), "gfx950")) return 1;
+    fennec_gaussianKernel(8, 1.5, k);                       /* ssim.go:223 */
+    double s = 0; for (int i = 0; i < 64; i++) s += k[i];
+    if (s < 0.999999999 || s > 1.000000001) return 2;
+    if (fennec_blurKernel(2.0, b) != 6) return 3;           /* effects.go:151: radius = ceil(3 sigma) */
+    if (fennec_ssimFastDims(3840, 2160, &w, &h) != 1 || w != 512 || h != 288) return 4;   /* ssim.go:52-56 */
+    fnx_ctx *c = 0;
+    int st = fnx_ctx_create(0, &c);                         /* no GPU here: must fail, not fall back */
+    if (st == FNX_OK) fnx_ctx_destroy(c);
+    printf("%d %d\n", fnx_device_count(), st);
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(fennec_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lfennec_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    ndev, st = int(out[0]), int(out[1])
+    assert (ndev > 0) == (st == 0)
