@@ -161,6 +161,27 @@ def test_resize_passes_with_explicit_tables(ctx, orc):
         assert np.array_equal(ctx.resize_pass(img, 70, False, tab), orc.resize_h(img, 70, tab)), gap
 
 
+def test_resize_v_with_scattered_windows(ctx, orc):
+    """resizeV with hand-made contiguous tap lists whose windows are NOT monotone from one output row to the
+    next (the column-walking V kernel shares source rows among 4 consecutive outputs and must still apply each
+    output's taps in its own order), with 1..32 taps (its table limit), and with longer / gapped lists that
+    take the generic kernel."""
+    img = synth.make_test_image_with_alpha(150, 120)
+    rng = np.random.default_rng(11)
+    for nmax, gap in ((6, False), (32, False), (40, False), (12, True)):
+        off, idx, wt = [0], [], []
+        for d in range(61):
+            n = int(rng.integers(1, nmax + 1))
+            span = 2 * n - 1 if gap else n
+            s0 = int(rng.integers(0, 120 - span + 1))
+            idx += [s0 + (2 * k if gap else k) for k in range(n)]
+            w = rng.uniform(-0.3, 1.0, size=n)
+            wt += list(w / w.sum()) if abs(w.sum()) > 0.2 else list(w)
+            off.append(len(idx))
+        tab = (np.array(off, np.int32), np.array(idx, np.int32), np.array(wt, np.float64))
+        assert np.array_equal(ctx.resize_pass(img, 61, True, tab), orc.resize_v(img, 61, tab)), (nmax, gap)
+
+
 def test_smart_resize(ctx, orc):
     img = synth.make_test_image(1000, 500)
     r = ctx.smartResize(img, 200, 200)
