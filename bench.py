@@ -126,9 +126,8 @@ def main() -> int:
 
     # ---- synthetic inputs, resident in HBM before the timed region ------------------------
     srcs, dsts = [], []
-    for i in range(B):
-        k = rank * B + i
-        srcs.append(torch.from_numpy(synth.large_photo(W4K, H4K, k)).cuda())
+    for img in synth.large_photo_batch(W4K, H4K, range(rank * B, rank * B + B)):    # image k = rank*B + i, all distinct
+        srcs.append(torch.from_numpy(img).cuda())
     for i in range(B):
         dsts.append(torch.empty((H4K, W4K, 4), dtype=torch.uint8, device="cuda"))
     torch.cuda.synchronize()
@@ -463,7 +462,7 @@ def other_workloads(args) -> int:
     wl = args.workload
     if wl == "config3":
         W, H, B = 3840, 2160, min(args.batch, 16)
-        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 193.4e6     # 41.47 (down) + 41.47 (implicit up) + 110.5 (MSSSIM) MB
 
         def step():
@@ -476,7 +475,7 @@ def other_workloads(args) -> int:
         name = "config3: 4K lanczosResize(1920x1080) + MSSSIM(4K, 1080p)"
     elif wl == "config4":
         W, H, B = 7680, 4320, min(args.batch, 8)
-        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 530.84e6
 
         def step():
@@ -489,7 +488,7 @@ def other_workloads(args) -> int:
         name = "config4: 8K AdaptiveSharpen(0.5) + full-resolution SSIM"
     elif wl == "analyze":     # Analyze (analyze.go:26-124), BenchmarkAnalyze's op at 4K
         W, H, B = 3840, 2160, args.batch
-        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         torch.cuda.synchronize()
         alg = 4.0 * W * H           # every pixel read once; the sampled passes touch < 1 % more
         plan = ctx.plan_analyze_batch(imgs)
@@ -504,7 +503,7 @@ def other_workloads(args) -> int:
         name = "analyze: Analyze() of 4K images (histogram, brightness, flags, sampled colours / contrast / Sobel)"
     elif wl == "palette":     # applyPalette + palettedToNRGBA (targetsize.go:488-546), 256 colours
         W, H, B = 3840, 2160, min(args.batch, 16)
-        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         pal = np.random.default_rng(1).integers(0, 256, size=(256, 4), dtype=np.uint8)
         pal[:, 3] = 255
         torch.cuda.synchronize()
@@ -520,7 +519,7 @@ def other_workloads(args) -> int:
         name = "palette: nearest of 256 palette colours per pixel, indices + quantized NRGBA out"
     elif wl == "scale-search":   # scaleSearch's data movement (targetsize.go:286-313)
         W, H, B = 3840, 2160, min(args.batch, 16)
-        imgs = [torch.from_numpy(synth.large_photo(W, H, rank * B + i)).cuda() for i in range(B)]
+        imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         torch.cuda.synchronize()
         # the bisection's 12 scales when the encoder says "fits" below 0.3 (a stand-in for testScaleFits: the
         # codec stays on the host and is not part of this line)
@@ -543,7 +542,7 @@ def other_workloads(args) -> int:
                 "copied to host memory (FNX_DEVICE_SRC)")
     else:   # config5: CompressBatch semantics, host JPEG codec (Pillow) + GPU SSIMFast
         W, H, B = 3840, 2160, min(args.batch, 16)
-        srcs = [synth.large_photo(W, H, rank * B + i) for i in range(B)]
+        srcs = synth.large_photo_batch(W, H, range(rank * B, rank * B + B))
         jpegs = [fbatch.pillow_encode(s, 92) for s in srcs]          # "4096 synthetic 4K JPEGs", q=92 up front
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
