@@ -420,8 +420,13 @@ __global__ __launch_bounds__(256) void scan_flags_kernel(const uint8_t *pix, lon
             flags |= ((v[e] >> 24) != 0xffu ? 1u : 0u) | ((r != g || g != b) ? 2u : 0u);
         }
     }
-    if (__ballot(flags & 1u) && (threadIdx.x & 63) == 0) atomicOr(out, 1u);
-    if (__ballot(flags & 2u) && (threadIdx.x & 63) == 0) atomicOr(out, 2u);
+    // one atomic per wave at most, and none once the word already holds the wave's bits: device-scope atomics
+    // on one word serialise across XCDs (~80 ns each), and a colour photograph sets bit 1 in every wave
+    const uint32_t wave_flags = (__ballot(flags & 1u) ? 1u : 0u) | (__ballot(flags & 2u) ? 2u : 0u);
+    if (wave_flags && (threadIdx.x & 63) == 0) {
+        const uint32_t seen = __atomic_load_n(out, __ATOMIC_RELAXED);   // stale reads only cost an extra atomic
+        if ((seen & wave_flags) != wave_flags) atomicOr(out, wave_flags);
+    }
 }
 
 // d_flags (device, one uint32): bit 0 = some alpha != 255, bit 1 = some pixel not grey
