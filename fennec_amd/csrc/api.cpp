@@ -1,4 +1,6 @@
 // fnx_* entry points: argument checks, host<->device staging, table upload, kernel launches.
+#include <atomic>
+#include <limits>
 #include <cmath>
 
 #include "common.hpp"
@@ -97,17 +99,47 @@ int ssim_fast_device(fnx_ctx *ctx, int n, const uint8_t *a, const uint8_t *const
 
 // n doubles the result kernels write into: pinned host memory mapped into the device's address
 // space, so that a blocking entry point only has to wait for the stream (result_wait) -- no D2H copy
+// The slots start out as NaN (no SSIM value is one: the denominators are >= C1*C2 > 0): the host can then
+// watch them fill instead of waiting for the runtime's completion signal (poll_results).
 int result_slot(fnx_ctx *ctx, int n, double **d)
 {
     void *p = nullptr;
     FNX_TRY(pinned_alloc(ctx, sizeof(double) * static_cast<size_t>(n > 16 ? n : 16), &p));
     *d = static_cast<double *>(p);
+    for (int i = 0; i < n; i++) (*d)[i] = std::numeric_limits<double>::quiet_NaN();
     return FNX_OK;
+}
+
+// Wait until the n result slots hold values.  The result kernels are the last work of a call and write
+// straight into (uncached) pinned host memory, so the values arrive a PCIe write after the kernel stores
+// them, while hipStreamSynchronize / hipEventSynchronize return 10-20 us later; the stream (or the event)
+// is still queried now and then, which also ends the wait if a value really is NaN or the GPU faulted.
+template <typename Done>
+int poll_results(const double *pinned, int n, Done done)
+{
+    const volatile double *v = pinned;
+    for (unsigned spin = 1;; spin++) {
+        bool all = true;
+        for (int i = 0; i < n; i++) {
+            const double x = v[i];
+            if (x != x) { all = false; break; }
+        }
+        if (all) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return FNX_OK;
+        }
+        if ((spin & 127u) == 0) {
+            const hipError_t q = done();
+            if (q == hipSuccess) return FNX_OK;
+            if (q != hipErrorNotReady) FNX_HIP(q);
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 int result_wait(fnx_ctx *ctx, const double *pinned, double *out, int n)
 {
-    FNX_HIP(hipStreamSynchronize(ctx->stream));
+    FNX_TRY(poll_results(pinned, n, [&] { return hipStreamQuery(ctx->stream); }));
     std::memcpy(out, pinned, sizeof(double) * size_t(n));
     return FNX_OK;
 }
@@ -376,7 +408,7 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
     FNX_REQUIRE(n >= 0 && out, "fetch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(ctx->res_pinned && ctx->res_event && n <= ctx->res_n, "no enqueued results of that size on this ctx");
-    FNX_HIP(hipEventSynchronize(ctx->res_event));
+    FNX_TRY(poll_results(ctx->res_pinned, n, [&] { return hipEventQuery(ctx->res_event); }));
     std::memcpy(out, ctx->res_pinned, sizeof(double) * size_t(n));
     return FNX_OK;
 }
