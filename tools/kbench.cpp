@@ -1,6 +1,6 @@
 // kbench: kernel-level timing of the batched C-ABI entry points with HIP events on the ctx
 // stream (development tool; bench.py is the contract benchmark).
-//   kbench [what] [batch] [iters] [W] [H]   what = blur | ssim | both | single | onepass | overlap ...
+//   kbench [what] [batch] [iters] [W] [H]   what = blur | ssim | both | single | onepass | pipelined | overlap ...
 // Variants are selected inside the library with FNX_* environment variables.
 #include <hip/hip_runtime.h>
 
@@ -87,6 +87,35 @@ int main(int argc, char **argv)
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         printf("gaussian_blur_ssim_fast_batch  B=%d %dx%d: %.3f ms per call, %.2f us/img, %.0f MP/s (wall clock, %d calls), ssim[0]=%.9f\n", B, W, H,
                dt / iters * 1e3, dt / iters / B * 1e6, mp * B * iters / dt, iters, out[0]);
+    }
+    if (what == "pipelined") {   // config 2 from a C++ host with two steps in flight: step s+1 is enqueued on a second
+                                 // context (its own stream and destinations) before step s's scores are fetched
+        fnx_ctx *c2;
+        FK(fnx_ctx_create(0, &c2));
+        std::vector<uint8_t *> dsts2(B);
+        for (int k = 0; k < B; k++) {
+            void *o;
+            FK(fnx_malloc(c2, S, &o));
+            dsts2[k] = (uint8_t *)o;
+        }
+        fnx_ctx *cs[2] = {ctx, c2};
+        uint8_t *const *ds[2] = {dsts.data(), dsts2.data()};
+        auto enq = [&](int d) { FK(fnx_gaussian_blur_ssim_fast_batch_enqueue(cs[d], B, srcs.data(), W * 4, W, H, kern.data(), radius,
+                                                                               FNX_BLUR_FAST, ds[d], W * 4, win)); };
+        auto run = [&](int n) {
+            for (int s = 0; s <= n; s++) {
+                if (s < n) enq(s & 1);
+                if (s >= 1) FK(fnx_results_fetch(cs[(s - 1) & 1], B, out.data()));
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.3) run(4);
+        t0 = std::chrono::steady_clock::now();
+        run(iters);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("gaussian_blur_ssim_fast_batch, 2 steps in flight  B=%d %dx%d: %.3f ms per step, %.2f us/img, %.0f MP/s (wall clock, %d steps), ssim[0]=%.9f\n",
+               B, W, H, dt / iters * 1e3, dt / iters / B * 1e6, mp * B * iters / dt, iters, out[0]);
+        fnx_ctx_destroy(c2);
     }
     if (what == "blur" || what == "both")
         time_it("gaussian_blur_batch", [&] { FK(fnx_gaussian_blur_batch(ctx, B, srcs.data(), W * 4, W, H, kern.data(), radius, FNX_BLUR_FAST, dsts.data(), W * 4)); }, 2.0 * S);
