@@ -267,7 +267,8 @@ class Context:
         self._chk(self._lib.fnx_ctx_profile(self._h, 1 if enable else 0), "fnx_ctx_profile")
 
     def kernel_ms(self) -> float:
-        """Duration of the last bracketed blur_direct_kernel launch, in ms (waits for it)."""
+        """Duration, in ms, of the oldest bracketed kernel launch not read yet (waits for it): one call per
+        launch, in launch order."""
         ms = C.c_float(0.0)
         self._chk(self._lib.fnx_ctx_kernel_ms(self._h, C.byref(ms)), "fnx_ctx_kernel_ms")
         return float(ms.value)

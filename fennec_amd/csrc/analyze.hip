@@ -339,13 +339,10 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
         return FNX_ERR_INVALID;
     }
     pa.row_px = static_cast<int>(row_px);
-    if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
+    FNX_TRY(prof_begin(ctx));
     hipLaunchKernelGGL(analyze_pass_kernel, dim3(G, n), dim3(256), 0, ctx->stream, pa);
     FNX_HIP(hipGetLastError());
-    if (ctx->prof) {
-        FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
-        ctx->prof_valid = true;
-    }
+    FNX_TRY(prof_end(ctx));
     hipLaunchKernelGGL(analyze_finish_kernel, dim3(16, n), dim3(256), 0, ctx->stream, pa.hist_part, pa.bright_part,
                        pa.flag_part, G, d_res);
     FNX_HIP(hipGetLastError());

@@ -144,14 +144,29 @@ int result_wait(fnx_ctx *ctx, const double *pinned, double *out, int n)
     return FNX_OK;
 }
 
-// an event right behind the result kernels: fnx_results_fetch then never waits for work that was
-// queued on this stream after the batch
+// An event right behind the result kernels, and the batch joins the ctx's FIFO of unfetched results:
+// fnx_results_fetch then never waits for work that was queued on this stream after the batch.
 int publish_results(fnx_ctx *ctx, const double *pinned, int n)
 {
-    if (!ctx->res_event) FNX_HIP(hipEventCreateWithFlags(&ctx->res_event, hipEventDisableTiming));
-    FNX_HIP(hipEventRecord(ctx->res_event, ctx->stream));
-    ctx->res_pinned = pinned;
-    ctx->res_n = n;
+    if (ctx->res_count == fnx_ctx::RES_DEPTH) {
+        set_error("invalid argument: %d enqueued batches are waiting for fnx_results_fetch on this ctx", ctx->res_count);
+        return FNX_ERR_INVALID;
+    }
+    fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
+    if (!q.ev) FNX_HIP(hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+    FNX_HIP(hipEventRecord(q.ev, ctx->stream));
+    q.pinned = pinned;
+    q.n = n;
+    ctx->res_count++;
+    return FNX_OK;
+}
+
+int can_enqueue(fnx_ctx *ctx)
+{
+    if (ctx->res_count == fnx_ctx::RES_DEPTH) {
+        set_error("invalid argument: %d enqueued batches are waiting for fnx_results_fetch on this ctx", ctx->res_count);
+        return FNX_ERR_INVALID;
+    }
     return FNX_OK;
 }
 
@@ -398,6 +413,7 @@ int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astri
                         const double *window, double *out)
 {
     FNX_REQUIRE(out != nullptr, "out is null");
+    FNX_REQUIRE(ctx && ctx->res_count == 0, "enqueued batches are waiting for fnx_results_fetch: fetch them before a blocking batch call");
     FNX_TRY(fnx_ssim_fast_batch_enqueue(ctx, n, as, astride, bs, bstride, w, h, window));
     return fnx_results_fetch(ctx, n, out);
 }
@@ -407,9 +423,12 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
     FNX_TRY(bind(ctx));
     FNX_REQUIRE(n >= 0 && out, "fetch arguments");
     if (n == 0) return FNX_OK;
-    FNX_REQUIRE(ctx->res_pinned && ctx->res_event && n <= ctx->res_n, "no enqueued results of that size on this ctx");
-    FNX_TRY(poll_results(ctx->res_pinned, n, [&] { return hipEventQuery(ctx->res_event); }));
-    std::memcpy(out, ctx->res_pinned, sizeof(double) * size_t(n));
+    FNX_REQUIRE(ctx->res_count > 0 && n <= ctx->res_q[ctx->res_head].n, "no enqueued results of that size on this ctx");
+    fnx_ctx::Pending &q = ctx->res_q[ctx->res_head];            // oldest unfetched batch
+    FNX_TRY(poll_results(q.pinned, n, [&] { return hipEventQuery(q.ev); }));
+    std::memcpy(out, q.pinned, sizeof(double) * size_t(n));
+    ctx->res_head = (ctx->res_head + 1) % fnx_ctx::RES_DEPTH;
+    ctx->res_count--;
     return FNX_OK;
 }
 
@@ -421,6 +440,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     FNX_REQUIRE(n >= 0 && as && bs && window, "batch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0 && astride >= 4 * w && bstride >= 4 * w, "dims");
+    FNX_TRY(can_enqueue(ctx));
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
@@ -457,6 +477,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
     FNX_REQUIRE(w > 0 && h > 0, "dims");
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
     for (int i = 0; i < n; i++) FNX_REQUIRE(srcs[i] && dsts[i] && srcs[i] != dsts[i], "null image in batch, or dst aliases src (the blur is not in-place)");
+    FNX_TRY(can_enqueue(ctx));
     int nw, nh;
     const bool down = ssim_fast_dims(w, h, &nw, &nh);
     if (down && nw >= 8 && nh >= 8) {
@@ -492,6 +513,7 @@ int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const 
                                       uint8_t *const *dsts, int dstride, const double *window, double *out)
 {
     FNX_REQUIRE(out != nullptr, "out is null");
+    FNX_REQUIRE(ctx && ctx->res_count == 0, "enqueued batches are waiting for fnx_results_fetch: fetch them before a blocking batch call");
     FNX_TRY(fnx_gaussian_blur_ssim_fast_batch_enqueue(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts,
                                                       dstride, window));
     return fnx_results_fetch(ctx, n, out);

@@ -575,7 +575,7 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
-    if (ctx->prof) FNX_HIP(hipEventRecord(ctx->prof_ev[0], ctx->stream));
+    FNX_TRY(prof_begin(ctx));
     if constexpr (SCORE) {
         fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
         // LDS left per workgroup at 4 (256 lanes) / 7 (128 lanes) workgroups per CU, next to the uint8
@@ -592,10 +592,7 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
         hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false, 1, 1, GUARD>), grid, dim3(NTH), 0, ctx->stream, fa);
     }
     FNX_HIP(hipGetLastError());
-    if (ctx->prof) {
-        FNX_HIP(hipEventRecord(ctx->prof_ev[1], ctx->stream));
-        ctx->prof_valid = true;
-    }
+    FNX_TRY(prof_end(ctx));
     return FNX_OK;
 }
 

@@ -88,15 +88,22 @@ struct fnx_ctx {
     unsigned char *pinned = nullptr;
     size_t pinned_cap = 0, pinned_off = 0;
     int num_cus = 256;
-    // results of the last *_enqueue call: copied to pinned memory right behind the kernels, so a
-    // later fetch waits for THIS event only, not for work queued on the stream afterwards
-    hipEvent_t res_event = nullptr;
-    // fnx_ctx_profile: events around the last blur_direct_kernel launch
+    // results of the *_enqueue calls not fetched yet, oldest first: each batch has its own pinned slots and
+    // an event right behind its result kernels, so a fetch waits for THAT batch only and a caller may queue
+    // the next batch before fetching this one (the stream never drains between steps)
+    static constexpr int RES_DEPTH = 4;
+    struct Pending {
+        const double *pinned = nullptr;
+        int n = 0;
+        hipEvent_t ev = nullptr;
+    } res_q[RES_DEPTH];
+    int res_head = 0, res_count = 0;
     fnx::ScoreGeom score_geom;
-    bool prof = false, prof_valid = false;
-    hipEvent_t prof_ev[2] = {nullptr, nullptr};
-    const double *res_pinned = nullptr;
-    int res_n = 0;
+    // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
+    static constexpr int PROF_DEPTH = 4;
+    bool prof = false;
+    hipEvent_t prof_ev[PROF_DEPTH][2] = {};
+    int prof_head = 0, prof_count = 0, prof_open = -1;
 };
 
 struct fnx_prepared {
@@ -144,6 +151,9 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
               DevOut *out);
 // Copy a staged output back (if host) and synchronise when `space` is host.
 int finish(fnx_ctx *ctx, int space, DevOut *out);
+// fnx_ctx_profile hooks: bracket the launch of a profiled kernel (no-ops when profiling is off)
+int prof_begin(fnx_ctx *ctx);
+int prof_end(fnx_ctx *ctx);
 // Fetch n doubles from device memory into host memory (synchronises).
 int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n);
 int fetch_bytes(fnx_ctx *ctx, const void *dptr, void *host, size_t bytes);

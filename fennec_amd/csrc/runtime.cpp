@@ -106,6 +106,27 @@ int upload_table(fnx_ctx *ctx, Slot slot, const void *host, size_t bytes, void *
     return upload_tables(ctx, slot, &host, &bytes, 1, dptr);
 }
 
+int prof_begin(fnx_ctx *ctx)
+{
+    if (!ctx->prof) return FNX_OK;
+    if (ctx->prof_count == fnx_ctx::PROF_DEPTH) {          // nobody is reading: forget the oldest launch
+        ctx->prof_head = (ctx->prof_head + 1) % fnx_ctx::PROF_DEPTH;
+        ctx->prof_count--;
+    }
+    ctx->prof_open = (ctx->prof_head + ctx->prof_count) % fnx_ctx::PROF_DEPTH;
+    FNX_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_open][0], ctx->stream));
+    return FNX_OK;
+}
+
+int prof_end(fnx_ctx *ctx)
+{
+    if (!ctx->prof || ctx->prof_open < 0) return FNX_OK;
+    FNX_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_open][1], ctx->stream));
+    ctx->prof_open = -1;
+    ctx->prof_count++;
+    return FNX_OK;
+}
+
 int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
              DevImg *out)
 {
@@ -241,9 +262,11 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
         for (auto &s : ctx->slot)
             if (s.p) (void)hipFree(s.p);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        if (ctx->res_event) (void)hipEventDestroy(ctx->res_event);
-        for (auto &e : ctx->prof_ev)
-            if (e) (void)hipEventDestroy(e);
+        for (auto &q : ctx->res_q)
+            if (q.ev) (void)hipEventDestroy(q.ev);
+        for (auto &pair : ctx->prof_ev)
+            for (auto &e : pair)
+                if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;
@@ -255,19 +278,24 @@ int fnx_ctx_profile(fnx_ctx *ctx, int enable)
 {
     FNX_TRY(bind(ctx));
     if (enable)
-        for (auto &e : ctx->prof_ev)
-            if (!e) FNX_HIP(hipEventCreate(&e));
+        for (auto &pair : ctx->prof_ev)
+            for (auto &e : pair)
+                if (!e) FNX_HIP(hipEventCreate(&e));
     ctx->prof = enable != 0;
-    ctx->prof_valid = false;
+    ctx->prof_head = ctx->prof_count = 0;      // (re-)enabling forgets unread launches
+    ctx->prof_open = -1;
     return FNX_OK;
 }
 
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms)
 {
     FNX_TRY(bind(ctx));
-    FNX_REQUIRE(ms != nullptr && ctx->prof_valid, "no profiled kernel launch on this ctx");
-    FNX_HIP(hipEventSynchronize(ctx->prof_ev[1]));
-    FNX_HIP(hipEventElapsedTime(ms, ctx->prof_ev[0], ctx->prof_ev[1]));
+    FNX_REQUIRE(ms != nullptr && ctx->prof_count > 0, "no unread profiled kernel launch on this ctx");
+    hipEvent_t *pair = ctx->prof_ev[ctx->prof_head];
+    FNX_HIP(hipEventSynchronize(pair[1]));
+    FNX_HIP(hipEventElapsedTime(ms, pair[0], pair[1]));
+    ctx->prof_head = (ctx->prof_head + 1) % fnx_ctx::PROF_DEPTH;
+    ctx->prof_count--;
     return FNX_OK;
 }
 

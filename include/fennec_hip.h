@@ -92,9 +92,10 @@ void *fnx_ctx_stream(fnx_ctx *ctx);
 int fnx_ctx_sync(fnx_ctx *ctx);
 /* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of a
  * call's dominant kernel (GaussianBlur fast path: blur_direct_kernel; Analyze:
- * analyze_pass_kernel) with a pair of HIP events on its stream.  fnx_ctx_kernel_ms waits for
- * the last bracketed launch and returns its duration in milliseconds (FNX_ERR_INVALID if none
- * was recorded). */
+ * analyze_pass_kernel) with a pair of HIP events on its stream.  fnx_ctx_kernel_ms waits for the
+ * OLDEST bracketed launch not read yet and returns its duration in milliseconds -- one call per
+ * launch, in launch order; the last 4 launches are kept (FNX_ERR_INVALID if none is unread).
+ * fnx_ctx_profile(ctx, 1) also forgets the unread ones. */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
 
@@ -187,10 +188,12 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
 int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
                         const uint8_t *const *bs, int bstride, int w, int h,
                         const double *window, double *out /* n, host */);
-/* The same split in two so that several contexts (= streams) can be kept busy by one host
- * thread: _enqueue only queues the kernels, the n results stay on the device until
- * fnx_results_fetch (which synchronises the ctx).  Fetch before enqueuing the next batch on the
- * SAME ctx. */
+/* The same split in two, so that one host thread can keep several contexts (= streams) busy, or keep
+ * ONE stream from draining between batches: _enqueue only queues the kernels; the n results land in
+ * pinned host memory and wait in the ctx's FIFO (up to 4 batches) until fnx_results_fetch takes the
+ * OLDEST one (it waits for that batch only, not for work queued behind it).  Enqueueing batch s+1 before
+ * fetching batch s is the intended use; the kernels of a ctx still run in order.  The blocking forms
+ * require an empty FIFO. */
 int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride,
                                 const uint8_t *const *bs, int bstride, int w, int h,
                                 const double *window);

@@ -887,6 +887,44 @@ def test_device_source_host_destination(orc):
     c.close()
 
 
+def test_enqueue_ahead_fifo(ctx, orc):
+    """Several batches enqueued on ONE ctx before any is fetched: fnx_results_fetch hands them back oldest
+    first, each with its own scores; a fifth waiting batch and a blocking call over a non-empty FIFO are
+    refused; the profile hook reads its launches in the same order."""
+    import torch
+    c = fennec_amd.Context(0)
+    sets = [[synth.large_photo(2048, 1200, 10 * j + k) for k in range(3)] for j in range(4)]
+    dev = [[torch.from_numpy(i).cuda() for i in st] for st in sets]
+    torch.cuda.synchronize()
+    plans = [c.plan_blur_ssim_fast_batch(d, 2.0) for d in dev]
+    want = [c.GaussianBlurSSIMFastBatch(d, 2.0)[1] for d in dev]          # one at a time
+    c.profile(True)
+    for p in plans:
+        p.enqueue()
+    with pytest.raises(fennec_amd.FennecError):
+        plans[0].enqueue()                                                # four batches are waiting
+    with pytest.raises(fennec_amd.FennecError):
+        c.GaussianBlurSSIMFastBatch(dev[0], 2.0)                          # blocking form over a non-empty FIFO
+    for j, p in enumerate(plans):
+        assert np.array_equal(p.fetch(), want[j]), j
+        assert c.kernel_ms() > 0
+    with pytest.raises(fennec_amd.FennecError):
+        plans[0].fetch()                                                  # nothing left
+    with pytest.raises(fennec_amd.FennecError):
+        c.kernel_ms()
+    # two-call flavour, interleaved with fetches
+    outs = [c.GaussianBlurBatch(d, 2.0) for d in dev[:2]]
+    ps = [c.plan_ssim_fast_batch(d, o) for d, o in zip(dev[:2], outs)]
+    ps[0].enqueue(); ps[1].enqueue()
+    a0 = ps[0].fetch().copy()
+    ps[0].enqueue()
+    a1 = ps[1].fetch().copy()
+    a2 = ps[0].fetch().copy()
+    assert np.array_equal(a0, a2) and np.array_equal(a0, want[0]) and np.array_equal(a1, want[1])
+    assert abs(a1[2] - orc.ssim_fast(sets[1][2], outs[1][2].cpu().numpy(), procs=8)) <= SSIM_TOL
+    c.close()
+
+
 def test_argument_errors_and_context_lifecycle(orc):
     """bad arguments come back as FennecError with the library's message (never a crash, never a silent
     fallback); contexts can be created and destroyed in a loop without leaking device memory"""
