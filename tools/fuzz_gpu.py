@@ -36,7 +36,8 @@ def rand_image(w, h):
 
 def blur_close(got, want):
     d = np.abs(got.astype(np.int16) - want.astype(np.int16))
-    return d.max() <= 1 and float((d[..., :3] != 0).mean()) <= 1e-3 and np.array_equal(got[..., 3], want[..., 3])
+    n_off = int((d[..., :3] != 0).sum())        # <= 0.1 % of samples; tiny images: <= 3 samples (a rate needs a population)
+    return d.max() <= 1 and n_off <= max(3, 1e-3 * d[..., :3].size) and np.array_equal(got[..., 3], want[..., 3])
 
 
 def case(name, ok, desc):
