@@ -40,6 +40,7 @@ LIB_PATH = os.environ.get("FENNEC_HIP_LIB") or os.path.join(_HERE, "libfennec_hi
 FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
 FNX_HOST, FNX_DEVICE, FNX_DEVICE_SRC = 0, 1, 2
 FNX_BLUR_FAST, FNX_BLUR_EXACT = 0, 1
+PROF_MAIN, PROF_SSIM, PROF_RESIZE, PROF_FX = 1, 2, 4, 8
 
 _u8p = C.c_void_p
 _f64p = C.POINTER(C.c_double)
@@ -262,9 +263,10 @@ class Context:
     def sync(self):
         self._chk(self._lib.fnx_ctx_sync(self._h), "fnx_ctx_sync")
 
-    def profile(self, enable: bool = True):
-        """Bracket every blur_direct_kernel launch with HIP events (fnx_ctx_profile)."""
-        self._chk(self._lib.fnx_ctx_profile(self._h, 1 if enable else 0), "fnx_ctx_profile")
+    def profile(self, enable=True):
+        """Bracket kernel launches with HIP events (fnx_ctx_profile).  True / 1: the blur / analyze pass
+        kernels; or a mask of PROF_MAIN | PROF_SSIM | PROF_RESIZE | PROF_FX."""
+        self._chk(self._lib.fnx_ctx_profile(self._h, int(enable)), "fnx_ctx_profile")
 
     def kernel_ms(self) -> float:
         """Duration, in ms, of the oldest bracketed kernel launch not read yet (waits for it): one call per
@@ -276,6 +278,54 @@ class Context:
     @property
     def stream(self) -> int:
         return int(self._lib.fnx_ctx_stream(self._h) or 0)
+
+    # -- ordering against torch's streams ---------------------------------------------------
+    # Device-space calls only ENQUEUE on the ctx's private (non-blocking) HIP stream.  torch knows nothing
+    # about that stream: inputs may still be being written on torch's current stream, outputs would be
+    # read by torch before the kernels have run, and the caching allocator could hand a dropped tensor's
+    # memory out again while ctx-stream kernels still use it.  Every method that takes device tensors
+    # therefore runs inside `_ordered(...)`:
+    #   before: the ctx stream waits for everything already queued on torch's current stream;
+    #   after : torch's current stream waits for the ctx stream, and every tensor involved is
+    #           record_stream()ed on the ctx stream (the allocator will not recycle it early).
+    # Host (numpy) calls are synchronous and skip all of this.
+    def _ext_stream(self):
+        import torch
+        ext = getattr(self, "_ext", None)
+        if ext is None:
+            ext = self._ext = torch.cuda.ExternalStream(self.stream, device=torch.device("cuda", self.device))
+        return ext
+
+    class _Ordered:
+        __slots__ = ("ctx", "tensors", "cur", "ext")
+
+        def __init__(self, ctx, tensors):
+            self.ctx = ctx
+            self.cur = self.ext = None
+            self.tensors = [t for t in tensors if _is_torch(t) and t.is_cuda]
+
+        def __enter__(self):
+            if self.tensors:
+                import torch
+                self.ext = self.ctx._ext_stream()
+                self.cur = torch.cuda.current_stream(self.tensors[0].device)
+                if self.cur.cuda_stream != self.ext.cuda_stream:
+                    self.ext.wait_stream(self.cur)
+            return self
+
+        def add(self, *tensors):
+            """Outputs allocated inside the block (they need the same allocator / ordering care)."""
+            self.tensors.extend(t for t in tensors if _is_torch(t) and t.is_cuda)
+
+        def __exit__(self, *exc):
+            if self.tensors and getattr(self, "cur", None) is not None and self.cur.cuda_stream != self.ext.cuda_stream:
+                self.cur.wait_stream(self.ext)
+                for t in self.tensors:
+                    t.record_stream(self.ext)
+            return False
+
+    def _ordered(self, *tensors):
+        return Context._Ordered(self, tensors)
 
     def _pair(self, a, b):
         ia, ib = _Img(a), _Img(b)
@@ -319,24 +369,27 @@ class Context:
         """ssim.go:24 -- full-resolution SSIM; a differently sized img2 is Lanczos-resized."""
         a, b = self._pair(img1, img2)
         out = C.c_double()
-        self._chk(self._lib.fennec_SSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
-                                        b.w, b.h, C.byref(out)), "SSIM")
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fennec_SSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
+                                            b.w, b.h, C.byref(out)), "SSIM")
         return out.value
 
     def SSIMFast(self, img1, img2) -> float:
         """ssim.go:48 -- SSIM on <=512 px box-downsampled copies."""
         a, b = self._pair(img1, img2)
         out = C.c_double()
-        self._chk(self._lib.fennec_SSIMFast(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h,
-                                            C.byref(out)), "SSIMFast")
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fennec_SSIMFast(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h,
+                                                C.byref(out)), "SSIMFast")
         return out.value
 
     def MSSSIM(self, img1, img2) -> float:
         """ssim.go:313 -- 5-level multi-scale SSIM."""
         a, b = self._pair(img1, img2)
         out = C.c_double()
-        self._chk(self._lib.fennec_MSSSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
-                                          b.w, b.h, C.byref(out)), "MSSSIM")
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fennec_MSSSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
+                                              b.w, b.h, C.byref(out)), "MSSSIM")
         return out.value
 
     def msssim_levels(self, img1, img2, window=None):
@@ -345,8 +398,9 @@ class Context:
         k, pk = _f64(self.gaussianKernel() if window is None else window)
         out = C.c_double()
         lv = np.empty(5, dtype=np.float64)
-        self._chk(self._lib.fnx_msssim(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h, pk,
-                                       C.byref(out), lv.ctypes.data_as(_f64p)), "fnx_msssim")
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fnx_msssim(self._h, a.space, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h, pk,
+                                           C.byref(out), lv.ctypes.data_as(_f64p)), "fnx_msssim")
         return out.value, lv
 
     def boxDownsample(self, img, dstW: int, dstH: int, to_host: bool = False):
@@ -358,8 +412,9 @@ class Context:
             return self._out_for(s, 0, 0, to_host)[1]
         space, dst = self._out_for(s, dstW, dstH, to_host)
         d = _Img(dst)
-        self._chk(self._lib.fennec_boxDownsample(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
-                                                 d.stride, dstW, dstH), "boxDownsample")
+        with self._ordered(img, dst):
+            self._chk(self._lib.fennec_boxDownsample(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
+                                                     d.stride, dstW, dstH), "boxDownsample")
         return dst
 
     @staticmethod
@@ -372,8 +427,9 @@ class Context:
     def ssim_fast_prepare(self, img):
         s = _Img(img)
         p = C.c_void_p()
-        self._chk(self._lib.fnx_ssim_fast_prepare(self._h, s.space, s.ptr, s.stride, s.w, s.h, C.byref(p)),
-                  "fnx_ssim_fast_prepare")
+        with self._ordered(img):
+            self._chk(self._lib.fnx_ssim_fast_prepare(self._h, s.space, s.ptr, s.stride, s.w, s.h, C.byref(p)),
+                      "fnx_ssim_fast_prepare")
         return _Prepared(self, p, s.w, s.h)
 
     # -- effects.go ---------------------------------------------------------------------
@@ -386,18 +442,19 @@ class Context:
         s = _Img(img)
         dst = s.like(s.w, s.h)
         d = _Img(dst)
-        if kernel is None and exact is None:
-            rc = self._lib.fennec_GaussianBlur(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(sigma),
-                                               d.ptr, d.stride)
-        else:
-            if kernel is None:
-                radius, kernel = self.blurKernel(sigma)
+        with self._ordered(img, dst):
+            if kernel is None and exact is None:
+                rc = self._lib.fennec_GaussianBlur(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(sigma),
+                                                   d.ptr, d.stride)
             else:
-                radius = (len(kernel) - 1) // 2
-            k, pk = _f64(kernel)
-            rc = self._lib.fnx_gaussian_blur(self._h, s.space, s.ptr, s.stride, s.w, s.h, pk, radius,
-                                             FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, d.ptr, d.stride)
-        self._chk(rc, "GaussianBlur")
+                if kernel is None:
+                    radius, kernel = self.blurKernel(sigma)
+                else:
+                    radius = (len(kernel) - 1) // 2
+                k, pk = _f64(kernel)
+                rc = self._lib.fnx_gaussian_blur(self._h, s.space, s.ptr, s.stride, s.w, s.h, pk, radius,
+                                                 FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, d.ptr, d.stride)
+            self._chk(rc, "GaussianBlur")
         return dst
 
     def blur3x3(self, img):
@@ -405,14 +462,16 @@ class Context:
         s = _Img(img)
         dst = s.like(s.w, s.h)
         d = _Img(dst)
-        self._chk(self._lib.fnx_blur3x3(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr, d.stride), "blur3x3")
+        with self._ordered(img, dst):
+            self._chk(self._lib.fnx_blur3x3(self._h, s.space, s.ptr, s.stride, s.w, s.h, d.ptr, d.stride), "blur3x3")
         return dst
 
     def _sharpen(self, fn, name, img, strength):
         s = _Img(img)
         dst = s.like(s.w, s.h)
         d = _Img(dst)
-        rc = self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(strength), d.ptr, d.stride), name)
+        with self._ordered(img, dst):
+            rc = self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(strength), d.ptr, d.stride), name)
         return img if rc == FNX_NOOP else dst
 
     def Sharpen(self, img, strength: float):
@@ -431,8 +490,9 @@ class Context:
             return self._out_for(s, 0, 0, to_host)[1]
         space, dst = self._out_for(s, dstW, dstH, to_host)
         d = _Img(dst)
-        self._chk(self._lib.fennec_lanczosResize(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
-                                                 d.stride, dstW, dstH), "lanczosResize")
+        with self._ordered(img, dst):
+            self._chk(self._lib.fennec_lanczosResize(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
+                                                     d.stride, dstW, dstH), "lanczosResize")
         return dst
 
     def smartResize(self, img, maxW: int, maxH: int):
@@ -450,8 +510,9 @@ class Context:
         dst = s.like(s.w, dst_size) if vertical else s.like(dst_size, s.h)
         d = _Img(dst)
         fn = self._lib.fnx_resize_v if vertical else self._lib.fnx_resize_h
-        self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, po, pi, pw, d.ptr, d.stride, dst_size),
-                  "resize_pass")
+        with self._ordered(img, dst):
+            self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, po, pi, pw, d.ptr, d.stride, dst_size),
+                      "resize_pass")
         return dst
 
     # -- exif.go ------------------------------------------------------------------------
@@ -464,8 +525,9 @@ class Context:
         ow, oh = (s.h, s.w) if orient >= 5 else (s.w, s.h)
         dst = s.like(ow, oh)
         d = _Img(dst)
-        self._chk(self._lib.fennec_ApplyOrientation(self._h, s.space, s.ptr, s.stride, s.w, s.h, orient,
-                                                    d.ptr, d.stride), "ApplyOrientation")
+        with self._ordered(img, dst):
+            self._chk(self._lib.fennec_ApplyOrientation(self._h, s.space, s.ptr, s.stride, s.w, s.h, orient,
+                                                        d.ptr, d.stride), "ApplyOrientation")
         return dst
 
     # -- Analyze (analyze.go) ---------------------------------------------------------------
@@ -483,21 +545,21 @@ class Context:
         """Analyze (analyze.go:26-124) -> dict with the ImageStats field names."""
         v = _Img(img)
         st = ImageStats()
-        self._chk(self._lib.fennec_Analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(st)), "Analyze")
+        with self._ordered(img):
+            self._chk(self._lib.fennec_Analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(st)), "Analyze")
         return self._stats_dict(st)
 
     def analyze_raw(self, img) -> dict:
         """fnx_analyze: the device-side accumulators (histogram, sums, counts)."""
         v = _Img(img)
         a = Analysis()
-        self._chk(self._lib.fnx_analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(a)), "fnx_analyze")
+        with self._ordered(img):
+            self._chk(self._lib.fnx_analyze(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(a)), "fnx_analyze")
         return self._analysis_dict(a)
 
     def plan_analyze_batch(self, imgs):
         """Pre-marshalled fnx_analyze_batch over n same-sized device images: run() -> list of ImageStats dicts."""
-        views = [_Img(t) for t in imgs]
-        if any(v.space != FNX_DEVICE for v in views):
-            raise FennecError("batched ops take device tensors")
+        views = self._batch_views(imgs)
         n, w, h, st = len(views), views[0].w, views[0].h, views[0].stride
         srcs = (C.c_void_p * n)(*[v.ptr for v in views])
         res = (Analysis * n)()
@@ -529,13 +591,15 @@ class Context:
     def isOpaque(self, img) -> bool:
         v = _Img(img)
         o = C.c_int(0)
-        self._chk(self._lib.fennec_isOpaque(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isOpaque")
+        with self._ordered(img):
+            self._chk(self._lib.fennec_isOpaque(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isOpaque")
         return bool(o.value)
 
     def isGrayscale(self, img) -> bool:
         v = _Img(img)
         o = C.c_int(0)
-        self._chk(self._lib.fennec_isGrayscale(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isGrayscale")
+        with self._ordered(img):
+            self._chk(self._lib.fennec_isGrayscale(self._h, v.space, v.ptr, v.stride, v.w, v.h, C.byref(o)), "isGrayscale")
         return bool(o.value)
 
     @staticmethod
@@ -563,8 +627,9 @@ class Context:
         else:
             dst = np.empty((h, w, 4), dtype=np.uint8)
         d = _Img(dst)
-        self._chk(self._lib.fnx_ycbcr_to_nrgba(self._h, space, yp, ys, cbp, crp, cs, int(ratio), w, h, d.ptr, d.stride),
-                  "ycbcrToNRGBA")
+        with self._ordered(y, cb, cr, dst):
+            self._chk(self._lib.fnx_ycbcr_to_nrgba(self._h, space, yp, ys, cbp, crp, cs, int(ratio), w, h, d.ptr, d.stride),
+                      "ycbcrToNRGBA")
         return dst
 
     def applyPalette(self, img, palette, want_quantized: bool = True):
@@ -581,31 +646,56 @@ class Context:
             iptr, istride = idx.ctypes.data, v.w
         q = v.like(v.w, v.h) if want_quantized else None
         qv = _Img(q) if want_quantized else None
-        self._chk(self._lib.fnx_apply_palette(self._h, v.space, v.ptr, v.stride, v.w, v.h, pal.ctypes.data, len(pal),
-                                              iptr, istride, qv.ptr if qv else None, qv.stride if qv else 0),
-                  "applyPalette")
+        with self._ordered(img, idx, q):
+            self._chk(self._lib.fnx_apply_palette(self._h, v.space, v.ptr, v.stride, v.w, v.h, pal.ctypes.data, len(pal),
+                                                  iptr, istride, qv.ptr if qv else None, qv.stride if qv else 0),
+                      "applyPalette")
         return idx, q
 
     # -- batched forms (device tensors) ---------------------------------------------------
+    # Contract of the plan_* objects: creating a plan synchronises torch's current stream once (the inputs
+    # exist from then on); run() / enqueue() only touch the ctx stream, fetch() / run() of the scoring plans
+    # block until the results -- and therefore every kernel queued before them -- are complete.  A caller
+    # that rewrites the input tensors with torch between two runs must order that itself (ctx.sync() /
+    # torch.cuda.synchronize()).  The convenience wrappers (GaussianBlurBatch, ...) order both ways.
+    @staticmethod
+    def _batch_views(imgs, what="images"):
+        """_Img views of n device tensors that share (w, h, stride, device); raises FennecError otherwise."""
+        views = [_Img(t) for t in imgs]
+        if not views:
+            raise FennecError(f"{what}: empty batch")
+        if any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("batched ops take device tensors")
+        v0 = views[0]
+        for k, v in enumerate(views):
+            if (v.w, v.h, v.stride) != (v0.w, v0.h, v0.stride) or v.obj.device != v0.obj.device:
+                raise FennecError(f"{what}[{k}]: every image of a batch must share width, height, stride and device "
+                                  f"(got {v.w}x{v.h} stride {v.stride} on {v.obj.device}, "
+                                  f"expected {v0.w}x{v0.h} stride {v0.stride} on {v0.obj.device})")
+        import torch
+        torch.cuda.current_stream(v0.obj.device).synchronize()
+        return views
+
     def GaussianBlurBatch(self, imgs, sigma: float, outs=None, exact: bool = False):
         """n same-sized device images, one launch per stage (enqueued; call sync() to wait)."""
         if sigma <= 0:
             return list(imgs)
         plan = self.plan_blur_batch(imgs, sigma, outs=outs, exact=exact)
-        plan.run()
+        with self._ordered(*imgs, *plan.outs):
+            plan.run()
         return plan.outs
 
     def plan_blur_batch(self, imgs, sigma: float, outs=None, exact: bool = False):
         """Pre-marshal a batched blur (pointer tables, kernel) so that run() is one C call --
         lets a caller bracket the launch tightly with events."""
-        views = [_Img(t) for t in imgs]
-        if any(v.space != FNX_DEVICE for v in views):
-            raise FennecError("batched ops take device tensors")
+        views = self._batch_views(imgs)
         w, h, st = views[0].w, views[0].h, views[0].stride
         if outs is None:
             outs = [views[0].like(w, h) for _ in views]
-        oviews = [_Img(t) for t in outs]
+        oviews = self._batch_views(outs, "outs")
         n = len(views)
+        if len(oviews) != n or (oviews[0].w, oviews[0].h) != (w, h):
+            raise FennecError("outs must hold one image of the inputs' size per input")
         srcs = (C.c_void_p * n)(*[v.ptr for v in views])
         dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
         radius, kernel = self.blurKernel(sigma)
@@ -625,11 +715,11 @@ class Context:
 
     def plan_ssim_fast_batch(self, imgs_a, imgs_b, window=None):
         """Pre-marshalled SSIMFastBatch: run() -> numpy array of n SSIM values (synchronises)."""
-        va = [_Img(t) for t in imgs_a]
-        vb = [_Img(t) for t in imgs_b]
+        va = self._batch_views(imgs_a, "imgs_a")
+        vb = self._batch_views(imgs_b, "imgs_b")
         n = len(va)
-        if n != len(vb) or any(v.space != FNX_DEVICE for v in va + vb):
-            raise FennecError("batched ops take two equally long lists of device tensors")
+        if n != len(vb) or (va[0].w, va[0].h) != (vb[0].w, vb[0].h):
+            raise FennecError("batched ops take two equally long lists of equally sized device tensors")
         as_ = (C.c_void_p * n)(*[v.ptr for v in va])
         bs_ = (C.c_void_p * n)(*[v.ptr for v in vb])
         k, pk = _f64(self.gaussianKernel() if window is None else window)
@@ -667,14 +757,14 @@ class Context:
         blurKernel(sigma) with a caller-supplied odd-length 1-D kernel."""
         if sigma <= 0:
             raise FennecError("sigma <= 0 returns the source itself (effects.go:147): nothing to plan")
-        views = [_Img(t) for t in imgs]
-        if any(v.space != FNX_DEVICE for v in views):
-            raise FennecError("batched ops take device tensors")
+        views = self._batch_views(imgs)
         w, h, st = views[0].w, views[0].h, views[0].stride
         if outs is None:
             outs = [views[0].like(w, h) for _ in views]
-        oviews = [_Img(t) for t in outs]
+        oviews = self._batch_views(outs, "outs")
         n = len(views)
+        if len(oviews) != n or (oviews[0].w, oviews[0].h) != (w, h):
+            raise FennecError("outs must hold one image of the inputs' size per input")
         srcs = (C.c_void_p * n)(*[v.ptr for v in views])
         dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
         if kernel is None:
@@ -715,7 +805,9 @@ class Context:
                                   kernel=None):
         """-> (blurred images, numpy array of SSIMFast(imgs[i], blurred[i]))."""
         plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window, kernel=kernel)
-        return plan.outs, plan.run().copy()
+        with self._ordered(*imgs, *plan.outs):
+            vals = plan.run().copy()
+        return plan.outs, vals
 
 
 class _Prepared:
@@ -730,8 +822,9 @@ class _Prepared:
             raise FennecError("candidate dims differ from the prepared reference")
         k, pk = _f64(self._ctx.gaussianKernel() if window is None else window)
         out = C.c_double()
-        self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against(self._ctx._h, self._p, s.space, s.ptr, s.stride,
-                                                            pk, C.byref(out)), "fnx_ssim_fast_against")
+        with self._ctx._ordered(img):
+            self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against(self._ctx._h, self._p, s.space, s.ptr, s.stride,
+                                                                pk, C.byref(out)), "fnx_ssim_fast_against")
         return out.value
 
     def against_ycbcr(self, y, cb, cr, ratio: int, window=None) -> float:
@@ -741,8 +834,9 @@ class _Prepared:
             raise FennecError("candidate dims differ from the prepared reference")
         k, pk = _f64(self._ctx.gaussianKernel() if window is None else window)
         out = C.c_double(0.0)
-        self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against_ycbcr(self._ctx._h, self._p, space, yp, ys, cbp, crp, cs,
-                                                                  int(ratio), pk, C.byref(out)), "against_ycbcr")
+        with self._ctx._ordered(y, cb, cr):
+            self._ctx._chk(self._ctx._lib.fnx_ssim_fast_against_ycbcr(self._ctx._h, self._p, space, yp, ys, cbp, crp, cs,
+                                                                      int(ratio), pk, C.byref(out)), "against_ycbcr")
         return float(out.value)
 
     def close(self):

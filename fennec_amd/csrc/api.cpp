@@ -110,6 +110,26 @@ int result_slot(fnx_ctx *ctx, int n, double **d)
     return FNX_OK;
 }
 
+// Result slots of an *_enqueue call: the batch's OWN pinned buffer (one per FIFO position), so that nothing
+// a later call does to the pinned ring (growth frees it, wrap-around reuses it) can touch results that were
+// enqueued and not fetched yet.  The position's buffer is free by construction: can_enqueue() has checked
+// res_count < RES_DEPTH, and a fetched batch has been copied out.
+int result_slot_queued(fnx_ctx *ctx, int n, double **d)
+{
+    fnx_ctx::ResBuf &rb = ctx->res_buf[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
+    const size_t need = sizeof(double) * static_cast<size_t>(n > 16 ? n : 16);
+    if (need > rb.cap) {
+        if (rb.p) FNX_HIP(hipHostFree(rb.p));
+        rb.p = nullptr;
+        rb.cap = 0;
+        FNX_HIP(hipHostMalloc(reinterpret_cast<void **>(&rb.p), need * 2, hipHostMallocDefault));
+        rb.cap = need * 2;
+    }
+    *d = rb.p;
+    for (int i = 0; i < n; i++) (*d)[i] = std::numeric_limits<double>::quiet_NaN();
+    return FNX_OK;
+}
+
 // Wait until the n result slots hold values.  The result kernels are the last work of a call and write
 // straight into (uncached) pinned host memory, so the values arrive a PCIe write after the kernel stores
 // them, while hipStreamSynchronize / hipEventSynchronize return 10-20 us later; the stream (or the event)
@@ -183,6 +203,7 @@ int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     if (w <= 0 || h <= 0) return FNX_OK;
+    FNX_REQUIRE(space != FNX_DEVICE || src != dst, "dst aliases src (the blur is not in-place)");
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
@@ -444,7 +465,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
-    FNX_TRY(result_slot(ctx, n, &dres));
+    FNX_TRY(result_slot_queued(ctx, n, &dres));
     int nw, nh;
     bool al = !(astride & 15) && !(bstride & 15);
     for (int i = 0; i < n; i++) {
@@ -497,7 +518,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
             void *dwin = nullptr;
             FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
             double *dres;
-            FNX_TRY(result_slot(ctx, n, &dres));
+            FNX_TRY(result_slot_queued(ctx, n, &dres));
             FNX_TRY(launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
                                          window, static_cast<const double *>(dwin), dres));
             return publish_results(ctx, dres, n);

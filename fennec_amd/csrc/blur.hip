@@ -603,7 +603,7 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 // Cost model: H work ~ staged rows, V work ~ output rows (about 55 : 45 of the instructions).
 static int direct_tile_rows(int R, bool tall)
 {
-    const int th0 = ((64 - 2 * R) / 4) * 4;
+    const int th0 = R >= 1 && R <= FUSED_RMAX ? ((64 - 2 * R) / 4) * 4 : 4;   // never 0: callers divide by it
     return tall ? 2 * th0 : th0;
 }
 static bool direct_tall(const fnx_ctx *ctx, int R, int n, int w, int h)
@@ -754,6 +754,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
                        uint8_t *planes, size_t plane, int dstW, int dstH)
 {
     if (n > 65535) return FNX_NOOP;   // grid.z
+    if (radius < 1 || radius > FUSED_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
     const bool exact = flags & FNX_BLUR_EXACT;
     if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);

@@ -98,10 +98,14 @@ struct fnx_ctx {
         hipEvent_t ev = nullptr;
     } res_q[RES_DEPTH];
     int res_head = 0, res_count = 0;
+    struct ResBuf {            // pinned home of FIFO position i's results (api.cpp: result_slot_queued)
+        double *p = nullptr;
+        size_t cap = 0;
+    } res_buf[RES_DEPTH];
     fnx::ScoreGeom score_geom;
     // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
     static constexpr int PROF_DEPTH = 4;
-    bool prof = false;
+    int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)
     hipEvent_t prof_ev[PROF_DEPTH][2] = {};
     int prof_head = 0, prof_count = 0, prof_open = -1;
 };
@@ -152,7 +156,7 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
 // Copy a staged output back (if host) and synchronise when `space` is host.
 int finish(fnx_ctx *ctx, int space, DevOut *out);
 // fnx_ctx_profile hooks: bracket the launch of a profiled kernel (no-ops when profiling is off)
-int prof_begin(fnx_ctx *ctx);
+int prof_begin(fnx_ctx *ctx, int cls = FNX_PROF_MAIN);
 int prof_end(fnx_ctx *ctx);
 // Fetch n doubles from device memory into host memory (synchronises).
 int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n);
@@ -200,7 +204,7 @@ int launch_box_downsample_pair(fnx_ctx *ctx, int n, const uint8_t *src, const ui
 // Windowed-SSIM launches whose final means are taken later by ONE finish launch (MSSSIM: five levels,
 // each finish is ~4.5 us of latency for a few hundred additions).  The caller reserves SLOT_PARTIAL
 // for all of them first (SSIM_DEFER_DOUBLES) so that the partial pointers stay valid.
-constexpr size_t SSIM_DEFER_DOUBLES = 8 * 1024;
+constexpr size_t SSIM_DEFER_DOUBLES = 64 * 1024;
 struct SsimDeferred {
     int count = 0;
     size_t used = 0;                       // doubles of SLOT_PARTIAL handed out

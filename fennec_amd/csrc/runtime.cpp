@@ -106,9 +106,9 @@ int upload_table(fnx_ctx *ctx, Slot slot, const void *host, size_t bytes, void *
     return upload_tables(ctx, slot, &host, &bytes, 1, dptr);
 }
 
-int prof_begin(fnx_ctx *ctx)
+int prof_begin(fnx_ctx *ctx, int cls)
 {
-    if (!ctx->prof) return FNX_OK;
+    if (!(ctx->prof & cls)) return FNX_OK;
     if (ctx->prof_count == fnx_ctx::PROF_DEPTH) {          // nobody is reading: forget the oldest launch
         ctx->prof_head = (ctx->prof_head + 1) % fnx_ctx::PROF_DEPTH;
         ctx->prof_count--;
@@ -264,6 +264,8 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
         for (auto &q : ctx->res_q)
             if (q.ev) (void)hipEventDestroy(q.ev);
+        for (auto &rb : ctx->res_buf)
+            if (rb.p) (void)hipHostFree(rb.p);
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
                 if (e) (void)hipEventDestroy(e);
@@ -281,7 +283,7 @@ int fnx_ctx_profile(fnx_ctx *ctx, int enable)
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
                 if (!e) FNX_HIP(hipEventCreate(&e));
-    ctx->prof = enable != 0;
+    ctx->prof = enable;
     ctx->prof_head = ctx->prof_count = 0;      // (re-)enabling forgets unread launches
     ctx->prof_open = -1;
     return FNX_OK;

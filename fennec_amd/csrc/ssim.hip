@@ -7,6 +7,8 @@
 #include "common.hpp"
 #include "devutil.hpp"
 
+#include <cstdlib>
+
 namespace fnx {
 
 // ------------------------------------------------------------------------------------
@@ -575,6 +577,141 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep24_kernel(WinSepArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// windowed SSIM, column-strip marching form (rank-1 windows) -- the kernel every big plane takes.
+//
+// The tile kernels above pay for a 2-D halo (1.61x luminance conversions per window at 32 x 24), an LDS
+// round trip for BOTH passes and ~30 instructions of staging arithmetic per staged pixel: PMC counted 213
+// VALU wave-instructions per window against a floor of 64 fp64 FMAs (4 moments x 8 taps x 2 passes).  Here a
+// WAVE owns a strip of 57 window columns (64 pixel columns, one per lane) and marches DOWN a segment of rows:
+//   * per row a lane loads ITS pixel of a and b once, turns each into the integer milli-luminance
+//     I = 299 R + 587 G + 114 B with three v_dot4_u32_u8 (exact; the reference's fp64 0.299 R + 0.587 G +
+//     0.114 B is I / 1000 to 3 ulp -- the SSIM formula is scale-invariant once C1, C2 are scaled by 1e6, so
+//     no division is needed and the result stays within 1e-12 of the reference's, bar 1e-9);
+//   * the horizontal 8-tap pass reads the neighbours' (a, b) and (a^2 + b^2, ab) pairs from a per-wave LDS row
+//     (16-byte reads at a 16-byte lane stride: conflict-free; no barrier -- one wave, in-order LDS);
+//   * the vertical pass never leaves registers: a ring of the 8 windows in flight per column x 4 moments,
+//     unrolled over the 8 phases of the ring so that every index is static; the window whose 8th row just
+//     arrived goes through the SSIM formula (rcp + 2 Newton steps) and into the lane's sum.
+// Row halo (S + 7) / S for a segment of S window rows, column halo 64 / 57; about 120 VALU instructions
+// per window.  Segments are sized so that the launch is a few thousand waves (launch_windowed_ssim).
+// ------------------------------------------------------------------------------------
+constexpr int WM_COLS = 57;          // window columns per wave (64 lanes - 7)
+constexpr int WM_LDSW = 72;          // LDS row entries per wave (lane + 7 taps, padded)
+
+struct MarchArgs {
+    const uint8_t *a;
+    const uint8_t *b;
+    size_t a_image_bytes, b_image_bytes;
+    int astride, bstride, w, h;
+    int strips, segs, seg_rows;   // per image: strips x segs wave-sized work items, seg_rows window rows each
+    double *partial;              // [n][strips * segs]
+    double col[8], row[8];        // k[j][i] ~= row[j] * col[i]
+};
+
+// exact integer milli-luminance: 299 R + 587 G + 114 B  (255 + 44, 255 + 255 + 77, 114)
+__device__ __forceinline__ double lum_milli(uint32_t p)
+{
+    uint32_t i = __builtin_amdgcn_udot4(p, 0x00004d00u, 0u, false);                                      // (0, 77, 0, 0)
+    i = __builtin_amdgcn_udot4(p, 0x0000ff2cu, i, false);                                               // (44, 255, 0, 0)
+    i = __builtin_amdgcn_udot4(p, 0x0072ffffu, i, false);                                               // (255, 255, 114, 0)
+    return u8_to_f64(i);
+}
+
+__global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
+{
+    // per wave: [0, WM_LDSW) (a, b) pairs, [WM_LDSW, 2 WM_LDSW) (a^2 + b^2, ab) pairs
+    __shared__ __attribute__((aligned(16))) double2 s_row[4][2 * WM_LDSW];
+    const int z = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    const int items = a.strips * a.segs;
+    if (item >= items) return;
+    // adjacent waves take adjacent strips of one segment: a workgroup reads 4 x 57 contiguous columns
+    const int seg = item / a.strips, strip = item - seg * a.strips;
+    const int ww = a.w - 8, wh = a.h - 8;
+    const int wy0 = seg * a.seg_rows;
+    const int nwin = min(a.seg_rows, wh - wy0);                  // window rows of this segment
+    const int wx = strip * WM_COLS + lane;
+    const bool live = lane < WM_COLS && wx < ww;
+    const int px = min(wx, a.w - 1);
+    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    double2 *s_p1 = s_row[wave], *s_p2 = s_row[wave] + WM_LDSW;
+    if (lane < WM_LDSW - 64) {                                    // the pad entries lanes 57..63 read: finite, unused
+        s_p1[64 + lane] = make_double2(0.0, 0.0);
+        s_p2[64 + lane] = make_double2(0.0, 0.0);
+    }
+    const int nrows = nwin + 7;                                   // pixel rows of the segment
+    double m[8][4];                                               // ring: window slot x {E[a], E[b], E[a^2 + b^2], E[ab]}
+#pragma unroll
+    for (int s = 0; s < 8; s++) m[s][0] = m[s][1] = m[s][2] = m[s][3] = 0.0;
+    double val = 0.0;
+    uint32_t qa = *(g_u32 *)pa, qb = *(g_u32 *)pb;                // row 0; row i + 1 is fetched while row i is used
+    constexpr double C1 = 6.5025e6, C2 = 58.5225e6;              // (0.01 * 255)^2, (0.03 * 255)^2 in milli-luminance^2
+
+    for (int r = 0; r < nrows; r += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int i = r + p;
+            if (i < nrows) {                                      // wave-uniform
+                const double va = lum_milli(qa), vb = lum_milli(qb);
+                if (i + 1 < nrows) {
+                    pa += a.astride;
+                    pb += a.bstride;
+                    qa = *(g_u32 *)pa;
+                    qb = *(g_u32 *)pb;
+                }
+                s_p1[lane] = make_double2(va, vb);
+                s_p2[lane] = make_double2(fma(vb, vb, va * va), va * vb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const double2 u = s_p1[lane + t], v = s_p2[lane + t];
+                    const double c = a.col[t];
+                    h0 = fma(u.x, c, h0);
+                    h1 = fma(u.y, c, h1);
+                    h2 = fma(v.x, c, h2);
+                    h3 = fma(v.y, c, h3);
+                }
+                __builtin_amdgcn_wave_barrier();                  // the row is consumed before the next one overwrites it
+                // vertical taps: slot s holds the window that started at row i - k, k = (p - s) mod 8
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int k = (p - s) & 7;
+                    const double rk = a.row[k];
+                    if (k == 0) {
+                        m[s][0] = h0 * rk; m[s][1] = h1 * rk; m[s][2] = h2 * rk; m[s][3] = h3 * rk;
+                    } else {
+                        m[s][0] = fma(h0, rk, m[s][0]); m[s][1] = fma(h1, rk, m[s][1]);
+                        m[s][2] = fma(h2, rk, m[s][2]); m[s][3] = fma(h3, rk, m[s][3]);
+                    }
+                }
+                if (i >= 7) {                                     // slot (p + 1) mod 8 just took its 8th row: window row wy0 + i - 7
+                    const int s = (p + 1) & 7;
+                    const double muA = m[s][0], muB = m[s][1];
+                    const double mu2 = fma(muB, muB, muA * muA), muAB = muA * muB;
+                    const double sSum = m[s][2] - mu2, sAB = m[s][3] - muAB;   // sigma_aa + sigma_bb, sigma_ab
+                    const double num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
+                    const double den = (mu2 + C1) * (sSum + C2);
+                    double rc = __builtin_amdgcn_rcp(den);        // den >= C1 * C2 > 0: rcp + 2 Newton steps ~ 1 ulp
+                    rc = fma(fma(-den, rc, 1.0), rc, rc);
+                    rc = fma(fma(-den, rc, 1.0), rc, rc);
+                    val = fma(num, rc, val);
+                }
+            }
+        }
+    }
+    if (!live) val = 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+    if (lane == 0) a.partial[static_cast<size_t>(z) * items + item] = val;
+}
+
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
 {
@@ -595,6 +732,13 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial,
     if (threadIdx.x == 0) out[blockIdx.x] = count > 0 ? t / count : 1.0;   // totalCount==0 -> 1.0 (ssim.go:162-164)
 }
 
+// FNX_SSIM_TILED=1 keeps the tile kernels (A/B measurements); default: the marching kernel
+static bool ssim_use_tiled()
+{
+    static const bool v = [] { const char *e = getenv("FNX_SSIM_TILED"); return e && e[0] == '1'; }();
+    return v;
+}
+
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
                          const double *h_window, const double *d_window, double *d_out,
@@ -604,24 +748,53 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     const bool have = ww > 0 && wh > 0;
     WinSepArgs sa{};
     const bool sep = have && window_rank1(h_window, sa.col, sa.row);
-    // big images: 32 x 24-window tiles (windowed_ssim_sep24_kernel: halo 1.61x instead of 1.80x, full lanes in
-    // the H pass, 16 waves per CU); small ones keep 32 x 16 for the tile count
+    const bool march = sep && !ssim_use_tiled();
+    // tile kernels (FNX_SSIM_TILED=1, and the 64-tap kernel for tables that are not rank-1)
     const bool big = sep && static_cast<long>(ww) * wh * n >= 4L * 1024 * ctx->num_cus;
     const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? W24_TY : WSS_TY) : WS_TY;
     int tiles_x = 0, tiles = 0;
-    if (have) {
+    MarchArgs ma{};
+    if (march) {
+        // wave-sized work items: strips of 57 window columns x row segments.  Segments are cut so that the
+        // launch holds about one resident round of waves (16 per CU) but never shorter than 32 window rows
+        // (row halo (S + 7) / S <= 1.22)
+        ma.strips = (ww + WM_COLS - 1) / WM_COLS;
+        const long target = 16L * ctx->num_cus;
+        long segs = target / (static_cast<long>(n) * ma.strips);
+        const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
+        if (segs > max_segs) segs = max_segs;
+        if (segs < 1) segs = 1;
+        ma.seg_rows = static_cast<int>((wh + segs - 1) / segs);
+        ma.segs = (wh + ma.seg_rows - 1) / ma.seg_rows;
+        tiles = ma.strips * ma.segs;
+    } else if (have) {
         tiles_x = (ww + TX - 1) / TX;
         tiles = tiles_x * ((wh + TY - 1) / TY);
     }
     void *part = nullptr;
-    if (defer && (n != 1 || defer->count >= 8 || defer->used + tiles + 2 > SSIM_DEFER_DOUBLES)) defer = nullptr;
     if (defer) {
+        // the caller reserved SLOT_PARTIAL for all deferred levels (growing it now would free partials that
+        // earlier levels' kernels are still writing); a level that does not fit is an error, not a fallback
+        if (n != 1 || defer->count >= 8 || defer->used + tiles + 2 > SSIM_DEFER_DOUBLES) {
+            set_error("deferred SSIM finish: level %d does not fit the reserved partial sums (%zu + %d of %zu)",
+                      defer->count, defer->used, tiles, SSIM_DEFER_DOUBLES);
+            return FNX_ERR_INVALID;
+        }
         FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));   // reserved by the caller: no growth
         part = static_cast<double *>(part) + defer->used;
     } else {
         FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
     }
-    if (sep) {
+    if (march) {
+        ma.a = a; ma.b = b; ma.a_image_bytes = a_image_bytes; ma.b_image_bytes = b_image_bytes;
+        ma.astride = astride; ma.bstride = bstride; ma.w = w; ma.h = h;
+        ma.partial = static_cast<double *>(part);
+        for (int i = 0; i < 8; i++) { ma.col[i] = sa.col[i]; ma.row[i] = sa.row[i]; }
+        FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
+        hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        FNX_HIP(hipGetLastError());
+        FNX_TRY(prof_end(ctx));
+    } else if (sep) {
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);

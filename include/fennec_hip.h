@@ -90,12 +90,17 @@ int fnx_ctx_device(const fnx_ctx *ctx);
 void *fnx_ctx_stream(fnx_ctx *ctx);
 /* Block until everything enqueued on the ctx has finished. */
 int fnx_ctx_sync(fnx_ctx *ctx);
-/* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of a
- * call's dominant kernel (GaussianBlur fast path: blur_direct_kernel; Analyze:
- * analyze_pass_kernel) with a pair of HIP events on its stream.  fnx_ctx_kernel_ms waits for the
- * OLDEST bracketed launch not read yet and returns its duration in milliseconds -- one call per
- * launch, in launch order; the last 4 launches are kept (FNX_ERR_INVALID if none is unread).
- * fnx_ctx_profile(ctx, 1) also forgets the unread ones. */
+/* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of the selected
+ * kernel classes with a pair of HIP events on the stream the kernel is launched on.  `enable` is a bit
+ * mask of FNX_PROF_* (0: off; 1 = FNX_PROF_MAIN keeps its round-1 meaning: blur_direct_kernel of the
+ * GaussianBlur fast / one-pass path and analyze_pass_kernel).  fnx_ctx_kernel_ms waits for the OLDEST
+ * bracketed launch not read yet and returns its duration in milliseconds -- one call per launch, in
+ * launch order; the last 4 launches are kept (FNX_ERR_INVALID if none is unread).  Calling
+ * fnx_ctx_profile with a non-zero mask also forgets the unread ones. */
+#define FNX_PROF_MAIN 1    /* blur_direct_kernel, analyze_pass_kernel */
+#define FNX_PROF_SSIM 2    /* windowed_ssim_march_kernel */
+#define FNX_PROF_RESIZE 4  /* resize H and V kernels (two launches per lanczosResize) */
+#define FNX_PROF_FX 8      /* fx kernels: gaussianBlur3x3 / Sharpen / AdaptiveSharpen */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
 

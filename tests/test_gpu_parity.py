@@ -425,6 +425,9 @@ def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
     imgs = [synth.noise_image(3000, 2000, 5, alpha=True)]
     for sigma in (0.3, 0.6, 1.0, 1.3, 1.6, 2.3, 2.6, 4.0):      # radius 1..8, then 12 (generic kernels)
         _one_pass_case(ctx, orc, imgs, sigma, check_oracle=())
+    # radius 31..33 made the tile-height arithmetic divide by zero before the radius check (round-1 advisor finding)
+    for sigma in (10.1, 10.5, 11.0):
+        _one_pass_case(ctx, orc, [synth.noise_image(1400, 900, 6, alpha=True)], sigma, check_oracle=())
     # boxes too small for the one-pass tables / no downsample at all
     _one_pass_case(ctx, orc, [synth.large_photo(1280, 720, 2), synth.large_photo(1280, 720, 4)], 2.0)
     _one_pass_case(ctx, orc, [synth.large_photo(500, 300, 2)], 2.0)
