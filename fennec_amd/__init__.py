@@ -286,8 +286,11 @@ class Context:
     # memory out again while ctx-stream kernels still use it.  Every method that takes device tensors
     # therefore runs inside `_ordered(...)`:
     #   before: the ctx stream waits for everything already queued on torch's current stream;
-    #   after : torch's current stream waits for the ctx stream, and every tensor involved is
-    #           record_stream()ed on the ctx stream (the allocator will not recycle it early).
+    #   after : torch's current stream waits for the ctx stream.  That also covers the caching allocator:
+    #           a block freed by torch is handed out again on its allocation stream, and everything that
+    #           stream does from here on is ordered behind the ctx kernels.  (Not record_stream(): the
+    #           allocator would then record events on the ctx's stream when the tensor dies -- possibly
+    #           after the Context, and its stream, are gone.)
     # Host (numpy) calls are synchronous and skip all of this.
     def _ext_stream(self):
         import torch
@@ -320,8 +323,6 @@ class Context:
         def __exit__(self, *exc):
             if self.tensors and getattr(self, "cur", None) is not None and self.cur.cuda_stream != self.ext.cuda_stream:
                 self.cur.wait_stream(self.ext)
-                for t in self.tensors:
-                    t.record_stream(self.ext)
             return False
 
     def _ordered(self, *tensors):
@@ -473,6 +474,17 @@ class Context:
         with self._ordered(img, dst):
             rc = self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(strength), d.ptr, d.stride), name)
         return img if rc == FNX_NOOP else dst
+
+    def sharpen_amount(self, img, amount: float, adaptive: bool = False):
+        """fnx_sharpen / fnx_adaptive_sharpen with the unsharp `amount` itself (1 + 1.5 s / 1 + 2 s in the
+        reference, effects.go:24,63): the kernel-level entry points, for callers and tests."""
+        s = _Img(img)
+        dst = s.like(s.w, s.h)
+        d = _Img(dst)
+        fn = self._lib.fnx_adaptive_sharpen if adaptive else self._lib.fnx_sharpen
+        with self._ordered(img, dst):
+            self._chk(fn(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(amount), d.ptr, d.stride), "sharpen_amount")
+        return dst
 
     def Sharpen(self, img, strength: float):
         """effects.go:10.  strength <= 0 or an image under 3x3 returns `img` itself."""

@@ -37,6 +37,18 @@ __device__ __forceinline__ uint32_t pack_u8(float x, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(floorf(x + 0.5f), sel, old);
 }
 
+// clampF of a fast-mode accumulator in ONE instruction.  v_cvt_pk_u8_f32 saturates to [0,255] and
+// rounds per the wave's FP32 round mode (probed on gfx950: nearest-even by default, truncation
+// under round-toward-zero).  Accumulators are seeded with 0.5, so truncation is floor(sum + 0.5)
+// = clampF's round-half-up; the mode is flipped (one SALU s_setreg each way) only around the
+// packing instructions, the FMAs all run in round-to-nearest-even.
+__device__ __forceinline__ void fp32_round_toward_zero() { __builtin_amdgcn_s_setreg(0x801, 3); }   // hwreg(MODE, 0, 2)
+__device__ __forceinline__ void fp32_round_nearest() { __builtin_amdgcn_s_setreg(0x801, 0); }
+__device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(x, sel, old);
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ uint32_t ld_px(const uint8_t *row, int x)

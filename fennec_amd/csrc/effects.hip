@@ -1,10 +1,30 @@
-// gaussianBlur3x3 / Sharpen / AdaptiveSharpen (effects.go:10-141) on gfx950.
-// One fused launch per op: the 3x3 binomial blur is exact in integers
-// (clampF(sum/16.0) == (sum+8)>>4 for non-negative integer sums), the unsharp step and the
-// Sobel edge mask are fp64, unfused, in the reference's operation order (TU built with
-// -ffp-contract=off; fp64 sqrt and divide are correctly rounded) => bit-exact uint8 output.
+// gaussianBlur3x3 / Sharpen / AdaptiveSharpen (effects.go:10-141) on gfx950: bit-exact, one launch per op.
+//
+//  * gaussianBlur3x3 is exact in integers: clampF(sum / 16.0) == (sum + 8) >> 4 for the binomial sums.
+//  * Sharpen: val = orig + amount * (orig - blur) (effects.go:37) depends on (orig, d = orig - blur) only, and
+//    clampF(fl(orig + fl(amount * d))) == clamp(orig + R[d]) with R[d] = floor(fl(amount * d) + 0.5): the sum's
+//    fp64 rounding (<= 2^-44) can only matter when fl(amount * d) sits within that of a half-integer without
+//    being one, which the host checks for all 511 values of d while it builds R (it then takes the fp64 kernel).
+//    Exact ties are exact sums and round away from zero = up for every value that survives the clamp.
+//  * AdaptiveSharpen (effects.go:49-112): val = orig + amount * e * (orig - blur), e = min(1, |Sobel| / 400) on
+//    BT.601 luminance.  The integer milli-luminance I = 299 R + 587 G + 114 B makes the Sobel sums EXACT
+//    integers; the rest runs in fp32 under a rounding guard (the technique of blur.hip's GUARD kernels): the
+//    accumulator is within E of the real value, it is packed at acc and at acc + 2G (G > E + the fp64 chain's
+//    own error), and a sample whose two bytes differ -- a rounding boundary within G -- is recomputed in fp64,
+//    in the reference's operation order, from the staged tile.  Proven, not sampled; see fx_guard().
+//
+// Tile: 64 x 32 outputs per 256-lane workgroup; the 66 x 34 source tile is staged once as two words per pixel
+// with the channels spread into 16-bit fields (R | B << 16, G | A << 16) plus I; a lane then owns one column
+// and walks down 8 output rows: the horizontal [1 2 1] sums, the Sobel column differences and row sums are
+// computed once per tile row and shared by the three output rows they feed.
+//
+// fx_ref_kernel (the round-1 kernel: fp64, the reference's operation order) remains for amounts outside the
+// guard's bound and for Sharpen amounts with a near-tie product.
 #include "common.hpp"
 #include "devutil.hpp"
+
+#include <cmath>
+#include <cstdlib>
 
 namespace fnx {
 
@@ -15,22 +35,59 @@ struct FxArgs {
     uint8_t *dst;
     int sstride, dstride, w, h;
     double amount;
+    // new kernels
+    const int32_t *rtab;   // device: R[d + 255], d in [-255, 255] (+ one pad entry); Sharpen, AdaptiveSharpen saturated pixels
+    float amt32, k32;      // AdaptiveSharpen: (float)amount, (float)(amount / 400000)
+    float guard;           // G
+    int use_table;         // AdaptiveSharpen: surely saturated pixels (e == 1) take R instead of the guard
+    int vec_ok;            // src base and stride 16-byte aligned
 };
 
-// Workgroup = 64 x 8 output pixels (2 per lane).  The 66 x 10 source tile is loaded once into
-// LDS -- as two words per pixel with the channels spread into 16-bit fields (R|B<<16, G|A<<16),
-// plus its BT.601 luminance -- so every pixel's luminance is computed once instead of once per
-// Sobel neighbour (8x), the 3x3 neighbourhood costs LDS reads, not global loads, and the binomial
-// sum (max 16*255 per field) runs on two channels per add.
-constexpr int FX_TW = 64, FX_TH = 8;
+// ------------------------------------------------------------------------------------
+// reference-order fp64 kernel (round 1): 64 x 8 outputs per workgroup
+// ------------------------------------------------------------------------------------
+constexpr int FXR_TW = 64, FXR_TH = 8;
+
+// one interior pixel exactly as effects.go:70-87 / 28-42 computes it, from spread-field tile words:
+// c_* = centre, n_*[9] = the 3 x 3 neighbourhood row-major (MODE ADAPTIVE reads all, SHARPEN the blur only)
+template <int MODE>
+__device__ __forceinline__ uint32_t fx_exact_px(const uint32_t (&nrb)[9], const uint32_t (&nga)[9], double amount)
+{
+    const uint32_t crb = nrb[4], cga = nga[4];
+    const uint32_t c = crb | (cga << 8);
+    const uint32_t srb = (nrb[0] + nrb[2] + nrb[6] + nrb[8]) + 2 * (nrb[1] + nrb[3] + nrb[5] + nrb[7]) + 4 * crb + 0x00080008u;
+    const uint32_t sga = (nga[0] + nga[2] + nga[6] + nga[8]) + 2 * (nga[1] + nga[3] + nga[5] + nga[7]) + 4 * cga + 0x00080008u;
+    const uint32_t blur[3] = {(srb >> 4) & 0xffu, (sga >> 4) & 0xffu, (srb >> 20) & 0xffu};
+    if (MODE == FX_BLUR3) return blur[0] | (blur[1] << 8) | (blur[2] << 16) | (c & 0xff000000u);
+    double amt = amount;
+    if (MODE == FX_ADAPTIVE) {                                   // localEdgeStrength, effects.go:93-112
+        double l[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) l[i] = lum601(nrb[i] | (nga[i] << 8));
+        const double gx = -l[0] + l[2] - 2 * l[3] + 2 * l[5] - l[6] + l[8];
+        const double gy = -l[0] - 2 * l[1] - l[2] + l[6] + 2 * l[7] + l[8];
+        const double mag = sqrt(gx * gx + gy * gy);
+        double normalized = mag / 400.0;
+        if (normalized > 1) normalized = 1;
+        amt = amount * normalized;                               // localAmount (effects.go:74)
+    }
+    uint32_t out = c & 0xff000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const double orig = u8_to_f64((c >> (8 * ch)) & 0xffu);
+        const double bl = u8_to_f64(blur[ch]);
+        const double val = orig + amt * (orig - bl);             // effects.go:37,82
+        out |= clampF_dev(val) << (8 * ch);
+    }
+    return out;
+}
 
 template <int MODE>
-__global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
+__global__ __launch_bounds__(256) void fx_ref_kernel(FxArgs a)
 {
-    constexpr int LW = FX_TW + 2, LH = FX_TH + 2;
+    constexpr int LW = FXR_TW + 2, LH = FXR_TH + 2;
     __shared__ uint32_t s_rb[LH * LW], s_ga[LH * LW];
-    __shared__ double s_lum[MODE == FX_ADAPTIVE ? LH * LW : 1];
-    const int x0 = blockIdx.x * FX_TW, y0 = blockIdx.y * FX_TH;
+    const int x0 = blockIdx.x * FXR_TW, y0 = blockIdx.y * FXR_TH;
     const int tid = threadIdx.x;
     for (int i = tid; i < LH * LW; i += 256) {
         const int ly = i / LW, lx = i - ly * LW;
@@ -40,7 +97,6 @@ __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
         const uint32_t p = ld_px(a.src + static_cast<size_t>(y) * a.sstride, x);
         s_rb[i] = p & 0x00ff00ffu;
         s_ga[i] = (p >> 8) & 0x00ff00ffu;
-        if (MODE == FX_ADAPTIVE) s_lum[i] = lum601(p);
     }
     __syncthreads();
     const int lx = tid & 63;
@@ -52,43 +108,225 @@ __global__ __launch_bounds__(256) void fx_kernel(FxArgs a)
         const int y = y0 + ly;
         if (y >= a.h) continue;
         const int ci = (ly + 1) * LW + lx + 1;          // tile cell of (x, y)
-        const uint32_t crb = s_rb[ci], cga = s_ga[ci];
-        const uint32_t c = crb | (cga << 8);
-        uint32_t out = c;   // borders and alpha are copies of the source (effects.go:68,120)
+        uint32_t out = s_rb[ci] | (s_ga[ci] << 8);      // borders and alpha are copies of the source (effects.go:68,120)
         if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
-            // [1 2 1; 2 4 2; 1 2 1] on two channels per word; (sum + 8) >> 4 per field (effects.go:125-135)
-            const uint32_t srb = (s_rb[ci - LW - 1] + s_rb[ci - LW + 1] + s_rb[ci + LW - 1] + s_rb[ci + LW + 1]) +
-                                 2 * (s_rb[ci - LW] + s_rb[ci - 1] + s_rb[ci + 1] + s_rb[ci + LW]) + 4 * crb + 0x00080008u;
-            const uint32_t sga = (s_ga[ci - LW - 1] + s_ga[ci - LW + 1] + s_ga[ci + LW - 1] + s_ga[ci + LW + 1]) +
-                                 2 * (s_ga[ci - LW] + s_ga[ci - 1] + s_ga[ci + 1] + s_ga[ci + LW]) + 4 * cga + 0x00080008u;
-            const uint32_t blur[3] = {(srb >> 4) & 0xffu, (sga >> 4) & 0xffu, (srb >> 20) & 0xffu};
-            if (MODE == FX_BLUR3) {
-                out = blur[0] | (blur[1] << 8) | (blur[2] << 16) | (c & 0xff000000u);
-            } else {
-                double amt = a.amount;
-                if (MODE == FX_ADAPTIVE) {                       // localEdgeStrength, effects.go:93-112
-                    const double l00 = s_lum[ci - LW - 1], l01 = s_lum[ci - LW], l02 = s_lum[ci - LW + 1];
-                    const double l10 = s_lum[ci - 1], l12 = s_lum[ci + 1];
-                    const double l20 = s_lum[ci + LW - 1], l21 = s_lum[ci + LW], l22 = s_lum[ci + LW + 1];
-                    const double gx = -l00 + l02 - 2 * l10 + 2 * l12 - l20 + l22;
-                    const double gy = -l00 - 2 * l01 - l02 + l20 + 2 * l21 + l22;
-                    const double mag = sqrt(gx * gx + gy * gy);
-                    double normalized = mag / 400.0;
-                    if (normalized > 1) normalized = 1;
-                    amt = a.amount * normalized;                 // localAmount (effects.go:74)
-                }
-                out = c & 0xff000000u;
+            uint32_t nrb[9], nga[9];
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const double orig = u8_to_f64((c >> (8 * ch)) & 0xffu);
-                    const double bl = u8_to_f64(blur[ch]);
-                    const double val = orig + amt * (orig - bl); // effects.go:37,82
-                    out |= clampF_dev(val) << (8 * ch);
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    nrb[3 * j + i] = s_rb[ci + (j - 1) * LW + i - 1];
+                    nga[3 * j + i] = s_ga[ci + (j - 1) * LW + i - 1];
                 }
-            }
+            out = fx_exact_px<MODE>(nrb, nga, a.amount);
         }
         *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
     }
+}
+
+// ------------------------------------------------------------------------------------
+// column-marching kernel
+// ------------------------------------------------------------------------------------
+constexpr int FX_TW = 64, FX_TH = 32, FX_RP = 8;       // tile, output rows per lane
+constexpr int FX_LW = 72, FX_LH = FX_TH + 2;           // tile row pitch in words: image column x0 + i lives at word 4 + i,
+                                                       // so that the 64-column body is 16-byte aligned; halos at 3 and 68
+constexpr int FX_FIX_CAP = 512;
+
+// 299 R + 587 G + 114 B: exact integer milli-luminance (three v_dot4_u32_u8; see ssim.hip)
+__device__ __forceinline__ uint32_t lum_milli_u32(uint32_t p)
+{
+    uint32_t i = __builtin_amdgcn_udot4(p, 0x00004d00u, 0u, false);
+    i = __builtin_amdgcn_udot4(p, 0x0000ff2cu, i, false);
+    return __builtin_amdgcn_udot4(p, 0x0072ffffu, i, false);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fx_march_kernel(FxArgs a)
+{
+    constexpr int LW = FX_LW, LH = FX_LH;
+    __shared__ __attribute__((aligned(16))) uint32_t s_rb[LH * LW], s_ga[LH * LW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lum[MODE == FX_ADAPTIVE ? LH * LW : 4];
+    __shared__ int32_t s_tab[MODE != FX_BLUR3 ? 512 : 1];
+    __shared__ uint32_t s_fix[MODE == FX_ADAPTIVE ? FX_FIX_CAP : 1];
+    __shared__ int s_nfix;
+    const int x0 = blockIdx.x * FX_TW, y0 = blockIdx.y * FX_TH;
+    const int tid = threadIdx.x;
+    if (MODE == FX_ADAPTIVE && tid == 0) s_nfix = 0;
+    if (MODE == FX_SHARPEN || (MODE == FX_ADAPTIVE && a.use_table)) {
+        s_tab[tid] = a.rtab[tid];
+        s_tab[256 + tid] = a.rtab[256 + tid];
+    }
+    auto put = [&](int cell, uint32_t p) {
+        s_rb[cell] = p & 0x00ff00ffu;
+        s_ga[cell] = (p >> 8) & 0x00ff00ffu;
+        if constexpr (MODE == FX_ADAPTIVE) s_lum[cell] = lum_milli_u32(p);
+    };
+    // ---- stage the (TH + 2) x (TW + 2) source tile: clamped reads -- out-of-image cells are only ever
+    // neighbours of border pixels, which are copies of the source and never look at them
+    if (a.vec_ok && x0 + FX_TW <= a.w) {
+        for (int i = tid; i < LH * (FX_TW / 4); i += 256) {
+            const int ly = i >> 4, c = i & 15;
+            const int y = clampi(y0 + ly - 1, 0, a.h - 1);
+            const u32x4 v = *(g_u32x4 *)(a.src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x0 + 4 * c));
+            const int cell = ly * LW + 4 + 4 * c;
+            *reinterpret_cast<u32x4 *>(&s_rb[cell]) = (u32x4){v[0] & 0x00ff00ffu, v[1] & 0x00ff00ffu, v[2] & 0x00ff00ffu, v[3] & 0x00ff00ffu};
+            *reinterpret_cast<u32x4 *>(&s_ga[cell]) = (u32x4){(v[0] >> 8) & 0x00ff00ffu, (v[1] >> 8) & 0x00ff00ffu,
+                                                              (v[2] >> 8) & 0x00ff00ffu, (v[3] >> 8) & 0x00ff00ffu};
+            if constexpr (MODE == FX_ADAPTIVE)
+                *reinterpret_cast<u32x4 *>(&s_lum[cell]) = (u32x4){lum_milli_u32(v[0]), lum_milli_u32(v[1]), lum_milli_u32(v[2]), lum_milli_u32(v[3])};
+        }
+        if (tid < 2 * LH) {                                      // halo columns x0 - 1 and x0 + 64
+            const int ly = tid >> 1, side = tid & 1;
+            const int y = clampi(y0 + ly - 1, 0, a.h - 1);
+            const int x = clampi(side ? x0 + FX_TW : x0 - 1, 0, a.w - 1);
+            put(ly * LW + (side ? 4 + FX_TW : 3), ld_px(a.src + static_cast<size_t>(y) * a.sstride, x));
+        }
+    } else {
+        for (int i = tid; i < LH * (FX_TW + 2); i += 256) {
+            const int ly = i / (FX_TW + 2), lx = i - ly * (FX_TW + 2);
+            const int x = clampi(x0 + lx - 1, 0, a.w - 1), y = clampi(y0 + ly - 1, 0, a.h - 1);
+            put(ly * LW + 3 + lx, ld_px(a.src + static_cast<size_t>(y) * a.sstride, x));
+        }
+    }
+    __syncthreads();
+
+    const int cx = tid & 63, rg = tid >> 6;
+    const int x = x0 + cx;
+    const int base = (rg * FX_RP) * LW + 4 + cx;                 // tile cell of (x, first output row - 1)
+    // per tile row: horizontal [1 2 1] of both field words; Sobel column difference and [1 2 1] row sum of I
+    uint32_t hrb[FX_RP + 2], hga[FX_RP + 2];
+    int32_t dxr[MODE == FX_ADAPTIVE ? FX_RP + 2 : 1], sxr[MODE == FX_ADAPTIVE ? FX_RP + 2 : 1];
+#pragma unroll
+    for (int r = 0; r < FX_RP + 2; r++) {
+        const int c = base + r * LW;
+        hrb[r] = s_rb[c - 1] + s_rb[c + 1] + 2 * s_rb[c];
+        hga[r] = s_ga[c - 1] + s_ga[c + 1] + 2 * s_ga[c];
+        if constexpr (MODE == FX_ADAPTIVE) {
+            const int32_t l = static_cast<int32_t>(s_lum[c - 1]), m = static_cast<int32_t>(s_lum[c]), rr = static_cast<int32_t>(s_lum[c + 1]);
+            dxr[r] = rr - l;
+            sxr[r] = l + rr + 2 * m;
+        }
+    }
+    const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+#pragma unroll
+    for (int j = 0; j < FX_RP; j++) {
+        const int y = y0 + rg * FX_RP + j;
+        const int ci = base + (j + 1) * LW;
+        const uint32_t crb = s_rb[ci], cga = s_ga[ci];
+        const uint32_t c = crb | (cga << 8);
+        uint32_t out = c;                                        // borders and alpha are copies of the source (effects.go:68,120)
+        bool flagged = false;
+        if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
+            // [1 2 1] vertically over the horizontal sums; (sum + 8) >> 4 per field (effects.go:125-135)
+            const uint32_t srb = hrb[j] + hrb[j + 2] + 2 * hrb[j + 1] + 0x00080008u;
+            const uint32_t sga = hga[j] + hga[j + 2] + 2 * hga[j + 1] + 0x00080008u;
+            const uint32_t br = (srb >> 4) & 0xffu, bg = (sga >> 4) & 0xffu, bb = (srb >> 20) & 0xffu;
+            if constexpr (MODE == FX_BLUR3) {
+                out = br | (bg << 8) | (bb << 16) | (c & 0xff000000u);
+            } else {
+                const int o_r = crb & 0xffu, o_g = cga & 0xffu, o_b = (crb >> 16) & 0xffu;
+                const int d_r = o_r - static_cast<int>(br), d_g = o_g - static_cast<int>(bg), d_b = o_b - static_cast<int>(bb);
+                // table form: clamp(orig + R[d])
+                auto tab = [&]() {
+                    const int vr = clampi(o_r + s_tab[d_r + 255], 0, 255), vg = clampi(o_g + s_tab[d_g + 255], 0, 255),
+                              vb = clampi(o_b + s_tab[d_b + 255], 0, 255);
+                    return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | (c & 0xff000000u);
+                };
+                if constexpr (MODE == FX_SHARPEN) {
+                    out = tab();
+                } else {
+                    // Sobel on I (exact integers, |g| <= 4 * 255000 < 2^24: the converts are exact)
+                    const float gx = static_cast<float>(dxr[j] + dxr[j + 2] + 2 * dxr[j + 1]);
+                    const float gy = static_cast<float>(sxr[j + 2] - sxr[j]);
+                    const float m2 = fmaf(gy, gy, gx * gx);
+                    const float t = fminf(a.amt32, __builtin_amdgcn_sqrtf(m2) * a.k32);   // amount * e, within 4e-7 relative
+                    const float fr = static_cast<float>(o_r), fg = static_cast<float>(o_g), fb = static_cast<float>(o_b);
+                    const float ar = fmaf(t, static_cast<float>(d_r), fr + seed);
+                    const float ag = fmaf(t, static_cast<float>(d_g), fg + seed);
+                    const float ab = fmaf(t, static_cast<float>(d_b), fb + seed);
+                    const float hr = ar + g2, hg = ag + g2, hb = ab + g2;
+                    fp32_round_toward_zero();
+                    out = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, c)));
+                    const uint32_t out2 = pk8(hb, 2, pk8(hg, 1, pk8(hr, 0, c)));
+                    fp32_round_nearest();
+                    flagged = out != out2;
+                    if (a.use_table && m2 > 1.6000016e11f) {     // e == 1 for certain (400000^2 + 1e-5 relative): exact by table
+                        out = tab();
+                        flagged = false;
+                    }
+                    if (flagged) {
+                        const int e = atomicAdd(&s_nfix, 1);
+                        if (e < FX_FIX_CAP) s_fix[e] = ((rg * FX_RP + j) << 8) | cx;
+                    }
+                }
+            }
+        }
+        if (x < a.w && y < a.h && !flagged)
+            *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
+    }
+    if constexpr (MODE == FX_ADAPTIVE) {
+        // flagged pixels (a rounding boundary within G of the fp32 value): the reference's own fp64 arithmetic.
+        // A list overflow recomputes every interior pixel of the tile.
+        __syncthreads();
+        const int nfix = s_nfix;
+        const int total = nfix > FX_FIX_CAP ? FX_TW * FX_TH : nfix;
+        for (int e = tid; e < total; e += 256) {
+            const int row = nfix > FX_FIX_CAP ? e >> 6 : static_cast<int>(s_fix[e] >> 8);
+            const int col = nfix > FX_FIX_CAP ? e & 63 : static_cast<int>(s_fix[e] & 0xffu);
+            const int px = x0 + col, py = y0 + row;
+            if (!(px >= 1 && py >= 1 && px < a.w - 1 && py < a.h - 1)) continue;
+            const int ci = (row + 1) * LW + 4 + col;
+            uint32_t nrb[9], nga[9];
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+                for (int ii = 0; ii < 3; ii++) {
+                    nrb[3 * jj + ii] = s_rb[ci + (jj - 1) * LW + ii - 1];
+                    nga[3 * jj + ii] = s_ga[ci + (jj - 1) * LW + ii - 1];
+                }
+            *(g_u32w *)(a.dst + static_cast<size_t>(py) * a.dstride + 4 * static_cast<size_t>(px)) =
+                fx_exact_px<FX_ADAPTIVE>(nrb, nga, a.amount);
+        }
+    }
+}
+
+// R[d + 255] = floor(fl(amount * d) + 0.5), d in [-255, 255].  false: some product is within 1e-6 of a
+// half-integer without being one (the sum's fp64 rounding could then decide), or the table would not fit.
+// *ties: some product IS a half-integer (only the guard's statistics care).
+static bool build_rtab(double amount, int32_t (&tab)[512], bool *ties)
+{
+    *ties = false;
+    if (!(std::fabs(amount) <= 64.0)) return false;
+    for (int d = -255; d <= 255; d++) {
+        const double p = amount * static_cast<double>(d);        // the reference's amount * (orig - blur)
+        const double fl = std::floor(p), f = p - fl;
+        if (f == 0.5) *ties = true;
+        else if (std::fabs(f - 0.5) < 1e-6) return false;
+        tab[d + 255] = static_cast<int32_t>(fl) + (f >= 0.5 ? 1 : 0);
+    }
+    tab[511] = 0;
+    return true;
+}
+
+// AdaptiveSharpen's rounding guard.  With I = 1000 * luminance exact, the real value of the reference's
+// expression is V = orig + A e d, e = min(1, sqrt(gx^2 + gy^2) / 400000), |d| <= 255, A = amount in (0, 8].
+// fp32 chain: gx, gy exact; m2 = fma(gy, gy, gx gx): <= 2^-23 relative; v_sqrt_f32 (1 ulp) of it: <= 1.5 * 2^-23;
+// times k32 = fl32(A / 400000), one multiply: <= 2.5 * 2^-23 < 3e-7; min with fl32(A): same bound.  So
+// t = A e (1 + dt), |dt| <= 4e-7 (margin included), |t d - A e d| <= A * 255 * 4e-7.  orig + seed rounds by
+// <= 2^-17 (< 256); the final fma rounds by half an ulp of a value below 256 (1 + A) + 1.  The reference's fp64
+// chain is within 1e-9 of V (luminances to 3 ulp, IEEE sqrt and divide).  The second pack's addend rounds by
+// one more half ulp (eta).  G = E + eta + 1e-5 > E + eta + 1e-9.
+static bool fx_guard(double amount, float *guard)
+{
+    if (!(amount > 0.0 && amount <= 8.0)) return false;
+    const double top = 256.0 * (1.0 + amount) + 1.0;
+    const double half_ulp = std::ldexp(1.0, static_cast<int>(std::ceil(std::log2(top))) - 24);
+    const double E = amount * 255.0 * 4e-7 + std::ldexp(1.0, -17) + half_ulp;
+    const double G = E + half_ulp + 1e-5;
+    float g = static_cast<float>(G);
+    if (static_cast<double>(g) < G) g = std::nextafterf(g, 1.0f);
+    *guard = g;
+    return true;
 }
 
 template <int MODE>
@@ -96,10 +334,40 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
                      uint8_t *dst, int dstride)
 {
     if (w <= 0 || h <= 0) return FNX_OK;
-    FxArgs a{src, dst, sstride, dstride, w, h, amount};
-    dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
-    hipLaunchKernelGGL((fx_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
+    FxArgs a{};
+    a.src = src; a.dst = dst; a.sstride = sstride; a.dstride = dstride; a.w = w; a.h = h; a.amount = amount;
+    a.vec_ok = aligned16(src, sstride) ? 1 : 0;
+    bool march = true;
+    const char *force_ref = getenv("FNX_FX_REF");                // A/B and tests: "1" takes the fp64 reference-order kernel
+    if (MODE != FX_BLUR3) {
+        int32_t tab[512];
+        bool ties = false;
+        const bool tab_ok = build_rtab(amount, tab, &ties);
+        if (MODE == FX_SHARPEN) {
+            march = tab_ok;
+        } else {
+            march = fx_guard(amount, &a.guard);
+            a.amt32 = static_cast<float>(amount);
+            a.k32 = static_cast<float>(amount / 400000.0);
+            a.use_table = (tab_ok && ties) ? 1 : 0;     // tie-prone amounts (1.5, 2.5, ...): saturated pixels skip the guard
+        }
+        if (march && (MODE == FX_SHARPEN || a.use_table)) {
+            void *d = nullptr;
+            FNX_TRY(upload_table(ctx, SLOT_TABLE0, tab, sizeof(tab), &d));
+            a.rtab = static_cast<const int32_t *>(d);
+        }
+    }
+    if (force_ref && force_ref[0] == '1') march = false;
+    FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
+    if (march) {
+        dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
+        hipLaunchKernelGGL((fx_march_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        dim3 grid((w + FXR_TW - 1) / FXR_TW, (h + FXR_TH - 1) / FXR_TH);
+        hipLaunchKernelGGL((fx_ref_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
+    }
     FNX_HIP(hipGetLastError());
+    FNX_TRY(prof_end(ctx));
     return FNX_OK;
 }
 

@@ -598,6 +598,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep24_kernel(WinSepArgs a)
 // ------------------------------------------------------------------------------------
 constexpr int WM_COLS = 57;          // window columns per wave (64 lanes - 7)
 constexpr int WM_LDSW = 72;          // LDS row entries per wave (lane + 7 taps, padded)
+constexpr int WM_PF = 4;             // pixel rows in flight per lane (divides the 8 ring phases)
 
 struct MarchArgs {
     const uint8_t *a;
@@ -648,7 +649,17 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
 #pragma unroll
     for (int s = 0; s < 8; s++) m[s][0] = m[s][1] = m[s][2] = m[s][3] = 0.0;
     double val = 0.0;
-    uint32_t qa = *(g_u32 *)pa, qb = *(g_u32 *)pb;                // row 0; row i + 1 is fetched while row i is used
+    // pixel rows are fetched WM_PF rows ahead (one row of work is ~450 clocks of issue, an HBM miss ~900):
+    // slot (i mod WM_PF) holds row i
+    uint32_t qa[WM_PF], qb[WM_PF];
+#pragma unroll
+    for (int k = 0; k < WM_PF; k++) {
+        const int rr = min(k, nrows - 1);
+        qa[k] = *(g_u32 *)(pa + static_cast<size_t>(rr) * a.astride);
+        qb[k] = *(g_u32 *)(pb + static_cast<size_t>(rr) * a.bstride);
+    }
+    pa += static_cast<size_t>(WM_PF) * a.astride;                 // -> row i + WM_PF
+    pb += static_cast<size_t>(WM_PF) * a.bstride;
     constexpr double C1 = 6.5025e6, C2 = 58.5225e6;              // (0.01 * 255)^2, (0.03 * 255)^2 in milli-luminance^2
 
     for (int r = 0; r < nrows; r += 8) {
@@ -656,12 +667,12 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
         for (int p = 0; p < 8; p++) {
             const int i = r + p;
             if (i < nrows) {                                      // wave-uniform
-                const double va = lum_milli(qa), vb = lum_milli(qb);
-                if (i + 1 < nrows) {
+                const double va = lum_milli(qa[p % WM_PF]), vb = lum_milli(qb[p % WM_PF]);
+                if (i + WM_PF < nrows) {
+                    qa[p % WM_PF] = *(g_u32 *)pa;
+                    qb[p % WM_PF] = *(g_u32 *)pb;
                     pa += a.astride;
                     pb += a.bstride;
-                    qa = *(g_u32 *)pa;
-                    qb = *(g_u32 *)pb;
                 }
                 s_p1[lane] = make_double2(va, vb);
                 s_p2[lane] = make_double2(fma(vb, vb, va * va), va * vb);

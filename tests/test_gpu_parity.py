@@ -125,6 +125,53 @@ def test_blur3x3_sharpen_adaptive(ctx, orc, name):
         assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), s
 
 
+def _soft_image(orc, w, h, seed):
+    """Noise blurred twice: Sobel magnitudes spread over (0, 400), so AdaptiveSharpen's edge strength is fractional."""
+    return orc.gaussian_blur(orc.gaussian_blur(synth.noise_image(w, h, seed, alpha=True), 2.0), 1.2)
+
+
+@pytest.mark.parametrize("w,h", [(64, 32), (65, 33), (200, 150), (1000, 37), (3, 3), (4, 700), (517, 389)])
+def test_sharpen_adaptive_guarded_kernels(ctx, orc, w, h):
+    """The marching kernels (Sharpen by table, AdaptiveSharpen under the fp32 rounding guard) on soft images --
+    fractional edge strengths, so the guard really decides -- and on tie-prone strengths (amount 1.5, 2.5, 1.375):
+    bit-exact against the oracle."""
+    soft = _soft_image(orc, w, h, w + h)
+    hard = synth.large_photo(w, h, 3)
+    for img in (soft, hard):
+        assert np.array_equal(ctx.blur3x3(img), orc.blur3x3(img))
+        for s in (0.05, 0.25, 0.3, 0.5, 0.6180339887, 0.75, 1.0):
+            assert np.array_equal(ctx.Sharpen(img, s), orc.sharpen(img, s)), ("sharpen", s)
+            assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), ("adaptive", s)
+
+
+def test_sharpen_amounts_against_reference_order_kernel(ctx, orc, monkeypatch):
+    """Kernel-level amounts outside what the reference ever passes (and an unaligned strided view): the marching
+    kernels against the round-1 fp64 kernel, which follows the reference's operation order (FNX_FX_REF=1)."""
+    import torch
+    soft = _soft_image(orc, 333, 217, 5)
+    big = torch.from_numpy(np.ascontiguousarray(np.pad(soft, ((0, 0), (3, 2), (0, 0))))).cuda()
+    view = big[:, 3:-2]                                         # 4-byte aligned rows, stride != 4 w
+    rng = np.random.default_rng(11)
+    amounts = [0.1, 1.0, 1.5, 2.0, 2.5, 3.0, 7.99, 8.5, 40.0, -0.5] + list(rng.uniform(0.01, 8.0, 6))
+    for adaptive in (False, True):
+        for amt in amounts:
+            monkeypatch.delenv("FNX_FX_REF", raising=False)
+            got = ctx.sharpen_amount(soft, amt, adaptive)
+            got_view = ctx.sharpen_amount(view, amt, adaptive).cpu().numpy()
+            monkeypatch.setenv("FNX_FX_REF", "1")
+            want = ctx.sharpen_amount(soft, amt, adaptive)
+            assert np.array_equal(got, want), (adaptive, amt)
+            assert np.array_equal(got_view, want), (adaptive, amt, "view")
+    monkeypatch.delenv("FNX_FX_REF", raising=False)
+
+
+def test_adaptive_sharpen_4k_soft(ctx, orc):
+    img = _soft_image(orc, 3840, 2160, 4)
+    for s in (0.25, 0.5):
+        assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s, procs=16)), s
+    assert np.array_equal(ctx.Sharpen(img, 0.5), orc.sharpen(img, 0.5, procs=16))
+
+
 def test_sharpen_guards(ctx):
     img = synth.make_test_image(100, 100)
     tiny = synth.make_test_image(2, 2)
