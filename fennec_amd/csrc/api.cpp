@@ -192,6 +192,44 @@ int can_enqueue(fnx_ctx *ctx)
 
 }  // namespace
 
+namespace fnx {
+
+int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                          const TapTable &th, const TapTable &tv, uint8_t *dst, int dstride, int dstW, int dstH)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space_io(space));
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
+    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
+    FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
+    if (srcW == dstW && srcH == dstH) {   // flat copy of Pix (resize.go:45-49)
+        const size_t sl = pix_len(srcW, srcH, sstride), dl = pix_len(dstW, dstH, dstride);
+        const size_t nbytes = sl < dl ? sl : dl;
+        if (space == FNX_HOST) {
+            std::memcpy(dst, src, nbytes);
+        } else if (space == FNX_DEVICE_SRC) {
+            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+            FNX_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return FNX_OK;
+    }
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, dstH, SLOT_OUT, &d));
+    // uint8 intermediate dstW x srcH (resize.go:51)
+    const int tp = pitch16(dstW);
+    void *tmp = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
+    FNX_TRY(resize_pass(ctx, false, th, s.p, s.stride, srcW, srcH, static_cast<uint8_t *>(tmp), tp));
+    FNX_TRY(resize_pass(ctx, true, tv, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+}  // namespace fnx
+
 extern "C" {
 
 int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
@@ -274,29 +312,6 @@ int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
 }
 
 // ---- resize ------------------------------------------------------------------------
-static int upload_taps(fnx_ctx *ctx, Slot slot, int nout, const int32_t *off, const int32_t *idx,
-                       const double *wt, const int32_t **d_off, const int32_t **d_idx, const double **d_wt,
-                       int *contig_taps = nullptr)
-{
-    FNX_REQUIRE(off && idx && wt, "tap table is null");
-    const int ntaps = off[nout];
-    FNX_REQUIRE(ntaps >= 0, "tap table offsets");
-    const void *hosts[3] = {wt, off, idx};
-    const size_t sizes[3] = {sizeof(double) * size_t(ntaps), sizeof(int32_t) * size_t(nout + 1),
-                             sizeof(int32_t) * size_t(ntaps)};
-    void *dp[3];
-    FNX_TRY(upload_tables(ctx, slot, hosts, sizes, 3, dp));
-    *d_wt = static_cast<const double *>(dp[0]);
-    *d_off = static_cast<const int32_t *>(dp[1]);
-    *d_idx = static_cast<const int32_t *>(dp[2]);
-    if (contig_taps) {      // scanned once per distinct table (the slot's cache says whether it changed)
-        TableCache &tc = ctx->tcache[slot];
-        if (tc.fresh) tc.contig_taps = resize_contiguous_taps(off, idx, nout);
-        *contig_taps = tc.contig_taps;
-    }
-    return FNX_OK;
-}
-
 int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
                  const int32_t *offset, const int32_t *index, const double *weight,
                  uint8_t *dst, int dstride, int dstW)
@@ -306,15 +321,12 @@ int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstW > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, srcH, "dst"));
-    const int32_t *doff, *didx;
-    const double *dwt;
-    int contig = 0;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offset, index, weight, &doff, &didx, &dwt, &contig));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, srcH, SLOT_OUT, &d));
-    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstW, contig));
+    const TapTable t{offset, index, weight, dstW, 0};
+    FNX_TRY(resize_pass(ctx, false, t, s.p, s.stride, srcW, srcH, d.p, d.stride));
     return finish(ctx, space, &d);
 }
 
@@ -327,15 +339,12 @@ int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstH > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, srcW, dstH, "dst"));
-    const int32_t *doff, *didx;
-    const double *dwt;
-    int contig = 0;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offset, index, weight, &doff, &didx, &dwt, &contig));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, srcW, dstH, SLOT_OUT, &d));
-    FNX_TRY(launch_resize_v(ctx, s.p, s.stride, srcW, srcH, doff, didx, dwt, d.p, d.stride, dstH, contig));
+    const TapTable t{offset, index, weight, dstH, 0};
+    FNX_TRY(resize_pass(ctx, true, t, s.p, s.stride, srcW, srcH, d.p, d.stride));
     return finish(ctx, space, &d);
 }
 
@@ -344,41 +353,8 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
                        const int32_t *offV, const int32_t *idxV, const double *wV,
                        uint8_t *dst, int dstride, int dstW, int dstH)
 {
-    FNX_TRY(bind(ctx));
-    FNX_TRY(check_space_io(space));
-    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
-    FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
-    FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
-    if (srcW == dstW && srcH == dstH) {   // flat copy of Pix (resize.go:45-49)
-        const size_t sl = pix_len(srcW, srcH, sstride), dl = pix_len(dstW, dstH, dstride);
-        const size_t nbytes = sl < dl ? sl : dl;
-        if (space == FNX_HOST) {
-            std::memcpy(dst, src, nbytes);
-        } else if (space == FNX_DEVICE_SRC) {
-            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-            FNX_HIP(hipStreamSynchronize(ctx->stream));
-        } else {
-            FNX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        return FNX_OK;
-    }
-    const int32_t *dOffH, *dIdxH, *dOffV, *dIdxV;
-    const double *dWH, *dWV;
-    int contig = 0;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE0, dstW, offH, idxH, wH, &dOffH, &dIdxH, &dWH, &contig));
-    int contigV = 0;
-    FNX_TRY(upload_taps(ctx, SLOT_TABLE1, dstH, offV, idxV, wV, &dOffV, &dIdxV, &dWV, &contigV));
-    DevImg s;
-    DevOut d;
-    FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
-    FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, dstH, SLOT_OUT, &d));
-    // uint8 intermediate dstW x srcH (resize.go:51)
-    const int tp = pitch16(dstW);
-    void *tmp = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
-    FNX_TRY(launch_resize_h(ctx, s.p, s.stride, srcW, srcH, dOffH, dIdxH, dWH, static_cast<uint8_t *>(tmp), tp, dstW, contig));
-    FNX_TRY(launch_resize_v(ctx, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, dOffV, dIdxV, dWV, d.p, d.stride, dstH, contigV));
-    return finish(ctx, space, &d);
+    const TapTable th{offH, idxH, wH, dstW, 0}, tv{offV, idxV, wV, dstH, 0};
+    return fnx::lanczos_resize_tables(ctx, space, src, sstride, srcW, srcH, th, tv, dst, dstride, dstW, dstH);
 }
 
 // ---- ssim.go -----------------------------------------------------------------------

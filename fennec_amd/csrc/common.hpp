@@ -77,7 +77,18 @@ struct ScoreGeom {
     std::vector<int32_t> map;   // the table blob uploaded to SLOT_BOXMAP
 };
 
+// A CSR tap table of one resize pass (precomputeWeights, resize.go:164-197).  id != 0 marks an immutable
+// table with a process-unique id (host_api.cpp's cache): plans are then looked up by id instead of content.
+struct TapTable {
+    const int32_t *off = nullptr, *idx = nullptr;
+    const double *wt = nullptr;
+    int nout = 0;
+    uint64_t id = 0;
+};
+
 }  // namespace fnx
+
+struct fnx_resize_plan;   // resize.hip: device tables of one (tap table, direction)
 
 struct fnx_ctx {
     int device = 0;
@@ -103,6 +114,7 @@ struct fnx_ctx {
         size_t cap = 0;
     } res_buf[RES_DEPTH];
     fnx::ScoreGeom score_geom;
+    std::vector<fnx_resize_plan *> rplans;   // at most 8, least recently used evicted (resize.hip)
     // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
     static constexpr int PROF_DEPTH = 4;
     int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)
@@ -181,6 +193,14 @@ int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, 
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,
                    double amount, uint8_t *dst, int dstride);
+// One pass of lanczosResize through the ctx's plan cache: guard-exact fp32 kernels where the table allows,
+// the fp64 kernels otherwise.  vertical == false: dst is t.nout x srcH; true: dst is srcW x t.nout.
+int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
+                uint8_t *dst, int dstride);
+void free_resize_plans(fnx_ctx *ctx);
+// lanczosResize (resize.go:37-53) with both tables given: the body of fnx_lanczos_resize
+int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
+                          const TapTable &th, const TapTable &tv, uint8_t *dst, int dstride, int dstW, int dstH);
 // contig_taps: resize_contiguous_taps() of the (host) H table -- most taps of any output when every
 // output's tap indices are consecutive, else 0
 int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,

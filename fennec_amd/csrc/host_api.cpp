@@ -3,6 +3,7 @@
 // generation, i.e. everything the Go side of a cgo shim keeps.  No pixel arithmetic happens
 // here: every image operation is a fnx_* call (HIP kernels); there is no CPU path.
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -19,6 +20,8 @@ namespace {
 struct Taps {
     std::vector<int32_t> off, idx;
     std::vector<double> wt;
+    uint64_t id = 0;      // process-unique, never reused: a ctx's resize plans are keyed by it
+    TapTable table(int nout) const { return TapTable{off.data(), idx.data(), wt.data(), nout, id}; }
 };
 
 void build_taps(int dstSize, int srcSize, Taps &t)
@@ -46,6 +49,8 @@ std::shared_ptr<const Taps> make_taps(int dstSize, int srcSize)
     }
     auto t = std::make_shared<Taps>();
     build_taps(dstSize, srcSize, *t);
+    static std::atomic<uint64_t> next_id{1};
+    t->id = next_id++;
     std::lock_guard<std::mutex> lk(mu);
     if (cache.size() >= 32) cache.erase(cache.begin());
     cache.emplace_back(key, t);
@@ -80,9 +85,8 @@ int resize_b_to(fnx_ctx *ctx, int space, const uint8_t *b, int bstride, int bw, 
         src = s.p;
         sstride = s.stride;
     }
-    int rc = fnx_lanczos_resize(ctx, FNX_DEVICE, src, sstride, bw, bh, th.off.data(), th.idx.data(),
-                                th.wt.data(), tv.off.data(), tv.idx.data(), tv.wt.data(),
-                                static_cast<uint8_t *>(d), w * 4, w, h);
+    int rc = lanczos_resize_tables(ctx, FNX_DEVICE, src, sstride, bw, bh, th.table(w), tv.table(h),
+                                   static_cast<uint8_t *>(d), w * 4, w, h);
     if (rc < 0) return rc;
     *out = static_cast<const uint8_t *>(d);
     *ostride = w * 4;
@@ -295,9 +299,8 @@ int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
                                   nullptr, nullptr, dst, dstride, dstW, dstH);
     const auto pth = make_taps(dstW, srcW), ptv = make_taps(dstH, srcH);
     const Taps &th = *pth, &tv = *ptv;
-    return fnx_lanczos_resize(ctx, space, src, sstride, srcW, srcH, th.off.data(), th.idx.data(),
-                              th.wt.data(), tv.off.data(), tv.idx.data(), tv.wt.data(), dst, dstride,
-                              dstW, dstH);
+    return lanczos_resize_tables(ctx, space, src, sstride, srcW, srcH, th.table(dstW), tv.table(dstH), dst, dstride,
+                                 dstW, dstH);
 }
 
 int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,

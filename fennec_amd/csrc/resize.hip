@@ -6,6 +6,12 @@
 #include "common.hpp"
 #include "devutil.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+
 namespace fnx {
 
 struct ResizeArgs {
@@ -253,6 +259,510 @@ __global__ __launch_bounds__(256) void resize_v_cols_kernel(ResizeColsArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Guard-exact fp32 passes (opaque windows: every photograph) -- the fast path of lanczosResize
+// ------------------------------------------------------------------------------------
+// For a window whose pixels all have A = 255 the reference's output (resize.go:93-113) is
+//     clampF(fl(r * inv)),  r = sum_k fl(R_k * aw_k),  aw_k = fl(255 w_k),  inv = fl(1 / sum_k aw_k)
+// whose real value is X = sum_k R_k W_k with W_k = aw_k / sum aw; the fp64 chain is within 1e-9 of X (~1e-13
+// in fact).  The guard kernels accumulate  acc = (0.5 - G) + sum_k fl32(W_k) R_k  with fp32 FMAs: the weights
+// are off by <= 2^-24 relative (255 S 2^-24 in all, S = sum |W_k|), every FMA rounds by at most half an ulp of a
+// value below 255 S + 1, the seed add by the same; E is their sum over the dense window.  Packed (truncating,
+// saturating) at acc and at acc + 2G with G > E + the second add's half ulp + 1e-6: when both bytes agree no
+// integer lies within G - E of X + 0.5 and floor(X + 0.5) -- the reference's clampF -- is that byte.  When they
+// differ, or when the window holds any alpha != 255, the output goes on a workgroup list and is recomputed by
+// resize_exact_px: fp64, unfused, tap order, premultiplied alpha, the a > 0.5 rule -- the reference's arithmetic.
+// A list overflow recomputes the workgroup's whole block that way.  Proven, not sampled.
+//
+// The taps of `HO` adjacent outputs are expanded on the host into a dense HO x NPX weight matrix over the union
+// of their windows (zeros where an output does not use a pixel: fma(x, 0, acc) == acc exactly), so that the
+// kernels' loops are fully unrolled although tap counts and window starts vary from output to output.
+//   H pass: a lane owns one group of HO output columns, keeps its weight matrix in registers and walks down
+//           `rows` rows; a pixel is converted once for all the outputs it feeds.
+//   V pass: a lane owns 2 adjacent columns and VG = 4 consecutive output rows; the group's weights are
+//           wave-uniform (scalar loads), every source row of the union is loaded and converted once.
+constexpr int RG_FIX_CAP = 1024;
+constexpr int RG_VG = 4;
+
+struct ResizeGuardArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int sstride, dstride;
+    int srcN;                 // source extent along the filtered axis
+    int nout;                 // outputs along the filtered axis
+    int other;                // extent of the other axis (rows for H, columns for V)
+    int ngroups, rows;        // H: groups of HO outputs, rows per lane.  V: groups of VG rows
+    int npx;                  // V: padded union rows per group (dense stride)
+    float guard;
+    const float *dense;       // H: [(j * NPX + i) * ngroups + g]   V: [(g * npx + i) * VG + j]
+    const int32_t *s0;        // first source index of each group's union window
+    const int32_t *cnt;       // V: union rows of each group
+    const uint32_t *alpha;    // H: clampF(a) of the group's outputs, one byte each (output j in byte j)
+                              // V: one word per output row, the byte already in bits 24..31
+    const double *aw;         // fp64 aw = 255 w of the dense window (0.0 where unused): H [(j * NPX + i) * ngroups + g],
+                              // V [(g * npx + i) * VG + j]
+    const double *inv;        // 1.0 / a per output (a = sum of its aw, in tap order)
+    // exact fix-ups
+    const int32_t *off, *idx;
+    const double *wt;
+};
+
+// one output exactly as resizeH / resizeV compute it (resize.go:93-113 / 137-156).  The guard kernels only run
+// on contiguous tap lists, so tap k reads source index idx[t0] + k: the loop fetches 8 taps' weights and pixels
+// with independent, branch-free loads (clamped to the last tap) before it applies them in order -- a tap at a
+// time it is a chain of dependent cache misses, ~1.4 us per tap, and a handful of listed outputs per workgroup
+// then outlast the whole fp32 pass.
+template <bool VERT>
+__device__ __forceinline__ uint32_t resize_exact_px(const ResizeGuardArgs &a, int x, int y)
+{
+    const int d = VERT ? y : x;
+    const int t0 = a.off[d], n = a.off[d + 1] - t0;
+    const int s0 = a.idx[t0];
+    const uint8_t *base = VERT ? a.src + 4 * static_cast<size_t>(x) : a.src + static_cast<size_t>(y) * a.sstride;
+    const size_t step = VERT ? static_cast<size_t>(a.sstride) : 4;
+    double r = 0, g = 0, b = 0, al = 0;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        uint32_t p[8];
+        double w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = min(k0 + e, n - 1);
+            p[e] = *(g_u32 *)(base + static_cast<size_t>(s0 + k) * step);
+            w[e] = a.wt[t0 + k];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (k0 + e < n) resize_tap(p[e], w[e], r, g, b, al);
+    }
+    uint32_t o = 0;
+    if (al > 0.5) {
+        const double inv = 1.0 / al;
+        o = clampF_dev(r * inv) | (clampF_dev(g * inv) << 8) | (clampF_dev(b * inv) << 16) | (clampF_dev(al) << 24);
+    }
+    return o;
+}
+
+// acc.x += f * w.x, acc.y += f * w.y: v_pk_fma_f32 with the low half of the first source feeding both lanes
+// (op_sel_hi), so the converted channel is not copied into a pair first
+__device__ __forceinline__ v2f fma_bcast(float f, v2f w, v2f acc)
+{
+    v2f ff;
+    asm("" : "=v"(ff));          // an (undefined) aligned register pair; only its low half is read
+    ff.x = f;
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(ff), "v"(w));
+    return acc;
+}
+
+constexpr int RG_HO = 2;    // outputs per H group.  Two is the sweet spot: at a 2x downscale the dense window is 16 pixels for
+                            // 12 real taps (4 outputs: 20 for 12), a 32-entry weight matrix leaves room for 6 waves per SIMD
+                            // (4 outputs: 80 entries, 1-2 waves), and converts + FMAs per output come out the same
+
+// Flag handling.  Photographs flag ~0.1 % of the outputs (a rounding boundary within G): those go on a
+// workgroup list and are recomputed by resize_exact_px after the main loop.  Synthetic content can flag
+// everything -- a linear ramp at an integer ratio puts EVERY output of a row on an exact tie -- so a wave
+// that finds RG_DENSE or more flagged lanes in a row leaves that row to a second, exact loop instead: fp64,
+// unfused, ascending taps (dense window, zero weights add +0.0), the reference's arithmetic for opaque windows
+// with the fp64 weights aw = 255 w staged in LDS and inv = 1 / sum aw; rows with a window that is not opaque
+// call resize_exact_px.  The list therefore holds at most (RG_DENSE - 1) lanes x HO outputs per wave
+// row and cannot overflow (RG_FIX_CAP >= 4 waves x 16 rows x 2 x (RG_DENSE - 1)).
+constexpr int RG_DENSE = 8;
+static_assert(4 * 16 * 2 * (RG_DENSE - 1) <= RG_FIX_CAP, "fix-up list capacity");
+
+template <int NV, bool PF>
+__global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
+{
+    constexpr int HO = RG_HO, NPX = 4 * NV;
+    __shared__ uint32_t s_fix[RG_FIX_CAP];
+    __shared__ int s_nfix;
+    // per workgroup (64 groups): fp64 aw [HO][NPX][64] for the exact loop, then the fp32 weight pairs
+    // [NPX][64] (output 0, output 1) of the guard loop -- one conflict-free ds_read_b64 per pixel instead of
+    // 2 NPX registers per lane (the 8-vector window then still runs at 4+ waves per SIMD with its prefetch)
+    extern __shared__ __attribute__((aligned(16))) double s_aw[];
+    v2f *s_w = reinterpret_cast<v2f *>(s_aw + HO * NPX * 64);
+    const int tid = threadIdx.x;
+    if (tid == 0) s_nfix = 0;
+    // issued before the staging below so that the three latencies overlap (a workgroup is short)
+    const int gc_ = min(static_cast<int>(blockIdx.x) * 64 + (tid & 63), a.ngroups - 1);
+    const int s0_ = a.s0[gc_];
+    const uint32_t ab_ = a.alpha[gc_];
+    {
+        const int g0 = blockIdx.x * 64;
+        for (int e = tid; e < NPX * 64; e += 256) {
+            const int gl = e & 63, i = e >> 6;
+            const bool in = g0 + gl < a.ngroups;
+            s_w[e] = (v2f){in ? a.dense[static_cast<size_t>(i) * a.ngroups + g0 + gl] : 0.0f,
+                           in ? a.dense[static_cast<size_t>(NPX + i) * a.ngroups + g0 + gl] : 0.0f};
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int g = blockIdx.x * 64 + lane;
+    // first row of this wave: provably scalar, so row pointers are SGPR pairs and the window loads need one
+    // 32-bit offset register each
+    const int yw = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * a.rows;
+    const bool active = g < a.ngroups && yw < a.other;
+    uint32_t exact_rows = 0;                                        // bit r: row yw + r of this wave awaits the exact loop
+    if (yw < a.other) {                                             // wave-uniform
+        const int gc = gc_;                                         // idle lanes shadow the last group (no stores)
+        static_assert(HO == 2, "the two outputs of a group ride in the two lanes of the packed FMAs");
+        const int s0 = s0_;                                          // the host keeps s0 + NPX <= srcN (shifted windows)
+        const uint32_t ab = ab_;
+        const int d0 = gc * HO;
+        const bool full = d0 + HO <= a.nout;
+        const bool st8 = full && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 7u) == 0;
+        const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+        const int y1 = min(a.other, yw + a.rows);
+        // NO branch may surround these loads: with one the compiler waits for vmcnt(0) in every iteration and the
+        // prefetch below is lost (row indices are clamped instead of tested)
+        auto load_row = [&](int y, u32x4 (&v)[NV]) {
+            const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+#pragma unroll
+            for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
+        };
+        // a wave walks its rows one after the other, so what it has in flight is what it prefetched: two rows
+        // ahead (the chip needs ~12 MB in flight to stream at HBM rate; one row ahead measured 2.7 TB/s at best)
+        u32x4 vn[PF ? NV : 1], vm[PF ? NV : 1];
+        if constexpr (PF) {
+            load_row(yw, vn);
+            load_row(min(yw + 1, y1 - 1), vm);
+        }
+        // rows whose flags are dense (ramps, flat ties, translucent regions) are left to the exact loop below;
+        // while that lasts only every 4th row still tries the fp32 form (`sticky`)
+        bool sticky = false;
+        for (int y = yw; y < y1; y++) {
+            if (sticky && ((y - yw) & 3) != 0) {
+                exact_rows |= 1u << (y - yw);
+                if constexpr (PF) {
+#pragma unroll
+                    for (int q = 0; q < NV; q++) vn[q] = vm[q];
+                    load_row(min(y + 2, y1 - 1), vm);
+                }
+                continue;
+            }
+            u32x4 v[NV];
+            if constexpr (PF) {
+#pragma unroll
+                for (int q = 0; q < NV; q++) { v[q] = vn[q]; vn[q] = vm[q]; }
+                load_row(min(y + 2, y1 - 1), vm);                   // two rows in flight while this one is used
+            } else {
+                load_row(y, v);
+            }
+            uint32_t andp = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NV; q++) andp &= (v[q][0] & v[q][1]) & (v[q][2] & v[q][3]);
+            v2f accr = {seed, seed}, accg = accr, accb = accr;     // .x: output 0, .y: output 1
+#pragma unroll
+            for (int i = 0; i < NPX; i++) {
+                const uint32_t p = v[i / 4][i % 4];
+                const v2f wi = s_w[i * 64 + lane];
+                accr = fma_bcast(static_cast<float>(p & 0xffu), wi, accr);
+                accg = fma_bcast(static_cast<float>((p >> 8) & 0xffu), wi, accg);
+                accb = fma_bcast(static_cast<float>((p >> 16) & 0xffu), wi, accb);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);       // two pixels' weight reads and converts in flight, not all of them
+            }
+            uint32_t o[HO], o2[HO];
+            const v2f hr = accr + (v2f){g2, g2}, hg = accg + (v2f){g2, g2}, hb = accb + (v2f){g2, g2};
+            fp32_round_toward_zero();
+            o[0] = pk8(accb.x, 2, pk8(accg.x, 1, pk8(accr.x, 0, (ab & 0xffu) << 24)));
+            o[1] = pk8(accb.y, 2, pk8(accg.y, 1, pk8(accr.y, 0, (ab & 0xff00u) << 16)));
+            o2[0] = pk8(hb.x, 2, pk8(hg.x, 1, pk8(hr.x, 0, (ab & 0xffu) << 24)));
+            o2[1] = pk8(hb.y, 2, pk8(hg.y, 1, pk8(hr.y, 0, (ab & 0xff00u) << 16)));
+            fp32_round_nearest();
+            const bool opaque = (andp >> 24) == 0xffu;
+            uint32_t flagged = 0;                                   // bit j: output j awaits the exact recompute
+            if (o[0] != o2[0]) flagged |= 1u;
+            if (o[1] != o2[1]) flagged |= 2u;
+            if (!opaque) flagged = 3u;                              // some alpha != 255 in the window: general arithmetic
+            if (!active) flagged = 0;
+            if (__popcll(__ballot(flagged != 0)) >= RG_DENSE) {     // wave-uniform: the whole row goes to the exact loop
+                exact_rows |= 1u << (y - yw);
+                sticky = true;
+                continue;
+            }
+            sticky = false;
+            if (active) {
+                uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(d0);
+                if (st8 && flagged == 0) {
+                    *(__attribute__((address_space(1))) u32x2 *)dp = (u32x2){o[0], o[1]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HO; j++)
+                        if (d0 + j < a.nout) {
+                            if (!((flagged >> j) & 1u)) {
+                                *(g_u32w *)(dp + 4 * j) = o[j];
+                            } else {
+                                const int e = atomicAdd(&s_nfix, 1);
+                                s_fix[e] = (static_cast<uint32_t>(y - blockIdx.y * 4 * a.rows) << 16) | static_cast<uint32_t>(d0 + j - blockIdx.x * 64 * HO);
+                            }
+                        }
+                }
+            }
+        }
+    }
+    // ---- exact loop: resizeH's own arithmetic (resize.go:93-113) for the marked rows.  Opaque windows:
+    // aw = 255 w and inv = 1 / sum aw are per column, so a row is r += R * aw (unfused, ascending taps; the
+    // dense window's zero weights add +0.0) and clampF(r * inv); other windows: resize_exact_px.  The fp64
+    // weights are staged only now, and only if some wave of the workgroup marked a row.
+    if (__syncthreads_or(exact_rows != 0)) {
+        const int g0 = blockIdx.x * 64;
+        for (int e = tid; e < HO * NPX * 64; e += 256) {
+            const int gl = e & 63, ji = e >> 6;
+            s_aw[e] = g0 + gl < a.ngroups ? a.aw[static_cast<size_t>(ji) * a.ngroups + g0 + gl] : 0.0;
+        }
+        __syncthreads();
+        if (exact_rows) {
+            const int gc = min(g, a.ngroups - 1);
+            const int s0 = a.s0[gc];
+            const uint32_t ab = a.alpha[gc];
+            const int d0 = gc * HO;
+            const bool st8 = d0 + HO <= a.nout && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 7u) == 0;
+            const int y1 = min(a.other, yw + a.rows);
+            auto load_row = [&](int y, u32x4 (&v)[NV]) {
+                const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+#pragma unroll
+                for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
+            };
+            const double inv0 = a.inv[d0], inv1 = a.inv[min(d0 + 1, a.nout - 1)];
+            for (int y = yw; y < y1; y++) {
+                if (!((exact_rows >> (y - yw)) & 1u)) continue;     // wave-uniform
+                u32x4 v[NV];
+                load_row(y, v);
+                uint32_t andp = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < NV; q++) andp &= (v[q][0] & v[q][1]) & (v[q][2] & v[q][3]);
+                uint32_t o0, o1;
+                if (__all((andp >> 24) == 0xffu || !active)) {
+                    double r0 = 0, g0 = 0, b0 = 0, r1 = 0, g1 = 0, b1 = 0;
+#pragma unroll
+                    for (int i = 0; i < NPX; i++) {
+                        const uint32_t p = v[i / 4][i % 4];
+                        const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
+                        const double aw0 = s_aw[i * 64 + lane], aw1 = s_aw[(NPX + i) * 64 + lane];
+                        r0 = r0 + fr * aw0; g0 = g0 + fg * aw0; b0 = b0 + fb * aw0;
+                        r1 = r1 + fr * aw1; g1 = g1 + fg * aw1; b1 = b1 + fb * aw1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    o0 = clampF_dev(r0 * inv0) | (clampF_dev(g0 * inv0) << 8) | (clampF_dev(b0 * inv0) << 16) | ((ab & 0xffu) << 24);
+                    o1 = clampF_dev(r1 * inv1) | (clampF_dev(g1 * inv1) << 8) | (clampF_dev(b1 * inv1) << 16) | ((ab & 0xff00u) << 16);
+                } else {
+                    o0 = resize_exact_px<false>(a, d0, y);
+                    o1 = resize_exact_px<false>(a, min(d0 + 1, a.nout - 1), y);
+                }
+                if (active) {
+                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(d0);
+                    if (st8) {
+                        *(__attribute__((address_space(1))) u32x2 *)dp = (u32x2){o0, o1};
+                    } else {
+                        *(g_u32w *)dp = o0;
+                        if (d0 + 1 < a.nout) *(g_u32w *)(dp + 4) = o1;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // exact outputs for the listed ones (never stored above)
+    const int nfix = s_nfix;
+    const int bx0 = blockIdx.x * 64 * HO, by0 = blockIdx.y * 4 * a.rows;
+    for (int e = tid; e < nfix; e += 256) {
+        const int x = bx0 + static_cast<int>(s_fix[e] & 0xffffu), y = by0 + static_cast<int>(s_fix[e] >> 16);
+        *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = resize_exact_px<false>(a, x, y);
+    }
+}
+
+// V pass: workgroup = 1024 columns (4 per lane: 16-byte loads and stores) x one group of VG output rows; the
+// group's weights are wave-uniform (scalar loads), every source row of the union is loaded -- two rows ahead --
+// and converted once for the VG rows it feeds.  Flags as in the H pass: sparse ones go on the list; an output row
+// with RG_DENSE or more flagged lanes in a wave is left to the exact sweep, which walks the union again (L1 / L2)
+// with fp64 accumulators for all VG rows of a column pair at a time and the dense fp64 weights aw = 255 w
+// (zeros outside a row's taps add +0.0): resizeV's arithmetic for opaque columns (resize.go:137-156); columns
+// with any alpha != 255 in the union call resize_exact_px.  The list holds at most (RG_DENSE - 1) lanes x 4
+// columns per wave and output row.
+constexpr int RG_VPX = 4;
+static_assert(4 * RG_VG * RG_VPX * (RG_DENSE - 1) <= RG_FIX_CAP, "fix-up list capacity");
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
+{
+    constexpr int VG = RG_VG, PX = RG_VPX;
+    __shared__ uint32_t s_fix[RG_FIX_CAP];
+    __shared__ int s_nfix;
+    // the group's weights, [union row][VG]: fp32 for the guard loop, fp64 aw = 255 w for the exact sweep.  The
+    // row loops read them as LDS broadcasts -- a scalar global load per row would put its miss latency (~1 us,
+    // nothing to overlap it with) into every iteration.  The host keeps the union at <= 64 rows.
+    __shared__ __attribute__((aligned(16))) float s_wv[64 * VG];
+    __shared__ __attribute__((aligned(16))) double s_awv[64 * VG];
+    const int tid = threadIdx.x;
+    const int grp = blockIdx.y;
+    if (tid == 0) s_nfix = 0;
+    // every small table read is issued up front: a workgroup is short, and each dependent miss (~1 us) in its
+    // prologue or epilogue would be a tenth of its life
+    const int s0 = a.s0[grp], nr = a.cnt[grp];                      // wave-uniform
+    uint32_t alv[VG];
+    double invv[VG];
+#pragma unroll
+    for (int j = 0; j < VG; j++) {
+        const int yy = min(grp * VG + j, a.nout - 1);
+        alv[j] = a.alpha[yy];
+        invv[j] = a.inv[yy];
+    }
+    {
+        const int nw = nr * VG;
+        if (tid < nw) {
+            s_wv[tid] = a.dense[static_cast<size_t>(grp) * a.npx * VG + tid];
+            s_awv[tid] = a.aw[static_cast<size_t>(grp) * a.npx * VG + tid];
+        }
+    }
+    __syncthreads();
+    const int xw = (blockIdx.x * 256 + (tid & ~63)) * PX;           // first column of this wave
+    const int y0 = grp * VG;
+    if (xw < a.other) {                                             // wave-uniform
+        const int xl = (blockIdx.x * 256 + tid) * PX;
+        const bool active = xl < a.other;
+        // a lane whose 4 columns would stick out of the image shifts left (the host keeps other >= 4): it then
+        // recomputes columns its neighbour owns and stores the same values -- no branch around the loads (see
+        // the H pass).  ALIGNED: src base, stride and other % 4 allow 16-byte loads at every lane.
+        const int x = min(xl, a.other - PX);
+        const int ncol = active ? PX : 0;
+        const uint8_t *col = a.src + 4 * static_cast<size_t>(x);
+        auto load = [&](int s) -> u32x4 {
+            const uint8_t *p = col + static_cast<size_t>(s) * a.sstride;
+            if constexpr (ALIGNED) {
+                return *(g_u32x4 *)p;
+            } else {
+                return (u32x4){*(g_u32 *)p, *(g_u32 *)(p + 4), *(g_u32 *)(p + 8), *(g_u32 *)(p + 12)};
+            }
+        };
+        const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+        v2f acc[VG][6];                                             // (r0,g0) (b0,r1) (g1,b1) (r2,g2) (b2,r3) (g3,b3)
+#pragma unroll
+        for (int j = 0; j < VG; j++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc[j][q] = (v2f){seed, seed};
+        u32x4 andp = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        // four source rows in flight per lane (see the H pass: a wave's own prefetch is all it has outstanding)
+        u32x4 t1 = load(s0), t2 = load(s0 + min(1, nr - 1)), t3 = load(s0 + min(2, nr - 1)), t4 = load(s0 + min(3, nr - 1));
+        for (int i = 0; i < nr; i++) {
+            const u32x4 t = t1;
+            t1 = t2; t2 = t3; t3 = t4;
+            t4 = load(s0 + min(i + 4, nr - 1));
+            andp &= t;
+            v2f f[6];
+            f[0] = (v2f){static_cast<float>(t[0] & 0xffu), static_cast<float>((t[0] >> 8) & 0xffu)};
+            f[1] = (v2f){static_cast<float>((t[0] >> 16) & 0xffu), static_cast<float>(t[1] & 0xffu)};
+            f[2] = (v2f){static_cast<float>((t[1] >> 8) & 0xffu), static_cast<float>((t[1] >> 16) & 0xffu)};
+            f[3] = (v2f){static_cast<float>(t[2] & 0xffu), static_cast<float>((t[2] >> 8) & 0xffu)};
+            f[4] = (v2f){static_cast<float>((t[2] >> 16) & 0xffu), static_cast<float>(t[3] & 0xffu)};
+            f[5] = (v2f){static_cast<float>((t[3] >> 8) & 0xffu), static_cast<float>((t[3] >> 16) & 0xffu)};
+#pragma unroll
+            for (int j = 0; j < VG; j++) {
+                const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wv[i * VG + j])));
+#pragma unroll
+                for (int q = 0; q < 6; q++) acc[j][q] = __builtin_elementwise_fma(f[q], (v2f){wj, wj}, acc[j][q]);
+            }
+        }
+        // windows are per output row; the union's AND is a conservative opacity test for all VG of them
+        uint32_t opq = 0;                                           // bit e: column e is opaque over the union
+#pragma unroll
+        for (int e = 0; e < PX; e++)
+            if ((andp[e] >> 24) == 0xffu) opq |= 1u << e;
+        const uint32_t own = (1u << ncol) - 1u;
+        const bool st16 = ALIGNED && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 15u) == 0;
+        uint32_t dense_rows = 0;
+#pragma unroll
+        for (int j = 0; j < VG; j++) {
+            const int y = y0 + j;
+            if (y < a.nout) {                                       // wave-uniform
+                const uint32_t al = alv[j];
+                u32x4 o, p;
+                fp32_round_toward_zero();
+                o[0] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al)));
+                o[1] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al)));
+                o[2] = pk8(acc[j][4].x, 2, pk8(acc[j][3].y, 1, pk8(acc[j][3].x, 0, al)));
+                o[3] = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, al)));
+                fp32_round_nearest();
+                v2f h[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) h[q] = acc[j][q] + (v2f){g2, g2};
+                fp32_round_toward_zero();
+                p[0] = pk8(h[1].x, 2, pk8(h[0].y, 1, pk8(h[0].x, 0, al)));
+                p[1] = pk8(h[2].y, 2, pk8(h[2].x, 1, pk8(h[1].y, 0, al)));
+                p[2] = pk8(h[4].x, 2, pk8(h[3].y, 1, pk8(h[3].x, 0, al)));
+                p[3] = pk8(h[5].y, 2, pk8(h[5].x, 1, pk8(h[4].y, 0, al)));
+                fp32_round_nearest();
+                uint32_t fl = ~opq;                                 // bit e: column e awaits the exact recompute
+#pragma unroll
+                for (int e = 0; e < PX; e++)
+                    if (o[e] != p[e]) fl |= 1u << e;
+                fl &= own;
+                if (__popcll(__ballot(fl != 0)) >= RG_DENSE) {      // wave-uniform: this row goes to the exact sweep
+                    dense_rows |= 1u << j;
+                    continue;
+                }
+                if (active) {
+                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
+                    if (st16 && fl == 0) {
+                        *(g_u32x4w *)dp = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < PX; e++)
+                            if (e < ncol) {
+                                if (!((fl >> e) & 1u)) *(g_u32w *)(dp + 4 * e) = o[e];
+                                else s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(j) << 28) | static_cast<uint32_t>(x + e);   // absolute column (< 2^24)
+                            }
+                    }
+                }
+            }
+        }
+        if (dense_rows) {                                           // wave-uniform
+#pragma unroll 1
+            for (int c = 0; c < PX; c += 2) {                       // a column pair at a time: 24 fp64 accumulators
+                double r[VG][6];
+#pragma unroll
+                for (int j = 0; j < VG; j++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) r[j][q] = 0.0;
+                const int c0 = min(c, max(ncol - 1, 0)), c1 = min(c + 1, max(ncol - 1, 0));
+#pragma unroll 1
+                for (int i = 0; i < nr; i++) {
+                    const uint8_t *pp = col + static_cast<size_t>(s0 + i) * a.sstride;
+                    const uint32_t q0 = *(g_u32 *)(pp + 4 * c0), q1 = *(g_u32 *)(pp + 4 * c1);
+                    const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                    const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+#pragma unroll
+                    for (int j = 0; j < VG; j++) {
+                        const double aw = s_awv[i * VG + j];        // 255 w, or 0.0 outside row j's taps
+                        r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                        r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VG; j++) {
+                    const int y = y0 + j;
+                    if (!((dense_rows >> j) & 1u) || !active) continue;
+                    const uint32_t al = alv[j];
+                    const double inv = invv[j];
+                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
+                    if (c < ncol)
+                        *(g_u32w *)(dp + 4 * c) = ((opq >> c) & 1u)
+                            ? clampF_dev(r[j][0] * inv) | (clampF_dev(r[j][1] * inv) << 8) | (clampF_dev(r[j][2] * inv) << 16) | al
+                            : resize_exact_px<true>(a, x + c, y);
+                    if (c + 1 < ncol)
+                        *(g_u32w *)(dp + 4 * (c + 1)) = ((opq >> (c + 1)) & 1u)
+                            ? clampF_dev(r[j][3] * inv) | (clampF_dev(r[j][4] * inv) << 8) | (clampF_dev(r[j][5] * inv) << 16) | al
+                            : resize_exact_px<true>(a, x + c + 1, y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nfix = s_nfix;
+    for (int e = tid; e < nfix; e += 256) {
+        const int xx = static_cast<int>(s_fix[e] & 0x0fffffffu), y = y0 + static_cast<int>(s_fix[e] >> 28);
+        *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xx)) = resize_exact_px<true>(a, xx, y);
+    }
+}
+
 // max taps of any output (0: indices not contiguous somewhere) -- host tables
 int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout)
 {
@@ -264,6 +774,333 @@ int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout)
         if (n > maxn) maxn = n;
     }
     return maxn;
+}
+
+}  // namespace fnx
+
+// ------------------------------------------------------------------------------------
+// resize plans: what one tap table turns into on the device, built once per (table, direction) and ctx
+// ------------------------------------------------------------------------------------
+struct fnx_resize_plan {
+    // key
+    uint64_t id = 0;                 // != 0: an immutable table of host_api's cache (no content compare)
+    bool vertical = false;
+    int nout = 0, srcN = 0;
+    std::vector<int32_t> k_off, k_idx;   // id == 0: copy of the caller's table, compared on every call
+    std::vector<double> k_wt;
+    uint64_t last_use = 0;
+    // device blob
+    void *blob = nullptr;
+    const int32_t *d_off = nullptr, *d_idx = nullptr;
+    const double *d_wt = nullptr;
+    int contig_taps = 0;
+    // guard form
+    bool guard_ok = false;
+    int HO = 0, NV = 0, ngroups = 0, npx = 0;
+    float guard = 0;
+    const float *d_dense = nullptr;
+    const int32_t *d_s0 = nullptr, *d_cnt = nullptr;
+    const uint32_t *d_alpha = nullptr;
+    const double *d_aw = nullptr, *d_inv = nullptr;
+};
+
+namespace fnx {
+
+void free_resize_plans(fnx_ctx *ctx)
+{
+    for (fnx_resize_plan *p : ctx->rplans) {
+        if (p->blob) (void)hipFree(p->blob);
+        delete p;
+    }
+    ctx->rplans.clear();
+}
+
+static bool resize_guard_disabled()
+{
+    const char *e = getenv("FNX_RESIZE_FP64");      // A/B and tests: "1" keeps the round-1 fp64 kernels
+    return e && e[0] == '1';
+}
+
+// Host side of the guard form.  Returns false when the table is outside what the guard kernels cover
+// (gaps in the tap lists, windows too wide for the register matrix, a <= 0.5 somewhere, wild weights).
+static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_plan &p, std::vector<float> &dense,
+                        std::vector<int32_t> &s0v, std::vector<int32_t> &cntv, std::vector<uint32_t> &alphav,
+                        std::vector<double> &awv, std::vector<double> &invv)
+{
+    const int nout = t.nout;
+    if (p.contig_taps <= 0) return false;
+    // per output: start, count, normalised fp32 weights, alpha byte
+    double smax = 0;
+    std::vector<uint32_t> abyte(nout);
+    invv.assign(nout, 0.0);
+    for (int d = 0; d < nout; d++) {
+        const int t0 = t.off[d], n = t.off[d + 1] - t0;
+        if (n < 1) return false;
+        double a = 0;
+        for (int k = 0; k < n; k++) {
+            const double aw = 255.0 * t.wt[t0 + k];                 // sa * w with sa = 255 (resize.go:95-96)
+            if (!std::isfinite(aw)) return false;
+            a += aw;
+        }
+        if (!(a > 0.5) || !std::isfinite(a)) return false;          // resize.go:107
+        const double inv = 1.0 / a;
+        invv[d] = inv;
+        double sabs = 0;
+        for (int k = 0; k < n; k++) sabs += std::fabs(255.0 * t.wt[t0 + k] * inv);
+        if (sabs > smax) smax = sabs;
+        double r = std::trunc(a);                                    // clampF(a)
+        if (std::fabs(a - r) >= 0.5) r += 1.0;
+        abyte[d] = static_cast<uint32_t>(std::fmin(std::fmax(r, 0.0), 255.0));
+    }
+    if (!(smax < 8.0)) return false;
+    auto wnorm = [&](int d, int k) {                                 // W_k = aw_k * inv in fp64, then fp32
+        const int t0 = t.off[d], n = t.off[d + 1] - t0;
+        double a = 0;
+        for (int q = 0; q < n; q++) a += 255.0 * t.wt[t0 + q];
+        return static_cast<float>(255.0 * t.wt[t0 + k] * (1.0 / a));
+    };
+    int nfma = 0;
+    if (!vertical) {
+        // groups of HO adjacent outputs, union window of 4 NV pixels (NV <= 8: 64 weights per lane)
+        constexpr int HO = RG_HO;
+        int need = 0;
+        for (int d0 = 0; d0 < nout; d0 += HO) {
+            const int s0 = t.idx[t.off[d0]];
+            int end = s0;
+            for (int j = 0; j < HO && d0 + j < nout; j++) {
+                const int tj = t.off[d0 + j], nj = t.off[d0 + j + 1] - tj;
+                if (t.idx[tj] < s0) return false;                    // windows must not start before the group's first
+                end = std::max(end, t.idx[tj] + nj);
+            }
+            need = std::max(need, end - s0);
+        }
+        int NV = std::max(2, (need + 3) / 4);
+        if (NV > 8 || srcN < 4 * NV) return false;                   // (tiny sources keep the fp64 kernels)
+        const int NPX = 4 * NV, ng = (nout + HO - 1) / HO;
+        dense.assign(static_cast<size_t>(HO) * NPX * ng, 0.0f);
+        awv.assign(static_cast<size_t>(HO) * NPX * ng, 0.0);
+        s0v.assign(ng, 0);
+        alphav.assign(ng, 0);
+        for (int g = 0; g < ng; g++) {
+            // the kernels always read 4 NV pixels from s0: a window that would stick out of the row starts earlier
+            // (its extra leading pixels get zero weights)
+            const int d0 = g * HO, s0 = std::min(t.idx[t.off[d0]], srcN - NPX);
+            s0v[g] = s0;
+            for (int j = 0; j < HO && d0 + j < nout; j++) {
+                const int tj = t.off[d0 + j], nj = t.off[d0 + j + 1] - tj;
+                for (int k = 0; k < nj; k++) {
+                    dense[static_cast<size_t>(j * NPX + (t.idx[tj] - s0 + k)) * ng + g] = wnorm(d0 + j, k);
+                    awv[static_cast<size_t>(j * NPX + (t.idx[tj] - s0 + k)) * ng + g] = 255.0 * t.wt[tj + k];
+                }
+                alphav[g] |= abyte[d0 + j] << (8 * j);
+            }
+        }
+        p.HO = HO; p.NV = NV; p.ngroups = ng; p.npx = NPX;
+        nfma = NPX;
+    } else {
+        constexpr int VG = RG_VG;
+        const int ng = (nout + VG - 1) / VG;
+        int need = 0;
+        s0v.assign(ng, 0);
+        cntv.assign(ng, 0);
+        for (int g = 0; g < ng; g++) {
+            const int d0 = g * VG;
+            int s0 = 1 << 30, end = 0;
+            for (int j = 0; j < VG && d0 + j < nout; j++) {
+                const int tj = t.off[d0 + j], nj = t.off[d0 + j + 1] - tj;
+                s0 = std::min(s0, t.idx[tj]);
+                end = std::max(end, t.idx[tj] + nj);
+            }
+            s0v[g] = s0;
+            cntv[g] = end - s0;
+            need = std::max(need, end - s0);
+        }
+        if (need > 64) return false;                                 // a lane per union row (resize_v_guard_kernel)
+        dense.assign(static_cast<size_t>(ng) * need * VG, 0.0f);
+        awv.assign(static_cast<size_t>(ng) * need * VG, 0.0);
+        for (int g = 0; g < ng; g++)
+            for (int j = 0; j < VG && g * VG + j < nout; j++) {
+                const int d = g * VG + j, tj = t.off[d], nj = t.off[d + 1] - tj;
+                for (int k = 0; k < nj; k++) {
+                    dense[(static_cast<size_t>(g) * need + (t.idx[tj] - s0v[g] + k)) * VG + j] = wnorm(d, k);
+                    awv[(static_cast<size_t>(g) * need + (t.idx[tj] - s0v[g] + k)) * VG + j] = 255.0 * t.wt[tj + k];
+                }
+            }
+        alphav.resize(nout);
+        for (int d = 0; d < nout; d++) alphav[d] = abyte[d] << 24;
+        p.HO = VG; p.NV = 0; p.ngroups = ng; p.npx = need;
+        nfma = need;
+    }
+    // the bound of the header comment
+    const double top = 255.0 * smax + 1.0;
+    const double half_ulp = std::ldexp(1.0, static_cast<int>(std::ceil(std::log2(top))) - 24);
+    const double E = 255.0 * smax * std::ldexp(1.0, -24) + (nfma + 1) * half_ulp;
+    const double G = E + half_ulp + 1e-6;
+    if (!(G < 0.05)) return false;
+    float gf = static_cast<float>(G);
+    if (static_cast<double>(gf) < G) gf = std::nextafterf(gf, 1.0f);
+    p.guard = gf;
+    (void)srcN;
+    return true;
+}
+
+static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool vertical, fnx_resize_plan **out)
+{
+    FNX_REQUIRE(t.off && t.idx && t.wt && t.nout > 0, "tap table is null");
+    const int ntaps = t.off[t.nout];
+    FNX_REQUIRE(ntaps >= 0, "tap table offsets");
+    static std::atomic<uint64_t> tick{1};
+    for (fnx_resize_plan *p : ctx->rplans) {
+        if (p->vertical != vertical || p->nout != t.nout || p->srcN != srcN) continue;
+        bool same;
+        if (t.id != 0 || p->id != 0) {
+            same = t.id == p->id;
+        } else {
+            same = static_cast<int>(p->k_idx.size()) == ntaps &&
+                   std::memcmp(p->k_off.data(), t.off, sizeof(int32_t) * (t.nout + 1)) == 0 &&
+                   std::memcmp(p->k_idx.data(), t.idx, sizeof(int32_t) * ntaps) == 0 &&
+                   std::memcmp(p->k_wt.data(), t.wt, sizeof(double) * ntaps) == 0;
+        }
+        if (same) {
+            p->last_use = tick++;
+            *out = p;
+            return FNX_OK;
+        }
+    }
+    // indices must address the source (the kernels do not check per tap)
+    for (int i = 0; i < ntaps; i++) FNX_REQUIRE(t.idx[i] >= 0 && t.idx[i] < srcN, "tap index outside the source");
+    for (int d = 0; d < t.nout; d++) FNX_REQUIRE(t.off[d + 1] >= t.off[d], "tap table offsets");
+    if (ctx->rplans.size() >= 8) {                                   // evict the least recently used
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx->rplans.size(); i++)
+            if (ctx->rplans[i]->last_use < ctx->rplans[victim]->last_use) victim = i;
+        FNX_HIP(hipStreamSynchronize(ctx->stream));                  // queued kernels may still read its tables
+        if (ctx->rplans[victim]->blob) FNX_HIP(hipFree(ctx->rplans[victim]->blob));
+        delete ctx->rplans[victim];
+        ctx->rplans.erase(ctx->rplans.begin() + victim);
+    }
+    std::unique_ptr<fnx_resize_plan> p(new fnx_resize_plan());
+    p->id = t.id; p->vertical = vertical; p->nout = t.nout; p->srcN = srcN;
+    if (t.id == 0) {
+        p->k_off.assign(t.off, t.off + t.nout + 1);
+        p->k_idx.assign(t.idx, t.idx + ntaps);
+        p->k_wt.assign(t.wt, t.wt + ntaps);
+    }
+    p->contig_taps = resize_contiguous_taps(t.off, t.idx, t.nout);
+    std::vector<float> dense;
+    std::vector<int32_t> s0v, cntv;
+    std::vector<uint32_t> alphav;
+    std::vector<double> awv, invv;
+    p->guard_ok = build_guard(t, srcN, vertical, *p, dense, s0v, cntv, alphav, awv, invv);
+    if (!p->guard_ok) { dense.clear(); s0v.clear(); cntv.clear(); alphav.clear(); awv.clear(); invv.clear(); }
+    // one blob: wt | off | idx | dense | s0 | cnt | alpha | aw | inv, each 16-byte aligned
+    auto al16 = [](size_t n) { return (n + 15) & ~size_t(15); };
+    const size_t b_wt = al16(sizeof(double) * std::max(ntaps, 1)), b_off = al16(sizeof(int32_t) * (t.nout + 1)),
+                 b_idx = al16(sizeof(int32_t) * std::max(ntaps, 1)), b_dense = al16(sizeof(float) * dense.size()),
+                 b_s0 = al16(sizeof(int32_t) * s0v.size()), b_cnt = al16(sizeof(int32_t) * cntv.size()),
+                 b_alpha = al16(sizeof(uint32_t) * alphav.size()), b_aw = al16(sizeof(double) * awv.size()),
+                 b_inv = al16(sizeof(double) * invv.size());
+    const size_t total = b_wt + b_off + b_idx + b_dense + b_s0 + b_cnt + b_alpha + b_aw + b_inv + 16;
+    std::vector<unsigned char> host(total, 0);
+    size_t o = 0;
+    std::memcpy(host.data() + o, t.wt, sizeof(double) * ntaps); const size_t o_wt = o; o += b_wt;
+    std::memcpy(host.data() + o, t.off, sizeof(int32_t) * (t.nout + 1)); const size_t o_off = o; o += b_off;
+    std::memcpy(host.data() + o, t.idx, sizeof(int32_t) * ntaps); const size_t o_idx = o; o += b_idx;
+    if (!dense.empty()) std::memcpy(host.data() + o, dense.data(), sizeof(float) * dense.size());
+    const size_t o_dense = o; o += b_dense;
+    if (!s0v.empty()) std::memcpy(host.data() + o, s0v.data(), sizeof(int32_t) * s0v.size());
+    const size_t o_s0 = o; o += b_s0;
+    if (!cntv.empty()) std::memcpy(host.data() + o, cntv.data(), sizeof(int32_t) * cntv.size());
+    const size_t o_cnt = o; o += b_cnt;
+    if (!alphav.empty()) std::memcpy(host.data() + o, alphav.data(), sizeof(uint32_t) * alphav.size());
+    const size_t o_alpha = o; o += b_alpha;
+    if (!awv.empty()) std::memcpy(host.data() + o, awv.data(), sizeof(double) * awv.size());
+    const size_t o_aw = o; o += b_aw;
+    if (!invv.empty()) std::memcpy(host.data() + o, invv.data(), sizeof(double) * invv.size());
+    const size_t o_inv = o;
+    FNX_HIP(hipMalloc(&p->blob, total));
+    // synchronous copy: the host vector dies with this call (plans are built once per table and ctx)
+    hipError_t e = hipMemcpy(p->blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(p->blob);
+        set_error("hipMemcpy of a resize plan failed: %s", hipGetErrorString(e));
+        return FNX_ERR_HIP;
+    }
+    const unsigned char *base = static_cast<const unsigned char *>(p->blob);
+    p->d_wt = reinterpret_cast<const double *>(base + o_wt);
+    p->d_off = reinterpret_cast<const int32_t *>(base + o_off);
+    p->d_idx = reinterpret_cast<const int32_t *>(base + o_idx);
+    p->d_dense = reinterpret_cast<const float *>(base + o_dense);
+    p->d_s0 = reinterpret_cast<const int32_t *>(base + o_s0);
+    p->d_cnt = reinterpret_cast<const int32_t *>(base + o_cnt);
+    p->d_alpha = reinterpret_cast<const uint32_t *>(base + o_alpha);
+    p->d_aw = reinterpret_cast<const double *>(base + o_aw);
+    p->d_inv = reinterpret_cast<const double *>(base + o_inv);
+    p->last_use = tick++;
+    *out = p.get();
+    ctx->rplans.push_back(p.release());
+    return FNX_OK;
+}
+
+template <int NV>
+static void launch_h_guard(fnx_ctx *ctx, const ResizeGuardArgs &ga, dim3 grid)
+{
+    // the next row's window is prefetched while the registers allow it
+    hipLaunchKernelGGL((resize_h_guard_kernel<NV, (NV <= 5)>), grid, dim3(256), (sizeof(double) * RG_HO + 2 * sizeof(float)) * 4 * NV * 64, ctx->stream, ga);
+}
+
+// one pass of lanczosResize: resizeH (vertical == false: src is srcW x srcH, dst outN x srcH) or resizeV
+// (src is srcW x srcH, dst srcW x outN); t.nout == outN
+int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
+                uint8_t *dst, int dstride)
+{
+    if (t.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_OK;
+    fnx_resize_plan *p = nullptr;
+    FNX_TRY(get_resize_plan(ctx, t, vertical ? srcH : srcW, vertical, &p));
+    const int other = vertical ? srcW : srcH;
+    FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
+    if (p->guard_ok && !resize_guard_disabled() && (!vertical || other >= RG_VPX)) {
+        ResizeGuardArgs ga{};
+        ga.src = src; ga.dst = dst; ga.sstride = sstride; ga.dstride = dstride;
+        ga.srcN = vertical ? srcH : srcW; ga.nout = t.nout; ga.other = other;
+        ga.ngroups = p->ngroups; ga.npx = p->npx; ga.guard = p->guard;
+        ga.dense = p->d_dense; ga.s0 = p->d_s0; ga.cnt = p->d_cnt; ga.alpha = p->d_alpha;
+        ga.off = p->d_off; ga.idx = p->d_idx; ga.wt = p->d_wt;
+        ga.aw = p->d_aw; ga.inv = p->d_inv;
+        if (vertical) {
+            const dim3 grid((other + 256 * RG_VPX - 1) / (256 * RG_VPX), p->ngroups);
+            const bool al = (other % RG_VPX) == 0 && ((reinterpret_cast<uintptr_t>(src) | static_cast<uintptr_t>(sstride)) & 15u) == 0;
+            if (al) hipLaunchKernelGGL(resize_v_guard_kernel<true>, grid, dim3(256), 0, ctx->stream, ga);
+            else hipLaunchKernelGGL(resize_v_guard_kernel<false>, grid, dim3(256), 0, ctx->stream, ga);
+        } else {
+            // rows per lane: the weight matrix is loaded once per lane, so long walks amortise it; short
+            // ones fill the chip (>= ~2 workgroups per CU)
+            int rows = 16;
+            const int gx = (p->ngroups + 63) / 64;
+            while (rows > 2 && static_cast<long>(gx) * ((other + 4 * rows - 1) / (4 * rows)) < 2L * ctx->num_cus) rows >>= 1;
+            if (const char *e = getenv("FNX_RH_ROWS")) rows = std::max(1, std::min(16, atoi(e)));   // experiments
+            ga.rows = rows;
+            const dim3 grid(gx, (other + 4 * rows - 1) / (4 * rows));
+            switch (p->NV) {
+            case 2: launch_h_guard<2>(ctx, ga, grid); break;
+            case 3: launch_h_guard<3>(ctx, ga, grid); break;
+            case 4: launch_h_guard<4>(ctx, ga, grid); break;
+            case 5: launch_h_guard<5>(ctx, ga, grid); break;
+            case 6: launch_h_guard<6>(ctx, ga, grid); break;
+            case 7: launch_h_guard<7>(ctx, ga, grid); break;
+            case 8: launch_h_guard<8>(ctx, ga, grid); break;
+            default: set_error("resize plan: no kernel for NV=%d", p->NV); return FNX_ERR_INVALID;
+            }
+        }
+        FNX_HIP(hipGetLastError());
+        return prof_end(ctx);
+    }
+    // fp64 kernels of round 1
+    int rc;
+    if (vertical) rc = launch_resize_v(ctx, src, sstride, srcW, srcH, p->d_off, p->d_idx, p->d_wt, dst, dstride, t.nout, p->contig_taps);
+    else rc = launch_resize_h(ctx, src, sstride, srcW, srcH, p->d_off, p->d_idx, p->d_wt, dst, dstride, t.nout, p->contig_taps);
+    if (rc < 0) return rc;
+    return prof_end(ctx);
 }
 
 // contig_taps: resize_contiguous_taps() of the H table (0: unknown / not contiguous)

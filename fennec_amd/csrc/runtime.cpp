@@ -266,6 +266,7 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
             if (q.ev) (void)hipEventDestroy(q.ev);
         for (auto &rb : ctx->res_buf)
             if (rb.p) (void)hipHostFree(rb.p);
+        free_resize_plans(ctx);
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
                 if (e) (void)hipEventDestroy(e);

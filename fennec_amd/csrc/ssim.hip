@@ -658,8 +658,8 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
         qa[k] = *(g_u32 *)(pa + static_cast<size_t>(rr) * a.astride);
         qb[k] = *(g_u32 *)(pb + static_cast<size_t>(rr) * a.bstride);
     }
-    pa += static_cast<size_t>(WM_PF) * a.astride;                 // -> row i + WM_PF
-    pb += static_cast<size_t>(WM_PF) * a.bstride;
+    pa += static_cast<size_t>(min(WM_PF, nrows - 1)) * a.astride;   // -> row i + WM_PF (clamped to the segment)
+    pb += static_cast<size_t>(min(WM_PF, nrows - 1)) * a.bstride;
     constexpr double C1 = 6.5025e6, C2 = 58.5225e6;              // (0.01 * 255)^2, (0.03 * 255)^2 in milli-luminance^2
 
     for (int r = 0; r < nrows; r += 8) {
@@ -668,9 +668,11 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
             const int i = r + p;
             if (i < nrows) {                                      // wave-uniform
                 const double va = lum_milli(qa[p % WM_PF]), vb = lum_milli(qb[p % WM_PF]);
-                if (i + WM_PF < nrows) {
-                    qa[p % WM_PF] = *(g_u32 *)pa;
-                    qb[p % WM_PF] = *(g_u32 *)pb;
+                // no branch around these loads (the compiler would wait for vmcnt(0) every row and lose the
+                // prefetch): past the segment's last row the pointers simply stop advancing
+                qa[p % WM_PF] = *(g_u32 *)pa;
+                qb[p % WM_PF] = *(g_u32 *)pb;
+                if (i + WM_PF + 1 < nrows) {
                     pa += a.astride;
                     pb += a.bstride;
                 }

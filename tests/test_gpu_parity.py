@@ -189,6 +189,64 @@ def test_lanczos_resize(ctx, orc, name):
     assert ctx.lanczosResize(img, 0, 50).shape[:2] == (0, 0)       # fennec_test.go:554-560
 
 
+def _opaque(img):
+    out = img.copy()
+    out[..., 3] = 255
+    return out
+
+
+@pytest.mark.parametrize("w,h,dw,dh", [(640, 480, 320, 240), (640, 480, 1280, 960), (517, 389, 300, 211), (300, 200, 100, 67),
+                                       (1000, 64, 231, 64), (64, 1000, 64, 231), (777, 333, 176, 75), (800, 600, 107, 80),
+                                       (130, 90, 195, 135), (33, 9, 66, 18), (2, 2, 5, 5), (1920, 1080, 960, 540)])
+def test_lanczos_resize_guard_kernels(ctx, orc, w, h, dw, dh):
+    """Opaque images take the fp32 kernels with the rounding guard (ratios 0.4 .. 7.5: window shapes NV = 2 .. 8 and
+    the fp64 fallback beyond): bit-exact against the oracle, on noise, on a soft image and on content built from
+    exact ties (two-level stripes at an integer ratio: every output is (a + b) / 2 with a + b odd)."""
+    noise = _opaque(synth.noise_image(w, h, w + dw, alpha=True))
+    photo = synth.large_photo(w, h, 1)
+    stripes = np.empty((h, w, 4), np.uint8)
+    stripes[:, 0::2] = (100, 7, 250, 255)
+    stripes[:, 1::2] = (101, 8, 255, 255)
+    stripes[1::2, :, :3] += 1                                    # and odd rows one level up: ties in the V pass too
+    holes = noise.copy()
+    holes[h // 3: h // 2, w // 4: w // 2, 3] = 17                # a translucent patch: those windows take the general path
+    for img in (noise, photo, stripes, holes):
+        assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh))
+
+
+def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
+    """Random geometries, device views with odd strides: the guard kernels against the round-1 fp64 kernels
+    (FNX_RESIZE_FP64=1), which follow the reference's operation order."""
+    import torch
+    rng = np.random.default_rng(3)
+    for _ in range(24):
+        w, h = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        dw, dh = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+        img = _opaque(synth.noise_image(w, h, w * 7 + h, alpha=True))
+        if rng.random() < 0.3:
+            img[rng.integers(0, h), rng.integers(0, w), 3] = 0
+        pad = int(rng.integers(0, 3))
+        big = torch.from_numpy(np.ascontiguousarray(np.pad(img, ((0, 0), (pad, 3 - pad), (0, 0))))).cuda()
+        view = big[:, pad: pad + w]
+        monkeypatch.delenv("FNX_RESIZE_FP64", raising=False)
+        got = ctx.lanczosResize(img, dw, dh)
+        got_view = ctx.lanczosResize(view, dw, dh).cpu().numpy()
+        monkeypatch.setenv("FNX_RESIZE_FP64", "1")
+        want = ctx.lanczosResize(img, dw, dh)
+        monkeypatch.delenv("FNX_RESIZE_FP64", raising=False)
+        assert np.array_equal(got, want), (w, h, dw, dh)
+        assert np.array_equal(got_view, want), (w, h, dw, dh, "view")
+
+
+def test_resize_plan_cache_eviction(ctx, orc):
+    """More distinct tables than the ctx keeps plans for (8), revisited: results stay those of the oracle."""
+    img = _opaque(synth.noise_image(240, 180, 2, alpha=True))
+    sizes = [(120 + 7 * k, 90 + 5 * k) for k in range(7)]
+    for rnd in range(2):
+        for dw, dh in sizes:
+            assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh)), (rnd, dw, dh)
+
+
 def test_resize_passes_with_explicit_tables(ctx, orc):
     img = synth.make_test_image_with_alpha(120, 90)
     tab = orc.precompute_weights(50, 120)

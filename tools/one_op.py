@@ -15,6 +15,8 @@ W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (7680, 432
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 ctx = fennec_amd.Context(0)
 imgs = [torch.from_numpy(synth.large_photo(W, H, k)).cuda() for k in range(3)]
+if os.environ.get("ONE_OP_SOFT") == "1":      # blurred noise: photograph-like statistics (no exact ties)
+    imgs = [ctx.GaussianBlur(ctx.GaussianBlur(torch.from_numpy(synth.noise_image(W, H, 5 + k)).cuda(), 2.0), 1.2) for k in range(3)]
 other = [ctx.AdaptiveSharpen(i, 0.5) for i in imgs]
 half = [ctx.lanczosResize(i, W // 2, H // 2) for i in imgs]
 ctx.sync()
