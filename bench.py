@@ -458,6 +458,48 @@ def main() -> int:
     return 0
 
 
+def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
+    """step() over `imgs` with `nctx` worker threads, one fnx ctx (= HIP stream + scratch) each, items taken from
+    a shared index -- CompressBatch's worker pool (batch.go:84-123) on one GPU.  The per-image ops of configs 3
+    and 4 are chains of short kernels with a host round trip at the end (the score): one context leaves the GPU
+    idle between them, several keep independent images in flight.  ctypes releases the GIL inside every call."""
+    import threading
+    nctx = max(1, min(nctx, len(imgs)))
+    ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
+    if nctx == 1:
+        return lambda: [one(ctx0, a) for a in imgs]
+
+    def step():
+        out = [None] * len(imgs)
+        nxt = [0]
+        lock = threading.Lock()
+        err = []
+
+        def run(c):
+            import torch
+            torch.cuda.set_device(device)
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= len(imgs):
+                    return
+                try:
+                    out[i] = one(c, imgs[i])
+                except Exception as e:      # surfaced below
+                    err.append(e)
+                    return
+        ts = [threading.Thread(target=run, args=(c,)) for c in ctxs]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+    return step
+
+
 def other_workloads(args) -> int:
     """BASELINE.json configs 3, 4, 5 (parity-test cases, not the headline bench line): same
     timing protocol, one JSON line.  Per-image C-ABI calls on device-resident tensors."""
@@ -479,12 +521,11 @@ def other_workloads(args) -> int:
         imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 193.4e6     # 41.47 (down) + 41.47 (implicit up) + 110.5 (MSSSIM) MB
 
-        def step():
-            out = []
-            for a in imgs:
-                small = ctx.lanczosResize(a, W // 2, H // 2)
-                out.append(ctx.MSSSIM(a, small))       # ssim.go:320-322 resizes `small` back to 4K
-            return out
+        def one(c, a):
+            small = c.lanczosResize(a, W // 2, H // 2)
+            return c.MSSSIM(a, small)                   # ssim.go:320-322 resizes `small` back to 4K
+
+        step = _pooled_step(fennec_amd, local_rank, ctx, imgs, one, args.contexts)
         metric, unit, units_per_step = "megapixels/sec: 4K -> 1920x1080 Lanczos-3 downscale + MS-SSIM", "MP/s", B * W * H / 1e6
         name = "config3: 4K lanczosResize(1920x1080) + MSSSIM(4K, 1080p)"
     elif wl == "config4":
@@ -492,12 +533,10 @@ def other_workloads(args) -> int:
         imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 530.84e6
 
-        def step():
-            out = []
-            for a in imgs:
-                c = ctx.AdaptiveSharpen(a, 0.5)
-                out.append(ctx.SSIM(a, c))
-            return out
+        def one(c, a):
+            return c.SSIM(a, c.AdaptiveSharpen(a, 0.5))
+
+        step = _pooled_step(fennec_amd, local_rank, ctx, imgs, one, args.contexts)
         metric, unit, units_per_step = "megapixels/sec: 8K AdaptiveSharpen + SSIM", "MP/s", B * W * H / 1e6
         name = "config4: 8K AdaptiveSharpen(0.5) + full-resolution SSIM"
     elif wl == "analyze":     # Analyze (analyze.go:26-124), BenchmarkAnalyze's op at 4K
@@ -560,26 +599,9 @@ def other_workloads(args) -> int:
         jpegs = [fbatch.pillow_encode(s, 92) for s in srcs]          # "4096 synthetic 4K JPEGs", q=92 up front
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
-        tl = __import__("threading").local()
-
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
-
-        def work(idx, state):
-            src = fbatch.pillow_decode(jpegs[idx % B])
-            t_gpu = [0.0]
-            t1 = time.perf_counter()
-            prep = state.ssim_fast_prepare(src)
-            t_gpu[0] += time.perf_counter() - t1
-
-            def score(dec):
-                t2 = time.perf_counter()
-                v = prep.against(dec)
-                t_gpu[0] += time.perf_counter() - t2
-                return v
-            q, s_, data, steps = fbatch.compress_jpeg_optimal(score, src, fbatch.TARGET_SSIM["Balanced"])
-            prep.close()
-            gpu_stage.append(t_gpu[0])
-            return fbatch.BatchResult(Index=idx, OriginalSize=len(jpegs[idx % B]), CompressedSize=len(data), SSIM=s_, Quality=q)
+        work = fbatch.jpeg_item_work([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
+                                     on_gpu_seconds=gpu_stage.append)
 
         states = {}
 

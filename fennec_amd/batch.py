@@ -96,6 +96,7 @@ class BatchResult:
     SSIM: float = 0.0
     Quality: int = 0
     has_result: bool = True
+    steps: int = 0          # search steps taken (diagnostics; not part of the reference's Result)
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
@@ -143,6 +144,49 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
     for t in threads:
         t.join()
     return [results[i] for i in mine]
+
+
+def jpeg_item_work(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
+                   ssim_fast: Optional[Callable] = None, on_gpu_seconds: Optional[Callable[[float], None]] = None):
+    """The per-item body of CompressBatch for JPEG inputs (batch.go:88-122 -> compressJPEGOptimal,
+    compress.go:21-87): decode the source JPEG, prepare it as the SSIMFast reference on the worker's ctx, run the
+    quality search with every candidate scored on the GPU, return the BatchResult.
+
+    Returns work(idx, state) for compress_batch; `state` is the worker's fennec_amd.Context.  `ssim_fast(src, dec)`
+    replaces the GPU scorer (tests drive the identical search with their CPU checker)."""
+    import time
+
+    def work(idx: int, state) -> BatchResult:
+        data = jpegs[idx]
+        src = pillow_decode(data)
+        gpu_s = 0.0
+        if ssim_fast is None:
+            t0 = time.perf_counter()
+            prep = state.ssim_fast_prepare(src)
+            gpu_s += time.perf_counter() - t0
+
+            def score(dec):
+                nonlocal gpu_s
+                t1 = time.perf_counter()
+                v = prep.against(dec)
+                gpu_s += time.perf_counter() - t1
+                return v
+        else:
+            prep = None
+
+            def score(dec):
+                return ssim_fast(src, dec)
+        try:
+            q, s_, out, steps = compress_jpeg_optimal(score, src, target_ssim)
+        finally:
+            if prep is not None:
+                prep.close()
+        if on_gpu_seconds is not None:
+            on_gpu_seconds(gpu_s)
+        r = BatchResult(Index=idx, OriginalSize=len(data), CompressedSize=len(out), SSIM=s_, Quality=q)
+        r.steps = steps
+        return r
+    return work
 
 
 @dataclass

@@ -761,7 +761,11 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     const bool have = ww > 0 && wh > 0;
     WinSepArgs sa{};
     const bool sep = have && window_rank1(h_window, sa.col, sa.row);
-    const bool march = sep && !ssim_use_tiled();
+    // the marching kernel needs long column segments to pay for its serial row walk (~0.45 us per row per
+    // wave): single small planes (one SSIMFast, the MSSSIM levels) keep the tile kernels, 2-5 us a launch
+    // against ~19.  FNX_SSIM_MARCH_MIN overrides the window count from which it takes over (experiments).
+    static const long march_min = [] { const char *e = getenv("FNX_SSIM_MARCH_MIN"); return e ? atol(e) : 1500000L; }();
+    const bool march = sep && !ssim_use_tiled() && static_cast<long>(ww) * wh * n >= march_min;
     // tile kernels (FNX_SSIM_TILED=1, and the 64-tap kernel for tables that are not rank-1)
     const bool big = sep && static_cast<long>(ww) * wh * n >= 4L * 1024 * ctx->num_cus;
     const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? W24_TY : WSS_TY) : WS_TY;
