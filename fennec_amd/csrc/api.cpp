@@ -478,26 +478,45 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
     int nw, nh;
     const bool down = ssim_fast_dims(w, h, &nw, &nh);
     if (down && nw >= 8 && nh >= 8) {
-        // one pass: the blur kernel also accumulates both boxDownsample planes
+        // one pass: the blur kernel also accumulates both boxDownsample planes.  Buffer set p (slabs, planes,
+        // partial sums) belongs to this step; the blur waits for the tail that used it two steps ago, and the
+        // step's own tail -- box_from_slabs, windowed SSIM, finish -- runs on the second stream, i.e. under the
+        // blur of whatever step the caller enqueues next.
+        const int p = ctx->parity;
         const void *hosts[2] = {srcs, dsts};
         const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
         void *dp[2];
         FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+        void *dwin = nullptr;
+        FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));   // before the blur: uploads ride on `stream`
         const size_t plane = static_cast<size_t>(nw) * nh * 4;
         void *t = nullptr;
-        FNX_TRY(scratch(ctx, SLOT_TMP2, plane * 2 * n + 16, &t));
+        FNX_TRY(scratch(ctx, p ? SLOT_PLANES1 : SLOT_PLANES0, plane * 2 * n + 16, &t));
         uint8_t *planes = static_cast<uint8_t *>(t);
+        if (ctx->tail_pending[p]) FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
         const int st = launch_blur_scored(ctx, n, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel,
                                           radius, flags, static_cast<uint8_t *const *>(dp[1]), dstride, planes, plane, nw, nh);
         if (st < 0) return st;
         if (st == FNX_OK) {
-            void *dwin = nullptr;
-            FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
             double *dres;
             FNX_TRY(result_slot_queued(ctx, n, &dres));
-            FNX_TRY(launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
-                                         window, static_cast<const double *>(dwin), dres));
-            return publish_results(ctx, dres, n);
+            // the windowed-SSIM launcher works on ctx->stream: point it at the tail stream for this call
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->stream2;
+            ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;
+            int rc = launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
+                                          window, static_cast<const double *>(dwin), dres);
+            if (rc >= 0) rc = publish_results(ctx, dres, n);      // the batch's event: behind the tail
+            if (rc >= 0 && hipEventRecord(ctx->ev_tail[p], ctx->stream2) != hipSuccess) {
+                set_error("hipEventRecord (tail) failed");
+                rc = FNX_ERR_HIP;
+            }
+            ctx->partial_slot = -1;
+            ctx->stream = main_stream;
+            if (rc < 0) return rc;
+            ctx->tail_pending[p] = true;
+            ctx->parity ^= 1;
+            return FNX_OK;
         }
     }
     // shapes the one-pass kernel is not built for: the two ops back to back

@@ -771,11 +771,15 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     fa.bx = static_cast<const int32_t *>(dmap) + 2 * NINV + ref_words; fa.by = fa.bx + w;
     fa.nbx = nbx; fa.nby = nby;
     void *slabs = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
+    FNX_TRY(scratch(ctx, ctx->parity ? SLOT_SLABS1 : SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
     fa.slabs = static_cast<unsigned long long *>(slabs);
     const int st = exact ? launch_direct_radius<true, true>(ctx, radius, n, fa, tall)
                          : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
     if (st < 0) return st;
+    // the rest of the step runs on the ctx's second stream, behind this blur (api.cpp: one-pass enqueue)
+    FNX_HIP(hipEventRecord(ctx->ev_blur[ctx->parity], ctx->stream));
+    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_blur[ctx->parity], 0));
+    ctx->stream2_used = true;
 
     SlabArgs sa{};
     sa.slabs = fa.slabs; sa.dst = planes; sa.plane = plane;
@@ -785,7 +789,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     sa.image_slabs = static_cast<size_t>(tiles) * 2 * slabn;
     sa.n = n; sa.dstW = dstW; sa.dstH = dstH; sa.slabn = slabn;
     hipLaunchKernelGGL(box_from_slabs_kernel, dim3((dstW + 63) / 64, (dstH + 3) / 4, n), dim3(256), 0,
-                       ctx->stream, sa);
+                       ctx->stream2, sa);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
 }

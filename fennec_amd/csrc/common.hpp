@@ -53,7 +53,14 @@ enum Slot {
     SLOT_RESULT,     // scalar results
     SLOT_PTRS,       // pointer arrays of batched ops
     SLOT_BOXMAP,     // source column/row -> box index tables (blur + SSIMFast in one pass)
-    SLOT_SLABS,      // per-tile box partial sums of that pass
+    SLOT_SLABS,      // per-tile box partial sums of that pass (buffer 0)
+    // second halves of the one-pass pipeline's double buffers, and its private plane / partial slots: its tail
+    // (box_from_slabs, windowed SSIM, finish) runs on the ctx's second stream under the NEXT step's blur
+    SLOT_SLABS1,
+    SLOT_PLANES0,
+    SLOT_PLANES1,
+    SLOT_PART0,
+    SLOT_PART1,
     SLOT_COUNT
 };
 
@@ -93,6 +100,15 @@ struct fnx_resize_plan;   // resize.hip: device tables of one (tap table, direct
 struct fnx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // One-pass GaussianBlur + SSIMFast batches (api.cpp): the blur kernel of step s runs on `stream`, the
+    // step's tail on `stream2`, ordered by ev_blur[p]; step s + 2 reuses buffer set p = s & 1 and waits for
+    // ev_tail[p] first.  A caller that enqueues step s + 1 before fetching step s gets the tail for free.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_blur[2] = {}, ev_tail[2] = {};
+    bool tail_pending[2] = {false, false};
+    int parity = 0;
+    bool stream2_used = false;
+    int partial_slot = -1;       // >= 0: launch_windowed_ssim takes its partial sums from this slot (one-pass tail)
     fnx::Scratch slot[fnx::SLOT_COUNT];
     fnx::TableCache tcache[fnx::SLOT_COUNT];
     // pinned host ring: tables going up, scalars coming down

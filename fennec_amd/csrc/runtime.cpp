@@ -1,6 +1,8 @@
 // Context, device memory, staging: the runtime under every fnx_* entry point.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace fnx {
 
 static thread_local char g_err[512] = "";
@@ -29,6 +31,7 @@ int scratch(fnx_ctx *ctx, Slot slot, size_t bytes, void **out)
     if (bytes > s.cap) {
         // everything enqueued may still use the old buffer
         FNX_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2_used) FNX_HIP(hipStreamSynchronize(ctx->stream2));
         if (s.p) FNX_HIP(hipFree(s.p));
         s.p = nullptr;
         s.cap = 0;
@@ -88,6 +91,8 @@ int upload_tables(fnx_ctx *ctx, Slot slot, const void *const *hosts, const size_
     }
     tc.fresh = !same;
     if (same) return FNX_OK;
+    // a one-pass tail still running on the second stream may be reading this slot's previous contents
+    if (ctx->stream2_used) FNX_HIP(hipStreamSynchronize(ctx->stream2));
     void *pin = nullptr;
     FNX_TRY(pinned_alloc(ctx, total ? total : 16, &pin));
     tc.host.assign(total, 0);
@@ -248,6 +253,26 @@ int fnx_ctx_create(int device, fnx_ctx **out)
         delete c;
         return FNX_ERR_HIP;
     }
+    {
+        // the tail stream.  FNX_TAIL_PRIO=low|high moves it to the end of the device's priority range (experiments)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char *pe = getenv("FNX_TAIL_PRIO");
+        int prio = (least + greatest) / 2;
+        if (pe && pe[0] == 'l') prio = least;
+        if (pe && pe[0] == 'h') prio = greatest;
+        e = pe ? hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio)
+               : hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            e = hipEventCreateWithFlags(&c->ev_blur[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            set_error("hipStreamCreate (tail stream) failed: %s", hipGetErrorString(e));
+            fnx_ctx_destroy(c);
+            return FNX_ERR_HIP;
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     *out = c;
@@ -259,6 +284,7 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
         for (auto &s : ctx->slot)
             if (s.p) (void)hipFree(s.p);
         if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -270,7 +296,12 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
                 if (e) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        for (int i = 0; i < 2; i++) {
+            if (ctx->ev_blur[i]) (void)hipEventDestroy(ctx->ev_blur[i]);
+            if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
+        }
     }
     delete ctx;
 }
@@ -308,6 +339,7 @@ int fnx_ctx_sync(fnx_ctx *ctx)
 {
     FNX_TRY(bind(ctx));
     FNX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2_used) FNX_HIP(hipStreamSynchronize(ctx->stream2));
     return FNX_OK;
 }
 
@@ -324,6 +356,7 @@ int fnx_free(fnx_ctx *ctx, void *dptr)
     FNX_TRY(bind(ctx));
     if (dptr) {
         FNX_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2_used) FNX_HIP(hipStreamSynchronize(ctx->stream2));
         FNX_HIP(hipFree(dptr));
     }
     return FNX_OK;

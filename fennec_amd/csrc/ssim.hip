@@ -800,7 +800,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));   // reserved by the caller: no growth
         part = static_cast<double *>(part) + defer->used;
     } else {
-        FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
+        const Slot ps = ctx->partial_slot >= 0 ? static_cast<Slot>(ctx->partial_slot) : SLOT_PARTIAL;
+        FNX_TRY(scratch(ctx, ps, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
     }
     if (march) {
         ma.a = a; ma.b = b; ma.a_image_bytes = a_image_bytes; ma.b_image_bytes = b_image_bytes;
