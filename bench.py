@@ -500,6 +500,38 @@ def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
     return step
 
 
+def _pooled_queue_step(fennec_amd, device, ctx0, n_items, run_ctx, nctx):
+    """step() where each of `nctx` worker contexts runs run_ctx(ctx, its item indices, out) -- item i belongs to
+    worker i mod nctx -- so that a worker can keep several items enqueued on its stream."""
+    import threading
+    nctx = max(1, min(nctx, n_items))
+    ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
+
+    def step():
+        out = [None] * n_items
+        if nctx == 1:
+            run_ctx(ctx0, range(n_items), out)
+            return out
+        err = []
+
+        def run(k):
+            import torch
+            torch.cuda.set_device(device)
+            try:
+                run_ctx(ctxs[k], range(k, n_items, nctx), out)
+            except Exception as e:
+                err.append(e)
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(nctx)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return out
+    return step
+
+
 def other_workloads(args) -> int:
     """BASELINE.json configs 3, 4, 5 (parity-test cases, not the headline bench line): same
     timing protocol, one JSON line.  Per-image C-ABI calls on device-resident tensors."""
@@ -521,11 +553,19 @@ def other_workloads(args) -> int:
         imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 193.4e6     # 41.47 (down) + 41.47 (implicit up) + 110.5 (MSSSIM) MB
 
+        kms = {"resize_h_down": [], "resize_v_down": [], "resize_h_up": [], "resize_v_up": []}
+
         def one(c, a):
             small = c.lanczosResize(a, W // 2, H // 2)
-            return c.MSSSIM(a, small)                   # ssim.go:320-322 resizes `small` back to 4K
+            v = c.MSSSIM(a, small)                      # ssim.go:320-322 resizes `small` back to 4K
+            if c is ctx and prof_on[0]:                 # the library's event pairs: H, V of the downscale, H, V of the implicit upscale
+                for k in kms:
+                    kms[k].append(c.kernel_ms())
+            return v
 
+        prof_on = [False]
         step = _pooled_step(fennec_amd, local_rank, ctx, imgs, one, args.contexts)
+        prof_mask = fennec_amd.PROF_RESIZE
         metric, unit, units_per_step = "megapixels/sec: 4K -> 1920x1080 Lanczos-3 downscale + MS-SSIM", "MP/s", B * W * H / 1e6
         name = "config3: 4K lanczosResize(1920x1080) + MSSSIM(4K, 1080p)"
     elif wl == "config4":
@@ -533,10 +573,29 @@ def other_workloads(args) -> int:
         imgs = [torch.from_numpy(im).cuda() for im in synth.large_photo_batch(W, H, range(rank * B, rank * B + B))]
         alg = 530.84e6
 
-        def one(c, a):
-            return c.SSIM(a, c.AdaptiveSharpen(a, 0.5))
+        kms = {"windowed_ssim": []}
+        prof_on = [False]
+        prof_mask = fennec_amd.PROF_SSIM
+        QD = 3                                           # images in flight per context (the ctx's result FIFO holds 4)
 
-        step = _pooled_step(fennec_amd, local_rank, ctx, imgs, one, args.contexts)
+        def run_ctx(c, mine, out):
+            """One worker: AdaptiveSharpen (async) + fnx_ssim_enqueue per image, results fetched QD images behind."""
+            pend = []
+            for i in mine:
+                sharp = c.AdaptiveSharpen(imgs[i], 0.5)
+                c.ssim_enqueue(imgs[i], sharp)
+                pend.append((i, sharp))
+                if len(pend) > QD:
+                    j, _ = pend.pop(0)
+                    out[j] = c.fetch_result()
+                    if c is ctx and prof_on[0]:
+                        kms["windowed_ssim"].append(c.kernel_ms())
+            for j, _ in pend:
+                out[j] = c.fetch_result()
+                if c is ctx and prof_on[0]:
+                    kms["windowed_ssim"].append(c.kernel_ms())
+
+        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), run_ctx, args.contexts)
         metric, unit, units_per_step = "megapixels/sec: 8K AdaptiveSharpen + SSIM", "MP/s", B * W * H / 1e6
         name = "config4: 8K AdaptiveSharpen(0.5) + full-resolution SSIM"
     elif wl == "analyze":     # SURVEY 8(f).3: Analyze (analyze.go:26-124), BenchmarkAnalyze's op at 4K
@@ -627,12 +686,21 @@ def other_workloads(args) -> int:
         step()
     for _ in range(args.warmup):
         vals = step()
+    if wl in ("config3", "config4"):
+        ctx.profile(prof_mask)      # the library brackets the dominant kernels with HIP events on its stream
+        prof_on[0] = True
     barrier()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         vals = step()
+        step_s.append(time.perf_counter() - t_s)
     barrier()
     elapsed = time.perf_counter() - t0
+    if wl in ("config3", "config4"):
+        prof_on[0] = False
+        ctx.profile(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -648,7 +716,44 @@ def other_workloads(args) -> int:
         "roofline": {"kernel": "whole step (all kernels of the workload)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None},
         "result_sample": float(vals[0]),
+        "step_ms": {"min": round(min(step_s) * 1e3, 4), "median": round(float(np.median(step_s)) * 1e3, 4),
+                    "max": round(max(step_s) * 1e3, 4)},
     }
+    if wl in ("config3", "config4"):
+        out["config"]["contexts_per_gpu"] = max(1, min(args.contexts, B))
+        out["roofline_step"] = out["roofline"]
+        S_img = 4.0 * W * H
+        if wl == "config4":
+            ms = float(np.mean(kms["windowed_ssim"]))
+            abytes = 2.0 * S_img                      # SSIM reads both full-size images once
+            g = abytes / (ms * 1e-3) / 1e9
+            # the kernel is fp64-VALU bound: 4 moments x 8 taps x 2 passes of fp64 FMA per window
+            win = float(W - 8) * float(H - 8)
+            out["roofline"] = {"kernel": "windowed_ssim_march_kernel (full-resolution SSIM of one 8K pair, luminance fused)",
+                               "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(g / HBM_PEAK_GBS, 4),
+                               "traffic": committed_traffic_named("windowed_ssim_march_kernel", "config4"),
+                               "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": len(kms["windowed_ssim"]),
+                               "fp64_fma_floor_ms": round(win * 64 / 39.3e12 * 1e3, 4),
+                               "note": "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown); "
+                                       "bytes are SURVEY 8(d)'s 2*S per pair"}
+        else:
+            means = {k: float(np.mean(v)) for k, v in kms.items() if v}
+            dom = "resize_h_down"
+            ms = means.get(dom, float("nan"))
+            abytes = S_img + S_img / 2                # resizeH of the downscale: reads S(4K), writes the 1920 x 2160 intermediate
+            g = abytes / (ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "resize_h_guard_kernel<4> (resizeH of the 4K -> 1080p downscale: the largest single kernel of the step)",
+                               "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(g / HBM_PEAK_GBS, 4),
+                               "traffic": committed_traffic_named("resize_h_guard_kernel", "config3"),
+                               "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4),
+                               "launches_timed": len(kms[dom]),
+                               "resize_kernels_ms": {k: round(v, 4) for k, v in means.items()},
+                               "note": "the step is ~20 short kernels per image (2 x 2 resize passes, 7 box downsamples, 5 window "
+                                       "kernels, 1 finish): see roofline_step for the whole step against SURVEY 8(d)'s 193.4 MB"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_other(wl, W, H)
     if wl == "config5":
         per_item = float(np.mean(gpu_stage[-B * args.steps:]))
         out["gpu_stage"] = {"seconds_per_image": round(per_item, 6), "images_per_s_per_context": round(1.0 / per_item, 1),
@@ -680,6 +785,54 @@ def other_workloads(args) -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def committed_traffic_named(kernel_substr: str, tag: str):
+    """HBM bytes per launch of a kernel from profiles/*<tag>*_traffic.json (see committed_traffic); None if absent."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{tag}*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(p))
+            for k, v in t["kernels"].items():
+                if kernel_substr in k:
+                    return float(v["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
+def cpu_baseline_other(wl: str, W: int, H: int) -> dict:
+    """configs 3 / 4 on the host cores with the oracle (a C restatement of the Go reference, its threading model),
+    on a bounded sample: one 4K image for config 3; a 1920 x 1080 crop of the 8K image for config 4 (every stage is
+    per-pixel work with fixed-size neighbourhoods, so MP/s carries over; the full 8K SSIM alone is ~10 s a pass)."""
+    from oracle import oracle
+    from fennec_amd import synth
+    cores = os.cpu_count() or 1
+    if wl == "config3":
+        img = synth.large_photo(W, H, 0)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            small = oracle.lanczos_resize(img, W // 2, H // 2, procs=cores)
+            oracle.msssim(img, small, procs=cores)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or n >= 16:
+                break
+        return {"value": round(n * W * H / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+                "sample": f"{n} x (lanczosResize 4K -> 1080p + MSSSIM(4K, 1080p)) in {dt:.1f} s, oracle/fennec_oracle.c with procs={cores}"}
+    cw, ch = 1920, 1080
+    img = np.ascontiguousarray(synth.large_photo(W, H, 0)[:ch, :cw])
+    n, t0 = 0, time.perf_counter()
+    while True:
+        sharp = oracle.adaptive_sharpen(img, 0.5, procs=cores)
+        oracle.ssim(img, sharp, procs=cores)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or n >= 64:
+            break
+    return {"value": round(n * cw * ch / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x (AdaptiveSharpen(0.5) + full-resolution SSIM) of a {cw}x{ch} crop of the 8K image in {dt:.1f} s, "
+                      f"oracle/fennec_oracle.c with procs={cores}"}
 
 
 def _template_flags(kernel_name: str):

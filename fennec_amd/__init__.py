@@ -134,6 +134,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ssim_fast_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p, _f64p])
         _sig(L, "fnx_ssim_fast_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
         _sig(L, "fnx_results_fetch", i, [ctx, i, _f64p])
+        _sig(L, "fnx_ssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
@@ -373,6 +374,22 @@ class Context:
         with self._ordered(img1, img2):
             self._chk(self._lib.fennec_SSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
                                             b.w, b.h, C.byref(out)), "SSIM")
+        return out.value
+
+    def ssim_enqueue(self, img1, img2, window=None):
+        """fnx_ssim_enqueue: SSIM of a device pair of equal dims, result fetched later with fetch_result()
+        (FIFO, at most 4 unfetched).  The caller keeps img1 / img2 alive until then."""
+        a, b = self._pair(img1, img2)
+        if a.space != FNX_DEVICE or (a.w, a.h) != (b.w, b.h):
+            raise FennecError("ssim_enqueue takes two device tensors of equal dims")
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fnx_ssim_enqueue(self._h, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h, pk), "fnx_ssim_enqueue")
+
+    def fetch_result(self) -> float:
+        """The oldest enqueued scalar result (fnx_results_fetch)."""
+        out = C.c_double()
+        self._chk(self._lib.fnx_results_fetch(self._h, 1, C.byref(out)), "fnx_results_fetch")
         return out.value
 
     def SSIMFast(self, img1, img2) -> float:

@@ -569,6 +569,27 @@ int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8
     return result_wait(ctx, dres, out, 1);
 }
 
+int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                     const double *window)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(window != nullptr && w > 0 && h > 0, "enqueue arguments");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    FNX_TRY(can_enqueue(ctx));
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    double *dres;
+    FNX_TRY(result_slot_queued(ctx, 1, &dres));
+    if (w < 8 || h < 8) {   // ssim.go:35-37
+        FNX_REQUIRE(pix_len(w, h, bstride) >= pix_len(w, h, astride), "b.Pix shorter than a.Pix (the reference would panic)");
+        FNX_TRY(launch_pixel_ssim(ctx, a, b, w, h, pix_len(w, h, astride), dres));
+    } else {
+        FNX_TRY(launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, window, static_cast<const double *>(dwin), dres));
+    }
+    return publish_results(ctx, dres, 1);
+}
+
 int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                int bstride, int w, int h, const double *window, double *out, double *per_level)
 {

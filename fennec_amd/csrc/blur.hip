@@ -490,19 +490,30 @@ struct BoxRef {           // where one output column (or row) finds its partial 
 
 struct SlabArgs {
     const unsigned long long *slabs;
-    const double *inv;        // inv[c] = 1.0 / c, c <= 256 (the reference's division, done once on the host)
+    const uint32_t *magic;    // magic[c] = floor(2^32 / 2c) + 1, c <= 256: (2 n + c) / 2c by one v_mul_hi_u32
+    const uint32_t *tiedown;  // tiedown[8 c + (k >> 5)] bit (k & 31): the reference's fp64 product at the tie
+                              // n / c == k + 0.5 falls BELOW it (clampF then gives k, not k + 1)
     const BoxRef *xref, *yref;
     uint8_t *dst;             // [src 0..n-1][blurred 0..n-1] tight dstW x dstH planes
     size_t plane, image_slabs;  // entries per image: tiles * 2 * slabn
     int n, dstW, dstH, slabn;
 };
 
-// clampF of a value known to lie in [0, 256): trunc + round-half-up, as clampF_dev without its guards
-__device__ __forceinline__ uint32_t round_u8_small(double x)
+// clampF(fl(n * fl(1 / c))) (ssim.go:301-308) for an integer channel sum n <= 255 c, c <= 256, in integers.
+// n / c is a tie only when 2 n == (2 k + 1) c; anywhere else it is at least 1 / 2c >= 2^-9 away from the next
+// half-integer, far beyond the fp64 product's error (2^-44), so the reference's result is the exact quotient
+// rounded half up: q = (2 n + c) / 2c.  AT a tie the product fl(n * fl(1 / c)) lands on k + 0.5 or an ulp
+// below it depending on c and k: the host evaluates exactly that product for every (c, k) -- the same two IEEE
+// operations the reference performs -- and hands over the ones that round DOWN as a bit table.
+__device__ __forceinline__ uint32_t box_mean_u8(uint32_t n, uint32_t c, uint32_t magic, const uint32_t *tiedown)
 {
-    double t = trunc(x);
-    if (x - t >= 0.5) t += 1.0;
-    return min(static_cast<uint32_t>(static_cast<int>(t)), 255u);
+    const uint32_t t = 2u * n + c;
+    uint32_t q = __umulhi(t, magic);                 // t / 2c exactly: t * (magic * 2c - 2^32) < 2^32 for t <= 511 c
+    if (t == q * 2u * c && q > 0) {                  // tie between q - 1 and q
+        const uint32_t k = q - 1;
+        if ((tiedown[8u * c + (k >> 5)] >> (k & 31u)) & 1u) q = k;
+    }
+    return q;
 }
 
 // One thread per box, both images.  The index arithmetic (box_edge, tile and entry of each part)
@@ -515,7 +526,8 @@ __global__ __launch_bounds__(256) void box_from_slabs_kernel(SlabArgs a)
     if (dx >= a.dstW || dy >= a.dstH) return;
     const int i = blockIdx.z;
     const BoxRef xr = a.xref[dx], yr = a.yref[dy];
-    const double inv = a.inv[xr.len * yr.len];
+    const uint32_t cnt = static_cast<uint32_t>(xr.len * yr.len);
+    const uint32_t magic = a.magic[cnt];
     const unsigned long long *base = a.slabs + a.image_slabs * i;
     // 2 x u16 per word: the whole box is <= 256 px, so no field overflows.  [0]: source, [1]: blurred
     uint32_t rg[2], b[2];
@@ -549,8 +561,8 @@ __global__ __launch_bounds__(256) void box_from_slabs_kernel(SlabArgs a)
     // clampF(sum * (1.0 / count)) per channel (ssim.go:301-308)
 #pragma unroll
     for (int img = 0; img < 2; img++) {
-        const uint32_t o = round_u8_small(u8_to_f64(rg[img] & 0xffffu) * inv) | (round_u8_small(u8_to_f64(rg[img] >> 16) * inv) << 8) |
-                           (round_u8_small(u8_to_f64(b[img] & 0xffffu) * inv) << 16);
+        const uint32_t o = box_mean_u8(rg[img] & 0xffffu, cnt, magic, a.tiedown) | (box_mean_u8(rg[img] >> 16, cnt, magic, a.tiedown) << 8) |
+                           (box_mean_u8(b[img] & 0xffffu, cnt, magic, a.tiedown) << 16);
         *reinterpret_cast<uint32_t *>(a.dst + a.plane * (static_cast<size_t>(img) * a.n + i) +
                                       (static_cast<size_t>(dy) * a.dstW + dx) * 4) = o;
     }
@@ -645,7 +657,7 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
 // pixels.  Returns FNX_NOOP without launching anything when the shape is outside what the
 // SCORE kernel is built for (the caller then runs the two ops separately).
 // Geometry of a one-pass launch: tile shape, box tables.  Cached on the ctx (batches repeat it).
-constexpr int NINV = 258;   // doubles at the head of the table blob: 1/c, c in [0, 256]
+constexpr int NHEAD = 260 + 257 * 8;   // uint32 words at the head of the table blob: magic[c] (c <= 256, padded to 260), tiedown[8 c + w]
 static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH)
 {
     if (radius < 1 || radius > FUSED_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
@@ -660,16 +672,27 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
     // two ops run back to back.  Upwards the limit is the 16-bit sum fields (boxes of <= 256 px).
     if (std::fmin(xr, yr) < 3.6) return false;
     // source column / row -> box index (boxes of a downscale are disjoint and ascending)
-    // one table blob: 1/c for c in [0, 256] (doubles) | BoxRef per output column, per output row |
+    // one table blob: magic[c], tiedown[c][8] (box_mean_u8) | BoxRef per output column, per output row |
     // box index of every source column, every source row
     const size_t ref_words = 4 * (static_cast<size_t>(dstW) + dstH);
     std::vector<int32_t> &map = g.map;
-    map.assign(2 * NINV + ref_words + static_cast<size_t>(w) + h, -1);
-    double *inv = reinterpret_cast<double *>(map.data());
-    inv[0] = inv[257] = 0.0;
-    for (int c = 1; c <= 256; c++) inv[c] = 1.0 / static_cast<double>(c);
-    BoxRef *xref = reinterpret_cast<BoxRef *>(map.data() + 2 * NINV), *yref = xref + dstW;
-    int32_t *bx = map.data() + 2 * NINV + ref_words, *by = bx + w;
+    map.assign(NHEAD + ref_words + static_cast<size_t>(w) + h, -1);
+    {
+        uint32_t *magic = reinterpret_cast<uint32_t *>(map.data()), *tiedown = magic + 260;
+        std::fill(magic, magic + NHEAD, 0u);
+        for (uint32_t c = 1; c <= 256; c++) {
+            magic[c] = static_cast<uint32_t>((1ull << 32) / (2ull * c)) + 1u;
+            if (c & 1u) continue;                                    // odd counts have no ties
+            const double inv = 1.0 / static_cast<double>(c);         // inv := 1.0 / count (ssim.go:301)
+            for (uint32_t k = 0; k < 256; k++) {
+                const double n = static_cast<double>(c / 2) * static_cast<double>(2 * k + 1);   // n / c == k + 0.5
+                if (n > 255.0 * c) break;
+                if (n * inv < static_cast<double>(k) + 0.5) tiedown[8 * c + (k >> 5)] |= 1u << (k & 31);
+            }
+        }
+    }
+    BoxRef *xref = reinterpret_cast<BoxRef *>(map.data() + NHEAD), *yref = xref + dstW;
+    int32_t *bx = map.data() + NHEAD + ref_words, *by = bx + w;
     int maxbw = 0, maxbh = 0;
     for (int d = 0; d < dstW; d++) {
         int s0, s1;
@@ -768,7 +791,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
         fa.wt[i] = static_cast<float>(kernel[i]);
         fa.wd[i] = kernel[i];
     }
-    fa.bx = static_cast<const int32_t *>(dmap) + 2 * NINV + ref_words; fa.by = fa.bx + w;
+    fa.bx = static_cast<const int32_t *>(dmap) + NHEAD + ref_words; fa.by = fa.bx + w;
     fa.nbx = nbx; fa.nby = nby;
     void *slabs = nullptr;
     FNX_TRY(scratch(ctx, ctx->parity ? SLOT_SLABS1 : SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
@@ -783,8 +806,9 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
 
     SlabArgs sa{};
     sa.slabs = fa.slabs; sa.dst = planes; sa.plane = plane;
-    sa.inv = static_cast<const double *>(dmap);
-    sa.xref = reinterpret_cast<const BoxRef *>(static_cast<const int32_t *>(dmap) + 2 * NINV);
+    sa.magic = static_cast<const uint32_t *>(dmap);
+    sa.tiedown = sa.magic + 260;
+    sa.xref = reinterpret_cast<const BoxRef *>(static_cast<const int32_t *>(dmap) + NHEAD);
     sa.yref = sa.xref + dstW;
     sa.image_slabs = static_cast<size_t>(tiles) * 2 * slabn;
     sa.n = n; sa.dstW = dstW; sa.dstH = dstH; sa.slabn = slabn;

@@ -203,6 +203,12 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
                                 const uint8_t *const *bs, int bstride, int w, int h,
                                 const double *window);
 int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
+/* SSIM (ssim.go:24-43, equal dims) of ONE device-resident pair, enqueued like the batches above: the value joins the
+ * ctx's FIFO and fnx_results_fetch(ctx, 1, &v) returns it later -- a worker that scores a stream of large images
+ * (config 4: AdaptiveSharpen + SSIM per 8K image) keeps the next image's kernels queued while this one's result
+ * crosses to the host instead of draining the stream at every call. */
+int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                     const double *window /* 64 */);
 
 /* dsts[i] = GaussianBlur(srcs[i]) AND out[i] = SSIMFast(srcs[i], dsts[i]) -- the pair of calls
  * the reference makes whenever it scores a processed image against its source (effects.go:146

@@ -581,6 +581,23 @@ def test_config3_4k_lanczos_msssim(ctx, orc):
     assert abs(got - want) <= SSIM_TOL
 
 
+def test_ssim_enqueue_fifo(ctx, orc):
+    """fnx_ssim_enqueue: three pairs queued, fetched oldest first, each equal to the blocking SSIM."""
+    import torch
+    imgs = [synth.large_photo(640, 480, k) for k in range(3)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    sharp = [ctx.AdaptiveSharpen(t, 0.5) for t in d]
+    for a, b in zip(d, sharp):
+        ctx.ssim_enqueue(a, b)
+    got = [ctx.fetch_result() for _ in d]
+    for k, (a, b) in enumerate(zip(d, sharp)):
+        assert got[k] == ctx.SSIM(a, b)
+        assert abs(got[k] - orc.ssim(imgs[k], b.cpu().numpy())) <= SSIM_TOL
+    tiny = torch.from_numpy(synth.noise_image(5, 3, 1, alpha=True)).cuda()
+    ctx.ssim_enqueue(tiny, tiny)
+    assert ctx.fetch_result() == ctx.SSIM(tiny, tiny)
+
+
 def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
     img = synth.large_photo(7680, 4320, 2)
     sharp = ctx.AdaptiveSharpen(img, 0.5)

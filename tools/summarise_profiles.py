@@ -58,7 +58,7 @@ with open(os.path.join(dst, f"{tag}_sq_counters.txt"), "w") as fo:
     for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
               "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"):
         for k, (v, n) in sorted(per_launch("pmc_sq", c).items()):
-            if "fnx::" in k:
+            if "fnx::" in k or "fnx_" in k:
                 fo.write(f"{c:24s} {v:16.0f}  (mean of {n} launches)  {k[:90]}\n")
 for name in ("bench_plain.json", "bench_under_stats.json"):
     p = os.path.join(src, name)
