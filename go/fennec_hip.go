@@ -45,15 +45,19 @@ import (
 // ---- context pool --------------------------------------------------------------------------
 // A fnx_ctx is not re-entrant and HIP's current device is per OS thread, while goroutines
 // migrate between threads: every call borrows a context (which binds its device itself).
+// Idle contexts are kept PER DEVICE and handed out round-robin over the devices on every get(), reuse included:
+// a single LIFO free list pinned sequential callers to whichever device's context was returned last (device 0).
 type hipPool struct {
 	mu   sync.Mutex
-	free []*C.fnx_ctx
+	free [][]*C.fnx_ctx // free[dev]: idle contexts of that device
+	dev  map[*C.fnx_ctx]int
 	next int
 	ndev int
 }
 
 var pool = func() *hipPool {
-	return &hipPool{ndev: int(C.fnx_device_count())}
+	n := int(C.fnx_device_count())
+	return &hipPool{ndev: n, free: make([][]*C.fnx_ctx, n), dev: map[*C.fnx_ctx]int{}}
 }()
 
 func (p *hipPool) get() *C.fnx_ctx {
@@ -61,26 +65,38 @@ func (p *hipPool) get() *C.fnx_ctx {
 		return nil
 	}
 	p.mu.Lock()
-	if n := len(p.free); n > 0 {
-		c := p.free[n-1]
-		p.free = p.free[:n-1]
+	dev := p.next % p.ndev // CompressBatch workers spread round-robin over the node's GPUs, on creation AND reuse
+	p.next++
+	if n := len(p.free[dev]); n > 0 {
+		c := p.free[dev][n-1]
+		p.free[dev] = p.free[dev][:n-1]
 		p.mu.Unlock()
 		return c
 	}
-	dev := p.next % p.ndev // CompressBatch workers spread round-robin over the node's GPUs
-	p.next++
 	p.mu.Unlock()
 	var c *C.fnx_ctx
 	if C.fnx_ctx_create(C.int(dev), &c) != C.FNX_OK {
 		return nil
 	}
+	p.mu.Lock()
+	p.dev[c] = dev
+	p.mu.Unlock()
 	return c
 }
 
 func (p *hipPool) put(c *C.fnx_ctx) {
 	p.mu.Lock()
-	p.free = append(p.free, c)
+	d := p.dev[c]
+	p.free[d] = append(p.free[d], c)
 	p.mu.Unlock()
+}
+
+// poolGetIf borrows a context only when the call will really use it.
+func poolGetIf(cond bool) *C.fnx_ctx {
+	if !cond {
+		return nil
+	}
+	return pool.get()
 }
 
 func pix(img *image.NRGBA) *C.uint8_t {
@@ -248,7 +264,7 @@ func GaussianBlur(img *image.NRGBA, sigma float64) *image.NRGBA {
 	for i := range kernel {
 		kernel[i] /= sum
 	}
-	if c := pool.get(); c != nil && w > 0 && h > 0 {
+	if c := poolGetIf(w > 0 && h > 0); c != nil { // (no borrow for empty images: a borrowed ctx must always be returned)
 		defer pool.put(c)
 		dst := image.NewNRGBA(image.Rect(0, 0, w, h))
 		// FNX_BLUR_EXACT reproduces the reference bit for bit.  A host-space call is PCIe-bound
@@ -328,7 +344,7 @@ func ApplyOrientation(img *image.NRGBA, orient Orientation) *image.NRGBA {
 		return img // exif.go:180-181,200-201
 	}
 	w, h := img.Bounds().Dx(), img.Bounds().Dy()
-	if c := pool.get(); c != nil && w > 0 && h > 0 {
+	if c := poolGetIf(w > 0 && h > 0); c != nil {
 		defer pool.put(c)
 		ow, oh := w, h
 		if orient >= 5 {
