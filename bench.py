@@ -468,8 +468,11 @@ def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
     ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
     if nctx == 1:
         return lambda: [one(ctx0, a) for a in imgs]
+    import torch
+    streams = [torch.cuda.Stream(device=device) for _ in ctxs]
 
     def step():
+        torch.cuda.synchronize()
         out = [None] * len(imgs)
         nxt = [0]
         lock = threading.Lock()
@@ -478,17 +481,20 @@ def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
         def run(c):
             import torch
             torch.cuda.set_device(device)
-            while True:
-                with lock:
-                    i = nxt[0]
-                    nxt[0] += 1
-                if i >= len(imgs):
-                    return
-                try:
-                    out[i] = one(c, imgs[i])
-                except Exception as e:      # surfaced below
-                    err.append(e)
-                    return
+            # a torch stream per worker: the ctx launches on the caller's current stream (fennec_amd._ordered), so
+            # workers sharing torch's default stream would serialise on it
+            with torch.cuda.stream(streams[ctxs.index(c)]):
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= len(imgs):
+                        return
+                    try:
+                        out[i] = one(c, imgs[i])
+                    except Exception as e:      # surfaced below
+                        err.append(e)
+                        return
         ts = [threading.Thread(target=run, args=(c,)) for c in ctxs]
         for t in ts:
             t.start()
@@ -506,19 +512,23 @@ def _pooled_queue_step(fennec_amd, device, ctx0, n_items, run_ctx, nctx):
     import threading
     nctx = max(1, min(nctx, n_items))
     ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
+    import torch
+    streams = [torch.cuda.Stream(device=device) for _ in ctxs]
 
     def step():
         out = [None] * n_items
         if nctx == 1:
             run_ctx(ctx0, range(n_items), out)
             return out
+        torch.cuda.synchronize()
         err = []
 
         def run(k):
             import torch
             torch.cuda.set_device(device)
             try:
-                run_ctx(ctxs[k], range(k, n_items, nctx), out)
+                with torch.cuda.stream(streams[k]):       # see _pooled_step
+                    run_ctx(ctxs[k], range(k, n_items, nctx), out)
             except Exception as e:
                 err.append(e)
         ts = [threading.Thread(target=run, args=(k,)) for k in range(nctx)]

@@ -109,6 +109,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ctx_device", i, [ctx])
         _sig(L, "fnx_ctx_stream", C.c_void_p, [ctx])
         _sig(L, "fnx_ctx_sync", i, [ctx])
+        _sig(L, "fnx_ctx_use_stream", i, [ctx, C.c_void_p])
+        _sig(L, "fnx_ctx_use_own_stream", i, [ctx])
         _sig(L, "fnx_ctx_profile", i, [ctx, i])
         _sig(L, "fnx_ctx_kernel_ms", i, [ctx, C.POINTER(C.c_float)])
         _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
@@ -240,6 +242,7 @@ class Context:
             raise FennecError(f"fnx_ctx_create({device}): {self._err()}")
         self._h = h
         self.device = int(device)
+        self._lent = -1            # handle of the torch stream the ctx currently launches on (-1: its own stream)
 
     # -- plumbing ---------------------------------------------------------------------
     def _err(self) -> str:
@@ -281,53 +284,44 @@ class Context:
         return int(self._lib.fnx_ctx_stream(self._h) or 0)
 
     # -- ordering against torch's streams ---------------------------------------------------
-    # Device-space calls only ENQUEUE on the ctx's private (non-blocking) HIP stream.  torch knows nothing
-    # about that stream: inputs may still be being written on torch's current stream, outputs would be
-    # read by torch before the kernels have run, and the caching allocator could hand a dropped tensor's
-    # memory out again while ctx-stream kernels still use it.  Every method that takes device tensors
-    # therefore runs inside `_ordered(...)`:
-    #   before: the ctx stream waits for everything already queued on torch's current stream;
-    #   after : torch's current stream waits for the ctx stream.  That also covers the caching allocator:
-    #           a block freed by torch is handed out again on its allocation stream, and everything that
-    #           stream does from here on is ordered behind the ctx kernels.  (Not record_stream(): the
-    #           allocator would then record events on the ctx's stream when the tensor dies -- possibly
-    #           after the Context, and its stream, are gone.)
-    # Host (numpy) calls are synchronous and skip all of this.
-    def _ext_stream(self):
-        import torch
-        ext = getattr(self, "_ext", None)
-        if ext is None:
-            ext = self._ext = torch.cuda.ExternalStream(self.stream, device=torch.device("cuda", self.device))
-        return ext
-
+    # Device-space calls only ENQUEUE.  torch knows nothing about a private HIP stream: inputs may still be being
+    # written on torch's current stream, outputs would be read by torch before the kernels have run, and the caching
+    # allocator could recycle a dropped tensor while kernels still use it.  So every method that takes device tensors
+    # runs inside `_ordered(...)`, which makes the ctx LAUNCH ON torch's current stream (fnx_ctx_use_stream): the work
+    # is then ordered like any torch op on that stream and the allocator's stream-ordered reuse is safe -- with no
+    # cross-stream event per call (the first version waited both ways on every call: ~25 us of idle GPU between two
+    # back-to-back calls, measured on the config-4 timeline).  The switch happens once per (ctx, stream) change.
+    # Concurrency between worker contexts therefore needs a torch stream per worker (`with torch.cuda.stream(s)`),
+    # exactly as for torch's own ops.  Host (numpy) calls are synchronous and skip all of this.
     class _Ordered:
-        __slots__ = ("ctx", "tensors", "cur", "ext")
+        __slots__ = ("ctx", "tensors")
 
         def __init__(self, ctx, tensors):
             self.ctx = ctx
-            self.cur = self.ext = None
             self.tensors = [t for t in tensors if _is_torch(t) and t.is_cuda]
 
         def __enter__(self):
             if self.tensors:
                 import torch
-                self.ext = self.ctx._ext_stream()
-                self.cur = torch.cuda.current_stream(self.tensors[0].device)
-                if self.cur.cuda_stream != self.ext.cuda_stream:
-                    self.ext.wait_stream(self.cur)
+                cur = torch.cuda.current_stream(self.tensors[0].device).cuda_stream
+                if self.ctx._lent != cur:
+                    self.ctx._chk(self.ctx._lib.fnx_ctx_use_stream(self.ctx._h, C.c_void_p(cur)), "fnx_ctx_use_stream")
+                    self.ctx._lent = cur
             return self
 
         def add(self, *tensors):
-            """Outputs allocated inside the block (they need the same allocator / ordering care)."""
             self.tensors.extend(t for t in tensors if _is_torch(t) and t.is_cuda)
 
         def __exit__(self, *exc):
-            if self.tensors and getattr(self, "cur", None) is not None and self.cur.cuda_stream != self.ext.cuda_stream:
-                self.cur.wait_stream(self.ext)
             return False
 
     def _ordered(self, *tensors):
         return Context._Ordered(self, tensors)
+
+    def use_own_stream(self):
+        """Back to the ctx's private stream (plans and C-style callers that order work themselves)."""
+        self._chk(self._lib.fnx_ctx_use_own_stream(self._h), "fnx_ctx_use_own_stream")
+        self._lent = -1
 
     def _pair(self, a, b):
         ia, ib = _Img(a), _Img(b)
@@ -683,7 +677,8 @@ class Context:
 
     # -- batched forms (device tensors) ---------------------------------------------------
     # Contract of the plan_* objects: creating a plan synchronises torch's current stream once (the inputs
-    # exist from then on); run() / enqueue() only touch the ctx stream, fetch() / run() of the scoring plans
+    # exist from then on); run() / enqueue() only touch the stream the ctx launches on (its own unless a per-image
+    # device call lent it torch's; use_own_stream() goes back), fetch() / run() of the scoring plans
     # block until the results -- and therefore every kernel queued before them -- are complete.  A caller
     # that rewrites the input tensors with torch between two runs must order that itself (ctx.sync() /
     # torch.cuda.synchronize()).  The convenience wrappers (GaussianBlurBatch, ...) order both ways.
@@ -709,8 +704,8 @@ class Context:
         """n same-sized device images, one launch per stage (enqueued; call sync() to wait)."""
         if sigma <= 0:
             return list(imgs)
-        plan = self.plan_blur_batch(imgs, sigma, outs=outs, exact=exact)
-        with self._ordered(*imgs, *plan.outs):
+        with self._ordered(*imgs):
+            plan = self.plan_blur_batch(imgs, sigma, outs=outs, exact=exact)
             plan.run()
         return plan.outs
 
@@ -833,8 +828,8 @@ class Context:
     def GaussianBlurSSIMFastBatch(self, imgs, sigma: float, outs=None, exact: bool = False, window=None,
                                   kernel=None):
         """-> (blurred images, numpy array of SSIMFast(imgs[i], blurred[i]))."""
-        plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window, kernel=kernel)
-        with self._ordered(*imgs, *plan.outs):
+        with self._ordered(*imgs):
+            plan = self.plan_blur_ssim_fast_batch(imgs, sigma, outs=outs, exact=exact, window=window, kernel=kernel)
             vals = plan.run().copy()
         return plan.outs, vals
 

@@ -99,7 +99,9 @@ struct fnx_resize_plan;   // resize.hip: device tables of one (tap table, direct
 
 struct fnx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // where the ctx launches: its own stream, or one lent by the caller (fnx_ctx_use_stream)
+    hipStream_t own_stream = nullptr;   // created with the ctx, destroyed with it
+    hipEvent_t ev_switch = nullptr;
     // One-pass GaussianBlur + SSIMFast batches (api.cpp): the blur kernel of step s runs on `stream`, the
     // step's tail on `stream2`, ordered by ev_blur[p]; step s + 2 reuses buffer set p = s & 1 and waits for
     // ev_tail[p] first.  A caller that enqueues step s + 1 before fetching step s gets the tail for free.

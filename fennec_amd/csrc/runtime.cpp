@@ -253,6 +253,7 @@ int fnx_ctx_create(int device, fnx_ctx **out)
         delete c;
         return FNX_ERR_HIP;
     }
+    c->own_stream = c->stream;
     {
         // the tail stream.  FNX_TAIL_PRIO=low|high moves it to the end of the device's priority range (experiments)
         int least = 0, greatest = 0;
@@ -296,8 +297,9 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
                 if (e) (void)hipEventDestroy(e);
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
         for (int i = 0; i < 2; i++) {
             if (ctx->ev_blur[i]) (void)hipEventDestroy(ctx->ev_blur[i]);
             if (ctx->ev_tail[i]) (void)hipEventDestroy(ctx->ev_tail[i]);
@@ -334,6 +336,34 @@ int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms)
 }
 
 void *fnx_ctx_stream(fnx_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+// Everything already enqueued by the ctx (on the stream it leaves and on its tail stream) is ordered before
+// whatever it launches on the new stream: one event hand-over at the switch, nothing per call afterwards.
+static int switch_stream(fnx_ctx *ctx, hipStream_t ns)
+{
+    if (ns == ctx->stream) return FNX_OK;
+    if (!ctx->ev_switch) FNX_HIP(hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming));
+    FNX_HIP(hipEventRecord(ctx->ev_switch, ctx->stream));
+    FNX_HIP(hipStreamWaitEvent(ns, ctx->ev_switch, 0));
+    if (ctx->stream2_used) {
+        FNX_HIP(hipEventRecord(ctx->ev_switch, ctx->stream2));
+        FNX_HIP(hipStreamWaitEvent(ns, ctx->ev_switch, 0));
+    }
+    ctx->stream = ns;
+    return FNX_OK;
+}
+
+int fnx_ctx_use_stream(fnx_ctx *ctx, void *stream)
+{
+    FNX_TRY(bind(ctx));
+    return switch_stream(ctx, static_cast<hipStream_t>(stream));
+}
+
+int fnx_ctx_use_own_stream(fnx_ctx *ctx)
+{
+    FNX_TRY(bind(ctx));
+    return switch_stream(ctx, ctx->own_stream);
+}
 
 int fnx_ctx_sync(fnx_ctx *ctx)
 {

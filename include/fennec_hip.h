@@ -88,6 +88,15 @@ void fnx_ctx_destroy(fnx_ctx *ctx);
 int fnx_ctx_device(const fnx_ctx *ctx);
 /* The ctx's hipStream_t (as void*), for callers that time or order work. */
 void *fnx_ctx_stream(fnx_ctx *ctx);
+/* Launch on a stream of the CALLER's (a framework's current stream, the NULL stream included) instead of the ctx's
+ * own: FNX_DEVICE work is then ordered with the caller's other work on that stream by construction -- inputs the
+ * caller produced there are complete before the kernels read them, outputs are ready for whatever the caller enqueues
+ * next, and a stream-ordered allocator may recycle the tensors safely -- with no cross-stream event per call (each such
+ * dependency costs ~25 us of idle GPU between two back-to-back calls).  The switch itself orders everything the ctx has
+ * already enqueued before the new stream's work.  The ctx does not own a lent stream: keep it alive until the ctx has
+ * been switched away from it (or destroyed after a sync).  fnx_ctx_use_own_stream returns to the ctx's stream. */
+int fnx_ctx_use_stream(fnx_ctx *ctx, void *hip_stream);
+int fnx_ctx_use_own_stream(fnx_ctx *ctx);
 /* Block until everything enqueued on the ctx has finished. */
 int fnx_ctx_sync(fnx_ctx *ctx);
 /* Diagnostics for roofline reporting: while enabled, the ctx brackets every launch of the selected
