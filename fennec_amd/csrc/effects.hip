@@ -164,23 +164,38 @@ __global__ __launch_bounds__(256) void fx_march_kernel(FxArgs a)
     // ---- stage the (TH + 2) x (TW + 2) source tile: clamped reads -- out-of-image cells are only ever
     // neighbours of border pixels, which are copies of the source and never look at them
     if (a.vec_ok && x0 + FX_TW <= a.w) {
-        for (int i = tid; i < LH * (FX_TW / 4); i += 256) {
+        // all of a lane's 16-byte loads are issued before the first is used (indices clamped, no branch around
+        // them): one memory latency per tile instead of one per trip
+        constexpr int NITEM = LH * (FX_TW / 4), TRIPS = (NITEM + 255) / 256;
+        u32x4 v[TRIPS];
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = min(tid + 256 * k, NITEM - 1);
             const int ly = i >> 4, c = i & 15;
             const int y = clampi(y0 + ly - 1, 0, a.h - 1);
-            const u32x4 v = *(g_u32x4 *)(a.src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x0 + 4 * c));
-            const int cell = ly * LW + 4 + 4 * c;
-            *reinterpret_cast<u32x4 *>(&s_rb[cell]) = (u32x4){v[0] & 0x00ff00ffu, v[1] & 0x00ff00ffu, v[2] & 0x00ff00ffu, v[3] & 0x00ff00ffu};
-            *reinterpret_cast<u32x4 *>(&s_ga[cell]) = (u32x4){(v[0] >> 8) & 0x00ff00ffu, (v[1] >> 8) & 0x00ff00ffu,
-                                                              (v[2] >> 8) & 0x00ff00ffu, (v[3] >> 8) & 0x00ff00ffu};
-            if constexpr (MODE == FX_ADAPTIVE)
-                *reinterpret_cast<u32x4 *>(&s_lum[cell]) = (u32x4){lum_milli_u32(v[0]), lum_milli_u32(v[1]), lum_milli_u32(v[2]), lum_milli_u32(v[3])};
+            v[k] = *(g_u32x4 *)(a.src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(x0 + 4 * c));
         }
+        uint32_t halo = 0;
         if (tid < 2 * LH) {                                      // halo columns x0 - 1 and x0 + 64
             const int ly = tid >> 1, side = tid & 1;
             const int y = clampi(y0 + ly - 1, 0, a.h - 1);
             const int x = clampi(side ? x0 + FX_TW : x0 - 1, 0, a.w - 1);
-            put(ly * LW + (side ? 4 + FX_TW : 3), ld_px(a.src + static_cast<size_t>(y) * a.sstride, x));
+            halo = ld_px(a.src + static_cast<size_t>(y) * a.sstride, x);
         }
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = tid + 256 * k;
+            if (i < NITEM) {
+                const int ly = i >> 4, c = i & 15;
+                const int cell = ly * LW + 4 + 4 * c;
+                *reinterpret_cast<u32x4 *>(&s_rb[cell]) = (u32x4){v[k][0] & 0x00ff00ffu, v[k][1] & 0x00ff00ffu, v[k][2] & 0x00ff00ffu, v[k][3] & 0x00ff00ffu};
+                *reinterpret_cast<u32x4 *>(&s_ga[cell]) = (u32x4){(v[k][0] >> 8) & 0x00ff00ffu, (v[k][1] >> 8) & 0x00ff00ffu,
+                                                                  (v[k][2] >> 8) & 0x00ff00ffu, (v[k][3] >> 8) & 0x00ff00ffu};
+                if constexpr (MODE == FX_ADAPTIVE)
+                    *reinterpret_cast<u32x4 *>(&s_lum[cell]) = (u32x4){lum_milli_u32(v[k][0]), lum_milli_u32(v[k][1]), lum_milli_u32(v[k][2]), lum_milli_u32(v[k][3])};
+            }
+        }
+        if (tid < 2 * LH) put((tid >> 1) * LW + ((tid & 1) ? 4 + FX_TW : 3), halo);
     } else {
         for (int i = tid; i < LH * (FX_TW + 2); i += 256) {
             const int ly = i / (FX_TW + 2), lx = i - ly * (FX_TW + 2);
