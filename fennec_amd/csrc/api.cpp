@@ -631,6 +631,11 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
         double *dres;
         FNX_TRY(result_slot(ctx, 5, &dres));
+        const int fused = launch_msssim_fused(ctx, da.p, da.stride, db.p, db.stride, w, h, nweights, window, dres, &nlev);
+        if (fused < 0) return fused;
+        if (fused == FNX_OK) {
+            FNX_TRY(result_wait(ctx, dres, lv, nlev));
+        } else {
         // pyramid storage: levels 1.. of both images, ping-ponged in two slots per side
         const uint8_t *ca = da.p, *cb = db.p;
         int cas = da.stride, cbs = db.stride, cw = w, ch = h;
@@ -657,6 +662,7 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         }
         FNX_TRY(launch_ssim_finish_deferred(ctx, defer, dres));
         FNX_TRY(result_wait(ctx, dres, lv, nlev));
+        }
     }
     double result = 0;
     for (int i = 0; i < nlev; i++) result += weights[i] * std::log(std::fmax(lv[i], 1e-10));   // ssim.go:351

@@ -255,6 +255,10 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
                          const double *h_window, const double *d_window, double *d_out,
                          SsimDeferred *defer = nullptr, int defer_out_index = 0);
 int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out);
+// MSSSIM's levels in five launches (ssim.hip); FNX_NOOP (nothing launched) for shapes it does not cover.
+// d_out[i] = SSIMFast of level i; *nlev = levels the reference's loop visits.
+int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                        int nweights, const double *h_window, double *d_out, int *nlev);
 int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
                       size_t pix_len, double *d_out);
 // Analyze's device side (analyze.hip): n images -> d_res[n]; aligned16_ok: every base pointer is 16-byte aligned

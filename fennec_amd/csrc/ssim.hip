@@ -7,6 +7,8 @@
 #include "common.hpp"
 #include "devutil.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace fnx {
@@ -91,16 +93,15 @@ __device__ __forceinline__ void box_trip(const uint8_t *q, int sstride, uint32_t
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
+__device__ __forceinline__ void box_tiled_body(const BoxArgs &a, const int bx, const int by, const int z)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
-    const int z = blockIdx.z;
     const bool second = z >= a.nimg;
     const int zi = second ? z - a.nimg : z;
     const uint8_t *src = second ? (a.srcs_b ? a.srcs_b[zi] : a.src_b) : (a.srcs ? a.srcs[zi] : a.src);
     const int sstride = second ? a.sstride_b : a.sstride;
-    const int dy = blockIdx.y;
-    const int dx_lo = blockIdx.x * a.seg;
+    const int dy = by;
+    const int dx_lo = bx * a.seg;
     const int dx_hi = min(dx_lo + a.seg, a.dstW);
     int sy0, sy1, sxa, sxb, t0, t1;
     box_edge(dy, a.yRatio, a.srcH, sy0, sy1);
@@ -176,6 +177,27 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
         *reinterpret_cast<uint32_t *>(dimg + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) =
             box_finish(r, g, b, al, count);
     }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
+{
+    box_tiled_body<VEC>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several independent pair downsamples in one launch (MSSSIM: the <= 512 px planes of every level that needs
+// them): blockIdx.z = 2 * job + side, grid x / y = the largest job's
+constexpr int BOX_MAXJOBS = 4;
+struct BoxMulti {
+    BoxArgs job[BOX_MAXJOBS];
+    int gx[BOX_MAXJOBS], gy[BOX_MAXJOBS];
+};
+
+__global__ __launch_bounds__(256) void box_tiled_multi_kernel(BoxMulti m)
+{
+    const int j = blockIdx.z >> 1;
+    if (static_cast<int>(blockIdx.x) >= m.gx[j] || static_cast<int>(blockIdx.y) >= m.gy[j]) return;
+    box_tiled_body<true>(m.job[j], blockIdx.x, blockIdx.y, blockIdx.z & 1);
 }
 
 int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
@@ -316,15 +338,13 @@ struct WinSepArgs {
 // luminance products saved 6 fp64 ops per pixel and cost 20 %: dependent, bank-conflicting reads.)
 // Big planes take windowed_ssim_sep24_kernel below; this one serves planes with too few windows for it.
 template <int TY, int NTHR>
-__global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
+__device__ __forceinline__ void ssim_sep_body(const WinSepArgs &a, const int tile, const int z)
 {
     constexpr int LW = WSS_TX + 8, LH = TY + 7;   // 39 columns are used; an even pitch keeps row starts 16-byte aligned
     constexpr int WPT = WSS_TX * TY / NTHR;       // vertically adjacent windows per lane
     __shared__ __attribute__((aligned(16))) double s_a[LH * LW], s_b[LH * LW];
     __shared__ __attribute__((aligned(16))) double s_h[4][LH * WSS_TX];   // E[a], E[b], E[a^2 + b^2], E[ab] after the H pass
     __shared__ double s_red[NTHR / 64];
-    const int z = blockIdx.y;
-    const int tile = blockIdx.x;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int wx0 = tx * WSS_TX, wy0 = ty * TY;
     const uint8_t *A = a.a + a.a_image_bytes * z;
@@ -423,6 +443,25 @@ __global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
         for (int wv = 1; wv < NTHR / 64; wv++) t += s_red[wv];
         a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
     }
+}
+
+template <int TY, int NTHR>
+__global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
+{
+    ssim_sep_body<TY, NTHR>(a, blockIdx.x, blockIdx.y);
+}
+
+// several single-pair window jobs of different sizes in one launch (MSSSIM's levels): blockIdx.y = job
+constexpr int WS_MAXJOBS = 5;
+struct WinSepMulti {
+    WinSepArgs job[WS_MAXJOBS];
+};
+
+__global__ __launch_bounds__(256) void windowed_ssim_sep_multi_kernel(WinSepMulti m)
+{
+    const WinSepArgs &a = m.job[blockIdx.y];
+    if (static_cast<int>(blockIdx.x) >= a.tiles) return;
+    ssim_sep_body<WSS_TY, 256>(a, blockIdx.x, 0);
 }
 
 // rank-1 factorisation of the 8x8 table: col[i] = sum_j k[j][i], row[j] = sum_i k[j][i] / sum(k).
@@ -836,6 +875,210 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(n), dim3(256), 0, ctx->stream,
                        static_cast<const double *>(part), tiles, count, d_out);
     FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// MSSSIM (ssim.go:313-365) in five launches instead of ~15: when every halving is an exact 2 x 2 box (both dims
+// divisible by 2^levels: 4K, 8K, 1080p/8 ...) one kernel reads the full-size pair ONCE and writes every level
+// (clampF(sum * 0.25) == (sum + 2) >> 2 for integer sums, all four channels); the <= 512 px SSIMFast planes of
+// the levels that need them come from ONE multi-job box launch, the five window sums from ONE multi-job launch,
+// the means from the deferred finish.  Anything else (odd dims, tables that are not rank-1, unaligned views)
+// returns FNX_NOOP and the caller runs the level-by-level loop.  Results are identical: same kernels' bodies,
+// same integer box arithmetic.
+// ------------------------------------------------------------------------------------
+struct PyrArgs {
+    const uint8_t *src[2];
+    int sstride[2];
+    int w, h, nl;            // level-0 dims, number of halvings (1..4)
+    uint8_t *lv[2][4];       // [side][k - 1]: level k, tight (w >> k) x (h >> k)
+};
+
+__device__ __forceinline__ uint32_t quad_mean(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11)
+{
+    const uint32_t rb = ((p00 & 0x00ff00ffu) + (p01 & 0x00ff00ffu) + (p10 & 0x00ff00ffu) + (p11 & 0x00ff00ffu) + 0x00020002u) >> 2;
+    const uint32_t ga = (((p00 >> 8) & 0x00ff00ffu) + ((p01 >> 8) & 0x00ff00ffu) + ((p10 >> 8) & 0x00ff00ffu) + ((p11 >> 8) & 0x00ff00ffu) + 0x00020002u) >> 2;
+    return (rb & 0x00ff00ffu) | ((ga & 0x00ff00ffu) << 8);
+}
+
+// workgroup = 128 x 16 level-0 pixels of one image -> 64 x 8 (L1), 32 x 4 (L2), 16 x 2 (L3), 8 x 1 (L4)
+__global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
+{
+    __shared__ uint32_t s_l1[8][64], s_l2[4][32], s_l3[2][16];
+    const int side = blockIdx.z, tid = threadIdx.x;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int lx = tid & 31, ly = tid >> 5;
+        const int x = bx * 128 + 4 * lx, y = by * 16 + 2 * ly;
+        u32x4 r0 = {0, 0, 0, 0}, r1 = r0;
+        const bool in = x < a.w && y < a.h;                        // w % 4 == 0, h % 2 == 0
+        if (in) {
+            const uint8_t *p = a.src[side] + static_cast<size_t>(y) * a.sstride[side] + 4 * static_cast<size_t>(x);
+            r0 = ld16_stream(p);
+            r1 = ld16_stream(p + a.sstride[side]);
+        }
+        const uint32_t q0 = quad_mean(r0[0], r0[1], r1[0], r1[1]), q1 = quad_mean(r0[2], r0[3], r1[2], r1[3]);
+        s_l1[ly][2 * lx] = q0;
+        s_l1[ly][2 * lx + 1] = q1;
+        if (in) {
+            const int w1 = a.w >> 1;
+            *reinterpret_cast<u32x2 *>(a.lv[side][0] + (static_cast<size_t>(by * 8 + ly) * w1 + bx * 64 + 2 * lx) * 4) = (u32x2){q0, q1};
+        }
+    }
+    if (a.nl < 2) return;
+    __syncthreads();
+    if (tid < 128) {
+        const int lx = tid & 31, ly = tid >> 5;
+        const uint32_t q = quad_mean(s_l1[2 * ly][2 * lx], s_l1[2 * ly][2 * lx + 1], s_l1[2 * ly + 1][2 * lx], s_l1[2 * ly + 1][2 * lx + 1]);
+        s_l2[ly][lx] = q;
+        const int X = bx * 32 + lx, Y = by * 4 + ly, w2 = a.w >> 2;
+        if (X < w2 && Y < (a.h >> 2)) *reinterpret_cast<uint32_t *>(a.lv[side][1] + (static_cast<size_t>(Y) * w2 + X) * 4) = q;
+    }
+    if (a.nl < 3) return;
+    __syncthreads();
+    if (tid < 32) {
+        const int lx = tid & 15, ly = tid >> 4;
+        const uint32_t q = quad_mean(s_l2[2 * ly][2 * lx], s_l2[2 * ly][2 * lx + 1], s_l2[2 * ly + 1][2 * lx], s_l2[2 * ly + 1][2 * lx + 1]);
+        s_l3[ly][lx] = q;
+        const int X = bx * 16 + lx, Y = by * 2 + ly, w3 = a.w >> 3;
+        if (X < w3 && Y < (a.h >> 3)) *reinterpret_cast<uint32_t *>(a.lv[side][2] + (static_cast<size_t>(Y) * w3 + X) * 4) = q;
+    }
+    if (a.nl < 4) return;
+    __syncthreads();
+    if (tid < 8) {
+        const uint32_t q = quad_mean(s_l3[0][2 * tid], s_l3[0][2 * tid + 1], s_l3[1][2 * tid], s_l3[1][2 * tid + 1]);
+        const int X = bx * 8 + tid, Y = by, w4 = a.w >> 4;
+        if (X < w4 && Y < (a.h >> 4)) *reinterpret_cast<uint32_t *>(a.lv[side][3] + (static_cast<size_t>(Y) * w4 + X) * 4) = q;
+    }
+}
+
+// SSIMFast's dims (ssim.go:52-56); api.cpp holds the same arithmetic for the per-op entry points
+static bool fast_dims(int w, int h, int *nw, int *nh)
+{
+    *nw = w; *nh = h;
+    if (w > 512 || h > 512) {
+        const double scale = 512.0 / std::fmax(double(w), double(h));
+        *nw = int(std::fmax(8, std::round(double(w) * scale)));
+        *nh = int(std::fmax(8, std::round(double(h) * scale)));
+        return true;
+    }
+    return false;
+}
+
+int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                        int nweights, const double *h_window, double *d_out, int *nlev)
+{
+    const char *lvw = getenv("FNX_MSSSIM_LEVELWISE");             // "1": A/B and tests
+    if ((lvw && lvw[0] == '1') || nweights < 1 || nweights > WS_MAXJOBS) return FNX_NOOP;
+    WinSepArgs proto{};
+    if (!window_rank1(h_window, proto.col, proto.row)) return FNX_NOOP;
+    // levels the reference's loop visits: level i + 1 exists while both halved dims stay >= 8 (ssim.go:354-358)
+    int lw[5], lh[5], levels = 1;
+    lw[0] = w; lh[0] = h;
+    while (levels < nweights && lw[levels - 1] / 2 >= 8 && lh[levels - 1] / 2 >= 8) {
+        lw[levels] = lw[levels - 1] / 2; lh[levels] = lh[levels - 1] / 2;
+        levels++;
+    }
+    const int nl = levels - 1;
+    if (w < 8 || h < 8 || (w & 3) || nl > 4) return FNX_NOOP;
+    if (nl > 0 && ((w & ((1 << nl) - 1)) || (h & ((1 << nl) - 1)))) return FNX_NOOP;      // some halving is not 2 x 2
+    if (!aligned16(a, astride) || !aligned16(b, bstride)) return FNX_NOOP;
+    // storage: pyramid levels 1..nl of both sides, then the SSIMFast planes of the levels that need them
+    size_t off_lv[2][4] = {}, total = 0;
+    for (int k = 1; k <= nl; k++)
+        for (int sd = 0; sd < 2; sd++) {
+            off_lv[sd][k - 1] = total;
+            total += (static_cast<size_t>(lw[k]) * lh[k] * 4 + 15) & ~size_t(15);
+        }
+    void *pyr = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP0, total + 16, &pyr));
+    int pw[5], ph[5];
+    bool down[5];
+    size_t off_pl[5] = {}, ptotal = 0;
+    for (int i = 0; i < levels; i++) {
+        down[i] = fast_dims(lw[i], lh[i], &pw[i], &ph[i]);
+        if (pw[i] < 9 || ph[i] < 9) return FNX_NOOP;             // pixelSSIM / zero-window levels: level-wise loop
+        if (down[i]) {
+            if (lw[i] & 3) return FNX_NOOP;                      // 16-byte rows for the tiled box kernel
+            off_pl[i] = ptotal;
+            ptotal += 2 * ((static_cast<size_t>(pw[i]) * ph[i] * 4 + 15) & ~size_t(15));
+        }
+    }
+    void *planes = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP2, ptotal + 16, &planes));
+    void *part = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));
+
+    const uint8_t *la[5], *lb[5];
+    int ls[5];
+    la[0] = a; lb[0] = b; ls[0] = 0;
+    if (nl > 0) {
+        PyrArgs pa{};
+        pa.src[0] = a; pa.src[1] = b; pa.sstride[0] = astride; pa.sstride[1] = bstride; pa.w = w; pa.h = h; pa.nl = nl;
+        for (int k = 1; k <= nl; k++) {
+            pa.lv[0][k - 1] = static_cast<uint8_t *>(pyr) + off_lv[0][k - 1];
+            pa.lv[1][k - 1] = static_cast<uint8_t *>(pyr) + off_lv[1][k - 1];
+            la[k] = pa.lv[0][k - 1]; lb[k] = pa.lv[1][k - 1]; ls[k] = lw[k] * 4;
+        }
+        hipLaunchKernelGGL(pyramid_halve_kernel, dim3((w + 127) / 128, (h + 15) / 16, 2), dim3(256), 0, ctx->stream, pa);
+        FNX_HIP(hipGetLastError());
+    }
+    // SSIMFast planes: one launch for every level that is downsampled
+    BoxMulti bm{};
+    int nb = 0, gx = 0, gy = 0;
+    const uint8_t *sa[5], *sb[5];
+    int sas[5], sbs[5];
+    for (int i = 0; i < levels; i++) {
+        sa[i] = la[i]; sb[i] = lb[i];
+        sas[i] = i == 0 ? astride : ls[i]; sbs[i] = i == 0 ? bstride : ls[i];
+        if (!down[i]) continue;
+        if (nb == BOX_MAXJOBS) return FNX_NOOP;
+        BoxArgs &ba = bm.job[nb];
+        uint8_t *dst = static_cast<uint8_t *>(planes) + off_pl[i];
+        const size_t plane = (static_cast<size_t>(pw[i]) * ph[i] * 4 + 15) & ~size_t(15);
+        ba.src = sa[i]; ba.src_b = sb[i]; ba.sstride = sas[i]; ba.sstride_b = sbs[i]; ba.nimg = 1;
+        ba.dst = dst; ba.dst_image_bytes = plane;
+        ba.srcW = lw[i]; ba.srcH = lh[i]; ba.dstride = pw[i] * 4; ba.dstW = pw[i]; ba.dstH = ph[i];
+        ba.xRatio = static_cast<double>(lw[i]) / static_cast<double>(pw[i]);      // ssim.go:251-252
+        ba.yRatio = static_cast<double>(lh[i]) / static_cast<double>(ph[i]);
+        ba.vec_in = 1;
+        const bool tiled = lw[i] >= pw[i] && lh[i] >= ph[i] && ba.yRatio + 1.0 < BOX_MAXROWS && ba.xRatio + 1.0 < BOX_MAXROWS &&
+                           ba.xRatio * 2 + 8 < 4 * BOX_CHUNKS;
+        if (!tiled || !aligned16(sa[i], sas[i]) || !aligned16(sb[i], sbs[i])) return FNX_NOOP;
+        ba.packed_ok = (static_cast<double>(static_cast<long>(ba.yRatio) + 2) * static_cast<double>(static_cast<long>(ba.xRatio) + 2) * 255.0) < 65536.0;
+        int seg = static_cast<int>((4 * BOX_CHUNKS - 8) / ba.xRatio);
+        ba.seg = seg > 256 ? 256 : (seg < 1 ? 1 : seg);
+        bm.gx[nb] = (pw[i] + ba.seg - 1) / ba.seg; bm.gy[nb] = ph[i];
+        gx = std::max(gx, bm.gx[nb]); gy = std::max(gy, bm.gy[nb]);
+        sa[i] = dst; sb[i] = dst + plane; sas[i] = sbs[i] = pw[i] * 4;
+        nb++;
+    }
+    if (nb > 0) {
+        hipLaunchKernelGGL(box_tiled_multi_kernel, dim3(gx, gy, 2 * nb), dim3(256), 0, ctx->stream, bm);
+        FNX_HIP(hipGetLastError());
+    }
+    // the window sums of every level: one launch
+    WinSepMulti wm{};
+    SsimDeferred defer;
+    int maxt = 1;
+    for (int i = 0; i < levels; i++) {
+        WinSepArgs &wa = wm.job[i];
+        wa = proto;
+        wa.a = sa[i]; wa.b = sb[i]; wa.astride = sas[i]; wa.bstride = sbs[i]; wa.a_image_bytes = wa.b_image_bytes = 0;
+        wa.w = pw[i]; wa.h = ph[i];
+        const int ww = pw[i] - 8, wh = ph[i] - 8;
+        wa.tiles_x = (ww + WSS_TX - 1) / WSS_TX;
+        wa.tiles = wa.tiles_x * ((wh + WSS_TY - 1) / WSS_TY);
+        if (defer.used + wa.tiles + 2 > SSIM_DEFER_DOUBLES) return FNX_NOOP;
+        wa.partial = static_cast<double *>(part) + defer.used;
+        defer.item[defer.count++] = {defer.used, wa.tiles, static_cast<double>(ww) * static_cast<double>(wh), i};
+        defer.used += static_cast<size_t>(wa.tiles) + 2;
+        maxt = std::max(maxt, wa.tiles);
+    }
+    hipLaunchKernelGGL(windowed_ssim_sep_multi_kernel, dim3(maxt, levels), dim3(256), 0, ctx->stream, wm);
+    FNX_HIP(hipGetLastError());
+    FNX_TRY(launch_ssim_finish_deferred(ctx, defer, d_out));
+    *nlev = levels;
     return FNX_OK;
 }
 

@@ -364,6 +364,29 @@ def test_msssim_levels(ctx, orc):
     assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (128, 96), (1024, 768), (2048, 1024), (144, 80), (1000, 600), (512, 512), (4096, 16)])
+def test_msssim_fused_levels(ctx, orc, monkeypatch, w, h):
+    """The five-launch MSSSIM (one-pass 2 x 2 pyramid, multi-job box and window launches) against the level-by-level
+    loop (FNX_MSSSIM_LEVELWISE=1) and the oracle: per level and combined.  Shapes that are not divisible by 2^levels
+    (1000 x 600) or too thin take the loop either way."""
+    import torch
+    a = synth.large_photo(w, h, 2)
+    b = orc.gaussian_blur(a, 1.1)
+    b[h // 3: h // 2, w // 4: w // 2, :3] //= 2
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    monkeypatch.delenv("FNX_MSSSIM_LEVELWISE", raising=False)
+    got, lv = ctx.msssim_levels(da, db)
+    got_h, lv_h = ctx.msssim_levels(a, b)
+    monkeypatch.setenv("FNX_MSSSIM_LEVELWISE", "1")
+    ref, lv_ref = ctx.msssim_levels(da, db)
+    monkeypatch.delenv("FNX_MSSSIM_LEVELWISE", raising=False)
+    want, wl = orc.msssim(a, b, per_level=True, procs=8)
+    assert np.array_equal(np.isnan(lv), np.isnan(wl)) and np.array_equal(np.isnan(lv_ref), np.isnan(wl))
+    assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL and np.nanmax(np.abs(lv_ref - wl)) <= SSIM_TOL
+    assert np.nanmax(np.abs(lv - lv_ref)) <= 1e-12 and got_h == got
+    assert abs(got - want) <= SSIM_TOL and abs(ref - want) <= SSIM_TOL
+
+
 def test_ssim_fast_prepared(ctx, orc):
     a = synth.large_photo(640, 480, 4)
     p = ctx.ssim_fast_prepare(a)
