@@ -74,8 +74,10 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="4K images per step per GPU")
-    ap.add_argument("--contexts", type=int, default=1,
-                    help="worker contexts (HIP streams) per GPU; >1 runs them in complementary phases")
+    ap.add_argument("--contexts", type=int, default=None,
+                    help="worker contexts (one fnx ctx + HIP stream each) per GPU.  Default: 1 for config 2 (one stream, so "
+                         "that `roofline` times the kernel alone) and config 4 (two 100+ us kernels per image already fill "
+                         "the GPU); 4 for config 3, whose ~10 short kernels per image leave most of the GPU idle on one stream")
     ap.add_argument("--pipeline", default="one-pass", choices=["one-pass", "two-call"],
                     help="one-pass (default): fnx_gaussian_blur_ssim_fast_batch, the blur kernel also gathers "
                          "SSIMFast's boxDownsample sums, each image crosses HBM once; two-call: "
@@ -100,6 +102,8 @@ def main() -> int:
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
+    if args.contexts is None:
+        args.contexts = 4 if args.workload == "config3" else 1
     if args.workload != "config2":
         return other_workloads(args)
 
@@ -153,6 +157,7 @@ def main() -> int:
     fused_plans = [c.plan_blur_ssim_fast_batch([srcs[i] for i in hv], SIGMA, outs=[dsts[i] for i in hv], exact=exact)
                    for c, hv in zip(ctxs, halves)] if one_pass else None
     kernel_ms = []
+    fetch_t = []               # host time at which each timed step's results were in hand (queue-ahead loop)
     if one_pass:
         ctx.profile(True)      # the library brackets its blur_direct_kernel launches with HIP events
     ext = torch.cuda.ExternalStream(ctx.stream, device=torch.device("cuda", local_rank))
@@ -199,6 +204,7 @@ def main() -> int:
                     vals[:] = fused_plans[0].fetch()           # fnx_results_fetch: the oldest unfetched batch
                     if events:
                         kernel_ms.append(ctx.kernel_ms())      # that step's blur kernel (oldest unread event pair)
+                        fetch_t.append(time.perf_counter())
             return
         if one_pass:
             for s in range(nsteps):
@@ -280,7 +286,9 @@ def main() -> int:
         roofline = {
             "kernel": f"blur_direct_kernel<R=6, SCORE> (GaussianBlur sigma=2 + both boxDownsample sums of SSIMFast, "
                       f"one launch of {nb0} images)",
-            "bound": "hbm",
+            # achieved / peak / frac are SURVEY 8(d)'s HBM figures (the contract of this object); what actually
+            # bounds the kernel is VALU issue (80.8 wave-instructions per pixel)
+            "bound": "valu",
             "achieved": round(blur_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -291,6 +299,11 @@ def main() -> int:
                                       "needs only 2*S of HBM traffic for it (see traffic)",
             "achieved_on_2S": round(blur_gbs / 2, 1),
             "avg_launch_ms": round(blur_ms, 4),
+            "launch_ms_min_median_max": [round(float(np.min(kernel_ms)), 4), round(float(np.median(kernel_ms)), 4),
+                                         round(float(np.max(kernel_ms)), 4)],
+            "valu_issue_frac": committed_valu_issue("blur_direct_kernel", blur_ms, scored=True, exact=exact),
+            "note": "the previous step's tail (box_from_slabs, windowed SSIM, finish) runs on the ctx's second stream "
+                    "under this launch, so its duration includes their share of the GPU",
         }
         if depth > 1:
             roofline["note"] = (f"measured live in the timed region, where the kernel shares the GPU with the previous "
@@ -362,6 +375,9 @@ def main() -> int:
         "roofline": roofline,
         "roofline_ssimfast": rest,
         "path_hbm_frac": round(path_gbs / world / HBM_PEAK_GBS, 4),
+        "step_ms": ({"min": round(float(np.min(np.diff(fetch_t))) * 1e3, 4), "median": round(float(np.median(np.diff(fetch_t))) * 1e3, 4),
+                     "max": round(float(np.max(np.diff(fetch_t))) * 1e3, 4), "how": "intervals between consecutive steps' results arriving"}
+                    if len(fetch_t) > 2 else None),
         "summarize": {"items": n_items, "avg_ssim": ssim_sum / max(n_items, 1)},
     }
 
@@ -429,16 +445,28 @@ def main() -> int:
         # the same step with bit-exact blurred images (FNX_BLUR_EXACT), after the timed region; never `value`
         ctx.profile(False)
         xplan = ctx.plan_blur_ssim_fast_batch(srcs, SIGMA, outs=dsts, exact=True)
+
+        def exact_steps(n):                               # the default loop's protocol: step s + 1 queued before step s is fetched
+            for s_ in range(n + 1):
+                if s_ < n:
+                    xplan.enqueue()
+                if s_ >= 1:
+                    xplan.fetch()
         t_x = time.perf_counter()
         while time.perf_counter() - t_x < 0.1:
-            xplan.run()
+            exact_steps(4)
+        exact_steps(args.warmup)
+        torch.cuda.synchronize()
         t_x = time.perf_counter()
-        for _ in range(10):
-            xplan.run()
-        t_x = (time.perf_counter() - t_x) / 10
+        exact_steps(args.steps)
+        torch.cuda.synchronize()
+        t_x = (time.perf_counter() - t_x) / args.steps
         out["exact_mode"] = {"value": round(mp_per_image * B / t_x, 1), "unit": "MP/s", "ms_per_step": round(t_x * 1e3, 4),
-                             "note": "same step with FNX_BLUR_EXACT: blurred images bit-identical to the reference's "
-                                     "GaussianBlur, scores from exactly those images; 10 steps after the timed region"}
+                             "steps": args.steps, "warmup": args.warmup,
+                             "note": "the same K steps with FNX_BLUR_EXACT (what the Go shim's GaussianBlur passes): blurred images "
+                                     "bit-identical to the reference's, scores from exactly those images; same protocol as the "
+                                     "timed region (warm-up, synchronize on both sides), run right after it; "
+                                     "`python bench.py --blur-mode exact` makes it the headline line"}
     if rank == 0 and not args.no_extras:
         host = srcs[0].cpu().numpy()
         ctx.GaussianBlur(host, SIGMA, exact=None)
@@ -795,6 +823,32 @@ def other_workloads(args) -> int:
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = False, exact: bool = False):
+    """Fraction of the chip's VALU issue slots the kernel fills: SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs; from the
+    committed PMC pass of this same command) x 4 clocks / (1024 SIMDs x launch duration x shader clock).  The clock is
+    GRBM_GUI_ACTIVE / duration of the profiled launches when that counter was collected, else 2.1 GHz (the steady
+    clock of this kernel).  None when no profile has been committed."""
+    import glob
+    import re
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.txt")), reverse=True):
+        try:
+            act = clk = None
+            for line in open(p):
+                m = re.match(r"(\S+)\s+([0-9.]+)\s+\(mean of \d+ launches\)\s+(.*)", line)
+                if not m or kernel_substr not in m.group(3) or _template_flags(m.group(3)) != (scored, exact):
+                    continue
+                if m.group(1) == "SQ_ACTIVE_INST_VALU":
+                    act = float(m.group(2))
+                if m.group(1) == "GRBM_GUI_ACTIVE_PER_XCD_PER_MS":
+                    clk = float(m.group(2)) * 1e3      # Hz
+            if act is not None:
+                hz = clk or 2.1e9
+                return round(act * 4.0 / (1024.0 * launch_ms * 1e-3 * hz), 4)
+        except Exception:
+            continue
+    return None
 
 
 def committed_traffic_named(kernel_substr: str, tag: str):
