@@ -25,7 +25,10 @@ for (W, H) in [(7680, 4320), (3840, 2160), (1920, 1080), (512, 288)]:
     t0 = time.perf_counter()
     for _ in range(10):
         v = ctx.SSIM(a, b)
-        ms.append(ctx.kernel_ms())
+        try:
+            ms.append(ctx.kernel_ms())
+        except fennec_amd.FennecError:          # small planes take the tile kernels, which are not bracketed
+            ms.append(float("nan"))
     wall = (time.perf_counter() - t0) / 10
     ctx.profile(0)
     win = (W - 8) * (H - 8)
