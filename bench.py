@@ -99,6 +99,9 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements made after the timed region (pipelined, exact_mode, pcie_inclusive): "
                          "profiler runs use it so that kernel statistics cover the timed configuration only")
+    ap.add_argument("--device-search", action="store_true",
+                    help="config5: the quality search round-trips every candidate on the device (fnx_jpeg_quality_search); the host "
+                         "codec decodes the source and encodes the winner only")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
@@ -697,8 +700,12 @@ def other_workloads(args) -> int:
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
-        work = fbatch.jpeg_item_work([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
-                                     on_gpu_seconds=gpu_stage.append)
+        if args.device_search:
+            work = fbatch.jpeg_item_work_device_search([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
+                                                       on_gpu_seconds=gpu_stage.append)
+        else:
+            work = fbatch.jpeg_item_work([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
+                                         on_gpu_seconds=gpu_stage.append)
 
         states = {}
 
@@ -712,6 +719,9 @@ def other_workloads(args) -> int:
             return [r.SSIM for r in res]
         metric, unit, units_per_step = "images/sec: CompressBatch 4K JPEG, SSIM-guided quality search", "images/s", B
         name = f"config5: {B} 4K JPEGs per step per GPU, Balanced (SSIM>=0.94) binary search, Pillow codec on {workers} host threads"
+        if args.device_search:
+            name += ("; search on the device (Go image/jpeg arithmetic without entropy coding, fnx_jpeg_quality_search), host "
+                     "codec: 1 decode + 1 encode per image")
 
     def barrier():
         if world > 1:
@@ -795,8 +805,10 @@ def other_workloads(args) -> int:
     if wl == "config5":
         per_item = float(np.mean(gpu_stage[-B * args.steps:]))
         out["gpu_stage"] = {"seconds_per_image": round(per_item, 6), "images_per_s_per_context": round(1.0 / per_item, 1),
-                            "note": "time inside the C ABI (prepare + every SSIMFast of the search, host buffers: PCIe-inclusive); "
-                                    "the rest of a step is the host JPEG codec (Pillow here, Go's image/jpeg in the reference)"}
+                            "note": ("time inside the C ABI (one H2D of the decoded source + the whole search on the device); the rest "
+                                     "of a step is the host codec: one decode and one encode per image") if args.device_search else
+                                    ("time inside the C ABI (prepare + every SSIMFast of the search, host buffers: PCIe-inclusive); "
+                                     "the rest of a step is the host JPEG codec (Pillow here, Go's image/jpeg in the reference)")}
     if wl == "analyze":
         ms = float(np.mean(pass_ms[-args.steps:]))
         g = alg * B / (ms * 1e-3) / 1e9

@@ -40,7 +40,7 @@ LIB_PATH = os.environ.get("FENNEC_HIP_LIB") or os.path.join(_HERE, "libfennec_hi
 FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
 FNX_HOST, FNX_DEVICE, FNX_DEVICE_SRC = 0, 1, 2
 FNX_BLUR_FAST, FNX_BLUR_EXACT = 0, 1
-PROF_MAIN, PROF_SSIM, PROF_RESIZE, PROF_FX = 1, 2, 4, 8
+PROF_MAIN, PROF_SSIM, PROF_RESIZE, PROF_FX, PROF_JPEG = 1, 2, 4, 8, 16
 
 _u8p = C.c_void_p
 _f64p = C.POINTER(C.c_double)
@@ -137,6 +137,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ssim_fast_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
         _sig(L, "fnx_results_fetch", i, [ctx, i, _f64p])
         _sig(L, "fnx_ssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
+        _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
+        _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
@@ -443,6 +445,29 @@ class Context:
             self._chk(self._lib.fnx_ssim_fast_prepare(self._h, s.space, s.ptr, s.stride, s.w, s.h, C.byref(p)),
                       "fnx_ssim_fast_prepare")
         return _Prepared(self, p, s.w, s.h)
+
+    # -- the JPEG quantisation round trip (first slice) -----------------------
+    def jpeg_roundtrip(self, img, quality: int):
+        """toNRGBARef(jpeg.Decode(jpeg.Encode(img, quality))) as far as the pixels go (fnx_jpeg_roundtrip): baseline
+        4:2:0 with Go's image/jpeg arithmetic, no entropy coding."""
+        s = _Img(img)
+        dst = s.like(s.w, s.h)
+        d = _Img(dst)
+        with self._ordered(img, dst):
+            self._chk(self._lib.fnx_jpeg_roundtrip(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(quality), d.ptr, d.stride),
+                      "fnx_jpeg_roundtrip")
+        return dst
+
+    def jpeg_quality_search(self, img, target_ssim: float, window=None):
+        """compressJPEGOptimal's binary search with every candidate round-tripped and scored on the device
+        (fnx_jpeg_quality_search) -> (quality, ssim, steps, found)."""
+        s = _Img(img)
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        q, st, v = C.c_int(), C.c_int(), C.c_double()
+        with self._ordered(img):
+            rc = self._chk(self._lib.fnx_jpeg_quality_search(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(target_ssim), pk,
+                                                             C.byref(q), C.byref(v), C.byref(st)), "fnx_jpeg_quality_search")
+        return q.value, v.value, st.value, rc == FNX_OK
 
     # -- effects.go ---------------------------------------------------------------------
     def GaussianBlur(self, img, sigma: float, exact: bool | None = False, kernel=None):

@@ -146,6 +146,30 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
     return [results[i] for i in mine]
 
 
+def jpeg_item_work_device_search(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
+                                 on_gpu_seconds: Optional[Callable[[float], None]] = None,
+                                 encode: Callable[[np.ndarray, int], bytes] = pillow_encode,
+                                 decode: Callable[[bytes], np.ndarray] = pillow_decode):
+    """The per-item body of CompressBatch with the quality search ON THE DEVICE (first slice): decode the
+    source once, fnx_jpeg_quality_search round-trips and scores every candidate quality on the GPU (Go's image/jpeg
+    arithmetic without the entropy coder), then the real codec encodes ONCE at the chosen quality -- 2 host codec
+    passes per item instead of ~15 (compress.go:45-74 does an encode and a decode per candidate)."""
+    import time
+
+    def work(idx: int, state) -> BatchResult:
+        data = jpegs[idx]
+        src = decode(data)
+        t0 = time.perf_counter()
+        q, s_, steps, found = state.jpeg_quality_search(src, target_ssim)
+        if on_gpu_seconds is not None:
+            on_gpu_seconds(time.perf_counter() - t0)
+        out = encode(src, q)                      # compress.go:76-86: bestData, or the fallback encode at bestQuality
+        r = BatchResult(Index=idx, OriginalSize=len(data), CompressedSize=len(out), SSIM=s_, Quality=q)
+        r.steps = steps
+        return r
+    return work
+
+
 def jpeg_item_work(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
                    ssim_fast: Optional[Callable] = None, on_gpu_seconds: Optional[Callable[[float], None]] = None):
     """The per-item body of CompressBatch for JPEG inputs (batch.go:88-122 -> compressJPEGOptimal,

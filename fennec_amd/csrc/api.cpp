@@ -837,6 +837,108 @@ int fnx_ssim_fast_against_ycbcr(fnx_ctx *ctx, const fnx_prepared *ref, int space
     return against_device(ctx, ref, static_cast<const uint8_t *>(t), w * 4, window, out);
 }
 
+// ---- the JPEG quantisation round trip (compress.go:45-74; SURVEY 8(f)2, first slice: jpeg.hip) -------------
+namespace {
+
+struct JpegPlanes {
+    uint8_t *p[3];
+    int ys, yh, cs, ch;
+};
+
+int jpeg_planes(fnx_ctx *ctx, Slot slot, int w, int h, JpegPlanes *jp)
+{
+    jpeg_plane_dims(w, h, &jp->ys, &jp->yh, &jp->cs, &jp->ch);
+    const size_t yb = static_cast<size_t>(jp->ys) * jp->yh, cb = static_cast<size_t>(jp->cs) * jp->ch;
+    void *t = nullptr;
+    FNX_TRY(scratch(ctx, slot, yb + 2 * cb + 16, &t));
+    jp->p[0] = static_cast<uint8_t *>(t);
+    jp->p[1] = jp->p[0] + yb;
+    jp->p[2] = jp->p[1] + cb;
+    return FNX_OK;
+}
+
+// planes at `quality` from the unquantised planes in SLOT_JPEG0, then the NRGBA image toNRGBARef makes of them
+int jpeg_decode_at(fnx_ctx *ctx, const JpegPlanes &orig, int w, int h, int quality, uint8_t *dst, int dstride)
+{
+    JpegPlanes work;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG1, w, h, &work));
+    const uint8_t *in[3] = {orig.p[0], orig.p[1], orig.p[2]};
+    FNX_TRY(launch_jpeg_blocks(ctx, w, h, quality, in, work.p));
+    return launch_ycbcr_to_nrgba(ctx, work.p[0], work.ys, work.p[1], work.p[2], work.cs, 2, w, h, dst, dstride);
+}
+
+}  // namespace
+
+int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality,
+                       uint8_t *dst, int dstride)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space_io(space));
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    FNX_TRY(check_img(dst, dstride, w, h, "dst"));
+    if (w <= 0 || h <= 0) return FNX_OK;
+    DevImg s;
+    DevOut d;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    FNX_TRY(jpeg_decode_at(ctx, orig, w, h, quality, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
+                            const double *window, int *quality, double *ssim, int *steps)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && quality && ssim && w > 0 && h > 0, "search arguments");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    // the source side of every SSIMFast of the search: prepared once (ssim.go:57 on the reference side)
+    fnx_prepared ref;
+    ref.w = w; ref.h = h;
+    const bool ds = ssim_fast_dims(w, h, &ref.pw, &ref.ph);
+    void *rp = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG3, static_cast<size_t>(ref.pw) * ref.ph * 4 + 16, &rp));
+    ref.pix = static_cast<uint8_t *>(rp);
+    if (ds) FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, w, h, ref.pix, ref.pw * 4, 0, ref.pw, ref.ph));
+    else FNX_HIP(hipMemcpy2DAsync(ref.pix, size_t(w) * 4, s.p, s.stride, size_t(w) * 4, h, hipMemcpyDeviceToDevice, ctx->stream));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    void *dec = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG2, static_cast<size_t>(w) * h * 4 + 16, &dec));
+    // compress.go:24-74
+    if (target_ssim >= 1.0) target_ssim = 0.999;
+    int lo = 1, hi = 100, best_q = hi, n = 0;
+    double best_ssim = 1.0;
+    bool found = false;
+    if (target_ssim >= 0.99) lo = 75;
+    else if (target_ssim >= 0.97) lo = 50;
+    else if (target_ssim >= 0.94) lo = 30;
+    else if (target_ssim >= 0.90) lo = 15;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        FNX_TRY(jpeg_decode_at(ctx, orig, w, h, mid, static_cast<uint8_t *>(dec), w * 4));
+        double v = 0;
+        FNX_TRY(against_device(ctx, &ref, static_cast<const uint8_t *>(dec), w * 4, window, &v));
+        n++;
+        if (v >= target_ssim) {
+            best_q = mid; best_ssim = v; found = true;
+            hi = mid - 1;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    *quality = best_q;
+    *ssim = best_ssim;
+    if (steps) *steps = n;
+    return found ? FNX_OK : FNX_NOOP;      // FNX_NOOP: no quality reached the target (compress.go:82-86: encode at 100)
+}
+
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
 {
     if (!p) return;

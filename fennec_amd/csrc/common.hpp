@@ -61,6 +61,11 @@ enum Slot {
     SLOT_PLANES1,
     SLOT_PART0,
     SLOT_PART1,
+    // the JPEG quantisation round trip (jpeg.hip): unquantised planes, planes at a quality, decoded NRGBA, search reference
+    SLOT_JPEG0,
+    SLOT_JPEG1,
+    SLOT_JPEG2,
+    SLOT_JPEG3,
     SLOT_COUNT
 };
 
@@ -274,5 +279,10 @@ int launch_ycbcr_to_nrgba(fnx_ctx *ctx, const uint8_t *y, int ystride, const uin
                           int cstride, int ratio, int w, int h, uint8_t *dst, int dstride);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
                   uint8_t *dst, int dstride);
+// jpeg.hip: plane geometry of the 4:2:0 round trip (Y: ys x yh, Cb / Cr: cs x ch), the quality-independent colour
+// conversion + chroma averaging, and fdct / quantise / dequantise / idct of every block at `quality` (in -> out)
+void jpeg_plane_dims(int w, int h, int *ys, int *yh, int *cs, int *ch);
+int launch_jpeg_ycc(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *yp, uint8_t *cbp, uint8_t *crp);
+int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const in[3], uint8_t *const out[3]);
 
 }  // namespace fnx

@@ -110,6 +110,7 @@ int fnx_ctx_sync(fnx_ctx *ctx);
 #define FNX_PROF_SSIM 2    /* windowed_ssim_march_kernel */
 #define FNX_PROF_RESIZE 4  /* resize H and V kernels (two launches per lanczosResize) */
 #define FNX_PROF_FX 8      /* fx kernels: gaussianBlur3x3 / Sharpen / AdaptiveSharpen */
+#define FNX_PROF_JPEG 16   /* jpeg_block_kernel (fdct, quantise, dequantise, idct of every block) */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
 
@@ -182,6 +183,20 @@ int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride
 int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
                           int bstride, const double *window, double *out);
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p);
+
+/* SURVEY 8(f)2, first slice -- the JPEG quantisation round trip on the device.  dst = toNRGBARef(jpeg.Decode(
+ * jpeg.Encode(src, Options{Quality: quality}))) as far as the PIXELS go (compress.go:50-58 via io.go:157-169): baseline
+ * 4:2:0, Go's colour equations, integer FDCT / IDCT and quantiser scaling, no entropy coding (it is lossless).  The
+ * arithmetic restates Go's standard library, which is not part of the reference tree: parity with Go is unpinned twice
+ * over; against the oracle's restatement it is bit-exact. */
+int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality,
+                       uint8_t *dst, int dstride);
+/* compressJPEGOptimal's binary search (compress.go:21-74) with every candidate quality round-tripped and scored on the
+ * device: *quality = lowest quality whose SSIMFast(src, round trip) >= target_ssim (the reference's lower bounds by
+ * target, target >= 1 -> 0.999), *ssim its score, *steps the candidates tried.  FNX_NOOP: none reached the target
+ * (*quality = 100, *ssim = 1.0, as the reference's fallback).  The caller encodes ONCE, at *quality, with the real codec. */
+int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
+                            const double *window /* 64 */, int *quality, double *ssim, int *steps);
 
 /* ---- convert.go / exif.go --------------------------------------------- */
 /* ApplyOrientation (exif.go:178-203 over convert.go:186-256).  orient 2..8;

@@ -1336,3 +1336,275 @@ ORC_API void orc_ycbcr_to_nrgba(const uint8_t *yp, int ystride, const uint8_t *c
         }
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* JPEG quantisation round trip: what decode(encode(img, q)) does to   */
+/* the PIXELS (compress.go:50-58 via io.go:157-169: jpeg.Encode with   */
+/* Options{Quality: q}, then jpeg.Decode + toNRGBARef)                 */
+/* ------------------------------------------------------------------ */
+/*
+ * The arithmetic is Go's standard library (image/jpeg: writer.go, fdct.go, idct.go, reader.go, scan.go;
+ * image/color: ycbcr.go), toolchain pinned by go.mod:3 (go 1.25.5) and NOT under /root/reference.  It is restated here
+ * from the published algorithms those files implement and cite -- the IJG's jfdctint.c (13-bit constants, the
+ * "slow-but-accurate" integer FDCT, output scaled by 8), the Chen-Wang integer IDCT of the MPEG-2 reference decoder
+ * (w1..w7 = 2048*sqrt(2)*cos(k*pi/16)), Annex K's quantisation tables with the IJG quality scaling, JFIF's colour
+ * equations in 16.16 fixed point -- as Go applies them: baseline, 4:2:0, 16x16 MCUs, edge pixels replicated, chroma
+ * averaged 2x2 as (sum + 2) >> 2, coefficients divided by 8*q rounded half away from zero.  Entropy coding is lossless
+ * and therefore absent: the decoded image is a function of the quantised coefficients alone.
+ * PARITY UNPINNED TWICE OVER: no Go toolchain to compare with, and the source restated is not even in the reference
+ * tree.  tests/test_jpeg_roundtrip.py sanity-checks it against libjpeg-turbo (Pillow): identical quantisation tables,
+ * decoded images within a few grey levels -- libjpeg differs from Go in its chroma constants, its downsampling bias and
+ * its fancy upsampling, so closeness is all that can be asked.
+ */
+/* Annex K.1 / K.2 in natural (row-major) order; writer.go holds them in zig-zag order (unscaledQuant), and so does the
+ * file: quantisation is element-wise, so the order cancels out of the round trip */
+static const uint8_t jpeg_k1[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56,
+                                    14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92,
+                                    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const uint8_t jpeg_k2[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99,
+                                    47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                    99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+/* writer.go, Encode: quality clipped to [1, 100]; scale = 5000/q below 50, 200 - 2q from 50; x = (x*scale + 50) / 100 in
+ * [1, 255].  Tables returned in NATURAL order (q[unzig[zig]] is writer.go's e.quant[..][zig]). */
+ORC_API void orc_jpeg_quant_tables(int quality, uint8_t *lum, uint8_t *chr)
+{
+    if (quality < 1) quality = 1;
+    if (quality > 100) quality = 100;
+    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int i = 0; i < 64; i++) {
+        int x = ((int)jpeg_k1[i] * scale + 50) / 100;
+        lum[i] = (uint8_t)(x < 1 ? 1 : (x > 255 ? 255 : x));
+        x = ((int)jpeg_k2[i] * scale + 50) / 100;
+        chr[i] = (uint8_t)(x < 1 ? 1 : (x > 255 ? 255 : x));
+    }
+}
+
+/* color.RGBToYCbCr (image/color/ycbcr.go): 16.16 fixed point, 19595 + 38470 + 7471 == 65536 */
+ORC_API void orc_rgb_to_ycbcr(uint8_t r, uint8_t g, uint8_t b, uint8_t *yy, uint8_t *cb, uint8_t *cr)
+{
+    const int32_t r1 = r, g1 = g, b1 = b;
+    *yy = (uint8_t)((19595 * r1 + 38470 * g1 + 7471 * b1 + (1 << 15)) >> 16);
+    int32_t c = -11056 * r1 - 21712 * g1 + 32768 * b1 + (257 << 15);
+    c = (((uint32_t)c & 0xff000000u) == 0) ? c >> 16 : ~(c >> 31);
+    *cb = (uint8_t)c;
+    c = 32768 * r1 - 27440 * g1 - 5328 * b1 + (257 << 15);
+    c = (((uint32_t)c & 0xff000000u) == 0) ? c >> 16 : ~(c >> 31);
+    *cr = (uint8_t)c;
+}
+
+/* fdct.go: jfdctint.c's algorithm, 13-bit constants, level shift included, results scaled up by 8 */
+#define JF_0_298631336 2446
+#define JF_0_390180644 3196
+#define JF_0_541196100 4433
+#define JF_0_765366865 6270
+#define JF_0_899976223 7373
+#define JF_1_175875602 9633
+#define JF_1_501321110 12299
+#define JF_1_847759065 15137
+#define JF_1_961570560 16069
+#define JF_2_053119869 16819
+#define JF_2_562915447 20995
+#define JF_3_072711026 25172
+#define JF_CONST_BITS 13
+#define JF_PASS1_BITS 2
+
+static void jpeg_fdct_1d(int32_t *s, int stride, int pass)
+{
+    const int32_t x0 = s[0], x1 = s[stride], x2 = s[2 * stride], x3 = s[3 * stride], x4 = s[4 * stride], x5 = s[5 * stride],
+                  x6 = s[6 * stride], x7 = s[7 * stride];
+    int32_t tmp0 = x0 + x7, tmp1 = x1 + x6, tmp2 = x2 + x5, tmp3 = x3 + x4;
+    int32_t tmp10 = tmp0 + tmp3, tmp12 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp13 = tmp1 - tmp2;
+    tmp0 = x0 - x7; tmp1 = x1 - x6; tmp2 = x2 - x5; tmp3 = x3 - x4;
+    int32_t z1;
+    const int sh = pass == 1 ? JF_CONST_BITS - JF_PASS1_BITS : JF_CONST_BITS + JF_PASS1_BITS;
+    if (pass == 1) {
+        s[0] = (tmp10 + tmp11 - 8 * 128) << JF_PASS1_BITS;             /* 8 * centerJSample */
+        s[4 * stride] = (tmp10 - tmp11) << JF_PASS1_BITS;
+    } else {
+        tmp10 += 1 << (JF_PASS1_BITS - 1);
+        s[0] = (tmp10 + tmp11) >> JF_PASS1_BITS;
+        s[4 * stride] = (tmp10 - tmp11) >> JF_PASS1_BITS;
+    }
+    z1 = (tmp12 + tmp13) * JF_0_541196100;
+    z1 += 1 << (sh - 1);
+    s[2 * stride] = (z1 + tmp12 * JF_0_765366865) >> sh;
+    s[6 * stride] = (z1 - tmp13 * JF_1_847759065) >> sh;
+
+    tmp10 = tmp0 + tmp3; tmp11 = tmp1 + tmp2; tmp12 = tmp0 + tmp2; tmp13 = tmp1 + tmp3;
+    z1 = (tmp12 + tmp13) * JF_1_175875602;
+    z1 += 1 << (sh - 1);
+    tmp0 *= JF_1_501321110; tmp1 *= JF_3_072711026; tmp2 *= JF_2_053119869; tmp3 *= JF_0_298631336;
+    tmp10 *= -JF_0_899976223; tmp11 *= -JF_2_562915447; tmp12 *= -JF_0_390180644; tmp13 *= -JF_1_961570560;
+    tmp12 += z1; tmp13 += z1;
+    s[1 * stride] = (tmp0 + tmp10 + tmp12) >> sh;
+    s[3 * stride] = (tmp1 + tmp11 + tmp13) >> sh;
+    s[5 * stride] = (tmp2 + tmp11 + tmp12) >> sh;
+    s[7 * stride] = (tmp3 + tmp10 + tmp13) >> sh;
+}
+
+ORC_API void orc_jpeg_fdct(int32_t *b)
+{
+    for (int y = 0; y < 8; y++) jpeg_fdct_1d(b + 8 * y, 1, 1);
+    for (int x = 0; x < 8; x++) jpeg_fdct_1d(b + x, 8, 2);
+}
+
+/* idct.go: Chen-Wang, w_k = 2048*sqrt(2)*cos(k*pi/16) */
+#define JI_W1 2841
+#define JI_W2 2676
+#define JI_W3 2408
+#define JI_W5 1609
+#define JI_W6 1108
+#define JI_W7 565
+#define JI_R2 181
+
+ORC_API void orc_jpeg_idct(int32_t *src)
+{
+    for (int y = 0; y < 8; y++) {                                      /* horizontal 1-D IDCT */
+        int32_t *s = src + 8 * y;
+        if (s[1] == 0 && s[2] == 0 && s[3] == 0 && s[4] == 0 && s[5] == 0 && s[6] == 0 && s[7] == 0) {
+            const int32_t dc = s[0] << 3;
+            for (int i = 0; i < 8; i++) s[i] = dc;
+            continue;
+        }
+        int32_t x0 = (s[0] << 11) + 128, x1 = s[4] << 11, x2 = s[6], x3 = s[2], x4 = s[1], x5 = s[7], x6 = s[5], x7 = s[3], x8;
+        x8 = JI_W7 * (x4 + x5);
+        x4 = x8 + (JI_W1 - JI_W7) * x4;
+        x5 = x8 - (JI_W1 + JI_W7) * x5;
+        x8 = JI_W3 * (x6 + x7);
+        x6 = x8 - (JI_W3 - JI_W5) * x6;
+        x7 = x8 - (JI_W3 + JI_W5) * x7;
+        x8 = x0 + x1;
+        x0 -= x1;
+        x1 = JI_W6 * (x3 + x2);
+        x2 = x1 - (JI_W2 + JI_W6) * x2;
+        x3 = x1 + (JI_W2 - JI_W6) * x3;
+        x1 = x4 + x6;
+        x4 -= x6;
+        x6 = x5 + x7;
+        x5 -= x7;
+        x7 = x8 + x3;
+        x8 -= x3;
+        x3 = x0 + x2;
+        x0 -= x2;
+        x2 = (JI_R2 * (x4 + x5) + 128) >> 8;
+        x4 = (JI_R2 * (x4 - x5) + 128) >> 8;
+        s[0] = (x7 + x1) >> 8; s[1] = (x3 + x2) >> 8; s[2] = (x0 + x4) >> 8; s[3] = (x8 + x6) >> 8;
+        s[4] = (x8 - x6) >> 8; s[5] = (x0 - x4) >> 8; s[6] = (x3 - x2) >> 8; s[7] = (x7 - x1) >> 8;
+    }
+    for (int x = 0; x < 8; x++) {                                      /* vertical 1-D IDCT (no all-zero shortcut) */
+        int32_t *s = src + x;
+        int32_t y0 = (s[8 * 0] << 8) + 8192, y1 = s[8 * 4] << 8, y2 = s[8 * 6], y3 = s[8 * 2], y4 = s[8 * 1], y5 = s[8 * 7],
+                y6 = s[8 * 5], y7 = s[8 * 3], y8;
+        y8 = JI_W7 * (y4 + y5) + 4;
+        y4 = (y8 + (JI_W1 - JI_W7) * y4) >> 3;
+        y5 = (y8 - (JI_W1 + JI_W7) * y5) >> 3;
+        y8 = JI_W3 * (y6 + y7) + 4;
+        y6 = (y8 - (JI_W3 - JI_W5) * y6) >> 3;
+        y7 = (y8 - (JI_W3 + JI_W5) * y7) >> 3;
+        y8 = y0 + y1;
+        y0 -= y1;
+        y1 = JI_W6 * (y3 + y2) + 4;
+        y2 = (y1 - (JI_W2 + JI_W6) * y2) >> 3;
+        y3 = (y1 + (JI_W2 - JI_W6) * y3) >> 3;
+        y1 = y4 + y6;
+        y4 -= y6;
+        y6 = y5 + y7;
+        y5 -= y7;
+        y7 = y8 + y3;
+        y8 -= y3;
+        y3 = y0 + y2;
+        y0 -= y2;
+        y2 = (JI_R2 * (y4 + y5) + 128) >> 8;
+        y4 = (JI_R2 * (y4 - y5) + 128) >> 8;
+        s[8 * 0] = (y7 + y1) >> 14; s[8 * 1] = (y3 + y2) >> 14; s[8 * 2] = (y0 + y4) >> 14; s[8 * 3] = (y8 + y6) >> 14;
+        s[8 * 4] = (y8 - y6) >> 14; s[8 * 5] = (y0 - y4) >> 14; s[8 * 6] = (y3 - y2) >> 14; s[8 * 7] = (y7 - y1) >> 14;
+    }
+}
+
+/* writer.go div: a / b rounded to nearest, halves away from zero */
+static int32_t jpeg_div(int32_t a, int32_t b)
+{
+    if (a >= 0) return (a + (b >> 1)) / b;
+    return -((-a + (b >> 1)) / b);
+}
+
+/* one 8x8 block of samples (0..255) through fdct -> quantise -> dequantise -> idct -> level shift + clamp
+ * (writer.go writeBlock; reader.go reconstructBlock); q in natural order */
+ORC_API void orc_jpeg_block_roundtrip(int32_t *b, const uint8_t *q)
+{
+    orc_jpeg_fdct(b);
+    for (int i = 0; i < 64; i++) b[i] = jpeg_div(b[i], 8 * (int32_t)q[i]) * (int32_t)q[i];
+    orc_jpeg_idct(b);
+    for (int i = 0; i < 64; i++) b[i] = b[i] < -128 ? 0 : (b[i] > 127 ? 255 : b[i] + 128);
+}
+
+/* The planes an *image.YCbCr holds after jpeg.Decode(jpeg.Encode(img, quality)) for an opaque NRGBA image: Y is
+ * 16*mx wide and 16*my high (mx, my = MCUs), Cb / Cr 8*mx x 8*my (4:2:0); the decoder's image is the w x h sub-image.
+ * yp: (16 mx) * (16 my) bytes, cb, cr: (8 mx) * (8 my). */
+ORC_API void orc_jpeg_roundtrip_planes(const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *yp, uint8_t *cbp,
+                                       uint8_t *crp)
+{
+    uint8_t ql[64], qc[64];
+    orc_jpeg_quant_tables(quality, ql, qc);
+    const int mx = (w + 15) / 16, my = (h + 15) / 16, ys = 16 * mx, cs = 8 * mx;
+    for (int my0 = 0; my0 < my; my0++)
+        for (int mx0 = 0; mx0 < mx; mx0++) {
+            int32_t yb[4][64], cbf[4][64], crf[4][64], cbb[64], crb[64];
+            for (int i = 0; i < 4; i++) {                              /* writer.go: xOff = (i&1)*8, yOff = (i&2)*4 */
+                const int px = 16 * mx0 + (i & 1) * 8, py = 16 * my0 + (i & 2) * 4;
+                for (int j = 0; j < 8; j++)
+                    for (int k = 0; k < 8; k++) {
+                        const int sx = px + k > w - 1 ? w - 1 : px + k, sy = py + j > h - 1 ? h - 1 : py + j;   /* toYCbCr clamps */
+                        const uint8_t *p = src + (size_t)sy * sstride + (size_t)sx * 4;
+                        uint8_t yy, cb, cr;
+                        /* io.go:157-169: an opaque image is handed over as *image.RGBA (rgbaToYCbCr reads the bytes); any
+                         * other goes through toYCbCr's m.At(x, y).RGBA(): color.NRGBA.RGBA() premultiplies in 16 bits
+                         * (r = R * 0x101 * A / 0xff) and the encoder keeps the high byte.  For A == 255 that IS R, so the
+                         * per-pixel form below covers both. */
+                        const uint32_t a8 = p[3];
+                        const uint8_t r8 = (uint8_t)(((uint32_t)p[0] * 0x101u * a8 / 0xffu) >> 8);
+                        const uint8_t g8 = (uint8_t)(((uint32_t)p[1] * 0x101u * a8 / 0xffu) >> 8);
+                        const uint8_t b8 = (uint8_t)(((uint32_t)p[2] * 0x101u * a8 / 0xffu) >> 8);
+                        orc_rgb_to_ycbcr(r8, g8, b8, &yy, &cb, &cr);
+                        yb[i][8 * j + k] = yy; cbf[i][8 * j + k] = cb; crf[i][8 * j + k] = cr;
+                    }
+            }
+            for (int i = 0; i < 4; i++) {                              /* writer.go scale(): 16x16 -> 8x8, (sum + 2) >> 2 */
+                const int dstOff = ((i & 2) << 4) | ((i & 1) << 2);
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++) {
+                        const int j = 16 * y + 2 * x;
+                        cbb[8 * y + x + dstOff] = (cbf[i][j] + cbf[i][j + 1] + cbf[i][j + 8] + cbf[i][j + 9] + 2) >> 2;
+                        crb[8 * y + x + dstOff] = (crf[i][j] + crf[i][j + 1] + crf[i][j + 8] + crf[i][j + 9] + 2) >> 2;
+                    }
+            }
+            for (int i = 0; i < 4; i++) {
+                orc_jpeg_block_roundtrip(yb[i], ql);
+                const int px = 16 * mx0 + (i & 1) * 8, py = 16 * my0 + (i & 2) * 4;
+                for (int j = 0; j < 8; j++)
+                    for (int k = 0; k < 8; k++) yp[(size_t)(py + j) * ys + px + k] = (uint8_t)yb[i][8 * j + k];
+            }
+            orc_jpeg_block_roundtrip(cbb, qc);
+            orc_jpeg_block_roundtrip(crb, qc);
+            for (int j = 0; j < 8; j++)
+                for (int k = 0; k < 8; k++) {
+                    cbp[(size_t)(8 * my0 + j) * cs + 8 * mx0 + k] = (uint8_t)cbb[8 * j + k];
+                    crp[(size_t)(8 * my0 + j) * cs + 8 * mx0 + k] = (uint8_t)crb[8 * j + k];
+                }
+        }
+}
+
+/* toNRGBARef(jpeg.Decode(jpeg.Encode(src, quality))) (compress.go:50-58): the image SSIMFast scores */
+ORC_API int orc_jpeg_roundtrip(const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *dst, int dstride)
+{
+    if (w <= 0 || h <= 0) return 0;
+    const int mx = (w + 15) / 16, my = (h + 15) / 16;
+    uint8_t *yp = (uint8_t *)malloc((size_t)256 * mx * my), *cb = (uint8_t *)malloc((size_t)64 * mx * my),
+            *cr = (uint8_t *)malloc((size_t)64 * mx * my);
+    if (!yp || !cb || !cr) { free(yp); free(cb); free(cr); return -1; }
+    orc_jpeg_roundtrip_planes(src, sstride, w, h, quality, yp, cb, cr);
+    orc_ycbcr_to_nrgba(yp, 16 * mx, cb, cr, 8 * mx, 2, w, h, dst, dstride);      /* ratio 2 = YCbCrSubsampleRatio420 */
+    free(yp); free(cb); free(cr);
+    return 1;
+}

@@ -391,3 +391,67 @@ def ycbcr_to_nrgba(y: np.ndarray, cb, cr, ratio: int) -> np.ndarray:
         lib().orc_ycbcr_to_nrgba(y.ctypes.data_as(_u8p), w, cb.ctypes.data_as(_u8p), cr.ctypes.data_as(_u8p),
                                  cb.shape[1], int(ratio), w, h, dst.ctypes.data_as(_u8p), 4 * w)
     return dst
+
+
+# ---------------------------------------------------------------- JPEG quantisation round trip (Go's image/jpeg arithmetic)
+def jpeg_quant_tables(quality: int):
+    """(luminance, chrominance) 8x8 tables in natural order as writer.go scales them for `quality`."""
+    lum = np.empty(64, dtype=np.uint8)
+    chr_ = np.empty(64, dtype=np.uint8)
+    L = lib()
+    L.orc_jpeg_quant_tables.restype = None
+    L.orc_jpeg_quant_tables.argtypes = [C.c_int, _u8p, _u8p]
+    L.orc_jpeg_quant_tables(int(quality), lum.ctypes.data_as(_u8p), chr_.ctypes.data_as(_u8p))
+    return lum.reshape(8, 8), chr_.reshape(8, 8)
+
+
+def jpeg_fdct(block: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(block, dtype=np.int32).reshape(64).copy()
+    L = lib()
+    L.orc_jpeg_fdct.restype = None
+    L.orc_jpeg_fdct.argtypes = [C.POINTER(C.c_int32)]
+    L.orc_jpeg_fdct(b.ctypes.data_as(C.POINTER(C.c_int32)))
+    return b.reshape(8, 8)
+
+
+def jpeg_idct(block: np.ndarray) -> np.ndarray:
+    b = np.ascontiguousarray(block, dtype=np.int32).reshape(64).copy()
+    L = lib()
+    L.orc_jpeg_idct.restype = None
+    L.orc_jpeg_idct.argtypes = [C.POINTER(C.c_int32)]
+    L.orc_jpeg_idct(b.ctypes.data_as(C.POINTER(C.c_int32)))
+    return b.reshape(8, 8)
+
+
+def rgb_to_ycbcr(r: int, g: int, b: int):
+    L = lib()
+    L.orc_rgb_to_ycbcr.restype = None
+    L.orc_rgb_to_ycbcr.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, _u8p, _u8p, _u8p]
+    o = np.zeros(3, dtype=np.uint8)
+    L.orc_rgb_to_ycbcr(int(r), int(g), int(b), o[0:].ctypes.data_as(_u8p), o[1:].ctypes.data_as(_u8p), o[2:].ctypes.data_as(_u8p))
+    return int(o[0]), int(o[1]), int(o[2])
+
+
+def jpeg_roundtrip_planes(img: np.ndarray, quality: int):
+    """(Y, Cb, Cr) planes of jpeg.Decode(jpeg.Encode(img, quality)): MCU-padded, 4:2:0."""
+    p, s, w, h = _img(img)
+    mx, my = (w + 15) // 16, (h + 15) // 16
+    y = np.empty((16 * my, 16 * mx), dtype=np.uint8)
+    cb = np.empty((8 * my, 8 * mx), dtype=np.uint8)
+    cr = np.empty((8 * my, 8 * mx), dtype=np.uint8)
+    L = lib()
+    L.orc_jpeg_roundtrip_planes.restype = None
+    L.orc_jpeg_roundtrip_planes.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p, _u8p]
+    L.orc_jpeg_roundtrip_planes(p, s, w, h, int(quality), y.ctypes.data_as(_u8p), cb.ctypes.data_as(_u8p), cr.ctypes.data_as(_u8p))
+    return y, cb, cr
+
+
+def jpeg_roundtrip(img: np.ndarray, quality: int) -> np.ndarray:
+    """toNRGBARef(jpeg.Decode(jpeg.Encode(img, quality))) for an opaque image (compress.go:50-58)."""
+    p, s, w, h = _img(img)
+    dst = new_image(w, h)
+    L = lib()
+    L.orc_jpeg_roundtrip.restype = C.c_int
+    L.orc_jpeg_roundtrip.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
+    L.orc_jpeg_roundtrip(p, s, w, h, int(quality), dst.ctypes.data_as(_u8p), w * 4)
+    return dst

@@ -1,0 +1,168 @@
+"""SURVEY 8(f)2, first slice: the JPEG quantisation round trip.
+
+CPU (not gpu): the oracle's restatement of Go's image/jpeg arithmetic against what CAN be checked here -- libjpeg-turbo
+through Pillow.  Quantisation tables must be identical for every quality (Go copied the IJG's scaling); the integer
+FDCT / IDCT must sit within 1 of the real DCT; a decoded round trip must be close to libjpeg's (not identical: libjpeg
+uses other chroma constants, alternates its downsampling bias and smooths chroma on the way up) and give nearly the
+same SSIMFast.  None of that pins the restatement against Go itself: unpinned twice over.
+
+GPU (-m gpu): jpeg.hip against the oracle bit for bit -- planes' worth of blocks, odd sizes, translucent pixels, every
+quality regime -- and fnx_jpeg_quality_search against the same search driven by the oracle.
+"""
+import io
+
+import numpy as np
+import pytest
+
+from fennec_amd import batch, synth
+from oracle import oracle as orc
+
+
+def _pil_tables(q):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(synth.make_test_image(32, 32)[..., :3], "RGB").save(buf, "JPEG", quality=q, subsampling=2)
+    t = Image.open(io.BytesIO(buf.getvalue())).quantization
+    return np.array(t[0]).reshape(8, 8), np.array(t[1]).reshape(8, 8)
+
+
+def test_quant_tables_equal_libjpeg_for_every_quality():
+    zig = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+    for q in list(range(1, 101, 7)) + [49, 50, 51, 92, 99, 100]:
+        lum, chr_ = orc.jpeg_quant_tables(q)
+        pl, pc = _pil_tables(q)
+        # Pillow >= 8.3 reports tables in natural order; older ones in zig-zag order: accept either, identically for both
+        nat = np.array_equal(lum, pl) and np.array_equal(chr_, pc)
+        zz = np.array_equal(lum.reshape(64)[zig].reshape(8, 8), pl) and np.array_equal(chr_.reshape(64)[zig].reshape(8, 8), pc)
+        assert nat or zz, q
+    assert orc.jpeg_quant_tables(0)[0].tolist() == orc.jpeg_quant_tables(1)[0].tolist()        # clipped to [1, 100]
+    assert orc.jpeg_quant_tables(1000)[0].tolist() == orc.jpeg_quant_tables(100)[0].tolist()
+    assert (orc.jpeg_quant_tables(100)[0] == 1).all()
+
+
+def test_integer_dct_against_the_real_one():
+    from scipy.fft import dctn, idctn
+    rng = np.random.default_rng(2)
+    for k in range(200):
+        x = rng.integers(0, 256, (8, 8)) if k % 3 else np.full((8, 8), rng.integers(0, 256))
+        f = orc.jpeg_fdct(x)
+        assert np.abs(f - 8 * dctn((x - 128).astype(float), norm="ortho")).max() <= 1.5     # jfdctint: scaled by 8; two fixed-point passes
+        # coefficients a decoder meets: a pixel block's DCT quantised and dequantised with some step (far larger ones wrap
+        # the 32-bit intermediates -- in Go as here -- and no JPEG of 8-bit samples holds them)
+        step = int(rng.integers(1, 64))
+        c = (np.rint(dctn((x - 128).astype(float), norm="ortho") / step) * step).astype(np.int64)
+        assert np.abs(orc.jpeg_idct(c) - idctn(c.astype(float), norm="ortho")).max() <= 1.0 + 1e-9
+    assert orc.rgb_to_ycbcr(0, 0, 0) == (0, 128, 128) and orc.rgb_to_ycbcr(255, 255, 255) == (255, 128, 128)
+    assert orc.rgb_to_ycbcr(255, 0, 0) == (76, 85, 255) and orc.rgb_to_ycbcr(0, 0, 255) == (29, 255, 107)
+
+
+@pytest.mark.parametrize("q", [30, 60, 92])
+def test_roundtrip_close_to_libjpeg(q):
+    smooth = orc.gaussian_blur(synth.noise_image(320, 240, 3), 3.0)
+    grad = synth.make_test_image(333, 217)
+    for img in (smooth, grad):
+        rt = orc.jpeg_roundtrip(img, q)
+        pil = batch.pillow_decode(batch.pillow_encode(img, q))
+        assert rt.shape == img.shape and (rt[..., 3] == 255).all()
+        d = np.abs(rt[..., :3].astype(int) - pil[..., :3].astype(int))
+        assert d.mean() < 1.6, d.mean()                                      # about one grey level on average
+        assert abs(orc.ssim_fast(img, rt) - orc.ssim_fast(img, pil)) < 2e-3
+    assert np.array_equal(orc.jpeg_roundtrip(smooth, 92), orc.jpeg_roundtrip(smooth, 92))
+
+
+def test_roundtrip_edge_replication_and_premultiplied_alpha():
+    # 17 x 9: one full MCU column + 1 px, rows short of one MCU -- the padded planes replicate the last row / column
+    img = synth.noise_image(17, 9, 5)
+    y, cb, cr = orc.jpeg_roundtrip_planes(img, 100)
+    assert y.shape == (16, 32) and cb.shape == (8, 16)
+    # at quality 100 (all steps 1) the round trip is the DCT pair alone: luma within 2 of the source's
+    yy = np.array([[orc.rgb_to_ycbcr(*img[j, i, :3])[0] for i in range(17)] for j in range(9)])
+    assert np.abs(y[:9, :17].astype(int) - yy).max() <= 2
+    # a translucent pixel is premultiplied before the colour conversion (color.NRGBA.RGBA())
+    a = np.zeros((16, 16, 4), np.uint8); a[...] = (200, 100, 50, 255)
+    b = a.copy(); b[..., 3] = 128
+    ya = orc.jpeg_roundtrip_planes(a, 100)[0]; yb = orc.jpeg_roundtrip_planes(b, 100)[0]
+    want = orc.rgb_to_ycbcr(*(((np.array([200, 100, 50]) * 0x101 * 128 // 0xff) >> 8).tolist()))[0]
+    assert abs(int(yb[4, 4]) - want) <= 1 and int(ya[4, 4]) > int(yb[4, 4])
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ctx():
+    import fennec_amd
+    return fennec_amd.Context(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(16, 16), (17, 9), (1, 1), (640, 480), (333, 217), (1000, 37), (8, 300), (1920, 1080)])
+def test_gpu_roundtrip_bit_exact(ctx, w, h):
+    import torch
+    imgs = [synth.large_photo(w, h, 2), synth.noise_image(w, h, w + h, alpha=True)]
+    if w * h >= 64:
+        imgs.append(orc.gaussian_blur(synth.noise_image(w, h, 4), 2.5))
+    for img in imgs:
+        for q in (1, 17, 30, 50, 75, 92, 100):
+            want = orc.jpeg_roundtrip(img, q)
+            assert np.array_equal(ctx.jpeg_roundtrip(img, q), want), (w, h, q)
+        d = torch.from_numpy(img).cuda()
+        assert np.array_equal(ctx.jpeg_roundtrip(d, 60).cpu().numpy(), orc.jpeg_roundtrip(img, 60))
+
+
+@pytest.mark.gpu
+def test_gpu_roundtrip_4k_and_strided_view(ctx):
+    import torch
+    img = synth.large_photo(3840, 2160, 1)
+    for q in (30, 85):
+        assert np.array_equal(ctx.jpeg_roundtrip(img, q), orc.jpeg_roundtrip(img, q)), q
+    small = synth.noise_image(150, 70, 1)
+    big = torch.from_numpy(np.ascontiguousarray(np.pad(small, ((0, 0), (2, 3), (0, 0))))).cuda()
+    assert np.array_equal(ctx.jpeg_roundtrip(big[:, 2:-3], 55).cpu().numpy(), orc.jpeg_roundtrip(small, 55))
+
+
+def _oracle_search(img, target):
+    """compress.go:21-74 with the oracle's round trip and SSIMFast."""
+    if target >= 1.0:
+        target = 0.999
+    lo, hi, best_q, best_s, found, n = batch.search_lower_bound(target), 100, 100, 1.0, False, 0
+    while lo <= hi:
+        mid = (lo + hi) // 2
+        s = orc.ssim_fast(img, orc.jpeg_roundtrip(img, mid), procs=8)
+        n += 1
+        if s >= target:
+            best_q, best_s, found, hi = mid, s, True, mid - 1
+        else:
+            lo = mid + 1
+    return best_q, best_s, n, found
+
+
+@pytest.mark.gpu
+def test_gpu_quality_search_matches_oracle_search(ctx):
+    import torch
+    cases = [(synth.large_photo(1920, 1080, 3), 0.94), (orc.gaussian_blur(synth.noise_image(800, 600, 2), 2.0), 0.97),
+             (synth.make_test_image(640, 480), 0.90), (synth.noise_image(300, 200, 9), 0.999), (synth.make_test_image(400, 300), 1.0),
+             (synth.large_photo(700, 500, 1), 0.5)]
+    for img, target in cases:
+        q, s, n, found = ctx.jpeg_quality_search(img, target)
+        wq, ws, wn, wfound = _oracle_search(img, target)
+        assert (q, n, found) == (wq, wn, wfound), (target, q, wq)
+        assert abs(s - ws) <= 1e-9
+        dq, ds, dn, dfound = ctx.jpeg_quality_search(torch.from_numpy(img).cuda(), target)
+        assert (dq, dn, dfound) == (q, n, found) and ds == s
+
+
+@pytest.mark.gpu
+def test_gpu_compress_batch_with_device_search(ctx):
+    """CompressBatch with the search on the device: every item's (quality, steps, SSIM) equals the oracle-driven search over
+    the oracle's round trip, the output is the host codec's encode at that quality."""
+    import fennec_amd
+    jpegs = [batch.pillow_encode(synth.large_photo(1920, 1080, k), 92) for k in range(4)]
+    states = {}
+    res = batch.compress_batch(len(jpegs), batch.jpeg_item_work_device_search(jpegs), lambda wid: states.setdefault(wid, fennec_amd.Context(0)),
+                               workers=2)
+    for r in res:
+        assert r.Err is None
+        src = batch.pillow_decode(jpegs[r.Index])
+        wq, ws, wn, _ = _oracle_search(src, batch.TARGET_SSIM["Balanced"])
+        assert (r.Quality, r.steps) == (wq, wn) and abs(r.SSIM - ws) <= 1e-9
+        assert r.CompressedSize == len(batch.pillow_encode(src, wq))
