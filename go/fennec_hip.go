@@ -567,3 +567,57 @@ func applyPalette(src *image.NRGBA, palette color.Palette) *image.Paletted {
 	}
 	return applyPaletteGo(src, palette)
 }
+
+// ---- compress.go: the whole quality search on the device (opt-in; DESIGN.md 3.11) -----------
+
+// jpegQualitySearchHIP runs compressJPEGOptimal's binary search (compress.go:24-74) with every candidate quality
+// round-tripped through image/jpeg's LOSSY arithmetic on the device (colour conversion, 4:2:0, FDCT, quantise,
+// dequantise, IDCT -- no entropy coding) and scored with SSIMFast there.  ok == false means the device was not
+// used and the caller runs the loop as before; found == false is the reference's "no quality reached the target"
+// (compress.go:82-86: encode at 100).  The caller encodes ONCE, at the returned quality:
+//
+//	if q, ssim, found, ok := jpegQualitySearchHIP(src, targetSSIM); ok { bestQuality, bestSSIM = q, ssim; ... }
+//
+// Off by default (useDeviceSearch): the arithmetic is restated from the algorithms image/jpeg implements and must be
+// pinned against the standard library first -- TestHIPRoundTripMatchesStdlib in INTEGRATION.md 4.2.
+var useDeviceSearch = false
+
+func jpegQualitySearchHIP(src *image.NRGBA, targetSSIM float64) (quality int, ssim float64, found, ok bool) {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	if !useDeviceSearch || w <= 0 || h <= 0 {
+		return 0, 0, false, false
+	}
+	c := pool.get()
+	if c == nil {
+		return 0, 0, false, false
+	}
+	defer pool.put(c)
+	var q, steps C.int
+	var s C.double
+	st := C.fnx_jpeg_quality_search(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), C.double(targetSSIM),
+		(*C.double)(unsafe.Pointer(&ssimWindow[0])), &q, &s, &steps)
+	runtime.KeepAlive(src)
+	if st != C.FNX_OK && st != C.FNX_NOOP {
+		return 0, 0, false, false
+	}
+	return int(q), float64(s), st == C.FNX_OK, true
+}
+
+// jpegRoundTripHIP is toNRGBARef(jpeg.Decode(jpeg.Encode(src, quality))) as far as the pixels go; nil when the device
+// was not used.  It exists for the pinning test.
+func jpegRoundTripHIP(src *image.NRGBA, quality int) *image.NRGBA {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	c := poolGetIf(w > 0 && h > 0)
+	if c == nil {
+		return nil
+	}
+	defer pool.put(c)
+	dst := image.NewNRGBA(image.Rect(0, 0, w, h))
+	st := C.fnx_jpeg_roundtrip(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), C.int(quality),
+		pix(dst), C.int(dst.Stride))
+	runtime.KeepAlive(src)
+	if st != C.FNX_OK {
+		return nil
+	}
+	return dst
+}
