@@ -137,6 +137,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ssim_fast_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
         _sig(L, "fnx_results_fetch", i, [ctx, i, _f64p])
         _sig(L, "fnx_ssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
+        _sig(L, "fnx_msssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
+        _sig(L, "fennec_MSSSIM_enqueue", i, [ctx] + img + [i, i] + img + [i, i])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
@@ -381,6 +383,16 @@ class Context:
         k, pk = _f64(self.gaussianKernel() if window is None else window)
         with self._ordered(img1, img2):
             self._chk(self._lib.fnx_ssim_enqueue(self._h, a.ptr, a.stride, b.ptr, b.stride, a.w, a.h, pk), "fnx_ssim_enqueue")
+
+    def msssim_enqueue(self, img1, img2):
+        """fennec_MSSSIM_enqueue: MSSSIM of a device pair (img2 resized to img1's dims first when they differ,
+        ssim.go:320-322) through the result FIFO; fetch_result() returns the value.  The caller keeps both alive."""
+        a, b = self._pair(img1, img2)
+        if a.space != FNX_DEVICE:
+            raise FennecError("msssim_enqueue takes two device tensors")
+        with self._ordered(img1, img2):
+            self._chk(self._lib.fennec_MSSSIM_enqueue(self._h, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride, b.w, b.h),
+                      "fennec_MSSSIM_enqueue")
 
     def fetch_result(self) -> float:
         """The oldest enqueued scalar result (fnx_results_fetch)."""

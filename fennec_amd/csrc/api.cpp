@@ -164,6 +164,14 @@ int result_wait(fnx_ctx *ctx, const double *pinned, double *out, int n)
     return FNX_OK;
 }
 
+// ssim.go:344-352: exp(sum_i weights[i] * log(max(level_i, 1e-10)))
+double msssim_combine(const double *lv, const double *weights, int nlev)
+{
+    double result = 0;
+    for (int i = 0; i < nlev; i++) result += weights[i] * std::log(std::fmax(lv[i], 1e-10));   // ssim.go:351
+    return std::exp(result);
+}
+
 // An event right behind the result kernels, and the batch joins the ctx's FIFO of unfetched results:
 // fnx_results_fetch then never waits for work that was queued on this stream after the batch.
 int publish_results(fnx_ctx *ctx, const double *pinned, int n)
@@ -177,6 +185,7 @@ int publish_results(fnx_ctx *ctx, const double *pinned, int n)
     FNX_HIP(hipEventRecord(q.ev, ctx->stream));
     q.pinned = pinned;
     q.n = n;
+    q.nraw = 0;
     ctx->res_count++;
     return FNX_OK;
 }
@@ -422,8 +431,13 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(ctx->res_count > 0 && n <= ctx->res_q[ctx->res_head].n, "no enqueued results of that size on this ctx");
     fnx_ctx::Pending &q = ctx->res_q[ctx->res_head];            // oldest unfetched batch
-    FNX_TRY(poll_results(q.pinned, n, [&] { return hipEventQuery(q.ev); }));
-    std::memcpy(out, q.pinned, sizeof(double) * size_t(n));
+    if (q.nraw > 0) {                                            // an enqueued MSSSIM: levels -> the weighted product
+        FNX_TRY(poll_results(q.pinned, q.nraw, [&] { return hipEventQuery(q.ev); }));
+        out[0] = msssim_combine(q.pinned, q.weights, q.nraw);
+    } else {
+        FNX_TRY(poll_results(q.pinned, n, [&] { return hipEventQuery(q.ev); }));
+        std::memcpy(out, q.pinned, sizeof(double) * size_t(n));
+    }
     ctx->res_head = (ctx->res_head + 1) % fnx_ctx::RES_DEPTH;
     ctx->res_count--;
     return FNX_OK;
@@ -590,55 +604,41 @@ int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t 
     return publish_results(ctx, dres, 1);
 }
 
-int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
-               int bstride, int w, int h, const double *window, double *out, double *per_level)
+// MSSSIM's weights, trimmed while a level's min dim < 8 (ssim.go:324-342)
+static int msssim_weights(int w, int h, double (&weights)[5])
 {
-    FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
-    FNX_REQUIRE(window && out, "window/out is null");
-    FNX_TRY(check_img(a, astride, w, h, "a"));
-    FNX_TRY(check_img(b, bstride, w, h, "b"));
-    // weights, trimmed while a level's min dim < 8 (ssim.go:324-342)
-    double weights[5] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    const double full[5] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+    for (int i = 0; i < 5; i++) weights[i] = full[i];
     int nweights = 5;
-    {
-        int tw = w, th = h;
-        for (int i = 0; i < 4; i++) {
-            int minDim = int(std::fmin(double(tw), double(th)));
-            if (minDim < 8) {
-                nweights = i + 1;
-                double sum = 0;
-                for (int j = 0; j < nweights; j++) sum += weights[j];
-                for (int j = 0; j < nweights; j++) weights[j] /= sum;
-                break;
-            }
-            tw /= 2;
-            th /= 2;
+    int tw = w, th = h;
+    for (int i = 0; i < 4; i++) {
+        int minDim = int(std::fmin(double(tw), double(th)));
+        if (minDim < 8) {
+            nweights = i + 1;
+            double sum = 0;
+            for (int j = 0; j < nweights; j++) sum += weights[j];
+            for (int j = 0; j < nweights; j++) weights[j] /= sum;
+            break;
         }
+        tw /= 2;
+        th /= 2;
     }
-    double lv[5];
-    for (double &v : lv) v = NAN;
+    return nweights;
+}
+
+// Every level's SSIMFast of a device-resident pair into dres[0 .. *nlev) (ssim.go:344-362); nothing waits.
+static int msssim_levels_device(fnx_ctx *ctx, const uint8_t *ap, int astride, const uint8_t *bp, int bstride, int w, int h,
+                                int nweights, const double *window, double *dres, int *nlev_out)
+{
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     int nlev = 0;
-    if (w <= 0 || h <= 0) {
-        // SSIMFast of empty images: pixelSSIM n==0 -> 1.0; the halving loop then breaks (nw < 8)
-        lv[0] = 1.0;
-        nlev = 1;
-    } else {
-        void *dwin = nullptr;
-        FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
-        DevImg da, db;
-        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
-        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
-        double *dres;
-        FNX_TRY(result_slot(ctx, 5, &dres));
-        const int fused = launch_msssim_fused(ctx, da.p, da.stride, db.p, db.stride, w, h, nweights, window, dres, &nlev);
-        if (fused < 0) return fused;
-        if (fused == FNX_OK) {
-            FNX_TRY(result_wait(ctx, dres, lv, nlev));
-        } else {
+    const int fused = launch_msssim_fused(ctx, ap, astride, bp, bstride, w, h, nweights, window, dres, &nlev);
+    if (fused < 0) return fused;
+    if (fused != FNX_OK) {
         // pyramid storage: levels 1.. of both images, ping-ponged in two slots per side
-        const uint8_t *ca = da.p, *cb = db.p;
-        int cas = da.stride, cbs = db.stride, cw = w, ch = h;
+        const uint8_t *ca = ap, *cb = bp;
+        int cas = astride, cbs = bstride, cw = w, ch = h;
         size_t lvl_bytes = static_cast<size_t>(w / 2) * (h / 2) * 4 + 16;
         void *pyr = nullptr;   // level k lives at (k&1)*2*lvl_bytes: [a][b]
         FNX_TRY(scratch(ctx, SLOT_TMP0, lvl_bytes * 4, &pyr));
@@ -661,14 +661,61 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
             }
         }
         FNX_TRY(launch_ssim_finish_deferred(ctx, defer, dres));
-        FNX_TRY(result_wait(ctx, dres, lv, nlev));
-        }
     }
-    double result = 0;
-    for (int i = 0; i < nlev; i++) result += weights[i] * std::log(std::fmax(lv[i], 1e-10));   // ssim.go:351
-    *out = std::exp(result);
+    *nlev_out = nlev;
+    return FNX_OK;
+}
+
+int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
+               int bstride, int w, int h, const double *window, double *out, double *per_level)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && out, "window/out is null");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    double weights[5];
+    const int nweights = msssim_weights(w, h, weights);
+    double lv[5];
+    for (double &v : lv) v = NAN;
+    int nlev = 0;
+    if (w <= 0 || h <= 0) {
+        // SSIMFast of empty images: pixelSSIM n==0 -> 1.0; the halving loop then breaks (nw < 8)
+        lv[0] = 1.0;
+        nlev = 1;
+    } else {
+        DevImg da, db;
+        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+        double *dres;
+        FNX_TRY(result_slot(ctx, 5, &dres));
+        FNX_TRY(msssim_levels_device(ctx, da.p, da.stride, db.p, db.stride, w, h, nweights, window, dres, &nlev));
+        FNX_TRY(result_wait(ctx, dres, lv, nlev));
+    }
+    *out = msssim_combine(lv, weights, nlev);
     if (per_level)
         for (int i = 0; i < 5; i++) per_level[i] = i < nlev ? lv[i] : NAN;
+    return FNX_OK;
+}
+
+int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                       const double *window)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(window != nullptr && w > 0 && h > 0, "enqueue arguments");
+    FNX_TRY(check_img(a, astride, w, h, "a"));
+    FNX_TRY(check_img(b, bstride, w, h, "b"));
+    FNX_TRY(can_enqueue(ctx));
+    double weights[5];
+    const int nweights = msssim_weights(w, h, weights);
+    double *dres;
+    FNX_TRY(result_slot_queued(ctx, 5, &dres));
+    int nlev = 0;
+    FNX_TRY(msssim_levels_device(ctx, a, astride, b, bstride, w, h, nweights, window, dres, &nlev));
+    fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
+    FNX_TRY(publish_results(ctx, dres, 1));
+    q.nraw = nlev;
+    for (int i = 0; i < 5; i++) q.weights[i] = weights[i];
     return FNX_OK;
 }
 

@@ -130,6 +130,10 @@ struct fnx_ctx {
         const double *pinned = nullptr;
         int n = 0;
         hipEvent_t ev = nullptr;
+        // fnx_msssim_enqueue: the slots hold `nraw` per-level SSIMFast values and the fetch returns ONE number,
+        // exp(sum weights[i] log(max(level i, 1e-10))) (ssim.go:344-352); nraw == 0: the values as they are
+        int nraw = 0;
+        double weights[5] = {0, 0, 0, 0, 0};
     } res_q[RES_DEPTH];
     int res_head = 0, res_count = 0;
     struct ResBuf {            // pinned home of FIFO position i's results (api.cpp: result_slot_queued)
@@ -139,7 +143,7 @@ struct fnx_ctx {
     fnx::ScoreGeom score_geom;
     std::vector<fnx_resize_plan *> rplans;   // at most 8, least recently used evicted (resize.hip)
     // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
-    static constexpr int PROF_DEPTH = 4;
+    static constexpr int PROF_DEPTH = 32;
     int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)
     hipEvent_t prof_ev[PROF_DEPTH][2] = {};
     int prof_head = 0, prof_count = 0, prof_open = -1;

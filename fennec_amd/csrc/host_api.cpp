@@ -252,6 +252,21 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
     return fnx_msssim(ctx, FNX_DEVICE, da.p, da.stride, rb, rbs, aw, ah, ssim_window(), out, nullptr);
 }
 
+int fennec_MSSSIM_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, int aw, int ah, const uint8_t *b, int bstride,
+                          int bw, int bh)
+{
+    FNX_TRY(bind(ctx));
+    if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
+        set_error("invalid argument: MSSSIM_enqueue takes non-empty device images");
+        return FNX_ERR_INVALID;
+    }
+    if (aw == bw && ah == bh) return fnx_msssim_enqueue(ctx, a, astride, b, bstride, aw, ah, ssim_window());
+    const uint8_t *rb;
+    int rbs;
+    FNX_TRY(resize_b_to(ctx, FNX_DEVICE, b, bstride, bw, bh, aw, ah, &rb, &rbs));   // ssim.go:320-322
+    return fnx_msssim_enqueue(ctx, a, astride, rb, rbs, aw, ah, ssim_window());
+}
+
 int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                         double sigma, uint8_t *dst, int dstride)
 {

@@ -233,6 +233,10 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
  * crosses to the host instead of draining the stream at every call. */
 int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                      const double *window /* 64 */);
+/* MSSSIM (ssim.go:313-365, equal dims) of ONE device-resident pair, enqueued the same way: the per-level values wait in
+ * the FIFO and fnx_results_fetch(ctx, 1, &v) combines them (exp of the weighted log sum, on the host as in fnx_msssim). */
+int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
+                       const double *window /* 64 */);
 
 /* dsts[i] = GaussianBlur(srcs[i]) AND out[i] = SSIMFast(srcs[i], dsts[i]) -- the pair of calls
  * the reference makes whenever it scores a processed image against its source (effects.go:146
@@ -354,6 +358,10 @@ int fennec_SSIMFast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, cons
                     int bstride, int w, int h, double *out);                      /* ssim.go:48 */
 int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,
                   const uint8_t *b, int bstride, int bw, int bh, double *out);   /* ssim.go:313 */
+/* MSSSIM of a device-resident pair through the ctx's result FIFO (fnx_msssim_enqueue), img2 resized to img1's
+ * dims first when they differ (ssim.go:320-322); fnx_results_fetch(ctx, 1, &v) returns the value. */
+int fennec_MSSSIM_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, int aw, int ah, const uint8_t *b, int bstride,
+                          int bw, int bh);
 int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                         double sigma, uint8_t *dst, int dstride);                 /* effects.go:146;
                         FNX_HOST: FNX_BLUR_EXACT (bit-exact; the call is PCIe-bound anyway),

@@ -1111,3 +1111,30 @@ def test_argument_errors_and_context_lifecycle(orc):
         cc.close()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20            # nothing accumulates across contexts
+
+
+@pytest.mark.gpu
+def test_msssim_enqueue_fifo(ctx, orc):
+    """fennec_MSSSIM_enqueue / fnx_msssim_enqueue: the same values as the blocking MSSSIM, through the result FIFO,
+    several images ahead, img2 resized to img1's dims when they differ (ssim.go:320-322)."""
+    import torch
+    pairs = []
+    for k, (w, h) in enumerate([(640, 480), (333, 217), (1024, 512), (40, 24), (640, 480)]):
+        a = synth.large_photo(w, h, k)
+        b = orc.gaussian_blur(a, 1.0 + 0.3 * k) if k != 4 else orc.lanczos_resize(a, w // 2, h // 2)
+        pairs.append((torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()))
+    want = [ctx.MSSSIM(a, b) for a, b in pairs]
+    got = []
+    for i, (a, b) in enumerate(pairs):
+        ctx.msssim_enqueue(a, b)
+        if i >= 3:
+            got.append(ctx.fetch_result())
+    while len(got) < len(pairs):
+        got.append(ctx.fetch_result())
+    assert got == want
+    assert abs(want[0] - orc.msssim(pairs[0][0].cpu().numpy(), pairs[0][1].cpu().numpy())) <= 1e-12
+    s0 = ctx.SSIM(*pairs[0])
+    ctx.ssim_enqueue(*pairs[0])                      # mixed kinds keep their order
+    ctx.msssim_enqueue(*pairs[1])
+    assert ctx.fetch_result() == s0
+    assert ctx.fetch_result() == want[1]
