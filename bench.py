@@ -99,6 +99,9 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements made after the timed region (pipelined, exact_mode, pcie_inclusive): "
                          "profiler runs use it so that kernel statistics cover the timed configuration only")
+    ap.add_argument("--queue", default="static", choices=["static", "dynamic"],
+                    help="config5 at N > 1: 'static' gives rank r the items i = r mod N; 'dynamic' is ONE queue for the job "
+                         "(a counter in torch.distributed's store, batch.go:72-126 across ranks)")
     ap.add_argument("--device-search", action="store_true",
                     help="config5: the quality search round-trips every candidate on the device (fnx_jpeg_quality_search); the host "
                          "codec decodes the source and encodes the winner only")
@@ -729,17 +732,19 @@ def other_workloads(args) -> int:
                 "copied to host memory (FNX_DEVICE_SRC)")
     else:   # config5: CompressBatch semantics, host JPEG codec (Pillow) + GPU SSIMFast
         W, H, B = 3840, 2160, min(args.batch, 16)
-        srcs = synth.large_photo_batch(W, H, range(rank * B, rank * B + B))
+        dyn = args.queue == "dynamic" and world > 1
+        # static: this rank's B items; dynamic: every rank can serve any of the job's world * B items
+        ks = range(world * B) if dyn else range(rank * B, rank * B + B)
+        srcs = synth.large_photo_batch(W, H, ks)
         jpegs = [fbatch.pillow_encode(s, 92) for s in srcs]          # "4096 synthetic 4K JPEGs", q=92 up front
+        NI = len(jpegs)
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
         if args.device_search:
-            work = fbatch.jpeg_item_work_device_search([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
-                                                       on_gpu_seconds=gpu_stage.append)
+            work = fbatch.jpeg_item_work_device_search(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
         else:
-            work = fbatch.jpeg_item_work([jpegs[i % B] for i in range(B)], fbatch.TARGET_SSIM["Balanced"],
-                                         on_gpu_seconds=gpu_stage.append)
+            work = fbatch.jpeg_item_work(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
 
         states = {}
 
@@ -749,10 +754,15 @@ def other_workloads(args) -> int:
             return states[wid]
 
         def step():
-            res = fbatch.compress_batch(B, work, make_state, workers=workers)
-            return [r.SSIM for r in res]
+            if dyn:
+                res = fbatch.compress_batch(NI, work, make_state, workers=workers, rank=rank, world=world, queue_mode="dynamic")
+            else:
+                res = fbatch.compress_batch(NI, work, make_state, workers=workers)
+            return [r.SSIM for r in res] or [float("nan")]
         metric, unit, units_per_step = "images/sec: CompressBatch 4K JPEG, SSIM-guided quality search", "images/s", B
         name = f"config5: {B} 4K JPEGs per step per GPU, Balanced (SSIM>=0.94) binary search, Pillow codec on {workers} host threads"
+        if dyn:
+            name += "; one dynamic queue over all ranks"
         if args.device_search:
             name += ("; search on the device (Go image/jpeg arithmetic without entropy coding, fnx_jpeg_quality_search), host "
                      "codec: 1 decode + 1 encode per image")

@@ -104,28 +104,77 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+class _RankQueue:
+    """The closed channel of batch.go:72-81 stretched over the ranks of one job: a counter in torch.distributed's
+    store hands out the next `chunk` indices to whichever worker of whichever rank asks first, so a rank with slower
+    items (or a slower GPU) simply takes fewer -- no data-path collective, one small TCP round trip per chunk."""
+    _seq = 0
+
+    def __init__(self, n_items: int, chunk: int = 1, group=None):
+        import torch.distributed as dist
+        from torch.distributed import distributed_c10d as c10d
+
+        self.n, self.chunk = n_items, max(1, int(chunk))
+        # every rank calls compress_batch the same number of times, so the sequence number names the same batch everywhere
+        _RankQueue._seq += 1
+        self.key = f"next_{_RankQueue._seq}"
+        self.store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())
+        self.lock = threading.Lock()
+
+    def take(self) -> List[int]:
+        with self.lock:
+            end = int(self.store.add(self.key, self.chunk))
+        return list(range(end - self.chunk, min(end, self.n)))
+
+
 def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], make_worker_state: Callable[[int], object],
                    workers: int = 1, rank: int = 0, world: int = 1,
-                   on_item: Optional[Callable[[int, int], None]] = None) -> List[BatchResult]:
-    """CompressBatch (batch.go:58-128) for this rank's shard: a closed queue of indices drained
-    by `workers` threads, results stored by index, `on_item(completed, total)` under a lock."""
-    mine = shard_indices(n_items, rank, world)
+                   on_item: Optional[Callable[[int, int], None]] = None, queue_mode: str = "static",
+                   chunk: int = 1) -> List[BatchResult]:
+    """CompressBatch (batch.go:58-128) for this rank: a closed queue of indices drained by `workers` threads, results
+    stored by index, `on_item(completed, total)` under a lock.
+
+    queue_mode "static": the rank owns items i = rank (mod world) (shard_indices) -- no communication at all.
+    queue_mode "dynamic" (world > 1, torch.distributed initialised): ONE queue for the whole job (_RankQueue), which
+    is what batch.go's channel is to its goroutines; ranks return the items they happened to take, by index."""
+    if n_items <= 0:
+        return []
+    dynamic = queue_mode == "dynamic" and world > 1
+    if queue_mode not in ("static", "dynamic"):
+        raise ValueError("queue_mode must be 'static' or 'dynamic'")
+    mine = list(range(n_items)) if dynamic else shard_indices(n_items, rank, world)
     if not mine:
         return []
     workers = max(1, min(workers, len(mine)))       # batch.go:63-69
     q: "queue.Queue[int]" = queue.Queue()
-    for i in mine:
-        q.put(i)
+    rq = _RankQueue(n_items, chunk) if dynamic else None
+    if not dynamic:
+        for i in mine:
+            q.put(i)
     results: dict = {}
     lock = threading.Lock()
     done = [0]
+    total = n_items if dynamic else len(mine)
+
+    def next_index():
+        while True:
+            try:
+                return q.get_nowait()
+            except queue.Empty:
+                if rq is None:
+                    return None
+                got = rq.take()
+                if not got:
+                    return None
+                for i in got[1:]:
+                    q.put(i)
+                return got[0]
 
     def run(wid: int):
         state = make_worker_state(wid)
         while True:
-            try:
-                idx = q.get_nowait()
-            except queue.Empty:
+            idx = next_index()
+            if idx is None:
                 return
             try:
                 r = work(idx, state)
@@ -136,14 +185,14 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
                 with lock:
                     done[0] += 1
                     c = done[0]
-                on_item(c, len(mine))
+                on_item(c, total)
 
     threads = [threading.Thread(target=run, args=(w,)) for w in range(workers)]
     for t in threads:
         t.start()
     for t in threads:
         t.join()
-    return [results[i] for i in mine]
+    return [results[i] for i in sorted(results)]
 
 
 def jpeg_item_work_device_search(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],

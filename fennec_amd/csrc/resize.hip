@@ -523,10 +523,19 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
                 for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
             };
             const double inv0 = a.inv[d0], inv1 = a.inv[min(d0 + 1, a.nout - 1)];
-            for (int y = yw; y < y1; y++) {
-                if (!((exact_rows >> (y - yw)) & 1u)) continue;     // wave-uniform
+            // the marked rows one after the other (exact_rows is wave-uniform), the next one's window in flight while
+            // this one is computed: without that every row would wait out a memory latency on its own
+            uint32_t todo = __builtin_amdgcn_readfirstlane(exact_rows);
+            u32x4 vnx[NV];
+            load_row(yw + __builtin_ctz(todo), vnx);
+            while (todo) {
+                const int y = yw + __builtin_ctz(todo);
+                todo &= todo - 1;
                 u32x4 v[NV];
-                load_row(y, v);
+#pragma unroll
+                for (int q = 0; q < NV; q++) v[q] = vnx[q];
+                load_row(todo ? yw + __builtin_ctz(todo) : y, vnx);  // (the last row loads itself again: no branch around a load)
+                (void)y1;
                 uint32_t andp = 0xffffffffu;
 #pragma unroll
                 for (int q = 0; q < NV; q++) andp &= (v[q][0] & v[q][1]) & (v[q][2] & v[q][3]);
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
     // row loops read them as LDS broadcasts -- a scalar global load per row would put its miss latency (~1 us,
     // nothing to overlap it with) into every iteration.  The host keeps the union at <= 64 rows.
     __shared__ __attribute__((aligned(16))) float s_wv[64 * VG];
-    __shared__ __attribute__((aligned(16))) double s_awv[64 * VG];
+    __shared__ __attribute__((aligned(16))) double s_awv[(64 + 4) * VG];   // + one zero trip of the exact sweep
     const int tid = threadIdx.x;
     const int grp = blockIdx.y;
     if (tid == 0) s_nfix = 0;
@@ -611,7 +620,10 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
         if (tid < nw) {
             s_wv[tid] = a.dense[static_cast<size_t>(grp) * a.npx * VG + tid];
             s_awv[tid] = a.aw[static_cast<size_t>(grp) * a.npx * VG + tid];
+        } else {
+            s_awv[tid] = 0.0;                                       // the exact sweep walks the union in fours: r + f * 0.0 == r
         }
+        if (tid < 4 * VG) s_awv[64 * VG + tid] = 0.0;
     }
     __syncthreads();
     const int xw = (blockIdx.x * 256 + (tid & ~63)) * PX;           // first column of this wave
@@ -723,17 +735,35 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
 #pragma unroll
                     for (int q = 0; q < 6; q++) r[j][q] = 0.0;
                 const int c0 = min(c, max(ncol - 1, 0)), c1 = min(c + 1, max(ncol - 1, 0));
-#pragma unroll 1
-                for (int i = 0; i < nr; i++) {
-                    const uint8_t *pp = col + static_cast<size_t>(s0 + i) * a.sstride;
-                    const uint32_t q0 = *(g_u32 *)(pp + 4 * c0), q1 = *(g_u32 *)(pp + 4 * c1);
-                    const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
-                    const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+                // four union rows per trip, the next four in flight meanwhile (rows past the union are the last one
+                // again with zero weights: no branch around a load, and r + f * 0.0 == r)
+                uint32_t n0[4], n1[4];
+                auto load4 = [&](int i0, uint32_t (&u0)[4], uint32_t (&u1)[4]) {
 #pragma unroll
-                    for (int j = 0; j < VG; j++) {
-                        const double aw = s_awv[i * VG + j];        // 255 w, or 0.0 outside row j's taps
-                        r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
-                        r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                    for (int k = 0; k < 4; k++) {
+                        const uint8_t *pp = col + static_cast<size_t>(s0 + min(i0 + k, nr - 1)) * a.sstride;
+                        u0[k] = *(g_u32 *)(pp + 4 * c0);
+                        u1[k] = *(g_u32 *)(pp + 4 * c1);
+                    }
+                };
+                load4(0, n0, n1);
+#pragma unroll 1
+                for (int i = 0; i < nr; i += 4) {
+                    uint32_t u0[4], u1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { u0[k] = n0[k]; u1[k] = n1[k]; }
+                    load4(i + 4, n0, n1);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t q0 = u0[k], q1 = u1[k];
+                        const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                        const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+#pragma unroll
+                        for (int j = 0; j < VG; j++) {
+                            const double aw = s_awv[(i + k) * VG + j];   // 255 w, or 0.0 outside row j's taps / past the union
+                            r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                            r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                        }
                     }
                 }
 #pragma unroll

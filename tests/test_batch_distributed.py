@@ -95,3 +95,65 @@ def test_world_size_2_gloo(orc):
     for _, _, (t, ok, bad, saved, avg) in got:                             # identical on every rank
         assert (t, ok, bad, saved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
         assert abs(avg - want["AvgSSIM"]) <= 1e-15 * 4
+
+
+def _uneven_work(idx, state):
+    """Items cost 25 ms on rank 0 (a slow device) and 1 ms on rank 1."""
+    import time
+    time.sleep(0.025 if state == 0 else 0.001)
+    return _fake_work(idx, None)
+
+
+def _rank_main_dynamic(rank, world, port, n_items, out_q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for chunk in (1, 3):                          # two batches in one job: the queue's key is per batch
+        res = batch.compress_batch(n_items, _uneven_work, lambda w: rank, workers=2, rank=rank, world=world,
+                                   queue_mode="dynamic", chunk=chunk)
+        s = batch.summarize_distributed(res)
+        out.append(([r.Index for r in res], (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM)))
+        dist.barrier()
+    out_q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_dynamic_queue(orc):
+    """ONE queue for the whole job (batch.go:72-126's channel across ranks).  With uneven item cost the
+    fast rank takes most of the items; every item is done exactly once; Summarize is the same on every rank and equal
+    to the single-process summary."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_items, world = 61, 2
+    procs = [ctx.Process(target=_rank_main_dynamic, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    allres = [(_fake_work(i, None) if i % 7 != 3 else batch.BatchResult(Index=i, Err="x", has_result=False)) for i in range(n_items)]
+    want = orc.summarize([r.Err is not None for r in allres], [r.has_result for r in allres],
+                         [r.OriginalSize for r in allres], [r.CompressedSize for r in allres], [r.SSIM for r in allres])
+    for b in range(2):
+        i0, s0 = got[0][b]
+        i1, s1 = got[1][b]
+        assert sorted(i0 + i1) == list(range(n_items))                    # every item exactly once
+        assert i0 == sorted(i0) and i1 == sorted(i1)
+        assert len(i1) > 2 * len(i0), (len(i0), len(i1))                  # the fast rank took most of them
+        for t, ok, bad, saved, avg in (s0, s1):
+            assert (t, ok, bad, saved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
+            assert abs(avg - want["AvgSSIM"]) <= 1e-15 * 4
+
+
+def test_dynamic_queue_single_rank_is_static():
+    res = batch.compress_batch(20, _fake_work, lambda w: None, workers=3, queue_mode="dynamic")
+    assert [r.Index for r in res] == list(range(20))
+    with pytest.raises(ValueError):
+        batch.compress_batch(3, _fake_work, lambda w: None, queue_mode="ring")

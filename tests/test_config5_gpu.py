@@ -24,14 +24,15 @@ def _jpegs(n=N_ITEMS, w=W, h=H):
     return [batch.pillow_encode(synth.large_photo(w, h, k), 92) for k in range(n)]     # "4K JPEGs, q = 92 up front"
 
 
-def _run_gpu(jpegs, workers, rank=0, world=1):
+def _run_gpu(jpegs, workers, rank=0, world=1, queue_mode="static"):
     states = {}
 
     def make_state(wid):
         if wid not in states:
             states[wid] = fennec_amd.Context(0)
         return states[wid]
-    res = batch.compress_batch(len(jpegs), batch.jpeg_item_work(jpegs), make_state, workers=workers, rank=rank, world=world)
+    res = batch.compress_batch(len(jpegs), batch.jpeg_item_work(jpegs), make_state, workers=workers, rank=rank, world=world,
+                               queue_mode=queue_mode)
     for c in states.values():
         c.close()
     return res
@@ -58,7 +59,7 @@ def test_config5_compress_batch_matches_oracle_search(orc):
     assert (got.Total, got.Succeeded, got.TotalSaved) == (s["Total"], s["Succeeded"], s["TotalSaved"]) and got.AvgSSIM == s["AvgSSIM"]
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, queue_mode="static"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -66,14 +67,15 @@ def _rank_main(rank, world, port, q):
     torch.cuda.set_device(0)                       # both ranks on GPU 0 (RCCL cannot share a device: gloo)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     jpegs = _jpegs()
-    res = _run_gpu(jpegs, workers=2, rank=rank, world=world)
+    res = _run_gpu(jpegs, workers=2, rank=rank, world=world, queue_mode=queue_mode)
     s = batch.summarize_distributed(res)
     q.put((rank, [(r.Index, r.Quality, r.steps, r.CompressedSize, r.SSIM) for r in res],
            (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM)))
     dist.destroy_process_group()
 
 
-def test_config5_two_ranks_on_one_gpu_equal_single_rank():
+@pytest.mark.parametrize("queue_mode", ["static", "dynamic"])
+def test_config5_two_ranks_on_one_gpu_equal_single_rank(queue_mode):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -82,7 +84,7 @@ def test_config5_two_ranks_on_one_gpu_equal_single_rank():
     want = batch.summarize_local(single)
     mpx = mp.get_context("spawn")
     q = mpx.Queue()
-    procs = [mpx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpx.Process(target=_rank_main, args=(r, 2, port, q, queue_mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]
@@ -91,10 +93,14 @@ def test_config5_two_ranks_on_one_gpu_equal_single_rank():
         assert p.exitcode == 0
     items = {}
     for rank, res, summ in got:
-        assert [i for i, *_ in res] == list(range(rank, N_ITEMS, 2))           # item i -> rank i mod W, order kept
+        if queue_mode == "static":
+            assert [i for i, *_ in res] == list(range(rank, N_ITEMS, 2))       # item i -> rank i mod W, order kept
+        else:
+            assert [i for i, *_ in res] == sorted(i for i, *_ in res)          # ONE queue: whichever rank asked first
         for i, qual, steps, size, ssim in res:
             items[i] = (qual, steps, size, ssim)
         assert summ[:4] == (want.Total, want.Succeeded, want.Failed, want.TotalSaved)
         assert abs(summ[4] - want.AvgSSIM) <= 4e-16 * N_ITEMS                     # the all-reduce re-associates the ssim sum
+    assert sorted(items) == list(range(N_ITEMS)) and sum(len(res) for _, res, _ in got) == N_ITEMS   # each item once
     for r in single:
         assert items[r.Index] == (r.Quality, r.steps, r.CompressedSize, r.SSIM), r.Index
