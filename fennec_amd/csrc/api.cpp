@@ -598,10 +598,31 @@ int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t 
     if (w < 8 || h < 8) {   // ssim.go:35-37
         FNX_REQUIRE(pix_len(w, h, bstride) >= pix_len(w, h, astride), "b.Pix shorter than a.Pix (the reference would panic)");
         FNX_TRY(launch_pixel_ssim(ctx, a, b, w, h, pix_len(w, h, astride), dres));
-    } else {
-        FNX_TRY(launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, window, static_cast<const double *>(dwin), dres));
+        return publish_results(ctx, dres, 1);
     }
-    return publish_results(ctx, dres, 1);
+    // The score's kernels run on the ctx's second stream, behind everything enqueued so far (the images were
+    // produced on `stream`): what the caller enqueues next -- the next image's AdaptiveSharpen in config 4 -- does
+    // not wait for them, so one kernel's last workgroups and the next one's first share the chip instead of each
+    // launch draining it (three launch boundaries per image, ~5 us each, at 8K).  The partial sums use the tail's
+    // own slot: other calls on `stream` may use SLOT_PARTIAL meanwhile.  a and b stay the caller's until the fetch.
+    static const bool same_stream = [] { const char *e = getenv("FNX_SSIM_ENQUEUE_INLINE"); return e && e[0] == '1'; }();
+    if (same_stream) {
+        FNX_TRY(launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, window, static_cast<const double *>(dwin), dres));
+        return publish_results(ctx, dres, 1);
+    }
+    hipEvent_t ev = ctx->ev_blur[ctx->ev_toggle];                 // the one-pass batches' hand-over events, same use
+    FNX_HIP(hipEventRecord(ev, ctx->stream));
+    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ev, 0));
+    ctx->stream2_used = true;
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;
+    ctx->partial_slot = SLOT_PART0;
+    int rc = launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, window, static_cast<const double *>(dwin), dres);
+    if (rc >= 0) rc = publish_results(ctx, dres, 1);              // the result's event: behind the score, on the second stream
+    ctx->partial_slot = -1;
+    ctx->stream = main_stream;
+    ctx->ev_toggle ^= 1;
+    return rc;
 }
 
 // MSSSIM's weights, trimmed while a level's min dim < 8 (ssim.go:324-342)

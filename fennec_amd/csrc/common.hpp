@@ -114,6 +114,7 @@ struct fnx_ctx {
     hipEvent_t ev_blur[2] = {}, ev_tail[2] = {};
     bool tail_pending[2] = {false, false};
     int parity = 0;
+    int ev_toggle = 0;           // fnx_ssim_enqueue alternates between the two hand-over events
     bool stream2_used = false;
     int partial_slot = -1;       // >= 0: launch_windowed_ssim takes its partial sums from this slot (one-pass tail)
     fnx::Scratch slot[fnx::SLOT_COUNT];

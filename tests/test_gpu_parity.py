@@ -1138,3 +1138,24 @@ def test_msssim_enqueue_fifo(ctx, orc):
     ctx.msssim_enqueue(*pairs[1])
     assert ctx.fetch_result() == s0
     assert ctx.fetch_result() == want[1]
+
+
+@pytest.mark.gpu
+def test_lanczos_resize_mixed_content_sequence(ctx, orc):
+    """One cached plan, content that takes different routes through the guard kernels from call to call: tie-dense
+    (the reference's ramps at an integer ratio: every row goes to the exact loops), noise (the fp32 form decides nearly
+    everything), translucent ramps (general arithmetic per output).  Every result is the oracle's."""
+    import torch
+    w, h, dw, dh = 1280, 720, 640, 360
+    ramp = [synth.large_photo(w, h, k) for k in range(3)]
+    noise = synth.noise_image(w, h, 11)
+    trans = synth.large_photo(w, h, 5)
+    trans[100:300, 200:900, 3] = 77
+    seq = [ramp[0], ramp[1], ramp[2], noise, noise, ramp[0], trans, trans, ramp[1], noise, ramp[2]]
+    want = {}
+    for k, img in enumerate(seq):
+        key = id(img)
+        if key not in want:
+            want[key] = orc.lanczos_resize(img, dw, dh, procs=8)
+        got = ctx.lanczosResize(torch.from_numpy(img).cuda(), dw, dh).cpu().numpy()
+        assert np.array_equal(got, want[key]), k
