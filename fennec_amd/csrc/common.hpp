@@ -66,6 +66,7 @@ enum Slot {
     SLOT_JPEG1,
     SLOT_JPEG2,
     SLOT_JPEG3,
+    SLOT_DONE,       // workgroup counters of the kernels that finish their own reduction (ssim.hip), zero between launches
     SLOT_COUNT
 };
 

@@ -20,6 +20,7 @@
 //
 // fx_ref_kernel (the round-1 kernel: fp64, the reference's operation order) remains for amounts outside the
 // guard's bound and for Sharpen amounts with a near-tie product.
+#include <type_traits>
 #include "common.hpp"
 #include "devutil.hpp"
 
@@ -140,21 +141,23 @@ __device__ __forceinline__ uint32_t lum_milli_u32(uint32_t p)
     return __builtin_amdgcn_udot4(p, 0x0072ffffu, i, false);
 }
 
+// AdaptiveSharpen is occupancy-bound (a workgroup is load tile -> barrier -> compute -> store, and what hides one
+// phase is other workgroups): 5 per CU -- <= 96 VGPRs, <= 32 KB of LDS each (16-bit table and fix-up list)
 template <int MODE>
-__global__ __launch_bounds__(256) void fx_march_kernel(FxArgs a)
+__global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_kernel(FxArgs a)
 {
     constexpr int LW = FX_LW, LH = FX_LH;
     __shared__ __attribute__((aligned(16))) uint32_t s_rb[LH * LW], s_ga[LH * LW];
     __shared__ __attribute__((aligned(16))) uint32_t s_lum[MODE == FX_ADAPTIVE ? LH * LW : 4];
-    __shared__ int32_t s_tab[MODE != FX_BLUR3 ? 512 : 1];
-    __shared__ uint32_t s_fix[MODE == FX_ADAPTIVE ? FX_FIX_CAP : 1];
+    __shared__ int16_t s_tab[MODE != FX_BLUR3 ? 512 : 2];                // |R[d]| <= 64 * 255 (build_rtab)
+    __shared__ uint16_t s_fix[MODE == FX_ADAPTIVE ? FX_FIX_CAP : 2];
     __shared__ int s_nfix;
     const int x0 = blockIdx.x * FX_TW, y0 = blockIdx.y * FX_TH;
     const int tid = threadIdx.x;
     if (MODE == FX_ADAPTIVE && tid == 0) s_nfix = 0;
     if (MODE == FX_SHARPEN || (MODE == FX_ADAPTIVE && a.use_table)) {
-        s_tab[tid] = a.rtab[tid];
-        s_tab[256 + tid] = a.rtab[256 + tid];
+        s_tab[tid] = static_cast<int16_t>(a.rtab[tid]);
+        s_tab[256 + tid] = static_cast<int16_t>(a.rtab[256 + tid]);
     }
     auto put = [&](int cell, uint32_t p) {
         s_rb[cell] = p & 0x00ff00ffu;
@@ -223,62 +226,74 @@ __global__ __launch_bounds__(256) void fx_march_kernel(FxArgs a)
         }
     }
     const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+    // tiles that touch no image border (all but the frame) skip the per-pixel edge tests
+    const bool interior = x0 >= 1 && y0 >= 1 && x0 + FX_TW < a.w && y0 + FX_TH < a.h;
+    auto rows = [&](auto tag) {
+        constexpr bool INTERIOR = decltype(tag)::value;
 #pragma unroll
-    for (int j = 0; j < FX_RP; j++) {
-        const int y = y0 + rg * FX_RP + j;
-        const int ci = base + (j + 1) * LW;
-        const uint32_t crb = s_rb[ci], cga = s_ga[ci];
-        const uint32_t c = crb | (cga << 8);
-        uint32_t out = c;                                        // borders and alpha are copies of the source (effects.go:68,120)
-        bool flagged = false;
-        if (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1) {
-            // [1 2 1] vertically over the horizontal sums; (sum + 8) >> 4 per field (effects.go:125-135)
-            const uint32_t srb = hrb[j] + hrb[j + 2] + 2 * hrb[j + 1] + 0x00080008u;
-            const uint32_t sga = hga[j] + hga[j + 2] + 2 * hga[j + 1] + 0x00080008u;
-            const uint32_t br = (srb >> 4) & 0xffu, bg = (sga >> 4) & 0xffu, bb = (srb >> 20) & 0xffu;
-            if constexpr (MODE == FX_BLUR3) {
-                out = br | (bg << 8) | (bb << 16) | (c & 0xff000000u);
-            } else {
-                const int o_r = crb & 0xffu, o_g = cga & 0xffu, o_b = (crb >> 16) & 0xffu;
-                const int d_r = o_r - static_cast<int>(br), d_g = o_g - static_cast<int>(bg), d_b = o_b - static_cast<int>(bb);
-                // table form: clamp(orig + R[d])
-                auto tab = [&]() {
-                    const int vr = clampi(o_r + s_tab[d_r + 255], 0, 255), vg = clampi(o_g + s_tab[d_g + 255], 0, 255),
-                              vb = clampi(o_b + s_tab[d_b + 255], 0, 255);
-                    return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | (c & 0xff000000u);
-                };
-                if constexpr (MODE == FX_SHARPEN) {
-                    out = tab();
+        for (int j = 0; j < FX_RP; j++) {
+            const int y = y0 + rg * FX_RP + j;
+            const int ci = base + (j + 1) * LW;
+            const uint32_t crb = s_rb[ci], cga = s_ga[ci];
+            const uint32_t c = crb | (cga << 8);
+            uint32_t out = c;                                    // borders and alpha are copies of the source (effects.go:68,120)
+            bool flagged = false;
+            if (INTERIOR || (x >= 1 && y >= 1 && x < a.w - 1 && y < a.h - 1)) {
+                // [1 2 1] vertically over the horizontal sums; (sum + 8) >> 4 per field (effects.go:125-135)
+                const uint32_t srb = hrb[j] + hrb[j + 2] + 2 * hrb[j + 1] + 0x00080008u;
+                const uint32_t sga = hga[j] + hga[j + 2] + 2 * hga[j + 1] + 0x00080008u;
+                if constexpr (MODE == FX_BLUR3) {
+                    const uint32_t br = (srb >> 4) & 0xffu, bg = (sga >> 4) & 0xffu, bb = (srb >> 20) & 0xffu;
+                    out = br | (bg << 8) | (bb << 16) | (c & 0xff000000u);
                 } else {
-                    // Sobel on I (exact integers, |g| <= 4 * 255000 < 2^24: the converts are exact)
-                    const float gx = static_cast<float>(dxr[j] + dxr[j + 2] + 2 * dxr[j + 1]);
-                    const float gy = static_cast<float>(sxr[j + 2] - sxr[j]);
-                    const float m2 = fmaf(gy, gy, gx * gx);
-                    const float t = fminf(a.amt32, __builtin_amdgcn_sqrtf(m2) * a.k32);   // amount * e, within 4e-7 relative
-                    const float fr = static_cast<float>(o_r), fg = static_cast<float>(o_g), fb = static_cast<float>(o_b);
-                    const float ar = fmaf(t, static_cast<float>(d_r), fr + seed);
-                    const float ag = fmaf(t, static_cast<float>(d_g), fg + seed);
-                    const float ab = fmaf(t, static_cast<float>(d_b), fb + seed);
-                    const float hr = ar + g2, hg = ag + g2, hb = ab + g2;
-                    fp32_round_toward_zero();
-                    out = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, c)));
-                    const uint32_t out2 = pk8(hb, 2, pk8(hg, 1, pk8(hr, 0, c)));
-                    fp32_round_nearest();
-                    flagged = out != out2;
-                    if (a.use_table && m2 > 1.6000016e11f) {     // e == 1 for certain (400000^2 + 1e-5 relative): exact by table
+                    // table form: clamp(orig + R[d]) on integers
+                    auto tab = [&]() {
+                        const int br = (srb >> 4) & 0xffu, bg = (sga >> 4) & 0xffu, bb = (srb >> 20) & 0xffu;
+                        const int o_r = crb & 0xffu, o_g = cga & 0xffu, o_b = (crb >> 16) & 0xffu;
+                        const int vr = clampi(o_r + s_tab[o_r - br + 255], 0, 255), vg = clampi(o_g + s_tab[o_g - bg + 255], 0, 255),
+                                  vb = clampi(o_b + s_tab[o_b - bb + 255], 0, 255);
+                        return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | (c & 0xff000000u);
+                    };
+                    if constexpr (MODE == FX_SHARPEN) {
                         out = tab();
-                        flagged = false;
-                    }
-                    if (flagged) {
-                        const int e = atomicAdd(&s_nfix, 1);
-                        if (e < FX_FIX_CAP) s_fix[e] = ((rg * FX_RP + j) << 8) | cx;
+                    } else {
+                        // Sobel on I (exact integers, |g| <= 4 * 255000 < 2^24: the converts are exact)
+                        const float gx = static_cast<float>(dxr[j] + dxr[j + 2] + 2 * dxr[j + 1]);
+                        const float gy = static_cast<float>(sxr[j + 2] - sxr[j]);
+                        const float m2 = fmaf(gy, gy, gx * gx);
+                        const float t = fminf(a.amt32, __builtin_amdgcn_sqrtf(m2) * a.k32);   // amount * e, within 4e-7 relative
+                        // bytes to floats directly (v_cvt_f32_ubyteN of the field words); orig - blur is exact in fp32
+                        const uint32_t brb = srb >> 4, bga = sga >> 4;      // blurred R | B << 16, blurred G in byte 0
+                        const float fr = static_cast<float>(crb & 0xffu), fg = static_cast<float>(cga & 0xffu),
+                                    fb = static_cast<float>((crb >> 16) & 0xffu);
+                        const float dr = fr - static_cast<float>(brb & 0xffu), dg = fg - static_cast<float>(bga & 0xffu),
+                                    db = fb - static_cast<float>((brb >> 16) & 0xffu);
+                        const float ar = fmaf(t, dr, fr + seed);
+                        const float ag = fmaf(t, dg, fg + seed);
+                        const float ab = fmaf(t, db, fb + seed);
+                        const float hr = ar + g2, hg = ag + g2, hb = ab + g2;
+                        fp32_round_toward_zero();
+                        out = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, c)));
+                        const uint32_t out2 = pk8(hb, 2, pk8(hg, 1, pk8(hr, 0, c)));
+                        fp32_round_nearest();
+                        flagged = out != out2;
+                        if (a.use_table && m2 > 1.6000016e11f) {     // e == 1 for certain (400000^2 + 1e-5 relative): exact by table
+                            out = tab();
+                            flagged = false;
+                        }
+                        if (flagged) {
+                            const int e = atomicAdd(&s_nfix, 1);
+                            if (e < FX_FIX_CAP) s_fix[e] = static_cast<uint16_t>(((rg * FX_RP + j) << 8) | cx);
+                        }
                     }
                 }
             }
+            if ((INTERIOR || (x < a.w && y < a.h)) && !flagged)
+                *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
         }
-        if (x < a.w && y < a.h && !flagged)
-            *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
-    }
+    };
+    if (interior) rows(std::true_type{});
+    else rows(std::false_type{});
     if constexpr (MODE == FX_ADAPTIVE) {
         // flagged pixels (a rounding boundary within G of the fp32 value): the reference's own fp64 arithmetic.
         // A list overflow recomputes every interior pixel of the tile.
@@ -376,7 +391,9 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
     if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
-        hipLaunchKernelGGL((fx_march_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
+        // FNX_FX_LDS_PAD=<bytes> of unused dynamic LDS: an A/B knob for workgroups per CU (8192 -> 4 instead of 5)
+        static const unsigned pad = [] { const char *e = getenv("FNX_FX_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+        hipLaunchKernelGGL((fx_march_kernel<MODE>), grid, dim3(256), pad, ctx->stream, a);
     } else {
         dim3 grid((w + FXR_TW - 1) / FXR_TW, (h + FXR_TH - 1) / FXR_TH);
         hipLaunchKernelGGL((fx_ref_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);

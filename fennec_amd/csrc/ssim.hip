@@ -647,6 +647,11 @@ struct MarchArgs {
     int strips, segs, seg_rows;   // per image: strips x segs wave-sized work items, seg_rows window rows each
     double *partial;              // [n][strips * segs]
     double col[8], row[8];        // k[j][i] ~= row[j] * col[i]
+    // out != nullptr: the LAST workgroup of an image to finish also takes the image's mean (the sum ssim_finish_kernel
+    // would take, in the same order) -- no second launch behind a kernel whose waves all end together
+    double *out;
+    unsigned *done;               // [n] workgroups finished, zero before and after the launch
+    double count;
 };
 
 // exact integer milli-luminance: 299 R + 587 G + 114 B  (255 + 44, 255 + 255 + 77, 114)
@@ -658,16 +663,34 @@ __device__ __forceinline__ double lum_milli(uint32_t p)
     return u8_to_f64(i);
 }
 
+// fixed-order sum of `tiles` partial sums by a 256-lane workgroup (valid in thread 0): 8 independent partial sums
+// per lane keep 8 loads in flight (a single chain waits out every load: 60 us for the 65 k tiles of an 8K SSIM);
+// the combination order is fixed, so results stay bit-reproducible from run to run
+__device__ __forceinline__ double finish_sum_256(const double *p, int tiles, double *s_red)
+{
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < tiles; i += 8 * 256) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += p[i + e * 256];
+    }
+    for (int e = 0; i < tiles; i += 256, e++) acc[e] += p[i];
+    const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    return block_sum_256(v, s_red);
+}
+
 __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
 {
     // per wave: [0, WM_LDSW) (a, b) pairs, [WM_LDSW, 2 WM_LDSW) (a^2 + b^2, ab) pairs
     __shared__ __attribute__((aligned(16))) double2 s_row[4][2 * WM_LDSW];
+    __shared__ double s_red[4];
+    __shared__ int s_last;
     const int z = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + wave;
     const int items = a.strips * a.segs;
-    if (item >= items) return;
+    if (item < items) {                                           // wave-uniform (a wave without an item still joins the finish)
     // adjacent waves take adjacent strips of one segment: a workgroup reads 4 x 57 contiguous columns
     const int seg = item / a.strips, strip = item - seg * a.strips;
     const int ww = a.w - 8, wh = a.h - 8;
@@ -761,26 +784,42 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
     if (!live) val = 0.0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
-    if (lane == 0) a.partial[static_cast<size_t>(z) * items + item] = val;
+    if (lane == 0) {
+        double *pp = a.partial + static_cast<size_t>(z) * items + item;
+        if (a.out) {
+            // write-through store + drain instead of an agent-scope release: the release is an L2 write-back
+            // (buffer_wbl2) per workgroup and cost 40 % of the launch
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp), "v"(val) : "memory");
+        } else {
+            *pp = val;
+        }
+    }
+    }
+    if (a.out) {
+        // partial sums written through, then the counter; whoever moves it to the last value reads them all back
+        // behind an agent-scope acquire (other CUs', other XCDs' stores: MI355X_MICROARCH "inter-workgroup visibility")
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&a.done[z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = prev == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const double t = finish_sum_256(a.partial + static_cast<size_t>(z) * items, items, s_red);
+            if (threadIdx.x == 0) {
+                a.out[z] = a.count > 0 ? t / a.count : 1.0;       // totalCount==0 -> 1.0 (ssim.go:162-164)
+                __hip_atomic_store(&a.done[z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
 {
     __shared__ double s_red[4];
-    const double *p = partial + static_cast<size_t>(blockIdx.x) * tiles;
-    // 8 independent partial sums per lane keep 8 loads in flight (a single chain waits out every load:
-    // 60 us for the 65 k tiles of an 8K SSIM); the combination order is fixed, so results stay
-    // bit-reproducible from run to run
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int i = threadIdx.x;
-    for (; i + 7 * 256 < tiles; i += 8 * 256) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] += p[i + e * 256];
-    }
-    for (int e = 0; i < tiles; i += 256, e++) acc[e] += p[i];
-    const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    const double t = block_sum_256(v, s_red);
+    const double t = finish_sum_256(partial + static_cast<size_t>(blockIdx.x) * tiles, tiles, s_red);
     if (threadIdx.x == 0) out[blockIdx.x] = count > 0 ? t / count : 1.0;   // totalCount==0 -> 1.0 (ssim.go:162-164)
 }
 
@@ -828,6 +867,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         tiles = tiles_x * ((wh + TY - 1) / TY);
     }
     void *part = nullptr;
+    bool folded = false;
     if (defer) {
         // the caller reserved SLOT_PARTIAL for all deferred levels (growing it now would free partials that
         // earlier levels' kernels are still writing); a level that does not fit is an error, not a fallback
@@ -847,6 +887,23 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         ma.astride = astride; ma.bstride = bstride; ma.w = w; ma.h = h;
         ma.partial = static_cast<double *>(part);
         for (int i = 0; i < 8; i++) { ma.col[i] = sa.col[i]; ma.row[i] = sa.row[i]; }
+        // the image's last workgroup takes the mean itself (no finish launch).  Counters: 2 x 4096, one half per
+        // stream the ctx launches on (a scored tail on the second stream may run beside a call on the first)
+        static const bool nofold = [] { const char *e = getenv("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
+        if (!defer && !nofold && n <= 4096) {
+            const Scratch &sl = ctx->slot[SLOT_DONE];
+            const void *before = sl.p;
+            void *dn = nullptr;
+            FNX_TRY(scratch(ctx, SLOT_DONE, sizeof(unsigned) * 2 * 4096, &dn));
+            if (dn != before) {                                   // first use: zero once, for both streams
+                FNX_HIP(hipMemsetAsync(dn, 0, sizeof(unsigned) * 2 * 4096, ctx->stream));
+                FNX_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            ma.done = static_cast<unsigned *>(dn) + (ctx->partial_slot >= 0 ? 4096 : 0);
+            ma.out = d_out;
+            ma.count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
+            folded = true;
+        }
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
         hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         FNX_HIP(hipGetLastError());
@@ -872,6 +929,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         defer->used += static_cast<size_t>(tiles) + 2;
         return FNX_OK;
     }
+    if (folded) return FNX_OK;
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(n), dim3(256), 0, ctx->stream,
                        static_cast<const double *>(part), tiles, count, d_out);
     FNX_HIP(hipGetLastError());
