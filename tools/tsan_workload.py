@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""What the worker pools do, on small images so that it runs under ThreadSanitizer in seconds: 6 threads, one fnx ctx
+each, every kind of call the batch paths make (tap-table cache shared between threads, thread-local errors, result
+FIFOs, plan caches, the second stream), plus deliberate argument errors on every thread."""
+import os
+import sys
+import threading
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fennec_amd  # noqa: E402
+from fennec_amd import batch, synth  # noqa: E402
+
+N_THREADS, ROUNDS = 6, 6
+errs = []
+
+
+def worker(k):
+    try:
+        import torch
+        torch.cuda.set_device(0)
+        c = fennec_amd.Context(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for r in range(ROUNDS):
+                w, h = 320 + 16 * ((k + r) % 5), 200 + 8 * ((k * 3 + r) % 7)
+                img = synth.large_photo(w, h, k + r)
+                d = torch.from_numpy(img).cuda()
+                small = c.lanczosResize(d, w // 2, h // 2)             # shared tap-table cache, per-ctx plans
+                c.msssim_enqueue(d, small)
+                sharp = c.AdaptiveSharpen(d, 0.5)
+                c.ssim_enqueue(d, sharp)                               # second stream
+                v1, v2 = c.fetch_result(), c.fetch_result()
+                b = c.GaussianBlur(img, 2.0)                           # host-space call
+                v3 = c.SSIMFast(img, b)
+                q, s_, steps, found = c.jpeg_quality_search(img, 0.94)
+                assert 0 < v1 <= 1 and 0 < v2 <= 1 and 0 < v3 <= 1 and 1 <= q <= 100
+                try:
+                    c.lanczosResize(np.zeros((4, 4, 3), np.uint8), 2, 2)   # thread-local error text
+                except Exception:
+                    pass
+        c.close()
+    except Exception as e:                                             # noqa: BLE001
+        errs.append((k, repr(e)))
+
+
+ts = [threading.Thread(target=worker, args=(k,)) for k in range(N_THREADS)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+# CompressBatch's pool itself
+jpegs = [batch.pillow_encode(synth.large_photo(640, 480, k), 92) for k in range(12)]
+states = {}
+res = batch.compress_batch(len(jpegs), batch.jpeg_item_work(jpegs), lambda wid: states.setdefault(wid, fennec_amd.Context(0)), workers=4)
+assert all(r.Err is None for r in res), [r.Err for r in res]
+print("errors:", errs)
+print("done" if not errs else "FAILED")
+sys.exit(1 if errs else 0)
