@@ -25,7 +25,7 @@ def test_bench_line_contract(path):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # the headline (one-pass) lines always carry the CPU baseline; side lines collected with --no-cpu-baseline (the same
     # baseline would be re-timed for nothing) may omit it
-    if d["n_gpus"] == 1 and ("cpu_baseline" in d or "onepass" in os.path.basename(path)):
+    if d["n_gpus"] == 1 and ("cpu_baseline" in d or os.path.basename(path).endswith("_onepass_bench_plain.json")):
         c = d["cpu_baseline"]
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in c, k
