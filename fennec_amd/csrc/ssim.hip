@@ -679,6 +679,45 @@ __device__ __forceinline__ double finish_sum_256(const double *p, int tiles, dou
     return block_sum_256(v, s_red);
 }
 
+// The end of a marching wave: its sum into the image's partial sums and -- out != nullptr -- the folded finish.  Every
+// wave of the workgroup calls it (val is ignored when the wave had no item).
+__device__ __forceinline__ void march_finish(const MarchArgs &a, int z, int item, int items, double val, double *s_red, int *s_last)
+{
+    const int lane = threadIdx.x & 63;
+    if (item < items) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+        if (lane == 0) {
+            double *pp = a.partial + static_cast<size_t>(z) * items + item;
+            if (a.out) {
+                // write-through store + drain instead of an agent-scope release: the release is an L2 write-back
+                // (buffer_wbl2) per workgroup and cost 40 % of the launch
+                asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp), "v"(val) : "memory");
+            } else {
+                *pp = val;
+            }
+        }
+    }
+    if (a.out) {
+        // partial sums written through, then the counter; whoever moves it to the last value reads them all back
+        // behind an agent-scope acquire (other CUs', other XCDs' stores: MI355X_MICROARCH "inter-workgroup visibility")
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(&a.done[z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_last = prev == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (*s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const double t = finish_sum_256(a.partial + static_cast<size_t>(z) * items, items, s_red);
+            if (threadIdx.x == 0) {
+                a.out[z] = a.count > 0 ? t / a.count : 1.0;       // totalCount==0 -> 1.0 (ssim.go:162-164)
+                __hip_atomic_store(&a.done[z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
 {
     // per wave: [0, WM_LDSW) (a, b) pairs, [WM_LDSW, 2 WM_LDSW) (a^2 + b^2, ab) pairs
@@ -690,6 +729,7 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + wave;
     const int items = a.strips * a.segs;
+    double val = 0.0;
     if (item < items) {                                           // wave-uniform (a wave without an item still joins the finish)
     // adjacent waves take adjacent strips of one segment: a workgroup reads 4 x 57 contiguous columns
     const int seg = item / a.strips, strip = item - seg * a.strips;
@@ -710,7 +750,6 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
     double m[8][4];                                               // ring: window slot x {E[a], E[b], E[a^2 + b^2], E[ab]}
 #pragma unroll
     for (int s = 0; s < 8; s++) m[s][0] = m[s][1] = m[s][2] = m[s][3] = 0.0;
-    double val = 0.0;
     // pixel rows are fetched WM_PF rows ahead (one row of work is ~450 clocks of issue, an HBM miss ~900):
     // slot (i mod WM_PF) holds row i
     uint32_t qa[WM_PF], qb[WM_PF];
@@ -782,37 +821,148 @@ __global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
         }
     }
     if (!live) val = 0.0;
+    }
+    march_finish(a, z, item, items, val, s_red, &s_last);
+}
+
+// ------------------------------------------------------------------------------------
+// The same march with TWO pixel columns per lane -- what the biggest planes take.
+//
+// The one-column kernel is bound by LDS bandwidth, not by its FMAs: per pixel row a lane reads 8 taps x 2 entries of
+// 16 bytes (256 B) and writes 32 B, 64 lanes x 288 B = 18 KB per wave-row at 128 B per clock per CU -> 144 clocks,
+// x 16 resident waves = 2300 clocks per row round against 4 x 94 x 4 = 1500 clocks of VALU issue per SIMD.  Two
+// ADJACENT columns share 7 of their 8 taps: a lane that owns pixels 2l and 2l + 1 reads 9 entries per array instead of
+// 16 (and a wave covers 128 pixel columns, so its 7 idle window columns are 5 % of the lanes' work instead of 11 %):
+// 176 LDS bytes per window instead of 288.  Even and odd pixels live in separate arrays so that every read is
+// 16 bytes at a 16-byte lane stride (one array at a 32-byte stride would be 2-way bank conflicts).  The rings of both
+// columns are 128 VGPRs, so this form runs 2 waves per SIMD -- the same windows in flight per SIMD as 4 one-column
+// waves, with the instruction-level parallelism inside the wave instead of between waves.
+// ------------------------------------------------------------------------------------
+constexpr int WM2_COLS = 121;        // window columns per wave (128 pixel columns - 7)
+constexpr int WM2_LDSW = 72;         // entries per parity array: lane + 4, padded
+
+__global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs a)
+{
+    // per wave, four arrays of WM2_LDSW: even (a, b), odd (a, b), even (a^2 + b^2, ab), odd (a^2 + b^2, ab)
+    __shared__ __attribute__((aligned(16))) double2 s_row[4][4 * WM2_LDSW];
+    __shared__ double s_red[4];
+    __shared__ int s_last;
+    const int z = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    const int items = a.strips * a.segs;
+    double val = 0.0;
+    if (item < items) {                                           // wave-uniform
+    const int seg = item / a.strips, strip = item - seg * a.strips;
+    const int ww = a.w - 8, wh = a.h - 8;
+    const int wy0 = seg * a.seg_rows;
+    const int nwin = min(a.seg_rows, wh - wy0);
+    const int wx = strip * WM2_COLS + 2 * lane;                   // window (= pixel) column of this lane's first column
+    const bool live0 = 2 * lane < WM2_COLS && wx < ww, live1 = 2 * lane + 1 < WM2_COLS && wx + 1 < ww;
+    // the pixel pair (px, px + 1), one 8-byte load (4-byte aligned).  Columns past w - 2 are taps of no live window
+    // (the image's last column is never sampled, ssim.go:110-111): such lanes re-read the last pair
+    const int px = min(wx, a.w - 2);
+    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    double2 *s_e1 = s_row[wave], *s_o1 = s_e1 + WM2_LDSW, *s_e2 = s_o1 + WM2_LDSW, *s_o2 = s_e2 + WM2_LDSW;
+    if (lane < WM2_LDSW - 64) {                                   // the entries lanes 60..63 read past lane 63: finite, unused
+        s_e1[64 + lane] = make_double2(0.0, 0.0); s_o1[64 + lane] = make_double2(0.0, 0.0);
+        s_e2[64 + lane] = make_double2(0.0, 0.0); s_o2[64 + lane] = make_double2(0.0, 0.0);
+    }
+    const int nrows = nwin + 7;
+    double m0[8][4], m1[8][4];                                    // the two columns' rings (see the one-column kernel)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
-    if (lane == 0) {
-        double *pp = a.partial + static_cast<size_t>(z) * items + item;
-        if (a.out) {
-            // write-through store + drain instead of an agent-scope release: the release is an L2 write-back
-            // (buffer_wbl2) per workgroup and cost 40 % of the launch
-            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp), "v"(val) : "memory");
-        } else {
-            *pp = val;
-        }
+    for (int s = 0; s < 8; s++) {
+        m0[s][0] = m0[s][1] = m0[s][2] = m0[s][3] = 0.0;
+        m1[s][0] = m1[s][1] = m1[s][2] = m1[s][3] = 0.0;
     }
+    double val0 = 0.0, val1 = 0.0;
+    typedef __attribute__((address_space(1))) const u32x2 g_u32x2;
+    u32x2 qa[WM_PF], qb[WM_PF];
+#pragma unroll
+    for (int k = 0; k < WM_PF; k++) {
+        const int rr = min(k, nrows - 1);
+        qa[k] = *(g_u32x2 *)(pa + static_cast<size_t>(rr) * a.astride);
+        qb[k] = *(g_u32x2 *)(pb + static_cast<size_t>(rr) * a.bstride);
     }
-    if (a.out) {
-        // partial sums written through, then the counter; whoever moves it to the last value reads them all back
-        // behind an agent-scope acquire (other CUs', other XCDs' stores: MI355X_MICROARCH "inter-workgroup visibility")
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(&a.done[z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = prev == gridDim.x - 1;
-        }
-        __syncthreads();
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const double t = finish_sum_256(a.partial + static_cast<size_t>(z) * items, items, s_red);
-            if (threadIdx.x == 0) {
-                a.out[z] = a.count > 0 ? t / a.count : 1.0;       // totalCount==0 -> 1.0 (ssim.go:162-164)
-                __hip_atomic_store(&a.done[z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pa += static_cast<size_t>(min(WM_PF, nrows - 1)) * a.astride;
+    pb += static_cast<size_t>(min(WM_PF, nrows - 1)) * a.bstride;
+    constexpr double C1 = 6.5025e6, C2 = 58.5225e6;
+
+    for (int r = 0; r < nrows; r += 8) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int i = r + p;
+            if (i < nrows) {                                      // wave-uniform
+                const double va0 = lum_milli(qa[p % WM_PF][0]), va1 = lum_milli(qa[p % WM_PF][1]);
+                const double vb0 = lum_milli(qb[p % WM_PF][0]), vb1 = lum_milli(qb[p % WM_PF][1]);
+                qa[p % WM_PF] = *(g_u32x2 *)pa;                   // no branch around the loads (see the one-column kernel)
+                qb[p % WM_PF] = *(g_u32x2 *)pb;
+                if (i + WM_PF + 1 < nrows) {
+                    pa += a.astride;
+                    pb += a.bstride;
+                }
+                s_e1[lane] = make_double2(va0, vb0);
+                s_o1[lane] = make_double2(va1, vb1);
+                s_e2[lane] = make_double2(fma(vb0, vb0, va0 * va0), va0 * vb0);
+                s_o2[lane] = make_double2(fma(vb1, vb1, va1 * va1), va1 * vb1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // pixel 2l + t: even t -> even[l + t / 2], odd t -> odd[l + t / 2].  Column 0's tap t is pixel 2l + t,
+                // column 1's tap t is pixel 2l + 1 + t.
+                double h00 = 0.0, h01 = 0.0, h02 = 0.0, h03 = 0.0, h10 = 0.0, h11 = 0.0, h12 = 0.0, h13 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 9; q++) {                     // pixel 2l + q
+                    const double2 u = (q & 1) ? s_o1[lane + q / 2] : s_e1[lane + q / 2];
+                    const double2 v = (q & 1) ? s_o2[lane + q / 2] : s_e2[lane + q / 2];
+                    if (q < 8) {
+                        const double c = a.col[q];
+                        h00 = fma(u.x, c, h00); h01 = fma(u.y, c, h01); h02 = fma(v.x, c, h02); h03 = fma(v.y, c, h03);
+                    }
+                    if (q >= 1) {
+                        const double c = a.col[q - 1];
+                        h10 = fma(u.x, c, h10); h11 = fma(u.y, c, h11); h12 = fma(v.x, c, h12); h13 = fma(v.y, c, h13);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                  // the row is consumed before the next one overwrites it
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int k = (p - s) & 7;
+                    const double rk = a.row[k];
+                    if (k == 0) {
+                        m0[s][0] = h00 * rk; m0[s][1] = h01 * rk; m0[s][2] = h02 * rk; m0[s][3] = h03 * rk;
+                        m1[s][0] = h10 * rk; m1[s][1] = h11 * rk; m1[s][2] = h12 * rk; m1[s][3] = h13 * rk;
+                    } else {
+                        m0[s][0] = fma(h00, rk, m0[s][0]); m0[s][1] = fma(h01, rk, m0[s][1]);
+                        m0[s][2] = fma(h02, rk, m0[s][2]); m0[s][3] = fma(h03, rk, m0[s][3]);
+                        m1[s][0] = fma(h10, rk, m1[s][0]); m1[s][1] = fma(h11, rk, m1[s][1]);
+                        m1[s][2] = fma(h12, rk, m1[s][2]); m1[s][3] = fma(h13, rk, m1[s][3]);
+                    }
+                }
+                if (i >= 7) {
+                    const int s = (p + 1) & 7;
+                    auto score = [&](const double (&mm)[4]) {
+                        const double muA = mm[0], muB = mm[1];
+                        const double mu2 = fma(muB, muB, muA * muA), muAB = muA * muB;
+                        const double sSum = mm[2] - mu2, sAB = mm[3] - muAB;
+                        const double num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
+                        const double den = (mu2 + C1) * (sSum + C2);
+                        double rc = __builtin_amdgcn_rcp(den);
+                        rc = fma(fma(-den, rc, 1.0), rc, rc);
+                        rc = fma(fma(-den, rc, 1.0), rc, rc);
+                        return num * rc;
+                    };
+                    val0 += score(m0[s]);
+                    val1 += score(m1[s]);
+                }
             }
         }
     }
+    val = (live0 ? val0 : 0.0) + (live1 ? val1 : 0.0);
+    }
+    march_finish(a, z, item, items, val, s_red, &s_last);
 }
 
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
@@ -849,12 +999,16 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? W24_TY : WSS_TY) : WS_TY;
     int tiles_x = 0, tiles = 0;
     MarchArgs ma{};
+    // the two-column form (2 waves per SIMD) once there is a round of such waves to fill the chip with
+    static const long march2_min = [] { const char *e = getenv("FNX_SSIM_MARCH2_MIN"); return e ? atol(e) : 4000000L; }();
+    const bool march2 = march && static_cast<long>(ww) * wh * n >= march2_min;
     if (march) {
-        // wave-sized work items: strips of 57 window columns x row segments.  Segments are cut so that the
-        // launch holds about one resident round of waves (16 per CU) but never shorter than 32 window rows
-        // (row halo (S + 7) / S <= 1.22)
-        ma.strips = (ww + WM_COLS - 1) / WM_COLS;
-        const long target = 16L * ctx->num_cus;
+        // wave-sized work items: strips of 57 (two-column form: 121) window columns x row segments.  Segments are cut
+        // so that the launch holds about one resident round of waves (16 per CU; 8) but never shorter than 32 window
+        // rows (row halo (S + 7) / S <= 1.22)
+        const int cols = march2 ? WM2_COLS : WM_COLS;
+        ma.strips = (ww + cols - 1) / cols;
+        const long target = (march2 ? 8L : 16L) * ctx->num_cus;
         long segs = target / (static_cast<long>(n) * ma.strips);
         const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
         if (segs > max_segs) segs = max_segs;
@@ -905,7 +1059,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
             folded = true;
         }
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
-        hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        else hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         FNX_HIP(hipGetLastError());
         FNX_TRY(prof_end(ctx));
     } else if (sep) {
