@@ -652,6 +652,7 @@ struct MarchArgs {
     double *out;
     unsigned *done;               // [n] workgroups finished, zero before and after the launch
     double count;
+    int prio;                     // march2: alternate the wave's priority by progress (A/B knob FNX_SSIM_PRIO)
 };
 
 // exact integer milli-luminance: 299 R + 587 G + 114 B  (255 + 44, 255 + 255 + 77, 114)
@@ -890,7 +891,17 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
     pb += static_cast<size_t>(min(WM_PF, nrows - 1)) * a.bstride;
     constexpr double C1 = 6.5025e6, C2 = 58.5225e6;
 
+    // The two waves of a SIMD are from two workgroups, and the issue arbiter prefers the OLDER wave every cycle: per-wave
+    // timestamps showed the first-dispatched half of an 8K launch finishing at 101 us and the second at 148 us --
+    // for a third of the launch every SIMD held ONE wave, which cannot hide its own LDS latency.  Priority by progress
+    // instead: a wave raises its priority on alternate groups of 8 rows, the SIMD's other wave (the other wave slot)
+    // on the groups in between; whoever runs ahead reaches its low-priority group sooner.  Measured: 114 / 142 us and
+    // the launch 139 -> 136 us -- the LDS queue still serves the older wave first, and a SIMD delivers about the same
+    // rows per microsecond with one wave as with two (the bound is the chain write -> reads -> FMAs, not the arbiter).
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;   // HW_REG_HW_ID.WAVE_ID bit 0
     for (int r = 0; r < nrows; r += 8) {
+        if (a.prio && (((r >> 3) ^ slot) & 1u) != 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             const int i = r + p;
@@ -1058,6 +1069,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
             ma.count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
             folded = true;
         }
+        static const int prio = [] { const char *e = getenv("FNX_SSIM_PRIO"); return e ? atoi(e) : 1; }();
+        ma.prio = prio;
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
         if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
