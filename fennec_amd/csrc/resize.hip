@@ -426,6 +426,13 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
             load_row(yw, vn);
             load_row(min(yw + 1, y1 - 1), vm);
         }
+        // NV <= 4: the wave's weight pairs ride in registers (32 VGPRs) instead of 16 LDS reads per row
+        constexpr bool WREG = NV <= 4;
+        v2f wreg[WREG ? NPX : 1];
+        if constexpr (WREG) {
+#pragma unroll
+            for (int i = 0; i < NPX; i++) wreg[i] = s_w[i * 64 + lane];
+        }
         // rows whose flags are dense (ramps, flat ties, translucent regions) are left to the exact loop below;
         // while that lasts only every 4th row still tries the fp32 form (`sticky`)
         bool sticky = false;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
 #pragma unroll
             for (int i = 0; i < NPX; i++) {
                 const uint32_t p = v[i / 4][i % 4];
-                const v2f wi = s_w[i * 64 + lane];
+                const v2f wi = WREG ? wreg[WREG ? i : 0] : s_w[i * 64 + lane];
                 accr = fma_bcast(static_cast<float>(p & 0xffu), wi, accr);
                 accg = fma_bcast(static_cast<float>((p >> 8) & 0xffu), wi, accg);
                 accb = fma_bcast(static_cast<float>((p >> 16) & 0xffu), wi, accb);
