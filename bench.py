@@ -99,6 +99,9 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the measurements made after the timed region (pipelined, exact_mode, pcie_inclusive): "
                          "profiler runs use it so that kernel statistics cover the timed configuration only")
+    ap.add_argument("--threads", type=int, default=None,
+                    help="configs 3/4: host threads driving the worker contexts (default: 2 for config3's four contexts -- python "
+                         "threads contend for the interpreter lock; every call only enqueues, so one thread feeds several streams)")
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"],
                     help="config5 at N > 1: 'static' gives rank r the items i = r mod N; 'dynamic' is ONE queue for the job "
                          "(a counter in torch.distributed's store, batch.go:72-126 across ranks)")
@@ -110,6 +113,8 @@ def main() -> int:
     args = ap.parse_args()
     if args.contexts is None:
         args.contexts = 4 if args.workload == "config3" else 1
+    if args.threads is None:
+        args.threads = 2 if args.workload == "config3" else args.contexts
     if args.workload != "config2":
         return other_workloads(args)
 
@@ -540,47 +545,74 @@ def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
     return step
 
 
-def _pooled_queue_step(fennec_amd, device, ctx0, n_items, run_ctx, nctx):
-    """step() where each of `nctx` worker contexts runs run_ctx(ctx, its item indices, out) -- item i belongs to
-    worker i mod nctx -- so that a worker can keep several items enqueued on its stream.  The workers are
-    CompressBatch's pool (batch.go:84-123): persistent threads, woken per step (starting and joining threads costs
-    ~0.1 ms per step, a tenth of a config-3 step)."""
+def _pooled_queue_step(fennec_amd, device, ctx0, n_items, submit, drain, nctx, nthreads=None):
+    """step() over n_items with `nctx` worker contexts (one fnx ctx + one HIP stream each) driven by `nthreads` host
+    threads: item i belongs to context i mod nctx, context k to thread k mod nthreads.  `submit(ctx, i, out)` enqueues
+    item i on ctx (and may fetch an older result of that ctx), `drain(ctx, out)` fetches what is left.  Every call only
+    ENQUEUES, so one host thread can keep several streams fed: the workers are CompressBatch's pool (batch.go:84-123)
+    with fewer threads than streams because python threads contend for the interpreter lock -- four threads issue these
+    calls at 92 us per image between them, two at 34 (tools/host_cost.py).  Threads are persistent, woken per step."""
     import threading
-    nctx = max(1, min(nctx, n_items))
-    ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
     import torch
+    nctx = max(1, min(nctx, n_items))
+    nthreads = max(1, min(nthreads or nctx, nctx))
+    ctxs = [ctx0] + [fennec_amd.Context(device) for _ in range(nctx - 1)]
     if nctx == 1:
         def step1():
             out = [None] * n_items
-            run_ctx(ctx0, range(n_items), out)
+            for i in range(n_items):
+                submit(ctx0, i, out)
+            drain(ctx0, out)
             return out
         return step1
     streams = [torch.cuda.Stream(device=device) for _ in ctxs]
-    go = [threading.Semaphore(0) for _ in ctxs]
+
+    def run_thread(t, out):
+        mine = [k for k in range(nctx) if k % nthreads == t]
+        if len(mine) == 1:                                # one stream for the whole step: enter it once
+            k = mine[0]
+            with torch.cuda.stream(streams[k]):
+                for i in range(k, n_items, nctx):
+                    submit(ctxs[k], i, out)
+                drain(ctxs[k], out)
+            return
+        for i in range(n_items):                          # round-robin over this thread's streams, in item order
+            k = i % nctx
+            if k % nthreads == t:
+                with torch.cuda.stream(streams[k]):
+                    submit(ctxs[k], i, out)
+        for k in mine:
+            with torch.cuda.stream(streams[k]):
+                drain(ctxs[k], out)
+
+    go = [threading.Semaphore(0) for _ in range(nthreads)]
     done = threading.Semaphore(0)
     state = {"out": None, "err": [], "stop": False}
 
-    def worker(k):
+    def worker(t):
         torch.cuda.set_device(device)
-        with torch.cuda.stream(streams[k]):               # see _pooled_step
-            while True:
-                go[k].acquire()
-                if state["stop"]:
-                    return
-                try:
-                    run_ctx(ctxs[k], range(k, n_items, nctx), state["out"])
-                except Exception as e:
-                    state["err"].append(e)
-                done.release()
-    ts = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(nctx)]
+        while True:
+            go[t].acquire()
+            if state["stop"]:
+                return
+            try:
+                run_thread(t, state["out"])
+            except Exception as e:
+                state["err"].append(e)
+            done.release()
+    ts = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(1, nthreads)]
     for t in ts:
         t.start()
 
     def step():
         state["out"] = [None] * n_items
-        for g in go:
+        for g in go[1:]:
             g.release()
-        for _ in ctxs:
+        try:
+            run_thread(0, state["out"])                   # the calling thread is worker 0
+        except Exception as e:
+            state["err"].append(e)
+        for _ in ts:
             done.acquire()
         if state["err"]:
             raise state["err"][0]
@@ -588,7 +620,7 @@ def _pooled_queue_step(fennec_amd, device, ctx0, n_items, run_ctx, nctx):
 
     def close():
         state["stop"] = True
-        for g in go:
+        for g in go[1:]:
             g.release()
         for t in ts:
             t.join()
@@ -620,29 +652,31 @@ def other_workloads(args) -> int:
         kms = {"resize_h_down": [], "resize_v_down": [], "resize_h_up": [], "resize_v_up": []}
 
         QD3 = 3                                          # images in flight per context (the ctx's result FIFO holds 4)
+        pend3 = {}
 
-        def run_ctx3(c, mine, out):
-            """One worker: lanczosResize (async) + MSSSIM through the result FIFO, results fetched QD3 images behind --
-            the stream never drains between images."""
-            pend = []
+        def fetch3(c, out):
+            j, _ = pend3[id(c)].pop(0)
+            out[j] = c.fetch_result()
+            if c is ctx and prof_on[0]:                  # the library's event pairs: H, V of the downscale, H, V of the implicit upscale
+                for k in kms:
+                    kms[k].append(c.kernel_ms())
 
-            def fetch():
-                j, _ = pend.pop(0)
-                out[j] = c.fetch_result()
-                if c is ctx and prof_on[0]:              # the library's event pairs: H, V of the downscale, H, V of the implicit upscale
-                    for k in kms:
-                        kms[k].append(c.kernel_ms())
-            for i in mine:
-                small = c.lanczosResize(imgs[i], W // 2, H // 2)
-                c.msssim_enqueue(imgs[i], small)         # ssim.go:320-322 resizes `small` back to 4K
-                pend.append((i, small))
-                if len(pend) > QD3:
-                    fetch()
-            while pend:
-                fetch()
+        def submit3(c, i, out):
+            """lanczosResize (async) + MSSSIM through the result FIFO, results fetched QD3 images behind -- the
+            stream never drains between images."""
+            pend = pend3.setdefault(id(c), [])
+            small = c.lanczosResize(imgs[i], W // 2, H // 2)
+            c.msssim_enqueue(imgs[i], small)             # ssim.go:320-322 resizes `small` back to 4K
+            pend.append((i, small))
+            if len(pend) > QD3:
+                fetch3(c, out)
+
+        def drain3(c, out):
+            while pend3.get(id(c)):
+                fetch3(c, out)
 
         prof_on = [False]
-        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), run_ctx3, args.contexts)
+        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), submit3, drain3, args.contexts, args.threads)
         prof_mask = fennec_amd.PROF_RESIZE
         metric, unit, units_per_step = "megapixels/sec: 4K -> 1920x1080 Lanczos-3 downscale + MS-SSIM", "MP/s", B * W * H / 1e6
         name = "config3: 4K lanczosResize(1920x1080) + MSSSIM(4K, 1080p)"
@@ -656,24 +690,28 @@ def other_workloads(args) -> int:
         prof_mask = fennec_amd.PROF_SSIM
         QD = 3                                           # images in flight per context (the ctx's result FIFO holds 4)
 
-        def run_ctx(c, mine, out):
-            """One worker: AdaptiveSharpen (async) + fnx_ssim_enqueue per image, results fetched QD images behind."""
-            pend = []
-            for i in mine:
-                sharp = c.AdaptiveSharpen(imgs[i], 0.5)
-                c.ssim_enqueue(imgs[i], sharp)
-                pend.append((i, sharp))
-                if len(pend) > QD:
-                    j, _ = pend.pop(0)
-                    out[j] = c.fetch_result()
-                    if c is ctx and prof_on[0]:
-                        kms["windowed_ssim"].append(c.kernel_ms())
-            for j, _ in pend:
-                out[j] = c.fetch_result()
-                if c is ctx and prof_on[0]:
-                    kms["windowed_ssim"].append(c.kernel_ms())
+        pend4 = {}
 
-        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), run_ctx, args.contexts)
+        def fetch4(c, out):
+            j, _ = pend4[id(c)].pop(0)
+            out[j] = c.fetch_result()
+            if c is ctx and prof_on[0]:
+                kms["windowed_ssim"].append(c.kernel_ms())
+
+        def submit4(c, i, out):
+            """AdaptiveSharpen (async) + fnx_ssim_enqueue per image, results fetched QD images behind."""
+            pend = pend4.setdefault(id(c), [])
+            sharp = c.AdaptiveSharpen(imgs[i], 0.5)
+            c.ssim_enqueue(imgs[i], sharp)
+            pend.append((i, sharp))
+            if len(pend) > QD:
+                fetch4(c, out)
+
+        def drain4(c, out):
+            while pend4.get(id(c)):
+                fetch4(c, out)
+
+        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), submit4, drain4, args.contexts, args.threads)
         metric, unit, units_per_step = "megapixels/sec: 8K AdaptiveSharpen + SSIM", "MP/s", B * W * H / 1e6
         name = "config4: 8K AdaptiveSharpen(0.5) + full-resolution SSIM"
     elif wl == "analyze":     # SURVEY 8(f).3: Analyze (analyze.go:26-124), BenchmarkAnalyze's op at 4K
@@ -813,6 +851,7 @@ def other_workloads(args) -> int:
     }
     if wl in ("config3", "config4"):
         out["config"]["contexts_per_gpu"] = max(1, min(args.contexts, B))
+        out["config"]["host_threads_per_gpu"] = max(1, min(args.threads or args.contexts, args.contexts, B))
         out["roofline_step"] = out["roofline"]
         S_img = 4.0 * W * H
         if wl == "config4":

@@ -15,9 +15,15 @@ for nthr in (1, 2, 4):
     def run(k):
         with torch.cuda.stream(streams[k]):
             c = ctxs[k]
+            pend = 0
             for _ in range(N):
                 small = c.lanczosResize(img, W // 2, H // 2)
-                c.MSSSIM(img, small)
+                c.msssim_enqueue(img, small)
+                pend += 1
+                if pend > 3:
+                    c.fetch_result(); pend -= 1
+            while pend:
+                c.fetch_result(); pend -= 1
     run(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
