@@ -1010,9 +1010,11 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     const int TX = sep ? WSS_TX : WS_TX, TY = sep ? (big ? W24_TY : WSS_TY) : WS_TY;
     int tiles_x = 0, tiles = 0;
     MarchArgs ma{};
-    // the two-column form (2 waves per SIMD) once there is a round of such waves to fill the chip with
+    // the two-column form (2 waves per SIMD) once ONE image has a round of such waves to fill the chip with
     static const long march2_min = [] { const char *e = getenv("FNX_SSIM_MARCH2_MIN"); return e ? atol(e) : 4000000L; }();
-    const bool march2 = march && static_cast<long>(ww) * wh * n >= march2_min;
+    // (per image: a batch of small planes -- the one-pass tail under the next blur -- keeps the one-column form, whose
+    // 104-VGPR waves fit into the gaps the blur's workgroups leave; 202-VGPR waves wait for two of them to retire)
+    const bool march2 = march && static_cast<long>(ww) * wh >= march2_min;
     if (march) {
         // wave-sized work items: strips of 57 (two-column form: 121) window columns x row segments.  Segments are cut
         // so that the launch holds about one resident round of waves (16 per CU; 8) but never shorter than 32 window
