@@ -1159,3 +1159,30 @@ def test_lanczos_resize_mixed_content_sequence(ctx, orc):
             want[key] = orc.lanczos_resize(img, dw, dh, procs=8)
         got = ctx.lanczosResize(torch.from_numpy(img).cuda(), dw, dh).cpu().numpy()
         assert np.array_equal(got, want[key]), k
+
+
+@pytest.mark.gpu
+def test_ssim_two_column_march_against_oracle(ctx, orc):
+    """windowed_ssim_march2_kernel (images of >= 4 M windows: two pixel columns per lane, strips of 121 window columns)
+    against the oracle directly: widths on both sides of strip multiples, an odd width (the last lane's pair re-reads
+    the last two columns), a 4-byte-aligned strided device view, a full 4K pair, and the same pair through the FIFO."""
+    import torch
+    rng_sizes = [(2309, 1801), (2428, 1713), (2429, 1712), (8200, 520), (3840, 2160)]
+    for (w, h) in rng_sizes:
+        assert (w - 8) * (h - 8) >= 4_000_000
+        a = synth.large_photo(w, h, w % 7)
+        b = ctx.AdaptiveSharpen(a, 0.5)
+        want = orc.ssim(a, b, procs=64)
+        assert abs(ctx.SSIM(a, b) - want) <= SSIM_TOL, (w, h)
+        da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        assert ctx.SSIM(da, db) == ctx.SSIM(a, b)
+        ctx.ssim_enqueue(da, db)
+        assert ctx.fetch_result() == ctx.SSIM(a, b)
+    # a view whose rows start 4 bytes off a 16-byte boundary, with padding behind every row
+    w, h = 2400, 1740
+    a = synth.noise_image(w + 4, h, 3)
+    b = orc.gaussian_blur(a, 0.8, procs=16)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    va, vb = da[:, 1:w + 1], db[:, 1:w + 1]
+    want = orc.ssim(np.ascontiguousarray(a[:, 1:w + 1]), np.ascontiguousarray(b[:, 1:w + 1]), procs=64)
+    assert abs(ctx.SSIM(va, vb) - want) <= SSIM_TOL
