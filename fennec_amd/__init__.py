@@ -139,6 +139,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fnx_msssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fennec_MSSSIM_enqueue", i, [ctx] + img + [i, i] + img + [i, i])
+        _sig(L, "fnx_jpeg_encode", i, [ctx, i] + img + [i, i, i, _u8p, C.c_size_t, C.POINTER(C.c_size_t)])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
@@ -469,6 +470,23 @@ class Context:
             self._chk(self._lib.fnx_jpeg_roundtrip(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(quality), d.ptr, d.stride),
                       "fnx_jpeg_roundtrip")
         return dst
+
+    def jpeg_encode(self, img, quality: int) -> bytes:
+        """jpeg.Encode(img, &jpeg.Options{Quality: quality}) on the device (fnx_jpeg_encode) -> the file's bytes."""
+        s = _Img(img)
+        cap = 4096 + (s.w * s.h * 3) // 2
+        n = C.c_size_t(0)
+        with self._ordered(img):
+            for _ in range(2):
+                buf = np.empty(cap, dtype=np.uint8)
+                rc = self._lib.fnx_jpeg_encode(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(quality), buf.ctypes.data_as(_u8p),
+                                               cap, C.byref(n))
+                if rc == FNX_OK:
+                    return buf[:n.value].tobytes()
+                if n.value <= cap:
+                    self._chk(rc, "fnx_jpeg_encode")
+                cap = n.value
+        self._chk(rc, "fnx_jpeg_encode")
 
     def jpeg_quality_search(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal's binary search with every candidate round-tripped and scored on the device

@@ -1007,6 +1007,48 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
     return found ? FNX_OK : FNX_NOOP;      // FNX_NOOP: no quality reached the target (compress.go:82-86: encode at 100)
 }
 
+int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
+                    size_t *nbytes)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(nbytes != nullptr && w > 0 && h > 0 && w <= 65535 && h <= 65535, "encode arguments (JPEG dims are 16-bit)");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    *nbytes = 0;
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    // two u64 the kernels write and the host reads: bits of the scan's string, 0xff bytes in it
+    double *slot;
+    FNX_TRY(result_slot(ctx, 2, &slot));
+    unsigned long long *totals = reinterpret_cast<unsigned long long *>(slot);
+    totals[0] = totals[1] = ~0ull;
+    const uint8_t *planes[3] = {orig.p[0], orig.p[1], orig.p[2]};
+    FNX_TRY(jpeg_entropy_code(ctx, w, h, quality, planes, totals));
+    FNX_HIP(hipStreamSynchronize(ctx->stream));
+    const unsigned long long tbits = totals[0];
+    void *ecs = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG_ECS, jpeg_ecs_capacity(tbits), &ecs));
+    FNX_TRY(jpeg_entropy_pack(ctx, w, h, tbits, static_cast<uint8_t *>(ecs), totals));
+    FNX_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t ecs_bytes = static_cast<size_t>((tbits + 7) / 8) + static_cast<size_t>(tbits ? totals[1] : 0);
+    std::vector<uint8_t> hdr;
+    jpeg_header(w, h, quality, hdr);
+    const size_t total = hdr.size() + ecs_bytes + 2;
+    *nbytes = total;
+    if (out == nullptr || cap < total) {
+        set_error("invalid argument: the file needs %zu bytes, the buffer holds %zu", total, cap);
+        return FNX_ERR_INVALID;
+    }
+    std::memcpy(out, hdr.data(), hdr.size());
+    if (ecs_bytes) FNX_HIP(hipMemcpy(out + hdr.size(), ecs, ecs_bytes, hipMemcpyDeviceToHost));
+    out[total - 2] = 0xff;
+    out[total - 1] = 0xd9;          // EOI
+    return FNX_OK;
+}
+
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
 {
     if (!p) return;

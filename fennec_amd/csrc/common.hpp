@@ -66,6 +66,7 @@ enum Slot {
     SLOT_JPEG1,
     SLOT_JPEG2,
     SLOT_JPEG3,
+    SLOT_JPEG_ENC, SLOT_JPEG_ENC2, SLOT_JPEG_LUT, SLOT_JPEG_ECS,   // jpeg.hip's entropy coder
     SLOT_DONE,       // workgroup counters of the kernels that finish their own reduction (ssim.hip), zero between launches
     SLOT_COUNT
 };
@@ -289,6 +290,10 @@ int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, i
 // conversion + chroma averaging, and fdct / quantise / dequantise / idct of every block at `quality` (in -> out)
 void jpeg_plane_dims(int w, int h, int *ys, int *yh, int *cs, int *ch);
 int launch_jpeg_ycc(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *yp, uint8_t *cbp, uint8_t *crp);
+void jpeg_header(int w, int h, int quality, std::vector<uint8_t> &out);
+int jpeg_entropy_code(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const planes[3], unsigned long long *totals);
+size_t jpeg_ecs_capacity(unsigned long long total_bits);
+int jpeg_entropy_pack(fnx_ctx *ctx, int w, int h, unsigned long long total_bits, uint8_t *ecs, unsigned long long *totals);
 int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const in[3], uint8_t *const out[3]);
 
 }  // namespace fnx

@@ -195,6 +195,13 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
  * device: *quality = lowest quality whose SSIMFast(src, round trip) >= target_ssim (the reference's lower bounds by
  * target, target >= 1 -> 0.999), *ssim its score, *steps the candidates tried.  FNX_NOOP: none reached the target
  * (*quality = 100, *ssim = 1.0, as the reference's fallback).  The caller encodes ONCE, at *quality, with the real codec. */
+/* jpeg.Encode(src, &jpeg.Options{Quality: quality}) (io.go:157-169) on the device: the complete file -- baseline, 4:2:0,
+ * the typical Huffman tables, writer.go's segment order -- into host memory `out` (capacity cap); *nbytes = its size.
+ * FNX_ERR_INVALID with *nbytes set when cap is too small (call again).  Decoding the file gives exactly
+ * fnx_jpeg_roundtrip's pixels (the entropy coder is lossless).  Restated from ITU T.81 and Go's file layout, not from
+ * Go's source: byte parity with jpeg.Encode is unpinned; libjpeg-turbo decodes the files. */
+int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
+                    size_t *nbytes);
 int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
                             const double *window /* 64 */, int *quality, double *ssim, int *steps);
 

@@ -1539,6 +1539,42 @@ ORC_API void orc_jpeg_block_roundtrip(int32_t *b, const uint8_t *q)
     for (int i = 0; i < 64; i++) b[i] = b[i] < -128 ? 0 : (b[i] > 127 ? 255 : b[i] + 128);
 }
 
+/* The six 8x8 sample blocks of MCU (mx0, my0) as writer.go forms them: four Y blocks (block i at xOff = (i&1)*8,
+ * yOff = (i&2)*4), then Cb and Cr scaled 16x16 -> 8x8. */
+static void jpeg_mcu_samples(const uint8_t *src, int sstride, int w, int h, int mx0, int my0, int32_t yb[4][64], int32_t *cbb,
+                             int32_t *crb)
+{
+    int32_t cbf[4][64], crf[4][64];
+    for (int i = 0; i < 4; i++) {                                      /* writer.go: xOff = (i&1)*8, yOff = (i&2)*4 */
+        const int px = 16 * mx0 + (i & 1) * 8, py = 16 * my0 + (i & 2) * 4;
+        for (int j = 0; j < 8; j++)
+            for (int k = 0; k < 8; k++) {
+                const int sx = px + k > w - 1 ? w - 1 : px + k, sy = py + j > h - 1 ? h - 1 : py + j;   /* toYCbCr clamps */
+                const uint8_t *p = src + (size_t)sy * sstride + (size_t)sx * 4;
+                uint8_t yy, cb, cr;
+                /* io.go:157-169: an opaque image is handed over as *image.RGBA (rgbaToYCbCr reads the bytes); any
+                 * other goes through toYCbCr's m.At(x, y).RGBA(): color.NRGBA.RGBA() premultiplies in 16 bits
+                 * (r = R * 0x101 * A / 0xff) and the encoder keeps the high byte.  For A == 255 that IS R, so the
+                 * per-pixel form below covers both. */
+                const uint32_t a8 = p[3];
+                const uint8_t r8 = (uint8_t)(((uint32_t)p[0] * 0x101u * a8 / 0xffu) >> 8);
+                const uint8_t g8 = (uint8_t)(((uint32_t)p[1] * 0x101u * a8 / 0xffu) >> 8);
+                const uint8_t b8 = (uint8_t)(((uint32_t)p[2] * 0x101u * a8 / 0xffu) >> 8);
+                orc_rgb_to_ycbcr(r8, g8, b8, &yy, &cb, &cr);
+                yb[i][8 * j + k] = yy; cbf[i][8 * j + k] = cb; crf[i][8 * j + k] = cr;
+            }
+    }
+    for (int i = 0; i < 4; i++) {                                      /* writer.go scale(): 16x16 -> 8x8, (sum + 2) >> 2 */
+        const int dstOff = ((i & 2) << 4) | ((i & 1) << 2);
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) {
+                const int j = 16 * y + 2 * x;
+                cbb[8 * y + x + dstOff] = (cbf[i][j] + cbf[i][j + 1] + cbf[i][j + 8] + cbf[i][j + 9] + 2) >> 2;
+                crb[8 * y + x + dstOff] = (crf[i][j] + crf[i][j + 1] + crf[i][j + 8] + crf[i][j + 9] + 2) >> 2;
+            }
+    }
+}
+
 /* The planes an *image.YCbCr holds after jpeg.Decode(jpeg.Encode(img, quality)) for an opaque NRGBA image: Y is
  * 16*mx wide and 16*my high (mx, my = MCUs), Cb / Cr 8*mx x 8*my (4:2:0); the decoder's image is the w x h sub-image.
  * yp: (16 mx) * (16 my) bytes, cb, cr: (8 mx) * (8 my). */
@@ -1550,35 +1586,8 @@ ORC_API void orc_jpeg_roundtrip_planes(const uint8_t *src, int sstride, int w, i
     const int mx = (w + 15) / 16, my = (h + 15) / 16, ys = 16 * mx, cs = 8 * mx;
     for (int my0 = 0; my0 < my; my0++)
         for (int mx0 = 0; mx0 < mx; mx0++) {
-            int32_t yb[4][64], cbf[4][64], crf[4][64], cbb[64], crb[64];
-            for (int i = 0; i < 4; i++) {                              /* writer.go: xOff = (i&1)*8, yOff = (i&2)*4 */
-                const int px = 16 * mx0 + (i & 1) * 8, py = 16 * my0 + (i & 2) * 4;
-                for (int j = 0; j < 8; j++)
-                    for (int k = 0; k < 8; k++) {
-                        const int sx = px + k > w - 1 ? w - 1 : px + k, sy = py + j > h - 1 ? h - 1 : py + j;   /* toYCbCr clamps */
-                        const uint8_t *p = src + (size_t)sy * sstride + (size_t)sx * 4;
-                        uint8_t yy, cb, cr;
-                        /* io.go:157-169: an opaque image is handed over as *image.RGBA (rgbaToYCbCr reads the bytes); any
-                         * other goes through toYCbCr's m.At(x, y).RGBA(): color.NRGBA.RGBA() premultiplies in 16 bits
-                         * (r = R * 0x101 * A / 0xff) and the encoder keeps the high byte.  For A == 255 that IS R, so the
-                         * per-pixel form below covers both. */
-                        const uint32_t a8 = p[3];
-                        const uint8_t r8 = (uint8_t)(((uint32_t)p[0] * 0x101u * a8 / 0xffu) >> 8);
-                        const uint8_t g8 = (uint8_t)(((uint32_t)p[1] * 0x101u * a8 / 0xffu) >> 8);
-                        const uint8_t b8 = (uint8_t)(((uint32_t)p[2] * 0x101u * a8 / 0xffu) >> 8);
-                        orc_rgb_to_ycbcr(r8, g8, b8, &yy, &cb, &cr);
-                        yb[i][8 * j + k] = yy; cbf[i][8 * j + k] = cb; crf[i][8 * j + k] = cr;
-                    }
-            }
-            for (int i = 0; i < 4; i++) {                              /* writer.go scale(): 16x16 -> 8x8, (sum + 2) >> 2 */
-                const int dstOff = ((i & 2) << 4) | ((i & 1) << 2);
-                for (int y = 0; y < 4; y++)
-                    for (int x = 0; x < 4; x++) {
-                        const int j = 16 * y + 2 * x;
-                        cbb[8 * y + x + dstOff] = (cbf[i][j] + cbf[i][j + 1] + cbf[i][j + 8] + cbf[i][j + 9] + 2) >> 2;
-                        crb[8 * y + x + dstOff] = (crf[i][j] + crf[i][j + 1] + crf[i][j + 8] + crf[i][j + 9] + 2) >> 2;
-                    }
-            }
+            int32_t yb[4][64], cbb[64], crb[64];
+            jpeg_mcu_samples(src, sstride, w, h, mx0, my0, yb, cbb, crb);
             for (int i = 0; i < 4; i++) {
                 orc_jpeg_block_roundtrip(yb[i], ql);
                 const int px = 16 * mx0 + (i & 1) * 8, py = 16 * my0 + (i & 2) * 4;
@@ -1595,7 +1604,6 @@ ORC_API void orc_jpeg_roundtrip_planes(const uint8_t *src, int sstride, int w, i
         }
 }
 
-/* toNRGBARef(jpeg.Decode(jpeg.Encode(src, quality))) (compress.go:50-58): the image SSIMFast scores */
 ORC_API int orc_jpeg_roundtrip(const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *dst, int dstride)
 {
     if (w <= 0 || h <= 0) return 0;
@@ -1607,4 +1615,411 @@ ORC_API int orc_jpeg_roundtrip(const uint8_t *src, int sstride, int w, int h, in
     orc_ycbcr_to_nrgba(yp, 16 * mx, cb, cr, 8 * mx, 2, w, h, dst, dstride);      /* ratio 2 = YCbCrSubsampleRatio420 */
     free(yp); free(cb); free(cr);
     return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* Baseline JPEG entropy coding: jpeg.Encode's file, byte for byte as   */
+/* far as it can be restated (io.go:157-169), and a decoder for it      */
+/* ------------------------------------------------------------------ */
+/*
+ * writer.go's encoder is baseline sequential, 8-bit, three components 4:2:0, one scan, no restart markers, the
+ * typical Huffman tables of Annex K.3.3 (theHuffmanSpec), no JFIF APP0 segment: SOI, one DQT segment with both
+ * tables (zig-zag order), SOF0, one DHT segment with the four tables in the order luminance DC, luminance AC,
+ * chrominance DC, chrominance AC, SOS, entropy-coded data with 0xff stuffed, the last byte padded with 1 bits, EOI.
+ * Per block (writeBlock): FDCT, dc = div(b[0], 8 q[0]) coded as the difference to the component's previous dc;
+ * ac = div(b[unzig[zig]], 8 q[zig]) in zig-zag order with (run, size) symbols, 0xf0 for 16 zeros, 0x00 at the end of
+ * a block that ends in zeros.  Restated from the standard (ITU T.81) and from how Go lays the file out, NOT from Go's
+ * source: parity unpinned twice over, like the round trip above.  What is checked: libjpeg-turbo (Pillow) decodes the
+ * files; its own non-optimised files carry exactly these Huffman tables; the decoder below, reading the encoder's
+ * file, returns exactly orc_jpeg_roundtrip_planes (the entropy coder is lossless and the file is self-consistent); and
+ * the decoder reads libjpeg's baseline files to pixels a few levels from libjpeg's own decode (its IDCT and
+ * chroma upsampling differ by design).
+ */
+static const uint8_t jpeg_unzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                       30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+typedef struct {
+    uint8_t count[16];
+    const uint8_t *value;
+    int nvalue;
+} jpeg_huff_spec;
+
+static const uint8_t jpeg_dc_values[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t jpeg_ac_lum_values[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81,
+    0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18,
+    0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+    0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99,
+    0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5,
+    0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t jpeg_ac_chr_values[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08,
+    0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25,
+    0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47,
+    0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74,
+    0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97,
+    0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4,
+    0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+/* index = the file's (class << 1 | table id) order of writer.go: 0 luminance DC, 1 luminance AC, 2 chrominance DC, 3 chrominance AC */
+static const jpeg_huff_spec jpeg_specs[4] = {
+    {{0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, jpeg_dc_values, 12},
+    {{0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125}, jpeg_ac_lum_values, 162},
+    {{0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0}, jpeg_dc_values, 12},
+    {{0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119}, jpeg_ac_chr_values, 162}};
+
+/* canonical codes: lut[value] = length << 24 | code */
+static void jpeg_build_lut(const jpeg_huff_spec *sp, uint32_t *lut)
+{
+    for (int i = 0; i < 256; i++) lut[i] = 0;
+    uint32_t code = 0;
+    int k = 0;
+    for (int len = 1; len <= 16; len++) {
+        for (int j = 0; j < sp->count[len - 1]; j++) {
+            lut[sp->value[k]] = ((uint32_t)len << 24) | code;
+            code++;
+            k++;
+        }
+        code <<= 1;
+    }
+}
+
+/* the standard tables as (length << 24 | code) per symbol: [4][256] */
+ORC_API void orc_jpeg_huffman_luts(uint32_t *luts)
+{
+    for (int t = 0; t < 4; t++) jpeg_build_lut(&jpeg_specs[t], luts + 256 * t);
+}
+
+typedef struct {
+    uint8_t *out;
+    size_t cap, n;
+    uint32_t bits, nbits;
+    int overflow;
+} jpeg_bitw;
+
+static void jw_byte(jpeg_bitw *w, uint8_t b)
+{
+    if (w->n < w->cap) w->out[w->n] = b;
+    else w->overflow = 1;
+    w->n++;
+}
+
+/* writer.go emit: MSB first, a stuffed 0x00 after every 0xff */
+static void jw_emit(jpeg_bitw *w, uint32_t bits, uint32_t nbits)
+{
+    nbits += w->nbits;
+    bits <<= 32 - nbits;
+    bits |= w->bits;
+    while (nbits >= 8) {
+        const uint8_t b = (uint8_t)(bits >> 24);
+        jw_byte(w, b);
+        if (b == 0xff) jw_byte(w, 0x00);
+        bits <<= 8;
+        nbits -= 8;
+    }
+    w->bits = bits;
+    w->nbits = nbits;
+}
+
+static void jw_huff(jpeg_bitw *w, const uint32_t *lut, int value)
+{
+    const uint32_t x = lut[value];
+    jw_emit(w, x & 0x00ffffffu, x >> 24);
+}
+
+static int jpeg_bitcount(uint32_t a)          /* bits needed for a (0 -> 0) */
+{
+    int n = 0;
+    while (a) { n++; a >>= 1; }
+    return n;
+}
+
+/* emitHuffRLE: the (run, size) symbol, then `size` bits of the value (negative values as value - 1, low bits) */
+static void jw_huff_rle(jpeg_bitw *w, const uint32_t *lut, int run, int32_t value)
+{
+    int32_t a = value, b = value;
+    if (a < 0) { a = -value; b = value - 1; }
+    const int nbits = jpeg_bitcount((uint32_t)a);
+    jw_huff(w, lut, (run << 4) | nbits);
+    if (nbits > 0) jw_emit(w, (uint32_t)b & ((1u << nbits) - 1u), (uint32_t)nbits);
+}
+
+/* writeBlock: samples (level-unshifted 0..255) -> the block's code; returns its quantised dc.  zz (optional, 64):
+ * the quantised coefficients in zig-zag order. */
+static int32_t jpeg_write_block(jpeg_bitw *w, int32_t *b, const uint8_t *q, const uint32_t *dc_lut, const uint32_t *ac_lut,
+                                int32_t prev_dc, int16_t *zz)
+{
+    orc_jpeg_fdct(b);
+    const int32_t dc = jpeg_div(b[0], 8 * (int32_t)q[0]);
+    if (zz) zz[0] = (int16_t)dc;
+    jw_huff_rle(w, dc_lut, 0, dc - prev_dc);
+    int run = 0;
+    for (int zig = 1; zig < 64; zig++) {
+        const int nat = jpeg_unzig[zig];
+        const int32_t ac = jpeg_div(b[nat], 8 * (int32_t)q[nat]);
+        if (zz) zz[zig] = (int16_t)ac;
+        if (ac == 0) {
+            run++;
+        } else {
+            while (run > 15) {
+                jw_huff(w, ac_lut, 0xf0);
+                run -= 16;
+            }
+            jw_huff_rle(w, ac_lut, run, ac);
+            run = 0;
+        }
+    }
+    if (run > 0) jw_huff(w, ac_lut, 0x00);
+    return dc;
+}
+
+static void jw_marker(jpeg_bitw *w, uint8_t m, int len)
+{
+    jw_byte(w, 0xff); jw_byte(w, m);
+    jw_byte(w, (uint8_t)(len >> 8)); jw_byte(w, (uint8_t)(len & 0xff));
+}
+
+/* The header bytes jpeg.Encode writes before the entropy-coded data (SOI .. SOS header); returns their count. */
+static void jpeg_write_headers(jpeg_bitw *w, int wd, int ht, const uint8_t *ql, const uint8_t *qc)
+{
+    jw_byte(w, 0xff); jw_byte(w, 0xd8);                                           /* SOI */
+    jw_marker(w, 0xdb, 2 + 2 * (1 + 64));                                         /* DQT: both tables, zig-zag order */
+    for (int t = 0; t < 2; t++) {
+        jw_byte(w, (uint8_t)t);
+        for (int zig = 0; zig < 64; zig++) jw_byte(w, (t ? qc : ql)[jpeg_unzig[zig]]);
+    }
+    jw_marker(w, 0xc0, 8 + 3 * 3);                                                /* SOF0 */
+    jw_byte(w, 8);
+    jw_byte(w, (uint8_t)(ht >> 8)); jw_byte(w, (uint8_t)(ht & 0xff));
+    jw_byte(w, (uint8_t)(wd >> 8)); jw_byte(w, (uint8_t)(wd & 0xff));
+    jw_byte(w, 3);
+    jw_byte(w, 1); jw_byte(w, 0x22); jw_byte(w, 0);                               /* Y: 2x2, table 0 */
+    jw_byte(w, 2); jw_byte(w, 0x11); jw_byte(w, 1);                               /* Cb */
+    jw_byte(w, 3); jw_byte(w, 0x11); jw_byte(w, 1);                               /* Cr */
+    int dht = 2;
+    for (int t = 0; t < 4; t++) dht += 1 + 16 + jpeg_specs[t].nvalue;
+    jw_marker(w, 0xc4, dht);                                                      /* DHT: the four tables in one segment */
+    static const uint8_t tc_th[4] = {0x00, 0x10, 0x01, 0x11};
+    for (int t = 0; t < 4; t++) {
+        jw_byte(w, tc_th[t]);
+        for (int i = 0; i < 16; i++) jw_byte(w, jpeg_specs[t].count[i]);
+        for (int i = 0; i < jpeg_specs[t].nvalue; i++) jw_byte(w, jpeg_specs[t].value[i]);
+    }
+    static const uint8_t sos[14] = {0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00};
+    for (int i = 0; i < 14; i++) jw_byte(w, sos[i]);
+}
+
+ORC_API int orc_jpeg_header_bytes(int wd, int ht, int quality, uint8_t *out, int cap)
+{
+    uint8_t ql[64], qc[64];
+    orc_jpeg_quant_tables(quality, ql, qc);
+    jpeg_bitw w = {out, (size_t)cap, 0, 0, 0, 0};
+    jpeg_write_headers(&w, wd, ht, ql, qc);
+    return w.overflow ? -(int)w.n : (int)w.n;
+}
+
+/* jpeg.Encode(img, &jpeg.Options{Quality: quality}) for an NRGBA image (io.go:157-169).  Returns the file's size;
+ * a negative size: `cap` was too small (the needed size, negated).  coef (optional): every block's quantised
+ * coefficients in zig-zag order, blocks in scan order (MCU-major: Y0 Y1 Y2 Y3 Cb Cr), 64 int16 each. */
+ORC_API long orc_jpeg_encode(const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, long cap, int16_t *coef)
+{
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return 0;
+    uint8_t ql[64], qc[64];
+    orc_jpeg_quant_tables(quality, ql, qc);
+    uint32_t luts[4][256];
+    for (int t = 0; t < 4; t++) jpeg_build_lut(&jpeg_specs[t], luts[t]);
+    jpeg_bitw bw = {out, (size_t)(cap > 0 ? cap : 0), 0, 0, 0, 0};
+    jpeg_write_headers(&bw, w, h, ql, qc);
+    const int mx = (w + 15) / 16, my = (h + 15) / 16;
+    int32_t pdy = 0, pdcb = 0, pdcr = 0;
+    size_t blk = 0;
+    for (int my0 = 0; my0 < my; my0++)
+        for (int mx0 = 0; mx0 < mx; mx0++) {
+            int32_t yb[4][64], cbb[64], crb[64];
+            jpeg_mcu_samples(src, sstride, w, h, mx0, my0, yb, cbb, crb);
+            for (int i = 0; i < 4; i++, blk++) pdy = jpeg_write_block(&bw, yb[i], ql, luts[0], luts[1], pdy, coef ? coef + 64 * blk : NULL);
+            pdcb = jpeg_write_block(&bw, cbb, qc, luts[2], luts[3], pdcb, coef ? coef + 64 * blk : NULL); blk++;
+            pdcr = jpeg_write_block(&bw, crb, qc, luts[2], luts[3], pdcr, coef ? coef + 64 * blk : NULL); blk++;
+        }
+    jw_emit(&bw, 0x7f, 7);                                                        /* pad the last byte with 1s */
+    jw_byte(&bw, 0xff); jw_byte(&bw, 0xd9);                                       /* EOI */
+    return bw.overflow ? -(long)bw.n : (long)bw.n;
+}
+
+/* ---- a baseline decoder: 8-bit, three components, 4:2:0 or 4:4:4, one scan, no restart intervals (what jpeg.Encode
+ * and libjpeg's defaults write).  Entropy decoding is the standard's (F.2.2); the pixels are made the way reader.go /
+ * idct.go make them: coefficient * q, the Chen-Wang IDCT, + 128, clamp. */
+typedef struct {
+    const uint8_t *p;
+    size_t n, pos;
+    uint32_t bits;
+    int nbits, bad;
+} jpeg_bitr;
+
+static int jr_bit(jpeg_bitr *r)
+{
+    if (r->nbits == 0) {
+        if (r->pos >= r->n) { r->bad = 1; return 0; }
+        uint8_t b = r->p[r->pos++];
+        if (b == 0xff) {
+            if (r->pos < r->n && r->p[r->pos] == 0x00) r->pos++;
+            else { r->bad = 1; return 0; }                                        /* a marker inside the scan */
+        }
+        r->bits = b;
+        r->nbits = 8;
+    }
+    r->nbits--;
+    return (int)((r->bits >> r->nbits) & 1u);
+}
+
+typedef struct {
+    int mincode[17], maxcode[17], valptr[17];
+    uint8_t value[256];
+} jpeg_dtab;
+
+static int jr_symbol(jpeg_bitr *r, const jpeg_dtab *t)
+{
+    int code = 0;
+    for (int len = 1; len <= 16; len++) {
+        code = (code << 1) | jr_bit(r);
+        if (r->bad) return 0;
+        if (t->maxcode[len] >= 0 && code <= t->maxcode[len] && code >= t->mincode[len]) return t->value[t->valptr[len] + code - t->mincode[len]];
+    }
+    r->bad = 1;
+    return 0;
+}
+
+static int32_t jr_receive_extend(jpeg_bitr *r, int s)
+{
+    if (s == 0) return 0;
+    int32_t v = 0;
+    for (int i = 0; i < s; i++) v = (v << 1) | jr_bit(r);
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+/* Decodes `data` into MCU-padded planes (yp: ys x 8*vmax*my rows ...).  Returns 1, with *wd, *ht, *ratio
+ * (2: 4:2:0, 0: 4:4:4) set, or a negative error.  Call with yp == NULL to learn the dims first. */
+ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
+                                   int16_t *coef)
+{
+    if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return -1;
+    uint8_t q[4][64];
+    jpeg_dtab dt[2][4];
+    int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    int W = 0, H = 0, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
+    long pos = 2;
+    for (;;) {
+        if (pos + 4 > n || data[pos] != 0xff) return -2;
+        const uint8_t m = data[pos + 1];
+        if (m == 0xff) { pos++; continue; }
+        const int len = (data[pos + 2] << 8) | data[pos + 3];
+        if (pos + 2 + len > n) return -2;
+        const uint8_t *seg = data + pos + 4;
+        const int sl = len - 2;
+        if (m == 0xdb) {                                                          /* DQT */
+            int o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (pq != 0 || tq > 3 || o + 65 > sl) return -3;
+                for (int zig = 0; zig < 64; zig++) q[tq][jpeg_unzig[zig]] = seg[o + 1 + zig];
+                have_q[tq] = 1;
+                o += 65;
+            }
+        } else if (m == 0xc0) {                                                   /* SOF0 */
+            if (sl < 6 + 9 || seg[0] != 8 || seg[5] != 3) return -4;
+            H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4];
+            for (int c = 0; c < 3; c++) {
+                comp_id[c] = seg[6 + 3 * c]; comp_h[c] = seg[7 + 3 * c] >> 4; comp_v[c] = seg[7 + 3 * c] & 15; comp_q[c] = seg[8 + 3 * c];
+            }
+        } else if (m == 0xc1 || m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+            return -5;                                                            /* not baseline */
+        } else if (m == 0xc4) {                                                   /* DHT */
+            int o = 0;
+            while (o < sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || th > 3 || o + 17 > sl) return -6;
+                jpeg_dtab *t = &dt[tc][th];
+                int total = 0, code = 0, k = 0;
+                for (int len2 = 1; len2 <= 16; len2++) {
+                    const int cnt = seg[o + len2];
+                    t->valptr[len2] = k;
+                    t->mincode[len2] = code;
+                    t->maxcode[len2] = cnt ? code + cnt - 1 : -1;
+                    code = (code + cnt) << 1;
+                    k += cnt;
+                    total += cnt;
+                }
+                if (total > 256 || o + 17 + total > sl) return -6;
+                for (int i = 0; i < total; i++) t->value[i] = seg[o + 17 + i];
+                have_t[tc][th] = 1;
+                o += 17 + total;
+            }
+        } else if (m == 0xdd) {
+            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return -7;              /* restart intervals: not handled */
+        } else if (m == 0xda) {                                                   /* SOS */
+            if (sl < 1 + 6 + 3 || seg[0] != 3) return -8;
+            int td[3], ta[3];
+            for (int c = 0; c < 3; c++) {
+                if (seg[1 + 2 * c] != comp_id[c]) return -8;
+                td[c] = seg[2 + 2 * c] >> 4; ta[c] = seg[2 + 2 * c] & 15;
+                if (!have_t[0][td[c]] || !have_t[1][ta[c]] || !have_q[comp_q[c]]) return -8;
+            }
+            if (W <= 0 || H <= 0) return -4;
+            const int r420 = comp_h[0] == 2 && comp_v[0] == 2 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
+            const int r444 = comp_h[0] == 1 && comp_v[0] == 1 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
+            if (!r420 && !r444) return -9;
+            *wd = W; *ht = H; *ratio = r420 ? 2 : 0;
+            if (!yp) return 1;
+            const int ms = r420 ? 16 : 8, mx = (W + ms - 1) / ms, my = (H + ms - 1) / ms, ys = ms * mx, cs = 8 * mx;
+            jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};
+            int32_t pred[3] = {0, 0, 0};
+            size_t blk = 0;
+            for (int my0 = 0; my0 < my; my0++)
+                for (int mx0 = 0; mx0 < mx; mx0++)
+                    for (int c = 0; c < 3; c++) {
+                        const int nb = c == 0 && r420 ? 4 : 1;
+                        for (int i = 0; i < nb; i++, blk++) {
+                            int32_t b[64];
+                            int16_t zz[64];
+                            for (int k = 0; k < 64; k++) { b[k] = 0; zz[k] = 0; }
+                            const int s = jr_symbol(&br, &dt[0][td[c]]);
+                            pred[c] += jr_receive_extend(&br, s);
+                            zz[0] = (int16_t)pred[c];
+                            for (int zig = 1; zig < 64;) {
+                                const int rs = jr_symbol(&br, &dt[1][ta[c]]);
+                                const int rr = rs >> 4, ss = rs & 15;
+                                if (br.bad) return -10;
+                                if (ss == 0) {
+                                    if (rr == 15) { zig += 16; continue; }
+                                    break;                                        /* EOB */
+                                }
+                                zig += rr;
+                                if (zig > 63) return -10;
+                                zz[zig] = (int16_t)jr_receive_extend(&br, ss);
+                                zig++;
+                            }
+                            if (br.bad) return -10;
+                            if (coef) for (int k = 0; k < 64; k++) coef[64 * blk + k] = zz[k];
+                            const uint8_t *qq = q[comp_q[c]];
+                            for (int zig = 0; zig < 64; zig++) b[jpeg_unzig[zig]] = (int32_t)zz[zig] * (int32_t)qq[jpeg_unzig[zig]];
+                            orc_jpeg_idct(b);
+                            for (int k = 0; k < 64; k++) b[k] = b[k] < -128 ? 0 : (b[k] > 127 ? 255 : b[k] + 128);
+                            if (c == 0) {
+                                const int px = ms * mx0 + (r420 ? (i & 1) * 8 : 0), py = ms * my0 + (r420 ? (i & 2) * 4 : 0);
+                                for (int j = 0; j < 8; j++)
+                                    for (int k = 0; k < 8; k++) yp[(size_t)(py + j) * ys + px + k] = (uint8_t)b[8 * j + k];
+                            } else {
+                                uint8_t *cp = c == 1 ? cbp : crp;
+                                for (int j = 0; j < 8; j++)
+                                    for (int k = 0; k < 8; k++) cp[(size_t)(8 * my0 + j) * cs + 8 * mx0 + k] = (uint8_t)b[8 * j + k];
+                            }
+                        }
+                    }
+            return 1;
+        }
+        pos += 2 + len;
+    }
 }

@@ -455,3 +455,68 @@ def jpeg_roundtrip(img: np.ndarray, quality: int) -> np.ndarray:
     L.orc_jpeg_roundtrip.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
     L.orc_jpeg_roundtrip(p, s, w, h, int(quality), dst.ctypes.data_as(_u8p), w * 4)
     return dst
+
+
+# ---------------------------------------------------------------- baseline JPEG files (jpeg.Encode's layout) and a decoder
+def jpeg_huffman_luts() -> np.ndarray:
+    """The four standard tables (luminance DC, luminance AC, chrominance DC, chrominance AC) as length << 24 | code."""
+    luts = np.zeros((4, 256), dtype=np.uint32)
+    L = lib()
+    L.orc_jpeg_huffman_luts.restype = None
+    L.orc_jpeg_huffman_luts.argtypes = [C.POINTER(C.c_uint32)]
+    L.orc_jpeg_huffman_luts(luts.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return luts
+
+
+def jpeg_encode(img: np.ndarray, quality: int, with_coefficients: bool = False):
+    """jpeg.Encode(img, &jpeg.Options{Quality: quality}) as restated (io.go:157-169) -> the file's bytes
+    [, the quantised coefficients, (blocks, 64) int16 in zig-zag order, blocks in scan order]."""
+    p, s, w, h = _img(img)
+    mx, my = (w + 15) // 16, (h + 15) // 16
+    cap = 1024 + mx * my * 6 * 64 * 4
+    out = np.empty(cap, dtype=np.uint8)
+    coef = np.zeros((mx * my * 6, 64), dtype=np.int16) if with_coefficients else None
+    L = lib()
+    L.orc_jpeg_encode.restype = C.c_long
+    L.orc_jpeg_encode.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_long, C.POINTER(C.c_int16)]
+    n = L.orc_jpeg_encode(p, s, w, h, int(quality), out.ctypes.data_as(_u8p), cap,
+                          coef.ctypes.data_as(C.POINTER(C.c_int16)) if coef is not None else None)
+    if n <= 0:
+        raise RuntimeError(f"orc_jpeg_encode: {n}")
+    data = out[:n].tobytes()
+    return (data, coef) if with_coefficients else data
+
+
+def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
+    """A baseline 3-component 4:2:0 / 4:4:4 file -> (w, h, ratio, Y, Cb, Cr) MCU-padded planes as reader.go would hold
+    them [, coefficients]."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    L = lib()
+    L.orc_jpeg_decode_planes.restype = C.c_int
+    L.orc_jpeg_decode_planes.argtypes = [_u8p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u8p, _u8p, _u8p,
+                                         C.POINTER(C.c_int16)]
+    w, h, ratio = C.c_int(), C.c_int(), C.c_int()
+    bp = buf.ctypes.data_as(_u8p)
+    rc = L.orc_jpeg_decode_planes(bp, len(data), C.byref(w), C.byref(h), C.byref(ratio), None, None, None, None)
+    if rc != 1:
+        raise RuntimeError(f"orc_jpeg_decode_planes: {rc}")
+    ms = 16 if ratio.value == 2 else 8
+    mx, my = (w.value + ms - 1) // ms, (h.value + ms - 1) // ms
+    y = np.empty((ms * my, ms * mx), dtype=np.uint8)
+    cb = np.empty((8 * my, 8 * mx), dtype=np.uint8)
+    cr = np.empty((8 * my, 8 * mx), dtype=np.uint8)
+    nblk = mx * my * (6 if ratio.value == 2 else 3)
+    coef = np.zeros((nblk, 64), dtype=np.int16) if with_coefficients else None
+    rc = L.orc_jpeg_decode_planes(bp, len(data), C.byref(w), C.byref(h), C.byref(ratio), y.ctypes.data_as(_u8p), cb.ctypes.data_as(_u8p),
+                                  cr.ctypes.data_as(_u8p), coef.ctypes.data_as(C.POINTER(C.c_int16)) if coef is not None else None)
+    if rc != 1:
+        raise RuntimeError(f"orc_jpeg_decode_planes: {rc}")
+    out = (w.value, h.value, ratio.value, y, cb, cr)
+    return out + (coef,) if with_coefficients else out
+
+
+def jpeg_decode(data: bytes) -> np.ndarray:
+    """toNRGBARef(jpeg.Decode(data)) for such a file."""
+    w, h, ratio, y, cb, cr = jpeg_decode_planes(data)
+    full = ycbcr_to_nrgba(y, cb, cr, ratio)
+    return np.ascontiguousarray(full[:h, :w])

@@ -87,6 +87,67 @@ def test_roundtrip_edge_replication_and_premultiplied_alpha():
     assert abs(int(yb[4, 4]) - want) <= 1 and int(ya[4, 4]) > int(yb[4, 4])
 
 
+def _segments(data):
+    """[(marker, payload)] up to and including SOS, and the offset of the entropy-coded data."""
+    out, pos = [], 2
+    while pos < len(data):
+        assert data[pos] == 0xFF
+        m, ln = data[pos + 1], (data[pos + 2] << 8) | data[pos + 3]
+        out.append((m, data[pos + 4:pos + 2 + ln]))
+        pos += 2 + ln
+        if m == 0xDA:
+            break
+    return out, pos
+
+
+def test_encoder_files_decode_with_libjpeg_and_with_the_oracle():
+    """orc.jpeg_encode: jpeg.Encode's file as restated (baseline, 4:2:0, typical Huffman tables, writer.go's segment
+    order).  libjpeg-turbo must decode it, to pixels close to the round trip's (other IDCT, fancy upsampling); the
+    oracle's own decoder must return the round trip exactly -- planes and coefficients."""
+    from PIL import Image
+    imgs = [orc.gaussian_blur(synth.noise_image(333, 217, 3), 2.0), synth.make_test_image(64, 48), synth.noise_image(17, 9, 5),
+            synth.large_photo(640, 480, 2), synth.noise_image(16, 16, 1, alpha=True)]
+    for img in imgs:
+        for q in (1, 30, 75, 92, 100):
+            data, coef = orc.jpeg_encode(img, q, with_coefficients=True)
+            assert data[:2] == b"\xff\xd8" and data[-2:] == b"\xff\xd9"
+            pil = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+            rt = orc.jpeg_roundtrip(img, q)
+            assert pil.shape[:2] == img.shape[:2]
+            if img.shape[0] * img.shape[1] >= 3000 and q >= 30:
+                # smooth content: within a couple of levels (IDCT and chroma upsampling differ by design); high-frequency
+                # chroma (the modular pattern, noise): libjpeg's "fancy" upsampling alone is worth several levels
+                d = np.abs(pil.astype(int) - rt[..., :3]).mean()
+                assert d < (2.5 if img is imgs[0] else 12.0), d
+            w, h, ratio, y, cb, cr, coef2 = orc.jpeg_decode_planes(data, with_coefficients=True)
+            yy, cbb, crr = orc.jpeg_roundtrip_planes(img, q)
+            assert (w, h, ratio) == (img.shape[1], img.shape[0], 2)
+            assert np.array_equal(y, yy) and np.array_equal(cb, cbb) and np.array_equal(cr, crr) and np.array_equal(coef, coef2)
+            assert np.array_equal(orc.jpeg_decode(data), rt)
+            # no 0xff in the scan without a stuffed 0x00 (or the EOI)
+            segs, pos = _segments(data)
+            scan = data[pos:-2]
+            assert all(scan[i + 1] == 0 for i in range(len(scan) - 1) if scan[i] == 0xFF) and (not scan or scan[-1] != 0xFF)
+            assert [m for m, _ in segs] == [0xDB, 0xC0, 0xC4, 0xDA]          # writer.go: DQT, SOF0, DHT, SOS -- no APP0
+
+
+def test_huffman_tables_are_libjpegs_and_the_decoder_reads_libjpeg_files():
+    img = orc.gaussian_blur(synth.noise_image(320, 240, 7), 1.5)
+    pdata = batch.pillow_encode(img, 75)                              # not optimised: the typical tables of Annex K.3.3
+    psegs, _ = _segments(pdata)
+    msegs, _ = _segments(orc.jpeg_encode(img, 75))
+    dht = lambda segs: b"".join(p for m, p in segs if m == 0xC4)
+    assert dht(psegs) == dht(msegs) and len(dht(msegs)) == 4 * 17 + 2 * 12 + 2 * 162
+    dqt = lambda segs: b"".join(p for m, p in segs if m == 0xDB)
+    assert dqt(psegs) == dqt(msegs)                                   # same tables, same (zig-zag) order in the file
+    mine, theirs = orc.jpeg_decode(pdata), batch.pillow_decode(pdata)
+    d = np.abs(mine[..., :3].astype(int) - theirs[..., :3].astype(int))
+    assert d.mean() < 2.5, d.mean()
+    # canonical code lengths of the LUT = the spec's counts
+    luts = orc.jpeg_huffman_luts()
+    assert sorted((luts[1] >> 24)[luts[1] != 0].tolist()).count(16) == 125 and int((luts[0] != 0).sum()) == 12
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -166,3 +227,35 @@ def test_gpu_compress_batch_with_device_search(ctx):
         wq, ws, wn, _ = _oracle_search(src, batch.TARGET_SSIM["Balanced"])
         assert (r.Quality, r.steps) == (wq, wn) and abs(r.SSIM - ws) <= 1e-9
         assert r.CompressedSize == len(batch.pillow_encode(src, wq))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(16, 16), (17, 9), (1, 1), (640, 480), (333, 217), (1000, 37), (1920, 1080)])
+def test_gpu_encode_is_the_oracles_file(ctx, w, h):
+    """fnx_jpeg_encode: byte for byte the file the oracle's encoder writes; libjpeg-turbo decodes it; the oracle's decoder
+    returns fnx_jpeg_roundtrip's pixels from it."""
+    import torch
+    from PIL import Image
+    imgs = [synth.large_photo(w, h, 2), synth.noise_image(w, h, w + h, alpha=True)]
+    if w * h >= 64:
+        imgs.append(orc.gaussian_blur(synth.noise_image(w, h, 4), 2.5))
+    for img in imgs:
+        for q in (1, 30, 75, 92, 100):
+            want = orc.jpeg_encode(img, q)
+            got = ctx.jpeg_encode(img, q)
+            assert got == want, (w, h, q, len(got), len(want))
+        got = ctx.jpeg_encode(torch.from_numpy(img).cuda(), 60)
+        assert got == orc.jpeg_encode(img, 60)
+        assert Image.open(io.BytesIO(got)).size == (w, h)
+        assert np.array_equal(orc.jpeg_decode(got), ctx.jpeg_roundtrip(img, 60))
+
+
+@pytest.mark.gpu
+def test_gpu_encode_4k_and_all_ff(ctx):
+    img = synth.large_photo(3840, 2160, 1)
+    for q in (30, 92):
+        assert ctx.jpeg_encode(img, q) == orc.jpeg_encode(img, q), q
+    # noise at quality 100: long codes, many 0xff bytes to stuff
+    noise = synth.noise_image(512, 384, 9)
+    data = ctx.jpeg_encode(noise, 100)
+    assert data == orc.jpeg_encode(noise, 100) and data.count(b"\xff\x00") > 50
