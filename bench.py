@@ -105,6 +105,8 @@ def main() -> int:
     ap.add_argument("--queue", default="static", choices=["static", "dynamic"],
                     help="config5 at N > 1: 'static' gives rank r the items i = r mod N; 'dynamic' is ONE queue for the job "
                          "(a counter in torch.distributed's store, batch.go:72-126 across ranks)")
+    ap.add_argument("--device-codec", action="store_true",
+                    help="config5: search AND encode on the device (fnx_jpeg_compress); the host codec only decodes the source")
     ap.add_argument("--device-search", action="store_true",
                     help="config5: the quality search round-trips every candidate on the device (fnx_jpeg_quality_search); the host "
                          "codec decodes the source and encodes the winner only")
@@ -779,7 +781,9 @@ def other_workloads(args) -> int:
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
-        if args.device_search:
+        if args.device_codec:
+            work = fbatch.jpeg_item_work_device_codec(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
+        elif args.device_search:
             work = fbatch.jpeg_item_work_device_search(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
         else:
             work = fbatch.jpeg_item_work(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
@@ -801,7 +805,10 @@ def other_workloads(args) -> int:
         name = f"config5: {B} 4K JPEGs per step per GPU, Balanced (SSIM>=0.94) binary search, Pillow codec on {workers} host threads"
         if dyn:
             name += "; one dynamic queue over all ranks"
-        if args.device_search:
+        if args.device_codec:
+            name += ("; search and encoder on the device (fnx_jpeg_compress: Go image/jpeg's arithmetic and file layout), host codec: "
+                     "1 decode per image")
+        elif args.device_search:
             name += ("; search on the device (Go image/jpeg arithmetic without entropy coding, fnx_jpeg_quality_search), host "
                      "codec: 1 decode + 1 encode per image")
 
@@ -888,7 +895,9 @@ def other_workloads(args) -> int:
     if wl == "config5":
         per_item = float(np.mean(gpu_stage[-B * args.steps:]))
         out["gpu_stage"] = {"seconds_per_image": round(per_item, 6), "images_per_s_per_context": round(1.0 / per_item, 1),
-                            "note": ("time inside the C ABI (one H2D of the decoded source + the whole search on the device); the rest "
+                            "note": ("time inside the C ABI (one H2D of the decoded source, the whole search and the entropy coder on the "
+                                     "device, the file's D2H); the rest of a step is the host decode of the source") if args.device_codec else
+                                    ("time inside the C ABI (one H2D of the decoded source + the whole search on the device); the rest "
                                      "of a step is the host codec: one decode and one encode per image") if args.device_search else
                                     ("time inside the C ABI (prepare + every SSIMFast of the search, host buffers: PCIe-inclusive); "
                                      "the rest of a step is the host JPEG codec (Pillow here, Go's image/jpeg in the reference)")}

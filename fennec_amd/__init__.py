@@ -140,6 +140,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_msssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fennec_MSSSIM_enqueue", i, [ctx] + img + [i, i] + img + [i, i])
         _sig(L, "fnx_jpeg_encode", i, [ctx, i] + img + [i, i, i, _u8p, C.c_size_t, C.POINTER(C.c_size_t)])
+        _sig(L, "fnx_jpeg_compress", i, [ctx, i] + img + [i, i, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
+                                          C.POINTER(i)])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
@@ -487,6 +489,24 @@ class Context:
                     self._chk(rc, "fnx_jpeg_encode")
                 cap = n.value
         self._chk(rc, "fnx_jpeg_encode")
+
+    def jpeg_compress(self, img, target_ssim: float, window=None):
+        """compressJPEGOptimal on the device (fnx_jpeg_compress): search + the winning file -> (bytes, quality, ssim, steps)."""
+        s = _Img(img)
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        cap = 4096 + (s.w * s.h * 3) // 2
+        n, q, st, v = C.c_size_t(0), C.c_int(), C.c_int(), C.c_double()
+        with self._ordered(img):
+            for _ in range(2):
+                buf = np.empty(cap, dtype=np.uint8)
+                rc = self._lib.fnx_jpeg_compress(self._h, s.space, s.ptr, s.stride, s.w, s.h, float(target_ssim), pk,
+                                                 buf.ctypes.data_as(_u8p), cap, C.byref(n), C.byref(q), C.byref(v), C.byref(st))
+                if rc == FNX_OK:
+                    return buf[:n.value].tobytes(), q.value, v.value, st.value
+                if n.value <= cap:
+                    break
+                cap = n.value
+        self._chk(rc, "fnx_jpeg_compress")
 
     def jpeg_quality_search(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal's binary search with every candidate round-tripped and scored on the device

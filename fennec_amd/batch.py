@@ -195,6 +195,28 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
     return [results[i] for i in sorted(results)]
 
 
+def jpeg_item_work_device_codec(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
+                                on_gpu_seconds: Optional[Callable[[float], None]] = None,
+                                decode: Callable[[bytes], np.ndarray] = pillow_decode):
+    """The per-item body of CompressBatch with the search AND the encoder on the device (fnx_jpeg_compress: SURVEY 8(f)2,
+    second slice): the host codec only decodes the source.  The output is the file jpeg.Encode would write at the
+    chosen quality, as far as that is restated."""
+    import time
+
+    def work(idx: int, state) -> BatchResult:
+        data = jpegs[idx]
+        src = decode(data)
+        t0 = time.perf_counter()
+        out, q, s_, steps = state.jpeg_compress(src, target_ssim)
+        if on_gpu_seconds is not None:
+            on_gpu_seconds(time.perf_counter() - t0)
+        r = BatchResult(Index=idx, OriginalSize=len(data), CompressedSize=len(out), SSIM=s_, Quality=q)
+        r.steps = steps
+        r.data = out
+        return r
+    return work
+
+
 def jpeg_item_work_device_search(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
                                  on_gpu_seconds: Optional[Callable[[float], None]] = None,
                                  encode: Callable[[np.ndarray, int], bytes] = pillow_encode,

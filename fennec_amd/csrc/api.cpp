@@ -956,15 +956,10 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     return finish(ctx, space, &d);
 }
 
-int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
-                            const double *window, int *quality, double *ssim, int *steps)
+// compressJPEGOptimal's search (compress.go:24-74) on a device-resident source whose unquantised planes are `orig`
+static int jpeg_search_device(fnx_ctx *ctx, const DevImg &s, const JpegPlanes &orig, int w, int h, double target_ssim,
+                              const double *window, int *quality, double *ssim, int *steps, bool *found_out)
 {
-    FNX_TRY(bind(ctx));
-    FNX_TRY(check_space(space));
-    FNX_REQUIRE(window && quality && ssim && w > 0 && h > 0, "search arguments");
-    FNX_TRY(check_img(src, sstride, w, h, "src"));
-    DevImg s;
-    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
     // the source side of every SSIMFast of the search: prepared once (ssim.go:57 on the reference side)
     fnx_prepared ref;
     ref.w = w; ref.h = h;
@@ -974,9 +969,6 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
     ref.pix = static_cast<uint8_t *>(rp);
     if (ds) FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, w, h, ref.pix, ref.pw * 4, 0, ref.pw, ref.ph));
     else FNX_HIP(hipMemcpy2DAsync(ref.pix, size_t(w) * 4, s.p, s.stride, size_t(w) * 4, h, hipMemcpyDeviceToDevice, ctx->stream));
-    JpegPlanes orig;
-    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
-    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
     void *dec = nullptr;
     FNX_TRY(scratch(ctx, SLOT_JPEG2, static_cast<size_t>(w) * h * 4 + 16, &dec));
     // compress.go:24-74
@@ -1004,22 +996,31 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
     *quality = best_q;
     *ssim = best_ssim;
     if (steps) *steps = n;
-    return found ? FNX_OK : FNX_NOOP;      // FNX_NOOP: no quality reached the target (compress.go:82-86: encode at 100)
+    *found_out = found;
+    ref.pix = nullptr;
+    return FNX_OK;
 }
 
-int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
-                    size_t *nbytes)
+int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
+                            const double *window, int *quality, double *ssim, int *steps)
 {
     FNX_TRY(bind(ctx));
     FNX_TRY(check_space(space));
-    FNX_REQUIRE(nbytes != nullptr && w > 0 && h > 0 && w <= 65535 && h <= 65535, "encode arguments (JPEG dims are 16-bit)");
+    FNX_REQUIRE(window && quality && ssim && w > 0 && h > 0, "search arguments");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
-    *nbytes = 0;
     DevImg s;
     FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
     JpegPlanes orig;
     FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
     FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    bool found = false;
+    FNX_TRY(jpeg_search_device(ctx, s, orig, w, h, target_ssim, window, quality, ssim, steps, &found));
+    return found ? FNX_OK : FNX_NOOP;      // FNX_NOOP: no quality reached the target (compress.go:82-86: encode at 100)
+}
+
+// the file of `orig`'s image at `quality` into host memory (see fnx_jpeg_encode)
+static int jpeg_file_from_planes(fnx_ctx *ctx, const JpegPlanes &orig, int w, int h, int quality, uint8_t *out, size_t cap, size_t *nbytes)
+{
     // two u64 the kernels write and the host reads: bits of the scan's string, 0xff bytes in it
     double *slot;
     FNX_TRY(result_slot(ctx, 2, &slot));
@@ -1047,6 +1048,41 @@ int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, in
     out[total - 2] = 0xff;
     out[total - 1] = 0xd9;          // EOI
     return FNX_OK;
+}
+
+int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
+                    size_t *nbytes)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(nbytes != nullptr && w > 0 && h > 0 && w <= 65535 && h <= 65535, "encode arguments (JPEG dims are 16-bit)");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    *nbytes = 0;
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    return jpeg_file_from_planes(ctx, orig, w, h, quality, out, cap, nbytes);
+}
+
+int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim, const double *window,
+                      uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(window && nbytes && quality && ssim && w > 0 && h > 0 && w <= 65535 && h <= 65535, "compress arguments");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    *nbytes = 0;
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    bool found = false;
+    FNX_TRY(jpeg_search_device(ctx, s, orig, w, h, target_ssim, window, quality, ssim, steps, &found));
+    // compress.go:76-86: the best candidate's bytes, or -- nothing reached the target -- an encode at bestQuality (100)
+    return jpeg_file_from_planes(ctx, orig, w, h, *quality, out, cap, nbytes);
 }
 
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)

@@ -202,6 +202,12 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
  * Go's source: byte parity with jpeg.Encode is unpinned; libjpeg-turbo decodes the files. */
 int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
                     size_t *nbytes);
+/* compressJPEGOptimal (compress.go:21-87) for one image in one call: the quality search of fnx_jpeg_quality_search, then
+ * the file at the quality it found (100 when nothing reached the target) as fnx_jpeg_encode writes it -- one upload of
+ * the source, no host codec.  *ssim is the winning candidate's SSIMFast (1.0 when none won, as the reference reports). */
+int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
+                      const double *window /* 64 */, uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim,
+                      int *steps /* may be NULL */);
 int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
                             const double *window /* 64 */, int *quality, double *ssim, int *steps);
 

@@ -259,3 +259,36 @@ def test_gpu_encode_4k_and_all_ff(ctx):
     noise = synth.noise_image(512, 384, 9)
     data = ctx.jpeg_encode(noise, 100)
     assert data == orc.jpeg_encode(noise, 100) and data.count(b"\xff\x00") > 50
+
+
+@pytest.mark.gpu
+def test_gpu_compress_is_search_plus_encode(ctx):
+    """fnx_jpeg_compress = compressJPEGOptimal in one call: the search's (quality, SSIM, steps), then the file at that
+    quality -- the oracle's file; when nothing reaches the target the file is the one at 100 (compress.go:82-86)."""
+    import torch
+    cases = [(synth.large_photo(1280, 720, 3), 0.94), (orc.gaussian_blur(synth.noise_image(800, 600, 2), 2.0), 0.97),
+             (synth.noise_image(300, 200, 9), 0.999), (synth.make_test_image(400, 300), 1.0)]
+    for img, target in cases:
+        data, q, s, n = ctx.jpeg_compress(img, target)
+        wq, ws, wn, found = ctx.jpeg_quality_search(img, target)
+        assert (q, s, n) == (wq, ws, wn)
+        assert data == orc.jpeg_encode(img, q)
+        assert found or q == 100
+        d2, q2, s2, n2 = ctx.jpeg_compress(torch.from_numpy(img).cuda(), target)
+        assert (d2, q2, s2, n2) == (data, q, s, n)
+
+
+@pytest.mark.gpu
+def test_gpu_compress_batch_with_device_codec(ctx):
+    import fennec_amd
+    jpegs = [batch.pillow_encode(synth.large_photo(1920, 1080, k), 92) for k in range(4)]
+    states = {}
+    res = batch.compress_batch(len(jpegs), batch.jpeg_item_work_device_codec(jpegs), lambda wid: states.setdefault(wid, fennec_amd.Context(0)),
+                               workers=2)
+    for r in res:
+        assert r.Err is None
+        src = batch.pillow_decode(jpegs[r.Index])
+        wq, ws, wn, _ = _oracle_search(src, batch.TARGET_SSIM["Balanced"])
+        assert (r.Quality, r.steps) == (wq, wn) and abs(r.SSIM - ws) <= 1e-9
+        assert r.data == orc.jpeg_encode(src, wq) and r.CompressedSize == len(r.data)
+        assert np.array_equal(orc.jpeg_decode(r.data), orc.jpeg_roundtrip(src, wq))

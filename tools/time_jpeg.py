@@ -30,7 +30,9 @@ for W, H in sizes:
     blocks = ((W + 15) // 16) * ((H + 15) // 16) * 6
     print(f"{W}x{H}: block kernel {m * 1e3:7.1f} us ({blocks} blocks, {W * H * 1.5 * 2 / m / 1e6:6.0f} GB/s of plane traffic)", flush=True)
     for call, label in ((lambda: ctx.jpeg_roundtrip(img, 60), "round trip (ycc + blocks + to NRGBA)"),
-                        (lambda: ctx.jpeg_quality_search(img, 0.94), "quality search, target 0.94")):
+                        (lambda: ctx.jpeg_quality_search(img, 0.94), "quality search, target 0.94"),
+                        (lambda: ctx.jpeg_encode(img, 60), "encode to a file (q=60, incl. 2 syncs + D2H)"),
+                        (lambda: ctx.jpeg_compress(img, 0.94), "compress = search + encode at the winner")):
         call(); ctx.sync()
         t0 = time.perf_counter()
         n = 20
@@ -38,5 +40,11 @@ for W, H in sizes:
             r = call()
         ctx.sync()
         dt = (time.perf_counter() - t0) / n
-        extra = f" -> q={r[0]} ssim={r[1]:.5f} steps={r[2]}" if isinstance(r, tuple) else ""
+        extra = ""
+        if isinstance(r, tuple) and isinstance(r[0], bytes):
+            extra = f" -> {len(r[0])} bytes q={r[1]} ssim={r[2]:.5f} steps={r[3]}"
+        elif isinstance(r, tuple):
+            extra = f" -> q={r[0]} ssim={r[1]:.5f} steps={r[2]}"
+        elif isinstance(r, bytes):
+            extra = f" -> {len(r)} bytes"
         print(f"    {label:40s} {dt * 1e3:8.3f} ms{extra}", flush=True)
