@@ -621,3 +621,57 @@ func jpegRoundTripHIP(src *image.NRGBA, quality int) *image.NRGBA {
 	}
 	return dst
 }
+
+// jpegEncodeHIP is jpeg.Encode(w, src, &jpeg.Options{Quality: quality})'s file from the device (fnx_jpeg_encode:
+// baseline, 4:2:0, the typical Huffman tables, writer.go's segment order); nil when the device was not used.
+func jpegEncodeHIP(src *image.NRGBA, quality int) []byte {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	c := poolGetIf(useDeviceSearch && w > 0 && h > 0)
+	if c == nil {
+		return nil
+	}
+	defer pool.put(c)
+	buf := make([]byte, 4096+w*h*3/2)
+	for try := 0; try < 2; try++ {
+		var n C.size_t
+		st := C.fnx_jpeg_encode(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), C.int(quality),
+			(*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n)
+		runtime.KeepAlive(src)
+		if st == C.FNX_OK {
+			return buf[:int(n)]
+		}
+		if int(n) <= len(buf) {
+			return nil
+		}
+		buf = make([]byte, int(n))
+	}
+	return nil
+}
+
+// jpegCompressHIP is compressJPEGOptimal (compress.go:21-87) in one call: the search and the winning file on the
+// device.  ok == false: the device was not used and the caller runs the loop as before.
+func jpegCompressHIP(src *image.NRGBA, targetSSIM float64) (data []byte, quality int, ssim float64, ok bool) {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	c := poolGetIf(useDeviceSearch && w > 0 && h > 0)
+	if c == nil {
+		return nil, 0, 0, false
+	}
+	defer pool.put(c)
+	buf := make([]byte, 4096+w*h*3/2)
+	for try := 0; try < 2; try++ {
+		var n C.size_t
+		var q, steps C.int
+		var s C.double
+		st := C.fnx_jpeg_compress(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), C.double(targetSSIM),
+			(*C.double)(unsafe.Pointer(&ssimWindow[0])), (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n, &q, &s, &steps)
+		runtime.KeepAlive(src)
+		if st == C.FNX_OK {
+			return buf[:int(n)], int(q), float64(s), true
+		}
+		if int(n) <= len(buf) {
+			return nil, 0, 0, false
+		}
+		buf = make([]byte, int(n))
+	}
+	return nil, 0, 0, false
+}
