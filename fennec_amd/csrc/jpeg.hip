@@ -292,7 +292,7 @@ int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *c
 //   3. prefix sum         of the bit counts (two launches) = every block's position in the string
 //   4. jpeg_pack_kernel   lane = block: the strip shifted into place (atomicOr into zeroed words, MSB first)
 //   5. stuffing           0xff bytes per word, prefix sum, every byte to its final place with 0x00 behind each 0xff
-// The host writes the header (623 bytes) and the EOI marker.  All integer work: byte-for-byte against the CPU
+// The host writes the header (589 bytes) and the EOI marker.  All integer work: byte-for-byte against the CPU
 // restatement the tests hold, which is itself checked against libjpeg-turbo where it can be and is
 // otherwise -- like the quantiser path -- unpinned against Go.
 // ------------------------------------------------------------------------------------
