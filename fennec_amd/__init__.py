@@ -490,6 +490,15 @@ class Context:
                 cap = n.value
         self._chk(rc, "fnx_jpeg_encode")
 
+    def jpeg_encoded_size(self, img, quality: int) -> int:
+        """len(jpeg.Encode(img, quality)) without fetching the bytes (fnx_jpeg_encode's size query)."""
+        s = _Img(img)
+        n = C.c_size_t(0)
+        with self._ordered(img):
+            self._chk(self._lib.fnx_jpeg_encode(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(quality), None, 0, C.byref(n)),
+                      "fnx_jpeg_encode")
+        return int(n.value)
+
     def jpeg_compress(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal on the device (fnx_jpeg_compress): search + the winning file -> (bytes, quality, ssim, steps)."""
         s = _Img(img)

@@ -1039,6 +1039,7 @@ static int jpeg_file_from_planes(fnx_ctx *ctx, const JpegPlanes &orig, int w, in
     jpeg_header(w, h, quality, hdr);
     const size_t total = hdr.size() + ecs_bytes + 2;
     *nbytes = total;
+    if (out == nullptr && cap == 0) return FNX_OK;       // size query: targetsize.go's searches need len(encoded) only
     if (out == nullptr || cap < total) {
         set_error("invalid argument: the file needs %zu bytes, the buffer holds %zu", total, cap);
         return FNX_ERR_INVALID;

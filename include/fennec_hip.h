@@ -197,7 +197,8 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
  * (*quality = 100, *ssim = 1.0, as the reference's fallback).  The caller encodes ONCE, at *quality, with the real codec. */
 /* jpeg.Encode(src, &jpeg.Options{Quality: quality}) (io.go:157-169) on the device: the complete file -- baseline, 4:2:0,
  * the typical Huffman tables, writer.go's segment order -- into host memory `out` (capacity cap); *nbytes = its size.
- * FNX_ERR_INVALID with *nbytes set when cap is too small (call again).  Decoding the file gives exactly
+ * FNX_ERR_INVALID with *nbytes set when cap is too small (call again); out == NULL with cap == 0 asks for the size
+ * only (what targetsize.go's searches look at) and copies nothing.  Decoding the file gives exactly
  * fnx_jpeg_roundtrip's pixels (the entropy coder is lossless).  Restated from ITU T.81 and Go's file layout, not from
  * Go's source: byte parity with jpeg.Encode is unpinned; libjpeg-turbo decodes the files. */
 int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,

@@ -259,6 +259,8 @@ def test_gpu_encode_4k_and_all_ff(ctx):
     noise = synth.noise_image(512, 384, 9)
     data = ctx.jpeg_encode(noise, 100)
     assert data == orc.jpeg_encode(noise, 100) and data.count(b"\xff\x00") > 50
+    for q in (5, 50, 100):                                        # the size query copies nothing
+        assert ctx.jpeg_encoded_size(noise, q) == len(orc.jpeg_encode(noise, q))
 
 
 @pytest.mark.gpu

@@ -14,8 +14,10 @@ python bench.py --blur-mode exact --no-cpu-baseline > $O/${R}_onepass_exact_benc
 python bench.py --pipeline two-call --no-cpu-baseline > $O/${R}_twocall_bench_plain.json 2>> $O/c3c4.log
 python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_bench_plain.json 2>> $O/c3c4.log
 python bench.py --workload config5 --device-search --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_device_search_bench_plain.json 2>> $O/c3c4.log
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/profile_${R}_config5_device_search/stats -o bench -- \
-    python $ROOT/bench.py --workload config5 --device-search --steps 2 --warmup 1 --no-cpu-baseline > $ROOT/$O/profile_${R}_config5_device_search/bench_under_stats.json 2> $ROOT/$O/c5stats.log )
+python bench.py --workload config5 --device-codec --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_device_codec_bench_plain.json 2>> $O/c3c4.log
+mkdir -p $O/profile_${R}_config5_device_codec
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/profile_${R}_config5_device_codec/stats -o bench -- \
+    python $ROOT/bench.py --workload config5 --device-codec --steps 2 --warmup 1 --no-cpu-baseline > $ROOT/$O/profile_${R}_config5_device_codec/bench_under_stats.json 2> $ROOT/$O/c5stats.log )
 python tools/time_ops.py > $O/${R}_time_ops.txt 2>&1
 python tools/time_fx.py > $O/${R}_time_fx.txt 2>&1
 python tools/time_resize.py > $O/${R}_time_resize_ramp.txt 2>&1
