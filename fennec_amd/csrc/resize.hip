@@ -385,6 +385,19 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
     const int gc_ = min(static_cast<int>(blockIdx.x) * 64 + (tid & 63), a.ngroups - 1);
     const int s0_ = a.s0[gc_];
     const uint32_t ab_ = a.alpha[gc_];
+    // ... and the wave's first two rows go out before the weights are staged and the barrier is crossed (rows clamped into
+    // the image: a wave past the last row reads it again and stores nothing)
+    const int yw_ = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * a.rows;
+    u32x4 vn[PF ? NV : 1], vm[PF ? NV : 1];
+    if constexpr (PF) {
+        const uint8_t *r0 = a.src + static_cast<size_t>(min(yw_, a.other - 1)) * a.sstride;
+        const uint8_t *r1 = a.src + static_cast<size_t>(min(yw_ + 1, min(a.other, yw_ + a.rows) - 1)) * a.sstride;   // in [0, other - 1] either way
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
+            vn[q] = *(g_u32x4 *)(r0 + 4 * static_cast<size_t>(s0_ + 4 * q));
+            vm[q] = *(g_u32x4 *)(r1 + 4 * static_cast<size_t>(s0_ + 4 * q));
+        }
+    }
     {
         const int g0 = blockIdx.x * 64;
         for (int e = tid; e < NPX * 64; e += 256) {
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
     const int g = blockIdx.x * 64 + lane;
     // first row of this wave: provably scalar, so row pointers are SGPR pairs and the window loads need one
     // 32-bit offset register each
-    const int yw = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(tid >> 6)) * a.rows;
+    const int yw = yw_;
     const bool active = g < a.ngroups && yw < a.other;
     uint32_t exact_rows = 0;                                        // bit r: row yw + r of this wave awaits the exact loop
     if (yw < a.other) {                                             // wave-uniform
@@ -421,11 +434,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
         };
         // a wave walks its rows one after the other, so what it has in flight is what it prefetched: two rows
         // ahead (the chip needs ~12 MB in flight to stream at HBM rate; one row ahead measured 2.7 TB/s at best)
-        u32x4 vn[PF ? NV : 1], vm[PF ? NV : 1];
-        if constexpr (PF) {
-            load_row(yw, vn);
-            load_row(min(yw + 1, y1 - 1), vm);
-        }
+        // (the first two rows were requested before the barrier)
         // NV <= 4: the wave's weight pairs ride in registers (32 VGPRs) instead of 16 LDS reads per row
         constexpr bool WREG = NV <= 4;
         v2f wreg[WREG ? NPX : 1];
@@ -622,6 +631,20 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
         alv[j] = a.alpha[yy];
         invv[j] = a.inv[yy];
     }
+    // ... and so are the first four source rows: issued before the weights are staged and the barrier is crossed, so that
+    // the two latencies overlap (idle lanes and waves read the last columns: clamped, harmless)
+    const int xl = (blockIdx.x * 256 + tid) * PX;
+    const int x = min(xl, a.other - PX);
+    const uint8_t *col = a.src + 4 * static_cast<size_t>(x);
+    auto load = [&](int s) -> u32x4 {
+        const uint8_t *p = col + static_cast<size_t>(s) * a.sstride;
+        if constexpr (ALIGNED) {
+            return *(g_u32x4 *)p;
+        } else {
+            return (u32x4){*(g_u32 *)p, *(g_u32 *)(p + 4), *(g_u32 *)(p + 8), *(g_u32 *)(p + 12)};
+        }
+    };
+    u32x4 t1 = load(s0), t2 = load(s0 + min(1, nr - 1)), t3 = load(s0 + min(2, nr - 1)), t4 = load(s0 + min(3, nr - 1));
     {
         const int nw = nr * VG;
         if (tid < nw) {
@@ -636,22 +659,11 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
     const int xw = (blockIdx.x * 256 + (tid & ~63)) * PX;           // first column of this wave
     const int y0 = grp * VG;
     if (xw < a.other) {                                             // wave-uniform
-        const int xl = (blockIdx.x * 256 + tid) * PX;
         const bool active = xl < a.other;
         // a lane whose 4 columns would stick out of the image shifts left (the host keeps other >= 4): it then
         // recomputes columns its neighbour owns and stores the same values -- no branch around the loads (see
         // the H pass).  ALIGNED: src base, stride and other % 4 allow 16-byte loads at every lane.
-        const int x = min(xl, a.other - PX);
         const int ncol = active ? PX : 0;
-        const uint8_t *col = a.src + 4 * static_cast<size_t>(x);
-        auto load = [&](int s) -> u32x4 {
-            const uint8_t *p = col + static_cast<size_t>(s) * a.sstride;
-            if constexpr (ALIGNED) {
-                return *(g_u32x4 *)p;
-            } else {
-                return (u32x4){*(g_u32 *)p, *(g_u32 *)(p + 4), *(g_u32 *)(p + 8), *(g_u32 *)(p + 12)};
-            }
-        };
         const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
         v2f acc[VG][6];                                             // (r0,g0) (b0,r1) (g1,b1) (r2,g2) (b2,r3) (g3,b3)
 #pragma unroll
@@ -660,7 +672,6 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
             for (int q = 0; q < 6; q++) acc[j][q] = (v2f){seed, seed};
         u32x4 andp = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         // four source rows in flight per lane (see the H pass: a wave's own prefetch is all it has outstanding)
-        u32x4 t1 = load(s0), t2 = load(s0 + min(1, nr - 1)), t3 = load(s0 + min(2, nr - 1)), t4 = load(s0 + min(3, nr - 1));
         for (int i = 0; i < nr; i++) {
             const u32x4 t = t1;
             t1 = t2; t2 = t3; t3 = t4;
