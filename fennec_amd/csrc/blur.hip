@@ -407,17 +407,40 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         if constexpr (SCORE) {   // blurred side of the box sums (columns / rows outside the image -> spare entries)
             unsigned long long *s_box_b = s_box + (RA + (cp & (RB - 1))) * a.cstride;
             const u32x2 co = *reinterpret_cast<const u32x2 *>(s_coloff + 2 * cp);
+            if constexpr (GUARD) {
 #pragma unroll
-            for (int j = 0; j < Q; j++) {
-                const uint32_t ro = s_rowoff[rg * Q + j];
-                if constexpr (GUARD) {   // provisional values of flagged pixels go to the spare corner entry
+                for (int j = 0; j < Q; j++) {   // provisional values of flagged pixels go to the spare corner entry
+                    const uint32_t ro = s_rowoff[rg * Q + j];
                     const uint32_t spare = 8u * ((a.nbx + 1) * a.nby + a.nbx);
                     box_add(s_box_b, (flagged >> (2 * j)) & 1u ? spare : ro + co.x, o[j].x);
                     box_add(s_box_b, (flagged >> (2 * j)) & 2u ? spare : ro + co.y, o[j].y);
-                } else {
-                    box_add(s_box_b, ro + co.x, o[j].x);
-                    box_add(s_box_b, ro + co.y, o[j].y);
                 }
+            } else {
+                // An item's Q rows cross two or three box rows: the channel sums of a column's run of rows inside one box
+                // row are taken in registers (16-bit fields: Q * 255 < 2^16) and go to the table once per run -- 4 to 6
+                // LDS atomics per item instead of 2 Q.  The row -> box row map is the same for the 32 lanes of a row group.
+                uint32_t cur = s_rowoff[rg * Q];
+                uint32_t rg0 = 0, ba0 = 0, rg1 = 0, ba1 = 0;
+                auto flush = [&](uint32_t ro) {
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_box_b) + ro + co.x),
+                                           (static_cast<unsigned long long>(ba0) << 32) | rg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(s_box_b) + ro + co.y),
+                                           (static_cast<unsigned long long>(ba1) << 32) | rg1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+#pragma unroll
+                for (int j = 0; j < Q; j++) {
+                    const uint32_t ro = s_rowoff[rg * Q + j];
+                    if (ro != cur) {
+                        flush(cur);
+                        rg0 = ba0 = rg1 = ba1 = 0;
+                        cur = ro;
+                    }
+                    rg0 += __builtin_amdgcn_perm(0u, o[j].x, 0x0c010c00u);
+                    ba0 += __builtin_amdgcn_perm(0u, o[j].x, 0x0c030c02u);
+                    rg1 += __builtin_amdgcn_perm(0u, o[j].y, 0x0c010c00u);
+                    ba1 += __builtin_amdgcn_perm(0u, o[j].y, 0x0c030c02u);
+                }
+                flush(cur);
             }
         }
         if (x < a.w) {
