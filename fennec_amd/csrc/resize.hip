@@ -791,14 +791,22 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
                     const uint32_t al = alv[j];
                     const double inv = invv[j];
                     uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
-                    if (c < ncol)
-                        *(g_u32w *)(dp + 4 * c) = ((opq >> c) & 1u)
-                            ? clampF_dev(r[j][0] * inv) | (clampF_dev(r[j][1] * inv) << 8) | (clampF_dev(r[j][2] * inv) << 16) | al
-                            : resize_exact_px<true>(a, x + c, y);
-                    if (c + 1 < ncol)
-                        *(g_u32w *)(dp + 4 * (c + 1)) = ((opq >> (c + 1)) & 1u)
-                            ? clampF_dev(r[j][3] * inv) | (clampF_dev(r[j][4] * inv) << 8) | (clampF_dev(r[j][5] * inv) << 16) | al
-                            : resize_exact_px<true>(a, x + c + 1, y);
+                    if (c < ncol && ((opq >> c) & 1u))
+                        *(g_u32w *)(dp + 4 * c) = clampF_dev(r[j][0] * inv) | (clampF_dev(r[j][1] * inv) << 8) | (clampF_dev(r[j][2] * inv) << 16) | al;
+                    if (c + 1 < ncol && ((opq >> (c + 1)) & 1u))
+                        *(g_u32w *)(dp + 4 * (c + 1)) = clampF_dev(r[j][3] * inv) | (clampF_dev(r[j][4] * inv) << 8) | (clampF_dev(r[j][5] * inv) << 16) | al;
+                }
+            }
+            // columns with some alpha != 255 in the union: the general arithmetic, once the 24 accumulators are dead
+            // (inlined beside them it cost the kernel a resident wave per SIMD)
+            if ((opq & own) != own) {
+#pragma unroll 1
+                for (int j = 0; j < VG; j++) {
+                    if (!((dense_rows >> j) & 1u)) continue;
+#pragma unroll 1
+                    for (int e = 0; e < ncol; e++)
+                        if (!((opq >> e) & 1u))
+                            *(g_u32w *)(a.dst + static_cast<size_t>(y0 + j) * a.dstride + 4 * static_cast<size_t>(x + e)) = resize_exact_px<true>(a, x + e, y0 + j);
                 }
             }
         }
