@@ -380,7 +380,10 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
     extern __shared__ __attribute__((aligned(16))) double s_aw[];
     v2f *s_w = reinterpret_cast<v2f *>(s_aw + HO * NPX * 64);
     const int tid = threadIdx.x;
+    constexpr bool WREG = NV <= 4;      // the wave's weight pairs ride in registers (32 VGPRs) instead of 16 LDS reads per row
     if (tid == 0) s_nfix = 0;
+    if constexpr (WREG) __syncthreads();        // the list's counter is in place before anybody adds to it: crossed at once,
+                                                // with nothing in flight yet (no weights are staged on this path)
     // issued before the staging below so that the three latencies overlap (a workgroup is short)
     const int gc_ = min(static_cast<int>(blockIdx.x) * 64 + (tid & 63), a.ngroups - 1);
     const int s0_ = a.s0[gc_];
@@ -398,7 +401,14 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
             vm[q] = *(g_u32x4 *)(r1 + 4 * static_cast<size_t>(s0_ + 4 * q));
         }
     }
-    {
+    // WREG: a lane's weight pairs straight from the plan's table (coalesced over the lanes' groups) -- no staging, no
+    // barrier between a wave and its first row
+    v2f wreg[WREG ? NPX : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int i = 0; i < NPX; i++)
+            wreg[i] = (v2f){a.dense[static_cast<size_t>(i) * a.ngroups + gc_], a.dense[static_cast<size_t>(NPX + i) * a.ngroups + gc_]};
+    } else {
         const int g0 = blockIdx.x * 64;
         for (int e = tid; e < NPX * 64; e += 256) {
             const int gl = e & 63, i = e >> 6;
@@ -406,8 +416,8 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
             s_w[e] = (v2f){in ? a.dense[static_cast<size_t>(i) * a.ngroups + g0 + gl] : 0.0f,
                            in ? a.dense[static_cast<size_t>(NPX + i) * a.ngroups + g0 + gl] : 0.0f};
         }
+        __syncthreads();
     }
-    __syncthreads();
     const int lane = tid & 63;
     const int g = blockIdx.x * 64 + lane;
     // first row of this wave: provably scalar, so row pointers are SGPR pairs and the window loads need one
@@ -435,13 +445,6 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
         // a wave walks its rows one after the other, so what it has in flight is what it prefetched: two rows
         // ahead (the chip needs ~12 MB in flight to stream at HBM rate; one row ahead measured 2.7 TB/s at best)
         // (the first two rows were requested before the barrier)
-        // NV <= 4: the wave's weight pairs ride in registers (32 VGPRs) instead of 16 LDS reads per row
-        constexpr bool WREG = NV <= 4;
-        v2f wreg[WREG ? NPX : 1];
-        if constexpr (WREG) {
-#pragma unroll
-            for (int i = 0; i < NPX; i++) wreg[i] = s_w[i * 64 + lane];
-        }
         // rows whose flags are dense (ramps, flat ties, translucent regions) are left to the exact loop below;
         // while that lasts only every 4th row still tries the fp32 form (`sticky`)
         bool sticky = false;
