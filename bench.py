@@ -207,9 +207,9 @@ def main() -> int:
         if depth > 1:
             return run_pipelined(nsteps, events)
         if one_pass and nctx == 1 and not args.no_queue_ahead:
-            # one context, one stream: step s+1 is ENQUEUED before step s's scores are fetched (the ctx keeps a
-            # FIFO of unfetched batches), so the stream does not drain while the host turns around; kernels of a
-            # stream run in order, so every blur kernel still has the GPU to itself
+            # one context: step s+1 is ENQUEUED before step s's scores are fetched (the ctx keeps a FIFO of unfetched
+            # batches), so the GPU does not drain while the host turns around; the blurs run in order on the ctx's
+            # stream, step s's tail (box finish, window sums) on its second stream, i.e. under step s+1's blur
             for s in range(nsteps + 1):
                 if s < nsteps:
                     fused_plans[0].enqueue()                   # fnx_gaussian_blur_ssim_fast_batch_enqueue
