@@ -88,6 +88,37 @@ while time.time() < t_end:
     ratio = int(rng.integers(0, 6))
     y, cb, cr = synth.ycbcr_planes(w, h, ratio, int(rng.integers(1 << 30)))
     case("ycbcr", np.array_equal(ctx.ycbcrToNRGBA(y, cb, cr, ratio), orc.ycbcr_to_nrgba(y, cb, cr, ratio)), desc + f" ratio={ratio}")
+    # the JPEG path: quantisation round trip, the file, the search (all integer: exact)
+    q = int(rng.integers(1, 101))
+    case("jpeg_roundtrip", np.array_equal(ctx.jpeg_roundtrip(img, q), orc.jpeg_roundtrip(img, q)), desc + f" q={q}")
+    data = ctx.jpeg_encode(img, q)
+    okj = data == orc.jpeg_encode(img, q)
+    if okj and it % 4 == 0:
+        okj = np.array_equal(orc.jpeg_decode(data), orc.jpeg_roundtrip(img, q)) and ctx.jpeg_encoded_size(img, q) == len(data)
+    case("jpeg_encode", okj, desc + f" q={q}")
+    if it % 5 == 0:
+        target = float(rng.choice([0.5, 0.9, 0.94, 0.97, 0.99, 1.0]))
+        data, bq, bs, bn = ctx.jpeg_compress(img, target)
+        sq, ss_, sn, found = ctx.jpeg_quality_search(img, target)
+        case("jpeg_compress", (bq, bs, bn) == (sq, ss_, sn) and data == orc.jpeg_encode(img, bq) and (found or bq == 100), desc + f" target={target}")
+    if it % 3 == 0:                         # the result FIFO: SSIM on the second stream, MSSSIM with the implicit resize
+        import torch
+        da, db = torch.from_numpy(img).cuda(), torch.from_numpy(other).cuda()
+        small = ctx.lanczosResize(da, max(1, w // 2), max(1, h // 2))
+        ctx.ssim_enqueue(da, db)
+        ctx.msssim_enqueue(da, small)
+        v1, v2 = ctx.fetch_result(), ctx.fetch_result()
+        case("enqueue", v1 == ctx.SSIM(da, db) and v2 == ctx.MSSSIM(da, small) and
+             abs(v2 - orc.msssim(img, small.cpu().numpy(), procs=8)) <= SSIM_TOL, desc)
+    if it % 10 == 0:                        # the two-column marching SSIM (>= 4 M windows per image), odd dims, resize at scale
+        w3, h3 = int(rng.integers(2100, 4200)), int(rng.integers(1930, 2400))
+        big = rand_image(w3, h3)
+        oth = ctx.AdaptiveSharpen(big, 0.5)
+        case("ssim_big", abs(ctx.SSIM(big, oth) - orc.ssim(big, oth, procs=32)) <= SSIM_TOL, f"seed={seed} it={it} {w3}x{h3}")
+        dw3, dh3 = int(rng.integers(600, 2200)), int(rng.integers(400, 1300))
+        case("resize_big", np.array_equal(ctx.lanczosResize(big, dw3, dh3), orc.lanczos_resize(big, dw3, dh3, procs=32)),
+             f"seed={seed} it={it} {w3}x{h3} -> {dw3}x{dh3}")
+        case("adaptive_big", np.array_equal(oth, orc.adaptive_sharpen(big, 0.5, procs=32)), f"seed={seed} it={it} {w3}x{h3}")
     if it % 6 == 0:                         # one-pass kernel: sizes inside its gate, odd dims, all radii
         import torch
         w2, h2 = int(rng.integers(1850, 4300)), int(rng.integers(1100, 2600))
