@@ -494,6 +494,13 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
             if (!opaque) flagged = 3u;                              // some alpha != 255 in the window: general arithmetic
             if (!active) flagged = 0;
             if (__popcll(__ballot(flagged != 0)) >= RG_DENSE) {     // wave-uniform: the whole row goes to the exact loop
+                if (y == yw) {
+                    // the wave's FIRST row is dense: all of its rows go to the exact loop at once.  On tie-dense content
+                    // (the reference's ramps at an integer ratio) walking the rest of the rows here -- loading every
+                    // one, trying every fourth -- was 6.4 us of a wave's 27 (per-wave timestamps) for nothing
+                    exact_rows = (y1 - yw >= 32) ? 0xffffffffu : ((1u << (y1 - yw)) - 1u);
+                    break;
+                }
                 exact_rows |= 1u << (y - yw);
                 sticky = true;
                 continue;
