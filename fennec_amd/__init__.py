@@ -140,6 +140,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_msssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fennec_MSSSIM_enqueue", i, [ctx] + img + [i, i] + img + [i, i])
         _sig(L, "fnx_jpeg_encode", i, [ctx, i] + img + [i, i, i, _u8p, C.c_size_t, C.POINTER(C.c_size_t)])
+        _sig(L, "fnx_jpeg_size_search", i, [ctx, i] + img + [i, i, C.c_longlong, i, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
+                                             _f64p, C.POINTER(i)])
         _sig(L, "fnx_jpeg_compress", i, [ctx, i] + img + [i, i, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
                                           C.POINTER(i)])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
@@ -498,6 +500,22 @@ class Context:
             self._chk(self._lib.fnx_jpeg_encode(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(quality), None, 0, C.byref(n)),
                       "fnx_jpeg_encode")
         return int(n.value)
+
+    def jpeg_size_search(self, img, target_bytes: int, skip_ssim: bool = False, window=None):
+        """jpegQualitySearchOpt (targetsize.go:125-176) on the device -> (bytes, quality, ssim, steps), or None when no
+        quality fits target_bytes."""
+        s = _Img(img)
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        cap = max(4096, int(target_bytes) + 16)
+        buf = np.empty(cap, dtype=np.uint8)
+        n, q, st, v = C.c_size_t(0), C.c_int(), C.c_int(), C.c_double()
+        with self._ordered(img):
+            rc = self._chk(self._lib.fnx_jpeg_size_search(self._h, s.space, s.ptr, s.stride, s.w, s.h, int(target_bytes), int(bool(skip_ssim)), pk,
+                                                          buf.ctypes.data_as(_u8p), cap, C.byref(n), C.byref(q), C.byref(v), C.byref(st)),
+                           "fnx_jpeg_size_search")
+        if rc != FNX_OK:
+            return None
+        return buf[:n.value].tobytes(), q.value, v.value, st.value
 
     def jpeg_compress(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal on the device (fnx_jpeg_compress): search + the winning file -> (bytes, quality, ssim, steps)."""

@@ -1067,6 +1067,62 @@ int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, in
     return jpeg_file_from_planes(ctx, orig, w, h, quality, out, cap, nbytes);
 }
 
+int fnx_jpeg_size_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, long long target_bytes, int skip_ssim,
+                         const double *window, uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(nbytes && quality && ssim && (skip_ssim || window) && w > 0 && h > 0 && w <= 65535 && h <= 65535, "size search arguments");
+    FNX_TRY(check_img(src, sstride, w, h, "src"));
+    *nbytes = 0; *quality = 0; *ssim = 0.0;
+    DevImg s;
+    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, w, h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, w, h, orig.p[0], orig.p[1], orig.p[2]));
+    // targetsize.go:125-176
+    const double pixels = static_cast<double>(static_cast<long long>(w) * h);
+    const double bpp = static_cast<double>(target_bytes * 8) / pixels;
+    int lo = 1, hi = 100;
+    if (bpp < 0.5) hi = 40;
+    else if (bpp < 1.0) { lo = 10; hi = 70; }
+    else if (bpp < 2.0) { lo = 30; hi = 90; }
+    else if (bpp > 4.0) lo = 60;
+    int best_q = 0, n = 0;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        size_t sz = 0;
+        FNX_TRY(jpeg_file_from_planes(ctx, orig, w, h, mid, nullptr, 0, &sz));       // len(encoded) only
+        n++;
+        if (static_cast<long long>(sz) <= target_bytes) {
+            best_q = mid;
+            lo = mid + 1;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    if (steps) *steps = n;
+    if (best_q == 0) return FNX_NOOP;                        // bestBuf == nil: nothing fits (the caller tries its next strategy)
+    *quality = best_q;
+    if (!skip_ssim) {
+        // the SSIMFast the reference takes of every fitting candidate; the one that survives is the best quality's
+        fnx_prepared ref;
+        ref.w = w; ref.h = h;
+        const bool ds = ssim_fast_dims(w, h, &ref.pw, &ref.ph);
+        void *rp = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_JPEG3, static_cast<size_t>(ref.pw) * ref.ph * 4 + 16, &rp));
+        ref.pix = static_cast<uint8_t *>(rp);
+        if (ds) FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, w, h, ref.pix, ref.pw * 4, 0, ref.pw, ref.ph));
+        else FNX_HIP(hipMemcpy2DAsync(ref.pix, size_t(w) * 4, s.p, s.stride, size_t(w) * 4, h, hipMemcpyDeviceToDevice, ctx->stream));
+        void *dec = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_JPEG2, static_cast<size_t>(w) * h * 4 + 16, &dec));
+        FNX_TRY(jpeg_decode_at(ctx, orig, w, h, best_q, static_cast<uint8_t *>(dec), w * 4));
+        FNX_TRY(against_device(ctx, &ref, static_cast<const uint8_t *>(dec), w * 4, window, ssim));
+        ref.pix = nullptr;
+    }
+    return jpeg_file_from_planes(ctx, orig, w, h, best_q, out, cap, nbytes);
+}
+
 int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim, const double *window,
                       uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps)
 {

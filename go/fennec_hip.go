@@ -675,3 +675,33 @@ func jpegCompressHIP(src *image.NRGBA, targetSSIM float64) (data []byte, quality
 	}
 	return nil, 0, 0, false
 }
+
+// jpegQualitySearchOptHIP is jpegQualitySearchOpt (targetsize.go:125-176) on the device: every candidate's size from the
+// device's entropy coder, the winner's file and (unless skipSSIM) its SSIMFast.  ok == false: the device was not used;
+// data == nil with ok: no quality fits (the reference returns nil, nil).
+func jpegQualitySearchOptHIP(src *image.NRGBA, targetBytes int, skipSSIM bool) (data []byte, quality int, ssim float64, ok bool) {
+	w, h := src.Bounds().Dx(), src.Bounds().Dy()
+	c := poolGetIf(useDeviceSearch && w > 0 && h > 0)
+	if c == nil {
+		return nil, 0, 0, false
+	}
+	defer pool.put(c)
+	buf := make([]byte, targetBytes+16)
+	var n C.size_t
+	var q, steps C.int
+	var s C.double
+	skip := C.int(0)
+	if skipSSIM {
+		skip = 1
+	}
+	st := C.fnx_jpeg_size_search(c, C.FNX_HOST, pix(src), C.int(src.Stride), C.int(w), C.int(h), C.longlong(targetBytes), skip,
+		(*C.double)(unsafe.Pointer(&ssimWindow[0])), (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n, &q, &s, &steps)
+	runtime.KeepAlive(src)
+	switch st {
+	case C.FNX_OK:
+		return buf[:int(n)], int(q), float64(s), true
+	case C.FNX_NOOP:
+		return nil, 0, 0, true
+	}
+	return nil, 0, 0, false
+}

@@ -203,6 +203,14 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
  * Go's source: byte parity with jpeg.Encode is unpinned; libjpeg-turbo decodes the files. */
 int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
                     size_t *nbytes);
+/* jpegQualitySearchOpt (targetsize.go:125-176): the HIGHEST quality whose file fits target_bytes -- the bisection over
+ * [lo, hi] the reference picks from the bits per pixel, every candidate's size from the device's entropy coder
+ * (nothing is copied for a candidate), then the winner's file into `out` and, unless skip_ssim, its SSIMFast against the
+ * source (the reference's computeSSIMNRGBA of the decoded winner).  FNX_NOOP: no quality fits (bestBuf == nil).
+ * FNX_ERR_INVALID with *nbytes set when cap is too small. */
+int fnx_jpeg_size_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, long long target_bytes, int skip_ssim,
+                         const double *window /* 64; may be NULL with skip_ssim */, uint8_t *out, size_t cap, size_t *nbytes,
+                         int *quality, double *ssim, int *steps /* may be NULL */);
 /* compressJPEGOptimal (compress.go:21-87) for one image in one call: the quality search of fnx_jpeg_quality_search, then
  * the file at the quality it found (100 when nothing reached the target) as fnx_jpeg_encode writes it -- one upload of
  * the source, no host codec.  *ssim is the winning candidate's SSIMFast (1.0 when none won, as the reference reports). */

@@ -294,3 +294,48 @@ def test_gpu_compress_batch_with_device_codec(ctx):
         assert (r.Quality, r.steps) == (wq, wn) and abs(r.SSIM - ws) <= 1e-9
         assert r.data == orc.jpeg_encode(src, wq) and r.CompressedSize == len(r.data)
         assert np.array_equal(orc.jpeg_decode(r.data), orc.jpeg_roundtrip(src, wq))
+
+
+def _oracle_size_search(img, target_bytes):
+    """targetsize.go:125-176 with the oracle's encoder."""
+    h, w = img.shape[:2]
+    bpp = float(target_bytes * 8) / float(w * h)
+    lo, hi = 1, 100
+    if bpp < 0.5:
+        hi = 40
+    elif bpp < 1.0:
+        lo, hi = 10, 70
+    elif bpp < 2.0:
+        lo, hi = 30, 90
+    elif bpp > 4.0:
+        lo = 60
+    best, best_q, n = None, 0, 0
+    while lo <= hi:
+        mid = (lo + hi) // 2
+        data = orc.jpeg_encode(img, mid)
+        n += 1
+        if len(data) <= target_bytes:
+            best, best_q, lo = data, mid, mid + 1
+        else:
+            hi = mid - 1
+    return best, best_q, n
+
+
+@pytest.mark.gpu
+def test_gpu_size_search_matches_oracle_search(ctx):
+    """fnx_jpeg_size_search = jpegQualitySearchOpt: the highest quality whose file fits, its file, its SSIMFast."""
+    import torch
+    imgs = [synth.large_photo(1280, 720, 3), orc.gaussian_blur(synth.noise_image(800, 600, 2), 2.0), synth.noise_image(300, 200, 9)]
+    for img in imgs:
+        full = len(orc.jpeg_encode(img, 100))
+        for target in (full * 2, full // 2, full // 5, full // 20, 700, 10):
+            want, wq, wn = _oracle_size_search(img, target)
+            got = ctx.jpeg_size_search(img, target)
+            if want is None:
+                assert got is None, target
+                continue
+            data, q, s, n = got
+            assert (q, n) == (wq, wn) and data == want and len(data) <= target, (target, q, wq)
+            assert abs(s - orc.ssim_fast(img, orc.jpeg_roundtrip(img, q), procs=8)) <= 1e-9
+            d2 = ctx.jpeg_size_search(torch.from_numpy(img).cuda(), target, skip_ssim=True)
+            assert d2[0] == data and d2[1] == q and d2[2] == 0.0
