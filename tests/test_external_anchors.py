@@ -69,3 +69,25 @@ def test_ssim_of_shifted_means_follows_the_closed_form():
     want = (2 * la * lb + 6.5025) / (la * la + lb * lb + 6.5025)
     assert abs(orc.ssim(a, b) - want) < 1e-12
     assert abs(orc.ssim_fast(a, b) - want) < 1e-12
+
+
+def test_orientations_are_the_references_permutations():
+    """Orientations 2, 3, 4, 6, 8 are the EXIF table's (what Pillow's exif_transpose applies).  For 5 and 7 the reference
+    composes rot270 + flipH and rot90 + flipH (exif.go:188-197), which is the ANTI-diagonal flip for 5 and the diagonal one
+    for 7 -- the opposite of the EXIF table's transpose / transverse.  The path reproduces the reference, quirk included."""
+    from PIL import Image
+    img = synth.noise_image(37, 23, 6, alpha=True)
+    pil = Image.fromarray(img, "RGBA")
+    ops = {2: Image.FLIP_LEFT_RIGHT, 3: Image.ROTATE_180, 4: Image.FLIP_TOP_BOTTOM, 6: Image.ROTATE_270, 8: Image.ROTATE_90}
+    for o, op in ops.items():                                        # Pillow's ROTATE_270 is 90 degrees clockwise
+        assert np.array_equal(orc.apply_orientation(img, o), np.asarray(pil.transpose(op))), o
+    assert np.array_equal(orc.apply_orientation(img, 5), np.asarray(pil.transpose(Image.TRANSVERSE)))
+    assert np.array_equal(orc.apply_orientation(img, 7), np.asarray(pil.transpose(Image.TRANSPOSE)))
+
+
+def test_msssim_and_ssim_identity_and_symmetry():
+    a = synth.large_photo(200, 150, 1)
+    b = orc.gaussian_blur(a, 1.5)
+    assert orc.ssim(a, a) == 1.0 and abs(orc.msssim(a, a) - 1.0) < 1e-12
+    assert abs(orc.ssim(a, b) - orc.ssim(b, a)) < 1e-15               # the formula is symmetric in its arguments
+    assert 0.0 < orc.msssim(a, b) < 1.0
