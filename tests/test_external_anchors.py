@@ -91,3 +91,21 @@ def test_msssim_and_ssim_identity_and_symmetry():
     assert orc.ssim(a, a) == 1.0 and abs(orc.msssim(a, a) - 1.0) < 1e-12
     assert abs(orc.ssim(a, b) - orc.ssim(b, a)) < 1e-15               # the formula is symmetric in its arguments
     assert 0.0 < orc.msssim(a, b) < 1.0
+
+
+def test_adaptive_sharpen_against_scipy_sobel():
+    """effects.go:49-112 from its description: Sobel magnitude of BT.601 luminance / 400, capped at 1, scales an unsharp
+    mask of the 3x3 binomial blur with amount 1 + 2 s; border pixels are copies."""
+    from scipy.ndimage import convolve, sobel
+    img = orc.gaussian_blur(synth.large_photo(120, 90, 5), 1.0)
+    s = 0.6
+    lum = 0.299 * img[..., 0].astype(np.float64) + 0.587 * img[..., 1] + 0.114 * img[..., 2]
+    e = np.minimum(1.0, np.hypot(sobel(lum, axis=1, mode="nearest"), sobel(lum, axis=0, mode="nearest")) / 400.0)
+    k = np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=np.int64)
+    blur = np.stack([(convolve(img[..., c].astype(np.int64), k, mode="nearest") + 8) >> 4 for c in range(3)], axis=-1)
+    o = img[..., :3].astype(np.float64)
+    want = np.clip(np.floor(o + (1.0 + 2.0 * s) * e[..., None] * (o - blur) + 0.5), 0, 255).astype(np.uint8)
+    mine = orc.adaptive_sharpen(img, s)
+    d = np.abs(mine[1:-1, 1:-1, :3].astype(int) - want[1:-1, 1:-1].astype(int))
+    assert d.max() <= 1 and (d != 0).mean() < 0.002, (d.max(), (d != 0).mean())   # the order of the fp64 operations differs
+    assert np.array_equal(mine[0], img[0]) and np.array_equal(mine[..., 3], img[..., 3])
