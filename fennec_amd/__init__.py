@@ -64,6 +64,12 @@ class ImageStats(C.Structure):
                 ("MeanBrightness", C.c_double), ("Contrast", C.c_double), ("EstimatedCompression", C.c_double)]
 
 
+class NativeBatchResult(C.Structure):
+    """fennec_BatchResult (include/fennec_hip.h)."""
+    _fields_ = [("index", C.c_int32), ("failed", C.c_int32), ("has_result", C.c_int32), ("quality", C.c_int32), ("steps", C.c_int32),
+                ("status", C.c_int32), ("original_size", C.c_int64), ("compressed_size", C.c_int64), ("ssim", C.c_double)]
+
+
 class FennecError(RuntimeError):
     pass
 
@@ -140,6 +146,10 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_msssim_enqueue", i, [ctx] + img + img + [i, i, _f64p])
         _sig(L, "fennec_MSSSIM_enqueue", i, [ctx] + img + [i, i] + img + [i, i])
         _sig(L, "fnx_jpeg_encode", i, [ctx, i] + img + [i, i, i, _u8p, C.c_size_t, C.POINTER(C.c_size_t)])
+        _sig(L, "fennec_CompressBatchNRGBA", i, [i, i, i, i, C.POINTER(C.c_void_p), C.POINTER(i), C.POINTER(i), C.POINTER(i), _i64p, d,
+                                                  C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i),
+                                                  C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_SummarizeResults", d, [i, C.POINTER(NativeBatchResult), _i64p])
         _sig(L, "fnx_jpeg_size_search", i, [ctx, i] + img + [i, i, C.c_longlong, i, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
                                              _f64p, C.POINTER(i)])
         _sig(L, "fnx_jpeg_compress", i, [ctx, i] + img + [i, i, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,

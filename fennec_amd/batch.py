@@ -328,3 +328,50 @@ def summarize_distributed(results: Sequence[BatchResult], device=None, group=Non
     if ok > 0:
         out.AvgSSIM = out.ssim_sum / float(ok)
     return out
+
+
+def compress_batch_native(images: Sequence, target_ssim: float = TARGET_SSIM["Balanced"], workers: int = 4, device: int = 0,
+                          original_sizes: Optional[Sequence[int]] = None):
+    """fennec_CompressBatchNRGBA: CompressBatch's pool in C++ (std::thread workers, one fnx ctx each, one atomic queue of
+    indices) with compressJPEGOptimal on the device as the per-item work.  `images`: decoded NRGBA items, all numpy
+    (host space) or all torch CUDA tensors (device space).  -> (results, files, summary): BatchResult per item by index,
+    the JPEG bytes per item, BatchSummary."""
+    import ctypes as C
+
+    import fennec_amd as fa
+    L = fa.load_library()
+    n = len(images)
+    if n == 0:
+        return [], [], BatchSummary()
+    views = [fa._Img(im) for im in images]
+    space = views[0].space
+    if any(v.space != space for v in views):
+        raise fa.FennecError("compress_batch_native: all items in one space")
+    srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+    strides = (C.c_int * n)(*[v.stride for v in views])
+    ws = (C.c_int * n)(*[v.w for v in views])
+    hs = (C.c_int * n)(*[v.h for v in views])
+    osz = (C.c_int64 * n)(*[int(x) for x in original_sizes]) if original_sizes is not None else None
+    bufs = [np.empty(4096 + (v.w * v.h * 3) // 2, dtype=np.uint8) for v in views]
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    caps = (C.c_size_t * n)(*[b.size for b in bufs])
+    res = (fa.NativeBatchResult * n)()
+    if space == fa.FNX_DEVICE:
+        import torch
+        torch.cuda.synchronize()                       # the workers' contexts launch on their own streams
+    rc = L.fennec_CompressBatchNRGBA(int(device), int(workers), n, space, srcs, strides, ws, hs, osz, float(target_ssim), outs, caps, res,
+                                     None, None, None)
+    if rc != fa.FNX_OK:
+        raise fa.FennecError(f"fennec_CompressBatchNRGBA: {L.fnx_last_error().decode()}")
+    results, files = [], []
+    for i in range(n):
+        r = res[i]
+        br = BatchResult(Index=r.index, OriginalSize=int(r.original_size), CompressedSize=int(r.compressed_size), SSIM=float(r.ssim),
+                         Quality=int(r.quality), Err=None if not r.failed else f"status {r.status}", has_result=bool(r.has_result))
+        br.steps = int(r.steps)
+        results.append(br)
+        files.append(bufs[i][:int(r.compressed_size)].tobytes() if not r.failed else b"")
+    out4 = (C.c_int64 * 4)()
+    avg = L.fennec_SummarizeResults(n, res, out4)
+    summ = BatchSummary(Total=int(out4[0]), Succeeded=int(out4[1]), Failed=int(out4[2]), TotalSaved=int(out4[3]), AvgSSIM=float(avg))
+    return results, files, summ

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -345,6 +346,88 @@ double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
     out4[1] = succeeded;
     out4[2] = nfailed;
     out4[3] = saved;
+    return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
+}
+
+// ---- CompressBatch (batch.go:58-128), per-item work = compressJPEGOptimal on the device ----------------------------
+int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
+                              const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
+                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
+                              fennec_on_item on_item, void *user)
+{
+    if (n <= 0) return FNX_OK;                                   // batch.go:59-61
+    if (!srcs || !strides || !widths || !heights || !outs || !caps || !results) {
+        set_error("invalid argument: CompressBatch arrays");
+        return FNX_ERR_INVALID;
+    }
+    if (workers <= 0) workers = static_cast<int>(std::thread::hardware_concurrency());      // batch.go:63-66
+    if (workers <= 0) workers = 1;
+    if (workers > n) workers = n;                                // batch.go:67-69
+    for (int i = 0; i < n; i++) {
+        results[i] = fennec_BatchResult{};
+        results[i].index = i;
+        results[i].failed = 1;                                   // until a worker says otherwise
+        results[i].status = FNX_ERR_INVALID;
+    }
+    std::atomic<int> next{0}, started{0};
+    std::mutex done_mu;
+    int completed = 0;
+    auto worker = [&]() {
+        fnx_ctx *ctx = nullptr;
+        if (fnx_ctx_create(device, &ctx) != FNX_OK || !ctx) return;
+        started.fetch_add(1);
+        for (;;) {
+            const int idx = next.fetch_add(1);                   // the closed channel of indices (batch.go:72-81, 88)
+            if (idx >= n) break;
+            fennec_BatchResult &r = results[idx];
+            if (cancel && *cancel) {                             // ctx.Done() before starting new work (batch.go:90-99)
+                r.failed = 1; r.status = FNX_NOOP;
+                continue;
+            }
+            size_t nbytes = 0;
+            int q = 0, steps = 0;
+            double s = 0;
+            const int rc = fnx_jpeg_compress(ctx, space, srcs[idx], strides[idx], widths[idx], heights[idx], target_ssim, ssim_window(),
+                                             outs[idx], caps[idx], &nbytes, &q, &s, &steps);
+            r.status = rc;
+            r.failed = rc == FNX_OK ? 0 : 1;
+            r.has_result = rc == FNX_OK ? 1 : 0;
+            r.quality = q; r.steps = steps; r.ssim = s;
+            r.original_size = original_sizes ? original_sizes[idx] : static_cast<int64_t>(widths[idx]) * heights[idx] * 4;
+            r.compressed_size = static_cast<int64_t>(nbytes);
+            if (on_item) {                                       // batch.go:113-119
+                std::lock_guard<std::mutex> lk(done_mu);
+                on_item(++completed, n, user);
+            }
+        }
+        fnx_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; w++) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+    if (started.load() == 0) {
+        set_error("CompressBatch: no worker could create a context on device %d", device);
+        return FNX_ERR_HIP;
+    }
+    return FNX_OK;
+}
+
+double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t out4[4])
+{   // batch.go:140-158
+    int64_t succeeded = 0, nfailed = 0, saved = 0;
+    double ssimSum = 0;
+    for (int i = 0; i < n; i++) {
+        if (results[i].failed) {
+            nfailed++;
+            continue;
+        }
+        succeeded++;
+        if (results[i].has_result) {
+            saved += results[i].original_size - results[i].compressed_size;
+            ssimSum += results[i].ssim;
+        }
+    }
+    out4[0] = n; out4[1] = succeeded; out4[2] = nfailed; out4[3] = saved;
     return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
 }
 

@@ -399,6 +399,25 @@ int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
 int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
                          int srcH, uint8_t *dst, int dstride, int dstW, int dstH); /* ssim.go:244 */
 
+/* CompressBatch (batch.go:58-128) over decoded NRGBA items with compressJPEGOptimal (compress.go:21-87) as the per-item
+ * work, all of it on the device (fnx_jpeg_compress): `workers` threads, ONE closed queue of indices (an atomic counter:
+ * the channel of batch.go:72-81), one fnx_ctx per worker on `device`, results stored by index, `on_item(completed,
+ * total, user)` serialised as OnItem is, `*cancel != 0` checked before each item (ctx.Done(), batch.go:90-99).  Item i's
+ * file goes to outs[i] (capacity caps[i]); a result with failed != 0 carries the FNX_* status in `status`.
+ * Returns FNX_OK when the pool ran (per-item failures are in the results), an error when no worker could start. */
+typedef struct fennec_BatchResult {
+    int32_t index, failed, has_result, quality, steps, status;
+    int64_t original_size, compressed_size;
+    double ssim;
+} fennec_BatchResult;
+typedef void (*fennec_on_item)(int completed, int total, void *user);
+int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
+                              const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
+                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                              const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* Summarize (batch.go:140-158) of such results: out4 = {Total, Succeeded, Failed, TotalSaved}; returns AvgSSIM. */
+double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t out4[4]);
+
 /* Summarize (batch.go:140-158) over parallel arrays; out4 = {Total, Succeeded,
  * Failed, TotalSaved}; returns AvgSSIM.  Pure host arithmetic in index order. */
 double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,

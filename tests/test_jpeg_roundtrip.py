@@ -339,3 +339,21 @@ def test_gpu_size_search_matches_oracle_search(ctx):
             assert abs(s - orc.ssim_fast(img, orc.jpeg_roundtrip(img, q), procs=8)) <= 1e-9
             d2 = ctx.jpeg_size_search(torch.from_numpy(img).cuda(), target, skip_ssim=True)
             assert d2[0] == data and d2[1] == q and d2[2] == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_native_compress_batch_pool(ctx):
+    """fennec_CompressBatchNRGBA: the C++ pool (batch.go:58-128) with the device codec per item, against the per-item
+    calls and the oracle's files; Summarize (batch.go:140-158) against the python harness's; host and device items."""
+    import torch
+    imgs = [synth.large_photo(640 + 16 * k, 480 - 8 * k, k) for k in range(9)] + [orc.gaussian_blur(synth.noise_image(333, 217, 3), 2.0)]
+    for items in (imgs, [torch.from_numpy(i).cuda() for i in imgs]):
+        res, files, summ = batch.compress_batch_native(items, 0.94, workers=4, original_sizes=[4 * i.shape[0] * i.shape[1] for i in imgs])
+        assert [r.Index for r in res] == list(range(len(imgs))) and all(r.Err is None for r in res)
+        for r, f, img in zip(res, files, imgs):
+            data, q, s, n = ctx.jpeg_compress(img, 0.94)
+            assert (r.Quality, r.SSIM, r.steps, r.CompressedSize) == (q, s, n, len(data)) and f == data == orc.jpeg_encode(img, q)
+        want = batch.summarize_local(res)
+        assert (summ.Total, summ.Succeeded, summ.Failed, summ.TotalSaved) == (want.Total, want.Succeeded, want.Failed, want.TotalSaved)
+        assert summ.AvgSSIM == want.AvgSSIM
+    assert batch.compress_batch_native([]) == ([], [], batch.BatchSummary())
