@@ -52,6 +52,10 @@ jpegs = [batch.pillow_encode(synth.large_photo(640, 480, k), 92) for k in range(
 states = {}
 res = batch.compress_batch(len(jpegs), batch.jpeg_item_work(jpegs), lambda wid: states.setdefault(wid, fennec_amd.Context(0)), workers=4)
 assert all(r.Err is None for r in res), [r.Err for r in res]
+# ... and its C++ twin: std::thread workers inside the library (fennec_CompressBatchNRGBA)
+items = [synth.large_photo(320 + 16 * k, 240, k) for k in range(10)]
+nres, nfiles, nsumm = batch.compress_batch_native(items, workers=4)
+assert all(r.Err is None for r in nres) and nsumm.Succeeded == len(items)
 print("errors:", errs)
 print("done" if not errs else "FAILED")
 sys.exit(1 if errs else 0)
