@@ -901,6 +901,20 @@ def other_workloads(args) -> int:
                                      "of a step is the host codec: one decode and one encode per image") if args.device_search else
                                     ("time inside the C ABI (prepare + every SSIMFast of the search, host buffers: PCIe-inclusive); "
                                      "the rest of a step is the host JPEG codec (Pillow here, Go's image/jpeg in the reference)")}
+        if rank == 0 and world == 1 and args.device_codec and not args.no_extras:
+            # the GPU stage alone -- decoded sources resident on the device, the C++ pool of
+            # fennec_CompressBatchNRGBA (search + entropy coder per item on the device), files copied to the host
+            dres = [torch.from_numpy(s_).cuda() for s_ in srcs[:B]]
+            torch.cuda.synchronize()
+            fbatch.compress_batch_native(dres, workers=4)
+            t_g = time.perf_counter()
+            for _ in range(3):
+                fbatch.compress_batch_native(dres, workers=4)
+            t_g = (time.perf_counter() - t_g) / 3
+            out["gpu_stage_only"] = {"value": round(len(dres) / t_g, 1), "unit": "images/s", "workers": 4,
+                                     "note": "fennec_CompressBatchNRGBA over device-resident decoded sources, 3 runs after the timed region "
+                                             "(python-side buffer handling included; tools/time_batch_native.py times the pool alone)"}
+            del dres
     if wl == "analyze":
         ms = float(np.mean(pass_ms[-args.steps:]))
         g = alg * B / (ms * 1e-3) / 1e9

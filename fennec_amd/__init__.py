@@ -149,6 +149,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fennec_CompressBatchNRGBA", i, [i, i, i, i, C.POINTER(C.c_void_p), C.POINTER(i), C.POINTER(i), C.POINTER(i), _i64p, d,
                                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i),
                                                   C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_pool_release", None, [])
         _sig(L, "fennec_SummarizeResults", d, [i, C.POINTER(NativeBatchResult), _i64p])
         _sig(L, "fnx_jpeg_size_search", i, [ctx, i] + img + [i, i, C.c_longlong, i, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
                                              _f64p, C.POINTER(i)])

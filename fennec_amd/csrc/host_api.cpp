@@ -350,6 +350,44 @@ double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
 }
 
 // ---- CompressBatch (batch.go:58-128), per-item work = compressJPEGOptimal on the device ----------------------------
+// Workers' contexts outlive a batch: creating one (streams, events) and growing its scratch to 4K size costs ~10 ms, a
+// 32-image batch ~25.  Idle contexts wait here, per device, until fennec_pool_release().
+namespace {
+std::mutex g_pool_mu;
+std::vector<std::pair<int, fnx_ctx *>> g_pool;
+
+fnx_ctx *pool_take(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].first == device) {
+                fnx_ctx *c = g_pool[i].second;
+                g_pool.erase(g_pool.begin() + static_cast<long>(i));
+                return c;
+            }
+    }
+    fnx_ctx *c = nullptr;
+    return fnx_ctx_create(device, &c) == FNX_OK ? c : nullptr;
+}
+
+void pool_give(int device, fnx_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.emplace_back(device, c);
+}
+}  // namespace
+
+void fennec_pool_release(void)
+{
+    std::vector<std::pair<int, fnx_ctx *>> all;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        all.swap(g_pool);
+    }
+    for (auto &e : all) fnx_ctx_destroy(e.second);
+}
+
 int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
                               const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
@@ -373,8 +411,8 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
     std::mutex done_mu;
     int completed = 0;
     auto worker = [&]() {
-        fnx_ctx *ctx = nullptr;
-        if (fnx_ctx_create(device, &ctx) != FNX_OK || !ctx) return;
+        fnx_ctx *ctx = pool_take(device);
+        if (!ctx) return;
         started.fetch_add(1);
         for (;;) {
             const int idx = next.fetch_add(1);                   // the closed channel of indices (batch.go:72-81, 88)
@@ -400,7 +438,7 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                 on_item(++completed, n, user);
             }
         }
-        fnx_ctx_destroy(ctx);
+        pool_give(device, ctx);
     };
     std::vector<std::thread> pool;
     for (int w = 0; w < workers; w++) pool.emplace_back(worker);

@@ -415,6 +415,8 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                               const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                               const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* The pool's idle worker contexts (kept between batches, per device) are destroyed. */
+void fennec_pool_release(void);
 /* Summarize (batch.go:140-158) of such results: out4 = {Total, Succeeded, Failed, TotalSaved}; returns AvgSSIM. */
 double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t out4[4]);
 
