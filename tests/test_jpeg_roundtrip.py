@@ -357,3 +357,40 @@ def test_gpu_native_compress_batch_pool(ctx):
         assert (summ.Total, summ.Succeeded, summ.Failed, summ.TotalSaved) == (want.Total, want.Succeeded, want.Failed, want.TotalSaved)
         assert summ.AvgSSIM == want.AvgSSIM
     assert batch.compress_batch_native([]) == ([], [], batch.BatchSummary())
+
+
+@pytest.mark.gpu
+def test_gpu_native_pool_callbacks_cancel_and_release():
+    """fennec_CompressBatchNRGBA's OnItem callback (serialised, 1..n), its cancel flag (ctx.Done(): every item reports
+    failed, nothing is encoded) and fennec_pool_release (idle worker contexts destroyed; the next batch makes new ones)."""
+    import ctypes as C
+    import fennec_amd as fa
+    L = fa.load_library()
+    imgs = [synth.large_photo(320, 240, k) for k in range(7)]
+    n = len(imgs)
+    views = [fa._Img(i) for i in imgs]
+    srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+    strides = (C.c_int * n)(*[v.stride for v in views]); ws = (C.c_int * n)(*[v.w for v in views]); hs = (C.c_int * n)(*[v.h for v in views])
+    bufs = [np.empty(200000, dtype=np.uint8) for _ in imgs]
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * n)(*[b.size for b in bufs])
+    res = (fa.NativeBatchResult * n)()
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
+    cb = CB(lambda c, t, u: seen.append((c, t)))
+    L.fennec_CompressBatchNRGBA.argtypes = L.fennec_CompressBatchNRGBA.argtypes[:-2] + [CB, C.c_void_p]
+    cancel = C.c_int(0)
+    assert L.fennec_CompressBatchNRGBA(0, 3, n, fa.FNX_HOST, srcs, strides, ws, hs, None, 0.94, outs, caps, res, C.byref(cancel), cb, None) == fa.FNX_OK
+    assert sorted(c for c, _ in seen) == list(range(1, n + 1)) and all(t == n for _, t in seen)
+    assert all(not r.failed and r.has_result and r.original_size == 4 * 320 * 240 for r in res)
+    assert bufs[0][:res[0].compressed_size].tobytes() == orc.jpeg_encode(imgs[0], res[0].quality)
+    cancel.value = 1
+    seen.clear()
+    assert L.fennec_CompressBatchNRGBA(0, 3, n, fa.FNX_HOST, srcs, strides, ws, hs, None, 0.94, outs, caps, res, C.byref(cancel), cb, None) == fa.FNX_OK
+    assert all(r.failed and not r.has_result for r in res) and not seen
+    out4 = (C.c_int64 * 4)()
+    assert L.fennec_SummarizeResults(n, res, out4) == 0.0 and list(out4) == [n, 0, n, 0]
+    L.fennec_pool_release()
+    cancel.value = 0
+    assert L.fennec_CompressBatchNRGBA(0, 2, n, fa.FNX_HOST, srcs, strides, ws, hs, None, 0.94, outs, caps, res, C.byref(cancel), cb, None) == fa.FNX_OK
+    assert all(not r.failed for r in res)
+    L.fennec_pool_release()
