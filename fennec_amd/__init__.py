@@ -70,8 +70,16 @@ class NativeBatchResult(C.Structure):
                 ("status", C.c_int32), ("original_size", C.c_int64), ("compressed_size", C.c_int64), ("ssim", C.c_double)]
 
 
+FNX_ERR_UNSUPPORTED = -5
+
+
 class FennecError(RuntimeError):
     pass
+
+
+class FennecUnsupported(FennecError):
+    """fnx_jpeg_decode / fnx_jpeg_recompress: a file the device decoder does not take (FNX_ERR_UNSUPPORTED) -- decode it
+    on the host."""
 
 
 _lib = None
@@ -156,6 +164,9 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_jpeg_compress", i, [ctx, i] + img + [i, i, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
                                           C.POINTER(i)])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
+        _sig(L, "fnx_jpeg_decode", i, [ctx, _u8p, C.c_size_t, i, C.c_void_p, i, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fnx_jpeg_recompress", i, [ctx, _u8p, C.c_size_t, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
+                                            C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
@@ -269,6 +280,8 @@ class Context:
         return (self._lib.fnx_last_error() or b"").decode()
 
     def _chk(self, rc: int, what: str) -> int:
+        if rc == FNX_ERR_UNSUPPORTED:
+            raise FennecUnsupported(f"{what} ({rc}): {self._err()}")
         if rc < 0:
             raise FennecError(f"{what} failed ({rc}): {self._err()}")
         return rc
@@ -545,6 +558,48 @@ class Context:
                     break
                 cap = n.value
         self._chk(rc, "fnx_jpeg_compress")
+
+    def jpeg_decode_config(self, data: bytes):
+        """jpeg.DecodeConfig as far as the device decoder goes: (w, h); FennecUnsupported for files it does not take."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        w, h = C.c_int(), C.c_int()
+        self._chk(self._lib.fnx_jpeg_decode(self._h, buf.ctypes.data_as(_u8p), len(data), FNX_HOST, None, 0, C.byref(w), C.byref(h)),
+                  "fnx_jpeg_decode")
+        return w.value, h.value
+
+    def jpeg_decode(self, data: bytes, device: bool = False):
+        """toNRGBARef(jpeg.Decode(data)) on the device (fnx_jpeg_decode): the file's bytes go up, an (h, w, 4) uint8 array
+        comes back -- or, with device=True, a torch tensor that stays on the ctx's device."""
+        w, h = self.jpeg_decode_config(data)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        if device:
+            import torch
+            dst = torch.empty((h, w, 4), dtype=torch.uint8, device=f"cuda:{self.device}")
+        else:
+            dst = np.empty((h, w, 4), dtype=np.uint8)
+        d = _Img(dst)
+        with self._ordered(dst):
+            self._chk(self._lib.fnx_jpeg_decode(self._h, buf.ctypes.data_as(_u8p), len(data), d.space, d.ptr, d.stride, C.byref(C.c_int()),
+                                                C.byref(C.c_int())), "fnx_jpeg_decode")
+        return dst
+
+    def jpeg_recompress(self, data: bytes, target_ssim: float, window=None):
+        """CompressBatch's item body for a JPEG source on the device (fnx_jpeg_recompress): decode, quality search, the
+        winner's file -> (bytes, quality, ssim, steps, (w, h))."""
+        src = np.frombuffer(data, dtype=np.uint8)
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        cap = max(4096, 2 * len(data))
+        n, q, st, v, w, h = C.c_size_t(0), C.c_int(), C.c_int(), C.c_double(), C.c_int(), C.c_int()
+        for _ in range(2):
+            buf = np.empty(cap, dtype=np.uint8)
+            rc = self._lib.fnx_jpeg_recompress(self._h, src.ctypes.data_as(_u8p), len(data), float(target_ssim), pk, buf.ctypes.data_as(_u8p),
+                                               cap, C.byref(n), C.byref(q), C.byref(v), C.byref(st), C.byref(w), C.byref(h))
+            if rc == FNX_OK:
+                return buf[:n.value].tobytes(), q.value, v.value, st.value, (w.value, h.value)
+            if n.value <= cap:
+                break
+            cap = n.value
+        self._chk(rc, "fnx_jpeg_recompress")
 
     def jpeg_quality_search(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal's binary search with every candidate round-tripped and scored on the device

@@ -1142,6 +1142,62 @@ int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
     return jpeg_file_from_planes(ctx, orig, w, h, *quality, out, cap, nbytes);
 }
 
+// ---- image.Decode of a baseline JPEG on the device (third slice: jpeg_dec.hip) ----------------
+// toNRGBARef(jpeg.Decode(data)) into SLOT_JPEG_DEC_IMG (tight rows); *f describes the file
+static int jpeg_decode_device(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t **img)
+{
+    uint8_t *pl[3];
+    int ys = 0, cs = 0;
+    FNX_TRY(jpeg_decode_planes(ctx, data, n, f, pl, &ys, &cs));
+    void *t = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_IMG, static_cast<size_t>(f->w) * f->h * 4 + 16, &t));
+    *img = static_cast<uint8_t *>(t);
+    return launch_ycbcr_to_nrgba(ctx, pl[0], ys, pl[1], pl[2], cs, f->ratio, f->w, f->h, *img, f->w * 4);
+}
+
+int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(data != nullptr && w != nullptr && h != nullptr, "decode arguments");
+    JpegFile f;
+    if (dst == nullptr) {                        // jpeg.DecodeConfig: the dimensions only (and whether the device handles the file)
+        FNX_TRY(jpeg_parse(data, n, &f));
+        *w = f.w; *h = f.h;
+        return FNX_OK;
+    }
+    FNX_TRY(check_space_io(space));
+    FNX_TRY(jpeg_parse(data, n, &f));
+    *w = f.w; *h = f.h;
+    FNX_TRY(check_img(dst, dstride, f.w, f.h, "dst"));
+    DevOut d;
+    FNX_TRY(stage_out(ctx, space, dst, dstride, f.w, f.h, SLOT_OUT, &d));
+    uint8_t *pl[3];
+    int ys = 0, cs = 0;
+    FNX_TRY(jpeg_decode_planes(ctx, data, n, &f, pl, &ys, &cs));
+    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, pl[1], pl[2], cs, f.ratio, f.w, f.h, d.p, d.stride));
+    return finish(ctx, space, &d);
+}
+
+int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double target_ssim, const double *window, uint8_t *out, size_t cap,
+                        size_t *nbytes, int *quality, double *ssim, int *steps, int *w, int *h)
+{
+    FNX_TRY(bind(ctx));
+    FNX_REQUIRE(data && window && nbytes && quality && ssim && w && h, "recompress arguments");
+    *nbytes = 0;
+    JpegFile f;
+    uint8_t *img = nullptr;
+    FNX_TRY(jpeg_decode_device(ctx, data, n, &f, &img));
+    *w = f.w; *h = f.h;
+    DevImg s;
+    s.p = img; s.stride = f.w * 4;
+    JpegPlanes orig;
+    FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, f.w, f.h, &orig));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, f.w, f.h, orig.p[0], orig.p[1], orig.p[2]));
+    bool found = false;
+    FNX_TRY(jpeg_search_device(ctx, s, orig, f.w, f.h, target_ssim, window, quality, ssim, steps, &found));
+    return jpeg_file_from_planes(ctx, orig, f.w, f.h, *quality, out, cap, nbytes);
+}
+
 void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
 {
     if (!p) return;

@@ -67,6 +67,7 @@ enum Slot {
     SLOT_JPEG2,
     SLOT_JPEG3,
     SLOT_JPEG_ENC, SLOT_JPEG_ENC2, SLOT_JPEG_LUT, SLOT_JPEG_ECS,   // jpeg.hip's entropy coder
+    SLOT_JPEG_DEC, SLOT_JPEG_DEC_PLANES, SLOT_JPEG_DEC_IMG,        // jpeg_dec.hip: the decoder's work arrays, its planes, toNRGBARef's image
     SLOT_DONE,       // workgroup counters of the kernels that finish their own reduction (ssim.hip), zero between launches
     SLOT_COUNT
 };
@@ -295,5 +296,29 @@ int jpeg_entropy_code(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *co
 size_t jpeg_ecs_capacity(unsigned long long total_bits);
 int jpeg_entropy_pack(fnx_ctx *ctx, int w, int h, unsigned long long total_bits, uint8_t *ecs, unsigned long long *totals);
 int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const in[3], uint8_t *const out[3]);
+
+// jpeg_dec.hip: Huffman decoding tables of one file (tables 0, 1: DC th 0, 1; 2, 3: AC th 0, 1) and what its segments say
+struct DecTables {                                   // tables 0, 1: DC (th 0, 1); 2, 3: AC (th 0, 1)
+    uint16_t fast[4][512];                           // by the next 9 bits: length << 8 | symbol; 0: a longer code
+    uint32_t limit[4][18];                           // [L]: (largest code of length L + 1) << (16 - L)
+    int32_t delta[4][18];                            // [L]: index of the first value of length L - its code
+    uint8_t value[4][256];
+};
+
+struct JpegFile {
+    int w = 0, h = 0;
+    int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 2 4:2:0
+    int hy = 1, vy = 1;          // Y blocks per MCU across / down
+    int nslots = 3;              // blocks per MCU
+    int mx = 0, my = 0;          // MCUs per row / column
+    uint32_t dcpack = 0, acpack = 0;
+    uint16_t q[3][64];           // per component, natural order
+    size_t scan = 0;             // offset of the entropy-coded segment in the file
+    int rounds = 0;              // cross-workgroup synchronisation rounds the decode took
+    DecTables tab;
+};
+int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);
+int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride);
+int launch_scan(fnx_ctx *ctx, const uint32_t *in, unsigned long long *out, unsigned long long *totals, int n, unsigned long long *grand);
 
 }  // namespace fnx

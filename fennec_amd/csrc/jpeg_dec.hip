@@ -1,0 +1,609 @@
+// Baseline JPEG decoding on the device -- SURVEY 8(f)2, third slice: image.Decode of CompressBatch's SOURCE
+// (batch.go:88-101 -> io.go:60-95) without the host codec, so that a JPEG crosses PCIe as its file bytes and the
+// quality search (jpeg.hip) starts from pixels that never left the GPU.
+//
+// A scan is one long Huffman-coded bit string: where a symbol starts depends on every symbol before it.  What makes it
+// parallel is that Huffman codes SELF-SYNCHRONISE: a decoder started at a wrong bit falls into step with the right one
+// after a few symbols, and from there on both produce the same thing.  (The decoder state here is more than the bit
+// position -- also the position inside the block and the block's place in the MCU, which picks the tables -- so "in
+// step" means all three agree.)  The string is cut into spans of 1024 bits, one per lane:
+//   1. jpeg_dsync_kernel<false>  every lane decodes its span from a guessed state (block start, first slot), notes
+//                                the state it ends in and the blocks it finished; then a lane whose predecessor ended
+//                                somewhere else than the lane assumed decodes again from there -- until nothing in the
+//                                workgroup changes.  No values are read, only code lengths.
+//   2. jpeg_dsync_kernel<true>   the same across workgroups: a workgroup whose predecessor's last lane ended somewhere
+//                                else than its first lane assumed repairs its chain (which stops as soon as a lane
+//                                ends where it ended before).  Launched until a round changes nothing.  When that
+//                                holds every lane's start state follows from the file's first bit: exact, whatever
+//                                the guesses were; content only decides how many rounds it takes.
+//   3. prefix sum of the finished-block counts = the block every lane starts in
+//   4. jpeg_dwrite_kernel        every lane decodes its span once more, now with the values, into the block-major
+//                                coefficient array (natural order; DC still as the difference)
+//   5. DC differences -> DC: one prefix sum over the blocks laid out component by component
+//   6. jpeg_didct_kernel         lane = block: dequantise, idct.go's IDCT, level shift, clamp, into the planes an
+//                                *image.YCbCr holds; convert.hip makes toNRGBARef's image of them
+// The host parses the segments, builds the decoding tables and removes the 0x00 stuffed behind every 0xff while it
+// copies the scan into pinned memory (one memchr pass).
+//
+// Handled: what jpeg.Encode, libjpeg and most cameras write -- baseline (SOF0), 8 bit, three components, 4:4:4 or
+// 4:2:0, one interleaved scan, no restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
+// host); a scan that ends early or holds a code outside its table is FNX_ERR_INVALID.  Restated from ITU T.81 and
+// reader.go / scan.go / huffman.go's published behaviour, not from Go's source: bit-exact against the CPU restatement
+// the tests hold (which libjpeg-turbo's files exercise), parity with Go unpinned.
+#include <cstring>
+#include <vector>
+#include "common.hpp"
+#include "devutil.hpp"
+#include "jpeg_idct.hpp"
+
+namespace fnx {
+
+constexpr int DEC_WPT = 32;                          // words of the bit string per lane
+constexpr int DEC_SPAN = 32 * DEC_WPT;               // ... in bits
+constexpr int DEC_WG_WORDS = 256 * DEC_WPT;
+constexpr int DEC_SEGW = 256 * (DEC_WPT + 1) + 4;    // a workgroup's words in LDS: one pad word per span (a span's words sit in
+                                                     // different banks than its neighbours'), 3 words of look-ahead
+
+struct DecArgs {
+    const uint32_t *ecs;                             // the scan without stuffing, bytes as in the file, zero-padded
+    const DecTables *tab;
+    unsigned long long *s_in, *s_out;                // per lane: the state it starts in / ends in
+    uint32_t *cnt;                                   // per lane: blocks finished inside its span
+    uint32_t *flag;                                  // <true>: set by a workgroup that decoded again
+    const unsigned long long *first_blk;             // write: exclusive prefix sum of cnt
+    int16_t *coef;                                   // write: [nblk][64], natural order, zeroed
+    uint32_t *err;                                   // write: != 0: a code outside its table or a run past the block
+    long long nwords;                                // words of ecs that may be read
+    int nlanes;                                      // spans in the string
+    int nblk, nslots;
+    uint32_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
+};
+
+// state: bit position | position in the block (0..63) << 40 | slot in the MCU << 48
+__device__ __forceinline__ unsigned long long dec_state(unsigned long long p, int z, int slot)
+{
+    return p | (static_cast<unsigned long long>(z) << 40) | (static_cast<unsigned long long>(slot) << 48);
+}
+
+__device__ __constant__ uint8_t c_unzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct DecShared {
+    uint32_t seg[DEC_SEGW];
+    unsigned long long out[256];
+    DecTables tab;
+    uint8_t unzig[64];
+};
+
+// the 64 bits of the workgroup's segment from bit `rel` on (bits past the first 33 are only valid while rel & 31 allows)
+__device__ __forceinline__ unsigned long long dec_window(const uint32_t *seg, uint32_t rel)
+{
+    const uint32_t wi = rel >> 5;
+    const uint32_t i0 = wi + (wi >> 5), i1 = (wi + 1) + ((wi + 1) >> 5);         // DEC_WPT == 32
+    const unsigned long long x = (static_cast<unsigned long long>(seg[i0]) << 32) | seg[i1];
+    return x << (rel & 31u);
+}
+
+// Decodes from (rel, z, slot) to the first symbol that starts at or after `end`.  WRITE: with the values.
+template <bool WRITE>
+__device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, uint32_t &rel, int &z, int &slot, uint32_t end, uint32_t &cnt,
+                                         long long blk, uint32_t &bad)
+{
+    while (rel < end) {
+        if (WRITE && blk + cnt >= a.nblk) break;                   // what follows the last block is padding
+        const unsigned long long win = dec_window(sh.seg, rel);
+        const uint32_t c16 = static_cast<uint32_t>(win >> 48);
+        const int t = z == 0 ? static_cast<int>((a.dcpack >> (4 * slot)) & 15u) : static_cast<int>((a.acpack >> (4 * slot)) & 15u);
+        uint32_t e = sh.tab.fast[t][c16 >> 7];
+        int len, sym;
+        if (e) {
+            len = static_cast<int>(e >> 8);
+            sym = static_cast<int>(e & 0xffu);
+        } else {
+            len = 16; sym = 0;
+            bool hit = false;
+            for (int L = 10; L <= 16; L++)
+                if (c16 < sh.tab.limit[t][L]) {
+                    len = L;
+                    sym = sh.tab.value[t][(static_cast<int>(c16 >> (16 - L)) + sh.tab.delta[t][L]) & 255];
+                    hit = true;
+                    break;
+                }
+            if (WRITE && !hit) bad |= 1u;
+        }
+        rel += static_cast<uint32_t>(len);
+        const int s = sym & 15;
+        int32_t v = 0;
+        if (WRITE && s) {                                          // receive + extend (T.81 F.2.2.1)
+            const uint32_t raw = static_cast<uint32_t>(dec_window(sh.seg, rel) >> (64 - s));
+            v = raw < (1u << (s - 1)) ? static_cast<int32_t>(raw) - (1 << s) + 1 : static_cast<int32_t>(raw);
+        }
+        if (z == 0) {
+            if (WRITE) {
+                if (sym > 11) bad |= 2u;
+                a.coef[(blk + cnt) * 64] = static_cast<int16_t>(v);
+            }
+            rel += static_cast<uint32_t>(s);
+            z = 1;
+        } else if (s) {
+            z += sym >> 4;
+            if (WRITE) {
+                if (z > 63) bad |= 4u;
+                else a.coef[(blk + cnt) * 64 + sh.unzig[z]] = static_cast<int16_t>(v);
+            }
+            rel += static_cast<uint32_t>(s);
+            z++;
+        } else if ((sym >> 4) == 15) {
+            z += 16;
+        } else {
+            z = 64;                                                // end of block
+        }
+        if (z >= 64) {
+            z = 0;
+            slot = slot + 1 == a.nslots ? 0 : slot + 1;
+            cnt++;
+        }
+    }
+}
+
+__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, int g)
+{
+    const long long base = static_cast<long long>(g) * DEC_WG_WORDS;
+    for (int i = threadIdx.x; i < DEC_WG_WORDS + 3; i += 256) {
+        const long long w = base + i;
+        sh.seg[i + (i >> 5)] = w < a.nwords ? __builtin_bswap32(a.ecs[w]) : 0u;
+    }
+    const uint32_t *tw = reinterpret_cast<const uint32_t *>(a.tab);
+    uint32_t *sw = reinterpret_cast<uint32_t *>(&sh.tab);
+    for (int i = threadIdx.x; i < static_cast<int>(sizeof(DecTables) / 4); i += 256) sw[i] = tw[i];
+    if (threadIdx.x < 64) sh.unzig[threadIdx.x] = c_unzig[threadIdx.x];
+}
+
+template <bool FIX>
+__global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
+{
+    __shared__ DecShared sh;
+    const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
+    const bool live = gt < a.nlanes;
+    const unsigned long long wg_bit = static_cast<unsigned long long>(g) * 256u * DEC_SPAN;
+    unsigned long long my_in, my_out = 0;
+    uint32_t my_cnt = 0;
+    bool need;
+    if (!FIX) {
+        my_in = dec_state(static_cast<unsigned long long>(gt) * DEC_SPAN, 0, 0);
+        my_out = my_in;
+        need = live;
+    } else {
+        if (g == 0) return;
+        // every lane reads the same two words: the branch is uniform
+        const unsigned long long prev = __hip_atomic_load(&a.s_out[g * 256 - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == a.s_in[g * 256]) return;
+        my_in = live ? a.s_in[gt] : 0;
+        my_out = live ? a.s_out[gt] : 0;
+        my_cnt = live ? a.cnt[gt] : 0;
+        need = t == 0;
+        if (t == 0) my_in = prev;
+    }
+    dec_stage(sh, a, g);
+    sh.out[t] = my_out;
+    __syncthreads();
+    const uint32_t end = static_cast<uint32_t>(t + 1) * DEC_SPAN;
+    for (;;) {
+        if (need) {
+            uint32_t rel = static_cast<uint32_t>((my_in & 0xffffffffffull) - wg_bit);
+            int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
+            uint32_t bad = 0;
+            my_cnt = 0;
+            dec_span<false>(sh, a, rel, z, slot, end, my_cnt, 0, bad);
+            my_out = dec_state(wg_bit + rel, z, slot);
+            sh.out[t] = my_out;
+        }
+        __syncthreads();
+        need = false;
+        if (t > 0 && live) {
+            const unsigned long long pv = sh.out[t - 1];
+            if (pv != my_in) {
+                my_in = pv;
+                need = true;
+            }
+        }
+        if (!__syncthreads_or(need ? 1 : 0)) break;
+    }
+    if (live) {
+        a.s_in[gt] = my_in;
+        __hip_atomic_store(&a.s_out[gt], my_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.cnt[gt] = my_cnt;
+    }
+    if (FIX && t == 0) a.flag[0] = 1u;
+}
+
+__global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
+{
+    __shared__ DecShared sh;
+    const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
+    dec_stage(sh, a, g);
+    __syncthreads();
+    if (gt >= a.nlanes) return;
+    const unsigned long long st = a.s_in[gt];
+    const long long blk = static_cast<long long>(a.first_blk[gt]);
+    if (blk >= a.nblk) return;                                     // padding behind the last block
+    const unsigned long long wg_bit = static_cast<unsigned long long>(g) * 256u * DEC_SPAN;
+    uint32_t rel = static_cast<uint32_t>((st & 0xffffffffffull) - wg_bit);
+    int z = static_cast<int>((st >> 40) & 0xffu), slot = static_cast<int>(st >> 48);
+    uint32_t cnt = 0, bad = 0;
+    dec_span<true>(sh, a, rel, z, slot, static_cast<uint32_t>(t + 1) * DEC_SPAN, cnt, blk, bad);
+    if (bad) atomicOr(a.err, bad);
+}
+
+// ---- DC prediction and the blocks ----
+struct DcArgs {
+    const int16_t *coef;
+    uint32_t *dcb;            // [nblk] DC difference + 2048, component by component (Y in scan order, then Cb, then Cr)
+    int nblk, nmcu, ny;       // ny: Y blocks per MCU (4 or 1)
+};
+
+// scan-order block -> its place in the component-major array
+__device__ __forceinline__ int dc_place(int b, int nmcu, int ny)
+{
+    const int per = ny + 2, m = b / per, j = b - m * per;
+    return j < ny ? m * ny + j : (ny + (j - ny)) * nmcu + m;
+}
+
+__global__ __launch_bounds__(256) void jpeg_dc_gather_kernel(DcArgs a)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.nblk) return;
+    a.dcb[dc_place(b, a.nmcu, a.ny)] = static_cast<uint32_t>(static_cast<int32_t>(a.coef[static_cast<size_t>(b) * 64]) + 2048);
+}
+
+struct IdctArgs {
+    const int16_t *coef;
+    const uint32_t *dcb;
+    const unsigned long long *dcsum;     // exclusive prefix sum of dcb
+    uint8_t *out[3];
+    int stride[3], nbx[3], nblocks[3];
+    int mx, nmcu, hy, vy;                // MCUs per row, MCUs, Y blocks per MCU across / down
+    uint16_t q[3][64];                   // natural order
+};
+
+__global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
+{
+    const int plane = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nblocks[plane]) return;
+    const int by = i / a.nbx[plane], bx = i - by * a.nbx[plane];
+    const int ny = a.hy * a.vy, per = ny + 2;
+    int sb, place, start;
+    if (plane == 0) {
+        const int m = (by / a.vy) * a.mx + bx / a.hy, j = (by % a.vy) * a.hy + bx % a.hy;
+        sb = m * per + j;
+        place = m * ny + j;
+        start = 0;
+    } else {
+        const int m = by * a.mx + bx;
+        sb = m * per + ny + plane - 1;
+        start = (ny + plane - 1) * a.nmcu;
+        place = start + m;
+    }
+    const int16_t *cp = a.coef + static_cast<size_t>(sb) * 64;
+    int32_t b[64];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(cp + 8 * r);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int32_t cv = static_cast<int16_t>((w[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+            b[8 * r + c] = cv * static_cast<int32_t>(a.q[plane][8 * r + c]);
+        }
+    }
+    // the block's DC: the sum of its component's differences up to it
+    const long long dsum = static_cast<long long>(a.dcsum[place] - a.dcsum[start]) + a.dcb[place] - 2048ll * (place - start + 1);
+    b[0] = static_cast<int32_t>(dsum) * static_cast<int32_t>(a.q[plane][0]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) idct8_row(b[8 * r], b[8 * r + 1], b[8 * r + 2], b[8 * r + 3], b[8 * r + 4], b[8 * r + 5], b[8 * r + 6], b[8 * r + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; c++) idct8_col(b[c], b[8 + c], b[16 + c], b[24 + c], b[32 + c], b[40 + c], b[48 + c], b[56 + c]);
+    const int stride = a.stride[plane];
+    uint8_t *op = a.out[plane] + static_cast<size_t>(8 * by) * stride + 8 * bx;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        u32x2 v = {0, 0};
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int32_t s = b[8 * r + c];
+            const uint32_t u = s < -128 ? 0u : (s > 127 ? 255u : static_cast<uint32_t>(s + 128));      // reader.go: level shift, clip
+            if (c < 4) v.x |= u << (8 * c); else v.y |= u << (8 * (c - 4));
+        }
+        *reinterpret_cast<u32x2 *>(op + static_cast<size_t>(r) * stride) = v;
+    }
+}
+
+// ---- the host side: segments, tables, the scan without its stuffing ----
+static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+static int unsupported(const char *what)
+{
+    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 3 components, 4:4:4 or 4:2:0, one scan, no restart intervals)", what);
+    return FNX_ERR_UNSUPPORTED;
+}
+
+static int corrupt(const char *what)
+{
+    set_error("jpeg decode: %s", what);
+    return FNX_ERR_INVALID;
+}
+
+int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
+{
+    if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return corrupt("no SOI marker");
+    bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
+    uint8_t q[4][64];
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    std::memset(&f->tab, 0, sizeof(f->tab));
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 4 > n) return corrupt("the file ends before its scan");
+        if (data[pos] != 0xff) return corrupt("a segment does not start with a marker");
+        const uint8_t m = data[pos + 1];
+        if (m == 0xff) { pos++; continue; }                              // fill bytes
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
+        if (m == 0xd9) return corrupt("EOI before any scan");
+        const size_t len = (static_cast<size_t>(data[pos + 2]) << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > n) return corrupt("a segment runs past the end of the file");
+        const uint8_t *seg = data + pos + 4;
+        const size_t sl = len - 2;
+        if (m == 0xdb) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (pq != 0) return unsupported("a 16-bit quantisation table");
+                if (tq > 3 || o + 65 > sl) return corrupt("bad DQT segment");
+                for (int zig = 0; zig < 64; zig++) q[tq][UNZIG_H[zig]] = seg[o + 1 + zig];
+                have_q[tq] = true;
+                o += 65;
+            }
+        } else if (m == 0xc0) {
+            if (have_sof) return corrupt("two SOF segments");
+            if (sl < 6) return corrupt("bad SOF segment");
+            if (seg[0] != 8) return unsupported("a sample precision other than 8 bits");
+            if (seg[5] != 3) return unsupported("a component count other than 3");
+            if (sl < 6 + 9) return corrupt("bad SOF segment");
+            f->h = (seg[1] << 8) | seg[2];
+            f->w = (seg[3] << 8) | seg[4];
+            if (f->w <= 0 || f->h <= 0) return unsupported("a zero dimension (DNL)");
+            for (int c = 0; c < 3; c++) {
+                comp_id[c] = seg[6 + 3 * c];
+                comp_h[c] = seg[7 + 3 * c] >> 4;
+                comp_v[c] = seg[7 + 3 * c] & 15;
+                comp_q[c] = seg[8 + 3 * c];
+                if (comp_q[c] > 3) return corrupt("bad quantisation table selector");
+            }
+            have_sof = true;
+        } else if (m == 0xc1 || m == 0xc2 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            return unsupported(m == 0xc2 ? "a progressive file" : "a frame type other than baseline");
+        } else if (m == 0xcc) {
+            return unsupported("arithmetic coding");
+        } else if (m == 0xc4) {
+            size_t o = 0;
+            while (o < sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || o + 17 > sl) return corrupt("bad DHT segment");
+                if (th > 1) return unsupported("a Huffman table selector above 1");
+                const int t = tc * 2 + th;
+                int total = 0;
+                for (int L = 1; L <= 16; L++) total += seg[o + L];
+                if (total > 256 || o + 17 + total > sl) return corrupt("bad DHT segment");
+                std::memset(f->tab.fast[t], 0, sizeof(f->tab.fast[t]));
+                uint32_t code = 0;
+                int k = 0;
+                for (int L = 1; L <= 16; L++) {
+                    const int cnt = seg[o + L];
+                    f->tab.delta[t][L] = k - static_cast<int32_t>(code);
+                    for (int j = 0; j < cnt; j++, k++, code++) {
+                        if (code >= (1u << L)) return corrupt("a Huffman table with more codes than its lengths allow");
+                        f->tab.value[t][k] = seg[o + 17 + k];
+                        if (L <= 9)
+                            for (uint32_t x = code << (9 - L); x < ((code + 1) << (9 - L)); x++)
+                                f->tab.fast[t][x] = static_cast<uint16_t>((L << 8) | seg[o + 17 + k]);
+                    }
+                    f->tab.limit[t][L] = code << (16 - L);
+                    code <<= 1;
+                }
+                have_t[t] = true;
+                o += 17 + total;
+            }
+        } else if (m == 0xdd) {
+            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return unsupported("a restart interval");
+        } else if (m == 0xee) {
+            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return unsupported("an Adobe colour transform other than YCbCr");
+        } else if (m == 0xda) {
+            if (!have_sof) return corrupt("SOS before SOF");
+            if (sl < 1 || seg[0] != 3) return unsupported("a scan that does not interleave all three components");
+            if (sl < 1 + 6 + 3) return corrupt("bad SOS segment");
+            int td[3], ta[3];
+            for (int c = 0; c < 3; c++) {
+                if (seg[1 + 2 * c] != comp_id[c]) return unsupported("scan components out of frame order");
+                td[c] = seg[2 + 2 * c] >> 4;
+                ta[c] = seg[2 + 2 * c] & 15;
+                if (td[c] > 1 || ta[c] > 1) return unsupported("a Huffman table selector above 1");
+                if (!have_t[td[c]] || !have_t[2 + ta[c]]) return corrupt("the scan uses a Huffman table the file does not define");
+                if (!have_q[comp_q[c]]) return corrupt("the frame uses a quantisation table the file does not define");
+            }
+            if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return unsupported("an RGB file");
+            const bool chroma11 = comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
+            if (chroma11 && comp_h[0] == 2 && comp_v[0] == 2) {
+                f->ratio = 2; f->hy = 2; f->vy = 2;
+            } else if (chroma11 && comp_h[0] == 1 && comp_v[0] == 1) {
+                f->ratio = 0; f->hy = 1; f->vy = 1;
+            } else {
+                return unsupported("a subsampling other than 4:4:4 and 4:2:0");
+            }
+            const int ny = f->hy * f->vy;
+            f->nslots = ny + 2;
+            f->dcpack = f->acpack = 0;
+            for (int s = 0; s < f->nslots; s++) {
+                const int c = s < ny ? 0 : s - ny + 1;
+                f->dcpack |= static_cast<uint32_t>(td[c]) << (4 * s);
+                f->acpack |= static_cast<uint32_t>(2 + ta[c]) << (4 * s);
+            }
+            for (int c = 0; c < 3; c++)
+                for (int k = 0; k < 64; k++) f->q[c][k] = q[comp_q[c]][k];
+            f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
+            f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
+            f->scan = pos + 2 + len;
+            return FNX_OK;
+        }
+        pos += 2 + len;
+    }
+}
+
+// The scan's bytes without the stuffing into `dst` (capacity: n - f.scan); *nbytes = what was written.
+static int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes)
+{
+    const uint8_t *s = data + f.scan, *end = data + n;
+    uint8_t *d = dst;
+    for (;;) {
+        const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(s, 0xff, static_cast<size_t>(end - s)));
+        if (!ff || ff + 1 >= end) return corrupt("the scan runs to the end of the file (no EOI)");
+        std::memcpy(d, s, static_cast<size_t>(ff - s));
+        d += ff - s;
+        const uint8_t m = ff[1];
+        if (m == 0x00) {
+            *d++ = 0xff;
+            s = ff + 2;
+        } else if (m == 0xff) {
+            s = ff + 1;                                                   // fill byte before a marker
+        } else if (m == 0xd9) {
+            break;
+        } else if (m >= 0xd0 && m <= 0xd7) {
+            return unsupported("a restart marker");
+        } else {
+            return unsupported("a second scan (or another segment) behind the first");
+        }
+    }
+    *nbytes = static_cast<size_t>(d - dst);
+    return FNX_OK;
+}
+
+constexpr int SCAN_PER_WG_D = 2048;
+
+// data (host): the file.  On return the planes (SLOT_JPEG_DEC_PLANES: Y, Cb, Cr back to back, MCU-padded) are
+// enqueued and *f describes them; the scan has been validated (one small read-back).
+int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride)
+{
+    FNX_TRY(jpeg_parse(data, n, f));
+    void *pin = nullptr, *tpin = nullptr;
+    const size_t cap = (n - f->scan + 64 + 63) & ~size_t(63);           // >= the scan + 4 words of zeros
+    FNX_TRY(pinned_alloc(ctx, cap + sizeof(DecTables), &pin));            // one slice: a second request could wrap the ring onto it
+    tpin = static_cast<uint8_t *>(pin) + cap;
+    size_t nb = 0;
+    FNX_TRY(jpeg_unstuff(data, n, *f, static_cast<uint8_t *>(pin), &nb));
+    const size_t nwords = (nb + 3) / 4 + 4;
+    std::memset(static_cast<uint8_t *>(pin) + nb, 0, nwords * 4 - nb);
+    const unsigned long long nbits = 8ull * nb;
+    const size_t nlanes_z = static_cast<size_t>((nbits + DEC_SPAN - 1) / DEC_SPAN);
+    const long long nmcu = static_cast<long long>(f->mx) * f->my;
+    const long long nblk_ll = nmcu * f->nslots;
+    if (nlanes_z == 0) return corrupt("an empty scan");
+    if (nlanes_z >= (size_t(1) << 30) || nblk_ll >= (1ll << 30)) return unsupported("a file this large");
+    const int nlanes = static_cast<int>(nlanes_z), nblk = static_cast<int>(nblk_ll);
+    const int nwg = (nlanes + 255) / 256;
+    const int ys = 8 * f->hy * f->mx, yh = 8 * f->vy * f->my, cs = 8 * f->mx, chh = 8 * f->my;
+
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t lanes_pad = static_cast<size_t>(nwg) * 256;
+    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(sizeof(DecTables)), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
+                 b_first = al(8 * lanes_pad), b_tot = al(8 * (lanes_pad / SCAN_PER_WG_D + 2)), b_flag = al(4 * 64 + 16),
+                 b_coef = al(sizeof(int16_t) * 64 * static_cast<size_t>(nblk)), b_dcb = al(4 * static_cast<size_t>(nblk)),
+                 b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2));
+    void *sc = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC, b_ecs + b_tab + 2 * b_state + b_cnt + b_first + b_tot + b_flag + b_coef + b_dcb + b_dcs + b_tot2, &sc));
+    unsigned char *p = static_cast<unsigned char *>(sc);
+    uint32_t *d_ecs = reinterpret_cast<uint32_t *>(p); p += b_ecs;
+    DecTables *d_tab = reinterpret_cast<DecTables *>(p); p += b_tab;
+    unsigned long long *d_in = reinterpret_cast<unsigned long long *>(p); p += b_state;
+    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(p); p += b_state;
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(p); p += b_cnt;
+    unsigned long long *d_first = reinterpret_cast<unsigned long long *>(p); p += b_first;
+    unsigned long long *d_tot = reinterpret_cast<unsigned long long *>(p); p += b_tot;
+    uint32_t *d_flag = reinterpret_cast<uint32_t *>(p); p += b_flag;          // [0..63] rounds, then err, then 2 x u64 totals
+    int16_t *d_coef = reinterpret_cast<int16_t *>(p); p += b_coef;
+    uint32_t *d_dcb = reinterpret_cast<uint32_t *>(p); p += b_dcb;
+    unsigned long long *d_dcs = reinterpret_cast<unsigned long long *>(p); p += b_dcs;
+    unsigned long long *d_tot2 = reinterpret_cast<unsigned long long *>(p);
+    void *pl = nullptr;
+    const size_t b_y = al(static_cast<size_t>(ys) * yh), b_c = al(static_cast<size_t>(cs) * chh);
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_PLANES, b_y + 2 * b_c, &pl));
+    planes[0] = static_cast<uint8_t *>(pl);
+    planes[1] = planes[0] + b_y;
+    planes[2] = planes[1] + b_c;
+    *ystride = ys; *cstride = cs;
+
+    std::memcpy(tpin, &f->tab, sizeof(DecTables));
+    FNX_HIP(hipMemcpyAsync(d_ecs, pin, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+    FNX_HIP(hipMemcpyAsync(d_tab, tpin, sizeof(DecTables), hipMemcpyHostToDevice, ctx->stream));
+    FNX_HIP(hipMemsetAsync(d_flag, 0, b_flag, ctx->stream));
+    FNX_HIP(hipMemsetAsync(d_coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk), ctx->stream));
+
+    DecArgs a{};
+    a.ecs = d_ecs; a.tab = d_tab; a.s_in = d_in; a.s_out = d_out; a.cnt = d_cnt; a.flag = d_flag;
+    a.first_blk = d_first; a.coef = d_coef; a.err = d_flag + 64;
+    a.nwords = static_cast<long long>(nwords); a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
+    a.dcpack = f->dcpack; a.acpack = f->acpack;
+    FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
+    hipLaunchKernelGGL(jpeg_dsync_kernel<false>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+    FNX_HIP(hipGetLastError());
+    FNX_TRY(prof_end(ctx));
+    // rounds across workgroups, two per read-back; a round that changes nothing ends it (at most nwg rounds can change something)
+    f->rounds = 0;
+    if (nwg > 1) {
+        uint32_t flags[64];
+        int r = 0;
+        for (;;) {
+            const int r0 = r;
+            for (int k = 0; k < 2 && r < 64; k++, r++) {
+                a.flag = d_flag + r;
+                hipLaunchKernelGGL(jpeg_dsync_kernel<true>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+            }
+            FNX_HIP(hipGetLastError());
+            FNX_TRY(fetch_bytes(ctx, d_flag, flags, sizeof(uint32_t) * static_cast<size_t>(r)));
+            bool quiet = false;
+            for (int k = r0; k < r; k++) quiet = quiet || flags[k] == 0;
+            f->rounds = r;
+            if (quiet) break;
+            if (r >= 64) {                       // start the flags over: the pattern that needs this many rounds is contrived, not wrong
+                FNX_HIP(hipMemsetAsync(d_flag, 0, 4 * 64, ctx->stream));
+                r = 0;
+            }
+        }
+    }
+    FNX_TRY(launch_scan(ctx, d_cnt, d_first, d_tot, nlanes, reinterpret_cast<unsigned long long *>(d_flag + 66)));
+    hipLaunchKernelGGL(jpeg_dwrite_kernel, dim3(nwg), dim3(256), 0, ctx->stream, a);
+    DcArgs da{d_coef, d_dcb, nblk, static_cast<int>(nmcu), f->hy * f->vy};
+    hipLaunchKernelGGL(jpeg_dc_gather_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, da);
+    FNX_TRY(launch_scan(ctx, d_dcb, d_dcs, d_tot2, nblk, nullptr));
+    IdctArgs ia{};
+    ia.coef = d_coef; ia.dcb = d_dcb; ia.dcsum = d_dcs;
+    for (int c = 0; c < 3; c++) {
+        ia.out[c] = planes[c];
+        ia.stride[c] = c ? cs : ys;
+        ia.nbx[c] = (c ? cs : ys) / 8;
+        ia.nblocks[c] = ia.nbx[c] * ((c ? chh : yh) / 8);
+        for (int k = 0; k < 64; k++) ia.q[c][k] = f->q[c][k];
+    }
+    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy;
+    hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, 3), dim3(256), 0, ctx->stream, ia);
+    FNX_HIP(hipGetLastError());
+    // what the scan held: blocks finished inside the string, and the write pass's complaints
+    struct { uint32_t err, pad; unsigned long long blocks; } chk;
+    FNX_TRY(fetch_bytes(ctx, d_flag + 64, &chk, sizeof(chk)));
+    if (chk.blocks < static_cast<unsigned long long>(nblk)) return corrupt("the scan ends before the last block");
+    if (chk.err) return corrupt("the scan holds a code outside its Huffman table or a run past the end of a block");
+    return FNX_OK;
+}
+
+}  // namespace fnx

@@ -59,6 +59,7 @@ extern "C" {
 #define FNX_ERR_NO_DEVICE (-2)
 #define FNX_ERR_HIP (-3)
 #define FNX_ERR_OOM (-4)
+#define FNX_ERR_UNSUPPORTED (-5) /* fnx_jpeg_decode / fnx_jpeg_recompress: a file the device decoder does not handle; decode it on the host */
 
 #define FNX_HOST 0
 #define FNX_DEVICE 1
@@ -219,6 +220,22 @@ int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
                       int *steps /* may be NULL */);
 int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
                             const double *window /* 64 */, int *quality, double *ssim, int *steps);
+/* SURVEY 8(f)2, third slice -- image.Decode of a JPEG source (batch.go:88-101 via io.go:60-95) on the device:
+ * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
+ * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all.  Handled: baseline
+ * (SOF0), 8 bit, three components, 4:4:4 or 4:2:0, one interleaved scan, no restart intervals; anything else returns
+ * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
+ * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Huffman decoding is parallel over
+ * 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how
+ * many rounds that takes.  Restated from ITU T.81 and Go's documented behaviour: bit-exact against the tests' CPU
+ * restatement, parity with Go unpinned. */
+int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h);
+/* CompressBatch's per-item body for a JPEG source in one call (batch.go:88-122 -> compress.go:21-87): decode `data`
+ * on the device, run compressJPEGOptimal's quality search there and write the winner's file into `out` -- the file
+ * bytes go up, the new file's bytes come down, no host codec.  Arguments as fnx_jpeg_compress; *w, *h: the image's
+ * dimensions.  FNX_ERR_UNSUPPORTED as fnx_jpeg_decode. */
+int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double target_ssim, const double *window /* 64 */, uint8_t *out,
+                        size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps /* may be NULL */, int *w, int *h);
 
 /* ---- convert.go / exif.go --------------------------------------------- */
 /* ApplyOrientation (exif.go:178-203 over convert.go:186-256).  orient 2..8;

@@ -1,0 +1,158 @@
+"""SURVEY 8(f)2, third slice: image.Decode of a JPEG source on the device (jpeg_dec.hip, fnx_jpeg_decode,
+fnx_jpeg_recompress).
+
+CPU (not gpu): the checker itself -- the oracle's decoder reads what libjpeg-turbo writes (standard and optimised
+Huffman tables, 4:2:0 and 4:4:4) and lands within the IDCT's tolerance of libjpeg's own decode; it reads its own
+encoder's files back to exactly the round trip's pixels.
+
+GPU (-m gpu): the device decoder against the oracle's, bit for bit: the oracle's files and libjpeg's, every MCU
+geometry, flat images (two symbols per block: many blocks per span) and noise at quality 100 (long codes, spans that
+hold less than a block), files large enough for several workgroups and several synchronisation rounds; what it must
+refuse (FNX_ERR_UNSUPPORTED) and what it must call corrupt; fnx_jpeg_recompress = decode + fnx_jpeg_compress.
+"""
+import io
+
+import numpy as np
+import pytest
+
+from fennec_amd import synth
+from oracle import oracle as orc
+
+
+def _pil(img, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(img[..., :3]), "RGB").save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _pil_decode(data):
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def _noise(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    a[..., 3] = 255
+    return a
+
+
+def _photo(w, h, seed=0):
+    """smooth structure + texture: what a camera file's statistics look like"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    base = 128 + 60 * np.sin(x / 37.0) * np.cos(y / 23.0) + 40 * np.sin((x + y) / 91.0)
+    img = np.stack([base + rng.normal(0, s, (h, w)) for s in (6, 9, 12)], axis=-1)
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    out[..., :3] = np.clip(img, 0, 255).astype(np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the checker
+@pytest.mark.parametrize("kw", [dict(quality=85, subsampling=2), dict(quality=60, subsampling=0), dict(quality=92, subsampling=2, optimize=True)])
+def test_oracle_decoder_reads_libjpeg_files(kw):
+    src = _photo(203, 117, 3)
+    data = _pil(src, **kw)
+    got = orc.jpeg_decode(data)
+    ref = _pil_decode(data)
+    assert got.shape == (117, 203, 4) and (got[..., 3] == 255).all()
+    # libjpeg: islow IDCT, fancy chroma upsampling for 4:2:0, its own colour constants -- close, not identical
+    d = np.abs(got[..., :3].astype(int) - ref.astype(int))
+    assert d.mean() < (1.6 if kw["subsampling"] == 2 else 0.6), d.mean()
+    assert np.percentile(d, 99) <= (12 if kw["subsampling"] == 2 else 3)
+
+
+def test_oracle_decoder_inverts_its_encoder_exactly():
+    for (w, h, q) in [(16, 16, 50), (33, 19, 90), (1, 1, 75), (120, 64, 100)]:
+        src = _photo(w, h, w)
+        assert np.array_equal(orc.jpeg_decode(orc.jpeg_encode(src, q)), orc.jpeg_roundtrip(src, q)), (w, h, q)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ctx():
+    import fennec_amd
+    return fennec_amd.Context(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(16, 16), (17, 9), (1, 1), (8, 8), (640, 480), (333, 217), (1000, 37), (8, 300), (1920, 1080)])
+def test_gpu_decode_of_the_oracles_files(ctx, w, h):
+    src = _photo(w, h, w + h)
+    for q in (10, 75, 100):
+        data = orc.jpeg_encode(src, q)
+        assert ctx.jpeg_decode_config(data) == (w, h)
+        got = ctx.jpeg_decode(data)
+        assert np.array_equal(got, orc.jpeg_decode(data)), (w, h, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(quality=85, subsampling=2), dict(quality=60, subsampling=0), dict(quality=92, subsampling=2, optimize=True),
+                                dict(quality=30, subsampling=0, optimize=True), dict(quality=100, subsampling=0), dict(quality=1, subsampling=2)])
+def test_gpu_decode_of_libjpeg_files(ctx, kw):
+    for (w, h) in [(203, 117), (64, 64), (1280, 720), (15, 33)]:
+        data = _pil(_photo(w, h, 5), **kw)
+        assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data)), (w, h, kw)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_flat_and_noise_extremes(ctx):
+    flat = np.full((1024, 2048, 4), 255, dtype=np.uint8)
+    flat[..., 1] = 77
+    for img, q in [(flat, 50), (_noise(1536, 1024, 1), 100), (_noise(512, 512, 2), 1)]:
+        # (libjpeg's optimising pass cannot take noise at quality 100 through Pillow's buffer: standard tables there)
+        for data in (orc.jpeg_encode(img, q), _pil(img, quality=q, subsampling=2), _pil(img, quality=q, subsampling=0, optimize=q < 100)):
+            assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data))
+
+
+@pytest.mark.gpu
+def test_gpu_decode_4k_many_workgroups_and_device_output(ctx):
+    import torch
+    src = synth.make_test_image(3840, 2160)
+    for data in (_pil(src, quality=90, subsampling=2), orc.jpeg_encode(_photo(3840, 2160, 9), 95)):
+        want = orc.jpeg_decode(data)
+        assert np.array_equal(ctx.jpeg_decode(data), want)
+        t = ctx.jpeg_decode(data, device=True)
+        assert t.is_cuda and torch.equal(t.cpu(), torch.from_numpy(want))
+    # back-to-back files of different geometry on one ctx: nothing of the previous decode leaks into the next
+    a, b = _pil(_photo(640, 360, 1), quality=70, subsampling=0), orc.jpeg_encode(_photo(97, 61, 2), 88)
+    for data in (a, b, a, b):
+        assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data))
+
+
+@pytest.mark.gpu
+def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
+    import fennec_amd
+    from PIL import Image
+    src = _photo(160, 120, 4)
+    for kw in (dict(quality=80, progressive=True), dict(quality=80, subsampling=1), dict(quality=80, restart_marker_blocks=4)):
+        with pytest.raises(fennec_amd.FennecUnsupported):
+            ctx.jpeg_decode(_pil(src, **kw))
+    buf = io.BytesIO()
+    Image.fromarray(src[..., 0], "L").save(buf, "JPEG", quality=80)
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        ctx.jpeg_decode_config(buf.getvalue())
+    good = _pil(src, quality=80, subsampling=2)
+    for bad in (good[: len(good) // 2], good[:-2], b"\x89PNG\r\n\x1a\n" + good, good[:300]):
+        with pytest.raises(fennec_amd.FennecError) as e:
+            ctx.jpeg_decode(bad)
+        assert not isinstance(e.value, fennec_amd.FennecUnsupported)
+    # a scan cut short but closed with an EOI: the blocks run out
+    cut = good[: len(good) * 3 // 4] + b"\xff\xd9"
+    with pytest.raises(fennec_amd.FennecError):
+        ctx.jpeg_decode(cut)
+    # and the ctx still works
+    assert np.array_equal(ctx.jpeg_decode(good), orc.jpeg_decode(good))
+
+
+@pytest.mark.gpu
+def test_gpu_recompress_is_decode_plus_compress(ctx):
+    for (w, h, kw) in [(640, 480, dict(quality=95, subsampling=2)), (333, 217, dict(quality=90, subsampling=0)), (1920, 1080, dict(quality=92, subsampling=2))]:
+        data = _pil(_photo(w, h, 7), **kw)
+        out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
+        assert dims == (w, h)
+        out2, q2, s2, steps2 = ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
+        assert (q, steps) == (q2, steps2) and s == s2 and out == out2
+        assert out[:2] == b"\xff\xd8" and out[-2:] == b"\xff\xd9"
