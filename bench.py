@@ -107,6 +107,8 @@ def main() -> int:
                          "(a counter in torch.distributed's store, batch.go:72-126 across ranks)")
     ap.add_argument("--device-codec", action="store_true",
                     help="config5: search AND encode on the device (fnx_jpeg_compress); the host codec only decodes the source")
+    ap.add_argument("--device-decode", action="store_true",
+                    help="config5: no host codec at all -- the source is decoded on the device too (fnx_jpeg_recompress)")
     ap.add_argument("--device-search", action="store_true",
                     help="config5: the quality search round-trips every candidate on the device (fnx_jpeg_quality_search); the host "
                          "codec decodes the source and encodes the winner only")
@@ -781,7 +783,9 @@ def other_workloads(args) -> int:
         workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
-        if args.device_codec:
+        if args.device_decode:
+            work = fbatch.jpeg_item_work_device_all(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
+        elif args.device_codec:
             work = fbatch.jpeg_item_work_device_codec(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
         elif args.device_search:
             work = fbatch.jpeg_item_work_device_search(jpegs, fbatch.TARGET_SSIM["Balanced"], on_gpu_seconds=gpu_stage.append)
@@ -805,7 +809,12 @@ def other_workloads(args) -> int:
         name = f"config5: {B} 4K JPEGs per step per GPU, Balanced (SSIM>=0.94) binary search, Pillow codec on {workers} host threads"
         if dyn:
             name += "; one dynamic queue over all ranks"
-        if args.device_codec:
+        if args.device_decode:
+            name = (f"config5: {B} 4K JPEGs per step per GPU, Balanced (SSIM>=0.94) binary search; decoder, search and encoder on the device "
+                    f"(fnx_jpeg_recompress: Go image/jpeg's arithmetic and file layout), no host codec, {workers} host threads")
+            if dyn:
+                name += "; one dynamic queue over all ranks"
+        elif args.device_codec:
             name += ("; search and encoder on the device (fnx_jpeg_compress: Go image/jpeg's arithmetic and file layout), host codec: "
                      "1 decode per image")
         elif args.device_search:
@@ -849,7 +858,7 @@ def other_workloads(args) -> int:
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8 (fp64 exact kernels)", "data": "synthetic",
         "config": {"workload": name, "images_per_step_per_gpu": B, "width": W, "height": H,
-                   "inputs": "device-resident, per-image C-ABI calls" if wl != "config5" else "host JPEG bytes, FNX_HOST staging per search step"},
+                   "inputs": "device-resident, per-image C-ABI calls" if wl != "config5" else ("host JPEG bytes; the file is all that crosses PCIe" if getattr(args, "device_decode", False) else "host JPEG bytes, FNX_HOST staging per search step")},
         "roofline": {"kernel": "whole step (all kernels of the workload)", "bound": "hbm", "achieved": round(gbs, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None},
         "result_sample": float(vals[0]),
@@ -895,7 +904,9 @@ def other_workloads(args) -> int:
     if wl == "config5":
         per_item = float(np.mean(gpu_stage[-B * args.steps:]))
         out["gpu_stage"] = {"seconds_per_image": round(per_item, 6), "images_per_s_per_context": round(1.0 / per_item, 1),
-                            "note": ("time inside the C ABI (one H2D of the decoded source, the whole search and the entropy coder on the "
+                            "note": ("time inside the C ABI: the whole item (file bytes up, decode + search + entropy coder on the device, "
+                                     "the new file down)") if args.device_decode else
+                                    ("time inside the C ABI (one H2D of the decoded source, the whole search and the entropy coder on the "
                                      "device, the file's D2H); the rest of a step is the host decode of the source") if args.device_codec else
                                     ("time inside the C ABI (one H2D of the decoded source + the whole search on the device); the rest "
                                      "of a step is the host codec: one decode and one encode per image") if args.device_search else

@@ -217,6 +217,37 @@ def jpeg_item_work_device_codec(jpegs: Sequence[bytes], target_ssim: float = TAR
     return work
 
 
+def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
+                              on_gpu_seconds: Optional[Callable[[float], None]] = None,
+                              decode: Callable[[bytes], np.ndarray] = pillow_decode):
+    """The per-item body of CompressBatch with NO host codec (fnx_jpeg_recompress: SURVEY 8(f)2, third slice): the file's
+    bytes go up, the decoder, the search and the encoder run on the device, the new file's bytes come down.  A file the
+    device decoder does not take (progressive, restart intervals, ...: FennecUnsupported) is decoded on the host by
+    THIS function -- the caller's choice, visible in the result's `host_decoded` -- and continues on the device."""
+    import time
+    from . import FennecUnsupported
+
+    def work(idx: int, state) -> BatchResult:
+        data = jpegs[idx]
+        t0 = time.perf_counter()
+        host_decoded = False
+        try:
+            out, q, s_, steps, _dims = state.jpeg_recompress(data, target_ssim)
+        except FennecUnsupported:
+            host_decoded = True
+            src = decode(data)
+            t0 = time.perf_counter()
+            out, q, s_, steps = state.jpeg_compress(src, target_ssim)
+        if on_gpu_seconds is not None:
+            on_gpu_seconds(time.perf_counter() - t0)
+        r = BatchResult(Index=idx, OriginalSize=len(data), CompressedSize=len(out), SSIM=s_, Quality=q)
+        r.steps = steps
+        r.data = out
+        r.host_decoded = host_decoded
+        return r
+    return work
+
+
 def jpeg_item_work_device_search(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
                                  on_gpu_seconds: Optional[Callable[[float], None]] = None,
                                  encode: Callable[[np.ndarray, int], bytes] = pillow_encode,

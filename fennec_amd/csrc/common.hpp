@@ -299,7 +299,7 @@ int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *c
 
 // jpeg_dec.hip: Huffman decoding tables of one file (tables 0, 1: DC th 0, 1; 2, 3: AC th 0, 1) and what its segments say
 struct DecTables {                                   // tables 0, 1: DC (th 0, 1); 2, 3: AC (th 0, 1)
-    uint16_t fast[4][512];                           // by the next 9 bits: length << 8 | symbol; 0: a longer code
+    uint16_t fast[4][2048];                          // by the next 11 bits: length << 8 | symbol; 0: a longer code
     uint32_t limit[4][18];                           // [L]: (largest code of length L + 1) << (16 - L)
     int32_t delta[4][18];                            // [L]: index of the first value of length L - its code
     uint8_t value[4][256];

@@ -39,6 +39,9 @@
 namespace fnx {
 
 constexpr int DEC_WPT = 32;                          // words of the bit string per lane
+constexpr int DEC_WARM = 16;                         // first pass: spans a workgroup decodes ahead of the ones it owns, so that its
+constexpr int DEC_OWN = 256 - DEC_WARM;              // first own span almost always starts from a synchronised state
+constexpr int DEC_FAST_BITS = 11;                    // (the host's copy of this is DecTables' fast[][1 << 11])
 constexpr int DEC_SPAN = 32 * DEC_WPT;               // ... in bits
 constexpr int DEC_WG_WORDS = 256 * DEC_WPT;
 constexpr int DEC_SEGW = 256 * (DEC_WPT + 1) + 4;    // a workgroup's words in LDS: one pad word per span (a span's words sit in
@@ -76,69 +79,68 @@ struct DecShared {
     uint8_t unzig[64];
 };
 
-// the 64 bits of the workgroup's segment from bit `rel` on (bits past the first 33 are only valid while rel & 31 allows)
-__device__ __forceinline__ unsigned long long dec_window(const uint32_t *seg, uint32_t rel)
+__device__ __forceinline__ uint32_t dec_word(const uint32_t *seg, uint32_t wi)
 {
-    const uint32_t wi = rel >> 5;
-    const uint32_t i0 = wi + (wi >> 5), i1 = (wi + 1) + ((wi + 1) >> 5);         // DEC_WPT == 32
-    const unsigned long long x = (static_cast<unsigned long long>(seg[i0]) << 32) | seg[i1];
-    return x << (rel & 31u);
+    return seg[wi + wi / DEC_WPT];
 }
 
 // Decodes from (rel, z, slot) to the first symbol that starts at or after `end`.  WRITE: with the values.
+// The loop is one dependent chain per symbol -- window, table look-up, new position -- and a wave has at most one other
+// wave on its SIMD to hide it behind, so the chain is kept short: three words of the string live in registers (the
+// third is fetched a symbol ahead), the symbol's effect on (position, z) is two selects instead of branches, and a code
+// longer than the fast table's 11 bits finds its length by counting, not by a loop.
 template <bool WRITE>
 __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, uint32_t &rel, int &z, int &slot, uint32_t end, uint32_t &cnt,
                                          long long blk, uint32_t &bad)
 {
+    uint32_t wi = rel >> 5;
+    uint32_t hi = dec_word(sh.seg, wi), lo = dec_word(sh.seg, wi + 1), nxt = dec_word(sh.seg, wi + 2);
     while (rel < end) {
         if (WRITE && blk + cnt >= a.nblk) break;                   // what follows the last block is padding
-        const unsigned long long win = dec_window(sh.seg, rel);
-        const uint32_t c16 = static_cast<uint32_t>(win >> 48);
-        const int t = z == 0 ? static_cast<int>((a.dcpack >> (4 * slot)) & 15u) : static_cast<int>((a.acpack >> (4 * slot)) & 15u);
-        uint32_t e = sh.tab.fast[t][c16 >> 7];
-        int len, sym;
-        if (e) {
-            len = static_cast<int>(e >> 8);
-            sym = static_cast<int>(e & 0xffu);
-        } else {
-            len = 16; sym = 0;
-            bool hit = false;
-            for (int L = 10; L <= 16; L++)
-                if (c16 < sh.tab.limit[t][L]) {
-                    len = L;
-                    sym = sh.tab.value[t][(static_cast<int>(c16 >> (16 - L)) + sh.tab.delta[t][L]) & 255];
-                    hit = true;
-                    break;
-                }
+        uint32_t off = rel - 32u * wi;                             // < 64: a symbol is at most 16 + 15 bits
+        const bool adv = off >= 32u;
+        hi = adv ? lo : hi;
+        lo = adv ? nxt : lo;
+        wi += adv ? 1u : 0u;
+        off -= adv ? 32u : 0u;
+        nxt = dec_word(sh.seg, wi + 2);
+        const unsigned long long pair = (static_cast<unsigned long long>(hi) << 32) | lo;
+        const uint32_t c16 = static_cast<uint32_t>((pair << off) >> 48);
+        const int t = static_cast<int>(((z == 0 ? a.dcpack : a.acpack) >> (4 * slot)) & 15u);
+        const uint32_t e = sh.tab.fast[t][c16 >> (16 - DEC_FAST_BITS)];
+        int len = static_cast<int>(e >> 8), sym = static_cast<int>(e & 0xffu);
+        if (e == 0) {
+            // limit[] rises with the length: the code's length is the first L with c16 < limit[L]
+            int L = DEC_FAST_BITS + 1;
+#pragma unroll
+            for (int k = DEC_FAST_BITS + 1; k < 16; k++) L += c16 >= sh.tab.limit[t][k] ? 1 : 0;
+            const bool hit = c16 < sh.tab.limit[t][16];
+            len = L;
+            sym = hit ? sh.tab.value[t][(static_cast<int>(c16 >> (16 - L)) + sh.tab.delta[t][L]) & 255] : 0;
             if (WRITE && !hit) bad |= 1u;
         }
-        rel += static_cast<uint32_t>(len);
-        const int s = sym & 15;
-        int32_t v = 0;
-        if (WRITE && s) {                                          // receive + extend (T.81 F.2.2.1)
-            const uint32_t raw = static_cast<uint32_t>(dec_window(sh.seg, rel) >> (64 - s));
-            v = raw < (1u << (s - 1)) ? static_cast<int32_t>(raw) - (1 << s) + 1 : static_cast<int32_t>(raw);
-        }
-        if (z == 0) {
-            if (WRITE) {
+        const int s = sym & 15, r = sym >> 4;
+        const bool dc = z == 0;
+        if (WRITE) {
+            int32_t v = 0;
+            if (s) {                                               // receive + extend (T.81 F.2.2.1)
+                const uint32_t o2 = off + static_cast<uint32_t>(len);
+                const unsigned long long w2 = o2 < 32u ? pair << o2 : ((static_cast<unsigned long long>(lo) << 32) | nxt) << (o2 - 32u);
+                const uint32_t raw = static_cast<uint32_t>(w2 >> (64 - s));
+                v = raw < (1u << (s - 1)) ? static_cast<int32_t>(raw) - (1 << s) + 1 : static_cast<int32_t>(raw);
+            }
+            if (dc) {
                 if (sym > 11) bad |= 2u;
                 a.coef[(blk + cnt) * 64] = static_cast<int16_t>(v);
+            } else if (s) {
+                if (z + r > 63) bad |= 4u;
+                else a.coef[(blk + cnt) * 64 + sh.unzig[z + r]] = static_cast<int16_t>(v);
             }
-            rel += static_cast<uint32_t>(s);
-            z = 1;
-        } else if (s) {
-            z += sym >> 4;
-            if (WRITE) {
-                if (z > 63) bad |= 4u;
-                else a.coef[(blk + cnt) * 64 + sh.unzig[z]] = static_cast<int16_t>(v);
-            }
-            rel += static_cast<uint32_t>(s);
-            z++;
-        } else if ((sym >> 4) == 15) {
-            z += 16;
-        } else {
-            z = 64;                                                // end of block
         }
+        rel += static_cast<uint32_t>(len + s);
+        // DC: on to the first AC.  AC: a value after r zeros, or sixteen zeros (r = 15, s = 0), both z + r + 1; any other
+        // s = 0 ends the block
+        z = dc ? 1 : ((s == 0 && r != 15) ? 64 : z + r + 1);
         if (z >= 64) {
             z = 0;
             slot = slot + 1 == a.nslots ? 0 : slot + 1;
@@ -147,12 +149,13 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
     }
 }
 
-__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, int g)
+// the 256 spans from span0 on (+ 3 words of look-ahead) into LDS; spans before the string's start or past its end read as zeros
+__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long long span0)
 {
-    const long long base = static_cast<long long>(g) * DEC_WG_WORDS;
+    const long long base = span0 * DEC_WPT;
     for (int i = threadIdx.x; i < DEC_WG_WORDS + 3; i += 256) {
         const long long w = base + i;
-        sh.seg[i + (i >> 5)] = w < a.nwords ? __builtin_bswap32(a.ecs[w]) : 0u;
+        sh.seg[i + i / DEC_WPT] = (w >= 0 && w < a.nwords) ? __builtin_bswap32(a.ecs[w]) : 0u;
     }
     const uint32_t *tw = reinterpret_cast<const uint32_t *>(a.tab);
     uint32_t *sw = reinterpret_cast<uint32_t *>(&sh.tab);
@@ -160,48 +163,52 @@ __device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, int g
     if (threadIdx.x < 64) sh.unzig[threadIdx.x] = c_unzig[threadIdx.x];
 }
 
+// <false>: workgroup g owns spans [g OWN, (g + 1) OWN) and decodes the WARM spans before them as well (their results
+// are dropped).  <true>: the same ownership, no warm-up -- only a workgroup whose predecessor ended elsewhere runs.
 template <bool FIX>
 __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
-    const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
-    const bool live = gt < a.nlanes;
-    const unsigned long long wg_bit = static_cast<unsigned long long>(g) * 256u * DEC_SPAN;
+    const int g = blockIdx.x, t = threadIdx.x;
+    const long long span0 = static_cast<long long>(g) * DEC_OWN - (FIX ? 0 : DEC_WARM);
+    const long long gs = span0 + t;
+    const bool live = gs >= 0 && gs < a.nlanes && (!FIX || t < DEC_OWN);
+    const long long wg_bit = span0 * DEC_SPAN;
     unsigned long long my_in, my_out = 0;
     uint32_t my_cnt = 0;
     bool need;
     if (!FIX) {
-        my_in = dec_state(static_cast<unsigned long long>(gt) * DEC_SPAN, 0, 0);
+        my_in = dec_state(static_cast<unsigned long long>(live ? gs : 0) * DEC_SPAN, 0, 0);
         my_out = my_in;
         need = live;
     } else {
         if (g == 0) return;
         // every lane reads the same two words: the branch is uniform
-        const unsigned long long prev = __hip_atomic_load(&a.s_out[g * 256 - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == a.s_in[g * 256]) return;
-        my_in = live ? a.s_in[gt] : 0;
-        my_out = live ? a.s_out[gt] : 0;
-        my_cnt = live ? a.cnt[gt] : 0;
+        const unsigned long long prev = __hip_atomic_load(&a.s_out[span0 - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == a.s_in[span0]) return;
+        my_in = live ? a.s_in[gs] : 0;
+        my_out = live ? a.s_out[gs] : 0;
+        my_cnt = live ? a.cnt[gs] : 0;
         need = t == 0;
         if (t == 0) my_in = prev;
     }
-    dec_stage(sh, a, g);
+    dec_stage(sh, a, span0);
     sh.out[t] = my_out;
     __syncthreads();
     const uint32_t end = static_cast<uint32_t>(t + 1) * DEC_SPAN;
     for (;;) {
         if (need) {
-            uint32_t rel = static_cast<uint32_t>((my_in & 0xffffffffffull) - wg_bit);
+            uint32_t rel = static_cast<uint32_t>(static_cast<long long>(my_in & 0xffffffffffull) - wg_bit);
             int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
             uint32_t bad = 0;
             my_cnt = 0;
             dec_span<false>(sh, a, rel, z, slot, end, my_cnt, 0, bad);
-            my_out = dec_state(wg_bit + rel, z, slot);
+            my_out = dec_state(static_cast<unsigned long long>(wg_bit + rel), z, slot);
             sh.out[t] = my_out;
         }
         __syncthreads();
         need = false;
-        if (t > 0 && live) {
+        if (t > 0 && live && gs > 0) {                     // (span 0 starts where the string starts: never corrected)
             const unsigned long long pv = sh.out[t - 1];
             if (pv != my_in) {
                 my_in = pv;
@@ -210,10 +217,10 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
         }
         if (!__syncthreads_or(need ? 1 : 0)) break;
     }
-    if (live) {
-        a.s_in[gt] = my_in;
-        __hip_atomic_store(&a.s_out[gt], my_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.cnt[gt] = my_cnt;
+    if (live && (FIX || t >= DEC_WARM)) {
+        a.s_in[gs] = my_in;
+        __hip_atomic_store(&a.s_out[gs], my_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.cnt[gs] = my_cnt;
     }
     if (FIX && t == 0) a.flag[0] = 1u;
 }
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
     const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
-    dec_stage(sh, a, g);
+    dec_stage(sh, a, static_cast<long long>(g) * 256);
     __syncthreads();
     if (gt >= a.nlanes) return;
     const unsigned long long st = a.s_in[gt];
@@ -406,8 +413,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                     for (int j = 0; j < cnt; j++, k++, code++) {
                         if (code >= (1u << L)) return corrupt("a Huffman table with more codes than its lengths allow");
                         f->tab.value[t][k] = seg[o + 17 + k];
-                        if (L <= 9)
-                            for (uint32_t x = code << (9 - L); x < ((code + 1) << (9 - L)); x++)
+                        if (L <= DEC_FAST_BITS)
+                            for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)
                                 f->tab.fast[t][x] = static_cast<uint16_t>((L << 8) | seg[o + 17 + k]);
                     }
                     f->tab.limit[t][L] = code << (16 - L);
@@ -511,7 +518,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     if (nlanes_z == 0) return corrupt("an empty scan");
     if (nlanes_z >= (size_t(1) << 30) || nblk_ll >= (1ll << 30)) return unsupported("a file this large");
     const int nlanes = static_cast<int>(nlanes_z), nblk = static_cast<int>(nblk_ll);
-    const int nwg = (nlanes + 255) / 256;
+    const int nwg = (nlanes + DEC_OWN - 1) / DEC_OWN, nwg_write = (nlanes + 255) / 256;
     const int ys = 8 * f->hy * f->mx, yh = 8 * f->vy * f->my, cs = 8 * f->mx, chh = 8 * f->my;
 
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -582,7 +589,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
         }
     }
     FNX_TRY(launch_scan(ctx, d_cnt, d_first, d_tot, nlanes, reinterpret_cast<unsigned long long *>(d_flag + 66)));
-    hipLaunchKernelGGL(jpeg_dwrite_kernel, dim3(nwg), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(jpeg_dwrite_kernel, dim3(nwg_write), dim3(256), 0, ctx->stream, a);
     DcArgs da{d_coef, d_dcb, nblk, static_cast<int>(nmcu), f->hy * f->vy};
     hipLaunchKernelGGL(jpeg_dc_gather_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, da);
     FNX_TRY(launch_scan(ctx, d_dcb, d_dcs, d_tot2, nblk, nullptr));
