@@ -912,6 +912,18 @@ def other_workloads(args) -> int:
                                      "of a step is the host codec: one decode and one encode per image") if args.device_search else
                                     ("time inside the C ABI (prepare + every SSIMFast of the search, host buffers: PCIe-inclusive); "
                                      "the rest of a step is the host JPEG codec (Pillow here, Go's image/jpeg in the reference)")}
+        if rank == 0 and world == 1 and args.device_decode and not args.no_extras:
+            # the same items through the C++ pool (fennec_CompressBatchJPEG: no interpreter between the items)
+            pools = {}
+            for nw in (4, 8, 16):
+                fbatch.compress_batch_jpeg_native(jpegs[:B], fbatch.TARGET_SSIM["Balanced"], workers=nw)
+                t_g = time.perf_counter()
+                for _ in range(3):
+                    fbatch.compress_batch_jpeg_native(jpegs[:B], fbatch.TARGET_SSIM["Balanced"], workers=nw)
+                pools[str(nw)] = round(3 * B / (time.perf_counter() - t_g), 1)
+            out["native_pool"] = {"images_per_s_by_workers": pools, "unit": "images/s",
+                                  "note": "fennec_CompressBatchJPEG over the same files, 3 runs per worker count after the timed region "
+                                          "(python-side buffer handling included)"}
         if rank == 0 and world == 1 and args.device_codec and not args.no_extras:
             # the GPU stage alone -- decoded sources resident on the device, the C++ pool of
             # fennec_CompressBatchNRGBA (search + entropy coder per item on the device), files copied to the host

@@ -70,6 +70,7 @@ class NativeBatchResult(C.Structure):
                 ("status", C.c_int32), ("original_size", C.c_int64), ("compressed_size", C.c_int64), ("ssim", C.c_double)]
 
 
+FNX_ERR_INVALID = -1
 FNX_ERR_UNSUPPORTED = -5
 
 
@@ -157,6 +158,8 @@ def load_library() -> C.CDLL:
         _sig(L, "fennec_CompressBatchNRGBA", i, [i, i, i, i, C.POINTER(C.c_void_p), C.POINTER(i), C.POINTER(i), C.POINTER(i), _i64p, d,
                                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i),
                                                   C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_CompressBatchJPEG", i, [i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), d, C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i), C.c_void_p, C.c_void_p])
         _sig(L, "fennec_pool_release", None, [])
         _sig(L, "fennec_SummarizeResults", d, [i, C.POINTER(NativeBatchResult), _i64p])
         _sig(L, "fnx_jpeg_size_search", i, [ctx, i] + img + [i, i, C.c_longlong, i, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
@@ -558,6 +561,19 @@ class Context:
                     break
                 cap = n.value
         self._chk(rc, "fnx_jpeg_compress")
+
+    @staticmethod
+    def jpeg_parse(data: bytes):
+        """jpeg_decode_config without a ctx (the segment parser is host code): (w, h), FennecUnsupported, or FennecError."""
+        L = load_library()
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        w, h = C.c_int(), C.c_int()
+        rc = L.fnx_jpeg_decode(None, buf.ctypes.data_as(_u8p), len(data), FNX_HOST, None, 0, C.byref(w), C.byref(h))
+        if rc == FNX_ERR_UNSUPPORTED:
+            raise FennecUnsupported(L.fnx_last_error().decode())
+        if rc < 0:
+            raise FennecError(f"fnx_jpeg_decode failed ({rc}): {L.fnx_last_error().decode()}")
+        return w.value, h.value
 
     def jpeg_decode_config(self, data: bytes):
         """jpeg.DecodeConfig as far as the device decoder goes: (w, h); FennecUnsupported for files it does not take."""

@@ -406,3 +406,67 @@ def compress_batch_native(images: Sequence, target_ssim: float = TARGET_SSIM["Ba
     avg = L.fennec_SummarizeResults(n, res, out4)
     summ = BatchSummary(Total=int(out4[0]), Succeeded=int(out4[1]), Failed=int(out4[2]), TotalSaved=int(out4[3]), AvgSSIM=float(avg))
     return results, files, summ
+
+
+_out_arena = None      # compress_batch_jpeg_native's output pages (not thread-safe: one batch at a time per process)
+
+
+def compress_batch_jpeg_native(files: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"], workers: int = 4, device: int = 0,
+                               decode: Callable[[bytes], np.ndarray] = pillow_decode):
+    """fennec_CompressBatchJPEG: CompressBatch over JPEG FILES (batch.go:88-122) with no host codec -- the C++ pool, per
+    item decoder + quality search + encoder on the device (fnx_jpeg_recompress).  Items the device decoder refuses
+    (status FNX_ERR_UNSUPPORTED) are decoded on the host HERE and sent through fennec_CompressBatchNRGBA; their results
+    carry host_decoded = True.  -> (results, files, summary)."""
+    import ctypes as C
+
+    import fennec_amd as fa
+    L = fa.load_library()
+    n = len(files)
+    if n == 0:
+        return [], [], BatchSummary()
+    arrs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    srcs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    sizes = (C.c_size_t * n)(*[len(f) for f in files])
+    # one arena for the outputs, kept between calls: fresh pages cost a fault each when the file comes down.  A search
+    # ends at a lower quality than a camera wrote, so the source's size (+ the header) is the usual bound; an item whose
+    # file is larger comes back FNX_ERR_INVALID with its size and runs again below.
+    capl = [len(f) + 4096 for f in files]
+    offs = np.concatenate(([0], np.cumsum(capl)))
+    global _out_arena
+    if _out_arena is None or _out_arena.size < int(offs[-1]):
+        _out_arena = np.empty(int(offs[-1]), dtype=np.uint8)
+    bufs = [_out_arena[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    caps = (C.c_size_t * n)(*capl)
+    res = (fa.NativeBatchResult * n)()
+    rc = L.fennec_CompressBatchJPEG(int(device), int(workers), n, srcs, sizes, float(target_ssim), outs, caps, res, None, None, None)
+    if rc != fa.FNX_OK:
+        raise fa.FennecError(f"fennec_CompressBatchJPEG: {L.fnx_last_error().decode()}")
+    for i in range(n):
+        if res[i].failed and res[i].status == fa.FNX_ERR_INVALID and int(res[i].compressed_size) > capl[i]:
+            big = np.empty(int(res[i].compressed_size), dtype=np.uint8)
+            one = (fa.NativeBatchResult * 1)()
+            L.fennec_CompressBatchJPEG(int(device), 1, 1, (C.c_void_p * 1)(arrs[i].ctypes.data), (C.c_size_t * 1)(len(files[i])),
+                                       float(target_ssim), (C.c_void_p * 1)(big.ctypes.data), (C.c_size_t * 1)(big.size), one, None, None, None)
+            one[0].index = i
+            res[i] = one[0]
+            bufs[i] = big
+    results, out_files = [], []
+    for i in range(n):
+        r = res[i]
+        br = BatchResult(Index=r.index, OriginalSize=int(r.original_size), CompressedSize=int(r.compressed_size), SSIM=float(r.ssim),
+                         Quality=int(r.quality), Err=None if not r.failed else f"status {r.status}", has_result=bool(r.has_result))
+        br.steps = int(r.steps)
+        br.host_decoded = False
+        results.append(br)
+        out_files.append(bufs[i][:int(r.compressed_size)].tobytes() if not r.failed else b"")
+    # the caller's side of FNX_ERR_UNSUPPORTED: host decode, then the NRGBA pool
+    redo = [i for i in range(n) if res[i].failed and res[i].status == fa.FNX_ERR_UNSUPPORTED]
+    if redo:
+        r2, f2, _ = compress_batch_native([decode(files[i]) for i in redo], target_ssim, workers=workers, device=device,
+                                          original_sizes=[len(files[i]) for i in redo])
+        for k, i in enumerate(redo):
+            r2[k].Index = i
+            r2[k].host_decoded = True
+            results[i], out_files[i] = r2[k], f2[k]
+    return results, out_files, summarize_local(results)

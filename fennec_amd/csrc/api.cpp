@@ -1157,14 +1157,14 @@ static int jpeg_decode_device(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegF
 
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h)
 {
-    FNX_TRY(bind(ctx));
     FNX_REQUIRE(data != nullptr && w != nullptr && h != nullptr, "decode arguments");
     JpegFile f;
-    if (dst == nullptr) {                        // jpeg.DecodeConfig: the dimensions only (and whether the device handles the file)
-        FNX_TRY(jpeg_parse(data, n, &f));
+    if (dst == nullptr) {                        // jpeg.DecodeConfig: the dimensions only (and whether the device handles the file);
+        FNX_TRY(jpeg_parse(data, n, &f));        // host work, no ctx needed
         *w = f.w; *h = f.h;
         return FNX_OK;
     }
+    FNX_TRY(bind(ctx));
     FNX_TRY(check_space_io(space));
     FNX_TRY(jpeg_parse(data, n, &f));
     *w = f.w; *h = f.h;

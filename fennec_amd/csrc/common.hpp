@@ -298,8 +298,9 @@ int jpeg_entropy_pack(fnx_ctx *ctx, int w, int h, unsigned long long total_bits,
 int launch_jpeg_blocks(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const in[3], uint8_t *const out[3]);
 
 // jpeg_dec.hip: Huffman decoding tables of one file (tables 0, 1: DC th 0, 1; 2, 3: AC th 0, 1) and what its segments say
+constexpr int DEC_FAST_BITS = 11;                    // DecTables::fast is indexed by this many bits of the string
 struct DecTables {                                   // tables 0, 1: DC (th 0, 1); 2, 3: AC (th 0, 1)
-    uint16_t fast[4][2048];                          // by the next 11 bits: length << 8 | symbol; 0: a longer code
+    uint16_t fast[4][1 << DEC_FAST_BITS];                          // by the next 11 bits: length << 8 | symbol; 0: a longer code
     uint32_t limit[4][18];                           // [L]: (largest code of length L + 1) << (16 - L)
     int32_t delta[4][18];                            // [L]: index of the first value of length L - its code
     uint8_t value[4][256];
@@ -318,6 +319,10 @@ struct JpegFile {
     DecTables tab;
 };
 int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);
+int jpeg_unsupported(const char *what);     // set_error + FNX_ERR_UNSUPPORTED
+int jpeg_corrupt(const char *what);         // set_error + FNX_ERR_INVALID
+// the scan's bytes without the stuffing into dst (capacity: n - f.scan); *nbytes = what was written
+int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes);
 int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride);
 int launch_scan(fnx_ctx *ctx, const uint32_t *in, unsigned long long *out, unsigned long long *totals, int n, unsigned long long *grand);
 

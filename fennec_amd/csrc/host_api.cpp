@@ -7,6 +7,9 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -388,16 +391,13 @@ void fennec_pool_release(void)
     for (auto &e : all) fnx_ctx_destroy(e.second);
 }
 
-int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
-                              const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
-                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
-                              fennec_on_item on_item, void *user)
+}  // extern "C"
+
+// The pool of batch.go:58-128: `workers` threads over ONE closed queue of indices; item(ctx, idx, &result) does the work.
+template <typename Item>
+static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *results, const volatile int *cancel, fennec_on_item on_item,
+                          void *user, Item item)
 {
-    if (n <= 0) return FNX_OK;                                   // batch.go:59-61
-    if (!srcs || !strides || !widths || !heights || !outs || !caps || !results) {
-        set_error("invalid argument: CompressBatch arrays");
-        return FNX_ERR_INVALID;
-    }
     if (workers <= 0) workers = static_cast<int>(std::thread::hardware_concurrency());      // batch.go:63-66
     if (workers <= 0) workers = 1;
     if (workers > n) workers = n;                                // batch.go:67-69
@@ -410,6 +410,9 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
     std::atomic<int> next{0}, started{0};
     std::mutex done_mu;
     int completed = 0;
+    const char *tr = std::getenv("FNX_POOL_TRACE");              // per-item wall times on stderr
+    const bool trace = tr && tr[0] == '1';
+    const auto t_batch = std::chrono::steady_clock::now();
     auto worker = [&]() {
         fnx_ctx *ctx = pool_take(device);
         if (!ctx) return;
@@ -422,17 +425,12 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                 r.failed = 1; r.status = FNX_NOOP;
                 continue;
             }
-            size_t nbytes = 0;
-            int q = 0, steps = 0;
-            double s = 0;
-            const int rc = fnx_jpeg_compress(ctx, space, srcs[idx], strides[idx], widths[idx], heights[idx], target_ssim, ssim_window(),
-                                             outs[idx], caps[idx], &nbytes, &q, &s, &steps);
-            r.status = rc;
-            r.failed = rc == FNX_OK ? 0 : 1;
-            r.has_result = rc == FNX_OK ? 1 : 0;
-            r.quality = q; r.steps = steps; r.ssim = s;
-            r.original_size = original_sizes ? original_sizes[idx] : static_cast<int64_t>(widths[idx]) * heights[idx] * 4;
-            r.compressed_size = static_cast<int64_t>(nbytes);
+            const auto t_item = std::chrono::steady_clock::now();
+            item(ctx, idx, r);
+            if (trace)
+                std::fprintf(stderr, "[fennec pool] item %d: %.3f ms (started %.3f ms into the batch)\n", idx,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_item).count(),
+                             std::chrono::duration<double, std::milli>(t_item - t_batch).count());
             if (on_item) {                                       // batch.go:113-119
                 std::lock_guard<std::mutex> lk(done_mu);
                 on_item(++completed, n, user);
@@ -448,6 +446,57 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
         return FNX_ERR_HIP;
     }
     return FNX_OK;
+}
+
+extern "C" {
+
+int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
+                              const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
+                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
+                              fennec_on_item on_item, void *user)
+{
+    if (n <= 0) return FNX_OK;                                   // batch.go:59-61
+    if (!srcs || !strides || !widths || !heights || !outs || !caps || !results) {
+        set_error("invalid argument: CompressBatch arrays");
+        return FNX_ERR_INVALID;
+    }
+    return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        size_t nbytes = 0;
+        int q = 0, steps = 0;
+        double s = 0;
+        const int rc = fnx_jpeg_compress(ctx, space, srcs[idx], strides[idx], widths[idx], heights[idx], target_ssim, ssim_window(),
+                                         outs[idx], caps[idx], &nbytes, &q, &s, &steps);
+        r.status = rc;
+        r.failed = rc == FNX_OK ? 0 : 1;
+        r.has_result = rc == FNX_OK ? 1 : 0;
+        r.quality = q; r.steps = steps; r.ssim = s;
+        r.original_size = original_sizes ? original_sizes[idx] : static_cast<int64_t>(widths[idx]) * heights[idx] * 4;
+        r.compressed_size = static_cast<int64_t>(nbytes);
+    });
+}
+
+int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes, double target_ssim,
+                             uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
+                             fennec_on_item on_item, void *user)
+{
+    if (n <= 0) return FNX_OK;                                   // batch.go:59-61
+    if (!files || !sizes || !outs || !caps || !results) {
+        set_error("invalid argument: CompressBatch arrays");
+        return FNX_ERR_INVALID;
+    }
+    return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        size_t nbytes = 0;
+        int q = 0, steps = 0, w = 0, h = 0;
+        double s = 0;
+        const int rc = fnx_jpeg_recompress(ctx, files[idx], sizes[idx], target_ssim, ssim_window(), outs[idx], caps[idx], &nbytes, &q, &s,
+                                           &steps, &w, &h);
+        r.status = rc;                                           // FNX_ERR_UNSUPPORTED: the caller decodes this one on the host
+        r.failed = rc == FNX_OK ? 0 : 1;
+        r.has_result = rc == FNX_OK ? 1 : 0;
+        r.quality = q; r.steps = steps; r.ssim = s;
+        r.original_size = static_cast<int64_t>(sizes[idx]);      // batch.go:103: the source FILE's size
+        r.compressed_size = static_cast<int64_t>(nbytes);
+    });
 }
 
 double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t out4[4])

@@ -30,6 +30,8 @@
 // host); a scan that ends early or holds a code outside its table is FNX_ERR_INVALID.  Restated from ITU T.81 and
 // reader.go / scan.go / huffman.go's published behaviour, not from Go's source: bit-exact against the CPU restatement
 // the tests hold (which libjpeg-turbo's files exercise), parity with Go unpinned.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "common.hpp"
@@ -41,7 +43,6 @@ namespace fnx {
 constexpr int DEC_WPT = 32;                          // words of the bit string per lane
 constexpr int DEC_WARM = 16;                         // first pass: spans a workgroup decodes ahead of the ones it owns, so that its
 constexpr int DEC_OWN = 256 - DEC_WARM;              // first own span almost always starts from a synchronised state
-constexpr int DEC_FAST_BITS = 11;                    // (the host's copy of this is DecTables' fast[][1 << 11])
 constexpr int DEC_SPAN = 32 * DEC_WPT;               // ... in bits
 constexpr int DEC_WG_WORDS = 256 * DEC_WPT;
 constexpr int DEC_SEGW = 256 * (DEC_WPT + 1) + 4;    // a workgroup's words in LDS: one pad word per span (a span's words sit in
@@ -49,14 +50,17 @@ constexpr int DEC_SEGW = 256 * (DEC_WPT + 1) + 4;    // a workgroup's words in L
 
 struct DecArgs {
     const uint32_t *ecs;                             // the scan without stuffing, bytes as in the file, zero-padded
-    const DecTables *tab;
+    const DecTables *tab;                            // write pass: fast[] = length << 8 | symbol
+    const DecTables *tab_sync;                       // sync passes: fast[] = bits the symbol takes (code + value) | steps in the block << 8
     unsigned long long *s_in, *s_out;                // per lane: the state it starts in / ends in
     uint32_t *cnt;                                   // per lane: blocks finished inside its span
     uint32_t *flag;                                  // <true>: set by a workgroup that decoded again
     const unsigned long long *first_blk;             // write: exclusive prefix sum of cnt
     int16_t *coef;                                   // write: [nblk][64], natural order, zeroed
     uint32_t *err;                                   // write: != 0: a code outside its table or a run past the block
+    uint32_t *dbg;                                   // sync: [0] max passes of a workgroup, [1] sum of passes, [2] lane-decodes (FNX_JPEG_TRACE)
     long long nwords;                                // words of ecs that may be read
+    unsigned long long nbits;                        // length of the string
     int nlanes;                                      // spans in the string
     int nblk, nslots;
     uint32_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
@@ -91,12 +95,16 @@ __device__ __forceinline__ uint32_t dec_word(const uint32_t *seg, uint32_t wi)
 // longer than the fast table's 11 bits finds its length by counting, not by a loop.
 template <bool WRITE>
 __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, uint32_t &rel, int &z, int &slot, uint32_t end, uint32_t &cnt,
-                                         long long blk, uint32_t &bad)
+                                         long long blk, uint32_t &bad, uint32_t lim = 0xffffffffu)
 {
     uint32_t wi = rel >> 5;
     uint32_t hi = dec_word(sh.seg, wi), lo = dec_word(sh.seg, wi + 1), nxt = dec_word(sh.seg, wi + 2);
     while (rel < end) {
         if (WRITE && blk + cnt >= a.nblk) break;                   // what follows the last block is padding
+        if (WRITE && rel >= lim) {                                 // a block the image needs starts past the end of the string
+            bad |= 8u;
+            break;
+        }
         uint32_t off = rel - 32u * wi;                             // < 64: a symbol is at most 16 + 15 bits
         const bool adv = off >= 32u;
         hi = adv ? lo : hi;
@@ -108,6 +116,18 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
         const uint32_t c16 = static_cast<uint32_t>((pair << off) >> 48);
         const int t = static_cast<int>(((z == 0 ? a.dcpack : a.acpack) >> (4 * slot)) & 15u);
         const uint32_t e = sh.tab.fast[t][c16 >> (16 - DEC_FAST_BITS)];
+        if (!WRITE && e) {
+            // the sync passes' table holds what the symbol does to the state, ready made: bits consumed (code + value)
+            // and steps inside the block (1 for a DC, r + 1 for a coefficient or sixteen zeros, 64 for the end of block)
+            rel += e & 0xffu;
+            z += static_cast<int>(e >> 8);
+            const bool fin = z >= 64;
+            z = fin ? 0 : z;
+            cnt += fin ? 1u : 0u;
+            const int s1 = slot + 1 == a.nslots ? 0 : slot + 1;
+            slot = fin ? s1 : slot;
+            continue;
+        }
         int len = static_cast<int>(e >> 8), sym = static_cast<int>(e & 0xffu);
         if (e == 0) {
             // limit[] rises with the length: the code's length is the first L with c16 < limit[L]
@@ -150,14 +170,14 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
 }
 
 // the 256 spans from span0 on (+ 3 words of look-ahead) into LDS; spans before the string's start or past its end read as zeros
-__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long long span0)
+__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long long span0, const DecTables *tab)
 {
     const long long base = span0 * DEC_WPT;
     for (int i = threadIdx.x; i < DEC_WG_WORDS + 3; i += 256) {
         const long long w = base + i;
         sh.seg[i + i / DEC_WPT] = (w >= 0 && w < a.nwords) ? __builtin_bswap32(a.ecs[w]) : 0u;
     }
-    const uint32_t *tw = reinterpret_cast<const uint32_t *>(a.tab);
+    const uint32_t *tw = reinterpret_cast<const uint32_t *>(tab);
     uint32_t *sw = reinterpret_cast<uint32_t *>(&sh.tab);
     for (int i = threadIdx.x; i < static_cast<int>(sizeof(DecTables) / 4); i += 256) sw[i] = tw[i];
     if (threadIdx.x < 64) sh.unzig[threadIdx.x] = c_unzig[threadIdx.x];
@@ -192,11 +212,14 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
         need = t == 0;
         if (t == 0) my_in = prev;
     }
-    dec_stage(sh, a, span0);
+    dec_stage(sh, a, span0, a.tab_sync);
     sh.out[t] = my_out;
     __syncthreads();
     const uint32_t end = static_cast<uint32_t>(t + 1) * DEC_SPAN;
+    uint32_t passes = 0, decodes = 0;
     for (;;) {
+        passes++;
+        decodes += need ? 1u : 0u;
         if (need) {
             uint32_t rel = static_cast<uint32_t>(static_cast<long long>(my_in & 0xffffffffffull) - wg_bit);
             int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
@@ -223,13 +246,20 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
         a.cnt[gs] = my_cnt;
     }
     if (FIX && t == 0) a.flag[0] = 1u;
+    if (a.dbg) {
+        if (t == 0) {
+            atomicMax(&a.dbg[0], passes);
+            atomicAdd(&a.dbg[1], passes);
+        }
+        atomicAdd(&a.dbg[2], decodes);
+    }
 }
 
 __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
     const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
-    dec_stage(sh, a, static_cast<long long>(g) * 256);
+    dec_stage(sh, a, static_cast<long long>(g) * 256, a.tab);
     __syncthreads();
     if (gt >= a.nlanes) return;
     const unsigned long long st = a.s_in[gt];
@@ -239,7 +269,9 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
     uint32_t rel = static_cast<uint32_t>((st & 0xffffffffffull) - wg_bit);
     int z = static_cast<int>((st >> 40) & 0xffu), slot = static_cast<int>(st >> 48);
     uint32_t cnt = 0, bad = 0;
-    dec_span<true>(sh, a, rel, z, slot, static_cast<uint32_t>(t + 1) * DEC_SPAN, cnt, blk, bad);
+    const unsigned long long left = a.nbits - wg_bit;              // (this lane exists: its span starts inside the string)
+    dec_span<true>(sh, a, rel, z, slot, static_cast<uint32_t>(t + 1) * DEC_SPAN, cnt, blk, bad,
+                   left > 0xfffffff0ull ? 0xfffffff0u : static_cast<uint32_t>(left));
     if (bad) atomicOr(a.err, bad);
 }
 
@@ -327,175 +359,7 @@ __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
     }
 }
 
-// ---- the host side: segments, tables, the scan without its stuffing ----
-static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
-static int unsupported(const char *what)
-{
-    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 3 components, 4:4:4 or 4:2:0, one scan, no restart intervals)", what);
-    return FNX_ERR_UNSUPPORTED;
-}
-
-static int corrupt(const char *what)
-{
-    set_error("jpeg decode: %s", what);
-    return FNX_ERR_INVALID;
-}
-
-int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
-{
-    if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return corrupt("no SOI marker");
-    bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
-    uint8_t q[4][64];
-    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
-    std::memset(&f->tab, 0, sizeof(f->tab));
-    size_t pos = 2;
-    for (;;) {
-        if (pos + 4 > n) return corrupt("the file ends before its scan");
-        if (data[pos] != 0xff) return corrupt("a segment does not start with a marker");
-        const uint8_t m = data[pos + 1];
-        if (m == 0xff) { pos++; continue; }                              // fill bytes
-        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
-        if (m == 0xd9) return corrupt("EOI before any scan");
-        const size_t len = (static_cast<size_t>(data[pos + 2]) << 8) | data[pos + 3];
-        if (len < 2 || pos + 2 + len > n) return corrupt("a segment runs past the end of the file");
-        const uint8_t *seg = data + pos + 4;
-        const size_t sl = len - 2;
-        if (m == 0xdb) {
-            size_t o = 0;
-            while (o < sl) {
-                const int pq = seg[o] >> 4, tq = seg[o] & 15;
-                if (pq != 0) return unsupported("a 16-bit quantisation table");
-                if (tq > 3 || o + 65 > sl) return corrupt("bad DQT segment");
-                for (int zig = 0; zig < 64; zig++) q[tq][UNZIG_H[zig]] = seg[o + 1 + zig];
-                have_q[tq] = true;
-                o += 65;
-            }
-        } else if (m == 0xc0) {
-            if (have_sof) return corrupt("two SOF segments");
-            if (sl < 6) return corrupt("bad SOF segment");
-            if (seg[0] != 8) return unsupported("a sample precision other than 8 bits");
-            if (seg[5] != 3) return unsupported("a component count other than 3");
-            if (sl < 6 + 9) return corrupt("bad SOF segment");
-            f->h = (seg[1] << 8) | seg[2];
-            f->w = (seg[3] << 8) | seg[4];
-            if (f->w <= 0 || f->h <= 0) return unsupported("a zero dimension (DNL)");
-            for (int c = 0; c < 3; c++) {
-                comp_id[c] = seg[6 + 3 * c];
-                comp_h[c] = seg[7 + 3 * c] >> 4;
-                comp_v[c] = seg[7 + 3 * c] & 15;
-                comp_q[c] = seg[8 + 3 * c];
-                if (comp_q[c] > 3) return corrupt("bad quantisation table selector");
-            }
-            have_sof = true;
-        } else if (m == 0xc1 || m == 0xc2 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-            return unsupported(m == 0xc2 ? "a progressive file" : "a frame type other than baseline");
-        } else if (m == 0xcc) {
-            return unsupported("arithmetic coding");
-        } else if (m == 0xc4) {
-            size_t o = 0;
-            while (o < sl) {
-                const int tc = seg[o] >> 4, th = seg[o] & 15;
-                if (tc > 1 || o + 17 > sl) return corrupt("bad DHT segment");
-                if (th > 1) return unsupported("a Huffman table selector above 1");
-                const int t = tc * 2 + th;
-                int total = 0;
-                for (int L = 1; L <= 16; L++) total += seg[o + L];
-                if (total > 256 || o + 17 + total > sl) return corrupt("bad DHT segment");
-                std::memset(f->tab.fast[t], 0, sizeof(f->tab.fast[t]));
-                uint32_t code = 0;
-                int k = 0;
-                for (int L = 1; L <= 16; L++) {
-                    const int cnt = seg[o + L];
-                    f->tab.delta[t][L] = k - static_cast<int32_t>(code);
-                    for (int j = 0; j < cnt; j++, k++, code++) {
-                        if (code >= (1u << L)) return corrupt("a Huffman table with more codes than its lengths allow");
-                        f->tab.value[t][k] = seg[o + 17 + k];
-                        if (L <= DEC_FAST_BITS)
-                            for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)
-                                f->tab.fast[t][x] = static_cast<uint16_t>((L << 8) | seg[o + 17 + k]);
-                    }
-                    f->tab.limit[t][L] = code << (16 - L);
-                    code <<= 1;
-                }
-                have_t[t] = true;
-                o += 17 + total;
-            }
-        } else if (m == 0xdd) {
-            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return unsupported("a restart interval");
-        } else if (m == 0xee) {
-            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return unsupported("an Adobe colour transform other than YCbCr");
-        } else if (m == 0xda) {
-            if (!have_sof) return corrupt("SOS before SOF");
-            if (sl < 1 || seg[0] != 3) return unsupported("a scan that does not interleave all three components");
-            if (sl < 1 + 6 + 3) return corrupt("bad SOS segment");
-            int td[3], ta[3];
-            for (int c = 0; c < 3; c++) {
-                if (seg[1 + 2 * c] != comp_id[c]) return unsupported("scan components out of frame order");
-                td[c] = seg[2 + 2 * c] >> 4;
-                ta[c] = seg[2 + 2 * c] & 15;
-                if (td[c] > 1 || ta[c] > 1) return unsupported("a Huffman table selector above 1");
-                if (!have_t[td[c]] || !have_t[2 + ta[c]]) return corrupt("the scan uses a Huffman table the file does not define");
-                if (!have_q[comp_q[c]]) return corrupt("the frame uses a quantisation table the file does not define");
-            }
-            if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return unsupported("an RGB file");
-            const bool chroma11 = comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
-            if (chroma11 && comp_h[0] == 2 && comp_v[0] == 2) {
-                f->ratio = 2; f->hy = 2; f->vy = 2;
-            } else if (chroma11 && comp_h[0] == 1 && comp_v[0] == 1) {
-                f->ratio = 0; f->hy = 1; f->vy = 1;
-            } else {
-                return unsupported("a subsampling other than 4:4:4 and 4:2:0");
-            }
-            const int ny = f->hy * f->vy;
-            f->nslots = ny + 2;
-            f->dcpack = f->acpack = 0;
-            for (int s = 0; s < f->nslots; s++) {
-                const int c = s < ny ? 0 : s - ny + 1;
-                f->dcpack |= static_cast<uint32_t>(td[c]) << (4 * s);
-                f->acpack |= static_cast<uint32_t>(2 + ta[c]) << (4 * s);
-            }
-            for (int c = 0; c < 3; c++)
-                for (int k = 0; k < 64; k++) f->q[c][k] = q[comp_q[c]][k];
-            f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
-            f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
-            f->scan = pos + 2 + len;
-            return FNX_OK;
-        }
-        pos += 2 + len;
-    }
-}
-
-// The scan's bytes without the stuffing into `dst` (capacity: n - f.scan); *nbytes = what was written.
-static int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes)
-{
-    const uint8_t *s = data + f.scan, *end = data + n;
-    uint8_t *d = dst;
-    for (;;) {
-        const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(s, 0xff, static_cast<size_t>(end - s)));
-        if (!ff || ff + 1 >= end) return corrupt("the scan runs to the end of the file (no EOI)");
-        std::memcpy(d, s, static_cast<size_t>(ff - s));
-        d += ff - s;
-        const uint8_t m = ff[1];
-        if (m == 0x00) {
-            *d++ = 0xff;
-            s = ff + 2;
-        } else if (m == 0xff) {
-            s = ff + 1;                                                   // fill byte before a marker
-        } else if (m == 0xd9) {
-            break;
-        } else if (m >= 0xd0 && m <= 0xd7) {
-            return unsupported("a restart marker");
-        } else {
-            return unsupported("a second scan (or another segment) behind the first");
-        }
-    }
-    *nbytes = static_cast<size_t>(d - dst);
-    return FNX_OK;
-}
-
+// ---- the host side (segments, tables, the scan without its stuffing: jpeg_parse.cpp) and the launches ----
 constexpr int SCAN_PER_WG_D = 2048;
 
 // data (host): the file.  On return the planes (SLOT_JPEG_DEC_PLANES: Y, Cb, Cr back to back, MCU-padded) are
@@ -505,7 +369,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     FNX_TRY(jpeg_parse(data, n, f));
     void *pin = nullptr, *tpin = nullptr;
     const size_t cap = (n - f->scan + 64 + 63) & ~size_t(63);           // >= the scan + 4 words of zeros
-    FNX_TRY(pinned_alloc(ctx, cap + sizeof(DecTables), &pin));            // one slice: a second request could wrap the ring onto it
+    FNX_TRY(pinned_alloc(ctx, cap + 2 * sizeof(DecTables), &pin));        // one slice: a second request could wrap the ring onto it
     tpin = static_cast<uint8_t *>(pin) + cap;
     size_t nb = 0;
     FNX_TRY(jpeg_unstuff(data, n, *f, static_cast<uint8_t *>(pin), &nb));
@@ -515,15 +379,15 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     const size_t nlanes_z = static_cast<size_t>((nbits + DEC_SPAN - 1) / DEC_SPAN);
     const long long nmcu = static_cast<long long>(f->mx) * f->my;
     const long long nblk_ll = nmcu * f->nslots;
-    if (nlanes_z == 0) return corrupt("an empty scan");
-    if (nlanes_z >= (size_t(1) << 30) || nblk_ll >= (1ll << 30)) return unsupported("a file this large");
+    if (nlanes_z == 0) return jpeg_corrupt("an empty scan");
+    if (nlanes_z >= (size_t(1) << 30) || nblk_ll >= (1ll << 30)) return jpeg_unsupported("a file this large");
     const int nlanes = static_cast<int>(nlanes_z), nblk = static_cast<int>(nblk_ll);
     const int nwg = (nlanes + DEC_OWN - 1) / DEC_OWN, nwg_write = (nlanes + 255) / 256;
     const int ys = 8 * f->hy * f->mx, yh = 8 * f->vy * f->my, cs = 8 * f->mx, chh = 8 * f->my;
 
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t lanes_pad = static_cast<size_t>(nwg) * 256;
-    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(sizeof(DecTables)), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
+    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(2 * sizeof(DecTables)), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
                  b_first = al(8 * lanes_pad), b_tot = al(8 * (lanes_pad / SCAN_PER_WG_D + 2)), b_flag = al(4 * 64 + 16),
                  b_coef = al(sizeof(int16_t) * 64 * static_cast<size_t>(nblk)), b_dcb = al(4 * static_cast<size_t>(nblk)),
                  b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2));
@@ -551,15 +415,30 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     *ystride = ys; *cstride = cs;
 
     std::memcpy(tpin, &f->tab, sizeof(DecTables));
+    {   // the sync passes' copy: the same tables with fast[] rewritten (slow-path arrays as they are)
+        DecTables *ts = reinterpret_cast<DecTables *>(static_cast<uint8_t *>(tpin) + sizeof(DecTables));
+        std::memcpy(ts, &f->tab, sizeof(DecTables));
+        for (int t = 0; t < 4; t++)
+            for (int i = 0; i < (1 << DEC_FAST_BITS); i++) {
+                const uint32_t e = f->tab.fast[t][i];
+                if (!e) continue;
+                const uint32_t len = e >> 8, sym = e & 0xffu, sz = sym & 15u, r = sym >> 4;
+                const uint32_t step = t < 2 ? 1u : ((sz == 0 && r != 15) ? 64u : r + 1u);
+                ts->fast[t][i] = static_cast<uint16_t>((len + sz) | (step << 8));
+            }
+    }
     FNX_HIP(hipMemcpyAsync(d_ecs, pin, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
-    FNX_HIP(hipMemcpyAsync(d_tab, tpin, sizeof(DecTables), hipMemcpyHostToDevice, ctx->stream));
+    FNX_HIP(hipMemcpyAsync(d_tab, tpin, 2 * sizeof(DecTables), hipMemcpyHostToDevice, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_flag, 0, b_flag, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk), ctx->stream));
 
     DecArgs a{};
-    a.ecs = d_ecs; a.tab = d_tab; a.s_in = d_in; a.s_out = d_out; a.cnt = d_cnt; a.flag = d_flag;
+    a.ecs = d_ecs; a.tab = d_tab; a.tab_sync = d_tab + 1; a.s_in = d_in; a.s_out = d_out; a.cnt = d_cnt; a.flag = d_flag;
     a.first_blk = d_first; a.coef = d_coef; a.err = d_flag + 64;
-    a.nwords = static_cast<long long>(nwords); a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
+    const char *trc = std::getenv("FNX_JPEG_TRACE");
+    const bool trace = trc && trc[0] == '1';
+    a.dbg = trace ? d_flag + 72 : nullptr;
+    a.nwords = static_cast<long long>(nwords); a.nbits = nbits; a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
     a.dcpack = f->dcpack; a.acpack = f->acpack;
     FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
     hipLaunchKernelGGL(jpeg_dsync_kernel<false>, dim3(nwg), dim3(256), 0, ctx->stream, a);
@@ -608,8 +487,15 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     // what the scan held: blocks finished inside the string, and the write pass's complaints
     struct { uint32_t err, pad; unsigned long long blocks; } chk;
     FNX_TRY(fetch_bytes(ctx, d_flag + 64, &chk, sizeof(chk)));
-    if (chk.blocks < static_cast<unsigned long long>(nblk)) return corrupt("the scan ends before the last block");
-    if (chk.err) return corrupt("the scan holds a code outside its Huffman table or a run past the end of a block");
+    if (trace) {
+        uint32_t dbg[3];
+        FNX_TRY(fetch_bytes(ctx, d_flag + 72, dbg, sizeof(dbg)));
+        std::fprintf(stderr, "[fennec jpeg] %d x %d, %zu scan bytes, %d lanes in %d workgroups: passes max %u avg %.1f, lane-decodes %u (%.2f per lane), "
+                             "cross-workgroup rounds %d\n", f->w, f->h, nb, nlanes, nwg, dbg[0], double(dbg[1]) / nwg, dbg[2], double(dbg[2]) / nlanes, f->rounds);
+    }
+    if (chk.blocks < static_cast<unsigned long long>(nblk)) return jpeg_corrupt("the scan ends before the last block");
+    if (chk.err & 8u) return jpeg_corrupt("the scan ends before the last block");
+    if (chk.err) return jpeg_corrupt("the scan holds a code outside its Huffman table or a run past the end of a block");
     return FNX_OK;
 }
 

@@ -1,0 +1,178 @@
+// The host side of the device JPEG decoder (jpeg_dec.hip): the file's segments, the Huffman decoding tables, and the
+// entropy-coded segment without its stuffing.  Plain C++ with no device code in it -- this is the part that reads
+// untrusted bytes, and the sanitizer builds (make asan / tsan) instrument it with the rest of the host layer.
+#include <cstring>
+#include "common.hpp"
+
+namespace fnx {
+
+static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+int jpeg_unsupported(const char *what)
+{
+    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 3 components, 4:4:4 or 4:2:0, one scan, no restart intervals)", what);
+    return FNX_ERR_UNSUPPORTED;
+}
+
+int jpeg_corrupt(const char *what)
+{
+    set_error("jpeg decode: %s", what);
+    return FNX_ERR_INVALID;
+}
+
+int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
+{
+    if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return jpeg_corrupt("no SOI marker");
+    bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
+    uint8_t q[4][64];
+    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    std::memset(&f->tab, 0, sizeof(f->tab));
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 4 > n) return jpeg_corrupt("the file ends before its scan");
+        if (data[pos] != 0xff) return jpeg_corrupt("a segment does not start with a marker");
+        const uint8_t m = data[pos + 1];
+        if (m == 0xff) { pos++; continue; }                              // fill bytes
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
+        if (m == 0xd9) return jpeg_corrupt("EOI before any scan");
+        const size_t len = (static_cast<size_t>(data[pos + 2]) << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > n) return jpeg_corrupt("a segment runs past the end of the file");
+        const uint8_t *seg = data + pos + 4;
+        const size_t sl = len - 2;
+        if (m == 0xdb) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (pq != 0) return jpeg_unsupported("a 16-bit quantisation table");
+                if (tq > 3 || o + 65 > sl) return jpeg_corrupt("bad DQT segment");
+                for (int zig = 0; zig < 64; zig++) q[tq][UNZIG_H[zig]] = seg[o + 1 + zig];
+                have_q[tq] = true;
+                o += 65;
+            }
+        } else if (m == 0xc0) {
+            if (have_sof) return jpeg_corrupt("two SOF segments");
+            if (sl < 6) return jpeg_corrupt("bad SOF segment");
+            if (seg[0] != 8) return jpeg_unsupported("a sample precision other than 8 bits");
+            if (seg[5] != 3) return jpeg_unsupported("a component count other than 3");
+            if (sl < 6 + 9) return jpeg_corrupt("bad SOF segment");
+            f->h = (seg[1] << 8) | seg[2];
+            f->w = (seg[3] << 8) | seg[4];
+            if (f->w <= 0 || f->h <= 0) return jpeg_unsupported("a zero dimension (DNL)");
+            for (int c = 0; c < 3; c++) {
+                comp_id[c] = seg[6 + 3 * c];
+                comp_h[c] = seg[7 + 3 * c] >> 4;
+                comp_v[c] = seg[7 + 3 * c] & 15;
+                comp_q[c] = seg[8 + 3 * c];
+                if (comp_q[c] > 3) return jpeg_corrupt("bad quantisation table selector");
+            }
+            have_sof = true;
+        } else if (m == 0xc1 || m == 0xc2 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            return jpeg_unsupported(m == 0xc2 ? "a progressive file" : "a frame type other than baseline");
+        } else if (m == 0xcc) {
+            return jpeg_unsupported("arithmetic coding");
+        } else if (m == 0xc4) {
+            size_t o = 0;
+            while (o < sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || o + 17 > sl) return jpeg_corrupt("bad DHT segment");
+                if (th > 1) return jpeg_unsupported("a Huffman table selector above 1");
+                const int t = tc * 2 + th;
+                int total = 0;
+                for (int L = 1; L <= 16; L++) total += seg[o + L];
+                if (total > 256 || o + 17 + total > sl) return jpeg_corrupt("bad DHT segment");
+                std::memset(f->tab.fast[t], 0, sizeof(f->tab.fast[t]));
+                uint32_t code = 0;
+                int k = 0;
+                for (int L = 1; L <= 16; L++) {
+                    const int cnt = seg[o + L];
+                    f->tab.delta[t][L] = k - static_cast<int32_t>(code);
+                    for (int j = 0; j < cnt; j++, k++, code++) {
+                        if (code >= (1u << L)) return jpeg_corrupt("a Huffman table with more codes than its lengths allow");
+                        f->tab.value[t][k] = seg[o + 17 + k];
+                        if (L <= DEC_FAST_BITS)
+                            for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)
+                                f->tab.fast[t][x] = static_cast<uint16_t>((L << 8) | seg[o + 17 + k]);
+                    }
+                    f->tab.limit[t][L] = code << (16 - L);
+                    code <<= 1;
+                }
+                have_t[t] = true;
+                o += 17 + total;
+            }
+        } else if (m == 0xdd) {
+            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return jpeg_unsupported("a restart interval");
+        } else if (m == 0xee) {
+            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
+        } else if (m == 0xda) {
+            if (!have_sof) return jpeg_corrupt("SOS before SOF");
+            if (sl < 1 || seg[0] != 3) return jpeg_unsupported("a scan that does not interleave all three components");
+            if (sl < 1 + 6 + 3) return jpeg_corrupt("bad SOS segment");
+            int td[3], ta[3];
+            for (int c = 0; c < 3; c++) {
+                if (seg[1 + 2 * c] != comp_id[c]) return jpeg_unsupported("scan components out of frame order");
+                td[c] = seg[2 + 2 * c] >> 4;
+                ta[c] = seg[2 + 2 * c] & 15;
+                if (td[c] > 1 || ta[c] > 1) return jpeg_unsupported("a Huffman table selector above 1");
+                if (!have_t[td[c]] || !have_t[2 + ta[c]]) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                if (!have_q[comp_q[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
+            }
+            if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return jpeg_unsupported("an RGB file");
+            const bool chroma11 = comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
+            if (chroma11 && comp_h[0] == 2 && comp_v[0] == 2) {
+                f->ratio = 2; f->hy = 2; f->vy = 2;
+            } else if (chroma11 && comp_h[0] == 1 && comp_v[0] == 1) {
+                f->ratio = 0; f->hy = 1; f->vy = 1;
+            } else {
+                return jpeg_unsupported("a subsampling other than 4:4:4 and 4:2:0");
+            }
+            const int ny = f->hy * f->vy;
+            f->nslots = ny + 2;
+            f->dcpack = f->acpack = 0;
+            for (int s = 0; s < f->nslots; s++) {
+                const int c = s < ny ? 0 : s - ny + 1;
+                f->dcpack |= static_cast<uint32_t>(td[c]) << (4 * s);
+                f->acpack |= static_cast<uint32_t>(2 + ta[c]) << (4 * s);
+            }
+            for (int c = 0; c < 3; c++)
+                for (int k = 0; k < 64; k++) f->q[c][k] = q[comp_q[c]][k];
+            f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
+            f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
+            f->scan = pos + 2 + len;
+            return FNX_OK;
+        }
+        pos += 2 + len;
+    }
+}
+
+// The scan's bytes without the stuffing into `dst` (capacity: n - f.scan); *nbytes = what was written.
+int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes)
+{
+    const uint8_t *s = data + f.scan, *end = data + n;
+    uint8_t *d = dst;
+    for (;;) {
+        const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(s, 0xff, static_cast<size_t>(end - s)));
+        if (!ff || ff + 1 >= end) return jpeg_corrupt("the scan runs to the end of the file (no EOI)");
+        std::memcpy(d, s, static_cast<size_t>(ff - s));
+        d += ff - s;
+        const uint8_t m = ff[1];
+        if (m == 0x00) {
+            *d++ = 0xff;
+            s = ff + 2;
+        } else if (m == 0xff) {
+            s = ff + 1;                                                   // fill byte before a marker
+        } else if (m == 0xd9) {
+            break;
+        } else if (m >= 0xd0 && m <= 0xd7) {
+            return jpeg_unsupported("a restart marker");
+        } else {
+            return jpeg_unsupported("a second scan (or another segment) behind the first");
+        }
+    }
+    *nbytes = static_cast<size_t>(d - dst);
+    return FNX_OK;
+}
+
+
+}  // namespace fnx

@@ -34,6 +34,7 @@ package fennec
 import "C"
 
 import (
+	"errors"
 	"image"
 	"image/color"
 	"math"
@@ -674,6 +675,64 @@ func jpegCompressHIP(src *image.NRGBA, targetSSIM float64) (data []byte, quality
 		buf = make([]byte, int(n))
 	}
 	return nil, 0, 0, false
+}
+
+func lastError(what string) error {
+	return errors.New(what + ": " + C.GoString(C.fnx_last_error()))
+}
+
+// jpegDecodeHIP is image.Decode + toNRGBARef for a JPEG file (io.go:60-95) on the device.  ok == false: the device was
+// not used or does not take this file (progressive, restart intervals, grey, 4:2:2: FNX_ERR_UNSUPPORTED) -- the
+// caller runs image.Decode as before.  err != nil: the file is corrupt (what image.Decode would report).
+func jpegDecodeHIP(data []byte) (img *image.NRGBA, ok bool, err error) {
+	c := poolGetIf(useDeviceSearch && len(data) > 4)
+	if c == nil {
+		return nil, false, nil
+	}
+	defer pool.put(c)
+	var w, h C.int
+	st := C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, nil, 0, &w, &h)
+	if st == C.FNX_ERR_UNSUPPORTED {
+		return nil, false, nil
+	}
+	if st != C.FNX_OK {
+		return nil, true, lastError("fnx_jpeg_decode")
+	}
+	img = image.NewNRGBA(image.Rect(0, 0, int(w), int(h)))
+	st = C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, pix(img), C.int(img.Stride), &w, &h)
+	runtime.KeepAlive(data)
+	if st != C.FNX_OK {
+		return nil, true, lastError("fnx_jpeg_decode")
+	}
+	return img, true, nil
+}
+
+// jpegRecompressHIP is CompressBatch's item body for a JPEG source (batch.go:88-122 -> compress.go:21-87) in one call:
+// the file goes up, decoder + quality search + encoder run on the device, the new file comes down.  ok == false: the
+// device was not used or refuses the file; the caller decodes on the host and calls jpegCompressHIP (or its own loop).
+func jpegRecompressHIP(data []byte, targetSSIM float64) (out []byte, quality int, ssim float64, w, h int, ok bool) {
+	c := poolGetIf(useDeviceSearch && len(data) > 4)
+	if c == nil {
+		return nil, 0, 0, 0, 0, false
+	}
+	defer pool.put(c)
+	buf := make([]byte, len(data)+4096)
+	for try := 0; try < 2; try++ {
+		var n C.size_t
+		var q, steps, cw, ch C.int
+		var s C.double
+		st := C.fnx_jpeg_recompress(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.double(targetSSIM),
+			(*C.double)(unsafe.Pointer(&ssimWindow[0])), (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n, &q, &s, &steps, &cw, &ch)
+		runtime.KeepAlive(data)
+		if st == C.FNX_OK {
+			return buf[:int(n)], int(q), float64(s), int(cw), int(ch), true
+		}
+		if st == C.FNX_ERR_UNSUPPORTED || int(n) <= len(buf) {
+			return nil, 0, 0, 0, 0, false
+		}
+		buf = make([]byte, int(n))
+	}
+	return nil, 0, 0, 0, 0, false
 }
 
 // jpegQualitySearchOptHIP is jpegQualitySearchOpt (targetsize.go:125-176) on the device: every candidate's size from the

@@ -222,7 +222,8 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
                             const double *window /* 64 */, int *quality, double *ssim, int *steps);
 /* SURVEY 8(f)2, third slice -- image.Decode of a JPEG source (batch.go:88-101 via io.go:60-95) on the device:
  * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
- * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all.  Handled: baseline
+ * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all (host work: ctx may be
+ * NULL and no device is touched).  Handled: baseline
  * (SOF0), 8 bit, three components, 4:4:4 or 4:2:0, one interleaved scan, no restart intervals; anything else returns
  * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
  * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Huffman decoding is parallel over
@@ -432,6 +433,13 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                               const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                               const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* The same pool over JPEG FILES in host memory (what CompressBatch reads for a .jpg item, batch.go:88-101): per item
+ * fnx_jpeg_recompress -- decoder, search and encoder on the device, no host codec.  A file the device decoder does not
+ * take comes back with failed != 0 and status == FNX_ERR_UNSUPPORTED: the caller decodes it on the host and sends it
+ * through fennec_CompressBatchNRGBA.  original_size = sizes[i]. */
+int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes, double target_ssim,
+                             uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                             const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
 /* The pool's idle worker contexts (kept between batches, per device) are destroyed. */
 void fennec_pool_release(void);
 /* Summarize (batch.go:140-158) of such results: out4 = {Total, Succeeded, Failed, TotalSaved}; returns AvgSSIM. */

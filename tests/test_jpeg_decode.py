@@ -70,6 +70,52 @@ def test_oracle_decoder_inverts_its_encoder_exactly():
         assert np.array_equal(orc.jpeg_decode(orc.jpeg_encode(src, q)), orc.jpeg_roundtrip(src, q)), (w, h, q)
 
 
+def _mutations(data, rng, n, lo, hi):
+    """n copies of `data` with 1-4 random bytes in [lo, hi) replaced"""
+    out = []
+    for _ in range(n):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            b[int(rng.integers(lo, min(hi, len(b))))] = int(rng.integers(0, 256))
+        out.append(bytes(b))
+    return out
+
+
+def test_segment_parser_answers_or_refuses_never_crashes():
+    """fnx_jpeg_decode(dst = NULL) is host code and needs no device: what it says about good files, files it must refuse,
+    every truncation of a header and a few thousand random mutations of one (it reads untrusted bytes)."""
+    import fennec_amd
+    from PIL import Image
+    parse = fennec_amd.Context.jpeg_parse
+    src = _photo(96, 64, 1)
+    good = [_pil(src, quality=80, subsampling=2), _pil(src, quality=80, subsampling=0, optimize=True), orc.jpeg_encode(src, 70)]
+    for g in good:
+        assert parse(g) == (96, 64)
+    for kw in (dict(progressive=True), dict(subsampling=1), dict(restart_marker_blocks=2)):
+        with pytest.raises(fennec_amd.FennecUnsupported):
+            parse(_pil(src, quality=80, **kw))
+    buf = io.BytesIO()
+    Image.fromarray(src[..., 0], "L").save(buf, "JPEG")
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        parse(buf.getvalue())
+    for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"GIF89a" + good[0], b"\xff\xd8\xff\xd9", b"\xff\xd8" + b"\xff" * 64):
+        with pytest.raises(fennec_amd.FennecError):
+            parse(junk)
+    rng = np.random.default_rng(7)
+    answered = refused = 0
+    for g in good:
+        head = g.index(b"\xff\xda") + 14
+        cases = [g[:k] for k in range(0, head + 4)] + _mutations(g, rng, 1500, 2, head)
+        for c in cases:
+            try:
+                w, h = parse(c)
+                assert 0 < w <= 65535 and 0 < h <= 65535
+                answered += 1
+            except fennec_amd.FennecError:
+                refused += 1
+    assert answered > 100 and refused > 100
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -156,3 +202,56 @@ def test_gpu_recompress_is_decode_plus_compress(ctx):
         out2, q2, s2, steps2 = ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
         assert (q, steps) == (q2, steps2) and s == s2 and out == out2
         assert out[:2] == b"\xff\xd8" and out[-2:] == b"\xff\xd9"
+
+
+@pytest.mark.gpu
+def test_gpu_native_pool_over_jpeg_files(ctx):
+    """fennec_CompressBatchJPEG: the C++ pool with fnx_jpeg_recompress per item, against the per-item calls; a progressive file
+    in the batch comes back FNX_ERR_UNSUPPORTED and the python caller's host decode takes it from there."""
+    from fennec_amd import batch
+    files = [_pil(_photo(640 + 16 * k, 480 - 8 * k, k), quality=95 - k, subsampling=2 if k % 2 else 0) for k in range(9)]
+    files.append(orc.jpeg_encode(_photo(333, 217, 3), 97))
+    files.insert(4, _pil(_photo(320, 200, 11), quality=90, progressive=True))
+    res, outs, summ = batch.compress_batch_jpeg_native(files, 0.94, workers=4)
+    assert [r.Index for r in res] == list(range(len(files))) and all(r.Err is None for r in res)
+    assert [r.host_decoded for r in res] == [i == 4 for i in range(len(files))]
+    for i, (r, f) in enumerate(zip(res, outs)):
+        src = batch.pillow_decode(files[i]) if i == 4 else orc.jpeg_decode(files[i])
+        data, q, s, n = ctx.jpeg_compress(src, 0.94)
+        assert (r.Quality, r.SSIM, r.steps, r.CompressedSize, r.OriginalSize) == (q, s, n, len(data), len(files[i])) and f == data
+    want = batch.summarize_local(res)
+    assert (summ.Total, summ.Succeeded, summ.Failed, summ.TotalSaved, summ.AvgSSIM) == (want.Total, want.Succeeded, want.Failed, want.TotalSaved, want.AvgSSIM)
+    assert batch.compress_batch_jpeg_native([]) == ([], [], batch.BatchSummary())
+
+
+@pytest.mark.gpu
+def test_gpu_decode_of_damaged_scans_terminates_and_agrees_with_the_checker(ctx):
+    """Random bytes of the scan replaced: the device either decodes -- then to the checker's pixels whenever the checker
+    decodes too -- or reports a corrupt file; it never hangs, and the ctx keeps working."""
+    import fennec_amd
+    rng = np.random.default_rng(11)
+    src = _photo(200, 136, 2)
+    both = dev_only = chk_only = neither = 0
+    for g in (_pil(src, quality=85, subsampling=2), orc.jpeg_encode(src, 60), _pil(src, quality=95, subsampling=0, optimize=True)):
+        scan = g.index(b"\xff\xda") + 14
+        for c in _mutations(g, rng, 120, scan, len(g) - 2):
+            try:
+                want = orc.jpeg_decode(c)
+            except Exception:
+                want = None
+            try:
+                got = ctx.jpeg_decode(c)
+            except fennec_amd.FennecError:
+                got = None
+            if got is not None and want is not None:
+                assert np.array_equal(got, want)
+                both += 1
+            elif got is not None:
+                dev_only += 1
+            elif want is not None:
+                chk_only += 1
+            else:
+                neither += 1
+        assert np.array_equal(ctx.jpeg_decode(g), orc.jpeg_decode(g))
+    print(f"damaged scans: both decode {both}, device only {dev_only}, checker only {chk_only}, neither {neither}")
+    assert both > 50

@@ -18,6 +18,12 @@ python bench.py --workload config5 --device-codec --steps 3 --warmup 1 --no-cpu-
 mkdir -p $O/profile_${R}_config5_device_codec
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/profile_${R}_config5_device_codec/stats -o bench -- \
     python $ROOT/bench.py --workload config5 --device-codec --steps 2 --warmup 1 --no-cpu-baseline > $ROOT/$O/profile_${R}_config5_device_codec/bench_under_stats.json 2> $ROOT/$O/c5stats.log )
+python bench.py --workload config5 --device-decode --no-cpu-baseline > $O/${R}_config5_device_decode_bench_plain.json 2>> $O/c3c4.log
+mkdir -p $O/profile_${R}_config5_device_decode
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$O/profile_${R}_config5_device_decode/stats -o bench -- \
+    python $ROOT/bench.py --workload config5 --device-decode --workers 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $ROOT/$O/profile_${R}_config5_device_decode/bench_under_stats.json 2> $ROOT/$O/c5dstats.log )
+python tools/time_jpeg_decode.py > $O/${R}_time_jpeg_decode.txt 2>&1
+python tools/time_batch_jpeg_native.py > $O/${R}_time_batch_jpeg_native.txt 2>&1
 python tools/time_ops.py > $O/${R}_time_ops.txt 2>&1
 python tools/time_fx.py > $O/${R}_time_fx.txt 2>&1
 python tools/time_resize.py > $O/${R}_time_resize_ramp.txt 2>&1
