@@ -377,7 +377,15 @@ def test_gpu_native_pool_callbacks_cancel_and_release():
     seen = []
     CB = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
     cb = CB(lambda c, t, u: seen.append((c, t)))
-    L.fennec_CompressBatchNRGBA.argtypes = L.fennec_CompressBatchNRGBA.argtypes[:-2] + [CB, C.c_void_p]
+    keep = L.fennec_CompressBatchNRGBA.argtypes
+    L.fennec_CompressBatchNRGBA.argtypes = keep[:-2] + [CB, C.c_void_p]
+    try:
+        _pool_callbacks_body(L, fa, C, n, srcs, strides, ws, hs, outs, caps, res, cb, seen, imgs, bufs)
+    finally:
+        L.fennec_CompressBatchNRGBA.argtypes = keep            # the wrapper (batch.compress_batch_native) passes None for the callback
+
+
+def _pool_callbacks_body(L, fa, C, n, srcs, strides, ws, hs, outs, caps, res, cb, seen, imgs, bufs):
     cancel = C.c_int(0)
     assert L.fennec_CompressBatchNRGBA(0, 3, n, fa.FNX_HOST, srcs, strides, ws, hs, None, 0.94, outs, caps, res, C.byref(cancel), cb, None) == fa.FNX_OK
     assert sorted(c for c, _ in seen) == list(range(1, n + 1)) and all(t == n for _, t in seen)

@@ -34,6 +34,9 @@ def worker(k):
                 b = c.GaussianBlur(img, 2.0)                           # host-space call
                 v3 = c.SSIMFast(img, b)
                 q, s_, steps, found = c.jpeg_quality_search(img, 0.94)
+                data = batch.pillow_encode(img, 90)
+                out, q2, s2, st2, dims = c.jpeg_recompress(data, 0.94)   # the decoder's host side (parser, unstuffing) + its launches
+                assert dims == (w, h) and out[:2] == b"\xff\xd8"
                 assert 0 < v1 <= 1 and 0 < v2 <= 1 and 0 < v3 <= 1 and 1 <= q <= 100
                 try:
                     c.lanczosResize(np.zeros((4, 4, 3), np.uint8), 2, 2)   # thread-local error text
@@ -56,6 +59,9 @@ assert all(r.Err is None for r in res), [r.Err for r in res]
 items = [synth.large_photo(320 + 16 * k, 240, k) for k in range(10)]
 nres, nfiles, nsumm = batch.compress_batch_native(items, workers=4)
 assert all(r.Err is None for r in nres) and nsumm.Succeeded == len(items)
+# ... over files (fennec_CompressBatchJPEG: decoder + search + encoder per item on the workers' contexts)
+jres, jfiles, jsumm = batch.compress_batch_jpeg_native(jpegs, workers=4)
+assert all(r.Err is None for r in jres) and jsumm.Succeeded == len(jpegs)
 print("errors:", errs)
 print("done" if not errs else "FAILED")
 sys.exit(1 if errs else 0)
