@@ -1152,7 +1152,8 @@ static int jpeg_decode_device(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegF
     void *t = nullptr;
     FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_IMG, static_cast<size_t>(f->w) * f->h * 4 + 16, &t));
     *img = static_cast<uint8_t *>(t);
-    return launch_ycbcr_to_nrgba(ctx, pl[0], ys, pl[1], pl[2], cs, f->ratio, f->w, f->h, *img, f->w * 4);
+    const bool grey = f->ncomp == 1;         // image.Gray: convert.hip's cb == cr == NULL form
+    return launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f->ratio, f->w, f->h, *img, f->w * 4);
 }
 
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h)
@@ -1174,7 +1175,8 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
     uint8_t *pl[3];
     int ys = 0, cs = 0;
     FNX_TRY(jpeg_decode_planes(ctx, data, n, &f, pl, &ys, &cs));
-    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, pl[1], pl[2], cs, f.ratio, f.w, f.h, d.p, d.stride));
+    const bool grey = f.ncomp == 1;
+    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, d.p, d.stride));
     return finish(ctx, space, &d);
 }
 

@@ -308,7 +308,8 @@ struct DecTables {                                   // tables 0, 1: DC (th 0, 1
 
 struct JpegFile {
     int w = 0, h = 0;
-    int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 2 4:2:0
+    int ncomp = 3;               // 3: image.YCbCr; 1: image.Gray
+    int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0; -1: one component
     int hy = 1, vy = 1;          // Y blocks per MCU across / down
     int nslots = 3;              // blocks per MCU
     int mx = 0, my = 0;          // MCUs per row / column

@@ -25,8 +25,8 @@
 // The host parses the segments, builds the decoding tables and removes the 0x00 stuffed behind every 0xff while it
 // copies the scan into pinned memory (one memchr pass).
 //
-// Handled: what jpeg.Encode, libjpeg and most cameras write -- baseline (SOF0), 8 bit, three components, 4:4:4 or
-// 4:2:0, one interleaved scan, no restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
+// Handled: what jpeg.Encode, libjpeg and most cameras write -- baseline (SOF0), 8 bit, three components (4:4:4, 4:2:2,
+// 4:2:0, 4:4:0) or one (image.Gray), one scan, no restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
 // host); a scan that ends early or holds a code outside its table is FNX_ERR_INVALID.  Restated from ITU T.81 and
 // reader.go / scan.go / huffman.go's published behaviour, not from Go's source: bit-exact against the CPU restatement
 // the tests hold (which libjpeg-turbo's files exercise), parity with Go unpinned.
@@ -279,13 +279,13 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
 struct DcArgs {
     const int16_t *coef;
     uint32_t *dcb;            // [nblk] DC difference + 2048, component by component (Y in scan order, then Cb, then Cr)
-    int nblk, nmcu, ny;       // ny: Y blocks per MCU (4 or 1)
+    int nblk, nmcu, ny, nc;   // ny: Y blocks per MCU (1, 2 or 4); nc: chroma components (2 or 0)
 };
 
 // scan-order block -> its place in the component-major array
-__device__ __forceinline__ int dc_place(int b, int nmcu, int ny)
+__device__ __forceinline__ int dc_place(int b, int nmcu, int ny, int nc)
 {
-    const int per = ny + 2, m = b / per, j = b - m * per;
+    const int per = ny + nc, m = b / per, j = b - m * per;
     return j < ny ? m * ny + j : (ny + (j - ny)) * nmcu + m;
 }
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void jpeg_dc_gather_kernel(DcArgs a)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= a.nblk) return;
-    a.dcb[dc_place(b, a.nmcu, a.ny)] = static_cast<uint32_t>(static_cast<int32_t>(a.coef[static_cast<size_t>(b) * 64]) + 2048);
+    a.dcb[dc_place(b, a.nmcu, a.ny, a.nc)] = static_cast<uint32_t>(static_cast<int32_t>(a.coef[static_cast<size_t>(b) * 64]) + 2048);
 }
 
 struct IdctArgs {
@@ -302,7 +302,7 @@ struct IdctArgs {
     const unsigned long long *dcsum;     // exclusive prefix sum of dcb
     uint8_t *out[3];
     int stride[3], nbx[3], nblocks[3];
-    int mx, nmcu, hy, vy;                // MCUs per row, MCUs, Y blocks per MCU across / down
+    int mx, nmcu, hy, vy, nc;            // MCUs per row, MCUs, Y blocks per MCU across / down, chroma components
     uint16_t q[3][64];                   // natural order
 };
 
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.nblocks[plane]) return;
     const int by = i / a.nbx[plane], bx = i - by * a.nbx[plane];
-    const int ny = a.hy * a.vy, per = ny + 2;
+    const int ny = a.hy * a.vy, per = ny + a.nc;
     int sb, place, start;
     if (plane == 0) {
         const int m = (by / a.vy) * a.mx + bx / a.hy, j = (by % a.vy) * a.hy + bx % a.hy;
@@ -469,7 +469,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     }
     FNX_TRY(launch_scan(ctx, d_cnt, d_first, d_tot, nlanes, reinterpret_cast<unsigned long long *>(d_flag + 66)));
     hipLaunchKernelGGL(jpeg_dwrite_kernel, dim3(nwg_write), dim3(256), 0, ctx->stream, a);
-    DcArgs da{d_coef, d_dcb, nblk, static_cast<int>(nmcu), f->hy * f->vy};
+    DcArgs da{d_coef, d_dcb, nblk, static_cast<int>(nmcu), f->hy * f->vy, f->ncomp - 1};
     hipLaunchKernelGGL(jpeg_dc_gather_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, da);
     FNX_TRY(launch_scan(ctx, d_dcb, d_dcs, d_tot2, nblk, nullptr));
     IdctArgs ia{};
@@ -481,8 +481,8 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
         ia.nblocks[c] = ia.nbx[c] * ((c ? chh : yh) / 8);
         for (int k = 0; k < 64; k++) ia.q[c][k] = f->q[c][k];
     }
-    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy;
-    hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, 3), dim3(256), 0, ctx->stream, ia);
+    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1;
+    hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, f->ncomp), dim3(256), 0, ctx->stream, ia);
     FNX_HIP(hipGetLastError());
     // what the scan held: blocks finished inside the string, and the write pass's complaints
     struct { uint32_t err, pad; unsigned long long blocks; } chk;

@@ -12,7 +12,7 @@ static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
 
 int jpeg_unsupported(const char *what)
 {
-    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 3 components, 4:4:4 or 4:2:0, one scan, no restart intervals)", what);
+    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 1 or 3 components, luminance factors 1 or 2, one scan, no restart intervals)", what);
     return FNX_ERR_UNSUPPORTED;
 }
 
@@ -27,7 +27,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
     if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return jpeg_corrupt("no SOI marker");
     bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
     uint8_t q[4][64];
-    int comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    int ncomp = 0, comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
     std::memset(&f->tab, 0, sizeof(f->tab));
     size_t pos = 2;
     for (;;) {
@@ -55,12 +55,13 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             if (have_sof) return jpeg_corrupt("two SOF segments");
             if (sl < 6) return jpeg_corrupt("bad SOF segment");
             if (seg[0] != 8) return jpeg_unsupported("a sample precision other than 8 bits");
-            if (seg[5] != 3) return jpeg_unsupported("a component count other than 3");
-            if (sl < 6 + 9) return jpeg_corrupt("bad SOF segment");
+            if (seg[5] != 3 && seg[5] != 1) return jpeg_unsupported("a component count other than 1 and 3");
+            ncomp = seg[5];
+            if (sl < 6 + 3 * static_cast<size_t>(ncomp)) return jpeg_corrupt("bad SOF segment");
             f->h = (seg[1] << 8) | seg[2];
             f->w = (seg[3] << 8) | seg[4];
             if (f->w <= 0 || f->h <= 0) return jpeg_unsupported("a zero dimension (DNL)");
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < ncomp; c++) {
                 comp_id[c] = seg[6 + 3 * c];
                 comp_h[c] = seg[7 + 3 * c] >> 4;
                 comp_v[c] = seg[7 + 3 * c] & 15;
@@ -107,10 +108,10 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
         } else if (m == 0xda) {
             if (!have_sof) return jpeg_corrupt("SOS before SOF");
-            if (sl < 1 || seg[0] != 3) return jpeg_unsupported("a scan that does not interleave all three components");
-            if (sl < 1 + 6 + 3) return jpeg_corrupt("bad SOS segment");
-            int td[3], ta[3];
-            for (int c = 0; c < 3; c++) {
+            if (sl < 1 || seg[0] != ncomp) return jpeg_unsupported("a scan that does not hold all the frame's components");
+            if (sl < 1 + 2 * static_cast<size_t>(ncomp) + 3) return jpeg_corrupt("bad SOS segment");
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
                 if (seg[1 + 2 * c] != comp_id[c]) return jpeg_unsupported("scan components out of frame order");
                 td[c] = seg[2 + 2 * c] >> 4;
                 ta[c] = seg[2 + 2 * c] & 15;
@@ -118,17 +119,20 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 if (!have_t[td[c]] || !have_t[2 + ta[c]]) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
                 if (!have_q[comp_q[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
             }
-            if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return jpeg_unsupported("an RGB file");
-            const bool chroma11 = comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
-            if (chroma11 && comp_h[0] == 2 && comp_v[0] == 2) {
-                f->ratio = 2; f->hy = 2; f->vy = 2;
-            } else if (chroma11 && comp_h[0] == 1 && comp_v[0] == 1) {
-                f->ratio = 0; f->hy = 1; f->vy = 1;
+            if (ncomp == 3 && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return jpeg_unsupported("an RGB file");
+            if (ncomp == 1) {
+                // a one-component scan is not interleaved (T.81 A.2.2): one block per MCU whatever the factors say; image.Gray
+                f->ratio = -1; f->hy = 1; f->vy = 1;
             } else {
-                return jpeg_unsupported("a subsampling other than 4:4:4 and 4:2:0");
+                if (!(comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1) || comp_h[0] < 1 || comp_h[0] > 2 ||
+                    comp_v[0] < 1 || comp_v[0] > 2)
+                    return jpeg_unsupported("a subsampling other than 4:4:4, 4:2:2, 4:2:0 and 4:4:0");
+                f->hy = comp_h[0]; f->vy = comp_v[0];
+                f->ratio = f->hy == 2 ? (f->vy == 2 ? 2 : 1) : (f->vy == 2 ? 3 : 0);       // image.YCbCrSubsampleRatio
             }
+            f->ncomp = ncomp;
             const int ny = f->hy * f->vy;
-            f->nslots = ny + 2;
+            f->nslots = ny + ncomp - 1;
             f->dcpack = f->acpack = 0;
             for (int s = 0; s < f->nslots; s++) {
                 const int c = s < ny ? 0 : s - ny + 1;
@@ -136,7 +140,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 f->acpack |= static_cast<uint32_t>(2 + ta[c]) << (4 * s);
             }
             for (int c = 0; c < 3; c++)
-                for (int k = 0; k < 64; k++) f->q[c][k] = q[comp_q[c]][k];
+                for (int k = 0; k < 64; k++) f->q[c][k] = c < ncomp ? q[comp_q[c]][k] : 1;
             f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
             f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
             f->scan = pos + 2 + len;

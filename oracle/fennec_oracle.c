@@ -1901,7 +1901,8 @@ static int32_t jr_receive_extend(jpeg_bitr *r, int s)
 }
 
 /* Decodes `data` into MCU-padded planes (yp: ys x 8*vmax*my rows ...).  Returns 1, with *wd, *ht, *ratio
- * (2: 4:2:0, 0: 4:4:4) set, or a negative error.  Call with yp == NULL to learn the dims first. */
+ * (image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0; -1: one component, image.Gray) set, or a negative
+ * error.  Call with yp == NULL to learn the dims first. */
 ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
                                    int16_t *coef)
 {
@@ -1909,7 +1910,7 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
     uint8_t q[4][64];
     jpeg_dtab dt[2][4];
     int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    int W = 0, H = 0, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
+    int W = 0, H = 0, ncomp = 0, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
     long pos = 2;
     for (;;) {
         if (pos + 4 > n || data[pos] != 0xff) return -2;
@@ -1929,9 +1930,10 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
                 o += 65;
             }
         } else if (m == 0xc0) {                                                   /* SOF0 */
-            if (sl < 6 + 9 || seg[0] != 8 || seg[5] != 3) return -4;
+            if (sl < 6 + 3 || seg[0] != 8 || (seg[5] != 3 && seg[5] != 1) || sl < 6 + 3 * seg[5]) return -4;
+            ncomp = seg[5];
             H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4];
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < ncomp; c++) {
                 comp_id[c] = seg[6 + 3 * c]; comp_h[c] = seg[7 + 3 * c] >> 4; comp_v[c] = seg[7 + 3 * c] & 15; comp_q[c] = seg[8 + 3 * c];
             }
         } else if (m == 0xc1 || m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
@@ -1960,27 +1962,33 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
         } else if (m == 0xdd) {
             if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return -7;              /* restart intervals: not handled */
         } else if (m == 0xda) {                                                   /* SOS */
-            if (sl < 1 + 6 + 3 || seg[0] != 3) return -8;
-            int td[3], ta[3];
-            for (int c = 0; c < 3; c++) {
+            if (ncomp == 0 || sl < 1 + 2 * ncomp + 3 || seg[0] != ncomp) return -8;
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
                 if (seg[1 + 2 * c] != comp_id[c]) return -8;
                 td[c] = seg[2 + 2 * c] >> 4; ta[c] = seg[2 + 2 * c] & 15;
                 if (!have_t[0][td[c]] || !have_t[1][ta[c]] || !have_q[comp_q[c]]) return -8;
             }
             if (W <= 0 || H <= 0) return -4;
-            const int r420 = comp_h[0] == 2 && comp_v[0] == 2 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
-            const int r444 = comp_h[0] == 1 && comp_v[0] == 1 && comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1;
-            if (!r420 && !r444) return -9;
-            *wd = W; *ht = H; *ratio = r420 ? 2 : 0;
+            /* Y blocks per MCU across / down: 1 or 2 each (4:4:4, 4:2:2, 4:2:0, 4:4:0); one component: a block per MCU,
+             * whatever its factors say (T.81 A.2.2: a one-component scan is not interleaved) */
+            int hy = 1, vy = 1;
+            if (ncomp == 3) {
+                if (comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) return -9;
+                hy = comp_h[0]; vy = comp_v[0];
+                if (hy < 1 || hy > 2 || vy < 1 || vy > 2) return -9;
+            }
+            *wd = W; *ht = H;
+            *ratio = ncomp == 1 ? -1 : (hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));     /* image.YCbCrSubsampleRatio; -1: image.Gray */
             if (!yp) return 1;
-            const int ms = r420 ? 16 : 8, mx = (W + ms - 1) / ms, my = (H + ms - 1) / ms, ys = ms * mx, cs = 8 * mx;
+            const int msx = 8 * hy, msy = 8 * vy, mx = (W + msx - 1) / msx, my = (H + msy - 1) / msy, ys = msx * mx, cs = 8 * mx;
             jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};
             int32_t pred[3] = {0, 0, 0};
             size_t blk = 0;
             for (int my0 = 0; my0 < my; my0++)
                 for (int mx0 = 0; mx0 < mx; mx0++)
-                    for (int c = 0; c < 3; c++) {
-                        const int nb = c == 0 && r420 ? 4 : 1;
+                    for (int c = 0; c < ncomp; c++) {
+                        const int nb = c == 0 ? hy * vy : 1;
                         for (int i = 0; i < nb; i++, blk++) {
                             int32_t b[64];
                             int16_t zz[64];
@@ -2008,7 +2016,7 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
                             orc_jpeg_idct(b);
                             for (int k = 0; k < 64; k++) b[k] = b[k] < -128 ? 0 : (b[k] > 127 ? 255 : b[k] + 128);
                             if (c == 0) {
-                                const int px = ms * mx0 + (r420 ? (i & 1) * 8 : 0), py = ms * my0 + (r420 ? (i & 2) * 4 : 0);
+                                const int px = msx * mx0 + (i % hy) * 8, py = msy * my0 + (i / hy) * 8;
                                 for (int j = 0; j < 8; j++)
                                     for (int k = 0; k < 8; k++) yp[(size_t)(py + j) * ys + px + k] = (uint8_t)b[8 * j + k];
                             } else {

@@ -488,8 +488,8 @@ def jpeg_encode(img: np.ndarray, quality: int, with_coefficients: bool = False):
 
 
 def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
-    """A baseline 3-component 4:2:0 / 4:4:4 file -> (w, h, ratio, Y, Cb, Cr) MCU-padded planes as reader.go would hold
-    them [, coefficients]."""
+    """A baseline one- or three-component file (4:4:4, 4:2:2, 4:2:0, 4:4:0) -> (w, h, ratio, Y, Cb, Cr) MCU-padded planes as
+    reader.go would hold them [, coefficients]; ratio -1 and Cb = Cr = None: one component (image.Gray)."""
     buf = np.frombuffer(data, dtype=np.uint8)
     L = lib()
     L.orc_jpeg_decode_planes.restype = C.c_int
@@ -500,18 +500,18 @@ def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
     rc = L.orc_jpeg_decode_planes(bp, len(data), C.byref(w), C.byref(h), C.byref(ratio), None, None, None, None)
     if rc != 1:
         raise RuntimeError(f"orc_jpeg_decode_planes: {rc}")
-    ms = 16 if ratio.value == 2 else 8
-    mx, my = (w.value + ms - 1) // ms, (h.value + ms - 1) // ms
-    y = np.empty((ms * my, ms * mx), dtype=np.uint8)
+    hy, vy = {-1: (1, 1), 0: (1, 1), 1: (2, 1), 2: (2, 2), 3: (1, 2)}[ratio.value]
+    mx, my = (w.value + 8 * hy - 1) // (8 * hy), (h.value + 8 * vy - 1) // (8 * vy)
+    y = np.empty((8 * vy * my, 8 * hy * mx), dtype=np.uint8)
     cb = np.empty((8 * my, 8 * mx), dtype=np.uint8)
     cr = np.empty((8 * my, 8 * mx), dtype=np.uint8)
-    nblk = mx * my * (6 if ratio.value == 2 else 3)
+    nblk = mx * my * (1 if ratio.value < 0 else hy * vy + 2)
     coef = np.zeros((nblk, 64), dtype=np.int16) if with_coefficients else None
     rc = L.orc_jpeg_decode_planes(bp, len(data), C.byref(w), C.byref(h), C.byref(ratio), y.ctypes.data_as(_u8p), cb.ctypes.data_as(_u8p),
                                   cr.ctypes.data_as(_u8p), coef.ctypes.data_as(C.POINTER(C.c_int16)) if coef is not None else None)
     if rc != 1:
         raise RuntimeError(f"orc_jpeg_decode_planes: {rc}")
-    out = (w.value, h.value, ratio.value, y, cb, cr)
+    out = (w.value, h.value, ratio.value, y, cb, cr) if ratio.value >= 0 else (w.value, h.value, -1, y, None, None)
     return out + (coef,) if with_coefficients else out
 
 

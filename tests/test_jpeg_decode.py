@@ -31,6 +31,32 @@ def _pil_decode(data):
     return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
 
 
+def _pil_grey(img, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(img[..., 1]), "L").save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _as_440(data):
+    """A 4:2:2 file relabelled as 4:4:0: the luminance factors 2x1 -> 1x2 and width <-> height in the frame header.  The
+    scan stays a valid bit string (two Y blocks, Cb, Cr per MCU, the same number of MCUs); only the geometry changes."""
+    i = data.index(b"\xff\xc0")
+    b = bytearray(data)
+    assert b[i + 9] == 3 and b[i + 11] == 0x21
+    b[i + 5:i + 9] = b[i + 7:i + 9] + b[i + 5:i + 7]
+    b[i + 11] = 0x12
+    return bytes(b)
+
+
+def _with_luma_factors(data, hv):
+    """the frame header's luminance sampling factors overwritten (for the parser: the scan no longer fits them)"""
+    i = data.index(b"\xff\xc0")
+    b = bytearray(data)
+    b[i + 11] = hv
+    return bytes(b)
+
+
 def _noise(w, h, seed=0):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
@@ -51,6 +77,25 @@ def _photo(w, h, seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ CPU: the checker
+def test_oracle_decoder_reads_422_440_and_grey_files():
+    src = _photo(203, 117, 3)
+    d422 = _pil(src, quality=85, subsampling=1)
+    got = orc.jpeg_decode(d422)
+    d = np.abs(got[..., :3].astype(int) - _pil_decode(d422).astype(int))
+    assert got.shape == (117, 203, 4) and d.mean() < 1.2 and np.percentile(d, 99) <= 10          # (libjpeg smooths chroma on the way up)
+    w, h, ratio, y, cb, cr = orc.jpeg_decode_planes(d422)
+    assert ratio == 1 and y.shape == (120, 208) and cb.shape == (120, 104)
+    w, h, ratio, y, cb, cr = orc.jpeg_decode_planes(_as_440(d422))
+    assert (w, h, ratio) == (117, 203, 3) and y.shape == (208, 120) and cb.shape == (104, 120)
+    grey = _pil_grey(src, quality=85)
+    got = orc.jpeg_decode(grey)
+    from PIL import Image
+    ref = np.asarray(Image.open(io.BytesIO(grey)).convert("L"))
+    assert (got[..., 0] == got[..., 1]).all() and (got[..., 1] == got[..., 2]).all() and (got[..., 3] == 255).all()
+    assert np.abs(got[..., 0].astype(int) - ref.astype(int)).max() <= 2            # islow IDCT vs idct.go's
+    assert orc.jpeg_decode_planes(grey)[2] == -1
+
+
 @pytest.mark.parametrize("kw", [dict(quality=85, subsampling=2), dict(quality=60, subsampling=0), dict(quality=92, subsampling=2, optimize=True)])
 def test_oracle_decoder_reads_libjpeg_files(kw):
     src = _photo(203, 117, 3)
@@ -91,11 +136,16 @@ def test_segment_parser_answers_or_refuses_never_crashes():
     good = [_pil(src, quality=80, subsampling=2), _pil(src, quality=80, subsampling=0, optimize=True), orc.jpeg_encode(src, 70)]
     for g in good:
         assert parse(g) == (96, 64)
-    for kw in (dict(progressive=True), dict(subsampling=1), dict(restart_marker_blocks=2)):
+    assert parse(_pil(src, quality=80, subsampling=1)) == (96, 64) and parse(_pil_grey(src, quality=80)) == (96, 64)
+    assert parse(_as_440(_pil(src, quality=80, subsampling=1))) == (64, 96)
+    for kw in (dict(progressive=True), dict(restart_marker_blocks=2)):
         with pytest.raises(fennec_amd.FennecUnsupported):
             parse(_pil(src, quality=80, **kw))
+    for hv in (0x41, 0x42, 0x14, 0x31):                       # 4:1:1, 4:1:0 and friends
+        with pytest.raises(fennec_amd.FennecUnsupported):
+            parse(_with_luma_factors(good[0], hv))
     buf = io.BytesIO()
-    Image.fromarray(src[..., 0], "L").save(buf, "JPEG")
+    Image.fromarray(src, "RGBA").convert("CMYK").save(buf, "JPEG")
     with pytest.raises(fennec_amd.FennecUnsupported):
         parse(buf.getvalue())
     for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"GIF89a" + good[0], b"\xff\xd8\xff\xd9", b"\xff\xd8" + b"\xff" * 64):
@@ -144,6 +194,20 @@ def test_gpu_decode_of_libjpeg_files(ctx, kw):
 
 
 @pytest.mark.gpu
+def test_gpu_decode_422_440_and_grey(ctx):
+    for (w, h) in [(203, 117), (16, 8), (17, 9), (1, 1), (1280, 720), (3840, 2160)]:
+        src = _photo(w, h, w)
+        for q in (35, 90):
+            d422 = _pil(src, quality=q, subsampling=1, optimize=q < 50)
+            for data in (d422, _as_440(d422), _pil_grey(src, quality=q, optimize=q < 50)):
+                assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data)), (w, h, q)
+    # the whole item for such sources: decode + compress
+    data = _pil(_photo(640, 480, 2), quality=93, subsampling=1)
+    out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
+    assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94) and dims == (640, 480)
+
+
+@pytest.mark.gpu
 def test_gpu_decode_flat_and_noise_extremes(ctx):
     flat = np.full((1024, 2048, 4), 255, dtype=np.uint8)
     flat[..., 1] = 77
@@ -173,11 +237,13 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
     import fennec_amd
     from PIL import Image
     src = _photo(160, 120, 4)
-    for kw in (dict(quality=80, progressive=True), dict(quality=80, subsampling=1), dict(quality=80, restart_marker_blocks=4)):
+    for kw in (dict(quality=80, progressive=True), dict(quality=80, restart_marker_blocks=4)):
         with pytest.raises(fennec_amd.FennecUnsupported):
             ctx.jpeg_decode(_pil(src, **kw))
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        ctx.jpeg_decode(_with_luma_factors(_pil(src, quality=80, subsampling=2), 0x41))
     buf = io.BytesIO()
-    Image.fromarray(src[..., 0], "L").save(buf, "JPEG", quality=80)
+    Image.fromarray(src, "RGBA").convert("CMYK").save(buf, "JPEG", quality=80)
     with pytest.raises(fennec_amd.FennecUnsupported):
         ctx.jpeg_decode_config(buf.getvalue())
     good = _pil(src, quality=80, subsampling=2)
