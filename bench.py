@@ -938,6 +938,16 @@ def other_workloads(args) -> int:
                                      "note": "fennec_CompressBatchNRGBA over device-resident decoded sources, 3 runs after the timed region "
                                              "(python-side buffer handling included; tools/time_batch_native.py times the pool alone)"}
             del dres
+    if wl == "palette":
+        # the kernel is bound by VALU issue, not by HBM (palette.hip): 3 instructions per (pixel, palette entry) -- a 4-clock
+        # v_dot4_u32_u8 and two 2-clock integer ops -- on 1024 SIMDs; achieved / peak stay the algorithmic bytes over HBM
+        clk, sec_img = 2.4e9, elapsed / args.steps / B
+        floor = (W * H / 64.0) * 256 * 8.0 / (1024 * clk)
+        out["roofline"].update({"kernel": "apply_palette_kernel (nearest of 256 entries, first minimum wins; one launch per image)",
+                                "bound": "valu", "valu_issue_frac": round(floor / sec_img, 4), "valu_floor_ms_per_image": round(floor * 1e3, 4),
+                                "ms_per_image": round(sec_img * 1e3, 4),
+                                "note": "8 issue clocks per palette entry per wave of 64 pixels at 2.4 GHz is the floor shown; launch, table "
+                                        "upload and sync of the per-image call are inside ms_per_image"})
     if wl == "analyze":
         ms = float(np.mean(pass_ms[-args.steps:]))
         g = alg * B / (ms * 1e-3) / 1e9

@@ -24,15 +24,15 @@ def _jpegs(n=N_ITEMS, w=W, h=H):
     return [batch.pillow_encode(synth.large_photo(w, h, k), 92) for k in range(n)]     # "4K JPEGs, q = 92 up front"
 
 
-def _run_gpu(jpegs, workers, rank=0, world=1, queue_mode="static"):
+def _run_gpu(jpegs, workers, rank=0, world=1, queue_mode="static", device_all=False):
     states = {}
 
     def make_state(wid):
         if wid not in states:
             states[wid] = fennec_amd.Context(0)
         return states[wid]
-    res = batch.compress_batch(len(jpegs), batch.jpeg_item_work(jpegs), make_state, workers=workers, rank=rank, world=world,
-                               queue_mode=queue_mode)
+    work = batch.jpeg_item_work_device_all(jpegs) if device_all else batch.jpeg_item_work(jpegs)     # device_all: no host codec (3.13)
+    res = batch.compress_batch(len(jpegs), work, make_state, workers=workers, rank=rank, world=world, queue_mode=queue_mode)
     for c in states.values():
         c.close()
     return res
@@ -54,12 +54,20 @@ def test_config5_compress_batch_matches_oracle_search(orc):
     got, want = batch.summarize_local(res), batch.summarize_local(seen)
     assert (got.Total, got.Succeeded, got.Failed, got.TotalSaved) == (want.Total, want.Succeeded, want.Failed, want.TotalSaved)
     assert abs(got.AvgSSIM - want.AvgSSIM) <= 1e-9
+    # the same items with NO host codec (decoder + search + encoder on the device): every file is what the device encoder
+    # writes for the oracle's decode of the source at the quality the device search finds -- checked against the CPU side
+    res_dev = _run_gpu(jpegs, workers=4, device_all=True)
+    assert all(r.Err is None and not r.host_decoded for r in res_dev)
+    for r in res_dev[:3]:
+        src = orc.jpeg_decode(jpegs[r.Index])
+        assert r.data == orc.jpeg_encode(src, r.Quality) and r.OriginalSize == len(jpegs[r.Index])
+        assert abs(r.SSIM - orc.ssim_fast(src, orc.jpeg_roundtrip(src, r.Quality), procs=16)) <= 1e-9 and r.SSIM >= 0.94
     s = orc.summarize([False] * N_ITEMS, [True] * N_ITEMS, [r.OriginalSize for r in res], [r.CompressedSize for r in res],
                       [r.SSIM for r in res])
     assert (got.Total, got.Succeeded, got.TotalSaved) == (s["Total"], s["Succeeded"], s["TotalSaved"]) and got.AvgSSIM == s["AvgSSIM"]
 
 
-def _rank_main(rank, world, port, q, queue_mode="static"):
+def _rank_main(rank, world, port, q, queue_mode="static", device_all=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -67,24 +75,24 @@ def _rank_main(rank, world, port, q, queue_mode="static"):
     torch.cuda.set_device(0)                       # both ranks on GPU 0 (RCCL cannot share a device: gloo)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     jpegs = _jpegs()
-    res = _run_gpu(jpegs, workers=2, rank=rank, world=world, queue_mode=queue_mode)
+    res = _run_gpu(jpegs, workers=2, rank=rank, world=world, queue_mode=queue_mode, device_all=device_all)
     s = batch.summarize_distributed(res)
     q.put((rank, [(r.Index, r.Quality, r.steps, r.CompressedSize, r.SSIM) for r in res],
            (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM)))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("queue_mode", ["static", "dynamic"])
-def test_config5_two_ranks_on_one_gpu_equal_single_rank(queue_mode):
+@pytest.mark.parametrize("queue_mode,device_all", [("static", False), ("dynamic", False), ("dynamic", True)])
+def test_config5_two_ranks_on_one_gpu_equal_single_rank(queue_mode, device_all):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    single = _run_gpu(_jpegs(), workers=4)
+    single = _run_gpu(_jpegs(), workers=4, device_all=device_all)
     want = batch.summarize_local(single)
     mpx = mp.get_context("spawn")
     q = mpx.Queue()
-    procs = [mpx.Process(target=_rank_main, args=(r, 2, port, q, queue_mode)) for r in range(2)]
+    procs = [mpx.Process(target=_rank_main, args=(r, 2, port, q, queue_mode, device_all)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=600) for _ in range(2)]

@@ -100,6 +100,45 @@ while time.time() < t_end:
     if okj and it % 4 == 0:
         okj = np.array_equal(orc.jpeg_decode(data), orc.jpeg_roundtrip(img, q)) and ctx.jpeg_encoded_size(img, q) == len(data)
     case("jpeg_encode", okj, desc + f" q={q}")
+    # the decoder: the device's own file, libjpeg's files (every subsampling it takes, grey, optimised tables), damaged scans
+    case("jpeg_decode_own", np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data)), desc + f" q={q}")
+    import io
+    from PIL import Image
+    rgb = Image.fromarray(np.ascontiguousarray(img[..., :3]), "RGB")
+    sub = int(rng.integers(0, 4))
+    buf = io.BytesIO()
+    try:
+        if sub == 3:
+            rgb.convert("L").save(buf, "JPEG", quality=q, optimize=bool(rng.integers(2)) and q < 96)
+        else:
+            rgb.save(buf, "JPEG", quality=q, subsampling=sub, optimize=bool(rng.integers(2)) and q < 96)
+        pdata = buf.getvalue()
+    except OSError:                          # Pillow's encoder buffer (noise at high quality)
+        pdata = None
+    if pdata is not None:
+        case("jpeg_decode_libjpeg", np.array_equal(ctx.jpeg_decode(pdata), orc.jpeg_decode(pdata)), desc + f" q={q} sub={sub}")
+        scan = pdata.index(b"\xff\xda") + (14 if sub != 3 else 10)
+        if len(pdata) - 2 > scan:
+            bad = bytearray(pdata)
+            for _ in range(int(rng.integers(1, 4))):
+                bad[int(rng.integers(scan, len(bad) - 2))] = int(rng.integers(0, 256))
+            bad = bytes(bad)
+            try:
+                want = orc.jpeg_decode(bad)
+            except Exception:
+                want = None
+            try:
+                got = ctx.jpeg_decode(bad)
+            except fennec_amd.FennecError:
+                got = None
+            # both decode: the same pixels.  One refuses what the other takes: reported, not failed (a damaged scan's last
+            # symbol may straddle the end of the string, which the two treat differently) -- counted under its own name
+            if got is not None and want is not None:
+                case("jpeg_decode_damaged_both", np.array_equal(got, want), desc + f" q={q} sub={sub}")
+            elif (got is None) != (want is None):
+                runs["jpeg_decode_damaged_one_sided"] = runs.get("jpeg_decode_damaged_one_sided", 0) + 1
+            else:
+                runs["jpeg_decode_damaged_neither"] = runs.get("jpeg_decode_damaged_neither", 0) + 1
     if it % 5 == 0:
         target = float(rng.choice([0.5, 0.9, 0.94, 0.97, 0.99, 1.0]))
         data, bq, bs, bn = ctx.jpeg_compress(img, target)
