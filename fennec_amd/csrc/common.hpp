@@ -312,6 +312,7 @@ struct JpegFile {
     int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0; -1: one component
     int hy = 1, vy = 1;          // Y blocks per MCU across / down
     int nslots = 3;              // blocks per MCU
+    int ri = 0;                  // MCUs per restart interval (DRI); 0: none
     int mx = 0, my = 0;          // MCUs per row / column
     uint32_t dcpack = 0, acpack = 0;
     uint16_t q[3][64];           // per component, natural order
@@ -323,7 +324,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);
 int jpeg_unsupported(const char *what);     // set_error + FNX_ERR_UNSUPPORTED
 int jpeg_corrupt(const char *what);         // set_error + FNX_ERR_INVALID
 // the scan's bytes without the stuffing into dst (capacity: n - f.scan); *nbytes = what was written
-int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes);
+// rst: the byte offsets (in dst) at which restart intervals 1, 2, ... start
+int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes, std::vector<uint32_t> *rst);
 int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride);
 int launch_scan(fnx_ctx *ctx, const uint32_t *in, unsigned long long *out, unsigned long long *totals, int n, unsigned long long *grand);
 

@@ -26,7 +26,7 @@
 // copies the scan into pinned memory (one memchr pass).
 //
 // Handled: what jpeg.Encode, libjpeg and most cameras write -- baseline (SOF0), 8 bit, three components (4:4:4, 4:2:2,
-// 4:2:0, 4:4:0) or one (image.Gray), one scan, no restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
+// 4:2:0, 4:4:0) or one (image.Gray), one scan, with or without restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
 // host); a scan that ends early or holds a code outside its table is FNX_ERR_INVALID.  Restated from ITU T.81 and
 // reader.go / scan.go / huffman.go's published behaviour, not from Go's source: bit-exact against the CPU restatement
 // the tests hold (which libjpeg-turbo's files exercise), parity with Go unpinned.
@@ -64,7 +64,21 @@ struct DecArgs {
     int nlanes;                                      // spans in the string
     int nblk, nslots;
     uint32_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
+    const uint32_t *rst;                             // byte offsets at which restart intervals 1, 2, ... start (ascending)
+    int nrst;
 };
+
+// Restart intervals (DRI): interval k starts on a byte boundary, in the state (block start, slot 0), with every DC
+// prediction at 0; what is left of the byte before it is padding (1 bits, never a complete code: T.81 forbids the
+// all-ones code).  For a decoder that means: standing on a boundary, start over; a symbol that would reach across
+// the next boundary is not one -- go to the boundary.  A decoder in a WRONG state obeys the same two rules, so every
+// boundary puts it right: with restart intervals no desynchronised run is longer than an interval.
+__device__ __forceinline__ uint32_t rst_rel(const DecArgs &a, int k, long long wg_bit)
+{
+    if (k >= a.nrst) return 0xffffffffu;
+    const long long b = 8ll * a.rst[k] - wg_bit;
+    return b > 0xfffffff0ll ? 0xffffffffu : (b < 0 ? 0u : static_cast<uint32_t>(b));
+}
 
 // state: bit position | position in the block (0..63) << 40 | slot in the MCU << 48
 __device__ __forceinline__ unsigned long long dec_state(unsigned long long p, int z, int slot)
@@ -93,17 +107,33 @@ __device__ __forceinline__ uint32_t dec_word(const uint32_t *seg, uint32_t wi)
 // wave on its SIMD to hide it behind, so the chain is kept short: three words of the string live in registers (the
 // third is fetched a symbol ahead), the symbol's effect on (position, z) is two selects instead of branches, and a code
 // longer than the fast table's 11 bits finds its length by counting, not by a loop.
-template <bool WRITE>
+template <bool WRITE, bool RST>
 __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, uint32_t &rel, int &z, int &slot, uint32_t end, uint32_t &cnt,
-                                         long long blk, uint32_t &bad, uint32_t lim = 0xffffffffu)
+                                         long long blk, uint32_t &bad, long long wg_bit, uint32_t lim = 0xffffffffu)
 {
     uint32_t wi = rel >> 5;
     uint32_t hi = dec_word(sh.seg, wi), lo = dec_word(sh.seg, wi + 1), nxt = dec_word(sh.seg, wi + 2);
+    int rk = 0;
+    uint32_t bnext = 0xffffffffu;
+    if (RST) {                                                     // the first boundary at or after this lane's start
+        const unsigned long long at = static_cast<unsigned long long>(wg_bit + rel);
+        int lo_k = 0, hi_k = a.nrst;
+        while (lo_k < hi_k) {
+            const int mid = (lo_k + hi_k) >> 1;
+            if (8ull * a.rst[mid] < at) lo_k = mid + 1; else hi_k = mid;
+        }
+        rk = lo_k;
+        bnext = rst_rel(a, rk, wg_bit);
+    }
     while (rel < end) {
         if (WRITE && blk + cnt >= a.nblk) break;                   // what follows the last block is padding
         if (WRITE && rel >= lim) {                                 // a block the image needs starts past the end of the string
             bad |= 8u;
             break;
+        }
+        if (RST && rel >= bnext) {                                 // on a boundary: the interval's first block, first slot
+            z = 0; slot = 0;
+            bnext = rst_rel(a, ++rk, wg_bit);
         }
         uint32_t off = rel - 32u * wi;                             // < 64: a symbol is at most 16 + 15 bits
         const bool adv = off >= 32u;
@@ -119,6 +149,10 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
         if (!WRITE && e) {
             // the sync passes' table holds what the symbol does to the state, ready made: bits consumed (code + value)
             // and steps inside the block (1 for a DC, r + 1 for a coefficient or sixteen zeros, 64 for the end of block)
+            if (RST && rel + (e & 0xffu) > bnext) {                // padding before a boundary
+                rel = bnext;
+                continue;
+            }
             rel += e & 0xffu;
             z += static_cast<int>(e >> 8);
             const bool fin = z >= 64;
@@ -129,6 +163,7 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             continue;
         }
         int len = static_cast<int>(e >> 8), sym = static_cast<int>(e & 0xffu);
+        bool nocode = false;
         if (e == 0) {
             // limit[] rises with the length: the code's length is the first L with c16 < limit[L]
             int L = DEC_FAST_BITS + 1;
@@ -137,10 +172,15 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             const bool hit = c16 < sh.tab.limit[t][16];
             len = L;
             sym = hit ? sh.tab.value[t][(static_cast<int>(c16 >> (16 - L)) + sh.tab.delta[t][L]) & 255] : 0;
-            if (WRITE && !hit) bad |= 1u;
+            nocode = !hit;
         }
         const int s = sym & 15, r = sym >> 4;
         const bool dc = z == 0;
+        if (RST && rel + static_cast<uint32_t>(len + s) > bnext) {  // padding before a boundary (the boundary resets the state)
+            rel = bnext;
+            continue;
+        }
+        if (WRITE && nocode) bad |= 1u;                            // (after the boundary test: padding is not a code either)
         if (WRITE) {
             int32_t v = 0;
             if (s) {                                               // receive + extend (T.81 F.2.2.1)
@@ -185,7 +225,7 @@ __device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long 
 
 // <false>: workgroup g owns spans [g OWN, (g + 1) OWN) and decodes the WARM spans before them as well (their results
 // are dropped).  <true>: the same ownership, no warm-up -- only a workgroup whose predecessor ended elsewhere runs.
-template <bool FIX>
+template <bool FIX, bool RST>
 __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
@@ -225,7 +265,7 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
             int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
             uint32_t bad = 0;
             my_cnt = 0;
-            dec_span<false>(sh, a, rel, z, slot, end, my_cnt, 0, bad);
+            dec_span<false, RST>(sh, a, rel, z, slot, end, my_cnt, 0, bad, wg_bit);
             my_out = dec_state(static_cast<unsigned long long>(wg_bit + rel), z, slot);
             sh.out[t] = my_out;
         }
@@ -255,6 +295,7 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
     }
 }
 
+template <bool RST>
 __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
@@ -270,8 +311,8 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
     int z = static_cast<int>((st >> 40) & 0xffu), slot = static_cast<int>(st >> 48);
     uint32_t cnt = 0, bad = 0;
     const unsigned long long left = a.nbits - wg_bit;              // (this lane exists: its span starts inside the string)
-    dec_span<true>(sh, a, rel, z, slot, static_cast<uint32_t>(t + 1) * DEC_SPAN, cnt, blk, bad,
-                   left > 0xfffffff0ull ? 0xfffffff0u : static_cast<uint32_t>(left));
+    dec_span<true, RST>(sh, a, rel, z, slot, static_cast<uint32_t>(t + 1) * DEC_SPAN, cnt, blk, bad, static_cast<long long>(wg_bit),
+                        left > 0xfffffff0ull ? 0xfffffff0u : static_cast<uint32_t>(left));
     if (bad) atomicOr(a.err, bad);
 }
 
@@ -303,6 +344,7 @@ struct IdctArgs {
     uint8_t *out[3];
     int stride[3], nbx[3], nblocks[3];
     int mx, nmcu, hy, vy, nc;            // MCUs per row, MCUs, Y blocks per MCU across / down, chroma components
+    int ri;                              // MCUs per restart interval (the DC prediction starts over in each); 0: one interval
     uint16_t q[3][64];                   // natural order
 };
 
@@ -318,12 +360,13 @@ __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
         const int m = (by / a.vy) * a.mx + bx / a.hy, j = (by % a.vy) * a.hy + bx % a.hy;
         sb = m * per + j;
         place = m * ny + j;
-        start = 0;
+        start = a.ri > 0 ? (m / a.ri) * a.ri * ny : 0;
     } else {
         const int m = by * a.mx + bx;
         sb = m * per + ny + plane - 1;
-        start = (ny + plane - 1) * a.nmcu;
-        place = start + m;
+        const int first = (ny + plane - 1) * a.nmcu;
+        place = first + m;
+        start = first + (a.ri > 0 ? (m / a.ri) * a.ri : 0);
     }
     const int16_t *cp = a.coef + static_cast<size_t>(sb) * 64;
     int32_t b[64];
@@ -337,7 +380,7 @@ __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
             b[8 * r + c] = cv * static_cast<int32_t>(a.q[plane][8 * r + c]);
         }
     }
-    // the block's DC: the sum of its component's differences up to it
+    // the block's DC: the sum of its component's differences from the start of its restart interval up to it
     const long long dsum = static_cast<long long>(a.dcsum[place] - a.dcsum[start]) + a.dcb[place] - 2048ll * (place - start + 1);
     b[0] = static_cast<int32_t>(dsum) * static_cast<int32_t>(a.q[plane][0]);
 #pragma unroll
@@ -369,10 +412,15 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     FNX_TRY(jpeg_parse(data, n, f));
     void *pin = nullptr, *tpin = nullptr;
     const size_t cap = (n - f->scan + 64 + 63) & ~size_t(63);           // >= the scan + 4 words of zeros
-    FNX_TRY(pinned_alloc(ctx, cap + 2 * sizeof(DecTables), &pin));        // one slice: a second request could wrap the ring onto it
+    const long long nmcu0 = static_cast<long long>(f->mx) * f->my;
+    const size_t rst_max = f->ri > 0 ? static_cast<size_t>((nmcu0 + f->ri - 1) / f->ri) : 0;
+    FNX_TRY(pinned_alloc(ctx, cap + 2 * sizeof(DecTables) + 4 * rst_max + 64, &pin));   // one slice: a second request could wrap the ring onto it
     tpin = static_cast<uint8_t *>(pin) + cap;
     size_t nb = 0;
-    FNX_TRY(jpeg_unstuff(data, n, *f, static_cast<uint8_t *>(pin), &nb));
+    std::vector<uint32_t> rst;
+    FNX_TRY(jpeg_unstuff(data, n, *f, static_cast<uint8_t *>(pin), &nb, &rst));
+    uint32_t *rpin = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(tpin) + 2 * sizeof(DecTables));
+    if (!rst.empty()) std::memcpy(rpin, rst.data(), 4 * rst.size());
     const size_t nwords = (nb + 3) / 4 + 4;
     std::memset(static_cast<uint8_t *>(pin) + nb, 0, nwords * 4 - nb);
     const unsigned long long nbits = 8ull * nb;
@@ -387,7 +435,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
 
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t lanes_pad = static_cast<size_t>(nwg) * 256;
-    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(2 * sizeof(DecTables)), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
+    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(2 * sizeof(DecTables) + 4 * rst_max + 16), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
                  b_first = al(8 * lanes_pad), b_tot = al(8 * (lanes_pad / SCAN_PER_WG_D + 2)), b_flag = al(4 * 64 + 16),
                  b_coef = al(sizeof(int16_t) * 64 * static_cast<size_t>(nblk)), b_dcb = al(4 * static_cast<size_t>(nblk)),
                  b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2));
@@ -428,7 +476,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
             }
     }
     FNX_HIP(hipMemcpyAsync(d_ecs, pin, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
-    FNX_HIP(hipMemcpyAsync(d_tab, tpin, 2 * sizeof(DecTables), hipMemcpyHostToDevice, ctx->stream));
+    FNX_HIP(hipMemcpyAsync(d_tab, tpin, 2 * sizeof(DecTables) + 4 * rst.size(), hipMemcpyHostToDevice, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_flag, 0, b_flag, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk), ctx->stream));
 
@@ -440,8 +488,11 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     a.dbg = trace ? d_flag + 72 : nullptr;
     a.nwords = static_cast<long long>(nwords); a.nbits = nbits; a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
     a.dcpack = f->dcpack; a.acpack = f->acpack;
+    a.rst = reinterpret_cast<const uint32_t *>(d_tab + 2); a.nrst = static_cast<int>(rst.size());
+    const bool has_rst = !rst.empty();
     FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
-    hipLaunchKernelGGL(jpeg_dsync_kernel<false>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+    if (has_rst) hipLaunchKernelGGL((jpeg_dsync_kernel<false, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((jpeg_dsync_kernel<false, false>), dim3(nwg), dim3(256), 0, ctx->stream, a);
     FNX_HIP(hipGetLastError());
     FNX_TRY(prof_end(ctx));
     // rounds across workgroups, two per read-back; a round that changes nothing ends it (at most nwg rounds can change something)
@@ -453,7 +504,8 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
             const int r0 = r;
             for (int k = 0; k < 2 && r < 64; k++, r++) {
                 a.flag = d_flag + r;
-                hipLaunchKernelGGL(jpeg_dsync_kernel<true>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+                if (has_rst) hipLaunchKernelGGL((jpeg_dsync_kernel<true, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((jpeg_dsync_kernel<true, false>), dim3(nwg), dim3(256), 0, ctx->stream, a);
             }
             FNX_HIP(hipGetLastError());
             FNX_TRY(fetch_bytes(ctx, d_flag, flags, sizeof(uint32_t) * static_cast<size_t>(r)));
@@ -468,7 +520,8 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
         }
     }
     FNX_TRY(launch_scan(ctx, d_cnt, d_first, d_tot, nlanes, reinterpret_cast<unsigned long long *>(d_flag + 66)));
-    hipLaunchKernelGGL(jpeg_dwrite_kernel, dim3(nwg_write), dim3(256), 0, ctx->stream, a);
+    if (has_rst) hipLaunchKernelGGL(jpeg_dwrite_kernel<true>, dim3(nwg_write), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(jpeg_dwrite_kernel<false>, dim3(nwg_write), dim3(256), 0, ctx->stream, a);
     DcArgs da{d_coef, d_dcb, nblk, static_cast<int>(nmcu), f->hy * f->vy, f->ncomp - 1};
     hipLaunchKernelGGL(jpeg_dc_gather_kernel, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, da);
     FNX_TRY(launch_scan(ctx, d_dcb, d_dcs, d_tot2, nblk, nullptr));
@@ -481,7 +534,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
         ia.nblocks[c] = ia.nbx[c] * ((c ? chh : yh) / 8);
         for (int k = 0; k < 64; k++) ia.q[c][k] = f->q[c][k];
     }
-    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1;
+    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1; ia.ri = f->ri;
     hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, f->ncomp), dim3(256), 0, ctx->stream, ia);
     FNX_HIP(hipGetLastError());
     // what the scan held: blocks finished inside the string, and the write pass's complaints

@@ -2,6 +2,7 @@
 // entropy-coded segment without its stuffing.  Plain C++ with no device code in it -- this is the part that reads
 // untrusted bytes, and the sanitizer builds (make asan / tsan) instrument it with the rest of the host layer.
 #include <cstring>
+#include <vector>
 #include "common.hpp"
 
 namespace fnx {
@@ -12,7 +13,7 @@ static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
 
 int jpeg_unsupported(const char *what)
 {
-    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 1 or 3 components, luminance factors 1 or 2, one scan, no restart intervals)", what);
+    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 1 or 3 components, luminance factors 1 or 2, one scan)", what);
     return FNX_ERR_UNSUPPORTED;
 }
 
@@ -29,6 +30,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
     uint8_t q[4][64];
     int ncomp = 0, comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
     std::memset(&f->tab, 0, sizeof(f->tab));
+    f->ri = 0;
     size_t pos = 2;
     for (;;) {
         if (pos + 4 > n) return jpeg_corrupt("the file ends before its scan");
@@ -103,7 +105,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 o += 17 + total;
             }
         } else if (m == 0xdd) {
-            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return jpeg_unsupported("a restart interval");
+            if (sl < 2) return jpeg_corrupt("bad DRI segment");
+            f->ri = (seg[0] << 8) | seg[1];                               // MCUs per restart interval; 0: none
         } else if (m == 0xee) {
             if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
         } else if (m == 0xda) {
@@ -151,10 +154,13 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
 }
 
 // The scan's bytes without the stuffing into `dst` (capacity: n - f.scan); *nbytes = what was written.
-int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes)
+int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes, std::vector<uint32_t> *rst)
 {
     const uint8_t *s = data + f.scan, *end = data + n;
     uint8_t *d = dst;
+    const long long nmcu = static_cast<long long>(f.mx) * f.my;
+    const long long want = f.ri > 0 ? (nmcu + f.ri - 1) / f.ri - 1 : 0;      // restart markers a complete scan holds
+    rst->clear();
     for (;;) {
         const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(s, 0xff, static_cast<size_t>(end - s)));
         if (!ff || ff + 1 >= end) return jpeg_corrupt("the scan runs to the end of the file (no EOI)");
@@ -169,11 +175,18 @@ int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst,
         } else if (m == 0xd9) {
             break;
         } else if (m >= 0xd0 && m <= 0xd7) {
-            return jpeg_unsupported("a restart marker");
+            // RSTn: the next interval starts here, on a byte boundary, with every prediction and the MCU position reset
+            if (f.ri <= 0) return jpeg_corrupt("a restart marker in a scan without restart intervals");
+            if (m != 0xd0 + (rst->size() & 7u)) return jpeg_corrupt("restart markers out of sequence");
+            if (static_cast<long long>(rst->size()) >= want) return jpeg_corrupt("more restart markers than the image has intervals");
+            if (static_cast<size_t>(d - dst) > 0xfffffff0u) return jpeg_unsupported("a scan this large with restart intervals");
+            rst->push_back(static_cast<uint32_t>(d - dst));
+            s = ff + 2;
         } else {
             return jpeg_unsupported("a second scan (or another segment) behind the first");
         }
     }
+    if (static_cast<long long>(rst->size()) != want) return jpeg_corrupt("fewer restart markers than the image has intervals");
     *nbytes = static_cast<size_t>(d - dst);
     return FNX_OK;
 }

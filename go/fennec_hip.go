@@ -682,7 +682,7 @@ func lastError(what string) error {
 }
 
 // jpegDecodeHIP is image.Decode + toNRGBARef for a JPEG file (io.go:60-95) on the device.  ok == false: the device was
-// not used or does not take this file (progressive, restart intervals, 4:1:1, CMYK: FNX_ERR_UNSUPPORTED) -- the
+// not used or does not take this file (progressive, 4:1:1, CMYK: FNX_ERR_UNSUPPORTED) -- the
 // caller runs image.Decode as before.  err != nil: the file is corrupt (what image.Decode would report).
 func jpegDecodeHIP(data []byte) (img *image.NRGBA, ok bool, err error) {
 	c := poolGetIf(useDeviceSearch && len(data) > 4)

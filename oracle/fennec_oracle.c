@@ -1849,8 +1849,8 @@ ORC_API long orc_jpeg_encode(const uint8_t *src, int sstride, int w, int h, int 
     return bw.overflow ? -(long)bw.n : (long)bw.n;
 }
 
-/* ---- a baseline decoder: 8-bit, three components, 4:2:0 or 4:4:4, one scan, no restart intervals (what jpeg.Encode
- * and libjpeg's defaults write).  Entropy decoding is the standard's (F.2.2); the pixels are made the way reader.go /
+/* ---- a baseline decoder: 8-bit, one component or three (luminance factors 1 or 2), one scan, restart intervals or none
+ * (what jpeg.Encode, libjpeg and cameras write).  Entropy decoding is the standard's (F.2.2); the pixels are made the way reader.go /
  * idct.go make them: coefficient * q, the Chen-Wang IDCT, + 128, clamp. */
 typedef struct {
     const uint8_t *p;
@@ -1910,6 +1910,7 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
     uint8_t q[4][64];
     jpeg_dtab dt[2][4];
     int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    int ri = 0;
     int W = 0, H = 0, ncomp = 0, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
     long pos = 2;
     for (;;) {
@@ -1960,7 +1961,7 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
                 o += 17 + total;
             }
         } else if (m == 0xdd) {
-            if (sl >= 2 && ((seg[0] << 8) | seg[1]) != 0) return -7;              /* restart intervals: not handled */
+            if (sl >= 2) ri = (seg[0] << 8) | seg[1];                             /* MCUs per restart interval; 0: none */
         } else if (m == 0xda) {                                                   /* SOS */
             if (ncomp == 0 || sl < 1 + 2 * ncomp + 3 || seg[0] != ncomp) return -8;
             int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
@@ -1985,8 +1986,16 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
             jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};
             int32_t pred[3] = {0, 0, 0};
             size_t blk = 0;
+            long mcu = 0;
             for (int my0 = 0; my0 < my; my0++)
-                for (int mx0 = 0; mx0 < mx; mx0++)
+                for (int mx0 = 0; mx0 < mx; mx0++, mcu++) {
+                    if (ri > 0 && mcu > 0 && mcu % ri == 0) {
+                        /* a restart interval ends: the rest of the byte is padding, RSTn follows, predictions start over */
+                        br.nbits = 0;
+                        if (br.pos + 2 > br.n || br.p[br.pos] != 0xff || br.p[br.pos + 1] != (uint8_t)(0xd0 + ((mcu / ri - 1) & 7))) return -11;
+                        br.pos += 2;
+                        pred[0] = pred[1] = pred[2] = 0;
+                    }
                     for (int c = 0; c < ncomp; c++) {
                         const int nb = c == 0 ? hy * vy : 1;
                         for (int i = 0; i < nb; i++, blk++) {
@@ -2026,6 +2035,7 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
                             }
                         }
                     }
+                }
             return 1;
         }
         pos += 2 + len;

@@ -109,6 +109,15 @@ def test_oracle_decoder_reads_libjpeg_files(kw):
     assert np.percentile(d, 99) <= (12 if kw["subsampling"] == 2 else 3)
 
 
+def test_oracle_decoder_restart_intervals_give_the_same_pixels():
+    src = _photo(203, 117, 3)
+    for sub in (0, 1, 2):
+        want = orc.jpeg_decode(_pil(src, quality=85, subsampling=sub))
+        for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=5), dict(restart_marker_rows=1)):
+            data = _pil(src, quality=85, subsampling=sub, **kw)
+            assert b"\xff\xdd" in data and np.array_equal(orc.jpeg_decode(data), want), (sub, kw)
+
+
 def test_oracle_decoder_inverts_its_encoder_exactly():
     for (w, h, q) in [(16, 16, 50), (33, 19, 90), (1, 1, 75), (120, 64, 100)]:
         src = _photo(w, h, w)
@@ -138,9 +147,9 @@ def test_segment_parser_answers_or_refuses_never_crashes():
         assert parse(g) == (96, 64)
     assert parse(_pil(src, quality=80, subsampling=1)) == (96, 64) and parse(_pil_grey(src, quality=80)) == (96, 64)
     assert parse(_as_440(_pil(src, quality=80, subsampling=1))) == (64, 96)
-    for kw in (dict(progressive=True), dict(restart_marker_blocks=2)):
-        with pytest.raises(fennec_amd.FennecUnsupported):
-            parse(_pil(src, quality=80, **kw))
+    assert parse(_pil(src, quality=80, restart_marker_blocks=2)) == (96, 64)
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        parse(_pil(src, quality=80, progressive=True))
     for hv in (0x41, 0x42, 0x14, 0x31):                       # 4:1:1, 4:1:0 and friends
         with pytest.raises(fennec_amd.FennecUnsupported):
             parse(_with_luma_factors(good[0], hv))
@@ -208,6 +217,29 @@ def test_gpu_decode_422_440_and_grey(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_decode_with_restart_intervals(ctx):
+    """DRI: every interval starts byte-aligned in a known state with the DC predictions at 0 -- intervals of one MCU, of a
+    few, of an MCU row, of more MCUs than the image has; every subsampling and grey; the same pixels as the file
+    without restart markers (the checker says so on the CPU, here the device must agree with the checker)."""
+    for (w, h) in [(203, 117), (16, 16), (1280, 720), (3840, 2160)]:
+        src = _photo(w, h, w)
+        plain = {}
+        for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=1), dict(restart_marker_blocks=60000)):     # (<= 65535: what a DRI segment can say)
+            if w > 2000 and kw.get("restart_marker_blocks") == 1:
+                continue
+            for sub in (0, 1, 2, "L"):
+                data = _pil_grey(src, quality=88, **kw) if sub == "L" else _pil(src, quality=88, subsampling=sub, **kw)
+                got = ctx.jpeg_decode(data)
+                assert np.array_equal(got, orc.jpeg_decode(data)), (w, h, kw, sub)
+                if sub not in plain:
+                    plain[sub] = ctx.jpeg_decode(_pil_grey(src, quality=88) if sub == "L" else _pil(src, quality=88, subsampling=sub))
+                assert np.array_equal(got, plain[sub]), (w, h, kw, sub)
+    data = _pil(_photo(640, 480, 2), quality=93, subsampling=2, restart_marker_rows=1)
+    out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
+    assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
+
+
+@pytest.mark.gpu
 def test_gpu_decode_flat_and_noise_extremes(ctx):
     flat = np.full((1024, 2048, 4), 255, dtype=np.uint8)
     flat[..., 1] = 77
@@ -237,9 +269,15 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
     import fennec_amd
     from PIL import Image
     src = _photo(160, 120, 4)
-    for kw in (dict(quality=80, progressive=True), dict(quality=80, restart_marker_blocks=4)):
-        with pytest.raises(fennec_amd.FennecUnsupported):
-            ctx.jpeg_decode(_pil(src, **kw))
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        ctx.jpeg_decode(_pil(src, quality=80, progressive=True))
+    # restart markers: one missing, two swapped
+    rs = _pil(src, quality=80, subsampling=2, restart_marker_blocks=3)
+    i0, i1 = rs.index(b"\xff\xd0"), rs.index(b"\xff\xd1")
+    for bad in (rs[:i0] + rs[i0 + 2:], rs[:i0] + b"\xff\xd1" + rs[i0 + 2:i1] + b"\xff\xd0" + rs[i1 + 2:]):
+        with pytest.raises(fennec_amd.FennecError) as e:
+            ctx.jpeg_decode(bad)
+        assert not isinstance(e.value, fennec_amd.FennecUnsupported)
     with pytest.raises(fennec_amd.FennecUnsupported):
         ctx.jpeg_decode(_with_luma_factors(_pil(src, quality=80, subsampling=2), 0x41))
     buf = io.BytesIO()

@@ -107,16 +107,18 @@ while time.time() < t_end:
     rgb = Image.fromarray(np.ascontiguousarray(img[..., :3]), "RGB")
     sub = int(rng.integers(0, 4))
     buf = io.BytesIO()
+    rs = {} if rng.integers(2) else ({"restart_marker_rows": int(rng.integers(1, 4))} if rng.integers(2) else
+                                     {"restart_marker_blocks": int(rng.integers(1, 40))})
     try:
         if sub == 3:
-            rgb.convert("L").save(buf, "JPEG", quality=q, optimize=bool(rng.integers(2)) and q < 96)
+            rgb.convert("L").save(buf, "JPEG", quality=q, optimize=bool(rng.integers(2)) and q < 96, **rs)
         else:
-            rgb.save(buf, "JPEG", quality=q, subsampling=sub, optimize=bool(rng.integers(2)) and q < 96)
+            rgb.save(buf, "JPEG", quality=q, subsampling=sub, optimize=bool(rng.integers(2)) and q < 96, **rs)
         pdata = buf.getvalue()
     except OSError:                          # Pillow's encoder buffer (noise at high quality)
         pdata = None
     if pdata is not None:
-        case("jpeg_decode_libjpeg", np.array_equal(ctx.jpeg_decode(pdata), orc.jpeg_decode(pdata)), desc + f" q={q} sub={sub}")
+        case("jpeg_decode_libjpeg", np.array_equal(ctx.jpeg_decode(pdata), orc.jpeg_decode(pdata)), desc + f" q={q} sub={sub} {rs}")
         scan = pdata.index(b"\xff\xda") + (14 if sub != 3 else 10)
         if len(pdata) - 2 > scan:
             bad = bytearray(pdata)
