@@ -51,7 +51,7 @@ constexpr int DEC_SEGW = 256 * (DEC_WPT + 1) + 4;    // a workgroup's words in L
 struct DecArgs {
     const uint32_t *ecs;                             // the scan without stuffing, bytes as in the file, zero-padded
     const DecTables *tab;                            // write pass: fast[] = length << 8 | symbol
-    const DecTables *tab_sync;                       // sync passes: fast[] = bits the symbol takes (code + value) | steps in the block << 8
+    const DecSyncTables *tab_sync;                   // sync passes: what one symbol -- or two -- does to the state
     unsigned long long *s_in, *s_out;                // per lane: the state it starts in / ends in
     uint32_t *cnt;                                   // per lane: blocks finished inside its span
     uint32_t *flag;                                  // <true>: set by a workgroup that decoded again
@@ -93,7 +93,10 @@ __device__ __constant__ uint8_t c_unzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
 struct DecShared {
     uint32_t seg[DEC_SEGW];
     unsigned long long out[256];
-    DecTables tab;
+    union {
+        DecTables tab;                               // write pass
+        DecSyncTables stab;                          // sync passes
+    };
     uint8_t unzig[64];
 };
 
@@ -145,33 +148,53 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
         const unsigned long long pair = (static_cast<unsigned long long>(hi) << 32) | lo;
         const uint32_t c16 = static_cast<uint32_t>((pair << off) >> 48);
         const int t = static_cast<int>(((z == 0 ? a.dcpack : a.acpack) >> (4 * slot)) & 15u);
-        const uint32_t e = sh.tab.fast[t][c16 >> (16 - DEC_FAST_BITS)];
-        if (!WRITE && e) {
-            // the sync passes' table holds what the symbol does to the state, ready made: bits consumed (code + value)
-            // and steps inside the block (1 for a DC, r + 1 for a coefficient or sixteen zeros, 64 for the end of block)
-            if (RST && rel + (e & 0xffu) > bnext) {                // padding before a boundary
-                rel = bnext;
+        uint32_t e;
+        if constexpr (!WRITE) {
+            // the sync passes' tables hold what a symbol does to the state, ready made -- and, for the AC tables, what the
+            // next one does as well when its code lies inside the same 11 bits (about every second look-up on a photograph)
+            const uint32_t px = c16 >> (16 - DEC_FAST_BITS);
+            uint32_t adv, step;
+            if (t < 2) {
+                e = sh.stab.dc[t][px];
+                adv = e & 0xffu; step = e >> 8;
+            } else {
+                e = sh.stab.ac[t - 2][px];
+                const uint32_t a1 = e & 0xffu, s1 = (e >> 8) & 0xffu, a2 = (e >> 16) & 0xffu, s2 = e >> 24;
+                // both symbols only if the second one belongs to this span and to this block (and, with restart intervals,
+                // never: the boundary tests are per symbol)
+                const bool two = !RST && a2 != 0 && rel + a1 < end && z + static_cast<int>(s1) < 64;
+                adv = two ? a2 : a1; step = two ? s2 : s1;
+            }
+            if (e) {
+                if (RST && rel + adv > bnext) {                    // padding before a boundary
+                    rel = bnext;
+                    continue;
+                }
+                rel += adv;
+                z += static_cast<int>(step);
+                const bool fin = z >= 64;
+                z = fin ? 0 : z;
+                cnt += fin ? 1u : 0u;
+                const int s1n = slot + 1 == a.nslots ? 0 : slot + 1;
+                slot = fin ? s1n : slot;
                 continue;
             }
-            rel += e & 0xffu;
-            z += static_cast<int>(e >> 8);
-            const bool fin = z >= 64;
-            z = fin ? 0 : z;
-            cnt += fin ? 1u : 0u;
-            const int s1 = slot + 1 == a.nslots ? 0 : slot + 1;
-            slot = fin ? s1 : slot;
-            continue;
+        } else {
+            e = sh.tab.fast[t][c16 >> (16 - DEC_FAST_BITS)];
         }
         int len = static_cast<int>(e >> 8), sym = static_cast<int>(e & 0xffu);
         bool nocode = false;
         if (e == 0) {
             // limit[] rises with the length: the code's length is the first L with c16 < limit[L]
             int L = DEC_FAST_BITS + 1;
+            const uint32_t (*limit)[18] = WRITE ? sh.tab.limit : sh.stab.limit;
+            const int32_t (*delta)[18] = WRITE ? sh.tab.delta : sh.stab.delta;
+            const uint8_t (*value)[256] = WRITE ? sh.tab.value : sh.stab.value;
 #pragma unroll
-            for (int k = DEC_FAST_BITS + 1; k < 16; k++) L += c16 >= sh.tab.limit[t][k] ? 1 : 0;
-            const bool hit = c16 < sh.tab.limit[t][16];
+            for (int k = DEC_FAST_BITS + 1; k < 16; k++) L += c16 >= limit[t][k] ? 1 : 0;
+            const bool hit = c16 < limit[t][16];
             len = L;
-            sym = hit ? sh.tab.value[t][(static_cast<int>(c16 >> (16 - L)) + sh.tab.delta[t][L]) & 255] : 0;
+            sym = hit ? value[t][(static_cast<int>(c16 >> (16 - L)) + delta[t][L]) & 255] : 0;
             nocode = !hit;
         }
         const int s = sym & 15, r = sym >> 4;
@@ -210,7 +233,7 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
 }
 
 // the 256 spans from span0 on (+ 3 words of look-ahead) into LDS; spans before the string's start or past its end read as zeros
-__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long long span0, const DecTables *tab)
+__device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long long span0, const void *tab, int tab_bytes)
 {
     const long long base = span0 * DEC_WPT;
     for (int i = threadIdx.x; i < DEC_WG_WORDS + 3; i += 256) {
@@ -219,7 +242,7 @@ __device__ __forceinline__ void dec_stage(DecShared &sh, const DecArgs &a, long 
     }
     const uint32_t *tw = reinterpret_cast<const uint32_t *>(tab);
     uint32_t *sw = reinterpret_cast<uint32_t *>(&sh.tab);
-    for (int i = threadIdx.x; i < static_cast<int>(sizeof(DecTables) / 4); i += 256) sw[i] = tw[i];
+    for (int i = threadIdx.x; i < tab_bytes / 4; i += 256) sw[i] = tw[i];
     if (threadIdx.x < 64) sh.unzig[threadIdx.x] = c_unzig[threadIdx.x];
 }
 
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
         need = t == 0;
         if (t == 0) my_in = prev;
     }
-    dec_stage(sh, a, span0, a.tab_sync);
+    dec_stage(sh, a, span0, a.tab_sync, static_cast<int>(sizeof(DecSyncTables)));
     sh.out[t] = my_out;
     __syncthreads();
     const uint32_t end = static_cast<uint32_t>(t + 1) * DEC_SPAN;
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
 {
     __shared__ DecShared sh;
     const int g = blockIdx.x, t = threadIdx.x, gt = g * 256 + t;
-    dec_stage(sh, a, static_cast<long long>(g) * 256, a.tab);
+    dec_stage(sh, a, static_cast<long long>(g) * 256, a.tab, static_cast<int>(sizeof(DecTables)));
     __syncthreads();
     if (gt >= a.nlanes) return;
     const unsigned long long st = a.s_in[gt];
@@ -414,12 +437,12 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     const size_t cap = (n - f->scan + 64 + 63) & ~size_t(63);           // >= the scan + 4 words of zeros
     const long long nmcu0 = static_cast<long long>(f->mx) * f->my;
     const size_t rst_max = f->ri > 0 ? static_cast<size_t>((nmcu0 + f->ri - 1) / f->ri) : 0;
-    FNX_TRY(pinned_alloc(ctx, cap + 2 * sizeof(DecTables) + 4 * rst_max + 64, &pin));   // one slice: a second request could wrap the ring onto it
+    FNX_TRY(pinned_alloc(ctx, cap + sizeof(DecTables) + sizeof(DecSyncTables) + 4 * rst_max + 64, &pin));   // one slice: a second request could wrap the ring onto it
     tpin = static_cast<uint8_t *>(pin) + cap;
     size_t nb = 0;
     std::vector<uint32_t> rst;
     FNX_TRY(jpeg_unstuff(data, n, *f, static_cast<uint8_t *>(pin), &nb, &rst));
-    uint32_t *rpin = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(tpin) + 2 * sizeof(DecTables));
+    uint32_t *rpin = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(tpin) + sizeof(DecTables) + sizeof(DecSyncTables));
     if (!rst.empty()) std::memcpy(rpin, rst.data(), 4 * rst.size());
     const size_t nwords = (nb + 3) / 4 + 4;
     std::memset(static_cast<uint8_t *>(pin) + nb, 0, nwords * 4 - nb);
@@ -435,7 +458,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
 
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t lanes_pad = static_cast<size_t>(nwg) * 256;
-    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(2 * sizeof(DecTables) + 4 * rst_max + 16), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
+    const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(sizeof(DecTables) + sizeof(DecSyncTables) + 4 * rst_max + 16), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
                  b_first = al(8 * lanes_pad), b_tot = al(8 * (lanes_pad / SCAN_PER_WG_D + 2)), b_flag = al(4 * 64 + 16),
                  b_coef = al(sizeof(int16_t) * 64 * static_cast<size_t>(nblk)), b_dcb = al(4 * static_cast<size_t>(nblk)),
                  b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2));
@@ -463,32 +486,59 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     *ystride = ys; *cstride = cs;
 
     std::memcpy(tpin, &f->tab, sizeof(DecTables));
-    {   // the sync passes' copy: the same tables with fast[] rewritten (slow-path arrays as they are)
-        DecTables *ts = reinterpret_cast<DecTables *>(static_cast<uint8_t *>(tpin) + sizeof(DecTables));
-        std::memcpy(ts, &f->tab, sizeof(DecTables));
-        for (int t = 0; t < 4; t++)
+    {   // the sync passes' form of the tables (common.hpp: DecSyncTables)
+        DecSyncTables *ts = reinterpret_cast<DecSyncTables *>(static_cast<uint8_t *>(tpin) + sizeof(DecTables));
+        std::memcpy(ts->limit, f->tab.limit, sizeof(ts->limit));
+        std::memcpy(ts->delta, f->tab.delta, sizeof(ts->delta));
+        std::memcpy(ts->value, f->tab.value, sizeof(ts->value));
+        auto effect = [](uint32_t e, bool ac, uint32_t *bits, uint32_t *step) {        // one symbol of the write pass's table
+            const uint32_t len = e >> 8, sym = e & 0xffu, sz = sym & 15u, r = sym >> 4;
+            *bits = len + sz;
+            *step = !ac ? 1u : ((sz == 0 && r != 15) ? 64u : r + 1u);
+        };
+        for (int t = 0; t < 2; t++)
             for (int i = 0; i < (1 << DEC_FAST_BITS); i++) {
                 const uint32_t e = f->tab.fast[t][i];
-                if (!e) continue;
-                const uint32_t len = e >> 8, sym = e & 0xffu, sz = sym & 15u, r = sym >> 4;
-                const uint32_t step = t < 2 ? 1u : ((sz == 0 && r != 15) ? 64u : r + 1u);
-                ts->fast[t][i] = static_cast<uint16_t>((len + sz) | (step << 8));
+                uint32_t b1 = 0, s1 = 0;
+                if (e) effect(e, false, &b1, &s1);
+                ts->dc[t][i] = static_cast<uint16_t>(e ? (b1 | (s1 << 8)) : 0u);
+            }
+        for (int t = 0; t < 2; t++)
+            for (int i = 0; i < (1 << DEC_FAST_BITS); i++) {
+                const uint32_t e = f->tab.fast[2 + t][i];
+                uint32_t v = 0;
+                if (e) {
+                    uint32_t b1, s1;
+                    effect(e, true, &b1, &s1);
+                    v = b1 | (s1 << 8);
+                    // a second symbol: the block goes on, and the code after symbol 1's bits lies inside the prefix
+                    if (s1 < 64 && b1 < static_cast<uint32_t>(DEC_FAST_BITS)) {
+                        const uint32_t rest = (static_cast<uint32_t>(i) << b1) & ((1u << DEC_FAST_BITS) - 1u);   // what is known of the bits behind it
+                        const uint32_t e2 = f->tab.fast[2 + t][rest];
+                        if (e2 && (e2 >> 8) <= static_cast<uint32_t>(DEC_FAST_BITS) - b1) {      // every prefix with these known bits holds this code
+                            uint32_t b2, s2;
+                            effect(e2, true, &b2, &s2);
+                            v |= ((b1 + b2) << 16) | ((s1 + s2) << 24);
+                        }
+                    }
+                }
+                ts->ac[t][i] = v;
             }
     }
     FNX_HIP(hipMemcpyAsync(d_ecs, pin, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
-    FNX_HIP(hipMemcpyAsync(d_tab, tpin, 2 * sizeof(DecTables) + 4 * rst.size(), hipMemcpyHostToDevice, ctx->stream));
+    FNX_HIP(hipMemcpyAsync(d_tab, tpin, sizeof(DecTables) + sizeof(DecSyncTables) + 4 * rst.size(), hipMemcpyHostToDevice, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_flag, 0, b_flag, ctx->stream));
     FNX_HIP(hipMemsetAsync(d_coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk), ctx->stream));
 
     DecArgs a{};
-    a.ecs = d_ecs; a.tab = d_tab; a.tab_sync = d_tab + 1; a.s_in = d_in; a.s_out = d_out; a.cnt = d_cnt; a.flag = d_flag;
+    a.ecs = d_ecs; a.tab = d_tab; a.tab_sync = reinterpret_cast<const DecSyncTables *>(d_tab + 1); a.s_in = d_in; a.s_out = d_out; a.cnt = d_cnt; a.flag = d_flag;
     a.first_blk = d_first; a.coef = d_coef; a.err = d_flag + 64;
     const char *trc = std::getenv("FNX_JPEG_TRACE");
     const bool trace = trc && trc[0] == '1';
     a.dbg = trace ? d_flag + 72 : nullptr;
     a.nwords = static_cast<long long>(nwords); a.nbits = nbits; a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
     a.dcpack = f->dcpack; a.acpack = f->acpack;
-    a.rst = reinterpret_cast<const uint32_t *>(d_tab + 2); a.nrst = static_cast<int>(rst.size());
+    a.rst = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_tab) + sizeof(DecTables) + sizeof(DecSyncTables)); a.nrst = static_cast<int>(rst.size());
     const bool has_rst = !rst.empty();
     FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
     if (has_rst) hipLaunchKernelGGL((jpeg_dsync_kernel<false, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
