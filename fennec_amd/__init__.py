@@ -74,6 +74,11 @@ FNX_ERR_INVALID = -1
 FNX_ERR_UNSUPPORTED = -5
 
 
+class FileOptions(C.Structure):
+    """fennec_FileOptions (include/fennec_hip.h): the Options fields CompressFile's JPEG path reads."""
+    _fields_ = [("orient", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32), ("auto_format", C.c_int32), ("target_ssim", C.c_double)]
+
+
 class FennecError(RuntimeError):
     pass
 
@@ -160,6 +165,11 @@ def load_library() -> C.CDLL:
                                                   C.c_void_p, C.c_void_p])
         _sig(L, "fennec_CompressBatchJPEG", i, [i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), d, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i), C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_CompressFileJPEG", i, [ctx, _u8p, C.c_size_t, C.POINTER(FileOptions), _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
+                                                _f64p, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fennec_CompressBatchJPEGOpts", i, [i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(FileOptions),
+                                                     C.POINTER(C.POINTER(FileOptions)), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                     C.POINTER(NativeBatchResult), C.POINTER(i), C.POINTER(i), C.c_void_p, C.c_void_p])
         _sig(L, "fennec_pool_release", None, [])
         _sig(L, "fennec_SummarizeResults", d, [i, C.POINTER(NativeBatchResult), _i64p])
         _sig(L, "fnx_jpeg_size_search", i, [ctx, i] + img + [i, i, C.c_longlong, i, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
@@ -616,6 +626,28 @@ class Context:
                 break
             cap = n.value
         self._chk(rc, "fnx_jpeg_recompress")
+
+    def compress_file_jpeg(self, data: bytes, target_ssim: float, orient: int = 1, max_w: int = 0, max_h: int = 0, auto_format: bool = False):
+        """CompressFile for a JPEG source in standard mode, every pixel stage on the device (fennec_CompressFileJPEG): decode,
+        ApplyOrientation(orient), smartResize(max_w, max_h), analyzeFormat (auto_format), compressJPEGOptimal ->
+        (bytes, quality, ssim, steps, original (w, h), final (w, h)); bytes is None when analyzeFormat chose PNG."""
+        src = np.frombuffer(data, dtype=np.uint8)
+        o = FileOptions(int(orient), int(max_w), int(max_h), 1 if auto_format else 0, float(target_ssim))
+        cap = max(4096, len(data) + 4096)
+        n, q, st, v = C.c_size_t(0), C.c_int(), C.c_int(), C.c_double()
+        dims = (C.c_int * 4)()
+        for _ in range(2):
+            buf = np.empty(cap, dtype=np.uint8)
+            rc = self._lib.fennec_CompressFileJPEG(self._h, src.ctypes.data_as(_u8p), len(data), C.byref(o), buf.ctypes.data_as(_u8p), cap,
+                                                   C.byref(n), C.byref(q), C.byref(v), C.byref(st), dims)
+            if rc == FNX_OK:
+                return buf[:n.value].tobytes(), q.value, v.value, st.value, (dims[0], dims[1]), (dims[2], dims[3])
+            if rc == FNX_NOOP:
+                return None, 0, 1.0, 0, (dims[0], dims[1]), (dims[2], dims[3])
+            if n.value <= cap:
+                break
+            cap = n.value
+        self._chk(rc, "fennec_CompressFileJPEG")
 
     def jpeg_quality_search(self, img, target_ssim: float, window=None):
         """compressJPEGOptimal's binary search with every candidate round-tripped and scored on the device

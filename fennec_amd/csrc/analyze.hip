@@ -440,4 +440,25 @@ int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t
     return FNX_OK;
 }
 
+// analyzeFormat's samples (convert.go:105-146): the pixels whose row-major index is a multiple of `step`, in order
+__global__ __launch_bounds__(256) void sample_pixels_kernel(const uint8_t *src, int sstride, int w, long long total, long long step,
+                                                            uint32_t *out, int nsamples)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nsamples) return;
+    const long long idx = static_cast<long long>(k) * step;
+    if (idx >= total) return;
+    const int y = static_cast<int>(idx / w), x = static_cast<int>(idx - static_cast<long long>(y) * w);
+    out[k] = *reinterpret_cast<const uint32_t *>(src + static_cast<size_t>(y) * sstride + 4 * static_cast<size_t>(x));
+}
+
+int launch_sample_pixels(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, long long step, uint32_t *d_out, int nsamples)
+{
+    if (nsamples <= 0) return FNX_OK;
+    hipLaunchKernelGGL(sample_pixels_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, src, sstride, w,
+                       static_cast<long long>(w) * h, step, d_out, nsamples);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
 }  // namespace fnx

@@ -67,6 +67,7 @@ enum Slot {
     SLOT_JPEG2,
     SLOT_JPEG3,
     SLOT_JPEG_ENC, SLOT_JPEG_ENC2, SLOT_JPEG_LUT, SLOT_JPEG_ECS,   // jpeg.hip's entropy coder
+    SLOT_FILE0, SLOT_FILE1, SLOT_FILE_SAMPLES,                     // host_api.cpp: fennec_CompressFileJPEG's images between its stages
     SLOT_JPEG_DEC, SLOT_JPEG_DEC_PLANES, SLOT_JPEG_DEC_IMG,        // jpeg_dec.hip: the decoder's work arrays, its planes, toNRGBARef's image
     SLOT_DONE,       // workgroup counters of the kernels that finish their own reduction (ssim.hip), zero between launches
     SLOT_COUNT
@@ -279,6 +280,8 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
                    bool aligned16_ok, fnx_analysis *d_res);
 // flat Pix scan: *d_flags bit 0 = some alpha != 255, bit 1 = some pixel with r != g or g != b
 int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags);
+// analyzeFormat's samples: pixels at row-major indices 0, step, 2 step, ... (nsamples of them) as packed NRGBA words
+int launch_sample_pixels(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, long long step, uint32_t *d_out, int nsamples);
 // applyPalette (+ palettedToNRGBA): palette = n x 4 host bytes (opaque); idx and/or quant may be null
 int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, const uint8_t *palette, int n,
                          uint8_t *idx, int istride, uint8_t *quant, int qstride);

@@ -391,6 +391,69 @@ void fennec_pool_release(void)
     for (auto &e : all) fnx_ctx_destroy(e.second);
 }
 
+// CompressFile for a JPEG source in standard mode (fennec.go:30-76 -> compressImageInternal :107-141 -> handleStandardMode
+// :162-205) from the file's bytes, every pixel stage on the device: image.Decode + toNRGBA, ApplyOrientation (AutoOrient;
+// the caller read the tag, exif.go), smartResize (MaxWidth / MaxHeight), analyzeFormat (Format: Auto), compressJPEGOptimal.
+int fennec_CompressFileJPEG(fnx_ctx *ctx, const uint8_t *data, size_t n, const fennec_FileOptions *o, uint8_t *out, size_t cap,
+                            size_t *nbytes, int *quality, double *ssim, int *steps, int dims[4])
+{
+    if (!ctx || !data || !o || !nbytes || !quality || !ssim || !dims) {
+        set_error("invalid argument: CompressFileJPEG");
+        return FNX_ERR_INVALID;
+    }
+    *nbytes = 0;
+    int w = 0, h = 0;
+    FNX_TRY(fnx_jpeg_decode(ctx, data, n, FNX_HOST, nullptr, 0, &w, &h));          // dimensions; refuses what the device decoder does not take
+    void *b0 = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_FILE0, static_cast<size_t>(w) * h * 4 + 16, &b0));
+    FNX_TRY(fnx_jpeg_decode(ctx, data, n, FNX_DEVICE, static_cast<uint8_t *>(b0), w * 4, &w, &h));
+    const uint8_t *img = static_cast<const uint8_t *>(b0);
+    bool in0 = true;
+    if (o->orient > 1 && o->orient <= 8) {                                         // fennec.go:119-122 (OrientNormal == 1)
+        const bool swap = o->orient >= 5;
+        const int ow = swap ? h : w, oh = swap ? w : h;
+        void *b1 = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_FILE1, static_cast<size_t>(ow) * oh * 4 + 16, &b1));
+        FNX_TRY(fnx_orient(ctx, FNX_DEVICE, img, w * 4, w, h, o->orient, static_cast<uint8_t *>(b1), ow * 4));
+        img = static_cast<const uint8_t *>(b1); w = ow; h = oh; in0 = false;
+    }
+    dims[0] = w; dims[1] = h;                                                      // OriginalDimensions
+    if (o->max_w > 0 || o->max_h > 0) {                                            // fennec.go:127-129
+        int nw = w, nh = h;
+        if (fennec_smartResizeDims(w, h, o->max_w, o->max_h, &nw, &nh)) {
+            void *b = nullptr;
+            FNX_TRY(scratch(ctx, in0 ? SLOT_FILE1 : SLOT_FILE0, static_cast<size_t>(nw) * nh * 4 + 16, &b));
+            FNX_TRY(fennec_lanczosResize(ctx, FNX_DEVICE, img, w * 4, w, h, static_cast<uint8_t *>(b), nw * 4, nw, nh));
+            img = static_cast<const uint8_t *>(b); w = nw; h = nh; in0 = !in0;
+        }
+    }
+    dims[2] = w; dims[3] = h;                                                      // FinalDimensions
+    if (o->auto_format) {
+        // analyzeFormat (convert.go:105-146) on what a JPEG decodes to (opaque): PNG when fewer than 256 distinct colours
+        // among the sampled pixels.  The samples come to the host (<= 80 KB); the set is the reference's, early stop included.
+        const long long total = static_cast<long long>(w) * h;
+        const long long step = total > 10000 ? total / 10000 : 1;
+        const int ns = static_cast<int>((total + step - 1) / step);
+        void *ds = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_FILE_SAMPLES, sizeof(uint32_t) * static_cast<size_t>(ns) + 16, &ds));
+        FNX_TRY(launch_sample_pixels(ctx, img, w * 4, w, h, step, static_cast<uint32_t *>(ds), ns));
+        std::vector<uint32_t> smp(static_cast<size_t>(ns));
+        FNX_TRY(fetch_bytes(ctx, ds, smp.data(), sizeof(uint32_t) * smp.size()));
+        std::vector<uint32_t> seen;
+        seen.reserve(512);
+        bool alpha = false;
+        for (int k = 0; k < ns && seen.size() < 512; k++) {
+            if ((smp[static_cast<size_t>(k)] >> 24) < 255u) alpha = true;
+            bool dup = false;
+            for (uint32_t v : seen)
+                if (v == smp[static_cast<size_t>(k)]) { dup = true; break; }
+            if (!dup) seen.push_back(smp[static_cast<size_t>(k)]);
+        }
+        if (alpha || seen.size() < 256) return FNX_NOOP;                          // Format PNG: the caller's compressPNG
+    }
+    return fnx_jpeg_compress(ctx, FNX_DEVICE, img, w * 4, w, h, o->target_ssim, ssim_window(), out, cap, nbytes, quality, ssim, steps);
+}
+
 }  // extern "C"
 
 // The pool of batch.go:58-128: `workers` threads over ONE closed queue of indices; item(ctx, idx, &result) does the work.
@@ -495,6 +558,32 @@ int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *cons
         r.has_result = rc == FNX_OK ? 1 : 0;
         r.quality = q; r.steps = steps; r.ssim = s;
         r.original_size = static_cast<int64_t>(sizes[idx]);      // batch.go:103: the source FILE's size
+        r.compressed_size = static_cast<int64_t>(nbytes);
+    });
+}
+
+int fennec_CompressBatchJPEGOpts(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes,
+                                 const fennec_FileOptions *default_opts, const fennec_FileOptions *const *item_opts, uint8_t *const *outs,
+                                 const size_t *caps, fennec_BatchResult *results, int *dims, const volatile int *cancel, fennec_on_item on_item,
+                                 void *user)
+{
+    if (n <= 0) return FNX_OK;                                   // batch.go:59-61
+    if (!files || !sizes || !default_opts || !outs || !caps || !results) {
+        set_error("invalid argument: CompressBatch arrays");
+        return FNX_ERR_INVALID;
+    }
+    return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        const fennec_FileOptions &o = item_opts && item_opts[idx] ? *item_opts[idx] : *default_opts;      // batch.go:101-105
+        size_t nbytes = 0;
+        int q = 0, steps = 0, d4[4] = {0, 0, 0, 0};
+        double s = 0;
+        const int rc = fennec_CompressFileJPEG(ctx, files[idx], sizes[idx], &o, outs[idx], caps[idx], &nbytes, &q, &s, &steps, d4);
+        if (dims) std::memcpy(dims + 4 * idx, d4, sizeof(d4));
+        r.status = rc;                                           // FNX_NOOP: analyzeFormat chose PNG; FNX_ERR_UNSUPPORTED: host decode
+        r.failed = rc == FNX_OK ? 0 : 1;
+        r.has_result = rc == FNX_OK ? 1 : 0;
+        r.quality = q; r.steps = steps; r.ssim = s;
+        r.original_size = static_cast<int64_t>(sizes[idx]);
         r.compressed_size = static_cast<int64_t>(nbytes);
     });
 }

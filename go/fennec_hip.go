@@ -735,6 +735,53 @@ func jpegRecompressHIP(data []byte, targetSSIM float64) (out []byte, quality int
 	return nil, 0, 0, 0, 0, false
 }
 
+// compressFileJPEGHIP is CompressFile's standard-mode JPEG path for a .jpg source (fennec.go:30-76, :107-141, :162-205) in
+// one call: decode, ApplyOrientation (opts.AutoOrient, orient as openWithOrientation read it), smartResize (MaxWidth /
+// MaxHeight), analyzeFormat (Format == Auto), compressJPEGOptimal -- every pixel stage on the device.
+//   ok == false            the device was not used or refuses the file: the reference's own path
+//   ok && data == nil      analyzeFormat chose PNG: the caller's compressPNG (orig / final dims are set)
+func compressFileJPEGHIP(file []byte, orient Orientation, opts Options, targetSSIM float64) (data []byte, quality int, ssim float64,
+	orig, final image.Point, ok bool) {
+	c := poolGetIf(useDeviceSearch && len(file) > 4 && opts.TargetSize == 0 && (opts.Format == JPEG || opts.Format == Auto))
+	if c == nil {
+		return nil, 0, 0, image.Point{}, image.Point{}, false
+	}
+	defer pool.put(c)
+	var fo C.fennec_FileOptions
+	if opts.AutoOrient {
+		fo.orient = C.int32_t(orient)
+	} else {
+		fo.orient = 1
+	}
+	fo.max_w, fo.max_h = C.int32_t(opts.MaxWidth), C.int32_t(opts.MaxHeight)
+	if opts.Format == Auto {
+		fo.auto_format = 1
+	}
+	fo.target_ssim = C.double(targetSSIM)
+	buf := make([]byte, len(file)+4096)
+	for try := 0; try < 2; try++ {
+		var n C.size_t
+		var q, steps C.int
+		var s C.double
+		var dims [4]C.int
+		st := C.fennec_CompressFileJPEG(c, (*C.uint8_t)(unsafe.Pointer(&file[0])), C.size_t(len(file)), &fo,
+			(*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &n, &q, &s, &steps, &dims[0])
+		runtime.KeepAlive(file)
+		orig, final = image.Pt(int(dims[0]), int(dims[1])), image.Pt(int(dims[2]), int(dims[3]))
+		switch {
+		case st == C.FNX_OK:
+			return buf[:int(n)], int(q), float64(s), orig, final, true
+		case st == C.FNX_NOOP:
+			return nil, 0, 1.0, orig, final, true
+		case st == C.FNX_ERR_INVALID && int(n) > len(buf):
+			buf = make([]byte, int(n))
+		default:
+			return nil, 0, 0, image.Point{}, image.Point{}, false
+		}
+	}
+	return nil, 0, 0, image.Point{}, image.Point{}, false
+}
+
 // jpegQualitySearchOptHIP is jpegQualitySearchOpt (targetsize.go:125-176) on the device: every candidate's size from the
 // device's entropy coder, the winner's file and (unless skipSSIM) its SSIMFast.  ok == false: the device was not used;
 // data == nil with ok: no quality fits (the reference returns nil, nil).

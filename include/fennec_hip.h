@@ -433,6 +433,21 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                               const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                               const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* CompressFile for a JPEG source in standard mode (fennec.go:30-76 -> compressImageInternal :107-141 -> handleStandardMode
+ * :162-205) from the file's bytes with every pixel stage on the device: image.Decode + toNRGBA (fnx_jpeg_decode),
+ * ApplyOrientation when opts->orient is 2..8 (Options.AutoOrient; the caller reads the tag as exif.go does),
+ * smartResize when max_w or max_h > 0 (Options.MaxWidth / MaxHeight), analyzeFormat when auto_format (Format: Auto),
+ * compressJPEGOptimal at target_ssim.  dims = {OriginalDimensions (after orientation), FinalDimensions}.
+ * FNX_NOOP: analyzeFormat chose PNG (fewer than 256 sampled colours) -- the caller's compressPNG takes the item, dims are
+ * set.  FNX_ERR_UNSUPPORTED as fnx_jpeg_decode.  Target-size mode stays the caller's (fnx_jpeg_size_search is its JPEG leg). */
+typedef struct fennec_FileOptions {
+    int32_t orient;      /* EXIF orientation 1..8; <= 1: none */
+    int32_t max_w, max_h;
+    int32_t auto_format; /* != 0: Format Auto */
+    double target_ssim;  /* Options.Quality.targetSSIM() or Options.TargetSSIM */
+} fennec_FileOptions;
+int fennec_CompressFileJPEG(fnx_ctx *ctx, const uint8_t *data, size_t n, const fennec_FileOptions *opts, uint8_t *out, size_t cap,
+                            size_t *nbytes, int *quality, double *ssim, int *steps /* may be NULL */, int dims[4]);
 /* The same pool over JPEG FILES in host memory (what CompressBatch reads for a .jpg item, batch.go:88-101): per item
  * fnx_jpeg_recompress -- decoder, search and encoder on the device, no host codec.  A file the device decoder does not
  * take comes back with failed != 0 and status == FNX_ERR_UNSUPPORTED: the caller decodes it on the host and sends it
@@ -440,6 +455,13 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
 int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes, double target_ssim,
                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                              const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* ... with CompressFile's options: per item fennec_CompressFileJPEG under item_opts[i] when that is not NULL, else under
+ * *default_opts (batch.go:101-105: item.Opts over BatchOptions.DefaultOpts).  dims (may be NULL): 4 ints per item, as
+ * fennec_CompressFileJPEG's.  An item analyzeFormat sends to PNG comes back failed with status FNX_NOOP. */
+int fennec_CompressBatchJPEGOpts(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes,
+                                 const fennec_FileOptions *default_opts, const fennec_FileOptions *const *item_opts /* may be NULL */,
+                                 uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, int *dims /* may be NULL */,
+                                 const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
 /* The pool's idle worker contexts (kept between batches, per device) are destroyed. */
 void fennec_pool_release(void);
 /* Summarize (batch.go:140-158) of such results: out4 = {Total, Succeeded, Failed, TotalSaved}; returns AvgSSIM. */

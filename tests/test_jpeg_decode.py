@@ -359,3 +359,75 @@ def test_gpu_decode_of_damaged_scans_terminates_and_agrees_with_the_checker(ctx)
         assert np.array_equal(ctx.jpeg_decode(g), orc.jpeg_decode(g))
     print(f"damaged scans: both decode {both}, device only {dev_only}, checker only {chk_only}, neither {neither}")
     assert both > 50
+
+
+def _analyze_format_is_png(img):
+    """analyzeFormat (convert.go:105-146): True when it answers PNG"""
+    h, w = img.shape[:2]
+    total = w * h
+    step = total // 10000 if total > 10000 else 1
+    flat = img.reshape(-1, 4)[::step]
+    seen, alpha = set(), False
+    for px in flat:
+        if len(seen) >= 512:
+            break
+        alpha = alpha or px[3] < 255
+        seen.add(px.tobytes())
+    return alpha or len(seen) < 256
+
+
+@pytest.mark.gpu
+def test_gpu_compress_file_jpeg_is_the_reference_pipeline(ctx):
+    """fennec_CompressFileJPEG = CompressFile's JPEG path (fennec.go:30-205): decode, ApplyOrientation, smartResize,
+    analyzeFormat, compressJPEGOptimal -- against the same stages composed from the oracle."""
+    src = _photo(640, 400, 5)
+    data = _pil(src, quality=93, subsampling=2)
+    dec = orc.jpeg_decode(data)
+    for orient, mw, mh in [(1, 0, 0), (6, 0, 0), (3, 320, 0), (8, 0, 150), (5, 200, 200), (1, 4000, 4000), (2, 0, 0)]:
+        want = orc.apply_orientation(dec, orient) if orient > 1 else dec
+        odims = (want.shape[1], want.shape[0])
+        if mw > 0 or mh > 0:
+            want = orc.smart_resize(want, mw, mh)
+        assert not _analyze_format_is_png(want)
+        out, q, s, steps, od, fd = ctx.compress_file_jpeg(data, 0.94, orient=orient, max_w=mw, max_h=mh, auto_format=True)
+        assert od == odims and fd == (want.shape[1], want.shape[0]), (orient, mw, mh)
+        assert (out, q, s, steps) == ctx.jpeg_compress(want, 0.94), (orient, mw, mh)
+    # Format Auto on a source of few colours: PNG is the reference's answer, the call says so and leaves the item to the caller
+    flat = np.zeros((240, 320, 4), dtype=np.uint8)
+    flat[..., 3] = 255
+    flat[:, 160:, 0] = 200
+    fdata = _pil(flat, quality=90, subsampling=0)
+    assert _analyze_format_is_png(orc.jpeg_decode(fdata))
+    out, q, s, steps, od, fd = ctx.compress_file_jpeg(fdata, 0.94, auto_format=True)
+    assert out is None and od == fd == (320, 240)
+    out, q, s, steps, od, fd = ctx.compress_file_jpeg(fdata, 0.94, auto_format=False)          # Format: JPEG
+    assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(fdata), 0.94)
+
+
+@pytest.mark.gpu
+def test_gpu_native_pool_with_file_options(ctx):
+    """fennec_CompressBatchJPEGOpts: BatchOptions.DefaultOpts with per-item overrides (batch.go:101-105), against the single call."""
+    import ctypes as C
+    import fennec_amd as fa
+    L = fa.load_library()
+    files = [_pil(_photo(400 + 16 * k, 300, k), quality=92, subsampling=2) for k in range(6)]
+    n = len(files)
+    default = fa.FileOptions(1, 256, 0, 1, 0.94)
+    special = fa.FileOptions(6, 0, 0, 0, 0.97)
+    per = (C.POINTER(fa.FileOptions) * n)()
+    per[2] = C.pointer(special)
+    arrs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+    srcs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs]); sizes = (C.c_size_t * n)(*[len(f) for f in files])
+    bufs = [np.empty(3 * len(f) + 65536, dtype=np.uint8) for f in files]     # (a higher target can pick a higher quality than the source's)
+    outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); caps = (C.c_size_t * n)(*[b.size for b in bufs])
+    res = (fa.NativeBatchResult * n)()
+    dims = (C.c_int * (4 * n))()
+    assert L.fennec_CompressBatchJPEGOpts(0, 3, n, srcs, sizes, C.byref(default), per, outs, caps, res, dims, None, None, None) == fa.FNX_OK
+    for i in range(n):
+        o = special if i == 2 else default
+        out, q, s, steps, od, fd = ctx.compress_file_jpeg(files[i], o.target_ssim, orient=o.orient, max_w=o.max_w, max_h=o.max_h,
+                                                          auto_format=bool(o.auto_format))
+        r = res[i]
+        assert not r.failed and (r.quality, r.ssim, r.steps, r.compressed_size, r.original_size) == (q, s, steps, len(out), len(files[i])), i
+        assert bufs[i][:r.compressed_size].tobytes() == out and tuple(dims[4 * i:4 * i + 4]) == od + fd
+    assert tuple(dims[8:12]) == (300, 432, 300, 432) and tuple(dims[0:4]) == (400, 300, 256, 192)
