@@ -219,11 +219,12 @@ def jpeg_item_work_device_codec(jpegs: Sequence[bytes], target_ssim: float = TAR
 
 def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"],
                               on_gpu_seconds: Optional[Callable[[float], None]] = None,
-                              decode: Callable[[bytes], np.ndarray] = pillow_decode):
+                              decode: Callable[[bytes], np.ndarray] = pillow_decode, file_options: Optional[dict] = None):
     """The per-item body of CompressBatch with NO host codec (fnx_jpeg_recompress: SURVEY 8(f)2, third slice): the file's
     bytes go up, the decoder, the search and the encoder run on the device, the new file's bytes come down.  A file the
     device decoder does not take (progressive, 4:1:1, CMYK: FennecUnsupported) is decoded on the host by
-    THIS function -- the caller's choice, visible in the result's `host_decoded` -- and continues on the device."""
+    THIS function -- the caller's choice, visible in the result's `host_decoded` -- and continues on the device (without
+    file_options' stages: those belong to the device call)."""
     import time
     from . import FennecUnsupported
 
@@ -232,7 +233,14 @@ def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGE
         t0 = time.perf_counter()
         host_decoded = False
         try:
-            out, q, s_, steps, _dims = state.jpeg_recompress(data, target_ssim)
+            if file_options:       # CompressFile's options (orient, max_w, max_h, auto_format): fennec_CompressFileJPEG
+                out, q, s_, steps, _od, _fd = state.compress_file_jpeg(data, target_ssim, **file_options)
+                if out is None:    # analyzeFormat chose PNG: not this harness's path
+                    r = BatchResult(Index=idx, OriginalSize=len(data), Err="analyzeFormat: PNG", has_result=False)
+                    r.host_decoded = False
+                    return r
+            else:
+                out, q, s_, steps, _dims = state.jpeg_recompress(data, target_ssim)
         except FennecUnsupported:
             host_decoded = True
             src = decode(data)
