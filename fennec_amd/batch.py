@@ -226,7 +226,7 @@ def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGE
     THIS function -- the caller's choice, visible in the result's `host_decoded` -- and continues on the device (without
     file_options' stages: those belong to the device call)."""
     import time
-    from . import FennecUnsupported
+    from . import FennecError
 
     def work(idx: int, state) -> BatchResult:
         data = jpegs[idx]
@@ -241,7 +241,7 @@ def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGE
                     return r
             else:
                 out, q, s_, steps, _dims = state.jpeg_recompress(data, target_ssim)
-        except FennecUnsupported:
+        except FennecError:          # refused (FNX_ERR_UNSUPPORTED) or found damaged (FNX_ERR_INVALID): the host codec's call
             host_decoded = True
             src = decode(data)
             t0 = time.perf_counter()
@@ -469,7 +469,7 @@ def compress_batch_jpeg_native(files: Sequence[bytes], target_ssim: float = TARG
         results.append(br)
         out_files.append(bufs[i][:int(r.compressed_size)].tobytes() if not r.failed else b"")
     # the caller's side of FNX_ERR_UNSUPPORTED: host decode, then the NRGBA pool
-    redo = [i for i in range(n) if res[i].failed and res[i].status == fa.FNX_ERR_UNSUPPORTED]
+    redo = [i for i in range(n) if res[i].failed and res[i].status in (fa.FNX_ERR_UNSUPPORTED, fa.FNX_ERR_INVALID)]
     if redo:
         r2, f2, _ = compress_batch_native([decode(files[i]) for i in redo], target_ssim, workers=workers, device=device,
                                           original_sizes=[len(files[i]) for i in redo])

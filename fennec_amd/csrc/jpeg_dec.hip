@@ -66,6 +66,7 @@ struct DecArgs {
     uint32_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
     const uint32_t *rst;                             // byte offsets at which restart intervals 1, 2, ... start (ascending)
     int nrst;
+    int ri_blocks;                                   // blocks per restart interval
 };
 
 // Restart intervals (DRI): interval k starts on a byte boundary, in the state (block start, slot 0), with every DC
@@ -135,6 +136,9 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             break;
         }
         if (RST && rel >= bnext) {                                 // on a boundary: the interval's first block, first slot
+            // (write pass: exactly the intervals before it must be complete -- a damaged interval that yields a block too
+            // many or too few would shift every block behind it)
+            if (WRITE && blk + cnt != static_cast<long long>(rk + 1) * a.ri_blocks) bad |= 16u;
             z = 0; slot = 0;
             bnext = rst_rel(a, ++rk, wg_bit);
         }
@@ -539,6 +543,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     a.nwords = static_cast<long long>(nwords); a.nbits = nbits; a.nlanes = nlanes; a.nblk = nblk; a.nslots = f->nslots;
     a.dcpack = f->dcpack; a.acpack = f->acpack;
     a.rst = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_tab) + sizeof(DecTables) + sizeof(DecSyncTables)); a.nrst = static_cast<int>(rst.size());
+    a.ri_blocks = f->ri * f->nslots;
     const bool has_rst = !rst.empty();
     FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
     if (has_rst) hipLaunchKernelGGL((jpeg_dsync_kernel<false, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
@@ -598,6 +603,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     }
     if (chk.blocks < static_cast<unsigned long long>(nblk)) return jpeg_corrupt("the scan ends before the last block");
     if (chk.err & 8u) return jpeg_corrupt("the scan ends before the last block");
+    if (chk.err & 16u) return jpeg_corrupt("a restart interval does not hold the blocks it should");
     if (chk.err) return jpeg_corrupt("the scan holds a code outside its Huffman table or a run past the end of a block");
     return FNX_OK;
 }

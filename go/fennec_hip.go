@@ -34,7 +34,6 @@ package fennec
 import "C"
 
 import (
-	"errors"
 	"image"
 	"image/color"
 	"math"
@@ -677,34 +676,28 @@ func jpegCompressHIP(src *image.NRGBA, targetSSIM float64) (data []byte, quality
 	return nil, 0, 0, false
 }
 
-func lastError(what string) error {
-	return errors.New(what + ": " + C.GoString(C.fnx_last_error()))
-}
-
 // jpegDecodeHIP is image.Decode + toNRGBARef for a JPEG file (io.go:60-95) on the device.  ok == false: the device was
-// not used or does not take this file (progressive, 4:1:1, CMYK: FNX_ERR_UNSUPPORTED) -- the
-// caller runs image.Decode as before.  err != nil: the file is corrupt (what image.Decode would report).
-func jpegDecodeHIP(data []byte) (img *image.NRGBA, ok bool, err error) {
+// not used, does not take this file (progressive, 4:1:1, CMYK: FNX_ERR_UNSUPPORTED) or finds it damaged
+// (FNX_ERR_INVALID) -- in every such case the caller runs image.Decode as before, and what the reference says about a
+// damaged file (an error, or an image: its decoder forgives some damage the device's strict block accounting does not)
+// stays the reference's own answer.
+func jpegDecodeHIP(data []byte) (img *image.NRGBA, ok bool) {
 	c := poolGetIf(useDeviceSearch && len(data) > 4)
 	if c == nil {
-		return nil, false, nil
+		return nil, false
 	}
 	defer pool.put(c)
 	var w, h C.int
-	st := C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, nil, 0, &w, &h)
-	if st == C.FNX_ERR_UNSUPPORTED {
-		return nil, false, nil
-	}
-	if st != C.FNX_OK {
-		return nil, true, lastError("fnx_jpeg_decode")
+	if C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, nil, 0, &w, &h) != C.FNX_OK {
+		return nil, false
 	}
 	img = image.NewNRGBA(image.Rect(0, 0, int(w), int(h)))
-	st = C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, pix(img), C.int(img.Stride), &w, &h)
+	st := C.fnx_jpeg_decode(c, (*C.uint8_t)(unsafe.Pointer(&data[0])), C.size_t(len(data)), C.FNX_HOST, pix(img), C.int(img.Stride), &w, &h)
 	runtime.KeepAlive(data)
 	if st != C.FNX_OK {
-		return nil, true, lastError("fnx_jpeg_decode")
+		return nil, false
 	}
-	return img, true, nil
+	return img, true
 }
 
 // jpegRecompressHIP is CompressBatch's item body for a JPEG source (batch.go:88-122 -> compress.go:21-87) in one call:

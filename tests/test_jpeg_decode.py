@@ -237,6 +237,19 @@ def test_gpu_decode_with_restart_intervals(ctx):
     data = _pil(_photo(640, 480, 2), quality=93, subsampling=2, restart_marker_rows=1)
     out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
     assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
+    # tests/golden/damaged_restart_interval.jpg (the fuzzer's find, seed 91): the last byte of an interval damaged so that
+    # its tail reads as one block more.  A decoder that counts MCUs (the checker, Go, libjpeg) never looks at those bits;
+    # the device decoder goes by position, so its block accounting per interval must notice -- an error, not an image
+    # with every later block shifted -- and the harness's host codec takes the file
+    import os
+    import fennec_amd
+    from fennec_amd import batch
+    bad = open(os.path.join(os.path.dirname(__file__), "golden", "damaged_restart_interval.jpg"), "rb").read()
+    assert orc.jpeg_decode(bad).shape == (312, 280, 4)
+    with pytest.raises(fennec_amd.FennecError, match="restart interval"):
+        ctx.jpeg_decode(bad)
+    r = batch.jpeg_item_work_device_all([bad], 0.94)(0, ctx)
+    assert r.host_decoded and r.Err is None and r.data[:2] == b"\xff\xd8"
 
 
 @pytest.mark.gpu

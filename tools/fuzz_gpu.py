@@ -136,7 +136,13 @@ while time.time() < t_end:
             # both decode: the same pixels.  One refuses what the other takes: reported, not failed (a damaged scan's last
             # symbol may straddle the end of the string, which the two treat differently) -- counted under its own name
             if got is not None and want is not None:
-                case("jpeg_decode_damaged_both", np.array_equal(got, want), desc + f" q={q} sub={sub}")
+                same = np.array_equal(got, want)
+                if not same:                 # keep the file: the iteration is not reproducible without everything before it
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}_{it}.jpg"), "wb").write(bad)
+                    open(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}_{it}_orig.jpg"), "wb").write(pdata)
+                    np.save(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{seed}_{it}_got.npy"), got)
+                case("jpeg_decode_damaged_both", same, desc + f" q={q} sub={sub} {rs}")
             elif (got is None) != (want is None):
                 runs["jpeg_decode_damaged_one_sided"] = runs.get("jpeg_decode_damaged_one_sided", 0) + 1
             else:
