@@ -456,6 +456,9 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     const long long nblk_ll = nmcu * f->nslots;
     if (nlanes_z == 0) return jpeg_corrupt("an empty scan");
     if (nlanes_z >= (size_t(1) << 30) || nblk_ll >= (1ll << 30)) return jpeg_unsupported("a file this large");
+    // every block costs at least two bits (a DC code and an end of block): a header that promises more blocks than the scan
+    // can hold is refused BEFORE anything is sized by it (65 535 x 65 535 in the frame header of a 1 KB file)
+    if (nbits < 2ull * static_cast<unsigned long long>(nblk_ll)) return jpeg_corrupt("the scan is too short for the image's blocks");
     const int nlanes = static_cast<int>(nlanes_z), nblk = static_cast<int>(nblk_ll);
     const int nwg = (nlanes + DEC_OWN - 1) / DEC_OWN, nwg_write = (nlanes + 255) / 256;
     const int ys = 8 * f->hy * f->mx, yh = 8 * f->vy * f->my, cs = 8 * f->mx, chh = 8 * f->my;

@@ -302,6 +302,12 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
         with pytest.raises(fennec_amd.FennecError) as e:
             ctx.jpeg_decode(bad)
         assert not isinstance(e.value, fennec_amd.FennecUnsupported)
+    # a frame header that claims 65 535 x 65 535 over the same small scan: refused before anything is sized by it
+    i = good.index(b"\xff\xc0")
+    huge = good[:i + 5] + b"\xff\xff\xff\xff" + good[i + 9:]
+    assert ctx.jpeg_decode_config(huge) == (65535, 65535)
+    with pytest.raises(fennec_amd.FennecError, match="too short"):
+        ctx.jpeg_decode_config(huge) and ctx._lib.fnx_jpeg_recompress and ctx.jpeg_recompress(huge, 0.94)
     # a scan cut short but closed with an EOI: the blocks run out
     cut = good[: len(good) * 3 // 4] + b"\xff\xd9"
     with pytest.raises(fennec_amd.FennecError):
