@@ -901,6 +901,8 @@ def other_workloads(args) -> int:
                                        "kernels, 1 finish): see roofline_step for the whole step against SURVEY 8(d)'s 193.4 MB"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_other(wl, W, H)
+    if wl == "config5" and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_config5(jpegs[:2], fbatch.TARGET_SSIM["Balanced"])
     if wl == "config5":
         per_item = float(np.mean(gpu_stage[-B * args.steps:]))
         out["gpu_stage"] = {"seconds_per_image": round(per_item, 6), "images_per_s_per_context": round(1.0 / per_item, 1),
@@ -1048,6 +1050,39 @@ def cpu_baseline_other(wl: str, W: int, H: int) -> dict:
     return {"value": round(n * cw * ch / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": f"{n} x (AdaptiveSharpen(0.5) + full-resolution SSIM) of a {cw}x{ch} crop of the 8K image in {dt:.1f} s, "
                       f"oracle/fennec_oracle.c with procs={cores}"}
+
+
+def cpu_baseline_config5(files, target: float) -> dict:
+    """CompressBatch on the host cores with the oracle standing in for Go's image/jpeg + ssim.go (the arithmetic the
+    device path is checked against): per item decode, compressJPEGOptimal's binary search with a round trip + SSIMFast per
+    candidate, the winner's file -- one item per worker thread as batch.go runs them (the oracle's C calls release the
+    interpreter lock), each item single-threaded.  A bounded sample: one item per worker, at most 32 workers."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    workers = max(1, min(32, os.cpu_count() or 1))
+
+    def item(data):
+        src = oracle.jpeg_decode(data)
+        lo, hi, best_q = 30, 100, 100            # compress.go:24-74 at the Balanced preset's bounds
+        steps = 0
+        while lo <= hi and steps < 7:
+            mid = (lo + hi) // 2
+            s = oracle.ssim_fast(src, oracle.jpeg_roundtrip(src, mid), procs=1)
+            steps += 1
+            if s >= target:
+                best_q, hi = mid, mid - 1
+            else:
+                lo = mid + 1
+        return len(oracle.jpeg_encode(src, best_q))
+
+    work = [files[k % len(files)] for k in range(workers)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        sizes = list(ex.map(item, work))
+    dt = time.perf_counter() - t0
+    return {"value": round(len(sizes) / dt, 3), "unit": "images/s", "cores": workers, "kind": "port",
+            "sample": f"{len(sizes)} x (decode + quality search + encode of a 4K JPEG), one per thread, in {dt:.1f} s; oracle/fennec_oracle.c, "
+                      f"each item single-threaded as in batch.go"}
 
 
 def _template_flags(kernel_name: str):
