@@ -614,7 +614,7 @@ class Context:
         winner's file -> (bytes, quality, ssim, steps, (w, h))."""
         src = np.frombuffer(data, dtype=np.uint8)
         k, pk = _f64(self.gaussianKernel() if window is None else window)
-        cap = max(4096, 2 * len(data))
+        cap = len(data) + 4096       # a search ends below the quality a camera wrote; a larger file asks again with its size
         n, q, st, v, w, h = C.c_size_t(0), C.c_int(), C.c_int(), C.c_double(), C.c_int(), C.c_int()
         for _ in range(2):
             buf = np.empty(cap, dtype=np.uint8)
