@@ -147,6 +147,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_box_downsample", i, [ctx, i] + img + [i, i] + img + [i, i])
         _sig(L, "fnx_ssim_fast", i, [ctx, i] + img + img + [i, i, _f64p, _f64p])
         _sig(L, "fnx_ssim", i, [ctx, i] + img + img + [i, i, _f64p, _f64p])
+        _sig(L, "fnx_pixel_ssim", i, [ctx, i, _u8p, C.c_size_t, _u8p, C.c_size_t, i, i, _f64p])
         _sig(L, "fnx_msssim", i, [ctx, i] + img + img + [i, i, _f64p, _f64p, _f64p])
         _sig(L, "fnx_ssim_fast_prepare", i, [ctx, i] + img + [i, i, C.POINTER(C.c_void_p)])
         _sig(L, "fnx_ssim_fast_against", i, [ctx, C.c_void_p, i] + img + [_f64p, _f64p])
@@ -414,6 +415,25 @@ class Context:
         with self._ordered(img1, img2):
             self._chk(self._lib.fennec_SSIM(self._h, a.space, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride,
                                             b.w, b.h, C.byref(out)), "SSIM")
+        return out.value
+
+    def pixelSSIM(self, pix_a, pix_b, w: int, h: int) -> float:
+        """ssim.go:169 over the two FLAT Pix slices as Go holds them (1-D uint8 numpy arrays or device tensors): for a
+        SubImage that is everything up to the end of the parent's buffer, which SSIM / SSIMFast cannot know."""
+        def flat(x):
+            if _is_torch(x):
+                return FNX_DEVICE, x.data_ptr(), int(x.numel())
+            x = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+            keep.append(x)
+            return FNX_HOST, x.ctypes.data, int(x.size)
+        keep = []
+        (sa, pa, na), (sb, pb, nb) = flat(pix_a), flat(pix_b)
+        if sa != sb:
+            raise FennecError("both Pix slices must live in the same space")
+        out = C.c_double()
+        with self._ordered(pix_a, pix_b):
+            self._chk(self._lib.fnx_pixel_ssim(self._h, sa, C.cast(pa, _u8p), na, C.cast(pb, _u8p), nb, int(w), int(h),
+                                               C.byref(out)), "pixelSSIM")
         return out.value
 
     def ssim_enqueue(self, img1, img2, window=None):

@@ -276,6 +276,15 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
                        radius, flags, nullptr, static_cast<uint8_t *const *>(dp[1]), dstride);
 }
 
+// The effects read a SubImage (sstride != 4w) two ways: by rows, and as the flat front of its Pix slice
+// (copy(dst.Pix, img.Pix), effects.go:68,120 -- see fx_flat_kernel): a host source of that kind goes up as the
+// slice it is, stride kept, instead of being packed row by row.
+static int stage_fx_src(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, DevImg *s)
+{
+    return sstride != w * 4 ? stage_in_flat(ctx, space, src, sstride, w, h, SLOT_IN_A, s)
+                            : stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, s);
+}
+
 int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                 uint8_t *dst, int dstride)
 {
@@ -286,7 +295,7 @@ int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
     if (w <= 0 || h <= 0) return FNX_OK;
     DevImg s;
     DevOut d;
-    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_fx_src(ctx, space, src, sstride, w, h, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
     FNX_TRY(launch_blur3x3(ctx, s.p, s.stride, w, h, d.p, d.stride));
     return finish(ctx, space, &d);
@@ -302,7 +311,7 @@ static int sharpen_common(fnx_ctx *ctx, bool adaptive, int space, const uint8_t 
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     DevImg s;
     DevOut d;
-    FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
+    FNX_TRY(stage_fx_src(ctx, space, src, sstride, w, h, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
     FNX_TRY(launch_sharpen(ctx, adaptive, s.p, s.stride, w, h, amount, d.p, d.stride));
     return finish(ctx, space, &d);
@@ -687,6 +696,38 @@ static int msssim_levels_device(fnx_ctx *ctx, const uint8_t *ap, int astride, co
     return FNX_OK;
 }
 
+int fnx_pixel_ssim(fnx_ctx *ctx, int space, const uint8_t *a_pix, size_t a_pix_len, const uint8_t *b_pix,
+                   size_t b_pix_len, int w, int h, double *out)
+{
+    FNX_TRY(bind(ctx));
+    FNX_TRY(check_space(space));
+    FNX_REQUIRE(out != nullptr && w >= 0 && h >= 0, "pixel_ssim arguments");
+    if (static_cast<long long>(w) * h == 0) {      // ssim.go:172-175
+        *out = 1.0;
+        return FNX_OK;
+    }
+    const size_t walk = (a_pix_len + 3) & ~size_t(3);         // i < len(a.Pix), i += 4, reads [i, i+2]
+    FNX_REQUIRE(a_pix_len == 0 || (a_pix && b_pix), "null Pix");
+    FNX_REQUIRE(a_pix_len == 0 || (walk - 1 <= a_pix_len && walk - 1 <= b_pix_len),
+                "a Pix slice ends inside the last pixel the loop reads, or b.Pix is shorter than a.Pix (the reference panics)");
+    const uint8_t *da = a_pix, *db = b_pix;
+    if (space == FNX_HOST && a_pix_len) {
+        void *ta = nullptr, *tb = nullptr;
+        FNX_TRY(scratch(ctx, SLOT_IN_A, walk + 16, &ta));
+        FNX_TRY(scratch(ctx, SLOT_IN_B, walk + 16, &tb));
+        FNX_HIP(hipMemsetAsync(static_cast<uint8_t *>(ta) + (walk - 4), 0, 4, ctx->stream));
+        FNX_HIP(hipMemsetAsync(static_cast<uint8_t *>(tb) + (walk - 4), 0, 4, ctx->stream));
+        FNX_HIP(hipMemcpyAsync(ta, a_pix, a_pix_len < walk ? a_pix_len : walk, hipMemcpyHostToDevice, ctx->stream));
+        FNX_HIP(hipMemcpyAsync(tb, b_pix, b_pix_len < walk ? b_pix_len : walk, hipMemcpyHostToDevice, ctx->stream));
+        da = static_cast<const uint8_t *>(ta);
+        db = static_cast<const uint8_t *>(tb);
+    }
+    double *dres;
+    FNX_TRY(result_slot(ctx, 1, &dres));
+    FNX_TRY(launch_pixel_ssim(ctx, da, db, w, h, walk, dres));
+    return result_wait(ctx, dres, out, 1);
+}
+
 int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                int bstride, int w, int h, const double *window, double *out, double *per_level)
 {
@@ -706,8 +747,10 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
         nlev = 1;
     } else {
         DevImg da, db;
-        FNX_TRY(stage_in(ctx, space, a, astride, w, h, SLOT_IN_A, &da));
-        FNX_TRY(stage_in(ctx, space, b, bstride, w, h, SLOT_IN_B, &db));
+        // aCopy := toNRGBA(a), bCopy := toNRGBA(b) (ssim.go:345-346): flat copies -- the strides only vouch for the
+        // slices' lengths (check_img above), the pyramid reads the first 4wh bytes of each as a tight image
+        FNX_TRY(stage_in_front(ctx, space, a, w, h, SLOT_IN_A, &da));
+        FNX_TRY(stage_in_front(ctx, space, b, w, h, SLOT_IN_B, &db));
         double *dres;
         FNX_TRY(result_slot(ctx, 5, &dres));
         FNX_TRY(msssim_levels_device(ctx, da.p, da.stride, db.p, db.stride, w, h, nweights, window, dres, &nlev));
@@ -732,7 +775,7 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
     double *dres;
     FNX_TRY(result_slot_queued(ctx, 5, &dres));
     int nlev = 0;
-    FNX_TRY(msssim_levels_device(ctx, a, astride, b, bstride, w, h, nweights, window, dres, &nlev));
+    FNX_TRY(msssim_levels_device(ctx, a, w * 4, b, w * 4, w, h, nweights, window, dres, &nlev));   // toNRGBA: flat (see fnx_msssim)
     fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
     FNX_TRY(publish_results(ctx, dres, 1));
     q.nraw = nlev;

@@ -195,6 +195,10 @@ int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, in
 // pixelSSIM walks the flat slice, row padding included (ssim.go:178).
 int stage_in_flat(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, Slot slot,
                   DevImg *out);
+// toNRGBA's copy (convert.go:12-19: copy(dst.Pix, nrgba.Pix) into a fresh tight image): the FIRST 4wh flat bytes of
+// the Pix slice as a tight w x h image -- the image's rows only when its stride is 4w.  MSSSIM's pyramid starts
+// from these copies (ssim.go:345-346).  Device sources are read in place with stride 4w.
+int stage_in_front(fnx_ctx *ctx, int space, const uint8_t *src, int w, int h, Slot slot, DevImg *out);
 int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, Slot slot,
               DevOut *out);
 // Copy a staged output back (if host) and synchronise when `space` is host.

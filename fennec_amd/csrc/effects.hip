@@ -359,6 +359,44 @@ static bool fx_guard(double amount, float *guard)
     return true;
 }
 
+// ------------------------------------------------------------------------------------
+// SubImage inputs (sstride != 4w): the reference's FLAT copies
+// ------------------------------------------------------------------------------------
+// gaussianBlur3x3 and AdaptiveSharpen start from copy(dst.Pix, img.Pix) (effects.go:120,68): Go's copy() moves the
+// first min(len(dst.Pix), len(img.Pix)) = 4wh FLAT bytes of the source slice into the tight destination, which are the
+// image's rows only when Stride == 4w.  So on a SubImage the reference's 3x3 blur has the flat bytes on its border and
+// in EVERY alpha byte (the interior writes R, G, B only, effects.go:135), AdaptiveSharpen has them on its border
+// (its interior writes all four bytes, :83-85), and Sharpen -- whose own output is written pixel by pixel (:28-42) --
+// sees them through the border of its blurred operand: val = orig + amount * (orig - flat).  The tile kernels above
+// compute every strided read of the reference; this pass, launched behind them for sstride != 4w only, rewrites what
+// the flat copy decides.  Pixel (x, y) of the tight destination is flat bytes [4(wy + x), +4) of the source slice.
+template <int MODE>
+__global__ __launch_bounds__(256) void fx_flat_kernel(FxArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.w || y >= a.h) return;
+    const bool border = x == 0 || y == 0 || x == a.w - 1 || y == a.h - 1;
+    if (MODE != FX_BLUR3 && !border) return;
+    const uint32_t flat = ld_px(a.src + (static_cast<size_t>(y) * a.w) * 4, x);
+    g_u32w *dp = (g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x));
+    if (MODE == FX_BLUR3) {
+        *dp = border ? flat : ((*dp & 0x00ffffffu) | (flat & 0xff000000u));
+    } else if (MODE == FX_ADAPTIVE) {
+        *dp = flat;
+    } else {
+        const uint32_t c = ld_px(a.src + static_cast<size_t>(y) * a.sstride, x);
+        uint32_t out = c & 0xff000000u;                               // effects.go:40
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const double orig = u8_to_f64((c >> (8 * ch)) & 0xffu);
+            const double bl = u8_to_f64((flat >> (8 * ch)) & 0xffu);
+            const double val = orig + a.amount * (orig - bl);         // effects.go:37
+            out |= clampF_dev(val) << (8 * ch);
+        }
+        *dp = out;
+    }
+}
+
 template <int MODE>
 static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, double amount,
                      uint8_t *dst, int dstride)
@@ -397,6 +435,10 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     } else {
         dim3 grid((w + FXR_TW - 1) / FXR_TW, (h + FXR_TH - 1) / FXR_TH);
         hipLaunchKernelGGL((fx_ref_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
+    }
+    if (sstride != w * 4) {                                      // a SubImage: the reference's flat copies (see fx_flat_kernel)
+        dim3 grid((w + 63) / 64, (h + 3) / 4);
+        hipLaunchKernelGGL((fx_flat_kernel<MODE>), grid, dim3(256), 0, ctx->stream, a);
     }
     FNX_HIP(hipGetLastError());
     FNX_TRY(prof_end(ctx));

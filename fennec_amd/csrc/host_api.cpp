@@ -252,7 +252,7 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
     if (space == FNX_DEVICE)
         return fnx_msssim(ctx, FNX_DEVICE, a, astride, rb, rbs, aw, ah, ssim_window(), out, nullptr);
     DevImg da;
-    FNX_TRY(stage_in(ctx, FNX_HOST, a, astride, aw, ah, SLOT_IN_A, &da));
+    FNX_TRY(stage_in_front(ctx, FNX_HOST, a, aw, ah, SLOT_IN_A, &da));      // toNRGBA(a): the flat front of a.Pix (ssim.go:345)
     return fnx_msssim(ctx, FNX_DEVICE, da.p, da.stride, rb, rbs, aw, ah, ssim_window(), out, nullptr);
 }
 

@@ -167,6 +167,21 @@ int stage_in_flat(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int 
     return FNX_OK;
 }
 
+int stage_in_front(fnx_ctx *ctx, int space, const uint8_t *src, int w, int h, Slot slot, DevImg *out)
+{
+    out->stride = w * 4;
+    if (space != FNX_HOST) {
+        out->p = src;
+        return FNX_OK;
+    }
+    const size_t len = static_cast<size_t>(w) * 4 * h;
+    void *d = nullptr;
+    FNX_TRY(scratch(ctx, slot, len + 16, &d));
+    FNX_HIP(hipMemcpyAsync(d, src, len, hipMemcpyHostToDevice, ctx->stream));
+    out->p = static_cast<const uint8_t *>(d);
+    return FNX_OK;
+}
+
 int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, Slot slot,
               DevOut *out)
 {

@@ -36,7 +36,9 @@ import "C"
 import (
 	"image"
 	"image/color"
+	"log"
 	"math"
+	"os"
 	"runtime"
 	"sync"
 	"unsafe"
@@ -99,6 +101,38 @@ func poolGetIf(cond bool) *C.fnx_ctx {
 	return pool.get()
 }
 
+// ---- CPU fallbacks: counted, never silent ------------------------------------------------------
+// None of the shadowed functions can return an error (SURVEY 8(b)), so a non-zero status -- no GPU, out of memory, a
+// refused argument -- runs the reference's own Go body.  That must not go unnoticed in production: every such call is
+// counted per function, HIPFallbacks() exposes the counts (a metrics endpoint, a test's assertion that a GPU build
+// really ran on the GPU), and FENNEC_HIP_LOG=1 logs the first fallback of each function with the library's error.
+var (
+	fallbackMu     sync.Mutex
+	fallbackCounts = map[string]int64{}
+	fallbackLog    = os.Getenv("FENNEC_HIP_LOG") == "1"
+)
+
+func fellBack(fn string) {
+	fallbackMu.Lock()
+	fallbackCounts[fn]++
+	first := fallbackCounts[fn] == 1
+	fallbackMu.Unlock()
+	if first && fallbackLog {
+		log.Printf("fennec_hip: %s fell back to the Go path: %s", fn, C.GoString(C.fnx_last_error()))
+	}
+}
+
+// HIPFallbacks returns how many calls of each shadowed function ran the pure-Go body instead of the HIP library.
+func HIPFallbacks() map[string]int64 {
+	fallbackMu.Lock()
+	defer fallbackMu.Unlock()
+	out := make(map[string]int64, len(fallbackCounts))
+	for k, v := range fallbackCounts {
+		out[k] = v
+	}
+	return out
+}
+
 func pix(img *image.NRGBA) *C.uint8_t {
 	if len(img.Pix) == 0 {
 		return nil
@@ -116,15 +150,29 @@ func SSIMFast(img1, img2 *image.NRGBA) float64 {
 		defer pool.put(c)
 		var out C.double
 		w, h := img1.Bounds().Dx(), img1.Bounds().Dy()
-		st := C.fnx_ssim_fast(c, C.FNX_HOST, pix(img1), C.int(img1.Stride), pix(img2), C.int(img2.Stride),
-			C.int(w), C.int(h), (*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		var st C.int
+		if w <= 512 && h <= 512 && (w < 8 || h < 8) {
+			st = pixelSSIMHIP(c, img1, img2, w, h, &out) // ssim.go:62-64 with len(Pix) as Go sees it
+		} else {
+			st = C.fnx_ssim_fast(c, C.FNX_HOST, pix(img1), C.int(img1.Stride), pix(img2), C.int(img2.Stride),
+				C.int(w), C.int(h), (*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		}
 		runtime.KeepAlive(img1)
 		runtime.KeepAlive(img2)
 		if st == C.FNX_OK {
 			return float64(out)
 		}
 	}
+	fellBack("SSIMFast")
 	return ssimFastGo(img1, img2)
+}
+
+// pixelSSIM (ssim.go:169-204) loops `for i := 0; i < len(a.Pix); i += 4`: for a SubImage that runs to the end of the
+// parent's buffer, which (pointer, stride, w, h) cannot say -- so this branch hands over the slices' real lengths.
+// A b.Pix shorter than a.Pix panics in the reference (index out of range); the library refuses it and the Go
+// fallback then panics exactly as the reference does.
+func pixelSSIMHIP(c *C.fnx_ctx, a, b *image.NRGBA, w, h int, out *C.double) C.int {
+	return C.fnx_pixel_ssim(c, C.FNX_HOST, pix(a), C.size_t(len(a.Pix)), pix(b), C.size_t(len(b.Pix)), C.int(w), C.int(h), out)
 }
 
 // SSIM replaces ssim.go:24.
@@ -137,14 +185,20 @@ func SSIM(img1, img2 image.Image) float64 {
 	if c := pool.get(); c != nil {
 		defer pool.put(c)
 		var out C.double
-		st := C.fnx_ssim(c, C.FNX_HOST, pix(a), C.int(a.Stride), pix(b), C.int(b.Stride), C.int(w), C.int(h),
-			(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		var st C.int
+		if w < 8 || h < 8 {
+			st = pixelSSIMHIP(c, a, b, w, h, &out) // ssim.go:35-37
+		} else {
+			st = C.fnx_ssim(c, C.FNX_HOST, pix(a), C.int(a.Stride), pix(b), C.int(b.Stride), C.int(w), C.int(h),
+				(*C.double)(unsafe.Pointer(&ssimWindow[0])), &out)
+		}
 		runtime.KeepAlive(a)
 		runtime.KeepAlive(b)
 		if st == C.FNX_OK {
 			return float64(out)
 		}
 	}
+	fellBack("SSIM")
 	return ssimGo(a, b)
 }
 
@@ -166,6 +220,7 @@ func MSSSIM(img1, img2 image.Image) float64 {
 			return float64(out)
 		}
 	}
+	fellBack("MSSSIM")
 	return msssimGo(a, b)
 }
 
@@ -185,6 +240,7 @@ func boxDownsample(img *image.NRGBA, dstW, dstH int) *image.NRGBA {
 			return dst
 		}
 	}
+	fellBack("boxDownsample")
 	return boxDownsampleGo(img, dstW, dstH)
 }
 
@@ -242,6 +298,7 @@ func lanczosResize(img *image.NRGBA, dstW, dstH int) *image.NRGBA {
 			return dst
 		}
 	}
+	fellBack("lanczosResize")
 	return lanczosResizeGo(img, dstW, dstH)
 }
 
@@ -278,6 +335,7 @@ func GaussianBlur(img *image.NRGBA, sigma float64) *image.NRGBA {
 			return dst
 		}
 	}
+	fellBack("GaussianBlur")
 	return gaussianBlurGo(img, sigma)
 }
 
@@ -316,6 +374,7 @@ func Sharpen(img *image.NRGBA, strength float64) *image.NRGBA {
 	if dst := sharpenHIP(img, 1.0+strength*1.5, false); dst != nil {
 		return dst
 	}
+	fellBack("Sharpen")
 	return sharpenGo(img, strength)
 }
 
@@ -333,6 +392,7 @@ func AdaptiveSharpen(img *image.NRGBA, strength float64) *image.NRGBA {
 	if dst := sharpenHIP(img, 1.0+strength*2.0, true); dst != nil {
 		return dst
 	}
+	fellBack("AdaptiveSharpen")
 	return adaptiveSharpenGo(img, strength)
 }
 
@@ -357,6 +417,7 @@ func ApplyOrientation(img *image.NRGBA, orient Orientation) *image.NRGBA {
 			return dst
 		}
 	}
+	fellBack("ApplyOrientation")
 	return applyOrientationGo(img, orient)
 }
 
@@ -400,6 +461,7 @@ func Analyze(img image.Image) ImageStats {
 			return stats
 		}
 	}
+	fellBack("Analyze")
 	return analyzeGo(img)
 }
 
@@ -478,6 +540,7 @@ func (r *ssimRef) against(decoded image.Image) float64 {
 			return float64(out)
 		}
 	}
+	fellBack("ssimRef.against")
 	return ssimFastGo(r.src, toNRGBARef(decoded)) // anything else: the reference's own path
 }
 
@@ -565,6 +628,7 @@ func applyPalette(src *image.NRGBA, palette color.Palette) *image.Paletted {
 			return indexed
 		}
 	}
+	fellBack("applyPalette")
 	return applyPaletteGo(src, palette)
 }
 

@@ -167,6 +167,16 @@ int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
  * 64 doubles.  Both images are w x h (the reference does not check). */
 int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                   int bstride, int w, int h, const double *window, double *out);
+/* pixelSSIM (ssim.go:169-204), the branch SSIM / SSIMFast take when w < 8 || h < 8, with the slices' REAL
+ * lengths: the reference walks `for i := 0; i < len(a.Pix); i += 4` over both flat Pix slices, and for a
+ * SubImage len(Pix) runs to the end of the PARENT's buffer (image.NRGBA.SubImage: Pix = p.Pix[i:]), not just to
+ * the sub-image's last pixel.  fnx_ssim / fnx_ssim_fast only know (h-1)*stride + 4w -- the shortest slice a
+ * w x h image can have, which is what image.NewNRGBA and every image in this path's own pipeline has; a caller
+ * holding a true SubImage under 8 px passes len(a.Pix), len(b.Pix) here.  b_pix_len < a_pix_len is
+ * FNX_ERR_INVALID (the reference panics: index out of range).  a_pix_len is rounded up to a multiple of 4 the way
+ * the loop's last iteration reads it (and must then fit).  Divides by w*h like the reference; w*h == 0 -> 1.0. */
+int fnx_pixel_ssim(fnx_ctx *ctx, int space, const uint8_t *a_pix, size_t a_pix_len, const uint8_t *b_pix,
+                   size_t b_pix_len, int w, int h, double *out);
 /* SSIM (ssim.go:24-43) for equal dims (the dims-differ resize is composed by
  * the caller, as fennec_SSIM does). */
 int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,

@@ -616,12 +616,16 @@ ORC_API double orc_msssim(const uint8_t *a, int astride, int aw, int ah, const u
             th /= 2;
         }
     }
-    /* toNRGBA copies (convert.go:12-19): tight w x h */
+    /* toNRGBA copies (convert.go:12-19, called at ssim.go:345-346): tight w x h images filled by
+     * copy(dst.Pix, nrgba.Pix) -- the FIRST 4wh flat bytes of each source slice (see flat_pix_copy above),
+     * so a SubImage (stride != 4w) enters the pyramid with its row padding folded in, exactly as in Go */
     size_t n0 = (size_t)(w > 0 ? w : 0) * (size_t)(h > 0 ? h : 0) * 4;
     uint8_t *ac = (uint8_t *)malloc(n0 + 4), *bc = (uint8_t *)malloc(n0 + 4);
-    for (int y = 0; y < h; y++) {
-        memcpy(ac + (size_t)y * w * 4, a + (size_t)y * astride, (size_t)w * 4);
-        memcpy(bc + (size_t)y * w * 4, b + (size_t)y * bstride, (size_t)w * 4);
+    (void)astride;
+    (void)bstride;
+    if (n0) {
+        memcpy(ac, a, n0);
+        memcpy(bc, b, n0);
     }
     int cw = w, ch = h;
     double result = 0;
@@ -798,12 +802,26 @@ static void blur3_rows(int from, int to, void *p)
     }
 }
 
-/* gaussianBlur3x3 (effects.go:116-141): dst = copy(src), interior blurred */
+/*
+ * copy(dst.Pix, img.Pix) (effects.go:68,120; convert.go:16): a FLAT copy of min(len(dst.Pix), len(img.Pix))
+ * bytes, not a row-by-row one.  dst is always a fresh tight w x h image (len 4wh); img.Pix of any valid
+ * *image.NRGBA holds at least (h-1)*Stride + 4w >= 4wh bytes (Stride >= 4w: NewNRGBA's 4w, or a SubImage's
+ * parent stride), so exactly the FIRST 4wh bytes of img.Pix move -- for a SubImage (Stride != 4w) those are
+ * not its rows but its first row, the parent's bytes behind it, the second row ...  Row y of the tight
+ * destination is flat bytes [4wy, 4w(y+1)) of the source slice; dstride only places that row.
+ */
+static void flat_pix_copy(const uint8_t *src_pix, int w, int h, uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * dstride, src_pix + (size_t)y * w * 4, (size_t)w * 4);
+}
+
+/* gaussianBlur3x3 (effects.go:116-141): dst = copy(dst.Pix, img.Pix) -- flat, see above -- then the interior's
+ * R, G, B blurred from the STRIDED source; the interior's alpha and the whole border keep the flat bytes */
 ORC_API void orc_blur3x3(const uint8_t *src, int sstride, int w, int h, uint8_t *dst, int dstride,
                          int procs)
 {
-    for (int y = 0; y < h; y++)
-        memcpy(dst + (size_t)y * dstride, src + (size_t)y * sstride, (size_t)w * 4);
+    flat_pix_copy(src, w, h, dst, dstride);                                    /* effects.go:120 */
     fx_arg a = {src, sstride, NULL, 0, dst, dstride, w, h, 0};
     parallel_do(1, h - 1, procs, blur3_rows, &a);
 }
@@ -895,8 +913,7 @@ ORC_API int orc_adaptive_sharpen(const uint8_t *src, int sstride, int w, int h, 
     if (w < 3 || h < 3) return 0;
     uint8_t *blurred = (uint8_t *)malloc((size_t)w * h * 4);
     orc_blur3x3(src, sstride, w, h, blurred, w * 4, procs);
-    for (int y = 0; y < h; y++)
-        memcpy(dst + (size_t)y * dstride, src + (size_t)y * sstride, (size_t)w * 4);
+    flat_pix_copy(src, w, h, dst, dstride);                                    /* effects.go:68: flat */
     fx_arg a = {src, sstride, blurred, w * 4, dst, dstride, w, h, 1.0 + strength * 2.0};
     parallel_do(1, h - 1, procs, adaptive_rows, &a);
     free(blurred);

@@ -178,6 +178,14 @@ def pixel_ssim(a: np.ndarray, b: np.ndarray) -> float:
     return float(lib().orc_pixel_ssim(pa, pb, w, h, a.size))
 
 
+def pixel_ssim_flat(pix_a: np.ndarray, pix_b: np.ndarray, w: int, h: int) -> float:
+    """pixelSSIM over two flat Pix slices as Go holds them (ssim.go:178: `i < len(a.Pix)`); w, h only give n."""
+    a = np.ascontiguousarray(pix_a, dtype=np.uint8).reshape(-1)
+    b = np.ascontiguousarray(pix_b, dtype=np.uint8).reshape(-1)
+    assert b.size >= a.size, "the reference panics (index out of range)"
+    return float(lib().orc_pixel_ssim(a.ctypes.data_as(_u8p), b.ctypes.data_as(_u8p), int(w), int(h), a.size))
+
+
 def box_downsample(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
     p, s, w, h = _img(img)
     if w <= 0 or h <= 0 or dw <= 0 or dh <= 0:

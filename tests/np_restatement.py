@@ -39,6 +39,18 @@ def seq_sum(v) -> float:
     return float(np.add.accumulate(v)[-1])
 
 
+def flat_pix_image(img):
+    """What `copy(dst.Pix, img.Pix)` leaves in a fresh tight w x h image (effects.go:68,120; convert.go:16):
+    Go's copy() moves min(len(dst), len(src)) FLAT bytes, and len(img.Pix) >= (h-1)*Stride + 4w >= 4wh for
+    every valid NRGBA, so it is the first 4wh bytes of the Pix slice reshaped -- the image's own rows only
+    when Stride == 4w.  `img` is an (h, w, 4) view whose first byte is Pix[0] and whose row stride is Stride."""
+    h, w = img.shape[:2]
+    if h == 0 or w == 0:
+        return img.copy()
+    assert img.strides[1:] == (4, 1) and (h == 1 or img.strides[0] >= 4 * w), "not an image.NRGBA layout"
+    return np.lib.stride_tricks.as_strided(img, shape=(h, w, 4), strides=(4 * w, 4, 1)).copy()
+
+
 # ------------------------------------------------------------------ ssim.go
 def to_luminance(img):
     """ssim.go:207-220"""
@@ -249,7 +261,7 @@ def lanczos_resize(img, dw, dh):
     if sw <= 0 or sh <= 0 or dw <= 0 or dh <= 0:
         return np.zeros((0, 0, 4), dtype=np.uint8)
     if sw == dw and sh == dh:
-        return img.copy()
+        return flat_pix_image(img)                     # resize.go:45-49: copy(dst.Pix, img.Pix)
     return _resize_axis(_resize_axis(img, dw, 1), dh, 0)
 
 
@@ -293,7 +305,7 @@ def msssim(a, b, kernel=None):
             break
         tw //= 2
         th //= 2
-    ac, bc = a.copy(), b.copy()
+    ac, bc = flat_pix_image(a), flat_pix_image(b)      # toNRGBA: copy(dst.Pix, nrgba.Pix), ssim.go:345-346
     result = 0.0
     for i, wt in enumerate(weights):
         s = ssim_fast(ac, bc, kernel)
@@ -344,8 +356,8 @@ def gaussian_blur(img, sigma):
 
 
 def blur3x3(img):
-    """effects.go:116-141"""
-    out = img.copy()
+    """effects.go:116-141: the border and every alpha byte are whatever copy(dst.Pix, img.Pix) put there"""
+    out = flat_pix_image(img)
     h, w = img.shape[:2]
     if h < 3 or w < 3:
         return out
@@ -399,8 +411,9 @@ def adaptive_sharpen(img, strength):
     orig = img[1:h - 1, 1:w - 1, :3].astype(np.float64)
     amount = 1.0 + strength * 2.0
     local = amount * edge_strength(img)
-    out = img.copy()
+    out = flat_pix_image(img)                          # effects.go:68
     out[1:h - 1, 1:w - 1, :3] = clampF(orig + local[..., None] * (orig - blur))
+    out[1:h - 1, 1:w - 1, 3] = img[1:h - 1, 1:w - 1, 3]      # effects.go:85
     return out
 
 

@@ -160,9 +160,82 @@ def test_sharpen_amounts_against_reference_order_kernel(ctx, orc, monkeypatch):
             got_view = ctx.sharpen_amount(view, amt, adaptive).cpu().numpy()
             monkeypatch.setenv("FNX_FX_REF", "1")
             want = ctx.sharpen_amount(soft, amt, adaptive)
+            want_view = ctx.sharpen_amount(view, amt, adaptive).cpu().numpy()
             assert np.array_equal(got, want), (adaptive, amt)
-            assert np.array_equal(got_view, want), (adaptive, amt, "view")
+            # a SubImage's border follows the reference's flat copy(dst.Pix, img.Pix) (test_subimage_flat_pix_copies_gpu)
+            assert np.array_equal(got_view, want_view), (adaptive, amt, "view")
+            assert np.array_equal(got_view[1:-1, 1:-1], want[1:-1, 1:-1]), (adaptive, amt, "view interior")
     monkeypatch.delenv("FNX_FX_REF", raising=False)
+
+
+@pytest.mark.parametrize("geom", [(20, 10, 4, 8, 6, 12), (160, 120, 5, 8, 80, 128), (700, 300, 7, 13, 280, 611), (33, 17, 0, 0, 17, 9)])
+def test_subimage_flat_pix_copies_gpu(ctx, orc, geom):
+    """effects.go:68,120 and convert.go:16 (MSSSIM, ssim.go:345-346) copy the FLAT Pix slice.  On a
+    SubImage (stride != 4w) gaussianBlur3x3's border and alpha, AdaptiveSharpen's border, Sharpen's border (through its
+    blurred operand) and MSSSIM's pyramid input are the first 4wh bytes of the slice, not the rows.  Host views and
+    device views against the oracle (whose flat semantics tests/test_oracle.py checks against Go's slice rules)."""
+    import torch
+    pw, ph, y0, x0, h, w = geom
+    big = synth.noise_image(pw, ph, 23, alpha=True)
+    sub = big[y0:y0 + h, x0:x0 + w]
+    dbig = torch.from_numpy(big).cuda()
+    dsub = dbig[y0:y0 + h, x0:x0 + w]
+    torch.cuda.synchronize()
+    tight = np.ascontiguousarray(sub)
+
+    def both(fn):
+        host = fn(sub)
+        dev = fn(dsub); ctx.sync()
+        return host, dev.cpu().numpy()
+
+    for got in both(ctx.blur3x3):
+        assert np.array_equal(got, orc.blur3x3(sub))
+    for s_ in (0.3, 0.5, 1.0):
+        for got in both(lambda im: ctx.Sharpen(im, s_)):
+            assert np.array_equal(got, orc.sharpen(sub, s_)), ("sharpen", s_)
+        for got in both(lambda im: ctx.AdaptiveSharpen(im, s_)):
+            assert np.array_equal(got, orc.adaptive_sharpen(sub, s_)), ("adaptive", s_)
+    if (y0, x0) != (0, 0) or w != pw:
+        assert not np.array_equal(orc.blur3x3(sub), orc.blur3x3(tight))      # the case is a real one
+    assert np.array_equal(ctx.lanczosResize(sub, w, h), orc.lanczos_resize(sub, w, h))          # resize.go:45-49
+    got = ctx.lanczosResize(dsub, w, h); ctx.sync()
+    assert np.array_equal(got.cpu().numpy(), orc.lanczos_resize(sub, w, h))
+
+    other = synth.noise_image(w, h, 5)
+    dother = torch.from_numpy(other).cuda()
+    torch.cuda.synchronize()
+    want = orc.msssim(sub, other)
+    assert abs(ctx.MSSSIM(sub, other) - want) <= SSIM_TOL and abs(ctx.MSSSIM(dsub, dother) - want) <= SSIM_TOL
+    want = orc.msssim(other, sub)
+    assert abs(ctx.MSSSIM(other, sub) - want) <= SSIM_TOL and abs(ctx.MSSSIM(dother, dsub) - want) <= SSIM_TOL
+    ctx.msssim_enqueue(dsub, dother)
+    assert abs(ctx.fetch_result() - orc.msssim(sub, other)) <= SSIM_TOL
+    # dims differ: b is Lanczos-resized by rows (resize.go), a enters the pyramid flat
+    small = synth.noise_image(max(w // 2, 1), max(h // 2, 1), 9)
+    want = orc.msssim(sub, small)
+    assert abs(ctx.MSSSIM(sub, small) - want) <= SSIM_TOL
+    assert abs(ctx.MSSSIM(dsub, torch.from_numpy(small).cuda()) - want) <= SSIM_TOL
+
+
+def test_pixel_ssim_walks_the_whole_slice(ctx, orc):
+    """pixelSSIM (ssim.go:178,190) loops to len(a.Pix): a SubImage's slice runs to the end of the PARENT's buffer."""
+    import torch
+    big_a = synth.noise_image(20, 12, 3, alpha=True)
+    big_b = synth.noise_image(20, 12, 4, alpha=True)
+    y0, x0, h, w = 2, 5, 6, 7
+    pa = big_a.reshape(-1)[(y0 * 20 + x0) * 4:]
+    pb = big_b.reshape(-1)[(y0 * 20 + x0) * 4:]
+    want = orc.pixel_ssim_flat(pa, pb, w, h)
+    assert ctx.pixelSSIM(pa, pb, w, h) == want
+    got = ctx.pixelSSIM(torch.from_numpy(pa.copy()).cuda(), torch.from_numpy(pb.copy()).cuda(), w, h)
+    assert got == want
+    # the shortest slice a w x h view can have is what SSIM / SSIMFast assume
+    short = ((h - 1) * 20 + w) * 4
+    assert ctx.pixelSSIM(pa[:short], pb[:short], w, h) == ctx.SSIMFast(big_a[y0:y0 + h, x0:x0 + w], big_b[y0:y0 + h, x0:x0 + w])
+    assert want != ctx.pixelSSIM(pa[:short], pb[:short], w, h)
+    with pytest.raises(fennec_amd.FennecError):
+        ctx.pixelSSIM(pa, pb[:-8], w, h)                   # the reference panics
+    assert ctx.pixelSSIM(pa[:0], pb[:0], 0, 5) == 1.0
 
 
 def test_adaptive_sharpen_4k_soft(ctx, orc):

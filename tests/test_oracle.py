@@ -237,6 +237,60 @@ def test_strided_input(orc):
     assert orc.ssim(sub, tight) == 1.0
 
 
+def _go_flat_copy(parent, y0, x0, h, w):
+    """copy(dst.Pix, img.Pix) for img = parent.SubImage(Rect(x0, y0, x0+w, y0+h)), written from Go's slice
+    rules and nothing else: img.Pix = parent.Pix[PixOffset(x0, y0):], dst.Pix has 4wh bytes, copy() moves
+    min(len(dst.Pix), len(img.Pix)) bytes from the front."""
+    pix = parent.reshape(-1)[(y0 * parent.shape[1] + x0) * 4:]
+    n = min(4 * w * h, pix.size)
+    out = np.zeros(4 * w * h, dtype=np.uint8)
+    out[:n] = pix[:n]
+    return out.reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("geom", [(20, 10, 4, 8, 6, 12), (80, 60, 5, 8, 40, 64), (33, 17, 0, 0, 17, 9), (16, 16, 3, 5, 9, 11)])
+def test_subimage_flat_pix_copies(orc, geom):
+    """effects.go:68,120 and convert.go:16 (via MSSSIM, ssim.go:345-346) copy the FLAT Pix slice: on a
+    SubImage (Stride != 4w) the 3x3 blur's border and alpha, AdaptiveSharpen's border, Sharpen's border
+    (through its blurred operand) and MSSSIM's whole pyramid input are the first 4wh bytes of the slice."""
+    pw, ph, y0, x0, h, w = geom
+    big = synth.noise_image(pw, ph, 23, alpha=True)
+    sub = big[y0:y0 + h, x0:x0 + w]
+    flat = _go_flat_copy(big, y0, x0, h, w)
+    tight = np.ascontiguousarray(sub)
+    interior = (slice(1, h - 1), slice(1, w - 1))
+    border = np.ones((h, w), dtype=bool); border[interior] = False
+
+    b3 = orc.blur3x3(sub)
+    assert np.array_equal(b3[border], flat[border])                                   # effects.go:120
+    assert np.array_equal(b3[..., 3], flat[..., 3])                                   # alpha "already copied above"
+    assert np.array_equal(b3[interior][..., :3], orc.blur3x3(tight)[interior][..., :3])
+    assert np.array_equal(b3, npr.blur3x3(sub))
+
+    ad = orc.adaptive_sharpen(sub, 0.5)
+    assert np.array_equal(ad[border], flat[border])                                   # effects.go:68
+    assert np.array_equal(ad[interior], orc.adaptive_sharpen(tight, 0.5)[interior])   # interior incl. alpha: strided reads
+    assert np.array_equal(ad, npr.adaptive_sharpen(sub, 0.5))
+
+    sh = orc.sharpen(sub, 0.5)
+    assert np.array_equal(sh[interior], orc.sharpen(tight, 0.5)[interior])
+    amount = 1.0 + 0.5 * 1.5                                                          # effects.go:26,37 on the border
+    want = npr.clampF(tight[..., :3].astype(np.float64) + amount * (tight[..., :3].astype(np.float64) - flat[..., :3].astype(np.float64)))
+    assert np.array_equal(sh[border][..., :3], want[border]) and np.array_equal(sh[..., 3], tight[..., 3])
+    assert np.array_equal(sh, npr.sharpen(sub, 0.5))
+
+    assert np.array_equal(orc.lanczos_resize(sub, w, h), flat)                        # resize.go:45-49
+    assert np.array_equal(npr.lanczos_resize(sub, w, h), flat)
+
+    other = synth.noise_image(w, h, 5)
+    assert orc.msssim(sub, other) == orc.msssim(flat, other) == npr.msssim(sub, other)    # toNRGBA(a): flat
+    assert orc.msssim(other, sub) == orc.msssim(other, flat)                              # toNRGBA(b): flat
+    if flat.tobytes() != tight.tobytes() and min(w, h) >= 8:
+        assert orc.msssim(sub, other) != orc.msssim(tight, other)
+    # on a tight image all of this is the old row-wise behaviour
+    assert np.array_equal(orc.blur3x3(tight)[border], tight[border])
+
+
 def test_summarize(orc):                # batch.go:140-158
     s = orc.summarize([0, 1, 0, 0], [1, 0, 1, 0], [100, 0, 300, 50], [40, 0, 100, 0], [0.95, 0, 0.97, 0])
     assert s["Total"] == 4 and s["Succeeded"] == 3 and s["Failed"] == 1
