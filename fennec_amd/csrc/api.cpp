@@ -186,6 +186,7 @@ int publish_results(fnx_ctx *ctx, const double *pinned, int n)
     q.pinned = pinned;
     q.n = n;
     q.nraw = 0;
+    q.tail_parity = -1;
     ctx->res_count++;
     return FNX_OK;
 }
@@ -447,6 +448,9 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
         FNX_TRY(poll_results(q.pinned, n, [&] { return hipEventQuery(q.ev); }));
         std::memcpy(out, q.pinned, sizeof(double) * size_t(n));
     }
+    // a one-pass batch whose results have arrived has read its slabs / planes / partial sums for the last time: the
+    // step that reuses the buffer set needs no stream-side wait for this tail (one barrier packet less per step)
+    if (q.tail_parity >= 0 && q.tail_gen == ctx->tail_gen[q.tail_parity]) ctx->tail_pending[q.tail_parity] = false;
     ctx->res_head = (ctx->res_head + 1) % fnx_ctx::RES_DEPTH;
     ctx->res_count--;
     return FNX_OK;
@@ -529,7 +533,14 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
             ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;
             int rc = launch_windowed_ssim(ctx, n, planes, nw * 4, plane, planes + plane * n, nw * 4, plane, nw, nh,
                                           window, static_cast<const double *>(dwin), dres);
-            if (rc >= 0) rc = publish_results(ctx, dres, n);      // the batch's event: behind the tail
+            if (rc >= 0) {
+                rc = publish_results(ctx, dres, n);      // the batch's event: behind the tail
+                if (rc >= 0) {
+                    fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count - 1) % fnx_ctx::RES_DEPTH];
+                    q.tail_parity = p;
+                    q.tail_gen = ++ctx->tail_gen[p];
+                }
+            }
             if (rc >= 0 && hipEventRecord(ctx->ev_tail[p], ctx->stream2) != hipSuccess) {
                 set_error("hipEventRecord (tail) failed");
                 rc = FNX_ERR_HIP;

@@ -14,6 +14,8 @@
 //  * blur_direct_kernel<R, ..., SCORE=true> + box_from_slabs_kernel: the same blur that also
 //    gathers SSIMFast's boxDownsample sums of the source and of the blurred image, so
 //    SSIMFast(src, blurred) needs no second pass over either (launch_blur_scored).
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "devutil.hpp"
 
@@ -356,13 +358,13 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         v2f acc[Q][3];                                           // (r0,g0) (b0,r1) (g1,b1)
 #pragma unroll
         for (int j = 0; j < Q; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){SEED, SEED};
-        uint32_t al0[Q], al1[Q];
+        u32x2 alg[GUARD ? Q : 1];                                // GUARD: the centre rows' words stay in registers (see below)
         u32x2 tn = *reinterpret_cast<const u32x2 *>(colp);
 #pragma unroll
         for (int i = 0; i < Q + 2 * R; i++) {
             const u32x2 t = tn;
             if (i + 1 < Q + 2 * R) tn = *reinterpret_cast<const u32x2 *>(colp + (i + 1) * TW);   // prefetch next row
-            if (i >= R && i < R + Q) { al0[i - R] = t.x; al1[i - R] = t.y; }   // centre rows carry the alpha
+            if constexpr (GUARD) { if (i >= R && i < R + Q) alg[i - R] = t; }
             const v2f f0 = {static_cast<float>(t.x & 0xffu), static_cast<float>((t.x >> 8) & 0xffu)};
             const v2f f1 = {static_cast<float>((t.x >> 16) & 0xffu), static_cast<float>(t.y & 0xffu)};
             const v2f f2 = {static_cast<float>((t.y >> 8) & 0xffu), static_cast<float>((t.y >> 16) & 0xffu)};
@@ -380,16 +382,34 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         u32x2 o[Q];
         uint32_t flagged = 0;                                    // GUARD && SCORE: bit 2j / 2j+1 = o[j].x / .y awaits its recompute
         static_assert(2 * Q <= 32, "flag bits");
+        // The centre rows carry the source alpha in byte 3 (effects.go:215): they are read AGAIN here, as the seeds of
+        // the pack chains, instead of being held through the accumulation -- 2 Q registers less (r3: the kernel fits
+        // 104 VGPRs instead of 128, so that four resident waves per SIMD leave a fifth of the register file to the tail
+        // kernels of the previous step, which then run beside the blur's waves instead of in place of one).  The guarded
+        // variant packs every sample twice and is register-bound elsewhere: it keeps them (re-reading made it spill).
+        u32x2 aln = {0, 0}, aln2 = {0, 0};
+        if constexpr (!GUARD) {
+            aln = *reinterpret_cast<const u32x2 *>(colp + R * TW);
+            aln2 = *reinterpret_cast<const u32x2 *>(colp + (R + 1) * TW);
+        }
         fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < Q; j++) {
-            o[j].x = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al0[j])));
-            o[j].y = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al1[j])));
+            u32x2 al;
+            if constexpr (GUARD) {
+                al = alg[j];
+            } else {
+                al = aln;                                        // two rows ahead: an LDS read is ~64 clocks
+                aln = aln2;
+                if (j + 2 < Q) aln2 = *reinterpret_cast<const u32x2 *>(colp + (j + 2 + R) * TW);
+            }
+            o[j].x = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al.x)));
+            o[j].y = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al.y)));
             if constexpr (GUARD) {
                 const v2f g2 = {2.0f * GUARD_G, 2.0f * GUARD_G};
                 const v2f h0 = acc[j][0] + g2, h1 = acc[j][1] + g2, h2 = acc[j][2] + g2;
-                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, al0[j])));
-                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, al1[j])));
+                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, al.x)));
+                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, al.y)));
                 if (p0 != o[j].x) {
                     const int e = atomicAdd(&s_nfix[1], 1);
                     if (e < FIX_CAP) s_fix[e] = ((rg * Q + j) << 8) | (2 * cp);
@@ -539,55 +559,79 @@ __device__ __forceinline__ uint32_t box_mean_u8(uint32_t n, uint32_t c, uint32_t
     return q;
 }
 
-// One thread per box, both images.  The index arithmetic (box_edge, tile and entry of each part)
-// is per column / per row and comes from host tables: what is left is <= 8 slab loads and the
-// fp64 finish.  Alpha is not produced: both planes only feed toLuminance (ssim.go:207-220).
-__global__ __launch_bounds__(256) void box_from_slabs_kernel(SlabArgs a)
+// One thread per FOUR adjacent boxes of an output row, both images.  The index arithmetic (box_edge, tile and entry
+// of each part) is per column / per row and comes from host tables: what is left is <= 32 slab loads, ALL issued
+// before the first use (parts that do not exist -- seven boxes in eight lie inside one tile -- are not loaded: read
+// unconditionally, 8 loads per box made the kernel address-bound, 61 us alone), and the integer finish.  r3: the kernel runs under the next step's blur, where a wave that waits on memory holds a slot a blur
+// wave wants -- one box per thread was 73.7 k waves of two dependent load levels each per 32-image step (36 us alone,
+// 100-120 us under the blur); four boxes per thread is a quarter of the waves at the same depth.
+// Alpha is not produced: both planes only feed toLuminance (ssim.go:207-220).
+constexpr int BFS_BOXES = 4;
+__global__ __launch_bounds__(256, 5) void box_from_slabs_kernel(SlabArgs a)   // <= 96 VGPRs: fits beside four blur waves per SIMD
 {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * BFS_BOXES;
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= a.dstW || dy >= a.dstH) return;
+    if (dx0 >= a.dstW || dy >= a.dstH) return;
     const int i = blockIdx.z;
-    const BoxRef xr = a.xref[dx], yr = a.yref[dy];
-    const uint32_t cnt = static_cast<uint32_t>(xr.len * yr.len);
-    const uint32_t magic = a.magic[cnt];
-    const unsigned long long *base = a.slabs + a.image_slabs * i;
-    // 2 x u16 per word: the whole box is <= 256 px, so no field overflows.  [0]: source, [1]: blurred
-    uint32_t rg[2], b[2];
+    const BoxRef yr = a.yref[dy];
+    BoxRef xr[BFS_BOXES];
 #pragma unroll
-    for (int img = 0; img < 2; img++) {
-        const unsigned long long v = base[yr.part0 + xr.part0 + img * a.slabn];
-        rg[img] = static_cast<uint32_t>(v);
-        b[img] = static_cast<uint32_t>(v >> 32);
-    }
-    if (xr.part1 >= 0) {
+    for (int j = 0; j < BFS_BOXES; j++) xr[j] = a.xref[dx0 + j < a.dstW ? dx0 + j : a.dstW - 1];
+    const unsigned long long *base = a.slabs + a.image_slabs * i;
+    const bool y2 = yr.part1 >= 0;
+    unsigned long long v[BFS_BOXES][2], vx[BFS_BOXES][2], vy[BFS_BOXES][2];   // [box][0: source, 1: blurred]: part 0; the second tile in x; in y (+ the corner)
+    uint32_t magic[BFS_BOXES], cnt[BFS_BOXES];
+#pragma unroll
+    for (int j = 0; j < BFS_BOXES; j++) {
+        cnt[j] = static_cast<uint32_t>(xr[j].len * yr.len);
+        magic[j] = a.magic[cnt[j]];
 #pragma unroll
         for (int img = 0; img < 2; img++) {
-            const unsigned long long v = base[yr.part0 + xr.part1 + img * a.slabn];
-            rg[img] += static_cast<uint32_t>(v);
-            b[img] += static_cast<uint32_t>(v >> 32);
+            v[j][img] = base[yr.part0 + xr[j].part0 + img * a.slabn];
+            vx[j][img] = vy[j][img] = 0;
         }
     }
-    if (yr.part1 >= 0) {
 #pragma unroll
-        for (int img = 0; img < 2; img++) {
-            unsigned long long v = base[yr.part1 + xr.part0 + img * a.slabn];
-            rg[img] += static_cast<uint32_t>(v);
-            b[img] += static_cast<uint32_t>(v >> 32);
-            if (xr.part1 >= 0) {
-                v = base[yr.part1 + xr.part1 + img * a.slabn];
-                rg[img] += static_cast<uint32_t>(v);
-                b[img] += static_cast<uint32_t>(v >> 32);
+    for (int j = 0; j < BFS_BOXES; j++) {
+        if (xr[j].part1 >= 0) {
+#pragma unroll
+            for (int img = 0; img < 2; img++) vx[j][img] = base[yr.part0 + xr[j].part1 + img * a.slabn];
+        }
+    }
+    if (y2) {                                                    // uniform over the workgroup's row
+#pragma unroll
+        for (int j = 0; j < BFS_BOXES; j++) {
+#pragma unroll
+            for (int img = 0; img < 2; img++) vy[j][img] = base[yr.part1 + xr[j].part0 + img * a.slabn];
+            if (xr[j].part1 >= 0) {
+#pragma unroll
+                for (int img = 0; img < 2; img++) vx[j][img] += base[yr.part1 + xr[j].part1 + img * a.slabn];
             }
         }
     }
-    // clampF(sum * (1.0 / count)) per channel (ssim.go:301-308)
+    // 2 x u16 per word: the whole box is <= 256 px, so no field overflows
+    uint32_t o[2][BFS_BOXES];
+#pragma unroll
+    for (int j = 0; j < BFS_BOXES; j++) {
+#pragma unroll
+        for (int img = 0; img < 2; img++) {
+            const unsigned long long t = v[j][img] + vx[j][img] + vy[j][img];
+            const uint32_t rg = static_cast<uint32_t>(t), b = static_cast<uint32_t>(t >> 32);
+            // clampF(sum * (1.0 / count)) per channel (ssim.go:301-308)
+            o[img][j] = box_mean_u8(rg & 0xffffu, cnt[j], magic[j], a.tiedown) | (box_mean_u8(rg >> 16, cnt[j], magic[j], a.tiedown) << 8) |
+                        (box_mean_u8(b & 0xffffu, cnt[j], magic[j], a.tiedown) << 16);
+        }
+    }
 #pragma unroll
     for (int img = 0; img < 2; img++) {
-        const uint32_t o = box_mean_u8(rg[img] & 0xffffu, cnt, magic, a.tiedown) | (box_mean_u8(rg[img] >> 16, cnt, magic, a.tiedown) << 8) |
-                           (box_mean_u8(b[img] & 0xffffu, cnt, magic, a.tiedown) << 16);
-        *reinterpret_cast<uint32_t *>(a.dst + a.plane * (static_cast<size_t>(img) * a.n + i) +
-                                      (static_cast<size_t>(dy) * a.dstW + dx) * 4) = o;
+        uint8_t *dp = a.dst + a.plane * (static_cast<size_t>(img) * a.n + i) + (static_cast<size_t>(dy) * a.dstW + dx0) * 4;
+        if (dx0 + BFS_BOXES <= a.dstW && !(reinterpret_cast<uintptr_t>(dp) & 15)) {
+            *reinterpret_cast<u32x4 *>(dp) = (u32x4){o[img][0], o[img][1], o[img][2], o[img][3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < BFS_BOXES; j++)
+                if (dx0 + j < a.dstW) reinterpret_cast<uint32_t *>(dp)[j] = o[img][j];
+        }
     }
 }
 
@@ -598,7 +642,14 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
-    FNX_TRY(prof_begin(ctx));
+    // the launch's events ride on its own packet (common.hpp: LaunchEvents): the profile pair when this class is
+    // profiled, and for SCORE launches always a stop event -- the tail on the ctx's second stream waits for it
+    LaunchEvents ev;
+    FNX_TRY(prof_bind(ctx, FNX_PROF_MAIN, &ev));
+    if constexpr (SCORE) {
+        if (!ev.stop) ev.stop = ctx->ev_blur[ctx->parity];
+        ctx->blur_done = ev.stop;
+    }
     if constexpr (SCORE) {
         fa.cstride = (((fa.nbx + 1) * (fa.nby + 1) + 11) / 16) * 16 + 4;
         // LDS left per workgroup at 4 (256 lanes) / 7 (128 lanes) workgroups per CU, next to the uint8
@@ -606,16 +657,15 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
         const size_t budget = (NTH == 256 ? 9600 : 6000) - (GUARD ? sizeof(uint32_t) * guard_fix_cap(true) : 0);
         const size_t per_copy = sizeof(unsigned long long) * fa.cstride;
         if (6 * per_copy <= budget)
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 2, 4, GUARD>), grid, dim3(NTH), 6 * per_copy, ctx->stream, fa);
+            hipExtLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 2, 4, GUARD>), grid, dim3(NTH), 6 * per_copy, ctx->stream, ev.start, ev.stop, 0, fa);
         else if (3 * per_copy <= budget)
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 2, GUARD>), grid, dim3(NTH), 3 * per_copy, ctx->stream, fa);
+            hipExtLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 2, GUARD>), grid, dim3(NTH), 3 * per_copy, ctx->stream, ev.start, ev.stop, 0, fa);
         else
-            hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1, GUARD>), grid, dim3(NTH), 2 * per_copy, ctx->stream, fa);
+            hipExtLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, true, 1, 1, GUARD>), grid, dim3(NTH), 2 * per_copy, ctx->stream, ev.start, ev.stop, 0, fa);
     } else {
-        hipLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false, 1, 1, GUARD>), grid, dim3(NTH), 0, ctx->stream, fa);
+        hipExtLaunchKernelGGL((blur_direct_kernel<R, NTH, IH, false, 1, 1, GUARD>), grid, dim3(NTH), 0, ctx->stream, ev.start, ev.stop, 0, fa);
     }
     FNX_HIP(hipGetLastError());
-    FNX_TRY(prof_end(ctx));
     return FNX_OK;
 }
 
@@ -823,8 +873,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
                          : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
     if (st < 0) return st;
     // the rest of the step runs on the ctx's second stream, behind this blur (api.cpp: one-pass enqueue)
-    FNX_HIP(hipEventRecord(ctx->ev_blur[ctx->parity], ctx->stream));
-    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_blur[ctx->parity], 0));
+    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->blur_done, 0));   // bound to the blur dispatch: no packet on `stream`
     ctx->stream2_used = true;
 
     SlabArgs sa{};
@@ -835,7 +884,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     sa.yref = sa.xref + dstW;
     sa.image_slabs = static_cast<size_t>(tiles) * 2 * slabn;
     sa.n = n; sa.dstW = dstW; sa.dstH = dstH; sa.slabn = slabn;
-    hipLaunchKernelGGL(box_from_slabs_kernel, dim3((dstW + 63) / 64, (dstH + 3) / 4, n), dim3(256), 0,
+    hipLaunchKernelGGL(box_from_slabs_kernel, dim3((dstW + 64 * BFS_BOXES - 1) / (64 * BFS_BOXES), (dstH + 3) / 4, n), dim3(256), 0,
                        ctx->stream2, sa);
     FNX_HIP(hipGetLastError());
     return FNX_OK;

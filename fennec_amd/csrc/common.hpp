@@ -116,7 +116,9 @@ struct fnx_ctx {
     // ev_tail[p] first.  A caller that enqueues step s + 1 before fetching step s gets the tail for free.
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_blur[2] = {}, ev_tail[2] = {};
+    hipEvent_t blur_done = nullptr;     // the stop event BOUND to the last one-pass blur dispatch (launch_direct_cfg)
     bool tail_pending[2] = {false, false};
+    unsigned long long tail_gen[2] = {0, 0};   // uses of each buffer set so far
     int parity = 0;
     int ev_toggle = 0;           // fnx_ssim_enqueue alternates between the two hand-over events
     bool stream2_used = false;
@@ -139,6 +141,8 @@ struct fnx_ctx {
         // exp(sum weights[i] log(max(level i, 1e-10))) (ssim.go:344-352); nraw == 0: the values as they are
         int nraw = 0;
         double weights[5] = {0, 0, 0, 0, 0};
+        int tail_parity = -1;  // one-pass batches: the buffer set (slabs, planes, partials) this batch's tail reads,
+        unsigned long long tail_gen = 0;   // and which use of that set it was
     } res_q[RES_DEPTH];
     int res_head = 0, res_count = 0;
     struct ResBuf {            // pinned home of FIFO position i's results (api.cpp: result_slot_queued)
@@ -204,6 +208,15 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
 // Copy a staged output back (if host) and synchronise when `space` is host.
 int finish(fnx_ctx *ctx, int space, DevOut *out);
 // fnx_ctx_profile hooks: bracket the launch of a profiled kernel (no-ops when profiling is off)
+// Events carried by ONE dispatch (hipExtLaunchKernelGGL's startEvent / stopEvent): they ride on the kernel packet's own
+// completion signal, so neither costs a barrier packet on the stream.  hipEventRecord before and after a launch is two
+// barrier packets, ~6-8 us each on this part: with the cross-stream hand-over event that was a 24 us bubble between
+// consecutive one-pass blur launches (r3 kernel trace).  prof_bind reserves the profile FIFO's next pair when the
+// class is being profiled (nulls otherwise); the launch must then really happen.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+int prof_bind(fnx_ctx *ctx, int cls, LaunchEvents *ev);
 int prof_begin(fnx_ctx *ctx, int cls = FNX_PROF_MAIN);
 int prof_end(fnx_ctx *ctx);
 // Fetch n doubles from device memory into host memory (synchronises).

@@ -123,6 +123,21 @@ int prof_begin(fnx_ctx *ctx, int cls)
     return FNX_OK;
 }
 
+int prof_bind(fnx_ctx *ctx, int cls, LaunchEvents *ev)
+{
+    ev->start = ev->stop = nullptr;
+    if (!(ctx->prof & cls)) return FNX_OK;
+    if (ctx->prof_count == fnx_ctx::PROF_DEPTH) {          // nobody is reading: forget the oldest launch
+        ctx->prof_head = (ctx->prof_head + 1) % fnx_ctx::PROF_DEPTH;
+        ctx->prof_count--;
+    }
+    const int slot = (ctx->prof_head + ctx->prof_count) % fnx_ctx::PROF_DEPTH;
+    ev->start = ctx->prof_ev[slot][0];
+    ev->stop = ctx->prof_ev[slot][1];
+    ctx->prof_count++;
+    return FNX_OK;
+}
+
 int prof_end(fnx_ctx *ctx)
 {
     if (!ctx->prof || ctx->prof_open < 0) return FNX_OK;

@@ -719,7 +719,11 @@ __device__ __forceinline__ void march_finish(const MarchArgs &a, int z, int item
     }
 }
 
-__global__ __launch_bounds__(256) void windowed_ssim_march_kernel(MarchArgs a)
+// SMALL = true: built for <= 96 VGPRs (a few spills: 150 against 148 us per 8K pair when it runs alone).  The one-pass
+// GaussianBlur + SSIMFast step launches it as its tail, under the NEXT step's blur, whose four waves per SIMD leave
+// 96 registers free: a wave of this size becomes resident BESIDE them, a 124-register one only in place of one.
+template <bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 5 : 1) void windowed_ssim_march_kernel(MarchArgs a)
 {
     // per wave: [0, WM_LDSW) (a, b) pairs, [WM_LDSW, 2 WM_LDSW) (a^2 + b^2, ab) pairs
     __shared__ __attribute__((aligned(16))) double2 s_row[4][2 * WM_LDSW];
@@ -1075,7 +1079,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         ma.prio = prio;
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
         if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
-        else hipLaunchKernelGGL(windowed_ssim_march_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        else if (ctx->partial_slot >= 0) hipLaunchKernelGGL(windowed_ssim_march_kernel<true>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        else hipLaunchKernelGGL(windowed_ssim_march_kernel<false>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         FNX_HIP(hipGetLastError());
         FNX_TRY(prof_end(ctx));
     } else if (sep) {
