@@ -67,7 +67,8 @@ class ImageStats(C.Structure):
 class NativeBatchResult(C.Structure):
     """fennec_BatchResult (include/fennec_hip.h)."""
     _fields_ = [("index", C.c_int32), ("failed", C.c_int32), ("has_result", C.c_int32), ("quality", C.c_int32), ("steps", C.c_int32),
-                ("status", C.c_int32), ("original_size", C.c_int64), ("compressed_size", C.c_int64), ("ssim", C.c_double)]
+                ("status", C.c_int32), ("original_size", C.c_int64), ("compressed_size", C.c_int64), ("ssim", C.c_double),
+                ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
 FNX_ERR_INVALID = -1
@@ -123,6 +124,7 @@ def load_library() -> C.CDLL:
         img = [_u8p, i]                                   # pointer, stride
         _sig(L, "fnx_version", C.c_char_p, [])
         _sig(L, "fnx_device_count", i, [])
+        _sig(L, "fnx_set_devices", i, [C.POINTER(C.c_int), i])
         _sig(L, "fnx_last_error", C.c_char_p, [])
         _sig(L, "fnx_ctx_create", i, [i, C.POINTER(ctx)])
         _sig(L, "fnx_ctx_destroy", None, [ctx])
@@ -166,6 +168,12 @@ def load_library() -> C.CDLL:
                                                   C.c_void_p, C.c_void_p])
         _sig(L, "fennec_CompressBatchJPEG", i, [i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), d, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i), C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_CompressBatchNRGBADevices", i, [C.POINTER(i), i, i, i, i, C.POINTER(C.c_void_p), C.POINTER(i), C.POINTER(i), C.POINTER(i),
+                                                         _i64p, d, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult),
+                                                         C.POINTER(i), C.c_void_p, C.c_void_p])
+        _sig(L, "fennec_CompressBatchJPEGDevices", i, [C.POINTER(i), i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), d,
+                                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(NativeBatchResult), C.POINTER(i),
+                                                        C.c_void_p, C.c_void_p])
         _sig(L, "fennec_CompressFileJPEG", i, [ctx, _u8p, C.c_size_t, C.POINTER(FileOptions), _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i),
                                                 _f64p, C.POINTER(i), C.POINTER(i)])
         _sig(L, "fennec_CompressBatchJPEGOpts", i, [i, i, i, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(FileOptions),

@@ -369,12 +369,23 @@ def summarize_distributed(results: Sequence[BatchResult], device=None, group=Non
     return out
 
 
+def _device_list(device, devices):
+    import ctypes as C
+    devs = [int(d) for d in devices] if devices is not None else [int(device)]
+    if not devs:
+        raise ValueError("empty device list")
+    return (C.c_int * len(devs))(*devs), len(devs)
+
+
 def compress_batch_native(images: Sequence, target_ssim: float = TARGET_SSIM["Balanced"], workers: int = 4, device: int = 0,
-                          original_sizes: Optional[Sequence[int]] = None):
-    """fennec_CompressBatchNRGBA: CompressBatch's pool in C++ (std::thread workers, one fnx ctx each, one atomic queue of
-    indices) with compressJPEGOptimal on the device as the per-item work.  `images`: decoded NRGBA items, all numpy
-    (host space) or all torch CUDA tensors (device space).  -> (results, files, summary): BatchResult per item by index,
-    the JPEG bytes per item, BatchSummary."""
+                          original_sizes: Optional[Sequence[int]] = None, devices: Optional[Sequence[int]] = None):
+    """fennec_CompressBatchNRGBA(Devices): CompressBatch's pool in C++ (std::thread workers, one fnx ctx each, one atomic
+    queue of indices) with compressJPEGOptimal on the device as the per-item work.  `images`: decoded NRGBA items, all
+    numpy (host space) or all torch CUDA tensors (device space).  `devices`: the node's pool -- worker i on
+    devices[i mod g], one queue (batch.go:63-126); host-space items only when the list names more than one device.
+    -> (results, files, summary): BatchResult per item by index (with .device), the JPEG bytes per item, BatchSummary.
+    An item whose file outgrows its buffer (a q=100 fallback, a noisy photograph: > 1.5 B/px) is run again with a
+    buffer of the size the library reported -- the reference never fails an item on output size."""
     import ctypes as C
 
     import fennec_amd as fa
@@ -382,6 +393,7 @@ def compress_batch_native(images: Sequence, target_ssim: float = TARGET_SSIM["Ba
     n = len(images)
     if n == 0:
         return [], [], BatchSummary()
+    devs, ndev = _device_list(device, devices)
     views = [fa._Img(im) for im in images]
     space = views[0].space
     if any(v.space != space for v in views):
@@ -398,16 +410,28 @@ def compress_batch_native(images: Sequence, target_ssim: float = TARGET_SSIM["Ba
     if space == fa.FNX_DEVICE:
         import torch
         torch.cuda.synchronize()                       # the workers' contexts launch on their own streams
-    rc = L.fennec_CompressBatchNRGBA(int(device), int(workers), n, space, srcs, strides, ws, hs, osz, float(target_ssim), outs, caps, res,
-                                     None, None, None)
+    rc = L.fennec_CompressBatchNRGBADevices(devs, ndev, int(workers), n, space, srcs, strides, ws, hs, osz, float(target_ssim), outs, caps,
+                                            res, None, None, None)
     if rc != fa.FNX_OK:
         raise fa.FennecError(f"fennec_CompressBatchNRGBA: {L.fnx_last_error().decode()}")
+    for i in range(n):                                 # the file did not fit: once more with the size the library reported
+        if res[i].failed and res[i].status == fa.FNX_ERR_INVALID and int(res[i].compressed_size) > bufs[i].size:
+            big = np.empty(int(res[i].compressed_size) + 4096, dtype=np.uint8)
+            one = (fa.NativeBatchResult * 1)()
+            one_osz = (C.c_int64 * 1)(int(original_sizes[i])) if original_sizes is not None else None
+            L.fennec_CompressBatchNRGBADevices(devs, ndev, 1, 1, space, (C.c_void_p * 1)(views[i].ptr), (C.c_int * 1)(views[i].stride),
+                                               (C.c_int * 1)(views[i].w), (C.c_int * 1)(views[i].h), one_osz, float(target_ssim),
+                                               (C.c_void_p * 1)(big.ctypes.data), (C.c_size_t * 1)(big.size), one, None, None, None)
+            one[0].index = i
+            res[i] = one[0]
+            bufs[i] = big
     results, files = [], []
     for i in range(n):
         r = res[i]
         br = BatchResult(Index=r.index, OriginalSize=int(r.original_size), CompressedSize=int(r.compressed_size), SSIM=float(r.ssim),
                          Quality=int(r.quality), Err=None if not r.failed else f"status {r.status}", has_result=bool(r.has_result))
         br.steps = int(r.steps)
+        br.device = int(r.device)
         results.append(br)
         files.append(bufs[i][:int(r.compressed_size)].tobytes() if not r.failed else b"")
     out4 = (C.c_int64 * 4)()
@@ -420,7 +444,7 @@ _out_arena = None      # compress_batch_jpeg_native's output pages (not thread-s
 
 
 def compress_batch_jpeg_native(files: Sequence[bytes], target_ssim: float = TARGET_SSIM["Balanced"], workers: int = 4, device: int = 0,
-                               decode: Callable[[bytes], np.ndarray] = pillow_decode):
+                               decode: Callable[[bytes], np.ndarray] = pillow_decode, devices: Optional[Sequence[int]] = None):
     """fennec_CompressBatchJPEG: CompressBatch over JPEG FILES (batch.go:88-122) with no host codec -- the C++ pool, per
     item decoder + quality search + encoder on the device (fnx_jpeg_recompress).  Items the device decoder refuses
     (status FNX_ERR_UNSUPPORTED) are decoded on the host HERE and sent through fennec_CompressBatchNRGBA; their results
@@ -447,15 +471,16 @@ def compress_batch_jpeg_native(files: Sequence[bytes], target_ssim: float = TARG
     outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
     caps = (C.c_size_t * n)(*capl)
     res = (fa.NativeBatchResult * n)()
-    rc = L.fennec_CompressBatchJPEG(int(device), int(workers), n, srcs, sizes, float(target_ssim), outs, caps, res, None, None, None)
+    devs, ndev = _device_list(device, devices)
+    rc = L.fennec_CompressBatchJPEGDevices(devs, ndev, int(workers), n, srcs, sizes, float(target_ssim), outs, caps, res, None, None, None)
     if rc != fa.FNX_OK:
         raise fa.FennecError(f"fennec_CompressBatchJPEG: {L.fnx_last_error().decode()}")
     for i in range(n):
         if res[i].failed and res[i].status == fa.FNX_ERR_INVALID and int(res[i].compressed_size) > capl[i]:
             big = np.empty(int(res[i].compressed_size), dtype=np.uint8)
             one = (fa.NativeBatchResult * 1)()
-            L.fennec_CompressBatchJPEG(int(device), 1, 1, (C.c_void_p * 1)(arrs[i].ctypes.data), (C.c_size_t * 1)(len(files[i])),
-                                       float(target_ssim), (C.c_void_p * 1)(big.ctypes.data), (C.c_size_t * 1)(big.size), one, None, None, None)
+            L.fennec_CompressBatchJPEGDevices(devs, ndev, 1, 1, (C.c_void_p * 1)(arrs[i].ctypes.data), (C.c_size_t * 1)(len(files[i])),
+                                              float(target_ssim), (C.c_void_p * 1)(big.ctypes.data), (C.c_size_t * 1)(big.size), one, None, None, None)
             one[0].index = i
             res[i] = one[0]
             bufs[i] = big
@@ -466,15 +491,26 @@ def compress_batch_jpeg_native(files: Sequence[bytes], target_ssim: float = TARG
                          Quality=int(r.quality), Err=None if not r.failed else f"status {r.status}", has_result=bool(r.has_result))
         br.steps = int(r.steps)
         br.host_decoded = False
+        br.device = int(r.device)
         results.append(br)
         out_files.append(bufs[i][:int(r.compressed_size)].tobytes() if not r.failed else b"")
     # the caller's side of FNX_ERR_UNSUPPORTED: host decode, then the NRGBA pool
     redo = [i for i in range(n) if res[i].failed and res[i].status in (fa.FNX_ERR_UNSUPPORTED, fa.FNX_ERR_INVALID)]
     if redo:
-        r2, f2, _ = compress_batch_native([decode(files[i]) for i in redo], target_ssim, workers=workers, device=device,
-                                          original_sizes=[len(files[i]) for i in redo])
-        for k, i in enumerate(redo):
-            r2[k].Index = i
-            r2[k].host_decoded = True
-            results[i], out_files[i] = r2[k], f2[k]
+        decoded, ok = [], []
+        for i in redo:                                 # batch.go:108-113: a file nobody can decode is THAT item's error, not the batch's
+            try:
+                decoded.append(decode(files[i]))
+                ok.append(i)
+            except Exception as e:
+                results[i] = BatchResult(Index=i, OriginalSize=len(files[i]), Err=f"{type(e).__name__}: {e}", has_result=False)
+                results[i].host_decoded = True
+                out_files[i] = b""
+        if ok:
+            r2, f2, _ = compress_batch_native(decoded, target_ssim, workers=workers, device=device, devices=devices,
+                                              original_sizes=[len(files[i]) for i in ok])
+            for k, i in enumerate(ok):
+                r2[k].Index = i
+                r2[k].host_decoded = True
+                results[i], out_files[i] = r2[k], f2[k]
     return results, out_files, summarize_local(results)

@@ -207,7 +207,7 @@ namespace fnx {
 int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
                           const TapTable &th, const TapTable &tv, uint8_t *dst, int dstride, int dstW, int dstH)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
@@ -245,7 +245,7 @@ extern "C" {
 int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                       const double *kernel, int radius, int flags, uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(kernel != nullptr && radius >= 0, "blur kernel");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -264,7 +264,7 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
                             int h, const double *kernel, int radius, int flags,
                             uint8_t *const *dsts, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0, "batch arguments");
     if (n == 0 || w <= 0 || h <= 0) return FNX_OK;
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
@@ -289,7 +289,7 @@ static int stage_fx_src(fnx_ctx *ctx, int space, const uint8_t *src, int sstride
 int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                 uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
@@ -305,7 +305,7 @@ int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
 static int sharpen_common(fnx_ctx *ctx, bool adaptive, int space, const uint8_t *src, int sstride,
                           int w, int h, double amount, uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(w >= 3 && h >= 3, "sharpen needs w,h >= 3 (the reference returns the input below that)");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -335,7 +335,7 @@ int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
                  const int32_t *offset, const int32_t *index, const double *weight,
                  uint8_t *dst, int dstride, int dstW)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstW > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
@@ -353,7 +353,7 @@ int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
                  const int32_t *offset, const int32_t *index, const double *weight,
                  uint8_t *dst, int dstride, int dstH)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstH > 0, "dims");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
@@ -380,7 +380,7 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
 int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
                        int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // ssim.go:246-248
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
@@ -396,7 +396,7 @@ int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
 int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                   int bstride, int w, int h, const double *window, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(window && out, "window/out is null");
     FNX_TRY(check_img(a, astride, w, h, "a"));
@@ -436,7 +436,7 @@ int fnx_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *as, int astri
 
 int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && out, "fetch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(ctx->res_count > 0 && n <= ctx->res_q[ctx->res_head].n, "no enqueued results of that size on this ctx");
@@ -460,7 +460,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
                                 const uint8_t *const *bs, int bstride, int w, int h,
                                 const double *window)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && as && bs && window, "batch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0 && astride >= 4 * w && bstride >= 4 * w, "dims");
@@ -495,7 +495,7 @@ int fnx_gaussian_blur_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t
                                               int w, int h, const double *kernel, int radius, int flags,
                                               uint8_t *const *dsts, int dstride, const double *window)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0 && window, "batch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0, "dims");
@@ -572,7 +572,7 @@ int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const 
 int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
              int bstride, int w, int h, const double *window, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(window && out, "window/out is null");
     FNX_TRY(check_img(a, astride, w, h, "a"));
@@ -606,7 +606,7 @@ int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8
 int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                      const double *window)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(window != nullptr && w > 0 && h > 0, "enqueue arguments");
     FNX_TRY(check_img(a, astride, w, h, "a"));
     FNX_TRY(check_img(b, bstride, w, h, "b"));
@@ -710,7 +710,7 @@ static int msssim_levels_device(fnx_ctx *ctx, const uint8_t *ap, int astride, co
 int fnx_pixel_ssim(fnx_ctx *ctx, int space, const uint8_t *a_pix, size_t a_pix_len, const uint8_t *b_pix,
                    size_t b_pix_len, int w, int h, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(out != nullptr && w >= 0 && h >= 0, "pixel_ssim arguments");
     if (static_cast<long long>(w) * h == 0) {      // ssim.go:172-175
@@ -742,7 +742,7 @@ int fnx_pixel_ssim(fnx_ctx *ctx, int space, const uint8_t *a_pix, size_t a_pix_l
 int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                int bstride, int w, int h, const double *window, double *out, double *per_level)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(window && out, "window/out is null");
     FNX_TRY(check_img(a, astride, w, h, "a"));
@@ -776,7 +776,7 @@ int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uin
 int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                        const double *window)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(window != nullptr && w > 0 && h > 0, "enqueue arguments");
     FNX_TRY(check_img(a, astride, w, h, "a"));
     FNX_TRY(check_img(b, bstride, w, h, "b"));
@@ -798,7 +798,7 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
 int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int w, int h,
                           fnx_prepared **out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(out != nullptr && w > 0 && h > 0, "prepare arguments");
     FNX_TRY(check_img(a, astride, w, h, "a"));
@@ -873,7 +873,7 @@ static int against_device(fnx_ctx *ctx, const fnx_prepared *ref, const uint8_t *
 int fnx_ssim_fast_against(fnx_ctx *ctx, const fnx_prepared *ref, int space, const uint8_t *b,
                           int bstride, const double *window, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(ref && window && out, "against arguments");
     FNX_TRY(check_img(b, bstride, ref->w, ref->h, "b"));
@@ -934,7 +934,7 @@ static int ycbcr_stage_convert(fnx_ctx *ctx, int space, const uint8_t *y, int ys
 int fnx_ycbcr_to_nrgba(fnx_ctx *ctx, int space, const uint8_t *y, int ystride, const uint8_t *cb,
                        const uint8_t *cr, int cstride, int ratio, int w, int h, uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     if (w <= 0 || h <= 0) return FNX_OK;
@@ -948,7 +948,7 @@ int fnx_ssim_fast_against_ycbcr(fnx_ctx *ctx, const fnx_prepared *ref, int space
                                 const uint8_t *cb, const uint8_t *cr, int cstride, int ratio,
                                 const double *window, double *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(ref && window && out, "against arguments");
     const int w = ref->w, h = ref->h;
@@ -994,7 +994,7 @@ int jpeg_decode_at(fnx_ctx *ctx, const JpegPlanes &orig, int w, int h, int quali
 int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality,
                        uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
@@ -1058,7 +1058,7 @@ static int jpeg_search_device(fnx_ctx *ctx, const DevImg &s, const JpegPlanes &o
 int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim,
                             const double *window, int *quality, double *ssim, int *steps)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(window && quality && ssim && w > 0 && h > 0, "search arguments");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -1108,7 +1108,7 @@ static int jpeg_file_from_planes(fnx_ctx *ctx, const JpegPlanes &orig, int w, in
 int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int quality, uint8_t *out, size_t cap,
                     size_t *nbytes)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(nbytes != nullptr && w > 0 && h > 0 && w <= 65535 && h <= 65535, "encode arguments (JPEG dims are 16-bit)");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -1124,7 +1124,7 @@ int fnx_jpeg_encode(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, in
 int fnx_jpeg_size_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, long long target_bytes, int skip_ssim,
                          const double *window, uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(nbytes && quality && ssim && (skip_ssim || window) && w > 0 && h > 0 && w <= 65535 && h <= 65535, "size search arguments");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -1180,7 +1180,7 @@ int fnx_jpeg_size_search(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
 int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, double target_ssim, const double *window,
                       uint8_t *out, size_t cap, size_t *nbytes, int *quality, double *ssim, int *steps)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(window && nbytes && quality && ssim && w > 0 && h > 0 && w <= 65535 && h <= 65535, "compress arguments");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -1219,7 +1219,7 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
         *w = f.w; *h = f.h;
         return FNX_OK;
     }
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_TRY(jpeg_parse(data, n, &f));
     *w = f.w; *h = f.h;
@@ -1237,7 +1237,7 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
 int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double target_ssim, const double *window, uint8_t *out, size_t cap,
                         size_t *nbytes, int *quality, double *ssim, int *steps, int *w, int *h)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(data && window && nbytes && quality && ssim && w && h, "recompress arguments");
     *nbytes = 0;
     JpegFile f;
@@ -1273,7 +1273,7 @@ static void clamp_unique(fnx_analysis *a, int n)
 
 int fnx_analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, fnx_analysis *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(out != nullptr, "out is null");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
@@ -1293,7 +1293,7 @@ int fnx_analyze(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
 int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
                       fnx_analysis *out)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && srcs && out, "batch arguments");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w > 0 && h > 0 && sstride >= 4 * w && !(sstride & 3), "dims");
@@ -1315,7 +1315,7 @@ int fnx_analyze_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstri
 
 int fnx_scan_flags(fnx_ctx *ctx, int space, const uint8_t *pix, size_t pix_len, int *is_opaque, int *is_grayscale)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(pix != nullptr || pix_len == 0, "pix is null");
     uint32_t flags = 0;
@@ -1342,7 +1342,7 @@ int fnx_apply_palette(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
                       const uint8_t *palette, int ncolors, uint8_t *indices, int istride,
                       uint8_t *quantized, int qstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space(space));
     FNX_REQUIRE(palette != nullptr && ncolors >= 1 && ncolors <= 256, "palette: 1..256 colours (image.Paletted indices are uint8)");
     for (int i = 0; i < ncolors; i++)
@@ -1377,7 +1377,7 @@ int fnx_apply_palette(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
 int fnx_orient(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, int orient,
                uint8_t *dst, int dstride)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     if (orient < 2 || orient > 8) return FNX_NOOP;   // exif.go:180-181,200-201
     const bool swap = orient >= 5;

@@ -107,7 +107,8 @@ struct TapTable {
 struct fnx_resize_plan;   // resize.hip: device tables of one (tap table, direction)
 
 struct fnx_ctx {
-    int device = 0;
+    int device = 0;             // HIP device ordinal
+    int logical_device = 0;     // its index in this library's device list (fnx_set_devices / FENNEC_HIP_DEVICES)
     hipStream_t stream = nullptr;       // where the ctx launches: its own stream, or one lent by the caller (fnx_ctx_use_stream)
     hipStream_t own_stream = nullptr;   // created with the ctx, destroyed with it
     hipEvent_t ev_switch = nullptr;
@@ -167,6 +168,19 @@ struct fnx_prepared {
 namespace fnx {
 
 int bind(fnx_ctx *ctx);
+// roctx range around an exported op (runtime.cpp: FNX_ROCTX=1 turns them on; off they cost a load and a branch)
+class OpRange {
+public:
+    explicit OpRange(const char *name);
+    ~OpRange();
+    OpRange(const OpRange &) = delete;
+    OpRange &operator=(const OpRange &) = delete;
+private:
+    bool on_;
+};
+#define FNX_ENTER(ctx)                  \
+    fnx::OpRange fnx_op_range_(__func__); \
+    FNX_TRY(bind(ctx))
 // Device scratch of at least `bytes` in `slot` (contents undefined).
 int scratch(fnx_ctx *ctx, Slot slot, size_t bytes, void **out);
 // Pinned host bytes valid until the next fnx call on this ctx wraps the ring.

@@ -204,7 +204,7 @@ int fennec_SSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, 
                 const uint8_t *b, int bstride, int bw, int bh, double *out)
 {
     if (aw == bw && ah == bh) return fnx_ssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out);
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     if (space != FNX_HOST && space != FNX_DEVICE) {
         set_error("invalid argument: space must be FNX_HOST or FNX_DEVICE");
         return FNX_ERR_INVALID;
@@ -236,7 +236,7 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
 {
     if (aw == bw && ah == bh)
         return fnx_msssim(ctx, space, a, astride, b, bstride, aw, ah, ssim_window(), out, nullptr);
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     if (space != FNX_HOST && space != FNX_DEVICE) {
         set_error("invalid argument: space must be FNX_HOST or FNX_DEVICE");
         return FNX_ERR_INVALID;
@@ -259,7 +259,7 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
 int fennec_MSSSIM_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, int aw, int ah, const uint8_t *b, int bstride,
                           int bw, int bh)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     if (aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0) {
         set_error("invalid argument: MSSSIM_enqueue takes non-empty device images");
         return FNX_ERR_INVALID;
@@ -457,10 +457,16 @@ int fennec_CompressFileJPEG(fnx_ctx *ctx, const uint8_t *data, size_t n, const f
 }  // extern "C"
 
 // The pool of batch.go:58-128: `workers` threads over ONE closed queue of indices; item(ctx, idx, &result) does the work.
+// A device LIST makes it the node's pool: workers = g x k goroutines' worth of threads, worker i bound to a
+// context on devices[i mod g], still ONE queue -- a GPU whose items are cheaper simply takes more of them.
 template <typename Item>
-static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *results, const volatile int *cancel, fennec_on_item on_item,
-                          void *user, Item item)
+static int run_batch_pool(const int *devices, int ndev, int workers, int n, fennec_BatchResult *results, const volatile int *cancel,
+                          fennec_on_item on_item, void *user, Item item)
 {
+    if (!devices || ndev <= 0) {
+        set_error("invalid argument: CompressBatch needs at least one device");
+        return FNX_ERR_INVALID;
+    }
     if (workers <= 0) workers = static_cast<int>(std::thread::hardware_concurrency());      // batch.go:63-66
     if (workers <= 0) workers = 1;
     if (workers > n) workers = n;                                // batch.go:67-69
@@ -469,6 +475,7 @@ static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *re
         results[i].index = i;
         results[i].failed = 1;                                   // until a worker says otherwise
         results[i].status = FNX_ERR_INVALID;
+        results[i].device = -1;
     }
     std::atomic<int> next{0}, started{0};
     std::mutex done_mu;
@@ -476,7 +483,8 @@ static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *re
     const char *tr = std::getenv("FNX_POOL_TRACE");              // per-item wall times on stderr
     const bool trace = tr && tr[0] == '1';
     const auto t_batch = std::chrono::steady_clock::now();
-    auto worker = [&]() {
+    auto worker = [&](int wid) {
+        const int device = devices[wid % ndev];
         fnx_ctx *ctx = pool_take(device);
         if (!ctx) return;
         started.fetch_add(1);
@@ -502,13 +510,20 @@ static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *re
         pool_give(device, ctx);
     };
     std::vector<std::thread> pool;
-    for (int w = 0; w < workers; w++) pool.emplace_back(worker);
+    for (int w = 0; w < workers; w++) pool.emplace_back(worker, w);
     for (auto &t : pool) t.join();
     if (started.load() == 0) {
-        set_error("CompressBatch: no worker could create a context on device %d", device);
+        set_error("CompressBatch: no worker could create a context on any of the %d listed devices (first: %d)", ndev, devices[0]);
         return FNX_ERR_HIP;
     }
     return FNX_OK;
+}
+
+template <typename Item>
+static int run_batch_pool(int device, int workers, int n, fennec_BatchResult *results, const volatile int *cancel, fennec_on_item on_item,
+                          void *user, Item item)
+{
+    return run_batch_pool(&device, 1, workers, n, results, cancel, on_item, user, item);
 }
 
 extern "C" {
@@ -518,12 +533,29 @@ int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const u
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
                               fennec_on_item on_item, void *user)
 {
+    return fennec_CompressBatchNRGBADevices(&device, 1, workers, n, space, srcs, strides, widths, heights, original_sizes, target_ssim, outs,
+                                            caps, results, cancel, on_item, user);
+}
+
+int fennec_CompressBatchNRGBADevices(const int *devices, int ndev, int workers, int n, int space, const uint8_t *const *srcs,
+                                     const int *strides, const int *widths, const int *heights, const int64_t *original_sizes,
+                                     double target_ssim, uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                                     const volatile int *cancel, fennec_on_item on_item, void *user)
+{
     if (n <= 0) return FNX_OK;                                   // batch.go:59-61
     if (!srcs || !strides || !widths || !heights || !outs || !caps || !results) {
         set_error("invalid argument: CompressBatch arrays");
         return FNX_ERR_INVALID;
     }
-    return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+    if (space != FNX_HOST && devices && ndev > 1) {
+        for (int i = 1; i < ndev; i++)
+            if (devices[i] != devices[0]) {
+                set_error("invalid argument: device-resident items live on ONE device; a device list takes host-space items");
+                return FNX_ERR_INVALID;
+            }
+    }
+    return run_batch_pool(devices, ndev, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        r.device = fnx_ctx_device(ctx);
         size_t nbytes = 0;
         int q = 0, steps = 0;
         double s = 0;
@@ -542,12 +574,20 @@ int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *cons
                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results, const volatile int *cancel,
                              fennec_on_item on_item, void *user)
 {
+    return fennec_CompressBatchJPEGDevices(&device, 1, workers, n, files, sizes, target_ssim, outs, caps, results, cancel, on_item, user);
+}
+
+int fennec_CompressBatchJPEGDevices(const int *devices, int ndev, int workers, int n, const uint8_t *const *files, const size_t *sizes,
+                                    double target_ssim, uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                                    const volatile int *cancel, fennec_on_item on_item, void *user)
+{
     if (n <= 0) return FNX_OK;                                   // batch.go:59-61
     if (!files || !sizes || !outs || !caps || !results) {
         set_error("invalid argument: CompressBatch arrays");
         return FNX_ERR_INVALID;
     }
-    return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+    return run_batch_pool(devices, ndev, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        r.device = fnx_ctx_device(ctx);
         size_t nbytes = 0;
         int q = 0, steps = 0, w = 0, h = 0;
         double s = 0;
@@ -573,6 +613,7 @@ int fennec_CompressBatchJPEGOpts(int device, int workers, int n, const uint8_t *
         return FNX_ERR_INVALID;
     }
     return run_batch_pool(device, workers, n, results, cancel, on_item, user, [&](fnx_ctx *ctx, int idx, fennec_BatchResult &r) {
+        r.device = fnx_ctx_device(ctx);
         const fennec_FileOptions &o = item_opts && item_opts[idx] ? *item_opts[idx] : *default_opts;      // batch.go:101-105
         size_t nbytes = 0;
         int q = 0, steps = 0, d4[4] = {0, 0, 0, 0};

@@ -1,9 +1,102 @@
 // Context, device memory, staging: the runtime under every fnx_* entry point.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace fnx {
+
+// ---- which devices the library uses ("one env var / option to force CPU or pick devices") ----------
+// Logical device i of this library = HIP device devmap[i].  Default: every HIP device, in order.  FENNEC_HIP_DEVICES
+// ("0,2,3") picks and orders them, FENNEC_HIP_DISABLE=1 leaves none -- fnx_device_count() is then 0 and fnx_ctx_create
+// returns FNX_ERR_NO_DEVICE, which is what sends the cgo shim (and any caller that honours the status) to its own CPU
+// path; the library itself still has none.  fnx_set_devices() does the same from code and wins over the environment.
+namespace {
+std::mutex g_dev_mu;
+bool g_dev_set = false;
+std::vector<int> g_devmap;
+
+int hip_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void devmap_init_locked()
+{
+    if (g_dev_set) return;
+    g_dev_set = true;
+    g_devmap.clear();
+    const char *off = std::getenv("FENNEC_HIP_DISABLE");
+    if (off && off[0] && off[0] != '0') return;
+    const int n = hip_device_count();
+    const char *pick = std::getenv("FENNEC_HIP_DEVICES");
+    if (pick && pick[0]) {
+        const char *p = pick;
+        while (*p) {
+            char *end = nullptr;
+            const long d = std::strtol(p, &end, 10);
+            if (end == p) break;
+            if (d >= 0 && d < n) g_devmap.push_back(static_cast<int>(d));
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+        return;
+    }
+    for (int i = 0; i < n; i++) g_devmap.push_back(i);
+}
+
+// roctx ranges per exported op, opt-in: FNX_ROCTX=1 resolves roctxRangePushA / roctxRangePop from
+// the ROCm tracing library at first use (no link-time dependency); off, a range is one relaxed load and a branch.
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)();
+std::atomic<int> g_roctx_state{0};        // 0: not looked at, 1: on, 2: off
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+
+bool roctx_on()
+{
+    int st = g_roctx_state.load(std::memory_order_acquire);
+    if (st == 0) {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        st = g_roctx_state.load(std::memory_order_relaxed);
+        if (st == 0) {
+            st = 2;
+            const char *e = std::getenv("FNX_ROCTX");
+            if (e && e[0] == '1') {
+                for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+                    void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+                    if (!h) continue;
+                    g_roctx_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+                    g_roctx_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+                    if (g_roctx_push && g_roctx_pop) { st = 1; break; }
+                }
+            }
+            g_roctx_state.store(st, std::memory_order_release);
+        }
+    }
+    return st == 1;
+}
+}  // namespace
+
+OpRange::OpRange(const char *name) : on_(roctx_on())
+{
+    if (on_) g_roctx_push(name);
+}
+OpRange::~OpRange()
+{
+    if (on_) g_roctx_pop();
+}
 
 static thread_local char g_err[512] = "";
 
@@ -254,12 +347,32 @@ const char *fnx_version(void) { return "fennec-hip 0.1 (gfx950)"; }
 
 int fnx_device_count(void)
 {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) {
-        (void)hipGetLastError();
-        return 0;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    devmap_init_locked();
+    return static_cast<int>(g_devmap.size());
+}
+
+int fnx_set_devices(const int *devices, int n)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (n < 0 || (n > 0 && !devices)) {
+        if (n < 0 && !devices) {               // (NULL, -1): back to the environment / every device
+            g_dev_set = false;
+            devmap_init_locked();
+            return FNX_OK;
+        }
+        set_error("invalid argument: fnx_set_devices");
+        return FNX_ERR_INVALID;
     }
-    return n;
+    const int have = hip_device_count();
+    for (int i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= have) {
+            set_error("invalid argument: fnx_set_devices names HIP device %d of %d", devices[i], have);
+            return FNX_ERR_INVALID;
+        }
+    g_dev_set = true;
+    g_devmap.assign(devices, devices + n);
+    return FNX_OK;
 }
 
 const char *fnx_last_error(void) { return g_err; }
@@ -274,9 +387,16 @@ int fnx_ctx_create(int device, fnx_ctx **out)
         return FNX_ERR_NO_DEVICE;
     }
     FNX_REQUIRE(device >= 0 && device < n, "device index out of range");
-    FNX_HIP(hipSetDevice(device));
+    int phys;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        FNX_REQUIRE(device < static_cast<int>(g_devmap.size()), "device index out of range");
+        phys = g_devmap[static_cast<size_t>(device)];
+    }
+    FNX_HIP(hipSetDevice(phys));
     fnx_ctx *c = new fnx_ctx();
-    c->device = device;
+    c->device = phys;
+    c->logical_device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -305,7 +425,7 @@ int fnx_ctx_create(int device, fnx_ctx **out)
         }
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, phys) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     *out = c;
     return FNX_OK;
 }
@@ -338,7 +458,7 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
     delete ctx;
 }
 
-int fnx_ctx_device(const fnx_ctx *ctx) { return ctx ? ctx->device : -1; }
+int fnx_ctx_device(const fnx_ctx *ctx) { return ctx ? ctx->logical_device : -1; }
 
 int fnx_ctx_profile(fnx_ctx *ctx, int enable)
 {

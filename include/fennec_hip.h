@@ -80,8 +80,14 @@ typedef struct fnx_prepared fnx_prepared;
 
 /* ---- runtime ---------------------------------------------------------- */
 const char *fnx_version(void);
-/* Number of usable HIP devices (0 when there is none / no driver). */
+/* Number of devices this library uses (0 when there is none / no driver / switched off).  Default: every HIP device.
+ * Environment, read once: FENNEC_HIP_DEVICES="0,2,3" picks and orders HIP ordinals (device index i below is then the
+ * i-th of them), FENNEC_HIP_DISABLE=1 leaves none -- fnx_ctx_create then returns FNX_ERR_NO_DEVICE, the status on
+ * which the cgo shim runs the reference's own Go bodies ("force CPU or pick devices"). */
 int fnx_device_count(void);
+/* The same choice from code (wins over the environment): the n HIP ordinals to use, in order; n == 0: none (force
+ * off); (NULL, -1): back to the environment's / every device.  Contexts that exist keep their device. */
+int fnx_set_devices(const int *hip_ordinals, int n);
 /* Thread-local text of the last error returned on this thread. */
 const char *fnx_last_error(void);
 int fnx_ctx_create(int device, fnx_ctx **out);
@@ -437,12 +443,22 @@ typedef struct fennec_BatchResult {
     int32_t index, failed, has_result, quality, steps, status;
     int64_t original_size, compressed_size;
     double ssim;
+    int32_t device;      /* index (in this library's device list) of the device whose worker took the item; -1: nobody did */
+    int32_t reserved;
 } fennec_BatchResult;
 typedef void (*fennec_on_item)(int completed, int total, void *user);
 int fennec_CompressBatchNRGBA(int device, int workers, int n, int space, const uint8_t *const *srcs, const int *strides,
                               const int *widths, const int *heights, const int64_t *original_sizes, double target_ssim,
                               uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                               const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* The same pool over the NODE's devices (batch.go:63-126 with g GPUs): `workers` threads (0: NumCPU, capped at
+ * n), worker i bound to a context on devices[i mod ndev], ONE queue of indices for all of them, results by index with the
+ * device that served each item.  A device may be listed more than once (more workers' contexts on it).  Device-resident
+ * items (space FNX_DEVICE) live on one device, so a list of several distinct devices takes host-space items only. */
+int fennec_CompressBatchNRGBADevices(const int *devices, int ndev, int workers, int n, int space, const uint8_t *const *srcs,
+                                     const int *strides, const int *widths, const int *heights, const int64_t *original_sizes,
+                                     double target_ssim, uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                                     const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
 /* CompressFile for a JPEG source in standard mode (fennec.go:30-76 -> compressImageInternal :107-141 -> handleStandardMode
  * :162-205) from the file's bytes with every pixel stage on the device: image.Decode + toNRGBA (fnx_jpeg_decode),
  * ApplyOrientation when opts->orient is 2..8 (Options.AutoOrient; the caller reads the tag as exif.go does),
@@ -465,6 +481,11 @@ int fennec_CompressFileJPEG(fnx_ctx *ctx, const uint8_t *data, size_t n, const f
 int fennec_CompressBatchJPEG(int device, int workers, int n, const uint8_t *const *files, const size_t *sizes, double target_ssim,
                              uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
                              const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
+/* ... over a device list, as fennec_CompressBatchNRGBADevices: CompressBatch of .jpg items on all GPUs of the node from one
+ * process (file bytes are host memory, so any device may take any item). */
+int fennec_CompressBatchJPEGDevices(const int *devices, int ndev, int workers, int n, const uint8_t *const *files, const size_t *sizes,
+                                    double target_ssim, uint8_t *const *outs, const size_t *caps, fennec_BatchResult *results,
+                                    const volatile int *cancel /* may be NULL */, fennec_on_item on_item /* may be NULL */, void *user);
 /* ... with CompressFile's options: per item fennec_CompressFileJPEG under item_opts[i] when that is not NULL, else under
  * *default_opts (batch.go:101-105: item.Opts over BatchOptions.DefaultOpts).  dims (may be NULL): 4 ints per item, as
  * fennec_CompressFileJPEG's.  An item analyzeFormat sends to PNG comes back failed with status FNX_NOOP. */

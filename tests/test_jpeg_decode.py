@@ -11,6 +11,7 @@ hold less than a block), files large enough for several workgroups and several s
 refuse (FNX_ERR_UNSUPPORTED) and what it must call corrupt; fnx_jpeg_recompress = decode + fnx_jpeg_compress.
 """
 import io
+import os
 
 import numpy as np
 import pytest
@@ -450,3 +451,101 @@ def test_gpu_native_pool_with_file_options(ctx):
         assert not r.failed and (r.quality, r.ssim, r.steps, r.compressed_size, r.original_size) == (q, s, steps, len(out), len(files[i])), i
         assert bufs[i][:r.compressed_size].tobytes() == out and tuple(dims[4 * i:4 * i + 4]) == od + fd
     assert tuple(dims[8:12]) == (300, 432, 300, 432) and tuple(dims[0:4]) == (400, 300, 256, 192)
+
+
+@pytest.mark.gpu
+def test_gpu_pool_over_a_device_list(ctx):
+    """fennec_CompressBatchJPEGDevices / NRGBADevices (batch.go:63-126 with g GPUs): workers g x k, worker i on
+    devices[i mod g], ONE index queue.  One GPU here, so the list names device 0 twice -- two 'devices', four workers: every item is
+    done once, by index, with the per-item results of the single-device pool, and each result says which list entry served it."""
+    from fennec_amd import batch
+    files = [_pil(_photo(640 + 16 * k, 480 - 8 * k, k), quality=95 - k, subsampling=2 if k % 2 else 0) for k in range(12)]
+    one, outs1, summ1 = batch.compress_batch_jpeg_native(files, 0.94, workers=4)
+    two, outs2, summ2 = batch.compress_batch_jpeg_native(files, 0.94, workers=4, devices=[0, 0])
+    assert [r.Index for r in two] == list(range(len(files))) and all(r.Err is None for r in two)
+    assert outs1 == outs2
+    assert [(r.Quality, r.SSIM, r.steps, r.CompressedSize, r.OriginalSize) for r in one] == [(r.Quality, r.SSIM, r.steps, r.CompressedSize, r.OriginalSize) for r in two]
+    assert (summ1.Total, summ1.Succeeded, summ1.TotalSaved, summ1.AvgSSIM) == (summ2.Total, summ2.Succeeded, summ2.TotalSaved, summ2.AvgSSIM)
+    assert all(r.device == 0 for r in two)                  # both list entries are logical device 0
+    imgs = [synth.large_photo(320 + 16 * k, 240, k) for k in range(6)]
+    r1, f1, _ = batch.compress_batch_native(imgs, 0.94, workers=2)
+    r2, f2, _ = batch.compress_batch_native(imgs, 0.94, workers=4, devices=[0, 0])
+    assert f1 == f2 and [r.Quality for r in r1] == [r.Quality for r in r2]
+    with pytest.raises(ValueError):
+        batch.compress_batch_native(imgs, 0.94, devices=[])
+    import fennec_amd as fa
+    with pytest.raises(fa.FennecError):                     # a device the library does not have
+        batch.compress_batch_native(imgs, 0.94, workers=2, devices=[fa.load_library().fnx_device_count()])
+
+
+@pytest.mark.gpu
+def test_gpu_pool_retries_an_item_whose_file_outgrows_its_buffer(ctx):
+    """compress_batch_native sized every output at 4096 + 1.5 B/px and reported larger files as failed.  Noise at a
+    target no quality reaches falls back to q = 100 (compress.go:76-84) and writes > 1.5 B/px: the item must come back whole."""
+    from fennec_amd import batch
+    noisy = synth.noise_image(256, 192, 5)
+    calm = synth.make_test_image(256, 192)
+    res, files, summ = batch.compress_batch_native([noisy, calm], 0.9999, workers=2)
+    assert all(r.Err is None for r in res) and summ.Failed == 0
+    data, q, s, n = ctx.jpeg_compress(noisy, 0.9999)
+    assert len(data) > 4096 + 256 * 192 * 3 // 2               # the case is real: the first buffer was too small
+    assert files[0] == data and (res[0].Quality, res[0].CompressedSize) == (q, len(data))
+
+
+@pytest.mark.gpu
+def test_gpu_pool_keeps_the_batch_when_one_file_is_beyond_repair(ctx):
+    """ADVICE r2: a file neither the device decoder nor the host codec can read is THAT item's Err (batch.go:108-113);
+    the other items' results stand."""
+    from fennec_amd import batch
+    good = [_pil(_photo(320, 240, k), quality=92, subsampling=2) for k in range(3)]
+    files = [good[0], b"\xff\xd8 this is not a JPEG file", good[1], good[2][:200]]
+    res, outs, summ = batch.compress_batch_jpeg_native(files, 0.94, workers=2)
+    assert [r.Index for r in res] == [0, 1, 2, 3]
+    assert res[0].Err is None and res[2].Err is None and outs[0] and outs[2]
+    assert res[1].Err is not None and res[3].Err is not None and outs[1] == b"" and outs[3] == b""
+    assert (summ.Total, summ.Succeeded, summ.Failed) == (4, 2, 2)
+
+
+@pytest.mark.gpu
+def test_gpu_device_selection_and_force_off():
+    """fnx_set_devices / FENNEC_HIP_DEVICES / FENNEC_HIP_DISABLE: an empty list is 'no device' -- the status the
+    cgo shim falls back on -- and (NULL, -1) restores the default.  In a child process: the choice is process-wide."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import fennec_amd as fa
+L = fa.load_library()
+n = L.fnx_device_count()
+assert n >= 1
+assert L.fnx_set_devices(None, 0) == 0 and L.fnx_device_count() == 0
+h = C.c_void_p()
+assert L.fnx_ctx_create(0, C.byref(h)) == -2 and b"no HIP device" in L.fnx_last_error()      # FNX_ERR_NO_DEVICE
+try:
+    fa.Context(0)
+    raise SystemExit("a context on a switched-off library")
+except fa.FennecError:
+    pass
+assert L.fnx_set_devices((C.c_int * 2)(0, 0), 2) == 0 and L.fnx_device_count() == 2
+c = fa.Context(1)                                            # logical device 1 = HIP device 0
+assert L.fnx_ctx_device(c._h) == 1
+import numpy as np
+img = np.zeros((16, 16, 4), np.uint8); img[..., 3] = 255
+assert c.SSIMFast(img, img) == 1.0
+assert L.fnx_set_devices((C.c_int * 1)(n + 3), 1) == -1      # no such HIP device
+assert L.fnx_set_devices(None, -1) == 0 and L.fnx_device_count() == n
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, FENNEC_HIP_DISABLE="1")
+    r = subprocess.run([sys.executable, "-c", "import os,sys; sys.path.insert(0, os.getcwd()); import fennec_amd as fa; print(fa.load_library().fnx_device_count())"],
+                       cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0"), r.stdout + r.stderr
+    env = dict(os.environ, FENNEC_HIP_DEVICES="0,0,0", FNX_ROCTX="1")      # roctx ranges on: calls must simply keep working
+    r = subprocess.run([sys.executable, "-c", "import os,sys; sys.path.insert(0, os.getcwd()); import numpy as np, fennec_amd as fa; "
+                        "print(fa.load_library().fnx_device_count()); c = fa.Context(2); a = np.full((32, 32, 4), 9, np.uint8); print(c.SSIMFast(a, a))"],
+                       cwd=root, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.split() == ["3", "1.0"], r.stdout + r.stderr
