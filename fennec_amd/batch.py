@@ -110,14 +110,20 @@ class _RankQueue:
     items (or a slower GPU) simply takes fewer -- no data-path collective, one small TCP round trip per chunk."""
     _seq = 0
 
-    def __init__(self, n_items: int, chunk: int = 1, group=None):
+    def __init__(self, n_items: int, chunk: int = 1, group=None, batch_id: Optional[str] = None):
         import torch.distributed as dist
         from torch.distributed import distributed_c10d as c10d
 
         self.n, self.chunk = n_items, max(1, int(chunk))
-        # every rank calls compress_batch the same number of times, so the sequence number names the same batch everywhere
-        _RankQueue._seq += 1
-        self.key = f"next_{_RankQueue._seq}"
+        self.world = dist.get_world_size(group)
+        # The counter's name must be the same batch on every rank.  A caller-supplied batch_id says so outright (use one
+        # whenever ranks may call compress_batch a different number of times -- an exception before a batch, a mix of
+        # static and dynamic calls); without it the per-process count of DYNAMIC batches names it, which holds as long as
+        # every rank runs the same sequence of dynamic batches.
+        if batch_id is None:
+            _RankQueue._seq += 1
+            batch_id = f"seq{_RankQueue._seq}"
+        self.key = f"next_{batch_id}"
         self.store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())
         self.lock = threading.Lock()
 
@@ -126,17 +132,34 @@ class _RankQueue:
             end = int(self.store.add(self.key, self.chunk))
         return list(range(end - self.chunk, min(end, self.n)))
 
+    def completed(self) -> int:
+        """One more item of the JOB is done: the job-wide count (what OnItem reports against the job-wide total)."""
+        with self.lock:
+            return int(self.store.add(self.key + "_completed", 1))
+
+    def close(self):
+        """The last rank to leave removes the batch's keys from the store (no barrier: a counter says who is last)."""
+        with self.lock:
+            if int(self.store.add(self.key + "_left", 1)) == self.world:
+                for k in (self.key, self.key + "_completed", self.key + "_left"):
+                    try:
+                        self.store.delete_key(k)
+                    except Exception:          # a store without delete_key: the keys stay, a few bytes per batch
+                        pass
+
 
 def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], make_worker_state: Callable[[int], object],
                    workers: int = 1, rank: int = 0, world: int = 1,
                    on_item: Optional[Callable[[int, int], None]] = None, queue_mode: str = "static",
-                   chunk: int = 1) -> List[BatchResult]:
+                   chunk: int = 1, batch_id: Optional[str] = None) -> List[BatchResult]:
     """CompressBatch (batch.go:58-128) for this rank: a closed queue of indices drained by `workers` threads, results
     stored by index, `on_item(completed, total)` under a lock.
 
     queue_mode "static": the rank owns items i = rank (mod world) (shard_indices) -- no communication at all.
     queue_mode "dynamic" (world > 1, torch.distributed initialised): ONE queue for the whole job (_RankQueue), which
-    is what batch.go's channel is to its goroutines; ranks return the items they happened to take, by index."""
+    is what batch.go's channel is to its goroutines; ranks return the items they happened to take, by index.  `batch_id`
+    names the job's counter in the store (see _RankQueue); `on_item` then reports the JOB's completed count against
+    the job's total on every rank (one store round trip per item), in static mode the rank's own."""
     if n_items <= 0:
         return []
     dynamic = queue_mode == "dynamic" and world > 1
@@ -147,7 +170,7 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
         return []
     workers = max(1, min(workers, len(mine)))       # batch.go:63-69
     q: "queue.Queue[int]" = queue.Queue()
-    rq = _RankQueue(n_items, chunk) if dynamic else None
+    rq = _RankQueue(n_items, chunk, batch_id=batch_id) if dynamic else None
     if not dynamic:
         for i in mine:
             q.put(i)
@@ -182,9 +205,12 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
                 r = BatchResult(Index=idx, Err=f"{type(e).__name__}: {e}", has_result=False)
             results[idx] = r
             if on_item:
-                with lock:
-                    done[0] += 1
-                    c = done[0]
+                if rq is not None:
+                    c = rq.completed()
+                else:
+                    with lock:
+                        done[0] += 1
+                        c = done[0]
                 on_item(c, total)
 
     threads = [threading.Thread(target=run, args=(w,)) for w in range(workers)]
@@ -192,6 +218,8 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
         t.start()
     for t in threads:
         t.join()
+    if rq is not None:
+        rq.close()
     return [results[i] for i in sorted(results)]
 
 

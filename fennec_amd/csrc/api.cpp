@@ -1258,7 +1258,8 @@ void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
 {
     if (!p) return;
     if (ctx && bind(ctx) == FNX_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
+        // hipFree waits for the device's outstanding work itself; a lent stream (fnx_ctx_use_stream) is its owner's to drain
+        if (ctx->stream == ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
         if (p->pix) (void)hipFree(p->pix);
     }
     delete p;

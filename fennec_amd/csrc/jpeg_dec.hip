@@ -208,6 +208,10 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             continue;
         }
         if (WRITE && nocode) bad |= 1u;                            // (after the boundary test: padding is not a code either)
+        if (WRITE && rel + static_cast<uint32_t>(len + s) > lim) { // a code or a value that straddles the string's end would be completed
+            bad |= 8u;                                             // from the zero padding behind it: Go reports unexpected EOF here
+            break;
+        }
         if (WRITE) {
             int32_t v = 0;
             if (s) {                                               // receive + extend (T.81 F.2.2.1)

@@ -93,6 +93,10 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                     f->tab.delta[t][L] = k - static_cast<int32_t>(code);
                     for (int j = 0; j < cnt; j++, k++, code++) {
                         if (code >= (1u << L)) return jpeg_corrupt("a Huffman table with more codes than its lengths allow");
+                        // T.81 C.2 keeps the all-ones code of every length unassigned, and the kernels lean on it: the 1-bits
+                        // that pad the byte before a restart marker (and the string's last byte) can then never be a symbol.
+                        // A table that assigns it is one the host codec gets to read.
+                        if (code + 1 == (1u << L)) return jpeg_unsupported("a Huffman table that assigns the all-ones code");
                         f->tab.value[t][k] = seg[o + 17 + k];
                         if (L <= DEC_FAST_BITS)
                             for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)

@@ -434,7 +434,9 @@ void fnx_ctx_destroy(fnx_ctx *ctx)
 {
     if (!ctx) return;
     if (hipSetDevice(ctx->device) == hipSuccess) {
-        (void)hipStreamSynchronize(ctx->stream);
+        // only streams the ctx OWNS: a stream lent through fnx_ctx_use_stream may already be gone (its owner orders and drains it;
+        // a lent stream must outlive the work enqueued on it, not the ctx)
+        if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
         if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
         for (auto &s : ctx->slot)
             if (s.p) (void)hipFree(s.p);

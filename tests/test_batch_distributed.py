@@ -110,12 +110,22 @@ def _rank_main_dynamic(rank, world, port, n_items, out_q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = []
+    if rank == 1:                                 # rank 1 runs a batch of its own first: the ranks' call COUNTS now differ, which the
+        batch.compress_batch(5, _fake_work, lambda w: None, workers=1)       # caller-supplied batch ids below must not mind
     for chunk in (1, 3):                          # two batches in one job: the queue's key is per batch
+        seen = []
         res = batch.compress_batch(n_items, _uneven_work, lambda w: rank, workers=2, rank=rank, world=world,
-                                   queue_mode="dynamic", chunk=chunk)
+                                   queue_mode="dynamic", chunk=chunk, batch_id=f"job-chunk{chunk}",
+                                   on_item=lambda c, t: seen.append((c, t)))
         s = batch.summarize_distributed(res)
-        out.append(([r.Index for r in res], (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM)))
+        # OnItem reports the JOB's progress (batch.go:113-119 counts the one pool's completions): job-wide counts against the job's total
+        assert len(seen) == len(res) and all(t == n_items and 1 <= c <= n_items for c, t in seen)
+        assert len({c for c, _ in seen}) == len(seen)
+        out.append(([r.Index for r in res], (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM), [c for c, _ in seen]))
         dist.barrier()
+    from torch.distributed import distributed_c10d as c10d
+    store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())
+    assert not store.check(["next_job-chunk1"]) and not store.check(["next_job-chunk3_completed"])    # the last rank out removed the keys
     out_q.put((rank, out))
     dist.destroy_process_group()
 
@@ -142,8 +152,9 @@ def test_world_size_2_dynamic_queue(orc):
     want = orc.summarize([r.Err is not None for r in allres], [r.has_result for r in allres],
                          [r.OriginalSize for r in allres], [r.CompressedSize for r in allres], [r.SSIM for r in allres])
     for b in range(2):
-        i0, s0 = got[0][b]
-        i1, s1 = got[1][b]
+        i0, s0, c0 = got[0][b]
+        i1, s1, c1 = got[1][b]
+        assert sorted(c0 + c1) == list(range(1, n_items + 1))             # OnItem: the job's count, each value once across the ranks
         assert sorted(i0 + i1) == list(range(n_items))                    # every item exactly once
         assert i0 == sorted(i0) and i1 == sorted(i1)
         assert len(i1) > 2 * len(i0), (len(i0), len(i1))                  # the fast rank took most of them
