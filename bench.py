@@ -112,6 +112,9 @@ def main() -> int:
     ap.add_argument("--device-search", action="store_true",
                     help="config5: the quality search round-trips every candidate on the device (fnx_jpeg_quality_search); the host "
                          "codec decodes the source and encodes the winner only")
+    ap.add_argument("--no-batch", action="store_true", help="skip the `batch` object (CompressBatch images/s over --batch-items 4K JPEGs)")
+    ap.add_argument("--batch-items", type=int, default=4096, help="items of the `batch` job (BASELINE config 5: 4096)")
+    ap.add_argument("--batch-files", type=int, default=64, help="distinct synthetic 4K JPEG files the items cycle through")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
@@ -309,6 +312,8 @@ def main() -> int:
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
             "traffic": committed_traffic("blur_direct_kernel", nb0, scored=True, exact=exact),
+            "traffic_source": "profiles/*onepass*_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of this command (committed; "
+                              "not measured in this run -- the driver's run has no profiler attached)",
             "algorithmic_bytes_per_launch": blur_bytes,
             "algorithmic_bytes_note": "SURVEY 8(d): 4*S per image for GaussianBlur+SSIMFast; the one-pass kernel "
                                       "needs only 2*S of HBM traffic for it (see traffic)",
@@ -317,16 +322,22 @@ def main() -> int:
             "launch_ms_min_median_max": [round(float(np.min(kernel_ms)), 4), round(float(np.median(kernel_ms)), 4),
                                          round(float(np.max(kernel_ms)), 4)],
             "valu_issue_frac": committed_valu_issue("blur_direct_kernel", blur_ms, scored=True, exact=exact),
-            "note": "the previous step's tail (box_from_slabs, windowed SSIM, finish) runs on the ctx's second stream "
-                    "under this launch, so its duration includes their share of the GPU",
+            "valu_issue_source": "SQ_ACTIVE_INST_VALU and the shader clock from profiles/*onepass*_sq_counters.txt (committed PMC pass) over THIS run's launch time",
+            "avg_launch_how": "HIP events bound to the dispatch itself (hipExtLaunchKernelGGL start / stop events: the kernel packet's own "
+                              "timestamps, no barrier packets on the stream), every launch of the timed region",
+            "note": "the previous step's tail (box_from_slabs, windowed SSIM with its finish) runs on the ctx's second stream "
+                    "under this launch -- beside its waves: the blur keeps 96 VGPRs per SIMD free for them -- so its duration "
+                    "includes their share of the GPU",
         }
         if depth > 1:
             roofline["note"] = (f"measured live in the timed region, where the kernel shares the GPU with the previous "
                                 f"step's tail kernels (pipeline depth {depth}); `serial` has the kernel running alone")
         rest = {
-            "kernels": "box_from_slabs_kernel + windowed_ssim_sep24_kernel + ssim_finish_kernel (results land in pinned host memory)",
+            "kernels": "box_from_slabs_kernel + windowed_ssim_march_kernel<true> (the last workgroup of an image takes its mean; results land "
+                       "in pinned host memory), both under the NEXT step's blur",
             "avg_ms": round(rest_ms, 4),
-            "how": "step period minus the blur kernel's duration (rocprofv3: 37 + 44 + 4 us of kernels, the rest is launch gaps)",
+            "how": "step period minus the blur kernel's duration = the dispatch gap between consecutive blur launches (the tail's own "
+                   "kernels, ~45 + 40 us alone, run concurrently: profiles/r03_onepass_kernel_stats.csv)",
         }
         if depth > 1:
             rest["note"] = "step period minus the (co-scheduled) blur kernel's duration: not a kernel time at this depth"
@@ -482,8 +493,9 @@ def main() -> int:
                                      "bit-identical to the reference's, scores from exactly those images; same protocol as the "
                                      "timed region (warm-up, synchronize on both sides), run right after it; "
                                      "`python bench.py --blur-mode exact` makes it the headline line"}
+    host0 = srcs[0].cpu().numpy() if rank == 0 else None
     if rank == 0 and not args.no_extras:
-        host = srcs[0].cpu().numpy()
+        host = host0
         ctx.GaussianBlur(host, SIGMA, exact=None)
         t_h = time.perf_counter()
         for _ in range(3):
@@ -492,13 +504,152 @@ def main() -> int:
         t_h = (time.perf_counter() - t_h) / 3
         out["pcie_inclusive"] = {"value": round(mp_per_image / t_h, 1), "unit": "MP/s", "ms_per_image": round(t_h * 1e3, 3),
                                  "note": "one context, pageable host buffers: 3 uploads + 1 download of 33 MB per image"}
+    if not args.no_batch:
+        # BASELINE.json's second metric: CompressBatch images/s, at every N (all ranks take part: ONE queue for the job)
+        ctx.profile(False)
+        bm = batch_metric(args, rank, world, local_rank, red_dev, ctx)
+        if rank == 0:
+            out["batch"] = bm
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["other_configs"] = other_configs(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(srcs[0].cpu().numpy())
+        out["cpu_baseline"] = cpu_baseline(host0)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def other_configs(args) -> dict:
+    """BASELINE configs 3, 4 and 5 in front of the driver: a bounded pass of each after the default line's timed region (same
+    protocol as their own `--workload` lines, smaller batches / fewer steps; about 15 s in all).  Never part of `value`."""
+    import copy
+    out = {}
+    plan = [("config3", dict(batch=32, steps=4, warmup=1, contexts=4, threads=2)),
+            ("config4", dict(batch=4, steps=4, warmup=1, contexts=1, threads=1)),
+            ("config5", dict(batch=16, steps=3, warmup=1, contexts=1, threads=1, device_decode=True))]
+    for wl, over in plan:
+        a = copy.copy(args)
+        a.workload, a.prewarm, a.no_cpu_baseline, a.no_extras = wl, 0.15, True, True
+        a.device_codec = a.device_search = False
+        a.device_decode = False
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            line = other_workload_line(a, embedded=True)
+            keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_step",
+                                        "step_ms", "gpu_stage", "result_sample") if k in line}
+            keep["workload"] = line["config"]["workload"]
+            keep["images_per_step"] = line["config"]["images_per_step_per_gpu"]
+            keep["wall_s"] = round(time.perf_counter() - t0, 2)
+            out[wl] = keep
+        except Exception as e:                  # a failure here must not cost the headline line
+            out[wl] = {"error": f"{type(e).__name__}: {e}"}
+    out["note"] = ("bounded passes after the timed region, the protocol of `bench.py --workload configN` at smaller batches; "
+                   "config5 is the --device-decode path (file bytes up, decoder + search + encoder on the device, new file down)")
+    return out
+
+
+def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
+    """BASELINE.json's batch metric: CompressBatch (batch.go:58-128) over N_ITEMS synthetic 4K JPEGs, SSIM-guided quality
+    search (Balanced, compress.go:21-87), sharded over the job's GPUs with ONE dynamic queue (a counter in
+    torch.distributed's store: whichever worker of whichever rank asks first takes the next indices), no data-path
+    collective; Summarize (batch.go:140-158) through the all-reduce (RCCL at N > 1).  Per item the FILE's bytes go up,
+    decoder + search + encoder run on the device (fnx_jpeg_recompress), the new file comes down.  The files: DISTINCT
+    synthetic 4K images (SURVEY 8(d)'s large_photo pattern, salted per image) encoded by the device encoder at q = 92 and 85
+    before the timed region; item i reads file i mod len(files) (4096 distinct 7 MB files would be 29 GB of host memory
+    per rank)."""
+    import torch
+    import torch.distributed as dist
+    import fennec_amd
+    from fennec_amd import batch as fbatch
+    from fennec_amd import synth
+
+    n_items = args.batch_items
+    n_files = max(1, min(args.batch_files, n_items))
+    workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
+    target = fbatch.TARGET_SSIM["Balanced"]
+    # the same file list on every rank (any rank may take any item)
+    files = []
+    nimg = (n_files + 1) // 2
+    for k, img in zip(range(nimg), synth.large_photo_batch(W4K, H4K, range(nimg))):
+        d = torch.from_numpy(img).cuda()
+        for q in (92, 85):
+            if len(files) < n_files:
+                files.append(ctx0.jpeg_encode(d, q))
+        del d
+    states = {}
+
+    def make_state(wid):
+        if wid not in states:
+            states[wid] = fennec_amd.Context(local_rank)
+        return states[wid]
+
+    work = fbatch.jpeg_item_work_device_all([files[i % n_files] for i in range(n_items)], target)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: worker contexts, scratch growth, clocks
+    fbatch.compress_batch(min(n_items, 8 * workers), work, make_state, workers=workers)
+    # N = 1 reference inside this job: rank 0 alone over a slice of the items, the other ranks idle
+    n_ref = min(n_items, 384)
+    barrier()
+    ref_rate = None
+    if rank == 0:
+        t_r = time.perf_counter()
+        fbatch.compress_batch(n_ref, work, make_state, workers=workers)
+        ref_rate = n_ref / (time.perf_counter() - t_r)
+    barrier()
+    t0 = time.perf_counter()
+    res = fbatch.compress_batch(n_items, work, make_state, workers=workers, rank=rank, world=world,
+                                queue_mode="dynamic" if world > 1 else "static", chunk=4, batch_id="bench-batch")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mine = len(res)
+    up = sum(r.OriginalSize for r in res)
+    down = sum(r.CompressedSize for r in res)
+    host_dec = sum(1 for r in res if getattr(r, "host_decoded", False))
+    summ = fbatch.summarize_distributed(res, device=red_dev if world > 1 else None)
+    per_rank = [mine]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        cnt[rank] = mine
+        io = torch.tensor([float(up), float(down), float(host_dec)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(io, op=dist.ReduceOp.SUM)
+        per_rank = [int(v) for v in cnt.tolist()]
+        up, down, host_dec = (int(v) for v in io.tolist())
+        r0 = torch.tensor([ref_rate or 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(r0, op=dist.ReduceOp.MAX)
+        ref_rate = float(r0.item())
+    for c in states.values():
+        c.close()
+    total = n_items / elapsed
+    return {
+        "metric": "images/sec: CompressBatch 4K JPEG, SSIM-guided quality search",
+        "value": round(total, 1), "unit": "images/s", "n_gpus": world, "items": n_items, "seconds": round(elapsed, 3),
+        "images_per_s_per_rank": [round(c / elapsed, 1) for c in per_rank], "items_per_rank": per_rank,
+        "n1_reference_images_per_s": round(ref_rate, 1),
+        "efficiency_vs_n1": round(total / (world * ref_rate), 4),
+        "n1_reference_how": f"rank 0 alone over {n_ref} of the same items right before the job, the other ranks idle",
+        "queue": "one dynamic queue for the job (store counter, chunks of 4 indices)" if world > 1 else "one rank: its own queue",
+        "path": "fnx_jpeg_recompress per item: file bytes up, decoder + quality search + encoder on the device, new file down; no host codec",
+        "host_threads_per_rank": workers, "host_decoded_items": host_dec,
+        "distinct_files": n_files, "file_bytes_mean": round(sum(len(f) for f in files) / n_files),
+        "pcie_bytes": {"up": up, "down": down, "per_item_up": round(up / n_items), "per_item_down": round(down / n_items)},
+        "summarize": {"Total": summ.Total, "Succeeded": summ.Succeeded, "Failed": summ.Failed, "TotalSaved": summ.TotalSaved,
+                      "AvgSSIM": summ.AvgSSIM, "how": (f"batch.go:140-158; all-reduce over {'RCCL' if red_dev == 'cuda' else 'gloo (test hook)'}" if world > 1 else "batch.go:140-158")},
+        "target_ssim": target,
+        "note": f"the job is the same {n_items} items at every N (strong scaling: `efficiency_vs_n1` is the figure to read); run after the config-2 timed region, never `value`",
+    }
 
 
 def _pooled_step(fennec_amd, device, ctx0, imgs, one, nctx):
@@ -632,16 +783,40 @@ def _pooled_queue_step(fennec_amd, device, ctx0, n_items, submit, drain, nctx, n
     return step
 
 
+DTYPES = {   # the arithmetic each workload's hot kernels compute in (not a precision claim: every integer output is bit-exact)
+    "config3": "u8 (fp32 FMA resize under a rounding guard + fp64 reference-order fix-ups; integer box sums; fp64 SSIM moments)",
+    "config4": "u8 (integer Sobel + fp32 AdaptiveSharpen under a rounding guard + fp64 fix-ups; integer milli-luminance, fp64 SSIM moments)",
+    "config5": "u8 / int32 (Go image/jpeg's integer DCT, quantisation and Huffman arithmetic; integer box sums; fp64 SSIM moments)",
+    "analyze": "u8 -> fp64 luminance sums, integer histogram",
+    "palette": "u8 / u32 integer distances",
+    "scale-search": "u8 (integer box sums, one fp64 multiply per sample)",
+}
+
+
 def other_workloads(args) -> int:
     """BASELINE.json configs 3, 4, 5 (parity-test cases, not the headline bench line): same
     timing protocol, one JSON line.  Per-image C-ABI calls on device-resident tensors."""
+    out = other_workload_line(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def other_workload_line(args, embedded: bool = False):
+    """The line of one --workload (rank 0: the dict; other ranks: None).  embedded: called from the default run at N = 1
+    after its timed region (`other_configs`): no process-group setup, no CPU baseline."""
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank, red_dev = _dist_setup(torch, dist, local_rank, world)
+    if embedded:
+        rank, world, red_dev = 0, 1, "cuda"
+        local_rank = torch.cuda.current_device()
+        args.no_cpu_baseline = True
+    else:
+        local_rank, red_dev = _dist_setup(torch, dist, local_rank, world)
     import fennec_amd
     from fennec_amd import batch as fbatch
     from fennec_amd import synth
@@ -856,7 +1031,7 @@ def other_workloads(args) -> int:
     out = {
         "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8 (fp64 exact kernels)", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPES.get(wl, "u8"), "data": "synthetic",
         "config": {"workload": name, "images_per_step_per_gpu": B, "width": W, "height": H,
                    "inputs": "device-resident, per-image C-ABI calls" if wl != "config5" else ("host JPEG bytes; the file is all that crosses PCIe" if getattr(args, "device_decode", False) else "host JPEG bytes, FNX_HOST staging per search step")},
         "roofline": {"kernel": "whole step (all kernels of the workload)", "bound": "hbm", "achieved": round(gbs, 1),
@@ -876,10 +1051,11 @@ def other_workloads(args) -> int:
             g = abytes / (ms * 1e-3) / 1e9
             # the kernel is fp64-VALU bound: 4 moments x 8 taps x 2 passes of fp64 FMA per window
             win = float(W - 8) * float(H - 8)
-            out["roofline"] = {"kernel": "windowed_ssim_march_kernel (full-resolution SSIM of one 8K pair, luminance fused)",
-                               "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline"] = {"kernel": "windowed_ssim_march2_kernel (full-resolution SSIM of one 8K pair, two pixel columns per lane, luminance fused)",
+                               "bound": "valu", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
-                               "traffic": committed_traffic_named("windowed_ssim_march_kernel", "config4"),
+                               "traffic": committed_traffic_named("windowed_ssim_march2_kernel", "config4"),
+                               "traffic_source": "profiles/*config4*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": len(kms["windowed_ssim"]),
                                "fp64_fma_floor_ms": round(win * 64 / 39.3e12 * 1e3, 4),
                                "note": "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown); "
@@ -894,6 +1070,7 @@ def other_workloads(args) -> int:
                                "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
                                "traffic": committed_traffic_named("resize_h_guard_kernel", "config3"),
+                               "traffic_source": "profiles/*config3*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4),
                                "launches_timed": len(kms[dom]),
                                "resize_kernels_ms": {k: round(v, 4) for k, v in means.items()},
@@ -971,11 +1148,11 @@ def other_workloads(args) -> int:
         dt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(reps * W * H / 1e6 / dt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
                                "sample": f"{reps} x Analyze(4K) in {dt:.1f} s, oracle/fennec_oracle.c (serial, as the reference)"}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if hasattr(step, "close"):
+        step.close()                       # the worker threads of _pooled_queue_step
+    if world > 1 and not embedded:
         dist.destroy_process_group()
-    return 0
+    return out if rank == 0 else None
 
 
 def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = False, exact: bool = False):

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 EXTRA=${2:-}      # e.g. "--pipeline one-pass" (use a tag of its own: r01_onepass)
-CMD="python $ROOT/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-extras $EXTRA"
+CMD="python $ROOT/bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-extras --no-batch $EXTRA"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $CMD > "$OUT/bench_under_stats.json" 2> "$OUT/stats.log"
 PCMD="$CMD --prewarm 0"     # counters do not depend on the clock ramp; keep the PMC passes short
