@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(PassArgs<T> a)
 // ------------------------------------------------------------------------------------
 // fused fast path
 // ------------------------------------------------------------------------------------
-constexpr int FUSED_RMAX = 8;
+constexpr int FUSED_RMAX = 16;    // radius <= 16 (sigma <= 5.33): the tile kernel; r3: 9..16 added (the H window streams through, see WIDE)
+constexpr int SCORE_RMAX = 8;     // the one-pass GaussianBlur + SSIMFast form and the 128-lane tile stop here
 
 struct FusedArgs {
     const uint8_t *src;
@@ -96,7 +97,8 @@ struct FusedArgs {
     int sstride, dstride, w, h;
     int tiles_x, tiles;   // per image
     float wt[2 * FUSED_RMAX + 1];
-    double wd[2 * FUSED_RMAX + 1];   // GUARD variant only: the caller's fp64 weights for the exact fix-ups
+    double wd[2 * SCORE_RMAX + 1];   // GUARD variant only: the caller's fp64 weights for the exact fix-ups (R <= 8: kernel arguments)
+    const double *wdp;               // ... R > 8: a device table (33 doubles next to 33 floats would not fit the scalar registers)
     // SCORE variant only (launch_blur_scored): boxDownsample partial sums of src and dst
     const int32_t *bx, *by;       // box column / row of each source column / row (-1: in no box)
     unsigned long long *slabs;    // [image][tile][2][slabn] packed 4 x u16 channel sums
@@ -158,14 +160,23 @@ __device__ __forceinline__ v2f fma2(v2f f, float w, v2f acc)
 // in place would run the fp64 code in almost every wave.  A list overflow recomputes the whole tile.
 // With SCORE the flagged blurred pixels add into a spare table entry in the V pass and into their box
 // after the recompute, so the box sums are those of the exact image (an overflow clears and rebuilds them).
-constexpr float GUARD_G = 2.0e-4f;
+// E at R = 16 is 255*2^-24 + 33*2^-17 = 2.67e-4; with the slack of the second add (2^-17) G = 3e-4 covers radii 9..16
+constexpr float guard_g(int R) { return R <= 8 ? 2.0e-4f : 3.0e-4f; }
 constexpr int guard_fix_cap(bool score) { return score ? 512 : 2048; }   // SCORE: LDS is shared with the tables
 
 template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1, bool GUARD = false>
-__global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
+// (guarded at R > 8: two waves per SIMD -- at four the compiler spilled 200-540 bytes per lane and sigma = 5 took 369 us
+// per 4K image; at 200+ registers it takes ~85)
+__global__ __launch_bounds__(NTH, (GUARD && R > 8) ? 2 : (GUARD && NTH == 128) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
 {
     constexpr int FIX_CAP = guard_fix_cap(SCORE);
+    constexpr float GUARD_G = guard_g(R);
     constexpr float SEED = GUARD ? 0.5f - GUARD_G : 0.5f;
+    // WIDE (R > 8): the H window is 8 + 2R <= 40 pixels x 2 rows -- held whole it is 80 registers next to the 48 accumulators.
+    // It streams through instead, four pixels at a time with two chunks in flight, and the eight centre pixels (the pack
+    // chains' alpha seeds) are set aside as they pass.  R <= 8 keeps the whole-window form its schedule was tuned for.
+    constexpr bool WIDE = R > SCORE_RMAX;
+    static_assert(!(WIDE && SCORE), "the one-pass form stops at R = 8");
     constexpr int TW = 64;
     constexpr int RG = NTH / 32;                    // row groups of the V pass (32 column pairs each)
     constexpr int TH = ((IH - 2 * R) / RG) * RG;    // output rows per tile
@@ -227,8 +238,10 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
     for (int item = tid; item < HITEMS; item += NTH) {
         const int rp = item / HGROUPS, g = item - rp * HGROUPS;
         const int xs = x0 + HO * g - R;                          // first px of the window
-        u32x4 t0[NV], t1[NV];
-        if (interior) {
+        u32x4 t0[WIDE ? 1 : NV], t1[WIDE ? 1 : NV];
+        if constexpr (WIDE) {
+            (void)t0; (void)t1;
+        } else if (interior) {
             const uint8_t *p0 = src + static_cast<size_t>(y0 - R + 2 * rp) * a.sstride + 4 * static_cast<size_t>(xs);
             const uint8_t *p1 = p0 + a.sstride;
 #pragma unroll
@@ -274,8 +287,64 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         v2f acc[HO][3];
 #pragma unroll
         for (int j = 0; j < HO; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){SEED, SEED};
+        uint32_t cw0[WIDE ? HO : 1], cw1[WIDE ? HO : 1];          // WIDE: the centre pixels of the two rows
+        if constexpr (WIDE) {
+            const int yr = y0 - R + 2 * rp;
+            const uint8_t *q0 = src + static_cast<size_t>(interior ? yr : clampi(yr, 0, a.h - 1)) * a.sstride;
+            const uint8_t *q1 = src + static_cast<size_t>(interior ? yr + 1 : clampi(yr + 1, 0, a.h - 1)) * a.sstride;
+            // one chunk of both rows; the clamped form (effects.go:174-178) only on tiles that touch the image's edge
+            // (`interior` is uniform over the workgroup: the two forms are separate loops, no branch sits between a
+            // load and the chunk that waits for it)
+            auto chunk = [&](auto edge, int q, u32x4 &c0, u32x4 &c1) {
+                const int x = xs + 4 * q;
+                if constexpr (!decltype(edge)::value) {
+                    c0 = *(g_u32x4 *)(q0 + 4 * static_cast<size_t>(x));
+                    c1 = *(g_u32x4 *)(q1 + 4 * static_cast<size_t>(x));
+                } else {
 #pragma unroll
-        for (int q = 0; q < NV; q++) {
+                    for (int e = 0; e < 4; e++) {
+                        const int xc = clampi(x + e, 0, a.w - 1);
+                        c0[e] = ld_px(q0, xc);
+                        c1[e] = ld_px(q1, xc);
+                    }
+                }
+            };
+            auto stream = [&](auto edge) {
+                u32x4 a0, a1, b0, b1;
+                chunk(edge, 0, a0, a1);
+                chunk(edge, 1, b0, b1);
+#pragma unroll
+                for (int q = 0; q < NV; q++) {
+                    const u32x4 c0 = a0, c1 = a1;
+                    a0 = b0; a1 = b1;
+                    if (q + 2 < NV) chunk(edge, q + 2, b0, b1);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int i = 4 * q + e;
+                        if (i < NPX) {
+                            const uint32_t p0 = c0[e], p1 = c1[e];
+                            if (i >= R && i < R + HO) { cw0[i - R] = p0; cw1[i - R] = p1; }
+                            const v2f f0 = {static_cast<float>(p0 & 0xffu), static_cast<float>((p0 >> 8) & 0xffu)};
+                            const v2f f1 = {static_cast<float>((p0 >> 16) & 0xffu), static_cast<float>(p1 & 0xffu)};
+                            const v2f f2 = {static_cast<float>((p1 >> 8) & 0xffu), static_cast<float>((p1 >> 16) & 0xffu)};
+#pragma unroll
+                            for (int j = 0; j < HO; j++) {
+                                const int k = i - j;
+                                if (k >= 0 && k < NT) {
+                                    acc[j][0] = fma2(f0, a.wt[k], acc[j][0]);
+                                    acc[j][1] = fma2(f1, a.wt[k], acc[j][1]);
+                                    acc[j][2] = fma2(f2, a.wt[k], acc[j][2]);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            };
+            if (interior) stream(std::false_type{}); else stream(std::true_type{});
+        }
+#pragma unroll
+        for (int q = 0; q < (WIDE ? 0 : NV); q++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int i = 4 * q + e;
@@ -303,14 +372,21 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         fp32_round_toward_zero();
 #pragma unroll
         for (int j = 0; j < HO; j++) {
-            const int c = j + R;
-            o0[j] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, t0[c / 4][c % 4])));
-            o1[j] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, t1[c / 4][c % 4])));
+            constexpr int c = 0;
+            uint32_t sd0, sd1;                                   // the centre source pixels: their alpha stays in byte 3
+            if constexpr (WIDE) {
+                sd0 = cw0[j]; sd1 = cw1[j];
+            } else {
+                sd0 = t0[(j + R) / 4][(j + R) % 4]; sd1 = t1[(j + R) / 4][(j + R) % 4];
+            }
+            (void)c;
+            o0[j] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, sd0)));
+            o1[j] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, sd1)));
             if constexpr (GUARD) {   // second pack at acc + 2G: a differing pixel is within G of a rounding boundary
                 const v2f g2 = {2.0f * GUARD_G, 2.0f * GUARD_G};
                 const v2f h0 = acc[j][0] + g2, h1 = acc[j][1] + g2, h2 = acc[j][2] + g2;
-                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, t0[c / 4][c % 4])));
-                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, t1[c / 4][c % 4])));
+                const uint32_t p0 = pk8(h1.x, 2, pk8(h0.y, 1, pk8(h0.x, 0, sd0)));
+                const uint32_t p1 = pk8(h2.y, 2, pk8(h2.x, 1, pk8(h1.y, 0, sd1)));
                 if (p0 != o0[j]) {
                     const int e = atomicAdd(&s_nfix[0], 1);
                     if (e < FIX_CAP) s_fix[e] = ((2 * rp) << 8) | (HO * g + j);
@@ -337,12 +413,19 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
             const int col = nfix > FIX_CAP ? e - row * TW : static_cast<int>(s_fix[e] & 0xffu);
             const uint8_t *prow = src + static_cast<size_t>(clampi(y0 - R + row, 0, a.h - 1)) * a.sstride;
             double r = 0, g = 0, b = 0;
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
+            auto tap = [&](int k) {
                 const uint32_t p = ld_px(prow, clampi(x0 + col + k - R, 0, a.w - 1));
-                r = r + u8_to_f64(p & 0xffu) * a.wd[k];
-                g = g + u8_to_f64((p >> 8) & 0xffu) * a.wd[k];
-                b = b + u8_to_f64((p >> 16) & 0xffu) * a.wd[k];
+                const double wk = WIDE ? a.wdp[k] : a.wd[WIDE ? 0 : k];
+                r = r + u8_to_f64(p & 0xffu) * wk;
+                g = g + u8_to_f64((p >> 8) & 0xffu) * wk;
+                b = b + u8_to_f64((p >> 16) & 0xffu) * wk;
+            };
+            if constexpr (WIDE) {      // a rolled loop: 33 taps unrolled keep 33 loads' registers alive in a kernel that has none to spare
+#pragma unroll 2
+                for (int k = 0; k < NT; k++) tap(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NT; k++) tap(k);
             }
             s_tmp[row * TW + col] = clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) |
                                     (s_tmp[row * TW + col] & 0xff000000u);
@@ -358,13 +441,14 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         v2f acc[Q][3];                                           // (r0,g0) (b0,r1) (g1,b1)
 #pragma unroll
         for (int j = 0; j < Q; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){SEED, SEED};
-        u32x2 alg[GUARD ? Q : 1];                                // GUARD: the centre rows' words stay in registers (see below)
+        constexpr bool KEEP_AL = GUARD && !WIDE;                 // GUARD at R <= 8: the centre rows' words stay in registers (see below)
+        u32x2 alg[KEEP_AL ? Q : 1];
         u32x2 tn = *reinterpret_cast<const u32x2 *>(colp);
 #pragma unroll
         for (int i = 0; i < Q + 2 * R; i++) {
             const u32x2 t = tn;
             if (i + 1 < Q + 2 * R) tn = *reinterpret_cast<const u32x2 *>(colp + (i + 1) * TW);   // prefetch next row
-            if constexpr (GUARD) { if (i >= R && i < R + Q) alg[i - R] = t; }
+            if constexpr (KEEP_AL) { if (i >= R && i < R + Q) alg[i - R] = t; }
             const v2f f0 = {static_cast<float>(t.x & 0xffu), static_cast<float>((t.x >> 8) & 0xffu)};
             const v2f f1 = {static_cast<float>((t.x >> 16) & 0xffu), static_cast<float>(t.y & 0xffu)};
             const v2f f2 = {static_cast<float>((t.y >> 8) & 0xffu), static_cast<float>((t.y >> 16) & 0xffu)};
@@ -388,7 +472,7 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
         // kernels of the previous step, which then run beside the blur's waves instead of in place of one).  The guarded
         // variant packs every sample twice and is register-bound elsewhere: it keeps them (re-reading made it spill).
         u32x2 aln = {0, 0}, aln2 = {0, 0};
-        if constexpr (!GUARD) {
+        if constexpr (!KEEP_AL) {
             aln = *reinterpret_cast<const u32x2 *>(colp + R * TW);
             aln2 = *reinterpret_cast<const u32x2 *>(colp + (R + 1) * TW);
         }
@@ -396,7 +480,7 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
 #pragma unroll
         for (int j = 0; j < Q; j++) {
             u32x2 al;
-            if constexpr (GUARD) {
+            if constexpr (KEEP_AL) {
                 al = alg[j];
             } else {
                 al = aln;                                        // two rows ahead: an LDS read is ~64 clocks
@@ -495,12 +579,19 @@ __global__ __launch_bounds__(NTH, (GUARD && NTH == 128) ? 3 : 4) void blur_direc
             const int x = x0 + col, y = y0 + row;
             if (x >= a.w || y >= a.h) continue;
             double r = 0, g = 0, b = 0;
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
+            auto tap = [&](int k) {
                 const uint32_t p = s_tmp[(row + k) * TW + col];
-                r = r + u8_to_f64(p & 0xffu) * a.wd[k];
-                g = g + u8_to_f64((p >> 8) & 0xffu) * a.wd[k];
-                b = b + u8_to_f64((p >> 16) & 0xffu) * a.wd[k];
+                const double wk = WIDE ? a.wdp[k] : a.wd[WIDE ? 0 : k];
+                r = r + u8_to_f64(p & 0xffu) * wk;
+                g = g + u8_to_f64((p >> 8) & 0xffu) * wk;
+                b = b + u8_to_f64((p >> 16) & 0xffu) * wk;
+            };
+            if constexpr (WIDE) {
+#pragma unroll 2
+                for (int k = 0; k < NT; k++) tap(k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NT; k++) tap(k);
             }
             const uint32_t px = clampF_dev(r) | (clampF_dev(g) << 8) | (clampF_dev(b) << 16) |
                                 (s_tmp[(row + R) * TW + col] & 0xff000000u);
@@ -674,13 +765,16 @@ static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 //   256 lanes x (2*TH+2R) rows         (TH = 104,      halo 1.12x) -- wins when the image height
 //     does not leave a mostly empty last tile row and there are enough tiles to fill the chip.
 // Cost model: H work ~ staged rows, V work ~ output rows (about 55 : 45 of the instructions).
+constexpr int WIDE_IH = 128;      // staged rows of the R > 8 tile (256 lanes): TH = the multiple of 8 below 128 - 2R
 static int direct_tile_rows(int R, bool tall)
 {
-    const int th0 = R >= 1 && R <= FUSED_RMAX ? ((64 - 2 * R) / 4) * 4 : 4;   // never 0: callers divide by it
+    if (R > SCORE_RMAX && R <= FUSED_RMAX) return ((WIDE_IH - 2 * R) / 8) * 8;
+    const int th0 = R >= 1 && R <= SCORE_RMAX ? ((64 - 2 * R) / 4) * 4 : 4;   // never 0: callers divide by it
     return tall ? 2 * th0 : th0;
 }
 static bool direct_tall(const fnx_ctx *ctx, int R, int n, int w, int h)
 {
+    if (R > SCORE_RMAX) return true;                            // one tile shape for the wide radii
     const int TH0 = direct_tile_rows(R, false), TH1 = direct_tile_rows(R, true);
     const long ty0 = (h + TH0 - 1) / TH0, ty1 = (h + TH1 - 1) / TH1;
     const double cost0 = ty0 * (0.55 * (TH0 + 2 * R) + 0.45 * TH0);
@@ -704,9 +798,14 @@ static bool guard_kernel_ok(const double *kernel, int radius)
 template <int R, bool SCORE, bool GUARD = false>
 static int launch_direct(fnx_ctx *ctx, int n, FusedArgs &fa, bool tall)
 {
-    constexpr int TH0 = ((64 - 2 * R) / 4) * 4;
-    if (tall) return launch_direct_cfg<R, 256, 2 * TH0 + 2 * R, SCORE, GUARD>(ctx, n, fa);
-    return launch_direct_cfg<R, 128, 64, SCORE, GUARD>(ctx, n, fa);
+    if constexpr (R > SCORE_RMAX) {
+        static_assert(!SCORE, "one-pass form: R <= 8");
+        return launch_direct_cfg<R, 256, WIDE_IH, false, GUARD>(ctx, n, fa);
+    } else {
+        constexpr int TH0 = ((64 - 2 * R) / 4) * 4;
+        if (tall) return launch_direct_cfg<R, 256, 2 * TH0 + 2 * R, SCORE, GUARD>(ctx, n, fa);
+        return launch_direct_cfg<R, 128, 64, SCORE, GUARD>(ctx, n, fa);
+    }
 }
 
 template <bool SCORE, bool GUARD = false>
@@ -722,6 +821,18 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
     case 7: return launch_direct<7, SCORE, GUARD>(ctx, n, fa, tall);
     case 8: return launch_direct<8, SCORE, GUARD>(ctx, n, fa, tall);
     }
+    if constexpr (!SCORE) {
+        switch (radius) {
+        case 9: return launch_direct<9, false, GUARD>(ctx, n, fa, tall);
+        case 10: return launch_direct<10, false, GUARD>(ctx, n, fa, tall);
+        case 11: return launch_direct<11, false, GUARD>(ctx, n, fa, tall);
+        case 12: return launch_direct<12, false, GUARD>(ctx, n, fa, tall);
+        case 13: return launch_direct<13, false, GUARD>(ctx, n, fa, tall);
+        case 14: return launch_direct<14, false, GUARD>(ctx, n, fa, tall);
+        case 15: return launch_direct<15, false, GUARD>(ctx, n, fa, tall);
+        case 16: return launch_direct<16, false, GUARD>(ctx, n, fa, tall);
+        }
+    }
     return FNX_ERR_INVALID;
 }
 
@@ -733,7 +844,7 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
 constexpr int NHEAD = 260 + 257 * 8;   // uint32 words at the head of the table blob: magic[c] (c <= 256, padded to 260), tiedown[8 c + w]
 static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH)
 {
-    if (radius < 1 || radius > FUSED_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
+    if (radius < 1 || radius > SCORE_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
         h >= (1 << 24))
         return false;
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
@@ -838,7 +949,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
                        uint8_t *planes, size_t plane, int dstW, int dstH)
 {
     if (n > 65535) return FNX_NOOP;   // grid.z
-    if (radius < 1 || radius > FUSED_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
+    if (radius < 1 || radius > SCORE_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
     const bool exact = flags & FNX_BLUR_EXACT;
     if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);
@@ -1092,10 +1203,17 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
             ga.sstride = sstride; ga.dstride = dstride; ga.w = w; ga.h = h;
             for (int i = 0; i < 2 * radius + 1; i++) {
                 ga.wt[i] = static_cast<float>(kernel[i]);
-                ga.wd[i] = kernel[i];
+                if (radius <= SCORE_RMAX) ga.wd[i] = kernel[i];
+            }
+            if (radius > SCORE_RMAX) {
+                void *dk = nullptr;
+                FNX_TRY(upload_table(ctx, SLOT_TABLE1, kernel, sizeof(double) * (2 * radius + 1), &dk));
+                ga.wdp = static_cast<const double *>(dk);
             }
             return launch_direct_radius<false, true>(ctx, radius, n, ga, direct_tall(ctx, radius, n, w, h));
         }
+        if (radius > SCORE_RMAX)              // blur_exact_kernel is built for R <= 8
+            return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
         ExactArgs ea{};
         ea.src = src; ea.srcs = srcs; ea.dst = dst; ea.dsts = dsts;
         ea.sstride = sstride; ea.dstride = dstride; ea.w = w; ea.h = h;

@@ -90,7 +90,7 @@ def _binomial(radius):
     return k            # dyadic weights summing to exactly 1: sums land on exact .5 ties
 
 
-@pytest.mark.parametrize("radius", range(1, 9))
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 16])
 def test_gaussian_blur_exact_ties(ctx, orc, radius):
     """EXACT mode on inputs built to sit on clampF's rounding boundary (convert.go:149-158).
 
@@ -110,10 +110,34 @@ def test_gaussian_blur_exact_ties(ctx, orc, radius):
 
 
 def test_gaussian_blur_exact_all_sigmas(ctx, orc):
-    """EXACT mode over every radius GaussianBlur's own kernel produces up to the fused limit and past it."""
+    """EXACT mode over every radius GaussianBlur's own kernel produces up to the fused limit and past it (r3: the tile
+    kernel takes radii 9..16 too -- sigma up to 5.33 -- with the H window streaming through)."""
     img = synth.noise_image(257, 131, 77, alpha=True)
-    for sigma in (0.3, 0.5, 0.7, 1.0, 1.3, 1.7, 2.0, 2.3, 2.6, 2.9, 3.4):
+    for sigma in (0.3, 0.5, 0.7, 1.0, 1.3, 1.7, 2.0, 2.3, 2.6, 2.9, 3.2, 3.4, 3.7, 4.0, 4.3, 4.6, 5.0, 5.3, 5.7):
         assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), orc.gaussian_blur(img, sigma)), sigma
+
+
+@pytest.mark.parametrize("sigma", [2.8, 3.1, 3.5, 3.9, 4.2, 4.5, 5.0, 5.33])
+def test_gaussian_blur_wide_radii(ctx, orc, sigma):
+    """Radii 9..16 (effects.go:153: radius = ceil(3 sigma)) in the tile kernel: fast mode within its tolerance, exact
+    mode equal, on shapes with edge tiles on every side, a device view at 4-byte alignment, and a batch."""
+    import torch
+    for (w, h, seed) in [(700, 300, 3), (64, 128, 5), (130, 97, 8), (31, 9, 2)]:
+        img = synth.noise_image(w, h, seed, alpha=True) if seed % 2 else synth.large_photo(w, h, seed)
+        want = orc.gaussian_blur(img, sigma, procs=8)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want), (sigma, w, h)
+        assert_blur_close(ctx.GaussianBlur(img, sigma), want)
+    big = synth.large_photo(1301, 420, 9)
+    d = torch.from_numpy(big).cuda()
+    torch.cuda.synchronize()
+    sub = d[5:400, 3:1200]
+    want = orc.gaussian_blur(big[5:400, 3:1200], sigma, procs=8)
+    out = ctx.GaussianBlur(sub, sigma, exact=True); ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), want)
+    imgs = [synth.large_photo(512, 384, k) for k in range(3)]
+    outs = ctx.GaussianBlurBatch([torch.from_numpy(i).cuda() for i in imgs], sigma, exact=True); ctx.sync()
+    for i, o in zip(imgs, outs):
+        assert np.array_equal(o.cpu().numpy(), orc.gaussian_blur(i, sigma, procs=8))
 
 
 @pytest.mark.parametrize("name", list(IMAGES))

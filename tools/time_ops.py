@@ -29,7 +29,14 @@ torch.cuda.synchronize()
 OPS = [
     ("GaussianBlur sigma=2 (fast)", lambda k: ctx.GaussianBlur(imgs[k], 2.0), 2 * S, False),
     ("GaussianBlur sigma=2 (exact)", lambda k: ctx.GaussianBlur(imgs[k], 2.0, exact=True), 2 * S, False),
-    ("GaussianBlur sigma=5 (generic fp32)", lambda k: ctx.GaussianBlur(imgs[k], 5.0), 2 * S, False),
+    ("GaussianBlur sigma=3 (R=9, fast)", lambda k: ctx.GaussianBlur(imgs[k], 3.0), 2 * S, False),
+    ("GaussianBlur sigma=4 (R=12, fast)", lambda k: ctx.GaussianBlur(imgs[k], 4.0), 2 * S, False),
+    ("GaussianBlur sigma=4 (R=12, exact)", lambda k: ctx.GaussianBlur(imgs[k], 4.0, exact=True), 2 * S, False),
+    ("GaussianBlur sigma=5 (R=15, fast)", lambda k: ctx.GaussianBlur(imgs[k], 5.0), 2 * S, False),
+    ("GaussianBlur sigma=5 (R=15, exact)", lambda k: ctx.GaussianBlur(imgs[k], 5.0, exact=True), 2 * S, False),
+    ("GaussianBlur sigma=5.3 (R=16, fast)", lambda k: ctx.GaussianBlur(imgs[k], 5.3), 2 * S, False),
+    ("GaussianBlur sigma=5.3 (R=16, exact)", lambda k: ctx.GaussianBlur(imgs[k], 5.3, exact=True), 2 * S, False),
+    ("GaussianBlur sigma=6 (R=18, generic fp32)", lambda k: ctx.GaussianBlur(imgs[k], 6.0), 2 * S, False),
     ("gaussianBlur3x3", lambda k: ctx.blur3x3(imgs[k]), 2 * S, False),
     ("Sharpen 0.5", lambda k: ctx.Sharpen(imgs[k], 0.5), 2 * S, False),
     ("AdaptiveSharpen 0.5", lambda k: ctx.AdaptiveSharpen(imgs[k], 0.5), 2 * S, False),
