@@ -10,8 +10,8 @@ STEPS=10 bash tools/collect_profiles.sh ${R}_onepass "" > $O/collect_onepass.log
 bash tools/collect_profiles.sh ${R}_config4 "--workload config4" > $O/collect_config4.log 2>&1
 bash tools/collect_profiles.sh ${R}_config3 "--workload config3 --contexts 1" > $O/collect_config3.log 2>&1
 python bench.py --workload config3 > $O/${R}_config3_contexts4_bench_plain.json 2> $O/c3c4.log
-python bench.py --blur-mode exact --no-cpu-baseline > $O/${R}_onepass_exact_bench_plain.json 2>> $O/c3c4.log
-python bench.py --pipeline two-call --no-cpu-baseline > $O/${R}_twocall_bench_plain.json 2>> $O/c3c4.log
+python bench.py --blur-mode exact --no-cpu-baseline --no-batch --no-extras > $O/${R}_onepass_exact_bench_plain.json 2>> $O/c3c4.log
+python bench.py --pipeline two-call --no-cpu-baseline --no-batch --no-extras > $O/${R}_twocall_bench_plain.json 2>> $O/c3c4.log
 python bench.py --workload config5 --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_bench_plain.json 2>> $O/c3c4.log
 python bench.py --workload config5 --device-search --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_device_search_bench_plain.json 2>> $O/c3c4.log
 python bench.py --workload config5 --device-codec --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_config5_device_codec_bench_plain.json 2>> $O/c3c4.log
