@@ -57,13 +57,28 @@ while time.time() < t_end:
         w, h = int(rng.integers(500, 2300)), int(rng.integers(300, 1300))
     img = rand_image(w, h)
     desc = f"seed={seed} it={it} {w}x{h}"
-    sigma = float(rng.choice([0.3, 0.7, 1.0, 1.5, 2.0, 2.6, 3.4]))
+    sigma = float(rng.choice([0.3, 0.7, 1.0, 1.5, 2.0, 2.6, 3.4, 3.9, 4.4, 5.0, 5.33]))      # r3: radii 9..16 in the tile kernel
     want = orc.gaussian_blur(img, sigma, procs=8)
     case("blur_exact", np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want), desc + f" sigma={sigma}")
     fast = ctx.GaussianBlur(img, sigma)
     dd = np.abs(fast.astype(np.int16) - want.astype(np.int16))
     case("blur_fast", blur_close(fast, want), desc + f" sigma={sigma} off={int((dd[..., :3] != 0).sum())} of {dd[..., :3].size} max={int(dd.max())} "
                                                      f"alpha_equal={np.array_equal(fast[..., 3], want[..., 3])}")
+    if w >= 6 and h >= 6 and it % 2 == 0:     # r3: SubImages (stride != 4w): the reference's flat copy(dst.Pix, img.Pix), host and device views
+        import torch
+        yv, xv = int(rng.integers(0, h // 3 + 1)), int(rng.integers(0, w // 3 + 1))
+        hv, wv = int(rng.integers(3, h - yv + 1)), int(rng.integers(3, w - xv + 1))
+        sub = img[yv:yv + hv, xv:xv + wv]
+        dsub = torch.from_numpy(img).cuda()[yv:yv + hv, xv:xv + wv]
+        sv = float(rng.uniform(0.05, 1.0))
+        vd = desc + f" view {wv}x{hv}+{xv}+{yv} s={sv}"
+        case("view_blur3x3", np.array_equal(ctx.blur3x3(sub), orc.blur3x3(sub)) and np.array_equal(ctx.blur3x3(dsub).cpu().numpy(), orc.blur3x3(sub)), vd)
+        case("view_sharpen", np.array_equal(ctx.Sharpen(sub, sv), orc.sharpen(sub, sv)) and np.array_equal(ctx.Sharpen(dsub, sv).cpu().numpy(), orc.sharpen(sub, sv)), vd)
+        case("view_adaptive", np.array_equal(ctx.AdaptiveSharpen(sub, sv), orc.adaptive_sharpen(sub, sv)) and np.array_equal(ctx.AdaptiveSharpen(dsub, sv).cpu().numpy(), orc.adaptive_sharpen(sub, sv)), vd)
+        oth = rand_image(wv, hv)
+        case("view_msssim", abs(ctx.MSSSIM(sub, oth) - orc.msssim(sub, oth)) <= SSIM_TOL and abs(ctx.MSSSIM(oth, sub) - orc.msssim(oth, sub)) <= SSIM_TOL, vd)
+        case("view_rowwise", np.array_equal(ctx.GaussianBlur(sub, 1.5, exact=True), orc.gaussian_blur(sub, 1.5)) and
+             abs(ctx.SSIMFast(sub, np.ascontiguousarray(oth)) - orc.ssim_fast(sub, oth)) <= SSIM_TOL, vd)
     st = float(rng.uniform(0.05, 1.3))
     case("sharpen", np.array_equal(ctx.Sharpen(img, st), orc.sharpen(img, st, procs=4)), desc + f" s={st}")
     case("adaptive", np.array_equal(ctx.AdaptiveSharpen(img, st), orc.adaptive_sharpen(img, st, procs=4)), desc + f" s={st}")
