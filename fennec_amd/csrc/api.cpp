@@ -232,9 +232,14 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
     // uint8 intermediate dstW x srcH (resize.go:51)
     const int tp = pitch16(dstW);
     void *tmp = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_TMP0, static_cast<size_t>(tp) * srcH + 16, &tmp));
-    FNX_TRY(resize_pass(ctx, false, th, s.p, s.stride, srcW, srcH, static_cast<uint8_t *>(tmp), tp));
-    FNX_TRY(resize_pass(ctx, true, tv, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, d.p, d.stride));
+    // ... followed by the H pass's verdict cells for the V pass (ResizeHint): at most one per 128 x 8 tmp pixels
+    const size_t tmp_bytes = (static_cast<size_t>(tp) * srcH + 16 + 15) & ~size_t(15);
+    ResizeHint hint;
+    hint.cap = (static_cast<size_t>(dstW) / 128 + 2) * (static_cast<size_t>(srcH) / 8 + 2);
+    FNX_TRY(scratch(ctx, SLOT_TMP0, tmp_bytes + sizeof(uint32_t) * hint.cap, &tmp));
+    hint.cells = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(tmp) + tmp_bytes);
+    FNX_TRY(resize_pass(ctx, false, th, s.p, s.stride, srcW, srcH, static_cast<uint8_t *>(tmp), tp, &hint));
+    FNX_TRY(resize_pass(ctx, true, tv, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, d.p, d.stride, &hint));
     return finish(ctx, space, &d);
 }
 

@@ -258,8 +258,16 @@ int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride,
                    double amount, uint8_t *dst, int dstride);
 // One pass of lanczosResize through the ctx's plan cache: guard-exact fp32 kernels where the table allows,
 // the fp64 kernels otherwise.  vertical == false: dst is t.nout x srcH; true: dst is srcW x t.nout.
+// `hint` (optional) carries the H pass's per-workgroup verdicts to the V pass of the same lanczosResize call: where
+// most H waves found their rows dense with rounding-guard flags the V pass skips its fp32 form (resize.hip).
+struct ResizeHint {
+    uint32_t *cells = nullptr;     // device, `cap` words
+    size_t cap = 0;
+    int gx = 0, gy = 0, rows = 0;  // filled by the H pass
+    bool valid = false;
+};
 int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
-                uint8_t *dst, int dstride);
+                uint8_t *dst, int dstride, ResizeHint *hint = nullptr);
 void free_resize_plans(fnx_ctx *ctx);
 // lanczosResize (resize.go:37-53) with both tables given: the body of fnx_lanczos_resize
 int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,

@@ -30,6 +30,25 @@ __device__ __forceinline__ uint32_t clampF_dev(double x)
     return static_cast<uint32_t>(static_cast<int>(t));
 }
 
+// clampF in three instructions for the exact (fp64) resize loops: min(u32(trunc(x + pred(0.5))), 255).
+// Why it equals clampF (convert.go:149-158) for every finite x below 2^63 (tests/test_oracle_exact.py replays it):
+//  * x < 0 or NaN: math.Round gives -0 / a negative / int64(NaN) < 0 -> 0; here x + c < 0.5 truncates to 0 or is
+//    negative / NaN, and v_cvt_u32_f64 saturates both to 0.
+//  * 0 <= x, n = floor(x), u = ulp(x), c = 0.5 - 2^-54.  x >= n + 0.5: x + c >= n + 1 - 2^-54, which for n >= 1
+//    lies closer to n + 1 than to the double below it (spacing >= 2^-52), and for n = 0 is the tie 1 - 2^-54 between
+//    1 - 2^-53 (odd) and 1.0 (even) or above it: the sum rounds to >= n + 1.  x < n + 0.5: x <= n + 0.5 - u (both are
+//    multiples of u when u <= 0.5), so x + c <= (n + 1 - u) - 2^-54 rounds to at most the double n + 1 - u.  (For
+//    x < 0.5 that reads x <= 0.5 - 2^-54, whose sum 1 - 2^-53 is exact.)  u >= 1: x is an integer and c < u / 2.
+//    [floor(fl(x + 0.5)) is wrong for the one double 0.5 - 2^-54, which this form gets right.]
+//  * the convert truncates and saturates at 2^32 - 1; the min makes that 255 = the reference's v > 255 branch.
+__device__ __forceinline__ uint32_t clampF_fast64(double x)
+{
+    const double t = x + 0.49999999999999994;
+    uint32_t i;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(i) : "v"(t));
+    return min(i, 255u);
+}
+
 // fast-mode rounding of an fp32 accumulator into byte `sel` of `old`:
 // floor(x+0.5) then saturating u8 convert + pack (v_cvt_pk_u8_f32).
 __device__ __forceinline__ uint32_t pack_u8(float x, uint32_t sel, uint32_t old)

@@ -305,6 +305,13 @@ struct ResizeGuardArgs {
     // exact fix-ups
     const int32_t *off, *idx;
     const double *wt;
+    // lanczosResize's two passes talk: the H pass leaves, per workgroup, how many of its 4 waves found their first row
+    // dense with flags (0..4) in hint[by * hint_gx + bx]; the V pass of the SAME call reads the cells over its columns
+    // and source rows and, where most waves were dense (ramps at integer ratios, translucent regions), goes straight
+    // to its exact sweep instead of computing the fp32 form first and throwing it away.  A heuristic about cost only:
+    // the exact sweep is the reference's arithmetic whatever the hint says.  nullptr: no hint.
+    uint32_t *hint;
+    int hint_gx, hint_gy, hint_rows;   // H grid; tmp rows per H workgroup (its columns: 64 * RG_HO outputs)
 };
 
 // one output exactly as resizeH / resizeV compute it (resize.go:93-113 / 137-156).  The guard kernels only run
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
 {
     constexpr int HO = RG_HO, NPX = 4 * NV;
     __shared__ uint32_t s_fix[RG_FIX_CAP];
-    __shared__ int s_nfix;
+    __shared__ int s_nfix, s_ndense;
     // per workgroup (64 groups): fp64 aw [HO][NPX][64] for the exact loop, then the fp32 weight pairs
     // [NPX][64] (output 0, output 1) of the guard loop -- one conflict-free ds_read_b64 per pixel instead of
     // 2 NPX registers per lane (the 8-vector window then still runs at 4+ waves per SIMD with its prefetch)
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
     v2f *s_w = reinterpret_cast<v2f *>(s_aw + HO * NPX * 64);
     const int tid = threadIdx.x;
     constexpr bool WREG = NV <= 4;      // the wave's weight pairs ride in registers (32 VGPRs) instead of 16 LDS reads per row
-    if (tid == 0) s_nfix = 0;
+    if (tid == 0) { s_nfix = 0; s_ndense = 0; }
     if constexpr (WREG) __syncthreads();        // the list's counter is in place before anybody adds to it: crossed at once,
                                                 // with nothing in flight yet (no weights are staged on this path)
     // issued before the staging below so that the three latencies overlap (a workgroup is short)
@@ -499,6 +506,7 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
                     // (the reference's ramps at an integer ratio) walking the rest of the rows here -- loading every
                     // one, trying every fourth -- was 6.4 us of a wave's 27 (per-wave timestamps) for nothing
                     exact_rows = (y1 - yw >= 32) ? 0xffffffffu : ((1u << (y1 - yw)) - 1u);
+                    if (lane == 0) atomicAdd(&s_ndense, 1);
                     break;
                 }
                 exact_rows |= 1u << (y - yw);
@@ -526,76 +534,114 @@ __global__ __launch_bounds__(256) void resize_h_guard_kernel(ResizeGuardArgs a)
         }
     }
     // ---- exact loop: resizeH's own arithmetic (resize.go:93-113) for the marked rows.  Opaque windows:
-    // aw = 255 w and inv = 1 / sum aw are per column, so a row is r += R * aw (unfused, ascending taps; the
-    // dense window's zero weights add +0.0) and clampF(r * inv); other windows: resize_exact_px.  The fp64
-    // weights are staged only now, and only if some wave of the workgroup marked a row.
-    if (__syncthreads_or(exact_rows != 0)) {
-        const int g0 = blockIdx.x * 64;
-        for (int e = tid; e < HO * NPX * 64; e += 256) {
-            const int gl = e & 63, ji = e >> 6;
-            s_aw[e] = g0 + gl < a.ngroups ? a.aw[static_cast<size_t>(ji) * a.ngroups + g0 + gl] : 0.0;
+    // aw = 255 w and inv = 1 / sum aw are per column, so a row is r += R * aw (unfused, ascending taps) and
+    // clampF(r * inv); other windows: resize_exact_px.  The dense window's zero weights would add +0.0 (r + R * 0.0 == r
+    // exactly: r is never -0.0), so a (pixel, output) pair whose weight is zero in EVERY lane of the wave is skipped
+    // outright -- wave-uniform masks, scalar branches: at a 2:1 ratio 24 of the 32 pairs are left, and two of the
+    // sixteen pixels are not even converted.  The fp64 weights are staged in LDS, and only if some wave of the workgroup
+    // marked a row.  (AWREG -- a lane's 2 x NPX fp64 weights in registers instead -- costs the whole kernel its
+    // occupancy: 163 VGPRs at NV = 4 against 119, 111 against 80 at NV = 2; kept for experiments.)
+    constexpr bool AWREG = false;
+    bool any_exact = exact_rows != 0;
+    if constexpr (!AWREG) {
+        any_exact = __syncthreads_or(exact_rows != 0);
+        if (any_exact) {
+            const int g0 = blockIdx.x * 64;
+            for (int e = tid; e < HO * NPX * 64; e += 256) {
+                const int gl = e & 63, ji = e >> 6;
+                s_aw[e] = g0 + gl < a.ngroups ? a.aw[static_cast<size_t>(ji) * a.ngroups + g0 + gl] : 0.0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (exact_rows) {
-            const int gc = min(g, a.ngroups - 1);
-            const int s0 = a.s0[gc];
-            const uint32_t ab = a.alpha[gc];
-            const int d0 = gc * HO;
-            const bool st8 = d0 + HO <= a.nout && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 7u) == 0;
-            const int y1 = min(a.other, yw + a.rows);
-            auto load_row = [&](int y, u32x4 (&v)[NV]) {
-                const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+    }
+    if (exact_rows) {                                               // wave-uniform
+        const int gc = min(g, a.ngroups - 1);
+        const int s0 = a.s0[gc];
+        const uint32_t ab = a.alpha[gc];
+        const int d0 = gc * HO;
+        const bool st8 = d0 + HO <= a.nout && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 7u) == 0;
+        auto load_row = [&](int y, u32x4 (&v)[NV]) {
+            const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
 #pragma unroll
-                for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
-            };
-            const double inv0 = a.inv[d0], inv1 = a.inv[min(d0 + 1, a.nout - 1)];
-            // the marked rows one after the other (exact_rows is wave-uniform), the next one's window in flight while
-            // this one is computed: without that every row would wait out a memory latency on its own
-            uint32_t todo = __builtin_amdgcn_readfirstlane(exact_rows);
-            u32x4 vnx[NV];
-            load_row(yw + __builtin_ctz(todo), vnx);
-            while (todo) {
-                const int y = yw + __builtin_ctz(todo);
-                todo &= todo - 1;
-                u32x4 v[NV];
+            for (int q = 0; q < NV; q++) v[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
+        };
+        // the marked rows one after the other (exact_rows is wave-uniform), the next one's window in flight while
+        // this one is computed: without that every row would wait out a memory latency on its own
+        uint32_t todo = __builtin_amdgcn_readfirstlane(exact_rows);
+        u32x4 vnx[NV];
+        load_row(yw + __builtin_ctz(todo), vnx);
+        const double inv0 = a.inv[d0], inv1 = a.inv[min(d0 + 1, a.nout - 1)];
+        double w0[AWREG ? NPX : 1], w1[AWREG ? NPX : 1];
+        if constexpr (AWREG) {
 #pragma unroll
-                for (int q = 0; q < NV; q++) v[q] = vnx[q];
-                load_row(todo ? yw + __builtin_ctz(todo) : y, vnx);  // (the last row loads itself again: no branch around a load)
-                (void)y1;
-                uint32_t andp = 0xffffffffu;
+            for (int i = 0; i < NPX; i++) {
+                w0[i] = a.aw[static_cast<size_t>(i) * a.ngroups + gc];
+                w1[i] = a.aw[static_cast<size_t>(NPX + i) * a.ngroups + gc];
+            }
+        }
+        uint32_t nz0 = 0, nz1 = 0;                                  // bit i: pixel i feeds output 0 / 1 in some lane of this wave
 #pragma unroll
-                for (int q = 0; q < NV; q++) andp &= (v[q][0] & v[q][1]) & (v[q][2] & v[q][3]);
-                uint32_t o0, o1;
-                if (__all((andp >> 24) == 0xffu || !active)) {
-                    double r0 = 0, g0 = 0, b0 = 0, r1 = 0, g1 = 0, b1 = 0;
+        for (int i = 0; i < NPX; i++) {
+            const double x0 = AWREG ? w0[AWREG ? i : 0] : s_aw[i * 64 + lane];
+            const double x1 = AWREG ? w1[AWREG ? i : 0] : s_aw[(NPX + i) * 64 + lane];
+            if (__ballot(x0 != 0.0) != 0ull) nz0 |= 1u << i;
+            if (__ballot(x1 != 0.0) != 0ull) nz1 |= 1u << i;
+        }
+        nz0 = __builtin_amdgcn_readfirstlane(nz0);
+        nz1 = __builtin_amdgcn_readfirstlane(nz1);
+        while (todo) {
+            const int y = yw + __builtin_ctz(todo);
+            todo &= todo - 1;
+            u32x4 v[NV];
 #pragma unroll
-                    for (int i = 0; i < NPX; i++) {
+            for (int q = 0; q < NV; q++) v[q] = vnx[q];
+            load_row(todo ? yw + __builtin_ctz(todo) : y, vnx);      // (the last row loads itself again: no branch around a load)
+            uint32_t andp = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NV; q++) andp &= (v[q][0] & v[q][1]) & (v[q][2] & v[q][3]);
+            uint32_t o0, o1;
+            if (__all((andp >> 24) == 0xffu || !active)) {
+                double r0 = 0, g0 = 0, b0 = 0, r1 = 0, g1 = 0, b1 = 0;
+                // the masks are laundered once per row: otherwise the compiler hoists all 3 NPX tests out of the row
+                // loop as 64-bit lane masks and spills SGPRs into VGPR lanes (two v_readlane per branch)
+                uint32_t m0 = nz0, m1 = nz1;
+                asm volatile("" : "+s"(m0), "+s"(m1));
+                // weights one pixel ahead of their use (unconditional LDS reads: a read issued inside a branch is waited
+                // for on the spot, ~100 clocks per (pixel, output) pair)
+                double nx0 = AWREG ? 0.0 : s_aw[lane], nx1 = AWREG ? 0.0 : s_aw[NPX * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < NPX; i++) {
+                    const double aw0 = AWREG ? w0[AWREG ? i : 0] : nx0, aw1 = AWREG ? w1[AWREG ? i : 0] : nx1;
+                    if constexpr (!AWREG)
+                        if (i + 1 < NPX) { nx0 = s_aw[(i + 1) * 64 + lane]; nx1 = s_aw[(NPX + i + 1) * 64 + lane]; }
+                    if (((m0 | m1) >> i) & 1u) {                         // scalar
                         const uint32_t p = v[i / 4][i % 4];
                         const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
-                        const double aw0 = s_aw[i * 64 + lane], aw1 = s_aw[(NPX + i) * 64 + lane];
-                        r0 = r0 + fr * aw0; g0 = g0 + fg * aw0; b0 = b0 + fb * aw0;
-                        r1 = r1 + fr * aw1; g1 = g1 + fg * aw1; b1 = b1 + fb * aw1;
-                        __builtin_amdgcn_sched_barrier(0);
+                        // (the empty asm keeps the compiler from if-converting the body into six multiply-adds + six selects)
+                        if ((m0 >> i) & 1u) { asm volatile(""); r0 = r0 + fr * aw0; g0 = g0 + fg * aw0; b0 = b0 + fb * aw0; }
+                        if ((m1 >> i) & 1u) { asm volatile(""); r1 = r1 + fr * aw1; g1 = g1 + fg * aw1; b1 = b1 + fb * aw1; }
                     }
-                    o0 = clampF_dev(r0 * inv0) | (clampF_dev(g0 * inv0) << 8) | (clampF_dev(b0 * inv0) << 16) | ((ab & 0xffu) << 24);
-                    o1 = clampF_dev(r1 * inv1) | (clampF_dev(g1 * inv1) << 8) | (clampF_dev(b1 * inv1) << 16) | ((ab & 0xff00u) << 16);
-                } else {
-                    o0 = resize_exact_px<false>(a, d0, y);
-                    o1 = resize_exact_px<false>(a, min(d0 + 1, a.nout - 1), y);
                 }
-                if (active) {
-                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(d0);
-                    if (st8) {
-                        *(__attribute__((address_space(1))) u32x2 *)dp = (u32x2){o0, o1};
-                    } else {
-                        *(g_u32w *)dp = o0;
-                        if (d0 + 1 < a.nout) *(g_u32w *)(dp + 4) = o1;
-                    }
+                o0 = clampF_fast64(r0 * inv0) | (clampF_fast64(g0 * inv0) << 8) | (clampF_fast64(b0 * inv0) << 16) | ((ab & 0xffu) << 24);
+                o1 = clampF_fast64(r1 * inv1) | (clampF_fast64(g1 * inv1) << 8) | (clampF_fast64(b1 * inv1) << 16) | ((ab & 0xff00u) << 16);
+            } else {
+                o0 = resize_exact_px<false>(a, d0, y);
+                o1 = resize_exact_px<false>(a, min(d0 + 1, a.nout - 1), y);
+            }
+            if (active) {
+                uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(d0);
+                if (st8) {
+                    *(__attribute__((address_space(1))) u32x2 *)dp = (u32x2){o0, o1};
+                } else {
+                    *(g_u32w *)dp = o0;
+                    if (d0 + 1 < a.nout) *(g_u32w *)(dp + 4) = o1;
                 }
             }
         }
     }
+    (void)any_exact;
     __syncthreads();
+    if (tid == 0 && a.hint) a.hint[blockIdx.y * a.hint_gx + blockIdx.x] = static_cast<uint32_t>(s_ndense);
     // exact outputs for the listed ones (never stored above)
     const int nfix = s_nfix;
     const int bx0 = blockIdx.x * 64 * HO, by0 = blockIdx.y * 4 * a.rows;
@@ -627,6 +673,7 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
     // nothing to overlap it with) into every iteration.  The host keeps the union at <= 64 rows.
     __shared__ __attribute__((aligned(16))) float s_wv[64 * VG];
     __shared__ __attribute__((aligned(16))) double s_awv[(64 + 4) * VG];   // + one zero trip of the exact sweep
+    __shared__ uint32_t s_tm[16 + 1];                                // per trip of 4 union rows: bit 4 k + j = row k feeds output row j
     const int tid = threadIdx.x;
     const int grp = blockIdx.y;
     if (tid == 0) s_nfix = 0;
@@ -640,6 +687,18 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
         const int yy = min(grp * VG + j, a.nout - 1);
         alv[j] = a.alpha[yy];
         invv[j] = a.inv[yy];
+    }
+    // the H pass's verdict on the tmp rows and columns this workgroup reads (see ResizeGuardArgs::hint): lane e of every
+    // wave takes one cell, two row bands x eight column blocks at most
+    uint32_t cell = 0;
+    int ncell = 0;
+    if (a.hint) {
+        const int bx0 = (blockIdx.x * 256 * PX) / (64 * RG_HO), bx1 = min(bx0 + (256 * PX) / (64 * RG_HO), a.hint_gx);
+        const int by0 = min(s0 / a.hint_rows, a.hint_gy - 1), by1 = min((s0 + nr - 1) / a.hint_rows, a.hint_gy - 1);
+        const int nx = bx1 - bx0;
+        ncell = nx * (by1 - by0 + 1);
+        const int e = tid & 63;
+        if (e < ncell) cell = a.hint[(by0 + e / nx) * a.hint_gx + bx0 + e % nx];
     }
     // ... and so are the first four source rows: issued before the weights are staged and the barrier is crossed, so that
     // the two latencies overlap (idle lanes and waves read the last columns: clamped, harmless)
@@ -657,13 +716,18 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
     u32x4 t1 = load(s0), t2 = load(s0 + min(1, nr - 1)), t3 = load(s0 + min(2, nr - 1)), t4 = load(s0 + min(3, nr - 1));
     {
         const int nw = nr * VG;
+        double awt = 0.0;
         if (tid < nw) {
             s_wv[tid] = a.dense[static_cast<size_t>(grp) * a.npx * VG + tid];
-            s_awv[tid] = a.aw[static_cast<size_t>(grp) * a.npx * VG + tid];
-        } else {
-            s_awv[tid] = 0.0;                                       // the exact sweep walks the union in fours: r + f * 0.0 == r
+            awt = a.aw[static_cast<size_t>(grp) * a.npx * VG + tid];
         }
+        s_awv[tid] = awt;                                           // past the union: zeros (the sweep walks it in fours)
         if (tid < 4 * VG) s_awv[64 * VG + tid] = 0.0;
+        // which (union row, output row) pairs carry a weight at all: a wave's ballot is 16 rows = 4 trips
+        const uint64_t nzb = __ballot(awt != 0.0);
+        const int l = tid & 63;
+        if (l < 4) s_tm[(tid >> 6) * 4 + l] = static_cast<uint32_t>(nzb >> (16 * l)) & 0xffffu;
+        if (tid == 0) s_tm[16] = 0;
     }
     __syncthreads();
     const int xw = (blockIdx.x * 256 + (tid & ~63)) * PX;           // first column of this wave
@@ -674,97 +738,109 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
         // recomputes columns its neighbour owns and stores the same values -- no branch around the loads (see
         // the H pass).  ALIGNED: src base, stride and other % 4 allow 16-byte loads at every lane.
         const int ncol = active ? PX : 0;
-        const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
-        v2f acc[VG][6];                                             // (r0,g0) (b0,r1) (g1,b1) (r2,g2) (b2,r3) (g3,b3)
-#pragma unroll
-        for (int j = 0; j < VG; j++)
-#pragma unroll
-            for (int q = 0; q < 6; q++) acc[j][q] = (v2f){seed, seed};
-        u32x4 andp = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        // four source rows in flight per lane (see the H pass: a wave's own prefetch is all it has outstanding)
-        for (int i = 0; i < nr; i++) {
-            const u32x4 t = t1;
-            t1 = t2; t2 = t3; t3 = t4;
-            t4 = load(s0 + min(i + 4, nr - 1));
-            andp &= t;
-            v2f f[6];
-            f[0] = (v2f){static_cast<float>(t[0] & 0xffu), static_cast<float>((t[0] >> 8) & 0xffu)};
-            f[1] = (v2f){static_cast<float>((t[0] >> 16) & 0xffu), static_cast<float>(t[1] & 0xffu)};
-            f[2] = (v2f){static_cast<float>((t[1] >> 8) & 0xffu), static_cast<float>((t[1] >> 16) & 0xffu)};
-            f[3] = (v2f){static_cast<float>(t[2] & 0xffu), static_cast<float>((t[2] >> 8) & 0xffu)};
-            f[4] = (v2f){static_cast<float>((t[2] >> 16) & 0xffu), static_cast<float>(t[3] & 0xffu)};
-            f[5] = (v2f){static_cast<float>((t[3] >> 8) & 0xffu), static_cast<float>((t[3] >> 16) & 0xffu)};
-#pragma unroll
-            for (int j = 0; j < VG; j++) {
-                const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wv[i * VG + j])));
-#pragma unroll
-                for (int q = 0; q < 6; q++) acc[j][q] = __builtin_elementwise_fma(f[q], (v2f){wj, wj}, acc[j][q]);
-            }
-        }
-        // windows are per output row; the union's AND is a conservative opacity test for all VG of them
-        uint32_t opq = 0;                                           // bit e: column e is opaque over the union
-#pragma unroll
-        for (int e = 0; e < PX; e++)
-            if ((andp[e] >> 24) == 0xffu) opq |= 1u << e;
         const uint32_t own = (1u << ncol) - 1u;
         const bool st16 = ALIGNED && ((reinterpret_cast<uintptr_t>(a.dst) | static_cast<uintptr_t>(a.dstride)) & 15u) == 0;
+        const uint32_t valid_rows = (y0 + VG <= a.nout) ? (1u << VG) - 1u : (1u << (a.nout - y0)) - 1u;
+        const bool hinted = ncell > 0 && 2 * __popcll(__ballot(cell >= 2u)) >= ncell;   // wave-uniform
         uint32_t dense_rows = 0;
+        if (hinted) {
+            dense_rows = valid_rows;                                // every row of the group straight to the exact sweep
+        } else {
+            const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+            v2f acc[VG][6];                                         // (r0,g0) (b0,r1) (g1,b1) (r2,g2) (b2,r3) (g3,b3)
 #pragma unroll
-        for (int j = 0; j < VG; j++) {
-            const int y = y0 + j;
-            if (y < a.nout) {                                       // wave-uniform
-                const uint32_t al = alv[j];
-                u32x4 o, p;
-                fp32_round_toward_zero();
-                o[0] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al)));
-                o[1] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al)));
-                o[2] = pk8(acc[j][4].x, 2, pk8(acc[j][3].y, 1, pk8(acc[j][3].x, 0, al)));
-                o[3] = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, al)));
-                fp32_round_nearest();
-                v2f h[6];
+            for (int j = 0; j < VG; j++)
 #pragma unroll
-                for (int q = 0; q < 6; q++) h[q] = acc[j][q] + (v2f){g2, g2};
-                fp32_round_toward_zero();
-                p[0] = pk8(h[1].x, 2, pk8(h[0].y, 1, pk8(h[0].x, 0, al)));
-                p[1] = pk8(h[2].y, 2, pk8(h[2].x, 1, pk8(h[1].y, 0, al)));
-                p[2] = pk8(h[4].x, 2, pk8(h[3].y, 1, pk8(h[3].x, 0, al)));
-                p[3] = pk8(h[5].y, 2, pk8(h[5].x, 1, pk8(h[4].y, 0, al)));
-                fp32_round_nearest();
-                uint32_t fl = ~opq;                                 // bit e: column e awaits the exact recompute
+                for (int q = 0; q < 6; q++) acc[j][q] = (v2f){seed, seed};
+            u32x4 andp = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            // four source rows in flight per lane (see the H pass: a wave's own prefetch is all it has outstanding)
+            for (int i = 0; i < nr; i++) {
+                const u32x4 t = t1;
+                t1 = t2; t2 = t3; t3 = t4;
+                t4 = load(s0 + min(i + 4, nr - 1));
+                andp &= t;
+                v2f f[6];
+                f[0] = (v2f){static_cast<float>(t[0] & 0xffu), static_cast<float>((t[0] >> 8) & 0xffu)};
+                f[1] = (v2f){static_cast<float>((t[0] >> 16) & 0xffu), static_cast<float>(t[1] & 0xffu)};
+                f[2] = (v2f){static_cast<float>((t[1] >> 8) & 0xffu), static_cast<float>((t[1] >> 16) & 0xffu)};
+                f[3] = (v2f){static_cast<float>(t[2] & 0xffu), static_cast<float>((t[2] >> 8) & 0xffu)};
+                f[4] = (v2f){static_cast<float>((t[2] >> 16) & 0xffu), static_cast<float>(t[3] & 0xffu)};
+                f[5] = (v2f){static_cast<float>((t[3] >> 8) & 0xffu), static_cast<float>((t[3] >> 16) & 0xffu)};
 #pragma unroll
-                for (int e = 0; e < PX; e++)
-                    if (o[e] != p[e]) fl |= 1u << e;
-                fl &= own;
-                if (__popcll(__ballot(fl != 0)) >= RG_DENSE) {      // wave-uniform: this row goes to the exact sweep
-                    dense_rows |= 1u << j;
-                    continue;
+                for (int j = 0; j < VG; j++) {
+                    const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wv[i * VG + j])));
+#pragma unroll
+                    for (int q = 0; q < 6; q++) acc[j][q] = __builtin_elementwise_fma(f[q], (v2f){wj, wj}, acc[j][q]);
                 }
-                if (active) {
-                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
-                    if (st16 && fl == 0) {
-                        *(g_u32x4w *)dp = o;
-                    } else {
+            }
+            // windows are per output row; the union's AND is a conservative opacity test for all VG of them
+            uint32_t opq = 0;                                       // bit e: column e is opaque over the union
 #pragma unroll
-                        for (int e = 0; e < PX; e++)
-                            if (e < ncol) {
-                                if (!((fl >> e) & 1u)) *(g_u32w *)(dp + 4 * e) = o[e];
-                                else s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(j) << 28) | static_cast<uint32_t>(x + e);   // absolute column (< 2^24)
-                            }
+            for (int e = 0; e < PX; e++)
+                if ((andp[e] >> 24) == 0xffu) opq |= 1u << e;
+#pragma unroll
+            for (int j = 0; j < VG; j++) {
+                const int y = y0 + j;
+                if (y < a.nout) {                                   // wave-uniform
+                    const uint32_t al = alv[j];
+                    u32x4 o, p;
+                    fp32_round_toward_zero();
+                    o[0] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al)));
+                    o[1] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al)));
+                    o[2] = pk8(acc[j][4].x, 2, pk8(acc[j][3].y, 1, pk8(acc[j][3].x, 0, al)));
+                    o[3] = pk8(acc[j][5].y, 2, pk8(acc[j][5].x, 1, pk8(acc[j][4].y, 0, al)));
+                    fp32_round_nearest();
+                    v2f h[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) h[q] = acc[j][q] + (v2f){g2, g2};
+                    fp32_round_toward_zero();
+                    p[0] = pk8(h[1].x, 2, pk8(h[0].y, 1, pk8(h[0].x, 0, al)));
+                    p[1] = pk8(h[2].y, 2, pk8(h[2].x, 1, pk8(h[1].y, 0, al)));
+                    p[2] = pk8(h[4].x, 2, pk8(h[3].y, 1, pk8(h[3].x, 0, al)));
+                    p[3] = pk8(h[5].y, 2, pk8(h[5].x, 1, pk8(h[4].y, 0, al)));
+                    fp32_round_nearest();
+                    uint32_t fl = ~opq;                             // bit e: column e awaits the exact recompute
+#pragma unroll
+                    for (int e = 0; e < PX; e++)
+                        if (o[e] != p[e]) fl |= 1u << e;
+                    fl &= own;
+                    if (__popcll(__ballot(fl != 0)) >= RG_DENSE) {  // wave-uniform: this row goes to the exact sweep
+                        dense_rows |= 1u << j;
+                        continue;
+                    }
+                    if (active) {
+                        uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
+                        if (st16 && fl == 0) {
+                            *(g_u32x4w *)dp = o;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < PX; e++)
+                                if (e < ncol) {
+                                    if (!((fl >> e) & 1u)) *(g_u32w *)(dp + 4 * e) = o[e];
+                                    else s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(j) << 28) | static_cast<uint32_t>(x + e);   // absolute column (< 2^24)
+                                }
+                        }
                     }
                 }
             }
         }
         if (dense_rows) {                                           // wave-uniform
+            // ---- exact sweep: resizeV's own arithmetic for opaque columns (resize.go:137-156), a column pair at a time
+            // (24 fp64 accumulators), four union rows per trip with the next four in flight (rows past the union are the
+            // last one again: no branch around a load; their weights are zero).  A (union row, output row) pair without a
+            // weight would add +0.0 (r + f * 0.0 == r exactly: r is never -0.0) and is skipped -- the weights are
+            // wave-uniform, so these are scalar branches on the trip's mask: at a 2:1 ratio 12 of a group's ~19 union
+            // rows feed each output row.  Output rows that are not in dense_rows are masked out the same way.
+            const uint32_t rowsel = __builtin_amdgcn_readfirstlane(dense_rows) * 0x1111u;
+            uint32_t opq = 0;
 #pragma unroll 1
-            for (int c = 0; c < PX; c += 2) {                       // a column pair at a time: 24 fp64 accumulators
+            for (int c = 0; c < PX; c += 2) {
                 double r[VG][6];
 #pragma unroll
                 for (int j = 0; j < VG; j++)
 #pragma unroll
                     for (int q = 0; q < 6; q++) r[j][q] = 0.0;
                 const int c0 = min(c, max(ncol - 1, 0)), c1 = min(c + 1, max(ncol - 1, 0));
-                // four union rows per trip, the next four in flight meanwhile (rows past the union are the last one
-                // again with zero weights: no branch around a load, and r + f * 0.0 == r)
                 uint32_t n0[4], n1[4];
                 auto load4 = [&](int i0, uint32_t (&u0)[4], uint32_t (&u1)[4]) {
 #pragma unroll
@@ -775,36 +851,56 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
                     }
                 };
                 load4(0, n0, n1);
+                uint32_t and0 = 0xffffffffu, and1 = 0xffffffffu;
+                uint32_t tmn = s_tm[0];
+                const double2 *wrow = reinterpret_cast<const double2 *>(s_awv);
 #pragma unroll 1
                 for (int i = 0; i < nr; i += 4) {
                     uint32_t u0[4], u1[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) { u0[k] = n0[k]; u1[k] = n1[k]; }
                     load4(i + 4, n0, n1);
+                    const uint32_t tm = __builtin_amdgcn_readfirstlane(tmn) & rowsel;
+                    tmn = s_tm[(i >> 2) + 1];                       // (entry 16 is zero)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
+                        // the row's four weights: read before the converts that hide the LDS latency, used after them
+                        const double2 wa = wrow[(i + k) * 2], wb = wrow[(i + k) * 2 + 1];
+                        const double wj[VG] = {wa.x, wa.y, wb.x, wb.y};
                         const uint32_t q0 = u0[k], q1 = u1[k];
-                        const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
-                        const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+                        and0 &= q0; and1 &= q1;
+                        if ((tm >> (4 * k)) & 0xfu) {               // scalar
+                            const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                            const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
 #pragma unroll
-                        for (int j = 0; j < VG; j++) {
-                            const double aw = s_awv[(i + k) * VG + j];   // 255 w, or 0.0 outside row j's taps / past the union
-                            r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
-                            r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                            for (int j = 0; j < VG; j++) {
+                                if ((tm >> (4 * k + j)) & 1u) {     // scalar
+                                    asm volatile("");               // (a real branch: not six multiply-adds + six selects)
+                                    const double aw = wj[j];
+                                    r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                                    r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                                }
+                            }
                         }
                     }
                 }
+                const bool q0ok = (and0 >> 24) == 0xffu, q1ok = (and1 >> 24) == 0xffu;
+                if (q0ok) opq |= 1u << c;
+                if (q1ok) opq |= 2u << c;
 #pragma unroll
                 for (int j = 0; j < VG; j++) {
-                    const int y = y0 + j;
                     if (!((dense_rows >> j) & 1u) || !active) continue;
                     const uint32_t al = alv[j];
                     const double inv = invv[j];
-                    uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x);
-                    if (c < ncol && ((opq >> c) & 1u))
-                        *(g_u32w *)(dp + 4 * c) = clampF_dev(r[j][0] * inv) | (clampF_dev(r[j][1] * inv) << 8) | (clampF_dev(r[j][2] * inv) << 16) | al;
-                    if (c + 1 < ncol && ((opq >> (c + 1)) & 1u))
-                        *(g_u32w *)(dp + 4 * (c + 1)) = clampF_dev(r[j][3] * inv) | (clampF_dev(r[j][4] * inv) << 8) | (clampF_dev(r[j][5] * inv) << 16) | al;
+                    uint8_t *dp = a.dst + static_cast<size_t>(y0 + j) * a.dstride + 4 * static_cast<size_t>(x);
+                    const uint32_t o0 = clampF_fast64(r[j][0] * inv) | (clampF_fast64(r[j][1] * inv) << 8) | (clampF_fast64(r[j][2] * inv) << 16) | al;
+                    const uint32_t o1 = clampF_fast64(r[j][3] * inv) | (clampF_fast64(r[j][4] * inv) << 8) | (clampF_fast64(r[j][5] * inv) << 16) | al;
+                    if (q0ok && q1ok && c + 1 < ncol && st16) {      // (st16: 8-byte aligned as well)
+                        *(__attribute__((address_space(1))) u32x2 *)(dp + 4 * c) = (u32x2){o0, o1};
+                    } else {
+                        if (c < ncol && q0ok) *(g_u32w *)(dp + 4 * c) = o0;
+                        if (c + 1 < ncol && q1ok) *(g_u32w *)(dp + 4 * (c + 1)) = o1;
+                    }
                 }
             }
             // columns with some alpha != 255 in the union: the general arithmetic, once the 24 accumulators are dead
@@ -1112,13 +1208,15 @@ template <int NV>
 static void launch_h_guard(fnx_ctx *ctx, const ResizeGuardArgs &ga, dim3 grid)
 {
     // the next row's window is prefetched while the registers allow it
-    hipLaunchKernelGGL((resize_h_guard_kernel<NV, (NV <= 5)>), grid, dim3(256), (sizeof(double) * RG_HO + 2 * sizeof(float)) * 4 * NV * 64, ctx->stream, ga);
+    // NV <= 4: the fp32 weight pairs ride in registers (WREG); the LDS holds the exact loop's fp64 weights only
+    const size_t lds = (sizeof(double) * RG_HO + (NV <= 4 ? 0 : 2 * sizeof(float))) * 4 * NV * 64;
+    hipLaunchKernelGGL((resize_h_guard_kernel<NV, (NV <= 5)>), grid, dim3(256), lds, ctx->stream, ga);
 }
 
 // one pass of lanczosResize: resizeH (vertical == false: src is srcW x srcH, dst outN x srcH) or resizeV
 // (src is srcW x srcH, dst srcW x outN); t.nout == outN
 int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
-                uint8_t *dst, int dstride)
+                uint8_t *dst, int dstride, ResizeHint *hint)
 {
     if (t.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_OK;
     fnx_resize_plan *p = nullptr;
@@ -1134,6 +1232,9 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
         ga.off = p->d_off; ga.idx = p->d_idx; ga.wt = p->d_wt;
         ga.aw = p->d_aw; ga.inv = p->d_inv;
         if (vertical) {
+            if (hint && hint->valid) {                               // the H pass of this call left its verdicts
+                ga.hint = hint->cells; ga.hint_gx = hint->gx; ga.hint_gy = hint->gy; ga.hint_rows = hint->rows;
+            }
             const dim3 grid((other + 256 * RG_VPX - 1) / (256 * RG_VPX), p->ngroups);
             const bool al = (other % RG_VPX) == 0 && ((reinterpret_cast<uintptr_t>(src) | static_cast<uintptr_t>(sstride)) & 15u) == 0;
             if (al) hipLaunchKernelGGL(resize_v_guard_kernel<true>, grid, dim3(256), 0, ctx->stream, ga);
@@ -1147,6 +1248,13 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
             if (const char *e = getenv("FNX_RH_ROWS")) rows = std::max(1, std::min(16, atoi(e)));   // experiments
             ga.rows = rows;
             const dim3 grid(gx, (other + 4 * rows - 1) / (4 * rows));
+            if (hint) {
+                hint->valid = hint->cells && static_cast<size_t>(grid.x) * grid.y <= hint->cap;
+                if (hint->valid) {
+                    hint->gx = static_cast<int>(grid.x); hint->gy = static_cast<int>(grid.y); hint->rows = 4 * rows;
+                    ga.hint = hint->cells; ga.hint_gx = hint->gx;
+                }
+            }
             switch (p->NV) {
             case 2: launch_h_guard<2>(ctx, ga, grid); break;
             case 3: launch_h_guard<3>(ctx, ga, grid); break;
@@ -1162,6 +1270,7 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
         return prof_end(ctx);
     }
     // fp64 kernels of round 1
+    if (hint && !vertical) hint->valid = false;
     int rc;
     if (vertical) rc = launch_resize_v(ctx, src, sstride, srcW, srcH, p->d_off, p->d_idx, p->d_wt, dst, dstride, t.nout, p->contig_taps);
     else rc = launch_resize_h(ctx, src, sstride, srcW, srcH, p->d_off, p->d_idx, p->d_wt, dst, dstride, t.nout, p->contig_taps);

@@ -461,7 +461,8 @@ def test_msssim_levels(ctx, orc):
     assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL
 
 
-@pytest.mark.parametrize("w,h", [(640, 480), (128, 96), (1024, 768), (2048, 1024), (144, 80), (1000, 600), (512, 512), (4096, 16)])
+@pytest.mark.parametrize("w,h", [(640, 480), (128, 96), (1024, 768), (2048, 1024), (144, 80), (1000, 600), (512, 512), (4096, 16),
+                                 (1200, 720), (1360, 752), (752, 1360), (528, 16 * 35)])
 def test_msssim_fused_levels(ctx, orc, monkeypatch, w, h):
     """The five-launch MSSSIM (one-pass 2 x 2 pyramid, multi-job box and window launches) against the level-by-level
     loop (FNX_MSSSIM_LEVELWISE=1) and the oracle: per level and combined.  Shapes that are not divisible by 2^levels
@@ -477,6 +478,12 @@ def test_msssim_fused_levels(ctx, orc, monkeypatch, w, h):
     monkeypatch.setenv("FNX_MSSSIM_LEVELWISE", "1")
     ref, lv_ref = ctx.msssim_levels(da, db)
     monkeypatch.delenv("FNX_MSSSIM_LEVELWISE", raising=False)
+    # r3: level 0 read once (box_halve_kernel: its planes and level 1 in one pass) against the two-read form -- the same
+    # integer arithmetic, so the values are identical, odd box edges (1200 / 512, 1360 / 512 ...) included
+    monkeypatch.setenv("FNX_MSSSIM_NOFUSE0", "1")
+    two, lv_two = ctx.msssim_levels(da, db)
+    monkeypatch.delenv("FNX_MSSSIM_NOFUSE0", raising=False)
+    assert two == got and np.array_equal(lv_two, lv, equal_nan=True)
     want, wl = orc.msssim(a, b, per_level=True, procs=8)
     assert np.array_equal(np.isnan(lv), np.isnan(wl)) and np.array_equal(np.isnan(lv_ref), np.isnan(wl))
     assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL and np.nanmax(np.abs(lv_ref - wl)) <= SSIM_TOL

@@ -72,6 +72,37 @@ def test_clampF_ties_and_neighbours():
         assert orc.clampF(float(x)) == go_clampF(float(x)), x
 
 
+def kernel_clampF_fast64(x: float) -> int:
+    """devutil.hpp clampF_fast64, replayed: min(u32(trunc(fl(x + pred(0.5)))), 255) with v_cvt_u32_f64's saturation
+    (negative and NaN -> 0, >= 2^32 -> 2^32 - 1).  The exact (fp64) resize loops use it in place of clampF_dev."""
+    if math.isnan(x):
+        return 0
+    t = fadd(x, 0.49999999999999994) if math.isfinite(x) else x
+    if t != t or t <= 0:
+        return 0
+    return 255 if t >= 4294967295.0 else min(int(math.floor(t)), 255)
+
+
+def test_clampF_fast64_equals_clampF_below_2_63():
+    assert 0.49999999999999994 == np.nextafter(0.5, 0.0)
+    xs = []
+    for k in list(range(-3, 260)) + [511, 512, 1023, 1024, 65535, 65536, 2 ** 31, 2 ** 32 - 1, 2 ** 32, 2 ** 51, 2 ** 52, 2 ** 53]:
+        for base in (k + 0.5, float(k), k + 0.25, k + 0.75):
+            for v in (base, np.nextafter(base, np.inf), np.nextafter(base, -np.inf),
+                      np.nextafter(np.nextafter(base, np.inf), np.inf), np.nextafter(np.nextafter(base, -np.inf), -np.inf)):
+                xs.append(float(v))
+    xs += [0.49999999999999994, 0.4999999999999999, 0.5000000000000001, -0.49999999999999994, -0.5, -0.5000000000000001,
+           1e-320, -1e-320, 0.0, -0.0, 254.99999999999997, 255.49999999999997, 255.5, 1e19 / 4, -1e19, -9.3e18,
+           float("-inf"), float("nan")]
+    rng = random.Random(7)
+    xs += [rng.uniform(-2, 258) for _ in range(20000)]
+    xs += [math.ldexp(rng.random(), rng.randint(-60, 62)) for _ in range(5000)]
+    for x in xs:
+        assert kernel_clampF_fast64(x) == go_clampF(x), x
+    # the one double floor(x + 0.5) gets wrong, and why this form is used instead
+    assert int(math.floor(0.49999999999999994 + 0.5)) == 1 and go_clampF(0.49999999999999994) == 0
+
+
 # ------------------------------------------------------------------ boxDownsample edges + means
 def box_edges(src: int, dst: int):
     """ssim.go:254-278 for every d, each double operation rounded once."""

@@ -13,8 +13,11 @@ import fennec_amd  # noqa: E402
 from fennec_amd import synth  # noqa: E402
 
 ctx = fennec_amd.Context(0)
-for (W, H, DW, DH) in [(3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (7680, 4320, 3840, 2160), (3840, 2160, 1280, 720),
-                       (3840, 2160, 2560, 1440)]:
+CASES = [(3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (7680, 4320, 3840, 2160), (3840, 2160, 1280, 720),
+         (3840, 2160, 2560, 1440)]
+if os.environ.get("FNX_TR_CASES"):          # e.g. "0" or "0,1": PMC passes of one shape
+    CASES = [CASES[int(i)] for i in os.environ["FNX_TR_CASES"].split(",")]
+for (W, H, DW, DH) in CASES:
     imgs = [torch.from_numpy(synth.large_photo(W, H, k)).cuda() for k in range(3)]
     if len(sys.argv) > 1 and sys.argv[1] == "soft":       # blurred ramps: no exact ties, the guard decides nearly everything
         imgs = [ctx.GaussianBlur(ctx.GaussianBlur(torch.from_numpy(synth.noise_image(W, H, 5 + k)).cuda(), 2.0), 1.2) for k in range(3)]
