@@ -229,6 +229,12 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, dstW, dstH, SLOT_OUT, &d));
+    // both passes in one launch where the tables allow it (the uint8 intermediate stays in LDS)
+    {
+        const int rc = resize_fused(ctx, th, tv, s.p, s.stride, srcW, srcH, d.p, d.stride);
+        if (rc < 0) return rc;
+        if (rc != FNX_NOOP) return finish(ctx, space, &d);
+    }
     // uint8 intermediate dstW x srcH (resize.go:51)
     const int tp = pitch16(dstW);
     void *tmp = nullptr;

@@ -268,6 +268,9 @@ struct ResizeHint {
 };
 int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
                 uint8_t *dst, int dstride, ResizeHint *hint = nullptr);
+// both passes in one launch (the uint8 intermediate in LDS); FNX_NOOP when the tables are outside its reach
+int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
+                 uint8_t *dst, int dstride);
 void free_resize_plans(fnx_ctx *ctx);
 // lanczosResize (resize.go:37-53) with both tables given: the body of fnx_lanczos_resize
 int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,

@@ -925,6 +925,423 @@ __global__ __launch_bounds__(256) void resize_v_guard_kernel(ResizeGuardArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------
+// lanczosResize in ONE launch (r3): resizeH into an LDS tile, resizeV out of it (resize.go:51-52: tmp stays a uint8
+// image, it just never reaches memory).
+//
+// Workgroup = 128 output columns (64 H groups of two: a wave's lanes) x `ng` V groups of four output rows; the tile
+// holds the tmp rows those V groups read (their windows' union, <= RF_RMAX rows: the host picks ng).  Phase 1 is
+// resize_h_guard_kernel's body with the tile as its destination -- a wave walks a quarter of the tile's rows, weights
+// in registers, rounding guard, sparse flags on a list, dense rows in the exact loop (uniform zero-weight masks).
+// Phase 2 is resize_v_guard_kernel's with the tile as its source: a wave takes a V group at a time, a lane two adjacent
+// columns (8-byte LDS reads, 8-byte stores), the group's weights are wave-uniform broadcasts; rows with dense flags go
+// through the exact sweep, and straight to it when half of the workgroup's H waves found their rows dense.
+// Same arithmetic, same proofs as the two-pass kernels; what changes is that the tmp image is neither written nor read
+// (16.6 MB each way at 4K <-> 1080p), that there is one launch, prologue and drain instead of two, and that phase 2 never
+// waits for memory.  The price is the tile's row halo: phase 1 computes the union, (2 ng + 6) / 2 ng of the rows at
+// 1:2, (8 ng + 12) / 8 ng at 2:1.  Windows of <= 16 pixels (NV <= 4): every upscale and downscales to about 2.3:1; the
+// rest, standalone passes and tables with non-monotone windows take the two-pass kernels.
+// ------------------------------------------------------------------------------------
+constexpr int RF_RMAX = 64;          // tmp rows a tile can hold (32 KB)
+constexpr int RF_TW = 128;           // output columns of a tile
+constexpr int RF_NGMAX = 16;         // V groups per tile: bounds the fix-up list (4 rows x 14 outputs per group)
+static_assert(RF_NGMAX * RG_VG * 2 * (RG_DENSE - 1) <= RG_FIX_CAP && 4 * 16 * 2 * (RG_DENSE - 1) <= RG_FIX_CAP, "fix-up list capacity");
+
+struct ResizeFusedArgs {
+    ResizeGuardArgs h;               // src = the source image, nout = dstW, other = srcH (dst unused)
+    ResizeGuardArgs v;               // dst = the destination, nout = dstH, other = dstW, srcN = srcH (src unused)
+    int ng;                          // V groups per tile
+};
+
+// one output of resizeV exactly as the reference computes it (resize.go:137-156), its taps read from the tile
+__device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &v, const uint32_t *tile, int r0, int col, int y)
+{
+    const int t0 = v.off[y], n = v.off[y + 1] - t0;
+    const int s0 = v.idx[t0];
+    double r = 0, g = 0, b = 0, al = 0;
+    for (int k = 0; k < n; k++) resize_tap(tile[(s0 + k - r0) * RF_TW + col], v.wt[t0 + k], r, g, b, al);
+    uint32_t o = 0;
+    if (al > 0.5) {
+        const double inv = 1.0 / al;
+        o = clampF_dev(r * inv) | (clampF_dev(g * inv) << 8) | (clampF_dev(b * inv) << 16) | (clampF_dev(al) << 24);
+    }
+    return o;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256, 3) void resize_fused_kernel(ResizeFusedArgs fa)
+{
+    constexpr int HO = RG_HO, NPX = 4 * NV, VG = RG_VG;
+    static_assert(NV <= 4 && HO == 2, "weights in registers; two outputs per lane");
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[RF_RMAX * RF_TW];
+    __shared__ uint32_t s_fix[RG_FIX_CAP];
+    __shared__ int s_nfix, s_nfix2, s_ndense;
+    // phase 1: fp64 aw [HO][NPX][64] of the exact loop.  phase 2, per wave: fp32 weights [64][VG], fp64 aw [64 + 4][VG],
+    // trip masks [16 + 4]
+    __shared__ __attribute__((aligned(16))) unsigned char s_u[16384];
+    static_assert(sizeof(double) * HO * NPX * 64 <= sizeof(s_u) && 4 * (sizeof(float) * 64 * VG + sizeof(double) * 68 * VG + sizeof(uint32_t) * 20) <= sizeof(s_u), "union");
+    const ResizeGuardArgs &a = fa.h;
+    const ResizeGuardArgs &v = fa.v;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { s_nfix = 0; s_nfix2 = 0; s_ndense = 0; }
+    // the tile's tmp rows [r0, r1): the union of its V groups' windows (monotone tables: the host checks)
+    const int gfirst = blockIdx.y * fa.ng, glast = min(gfirst + fa.ng, v.ngroups) - 1;
+    const int r0 = v.s0[gfirst], r1 = v.s0[glast] + v.cnt[glast];
+    const int rpw = (r1 - r0 + 3) >> 2;
+    const int yw = r0 + wave * rpw, y1 = min(yw + rpw, r1);        // this wave's rows (<= 16)
+    const int g = blockIdx.x * 64 + lane;
+    const int gc = min(g, a.ngroups - 1);                           // idle lanes shadow the last group (their columns are never stored)
+    const bool active = g < a.ngroups;
+    const int s0 = a.s0[gc];
+    const uint32_t ab = a.alpha[gc];
+    const int d0 = gc * HO;
+    uint32_t *trow = s_tile + 2 * lane;                             // + (y - r0) * RF_TW: this lane's two tmp pixels of row y
+    // phase 2's weights travel one V group ahead of their use, the first group's from here (a dependent miss at the
+    // start of phase 2 would have nothing to hide behind): lane l holds entries l, l + 64, ... of the group's table
+    double pre_aw[5];
+    float pre_w[4];
+    auto fetch_weights = [&](int gi) {
+        const int gq = min(gi, v.ngroups - 1);
+        const int nrq = v.cnt[gq] * VG;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = min(lane + 64 * k, v.npx * VG - 1);
+            pre_aw[k] = v.aw[static_cast<size_t>(gq) * v.npx * VG + idx];
+            if (lane + 64 * k >= nrq) pre_aw[k] = 0.0;
+            if (k < 4) {
+                pre_w[k] = v.dense[static_cast<size_t>(gq) * v.npx * VG + idx];
+                if (lane + 64 * k >= nrq) pre_w[k] = 0.0f;
+            }
+        }
+    };
+    fetch_weights(gfirst + wave);
+    __syncthreads();                                                // the counters are in place
+    uint32_t exact_rows = 0;                                        // bit r: row yw + r of this wave awaits the exact loop
+    auto load_row = [&](int y, u32x4 (&w)[NV]) {
+        const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+#pragma unroll
+        for (int q = 0; q < NV; q++) w[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
+    };
+    // ---------------- phase 1: resizeH (resize.go:77-117) into the tile ----------------
+    if (yw < y1) {                                                  // wave-uniform
+        u32x4 vn[NV], vm[NV];
+        load_row(yw, vn);
+        load_row(min(yw + 1, y1 - 1), vm);
+        v2f wreg[NPX];
+#pragma unroll
+        for (int i = 0; i < NPX; i++)
+            wreg[i] = (v2f){a.dense[static_cast<size_t>(i) * a.ngroups + gc], a.dense[static_cast<size_t>(NPX + i) * a.ngroups + gc]};
+        const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+        bool sticky = false;
+        for (int y = yw; y < y1; y++) {
+            if (sticky && ((y - yw) & 3) != 0) {
+                exact_rows |= 1u << (y - yw);
+#pragma unroll
+                for (int q = 0; q < NV; q++) vn[q] = vm[q];
+                load_row(min(y + 2, y1 - 1), vm);
+                continue;
+            }
+            u32x4 w[NV];
+#pragma unroll
+            for (int q = 0; q < NV; q++) { w[q] = vn[q]; vn[q] = vm[q]; }
+            load_row(min(y + 2, y1 - 1), vm);                       // two rows in flight while this one is used
+            uint32_t andp = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < NV; q++) andp &= (w[q][0] & w[q][1]) & (w[q][2] & w[q][3]);
+            v2f accr = {seed, seed}, accg = accr, accb = accr;     // .x: output 0, .y: output 1
+#pragma unroll
+            for (int i = 0; i < NPX; i++) {
+                const uint32_t p = w[i / 4][i % 4];
+                accr = fma_bcast(static_cast<float>(p & 0xffu), wreg[i], accr);
+                accg = fma_bcast(static_cast<float>((p >> 8) & 0xffu), wreg[i], accg);
+                accb = fma_bcast(static_cast<float>((p >> 16) & 0xffu), wreg[i], accb);
+                if (i & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t o[HO], o2[HO];
+            const v2f hr = accr + (v2f){g2, g2}, hg = accg + (v2f){g2, g2}, hb = accb + (v2f){g2, g2};
+            fp32_round_toward_zero();
+            o[0] = pk8(accb.x, 2, pk8(accg.x, 1, pk8(accr.x, 0, (ab & 0xffu) << 24)));
+            o[1] = pk8(accb.y, 2, pk8(accg.y, 1, pk8(accr.y, 0, (ab & 0xff00u) << 16)));
+            o2[0] = pk8(hb.x, 2, pk8(hg.x, 1, pk8(hr.x, 0, (ab & 0xffu) << 24)));
+            o2[1] = pk8(hb.y, 2, pk8(hg.y, 1, pk8(hr.y, 0, (ab & 0xff00u) << 16)));
+            fp32_round_nearest();
+            uint32_t flagged = 0;                                   // bit j: output j awaits the exact recompute
+            if (o[0] != o2[0]) flagged |= 1u;
+            if (o[1] != o2[1]) flagged |= 2u;
+            if ((andp >> 24) != 0xffu) flagged = 3u;                // some alpha != 255 in the window: general arithmetic
+            if (!active) flagged = 0;
+            if (d0 + 1 >= a.nout) flagged &= 1u;                    // (an odd width's last group has one output)
+            if (__popcll(__ballot(flagged != 0)) >= RG_DENSE) {     // wave-uniform: the whole row goes to the exact loop
+                if (y == yw) {                                      // the wave's FIRST row is dense: all of its rows at once
+                    exact_rows = (1u << (y1 - yw)) - 1u;
+                    if (lane == 0) atomicAdd(&s_ndense, 1);
+                    break;
+                }
+                exact_rows |= 1u << (y - yw);
+                sticky = true;
+                continue;
+            }
+            sticky = false;
+            uint32_t *tp = trow + (y - r0) * RF_TW;
+            if (!(flagged & 1u)) tp[0] = o[0];
+            else s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(y - r0) << 8) | static_cast<uint32_t>(2 * lane);
+            if (!(flagged & 2u)) tp[1] = o[1];
+            else s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(y - r0) << 8) | static_cast<uint32_t>(2 * lane + 1);
+        }
+    }
+    // the exact loop of resize_h_guard_kernel (see there): fp64 weights staged only if some wave marked a row
+    double *s_aw = reinterpret_cast<double *>(s_u);
+    if (__syncthreads_or(exact_rows != 0)) {
+        const int g0 = blockIdx.x * 64;
+        for (int e = tid; e < HO * NPX * 64; e += 256) {
+            const int gl = e & 63, ji = e >> 6;
+            s_aw[e] = g0 + gl < a.ngroups ? a.aw[static_cast<size_t>(ji) * a.ngroups + g0 + gl] : 0.0;
+        }
+        __syncthreads();
+        if (exact_rows) {                                           // wave-uniform
+            uint32_t todo = __builtin_amdgcn_readfirstlane(exact_rows);
+            u32x4 vnx[NV];
+            load_row(yw + __builtin_ctz(todo), vnx);
+            const double inv0 = a.inv[d0], inv1 = a.inv[min(d0 + 1, a.nout - 1)];
+            uint32_t nz0 = 0, nz1 = 0;                              // bit i: pixel i feeds output 0 / 1 in some lane of this wave
+#pragma unroll
+            for (int i = 0; i < NPX; i++) {
+                if (__ballot(s_aw[i * 64 + lane] != 0.0) != 0ull) nz0 |= 1u << i;
+                if (__ballot(s_aw[(NPX + i) * 64 + lane] != 0.0) != 0ull) nz1 |= 1u << i;
+            }
+            nz0 = __builtin_amdgcn_readfirstlane(nz0);
+            nz1 = __builtin_amdgcn_readfirstlane(nz1);
+            while (todo) {
+                const int y = yw + __builtin_ctz(todo);
+                todo &= todo - 1;
+                u32x4 w[NV];
+#pragma unroll
+                for (int q = 0; q < NV; q++) w[q] = vnx[q];
+                load_row(todo ? yw + __builtin_ctz(todo) : y, vnx);
+                uint32_t andp = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < NV; q++) andp &= (w[q][0] & w[q][1]) & (w[q][2] & w[q][3]);
+                uint32_t o0, o1;
+                if (__all((andp >> 24) == 0xffu || !active)) {
+                    double rr0 = 0, gg0 = 0, bb0 = 0, rr1 = 0, gg1 = 0, bb1 = 0;
+                    uint32_t m0 = nz0, m1 = nz1;
+                    asm volatile("" : "+s"(m0), "+s"(m1));
+                    double nx0 = s_aw[lane], nx1 = s_aw[NPX * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < NPX; i++) {
+                        const double aw0 = nx0, aw1 = nx1;
+                        if (i + 1 < NPX) { nx0 = s_aw[(i + 1) * 64 + lane]; nx1 = s_aw[(NPX + i + 1) * 64 + lane]; }
+                        if (((m0 | m1) >> i) & 1u) {                // scalar
+                            const uint32_t p = w[i / 4][i % 4];
+                            const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
+                            if ((m0 >> i) & 1u) { asm volatile(""); rr0 = rr0 + fr * aw0; gg0 = gg0 + fg * aw0; bb0 = bb0 + fb * aw0; }
+                            if ((m1 >> i) & 1u) { asm volatile(""); rr1 = rr1 + fr * aw1; gg1 = gg1 + fg * aw1; bb1 = bb1 + fb * aw1; }
+                        }
+                    }
+                    o0 = clampF_fast64(rr0 * inv0) | (clampF_fast64(gg0 * inv0) << 8) | (clampF_fast64(bb0 * inv0) << 16) | ((ab & 0xffu) << 24);
+                    o1 = clampF_fast64(rr1 * inv1) | (clampF_fast64(gg1 * inv1) << 8) | (clampF_fast64(bb1 * inv1) << 16) | ((ab & 0xff00u) << 16);
+                } else {
+                    o0 = resize_exact_px<false>(a, d0, y);
+                    o1 = resize_exact_px<false>(a, min(d0 + 1, a.nout - 1), y);
+                }
+                uint32_t *tp = trow + (y - r0) * RF_TW;
+                tp[0] = o0;
+                tp[1] = o1;
+            }
+        }
+    }
+    __syncthreads();
+    {   // exact tmp pixels for the listed ones
+        const int nfix = s_nfix;
+        for (int e = tid; e < nfix; e += 256) {
+            const int row = static_cast<int>(s_fix[e] >> 8), col = static_cast<int>(s_fix[e] & 0xffu);
+            s_tile[row * RF_TW + col] = resize_exact_px<false>(a, blockIdx.x * RF_TW + col, r0 + row);
+        }
+    }
+    __syncthreads();
+    const bool hinted = s_ndense >= 2;                              // wave-uniform
+
+    // ---------------- phase 2: resizeV (resize.go:120-160) out of the tile ----------------
+    float *s_wv = reinterpret_cast<float *>(s_u) + wave * (64 * VG);
+    double *s_awv = reinterpret_cast<double *>(s_u + 4 * sizeof(float) * 64 * VG) + wave * (68 * VG);
+    uint32_t *s_tm = reinterpret_cast<uint32_t *>(s_u + 4 * (sizeof(float) * 64 * VG + sizeof(double) * 68 * VG)) + wave * 20;
+    const int x = blockIdx.x * RF_TW + 2 * lane;
+    const int ncol = x + 1 < v.other ? 2 : (x < v.other ? 1 : 0);
+    const uint32_t own = (1u << ncol) - 1u;
+    const bool st8 = ((reinterpret_cast<uintptr_t>(v.dst) | static_cast<uintptr_t>(v.dstride)) & 7u) == 0;
+    const uint32_t *tcol = s_tile + 2 * lane;
+    typedef __attribute__((address_space(1))) u32x2 g_u32x2w;
+    for (int gi = gfirst + wave; gi <= glast; gi += 4) {            // wave-uniform
+        const int sg = v.s0[gi], nr = v.cnt[gi];
+        const int y0 = gi * VG;
+        uint32_t alv[VG];
+        double invv[VG];
+#pragma unroll
+        for (int j = 0; j < VG; j++) {
+            const int yy = min(y0 + j, v.nout - 1);
+            alv[j] = v.alpha[yy];
+            invv[j] = v.inv[yy];
+        }
+        // the group's weights into this wave's corner of the LDS (previous group's reads have all returned: in-order)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int idx = lane + 64 * k;
+            const double awt = pre_aw[k];
+            if (idx < 68 * VG) s_awv[idx] = awt;
+            if (k < 4) s_wv[idx] = pre_w[k];
+            const uint64_t nzb = __ballot(awt != 0.0);
+            if (lane < 4) s_tm[4 * k + lane] = static_cast<uint32_t>(nzb >> (16 * lane)) & 0xffffu;
+        }
+        fetch_weights(gi + 4);                                      // the next group's, in flight while this one is computed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t *tg = tcol + (sg - r0) * RF_TW;              // the group's first union row, this lane's two columns
+        const uint32_t valid_rows = (y0 + VG <= v.nout) ? (1u << VG) - 1u : (1u << (v.nout - y0)) - 1u;
+        uint32_t dense_rows = 0;
+        if (hinted) {
+            dense_rows = valid_rows;
+        } else {
+            const float seed = 0.5f - v.guard, g2 = 2.0f * v.guard;
+            v2f acc[VG][3];                                         // (r0,g0) (b0,r1) (g1,b1)
+#pragma unroll
+            for (int j = 0; j < VG; j++) acc[j][0] = acc[j][1] = acc[j][2] = (v2f){seed, seed};
+            u32x2 andp = {0xffffffffu, 0xffffffffu};
+            u32x2 t1 = *reinterpret_cast<const u32x2 *>(tg), t2 = *reinterpret_cast<const u32x2 *>(tg + min(1, nr - 1) * RF_TW);
+            for (int i = 0; i < nr; i++) {
+                const u32x2 t = t1;
+                t1 = t2;
+                t2 = *reinterpret_cast<const u32x2 *>(tg + min(i + 2, nr - 1) * RF_TW);
+                andp &= t;
+                v2f f[3];
+                f[0] = (v2f){static_cast<float>(t[0] & 0xffu), static_cast<float>((t[0] >> 8) & 0xffu)};
+                f[1] = (v2f){static_cast<float>((t[0] >> 16) & 0xffu), static_cast<float>(t[1] & 0xffu)};
+                f[2] = (v2f){static_cast<float>((t[1] >> 8) & 0xffu), static_cast<float>((t[1] >> 16) & 0xffu)};
+#pragma unroll
+                for (int j = 0; j < VG; j++) {
+                    const float wj = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wv[i * VG + j])));
+#pragma unroll
+                    for (int q = 0; q < 3; q++) acc[j][q] = __builtin_elementwise_fma(f[q], (v2f){wj, wj}, acc[j][q]);
+                }
+            }
+            uint32_t opq = 0;                                       // bit e: column e is opaque over the union
+            if ((andp[0] >> 24) == 0xffu) opq |= 1u;
+            if ((andp[1] >> 24) == 0xffu) opq |= 2u;
+#pragma unroll
+            for (int j = 0; j < VG; j++) {
+                const int y = y0 + j;
+                if (y < v.nout) {                                   // wave-uniform
+                    const uint32_t al = alv[j];
+                    u32x2 o, p;
+                    fp32_round_toward_zero();
+                    o[0] = pk8(acc[j][1].x, 2, pk8(acc[j][0].y, 1, pk8(acc[j][0].x, 0, al)));
+                    o[1] = pk8(acc[j][2].y, 2, pk8(acc[j][2].x, 1, pk8(acc[j][1].y, 0, al)));
+                    fp32_round_nearest();
+                    v2f hh[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) hh[q] = acc[j][q] + (v2f){g2, g2};
+                    fp32_round_toward_zero();
+                    p[0] = pk8(hh[1].x, 2, pk8(hh[0].y, 1, pk8(hh[0].x, 0, al)));
+                    p[1] = pk8(hh[2].y, 2, pk8(hh[2].x, 1, pk8(hh[1].y, 0, al)));
+                    fp32_round_nearest();
+                    uint32_t fl = ~opq;                             // bit e: column e awaits the exact recompute
+                    if (o[0] != p[0]) fl |= 1u;
+                    if (o[1] != p[1]) fl |= 2u;
+                    fl &= own;
+                    if (__popcll(__ballot(fl != 0)) >= RG_DENSE) {  // wave-uniform: this row goes to the exact sweep
+                        dense_rows |= 1u << j;
+                        continue;
+                    }
+                    if (ncol) {
+                        uint8_t *dp = v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(x);
+                        if (st8 && ncol == 2 && fl == 0) {
+                            *(g_u32x2w *)dp = o;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 2; e++)
+                                if (e < ncol) {
+                                    if (!((fl >> e) & 1u)) *(g_u32w *)(dp + 4 * e) = o[e];
+                                    else s_fix[atomicAdd(&s_nfix2, 1)] = (static_cast<uint32_t>(y) << 8) | static_cast<uint32_t>(2 * lane + e);
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        if (dense_rows) {                                           // wave-uniform: the exact sweep (see resize_v_guard_kernel)
+            const uint32_t rowsel = __builtin_amdgcn_readfirstlane(dense_rows) * 0x1111u;
+            double r[VG][6];
+#pragma unroll
+            for (int j = 0; j < VG; j++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) r[j][q] = 0.0;
+            uint32_t and0 = 0xffffffffu, and1 = 0xffffffffu;
+            uint32_t tmn = s_tm[0];
+            const double2 *wrow = reinterpret_cast<const double2 *>(s_awv);
+#pragma unroll 1
+            for (int i = 0; i < nr; i += 4) {
+                u32x2 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) u[k] = *reinterpret_cast<const u32x2 *>(tg + min(i + k, nr - 1) * RF_TW);
+                const uint32_t tm = __builtin_amdgcn_readfirstlane(tmn) & rowsel;
+                tmn = s_tm[(i >> 2) + 1];                           // (entries 16..19 are zero)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double2 wa = wrow[(i + k) * 2], wb = wrow[(i + k) * 2 + 1];
+                    const double wj[VG] = {wa.x, wa.y, wb.x, wb.y};
+                    const uint32_t q0 = u[k][0], q1 = u[k][1];
+                    and0 &= q0; and1 &= q1;
+                    if ((tm >> (4 * k)) & 0xfu) {                   // scalar
+                        const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                        const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+#pragma unroll
+                        for (int j = 0; j < VG; j++) {
+                            if ((tm >> (4 * k + j)) & 1u) {         // scalar
+                                asm volatile("");
+                                const double aw = wj[j];
+                                r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                                r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                            }
+                        }
+                    }
+                }
+            }
+            const bool q0ok = (and0 >> 24) == 0xffu, q1ok = (and1 >> 24) == 0xffu;
+#pragma unroll
+            for (int j = 0; j < VG; j++) {
+                if (!((dense_rows >> j) & 1u) || !ncol) continue;
+                const uint32_t al = alv[j];
+                const double inv = invv[j];
+                const int y = y0 + j;
+                uint8_t *dp = v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(x);
+                const uint32_t o0 = clampF_fast64(r[j][0] * inv) | (clampF_fast64(r[j][1] * inv) << 8) | (clampF_fast64(r[j][2] * inv) << 16) | al;
+                const uint32_t o1 = clampF_fast64(r[j][3] * inv) | (clampF_fast64(r[j][4] * inv) << 8) | (clampF_fast64(r[j][5] * inv) << 16) | al;
+                if (q0ok && q1ok && ncol == 2 && st8) {
+                    *(g_u32x2w *)dp = (u32x2){o0, o1};
+                } else {
+                    if (q0ok) *(g_u32w *)dp = o0;
+                    else *(g_u32w *)dp = resize_exact_px_tile(v, s_tile, r0, 2 * lane, y);
+                    if (ncol == 2) {
+                        if (q1ok) *(g_u32w *)(dp + 4) = o1;
+                        else *(g_u32w *)(dp + 4) = resize_exact_px_tile(v, s_tile, r0, 2 * lane + 1, y);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // exact outputs for the listed ones (never stored above)
+        const int nfix = s_nfix2;
+        for (int e = tid; e < nfix; e += 256) {
+            const int y = static_cast<int>(s_fix[e] >> 8), col = static_cast<int>(s_fix[e] & 0xffu);
+            *(g_u32w *)(v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(blockIdx.x * RF_TW + col)) =
+                resize_exact_px_tile(v, s_tile, r0, col, y);
+        }
+    }
+}
+
 // max taps of any output (0: indices not contiguous somewhere) -- host tables
 int resize_contiguous_taps(const int32_t *off, const int32_t *idx, int nout)
 {
@@ -959,6 +1376,7 @@ struct fnx_resize_plan {
     // guard form
     bool guard_ok = false;
     int HO = 0, NV = 0, ngroups = 0, npx = 0;
+    int fused_ng = 0;                // vertical plans: V groups per tile of resize_fused_kernel (0: not eligible)
     float guard = 0;
     const float *d_dense = nullptr;
     const int32_t *d_s0 = nullptr, *d_cnt = nullptr;
@@ -1092,6 +1510,20 @@ static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_p
         for (int d = 0; d < nout; d++) alphav[d] = abyte[d] << 24;
         p.HO = VG; p.NV = 0; p.ngroups = ng; p.npx = need;
         nfma = need;
+        // resize_fused_kernel: a tile's tmp rows are [s0 of its first group, end of its last) -- windows must move down
+        // monotonically -- and at most RF_RMAX of them; the largest group count that fits every tile
+        bool mono = true;
+        for (int g = 1; g < ng; g++)
+            if (s0v[g] < s0v[g - 1] || s0v[g] + cntv[g] < s0v[g - 1] + cntv[g - 1]) mono = false;
+        p.fused_ng = 0;
+        for (int cand = RF_NGMAX; mono && cand >= 1 && p.fused_ng == 0; cand--) {
+            bool fits = true;
+            for (int g0 = 0; g0 < ng && fits; g0 += cand) {
+                const int gl = std::min(g0 + cand, ng) - 1;
+                if (s0v[gl] + cntv[gl] - s0v[g0] > RF_RMAX) fits = false;
+            }
+            if (fits) p.fused_ng = cand;
+        }
     }
     // the bound of the header comment
     const double top = 255.0 * smax + 1.0;
@@ -1211,6 +1643,55 @@ static void launch_h_guard(fnx_ctx *ctx, const ResizeGuardArgs &ga, dim3 grid)
     // NV <= 4: the fp32 weight pairs ride in registers (WREG); the LDS holds the exact loop's fp64 weights only
     const size_t lds = (sizeof(double) * RG_HO + (NV <= 4 ? 0 : 2 * sizeof(float))) * 4 * NV * 64;
     hipLaunchKernelGGL((resize_h_guard_kernel<NV, (NV <= 5)>), grid, dim3(256), lds, ctx->stream, ga);
+}
+
+// lanczosResize in one launch (resize_fused_kernel) when both tables take the guard form, the H windows fit the
+// register matrix and the V windows a tile.  FNX_NOOP: not covered -- the caller runs the two passes.
+int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
+                 uint8_t *dst, int dstride)
+{
+    const char *fe = getenv("FNX_RESIZE_FUSED");                     // "0": A/B and tests (the two-pass kernels)
+    const bool off = fe && fe[0] == '0';
+    if (off || resize_guard_disabled() || th.nout <= 0 || tv.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_NOOP;
+    fnx_resize_plan *ph = nullptr, *pv = nullptr;
+    FNX_TRY(get_resize_plan(ctx, th, srcW, false, &ph));
+    FNX_TRY(get_resize_plan(ctx, tv, srcH, true, &pv));
+    if (!ph->guard_ok || !pv->guard_ok || ph->NV > 4 || pv->fused_ng < 1 || th.nout < 2) return FNX_NOOP;
+    ResizeFusedArgs fa{};
+    ResizeGuardArgs &h = fa.h, &v = fa.v;
+    h.src = src; h.sstride = sstride; h.srcN = srcW; h.nout = th.nout; h.other = srcH;
+    h.ngroups = ph->ngroups; h.npx = ph->npx; h.guard = ph->guard;
+    h.dense = ph->d_dense; h.s0 = ph->d_s0; h.cnt = ph->d_cnt; h.alpha = ph->d_alpha;
+    h.off = ph->d_off; h.idx = ph->d_idx; h.wt = ph->d_wt; h.aw = ph->d_aw; h.inv = ph->d_inv;
+    v.dst = dst; v.dstride = dstride; v.srcN = srcH; v.nout = tv.nout; v.other = th.nout;
+    v.ngroups = pv->ngroups; v.npx = pv->npx; v.guard = pv->guard;
+    v.dense = pv->d_dense; v.s0 = pv->d_s0; v.cnt = pv->d_cnt; v.alpha = pv->d_alpha;
+    v.off = pv->d_off; v.idx = pv->d_idx; v.wt = pv->d_wt; v.aw = pv->d_aw; v.inv = pv->d_inv;
+    // V groups per tile.  A workgroup lives for tens of microseconds and three fit a CU, so what matters is how full the
+    // LAST round of workgroups is: 810 workgroups on 768 slots take two rounds, 675 one.  Among the counts from what the
+    // tile holds down to half of it (more groups = less row halo in phase 1), the one whose rounds are fullest.
+    const int gx = (ph->ngroups + 63) / 64;
+    int ng = pv->fused_ng;
+    {
+        const double slots = 3.0 * ctx->num_cus;
+        double best = -1.0;
+        for (int cand = pv->fused_ng; cand >= std::max(2, pv->fused_ng / 2); cand--) {
+            const double rounds = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand) / slots;
+            const double fill = rounds / std::ceil(rounds);
+            if (fill > best + 0.02) { best = fill; ng = cand; }
+        }
+    }
+    if (const char *e = getenv("FNX_RF_NG")) ng = std::max(1, std::min(pv->fused_ng, atoi(e)));   // experiments
+    fa.ng = ng;
+    const dim3 grid(gx, (pv->ngroups + ng - 1) / ng);
+    FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
+    switch (ph->NV) {
+    case 2: hipLaunchKernelGGL(resize_fused_kernel<2>, grid, dim3(256), 0, ctx->stream, fa); break;
+    case 3: hipLaunchKernelGGL(resize_fused_kernel<3>, grid, dim3(256), 0, ctx->stream, fa); break;
+    default: hipLaunchKernelGGL(resize_fused_kernel<4>, grid, dim3(256), 0, ctx->stream, fa); break;
+    }
+    FNX_HIP(hipGetLastError());
+    return prof_end(ctx);
 }
 
 // one pass of lanczosResize: resizeH (vertical == false: src is srcW x srcH, dst outN x srcH) or resizeV

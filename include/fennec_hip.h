@@ -111,11 +111,11 @@ int fnx_ctx_sync(fnx_ctx *ctx);
  * mask of FNX_PROF_* (0: off; 1 = FNX_PROF_MAIN keeps its round-1 meaning: blur_direct_kernel of the
  * GaussianBlur fast / one-pass path and analyze_pass_kernel).  fnx_ctx_kernel_ms waits for the OLDEST
  * bracketed launch not read yet and returns its duration in milliseconds -- one call per launch, in
- * launch order; the last 4 launches are kept (FNX_ERR_INVALID if none is unread).  Calling
+ * launch order; the last 32 launches are kept (FNX_ERR_INVALID if none is unread).  Calling
  * fnx_ctx_profile with a non-zero mask also forgets the unread ones. */
 #define FNX_PROF_MAIN 1    /* blur_direct_kernel, analyze_pass_kernel */
 #define FNX_PROF_SSIM 2    /* windowed_ssim_march_kernel */
-#define FNX_PROF_RESIZE 4  /* resize H and V kernels (two launches per lanczosResize) */
+#define FNX_PROF_RESIZE 4  /* resize kernels: one launch per lanczosResize (fused H + V) or two (resizeH, resizeV) */
 #define FNX_PROF_FX 8      /* fx kernels: gaussianBlur3x3 / Sharpen / AdaptiveSharpen */
 #define FNX_PROF_JPEG 16   /* jpeg_block_kernel (fdct, quantise, dequantise, idct of every block) */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
