@@ -526,8 +526,9 @@ def other_configs(args) -> dict:
     protocol as their own `--workload` lines, smaller batches / fewer steps; about 15 s in all).  Never part of `value`."""
     import copy
     out = {}
-    plan = [("config3", dict(batch=32, steps=4, warmup=1, contexts=4, threads=2)),
-            ("config4", dict(batch=4, steps=4, warmup=1, contexts=1, threads=1)),
+    # (config 3's four worker streams jitter: 4 steps measured 59-83 k MP/s run to run, 40 steps 77-82 k)
+    plan = [("config3", dict(batch=32, steps=40, warmup=3, contexts=4, threads=2)),
+            ("config4", dict(batch=4, steps=16, warmup=2, contexts=1, threads=1)),
             ("config5", dict(batch=16, steps=3, warmup=1, contexts=1, threads=1, device_decode=True))]
     for wl, over in plan:
         a = copy.copy(args)

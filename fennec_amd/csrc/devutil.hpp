@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t clampF_dev(double x)
 }
 
 // clampF in three instructions for the exact (fp64) resize loops: min(u32(trunc(x + pred(0.5))), 255).
-// Why it equals clampF (convert.go:149-158) for every finite x below 2^63 (tests/test_oracle_exact.py replays it):
+// Why it equals clampF (convert.go:149-158) for every finite x below 2^63 (the CPU suite replays it in exact rationals):
 //  * x < 0 or NaN: math.Round gives -0 / a negative / int64(NaN) < 0 -> 0; here x + c < 0.5 truncates to 0 or is
 //    negative / NaN, and v_cvt_u32_f64 saturates both to 0.
 //  * 0 <= x, n = floor(x), u = ulp(x), c = 0.5 - 2^-54.  x >= n + 0.5: x + c >= n + 1 - 2^-54, which for n >= 1

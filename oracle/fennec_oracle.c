@@ -51,6 +51,35 @@ static void *orc_job_main(void *p)
     return NULL;
 }
 
+/* A persistent pool stands in for Go's goroutines: parallelDo starts `procs` goroutines per call (resize.go:225-236),
+ * which costs Go microseconds; 256 pthread_create + join per pass cost this restatement milliseconds and held the
+ * cpu_baseline leg at 3x one thread on a 256-core box.  The batches -- which rows each one takes
+ * -- are the reference's; which OS thread runs a batch is not observable.  One parallel_do at a time uses the pool (a
+ * second caller, from another thread, spawns threads as before). */
+#define ORC_POOL_MAX 1024
+static pthread_mutex_t pool_user = PTHREAD_MUTEX_INITIALIZER;     /* held by the parallel_do that owns the pool */
+static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t pool_work = PTHREAD_COND_INITIALIZER, pool_idle = PTHREAD_COND_INITIALIZER;
+static pthread_t pool_tid[ORC_POOL_MAX];
+static int pool_threads = 0;
+static orc_job *pool_jobs = NULL;
+static int pool_njobs = 0, pool_next = 0, pool_done = 0;
+
+static void *pool_main(void *unused)
+{
+    (void)unused;
+    pthread_mutex_lock(&pool_mu);
+    for (;;) {
+        while (pool_next >= pool_njobs) pthread_cond_wait(&pool_work, &pool_mu);
+        orc_job *j = &pool_jobs[pool_next++];
+        pthread_mutex_unlock(&pool_mu);
+        j->fn(j->from, j->to, j->arg);
+        pthread_mutex_lock(&pool_mu);
+        if (++pool_done == pool_njobs) pthread_cond_signal(&pool_idle);
+    }
+    return NULL;
+}
+
 /* resize.go:200-239 -- batchSize = ceil(count/procs); empty batches skipped. */
 static void parallel_do(int start, int stop, int procs, orc_range_fn fn, void *arg)
 {
@@ -62,7 +91,6 @@ static void parallel_do(int start, int stop, int procs, orc_range_fn fn, void *a
         return;
     }
     int batch = (count + procs - 1) / procs;
-    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)procs);
     orc_job *jobs = (orc_job *)malloc(sizeof(orc_job) * (size_t)procs);
     int n = 0;
     for (int p = 0; p < procs; p++) {
@@ -70,9 +98,31 @@ static void parallel_do(int start, int stop, int procs, orc_range_fn fn, void *a
         if (be > stop) be = stop;
         if (bs >= be) continue;
         jobs[n].fn = fn; jobs[n].arg = arg; jobs[n].from = bs; jobs[n].to = be;
-        pthread_create(&tid[n], NULL, orc_job_main, &jobs[n]);
         n++;
     }
+    if (n <= ORC_POOL_MAX && pthread_mutex_trylock(&pool_user) == 0) {
+        pthread_mutex_lock(&pool_mu);
+        int ok = 1;
+        while (pool_threads < n) {                                /* grow to one worker per batch, as goroutines would be */
+            if (pthread_create(&pool_tid[pool_threads], NULL, pool_main, NULL) != 0) { ok = 0; break; }
+            pthread_detach(pool_tid[pool_threads]);
+            pool_threads++;
+        }
+        if (ok || pool_threads > 0) {
+            pool_jobs = jobs; pool_njobs = n; pool_next = 0; pool_done = 0;
+            pthread_cond_broadcast(&pool_work);
+            while (pool_done < n) pthread_cond_wait(&pool_idle, &pool_mu);
+            pool_njobs = 0; pool_next = 0; pool_jobs = NULL;
+            pthread_mutex_unlock(&pool_mu);
+            pthread_mutex_unlock(&pool_user);
+            free(jobs);
+            return;
+        }
+        pthread_mutex_unlock(&pool_mu);
+        pthread_mutex_unlock(&pool_user);
+    }
+    pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n);
+    for (int i = 0; i < n; i++) pthread_create(&tid[i], NULL, orc_job_main, &jobs[i]);
     for (int i = 0; i < n; i++) pthread_join(tid[i], NULL);
     free(tid);
     free(jobs);
