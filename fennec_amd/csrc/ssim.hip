@@ -200,6 +200,23 @@ __global__ __launch_bounds__(256) void box_tiled_multi_kernel(BoxMulti m)
     box_tiled_body<true>(m.job[j], blockIdx.x, blockIdx.y, blockIdx.z & 1);
 }
 
+// "workgroups finished" counters of the kernels whose last workgroup takes the final sum itself: 2 x 4096 for the
+// marching SSIM kernels (one half per stream the ctx launches on), one more for MSSSIM's multi-level window launch.
+// Zero between launches (the last workgroup puts its counter back).
+constexpr int SSIM_DONE_WORDS = 2 * 4096 + 16;
+static int ssim_done_counters(fnx_ctx *ctx, unsigned **out)
+{
+    const void *before = ctx->slot[SLOT_DONE].p;
+    void *dn = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_DONE, sizeof(unsigned) * SSIM_DONE_WORDS, &dn));
+    if (dn != before) {                                           // first use: zero once, for both streams
+        FNX_HIP(hipMemsetAsync(dn, 0, sizeof(unsigned) * SSIM_DONE_WORDS, ctx->stream));
+        FNX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *out = static_cast<unsigned *>(dn);
+    return FNX_OK;
+}
+
 int launch_box_downsample(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs,
                           int sstride, int srcW, int srcH, uint8_t *dst, int dstride,
                           size_t dst_image_bytes, int dstW, int dstH)
@@ -329,7 +346,55 @@ struct WinSepArgs {
     int tiles_x, tiles;
     double *partial;
     double col[8], row[8];   // k[j][i] ~= row[j] * col[i]
+    // boxed != 0 (r3, MSSSIM's middle levels): a and b are srcW x srcH images and the w x h plane the windows run over
+    // is their boxDownsample (ssim.go:244-309), taken on the fly in the tile load -- boxes of at most 5 x 5 pixels, the
+    // integer sums and the fp64 finish of box_tiled_kernel, so the plane's pixels are the same bytes and no kernel
+    // has to write them first
+    int boxed, srcW, srcH;
+    double xRatio, yRatio;
 };
+
+// the box of at most MB x MB pixels behind plane pixel (x, y): every load is issued before the first is used (indices
+// clamped into the box, the surplus masked out of the sums) -- a loop over the box's own extent is a chain of dependent
+// misses per staged pixel, and this kernel has few workgroups to hide them behind
+template <int MB>
+__device__ __forceinline__ uint32_t win_box_px(const WinSepArgs &a, const uint8_t *img, int stride, int x, int y)
+{
+    int sx0, sx1, sy0, sy1;
+    box_edge(x, a.xRatio, a.srcW, sx0, sx1);
+    box_edge(y, a.yRatio, a.srcH, sy0, sy1);
+    uint32_t p[MB][MB];
+#pragma unroll
+    for (int jy = 0; jy < MB; jy++) {
+        const uint8_t *row = img + static_cast<size_t>(min(sy0 + jy, sy1 - 1)) * stride;
+#pragma unroll
+        for (int jx = 0; jx < MB; jx++) p[jy][jx] = ld_px(row, min(sx0 + jx, sx1 - 1));
+    }
+    uint32_t rb = 0, ga = 0;                             // 25 x 255 < 65536: packed 16-bit fields cannot carry
+#pragma unroll
+    for (int jy = 0; jy < MB; jy++)
+#pragma unroll
+        for (int jx = 0; jx < MB; jx++) {
+            const bool in = sy0 + jy < sy1 && sx0 + jx < sx1;
+            rb += in ? p[jy][jx] & 0x00ff00ffu : 0u;
+            ga += in ? (p[jy][jx] >> 8) & 0x00ff00ffu : 0u;
+        }
+    return box_finish(rb & 0xffffu, ga & 0xffffu, rb >> 16, ga >> 16, (sy1 - sy0) * (sx1 - sx0));
+}
+
+// pixel (x, y) of the plane a window job runs over: the image's own, or the box mean of the larger image behind it
+// (a.boxed = the largest box side, 2..5)
+__device__ __forceinline__ uint32_t win_plane_px(const WinSepArgs &a, const uint8_t *img, int stride, int x, int y)
+{
+    switch (a.boxed) {                                   // uniform over the workgroup
+    case 0: return ld_px(img + static_cast<size_t>(y) * stride, x);
+    case 1:
+    case 2: return win_box_px<2>(a, img, stride, x, y);
+    case 3: return win_box_px<3>(a, img, stride, x, y);
+    case 4: return win_box_px<4>(a, img, stride, x, y);
+    default: return win_box_px<5>(a, img, stride, x, y);
+    }
+}
 
 // TY = 16 rows of windows per workgroup (a 32-row tile trims the halos from 1.75x / 1.44x to 1.49x /
 // 1.22x but needs 70 KB of LDS: 2 workgroups per CU, measured 7 % slower at 8K).  The kernel is fp64-issue bound (fp64 runs at
@@ -337,8 +402,8 @@ struct WinSepArgs {
 // adjacent H outputs and TY/8 vertically adjacent windows per lane.  (A 3 x 256 LDS table of the
 // luminance products saved 6 fp64 ops per pixel and cost 20 %: dependent, bank-conflicting reads.)
 // Big planes take windowed_ssim_sep24_kernel below; this one serves planes with too few windows for it.
-template <int TY, int NTHR>
-__device__ __forceinline__ void ssim_sep_body(const WinSepArgs &a, const int tile, const int z)
+template <int TY, int NTHR, bool STORE = true>
+__device__ __forceinline__ double ssim_sep_body(const WinSepArgs &a, const int tile, const int z)
 {
     constexpr int LW = WSS_TX + 8, LH = TY + 7;   // 39 columns are used; an even pitch keeps row starts 16-byte aligned
     constexpr int WPT = WSS_TX * TY / NTHR;       // vertically adjacent windows per lane
@@ -353,8 +418,8 @@ __device__ __forceinline__ void ssim_sep_body(const WinSepArgs &a, const int til
     for (int i = tid; i < LH * LW; i += NTHR) {
         const int ly = i / LW, lx = i - ly * LW;
         const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
-        s_a[i] = lum601(ld_px(A + static_cast<size_t>(y) * a.astride, x));
-        s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
+        s_a[i] = lum601(win_plane_px(a, A, a.astride, x, y));
+        s_b[i] = lum601(win_plane_px(a, B, a.bstride, x, y));
     }
     __syncthreads();
     // horizontal 8-tap pass; item = (row, 2 adjacent outputs): the 9-value window is read once
@@ -437,12 +502,14 @@ __device__ __forceinline__ void ssim_sep_body(const WinSepArgs &a, const int til
     for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
     if ((tid & 63) == 0) s_red[tid >> 6] = val;
     __syncthreads();
+    double t = 0.0;
     if (tid == 0) {
-        double t = s_red[0];
+        t = s_red[0];
 #pragma unroll
         for (int wv = 1; wv < NTHR / 64; wv++) t += s_red[wv];
-        a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
+        if (STORE) a.partial[static_cast<size_t>(z) * a.tiles + tile] = t;
     }
+    return t;                                            // the tile's sum (thread 0)
 }
 
 template <int TY, int NTHR>
@@ -455,13 +522,46 @@ __global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
 constexpr int WS_MAXJOBS = 5;
 struct WinSepMulti {
     WinSepArgs job[WS_MAXJOBS];
+    // out != nullptr: the LAST workgroup of a job to finish also takes the job's mean -- the sum
+    // ssim_finish_multi_kernel would take, in the same order -- so that no sixth launch waits behind this one
+    double *out;
+    unsigned *done;                  // a counter per job, zero before and after the launch
+    int njobs;
+    int out_index[WS_MAXJOBS];
+    double windows[WS_MAXJOBS];
 };
+
+__device__ __forceinline__ double finish_sum_256(const double *p, int tiles, double *s_red);
 
 __global__ __launch_bounds__(256) void windowed_ssim_sep_multi_kernel(WinSepMulti m)
 {
+    __shared__ double s_fin[4];
+    __shared__ int s_last;
     const WinSepArgs &a = m.job[blockIdx.y];
     if (static_cast<int>(blockIdx.x) >= a.tiles) return;
-    ssim_sep_body<WSS_TY, 256>(a, blockIdx.x, 0);
+    // (ONE instantiation of the body: its LDS arrays are per instantiation, and two of them halved the kernel's occupancy)
+    const double t = ssim_sep_body<WSS_TY, 256, false>(a, blockIdx.x, 0);
+    if (!m.out) {
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        // written through, then the job's counter (see march_finish: an agent-scope release would be an L2 write-back per workgroup)
+        double *pp = a.partial + blockIdx.x;
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp), "v"(t) : "memory");
+        const unsigned prev = __hip_atomic_fetch_add(m.done + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == static_cast<unsigned>(a.tiles) - 1u;
+    }
+    __syncthreads();
+    if (s_last) {                                        // the job's last workgroup: its mean (the five jobs end independently)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int j = blockIdx.y;
+        const double sum = finish_sum_256(a.partial, a.tiles, s_fin);
+        if (threadIdx.x == 0) {
+            m.out[m.out_index[j]] = m.windows[j] > 0 ? sum / m.windows[j] : 1.0;
+            __hip_atomic_store(m.done + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // rank-1 factorisation of the 8x8 table: col[i] = sum_j k[j][i], row[j] = sum_i k[j][i] / sum(k).
@@ -1062,15 +1162,9 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         // stream the ctx launches on (a scored tail on the second stream may run beside a call on the first)
         static const bool nofold = [] { const char *e = getenv("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
         if (!defer && !nofold && n <= 4096) {
-            const Scratch &sl = ctx->slot[SLOT_DONE];
-            const void *before = sl.p;
-            void *dn = nullptr;
-            FNX_TRY(scratch(ctx, SLOT_DONE, sizeof(unsigned) * 2 * 4096, &dn));
-            if (dn != before) {                                   // first use: zero once, for both streams
-                FNX_HIP(hipMemsetAsync(dn, 0, sizeof(unsigned) * 2 * 4096, ctx->stream));
-                FNX_HIP(hipStreamSynchronize(ctx->stream));
-            }
-            ma.done = static_cast<unsigned *>(dn) + (ctx->partial_slot >= 0 ? 4096 : 0);
+            unsigned *dn = nullptr;
+            FNX_TRY(ssim_done_counters(ctx, &dn));
+            ma.done = dn + (ctx->partial_slot >= 0 ? 4096 : 0);
             ma.out = d_out;
             ma.count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
             folded = true;
@@ -1416,6 +1510,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
     int nb = 0, gx = 0, gy = 0;
     const uint8_t *sa[5], *sb[5];
     int sas[5], sbs[5];
+    bool onfly[5] = {false, false, false, false, false};
     for (int i = 0; i < levels; i++) {
         sa[i] = la[i]; sb[i] = lb[i];
         sas[i] = i == 0 ? astride : ls[i]; sbs[i] = i == 0 ? bstride : ls[i];
@@ -1425,6 +1520,20 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
             uint8_t *dst0 = static_cast<uint8_t *>(planes) + off_pl[0];
             sa[0] = dst0; sb[0] = dst0 + plane0; sas[0] = sbs[0] = pw[0] * 4;
             continue;
+        }
+        // boxes of at most 5 x 5 pixels (levels downsampled by less than 4: 1080p and 960 x 540 under a 4K pair) are taken
+        // by the window kernel's tile load itself -- no plane is written, no launch has to finish first
+        {
+            const double xr = static_cast<double>(lw[i]) / static_cast<double>(pw[i]), yr = static_cast<double>(lh[i]) / static_cast<double>(ph[i]);
+            const char *nb_env = getenv("FNX_MSSSIM_BOXFLY");        // "1": on.  Off by default: one launch fewer and 5 us off a single
+                                                                     // 4K call, but the window kernel then finishes every staged pixel's
+                                                                     // box 1.75 times over (tile halos) and config 3's four streams
+                                                                     // measured 68 k MP/s against 72 k
+            if ((nb_env && nb_env[0] == '1') && i > 0 && lw[i] >= pw[i] && lh[i] >= ph[i] &&
+                (static_cast<int>(xr) + 1) * (static_cast<int>(yr) + 1) <= 25) {
+                onfly[i] = true;
+                continue;
+            }
         }
         if (nb == BOX_MAXJOBS) return FNX_NOOP;
         BoxArgs &ba = bm.job[nb];
@@ -1460,6 +1569,13 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         wa = proto;
         wa.a = sa[i]; wa.b = sb[i]; wa.astride = sas[i]; wa.bstride = sbs[i]; wa.a_image_bytes = wa.b_image_bytes = 0;
         wa.w = pw[i]; wa.h = ph[i];
+        if (onfly[i]) {
+            wa.boxed = std::max(static_cast<int>(static_cast<double>(lw[i]) / static_cast<double>(pw[i])),
+                                static_cast<int>(static_cast<double>(lh[i]) / static_cast<double>(ph[i]))) + 1;   // largest box side (<= 5)
+            wa.srcW = lw[i]; wa.srcH = lh[i];
+            wa.xRatio = static_cast<double>(lw[i]) / static_cast<double>(pw[i]);      // ssim.go:251-252
+            wa.yRatio = static_cast<double>(lh[i]) / static_cast<double>(ph[i]);
+        }
         const int ww = pw[i] - 8, wh = ph[i] - 8;
         wa.tiles_x = (ww + WSS_TX - 1) / WSS_TX;
         wa.tiles = wa.tiles_x * ((wh + WSS_TY - 1) / WSS_TY);
@@ -1469,9 +1585,23 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         defer.used += static_cast<size_t>(wa.tiles) + 2;
         maxt = std::max(maxt, wa.tiles);
     }
+    // FNX_MSSSIM_FOLD=1: each level's last workgroup takes the level's mean itself instead of the separate finish launch.
+    // Off by default: the write-through stores and counters cost what the launch costs (a single 4K call 75 us against
+    // 71, config 3 the same within its noise); kept, with its test, as the measured alternative.
+    const char *nf_env = getenv("FNX_MSSSIM_FOLD");
+    const bool fold = nf_env && nf_env[0] == '1';
+    if (fold) {
+        unsigned *dn = nullptr;
+        FNX_TRY(ssim_done_counters(ctx, &dn));
+        wm.out = d_out; wm.done = dn + 2 * 4096; wm.njobs = levels;
+        for (int i = 0; i < levels; i++) {
+            wm.out_index[i] = defer.item[i].out_index;
+            wm.windows[i] = defer.item[i].windows;
+        }
+    }
     hipLaunchKernelGGL(windowed_ssim_sep_multi_kernel, dim3(maxt, levels), dim3(256), 0, ctx->stream, wm);
     FNX_HIP(hipGetLastError());
-    FNX_TRY(launch_ssim_finish_deferred(ctx, defer, d_out));
+    if (!fold) FNX_TRY(launch_ssim_finish_deferred(ctx, defer, d_out));
     *nlev = levels;
     return FNX_OK;
 }

@@ -484,6 +484,18 @@ def test_msssim_fused_levels(ctx, orc, monkeypatch, w, h):
     two, lv_two = ctx.msssim_levels(da, db)
     monkeypatch.delenv("FNX_MSSSIM_NOFUSE0", raising=False)
     assert two == got and np.array_equal(lv_two, lv, equal_nan=True)
+    # r3: the means taken by each level's last workgroup against the separate finish launch, and (opt-in) boxes of <= 5 x 5
+    # pixels taken in the window kernel's tile load against planes written by the box kernel: the same bytes, the same sums
+    # in the same order
+    monkeypatch.setenv("FNX_MSSSIM_FOLD", "1")                # (off by default: see launch_msssim_fused)
+    old, lv_old = ctx.msssim_levels(da, db)
+    old2, lv_old2 = ctx.msssim_levels(da, db)                 # (the folded finish leaves its counters at zero)
+    monkeypatch.delenv("FNX_MSSSIM_FOLD", raising=False)
+    assert old == got and np.array_equal(lv_old, lv, equal_nan=True) and old2 == got
+    monkeypatch.setenv("FNX_MSSSIM_BOXFLY", "1")              # (off by default: see launch_msssim_fused)
+    fly, lv_fly = ctx.msssim_levels(da, db)
+    monkeypatch.delenv("FNX_MSSSIM_BOXFLY", raising=False)
+    assert fly == got and np.array_equal(lv_fly, lv, equal_nan=True)
     want, wl = orc.msssim(a, b, per_level=True, procs=8)
     assert np.array_equal(np.isnan(lv), np.isnan(wl)) and np.array_equal(np.isnan(lv_ref), np.isnan(wl))
     assert np.nanmax(np.abs(lv - wl)) <= SSIM_TOL and np.nanmax(np.abs(lv_ref - wl)) <= SSIM_TOL
