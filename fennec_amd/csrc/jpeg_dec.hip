@@ -135,6 +135,15 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             bad |= 8u;
             break;
         }
+        // write pass: every block of the intervals before the next boundary is complete -- what is left before it is not data.
+        // (In a sound file that is the padding, which the symbol rule below skips as well; in a DAMAGED interval whose blocks
+        // end early the leftover bits can read as the start of one more block: a decoder that counts MCUs never looks at
+        // them, and written here they would stay in the coefficients of the next interval's first block -- the fuzzer's
+        // find, seed 41: tests/golden/damaged_interval_ends_early.jpg.)
+        if (WRITE && RST && rel < bnext && rk < a.nrst && blk + cnt >= static_cast<long long>(rk + 1) * a.ri_blocks) {
+            rel = bnext;
+            if (rel >= end) break;                                 // the boundary lies in a later span: that lane starts over there
+        }
         if (RST && rel >= bnext) {                                 // on a boundary: the interval's first block, first slot
             // (write pass: exactly the intervals before it must be complete -- a damaged interval that yields a block too
             // many or too few would shift every block behind it)

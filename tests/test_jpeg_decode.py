@@ -251,6 +251,12 @@ def test_gpu_decode_with_restart_intervals(ctx):
         ctx.jpeg_decode(bad)
     r = batch.jpeg_item_work_device_all([bad], 0.94)(0, ctx)
     assert r.host_decoded and r.Err is None and r.data[:2] == b"\xff\xd8"
+    # tests/golden/damaged_interval_ends_early.jpg (the fuzzer's find, seed 41, r3): a damaged byte makes an interval's 11
+    # blocks end early and the leftover bits read as the START of a twelfth -- incomplete, so the block accounting above
+    # holds, but its coefficients used to stay in the next interval's first block.  Once an interval's blocks are complete
+    # the write pass now goes to the boundary, as a decoder that counts MCUs does: the same pixels as the checker.
+    bad = open(os.path.join(os.path.dirname(__file__), "golden", "damaged_interval_ends_early.jpg"), "rb").read()
+    assert np.array_equal(ctx.jpeg_decode(bad), orc.jpeg_decode(bad))
 
 
 @pytest.mark.gpu
