@@ -415,11 +415,21 @@ __device__ __forceinline__ double ssim_sep_body(const WinSepArgs &a, const int t
     const uint8_t *A = a.a + a.a_image_bytes * z;
     const uint8_t *B = a.b + a.b_image_bytes * z;
     const int tid = threadIdx.x;
-    for (int i = tid; i < LH * LW; i += NTHR) {
-        const int ly = i / LW, lx = i - ly * LW;
-        const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
-        s_a[i] = lum601(win_plane_px(a, A, a.astride, x, y));
-        s_b[i] = lum601(win_plane_px(a, B, a.bstride, x, y));
+    if (!a.boxed) {        // (its own loop: with the boxed form inside it the plain loads were no longer issued together -- 9.4 -> 13.9 us per 4K MSSSIM)
+        for (int i = tid; i < LH * LW; i += NTHR) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
+            s_a[i] = lum601(ld_px(A + static_cast<size_t>(y) * a.astride, x));
+            s_b[i] = lum601(ld_px(B + static_cast<size_t>(y) * a.bstride, x));
+        }
+    } else {
+#pragma unroll 1
+        for (int i = tid; i < LH * LW; i += NTHR) {
+            const int ly = i / LW, lx = i - ly * LW;
+            const int x = min(wx0 + lx, a.w - 1), y = min(wy0 + ly, a.h - 1);
+            s_a[i] = lum601(win_plane_px(a, A, a.astride, x, y));
+            s_b[i] = lum601(win_plane_px(a, B, a.bstride, x, y));
+        }
     }
     __syncthreads();
     // horizontal 8-tap pass; item = (row, 2 adjacent outputs): the 9-value window is read once
