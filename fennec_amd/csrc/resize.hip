@@ -1651,7 +1651,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
                  uint8_t *dst, int dstride)
 {
     const char *fe = getenv("FNX_RESIZE_FUSED");                     // "0": A/B and tests (the two-pass kernels)
-    const bool off = fe && fe[0] == '0';
+    const bool off = (fe && fe[0] == '0') || (fe && fe[0] == '2' && th.nout < srcW);   // "2": upscales only (experiments)
     if (off || resize_guard_disabled() || th.nout <= 0 || tv.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_NOOP;
     fnx_resize_plan *ph = nullptr, *pv = nullptr;
     FNX_TRY(get_resize_plan(ctx, th, srcW, false, &ph));
