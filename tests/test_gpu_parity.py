@@ -335,6 +335,41 @@ def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
         assert np.array_equal(got_view, want), (w, h, dw, dh, "view")
 
 
+@pytest.mark.parametrize("w,h,dw,dh", [(640, 480, 320, 240), (640, 480, 1280, 960), (641, 479, 301, 1000), (517, 389, 233, 800),
+                                       (130, 90, 195, 41), (33, 9, 67, 18), (3, 200, 6, 97), (1920, 1080, 3840, 2160),
+                                       (3840, 2160, 1920, 1080), (2048, 70, 929, 151), (9, 9, 4, 20)])
+def test_lanczos_resize_one_launch_vs_two_pass(ctx, orc, monkeypatch, w, h, dw, dh):
+    """r3: resize_fused_kernel (resizeH into an LDS tile, resizeV out of it: windows of <= 16 source pixels) against the
+    two-pass kernels (FNX_RESIZE_FUSED=0) and, below 4K, the oracle -- noise, SURVEY 8(d)'s ramp (dense exact ties at 2:1),
+    two-level stripes (ties in both passes), a translucent patch (the general arithmetic from the tile), odd widths (the
+    last H group has one output), tiles with fewer V groups than the tile holds, host arrays and strided device views."""
+    import torch
+    noise = _opaque(synth.noise_image(w, h, w + dw, alpha=True))
+    ramp = synth.large_photo(w, h, 3)
+    stripes = np.empty((h, w, 4), np.uint8)
+    stripes[:, 0::2] = (100, 7, 250, 255)
+    stripes[:, 1::2] = (101, 8, 255, 255)
+    stripes[1::2, :, :3] += 1
+    holes = noise.copy()
+    holes[h // 3: h // 2 + 1, w // 4: w // 2 + 1, 3] = 17
+    soft = synth.noise_image(w, h, 11, alpha=True)             # every window translucent
+    big = w * h > 3000 * 2000
+    for k, img in enumerate((noise, ramp, stripes, holes, soft)):
+        if big and k in (2, 4):
+            continue
+        monkeypatch.delenv("FNX_RESIZE_FUSED", raising=False)
+        got = ctx.lanczosResize(img, dw, dh)
+        pad = 1 + k % 3
+        view = torch.from_numpy(np.ascontiguousarray(np.pad(img, ((0, 0), (pad, 4 - pad), (0, 0))))).cuda()[:, pad: pad + w]
+        got_view = ctx.lanczosResize(view, dw, dh).cpu().numpy()
+        monkeypatch.setenv("FNX_RESIZE_FUSED", "0")
+        two = ctx.lanczosResize(img, dw, dh)
+        monkeypatch.delenv("FNX_RESIZE_FUSED", raising=False)
+        assert np.array_equal(got, two) and np.array_equal(got_view, two), (k, w, h, dw, dh)
+        if not big or k == 3:                                  # at 4K the oracle checks the translucent-patch image only
+            assert np.array_equal(got, orc.lanczos_resize(img, dw, dh, procs=32 if big else 8)), (k, w, h, dw, dh)
+
+
 def test_resize_plan_cache_eviction(ctx, orc):
     """More distinct tables than the ctx keeps plans for (8), revisited: results stay those of the oracle."""
     img = _opaque(synth.noise_image(240, 180, 2, alpha=True))
