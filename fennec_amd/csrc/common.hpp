@@ -351,14 +351,14 @@ struct DecTables {                                   // tables 0, 1: DC (th 0, 1
     uint8_t value[4][256];
 };
 
-// The synchronisation passes' form of the same tables: what a symbol DOES to the decoder's state, ready made.
-//   dc[t][prefix]   bits consumed (code + value) | 1 << 8                                        (0: a longer code)
-//   ac[t][prefix]   first symbol: bits | steps << 8 (steps: r + 1, or 64 for the end of block);
-//                   the first TWO symbols where the second one's code lies inside the prefix and the first does not
-//                   end the block: total bits << 16 | total steps << 24 (else 0)
+// The synchronisation passes' form of the same tables: what a symbol DOES to the decoder's state, ready made -- ONE
+// entry format for all four tables, so that a wave whose lanes stand in DC and in AC positions makes one LDS look-up per
+// symbol instead of two divergent ones (r3: the loop is a chain of dependent LDS round trips, ~600 clocks per symbol).
+//   st[t][prefix]   first symbol: bits consumed (code + value) | steps << 8 (DC: 1; AC: r + 1, or 64 for the end of block);
+//                   AC tables: the first TWO symbols where the second one's code lies inside the prefix and the first
+//                   does not end the block: total bits << 16 | total steps << 24 (else 0).  0: a longer code
 struct DecSyncTables {
-    uint32_t ac[2][1 << DEC_FAST_BITS];
-    uint16_t dc[2][1 << DEC_FAST_BITS];
+    uint32_t st[4][1 << DEC_FAST_BITS];
     uint32_t limit[4][18];
     int32_t delta[4][18];
     uint8_t value[4][256];

@@ -166,18 +166,12 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             // the sync passes' tables hold what a symbol does to the state, ready made -- and, for the AC tables, what the
             // next one does as well when its code lies inside the same 11 bits (about every second look-up on a photograph)
             const uint32_t px = c16 >> (16 - DEC_FAST_BITS);
-            uint32_t adv, step;
-            if (t < 2) {
-                e = sh.stab.dc[t][px];
-                adv = e & 0xffu; step = e >> 8;
-            } else {
-                e = sh.stab.ac[t - 2][px];
-                const uint32_t a1 = e & 0xffu, s1 = (e >> 8) & 0xffu, a2 = (e >> 16) & 0xffu, s2 = e >> 24;
-                // both symbols only if the second one belongs to this span and to this block (and, with restart intervals,
-                // never: the boundary tests are per symbol)
-                const bool two = !RST && a2 != 0 && rel + a1 < end && z + static_cast<int>(s1) < 64;
-                adv = two ? a2 : a1; step = two ? s2 : s1;
-            }
+            e = sh.stab.st[t][px];
+            const uint32_t a1 = e & 0xffu, s1 = (e >> 8) & 0xffu, a2 = (e >> 16) & 0xffu, s2 = e >> 24;
+            // both symbols only if the second one belongs to this span and to this block (and, with restart intervals,
+            // never: the boundary tests are per symbol); DC entries hold one symbol (a2 == 0)
+            const bool two = !RST && a2 != 0 && rel + a1 < end && z + static_cast<int>(s1) < 64;
+            const uint32_t adv = two ? a2 : a1, step = two ? s2 : s1;
             if (e) {
                 if (RST && rel + adv > bnext) {                    // padding before a boundary
                     rel = bnext;
@@ -521,7 +515,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
                 const uint32_t e = f->tab.fast[t][i];
                 uint32_t b1 = 0, s1 = 0;
                 if (e) effect(e, false, &b1, &s1);
-                ts->dc[t][i] = static_cast<uint16_t>(e ? (b1 | (s1 << 8)) : 0u);
+                ts->st[t][i] = e ? (b1 | (s1 << 8)) : 0u;
             }
         for (int t = 0; t < 2; t++)
             for (int i = 0; i < (1 << DEC_FAST_BITS); i++) {
@@ -542,7 +536,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
                         }
                     }
                 }
-                ts->ac[t][i] = v;
+                ts->st[2 + t][i] = v;
             }
     }
     FNX_HIP(hipMemcpyAsync(d_ecs, pin, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
