@@ -968,18 +968,20 @@ __device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &
     return o;
 }
 
-template <int NV>
-__global__ __launch_bounds__(256, 3) void resize_fused_kernel(ResizeFusedArgs fa)
+// RMAX: the tile's rows.  64 (32 KB: three workgroups per CU) where a 2:1 downscale needs them; 32 (16 KB) for upscales,
+// whose V groups read few tmp rows: with the phase buffers sized by the window (NV = 2: 13 KB) four workgroups fit a CU.
+template <int NV, int RMAX>
+__global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(ResizeFusedArgs fa)
 {
     constexpr int HO = RG_HO, NPX = 4 * NV, VG = RG_VG;
     static_assert(NV <= 4 && HO == 2, "weights in registers; two outputs per lane");
-    __shared__ __attribute__((aligned(16))) uint32_t s_tile[RF_RMAX * RF_TW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[RMAX * RF_TW];
     __shared__ uint32_t s_fix[RG_FIX_CAP];
     __shared__ int s_nfix, s_nfix2, s_ndense;
     // phase 1: fp64 aw [HO][NPX][64] of the exact loop.  phase 2, per wave: fp32 weights [64][VG], fp64 aw [64 + 4][VG],
     // trip masks [16 + 4]
-    __shared__ __attribute__((aligned(16))) unsigned char s_u[16384];
-    static_assert(sizeof(double) * HO * NPX * 64 <= sizeof(s_u) && 4 * (sizeof(float) * 64 * VG + sizeof(double) * 68 * VG + sizeof(uint32_t) * 20) <= sizeof(s_u), "union");
+    constexpr size_t U_H = sizeof(double) * HO * NPX * 64, U_V = 4 * (sizeof(float) * 64 * VG + sizeof(double) * 68 * VG + sizeof(uint32_t) * 20);
+    __shared__ __attribute__((aligned(16))) unsigned char s_u[(U_H > U_V ? U_H : U_V + 15) & ~size_t(15)];
     const ResizeGuardArgs &a = fa.h;
     const ResizeGuardArgs &v = fa.v;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1015,7 +1017,8 @@ __global__ __launch_bounds__(256, 3) void resize_fused_kernel(ResizeFusedArgs fa
             }
         }
     };
-    fetch_weights(gfirst + wave);
+    constexpr bool PRE = RMAX > 32;      // (the 32-row form has no registers to carry them through phase 1: it fetches per group)
+    if constexpr (PRE) fetch_weights(gfirst + wave);
     __syncthreads();                                                // the counters are in place
     uint32_t exact_rows = 0;                                        // bit r: row yw + r of this wave awaits the exact loop
     auto load_row = [&](int y, u32x4 (&w)[NV]) {
@@ -1185,6 +1188,7 @@ __global__ __launch_bounds__(256, 3) void resize_fused_kernel(ResizeFusedArgs fa
         }
         // the group's weights into this wave's corner of the LDS (previous group's reads have all returned: in-order)
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!PRE) fetch_weights(gi);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int idx = lane + 64 * k;
@@ -1194,7 +1198,7 @@ __global__ __launch_bounds__(256, 3) void resize_fused_kernel(ResizeFusedArgs fa
             const uint64_t nzb = __ballot(awt != 0.0);
             if (lane < 4) s_tm[4 * k + lane] = static_cast<uint32_t>(nzb >> (16 * lane)) & 0xffffu;
         }
-        fetch_weights(gi + 4);                                      // the next group's, in flight while this one is computed
+        if constexpr (PRE) fetch_weights(gi + 4);                   // the next group's, in flight while this one is computed
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1376,7 +1380,7 @@ struct fnx_resize_plan {
     // guard form
     bool guard_ok = false;
     int HO = 0, NV = 0, ngroups = 0, npx = 0;
-    int fused_ng = 0;                // vertical plans: V groups per tile of resize_fused_kernel (0: not eligible)
+    int fused_ng = 0, fused_ng32 = 0;   // vertical plans: V groups per 64-row / 32-row tile of resize_fused_kernel (0: not eligible)
     float guard = 0;
     const float *d_dense = nullptr;
     const int32_t *d_s0 = nullptr, *d_cnt = nullptr;
@@ -1515,15 +1519,19 @@ static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_p
         bool mono = true;
         for (int g = 1; g < ng; g++)
             if (s0v[g] < s0v[g - 1] || s0v[g] + cntv[g] < s0v[g - 1] + cntv[g - 1]) mono = false;
-        p.fused_ng = 0;
-        for (int cand = RF_NGMAX; mono && cand >= 1 && p.fused_ng == 0; cand--) {
-            bool fits = true;
-            for (int g0 = 0; g0 < ng && fits; g0 += cand) {
-                const int gl = std::min(g0 + cand, ng) - 1;
-                if (s0v[gl] + cntv[gl] - s0v[g0] > RF_RMAX) fits = false;
+        auto groups_that_fit = [&](int rmax) {
+            for (int cand = RF_NGMAX; mono && cand >= 1; cand--) {
+                bool fits = true;
+                for (int g0 = 0; g0 < ng && fits; g0 += cand) {
+                    const int gl = std::min(g0 + cand, ng) - 1;
+                    if (s0v[gl] + cntv[gl] - s0v[g0] > rmax) fits = false;
+                }
+                if (fits) return cand;
             }
-            if (fits) p.fused_ng = cand;
-        }
+            return 0;
+        };
+        p.fused_ng = groups_that_fit(RF_RMAX);
+        p.fused_ng32 = groups_that_fit(32);
     }
     // the bound of the header comment
     const double top = 255.0 * smax + 1.0;
@@ -1667,28 +1675,36 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     v.ngroups = pv->ngroups; v.npx = pv->npx; v.guard = pv->guard;
     v.dense = pv->d_dense; v.s0 = pv->d_s0; v.cnt = pv->d_cnt; v.alpha = pv->d_alpha;
     v.off = pv->d_off; v.idx = pv->d_idx; v.wt = pv->d_wt; v.aw = pv->d_aw; v.inv = pv->d_inv;
-    // V groups per tile.  A workgroup lives for tens of microseconds and three fit a CU, so what matters is how full the
-    // LAST round of workgroups is: 810 workgroups on 768 slots take two rounds, 675 one.  Among the counts from what the
-    // tile holds down to half of it (more groups = less row halo in phase 1), the one whose rounds are fullest.
+    // Tile height: 32 rows (four workgroups per CU) where they hold at least eight V groups -- upscales -- else 64 (three).
+    // V groups per tile: a workgroup lives for tens of microseconds, so what matters is how full the LAST round of
+    // workgroups is (810 workgroups on 768 slots take two rounds, 675 one): among the counts from what the tile holds
+    // down to half of it (more groups = less row halo in phase 1), the one whose rounds are fullest.
     const int gx = (ph->ngroups + 63) / 64;
-    int ng = pv->fused_ng;
+    static const bool no32 = [] { const char *e = getenv("FNX_RF_NO32"); return e && e[0] == '1'; }();   // experiments
+    const bool low = !no32 && ph->NV <= 2 && pv->fused_ng32 >= 8;
+    const int ngmax = low ? pv->fused_ng32 : pv->fused_ng;
+    int ng = ngmax;
     {
-        const double slots = 3.0 * ctx->num_cus;
+        const double slots = (low ? 4.0 : 3.0) * ctx->num_cus;
         double best = -1.0;
-        for (int cand = pv->fused_ng; cand >= std::max(2, pv->fused_ng / 2); cand--) {
+        for (int cand = ngmax; cand >= std::max(2, ngmax / 2); cand--) {
             const double rounds = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand) / slots;
             const double fill = rounds / std::ceil(rounds);
             if (fill > best + 0.02) { best = fill; ng = cand; }
         }
     }
-    if (const char *e = getenv("FNX_RF_NG")) ng = std::max(1, std::min(pv->fused_ng, atoi(e)));   // experiments
+    if (const char *e = getenv("FNX_RF_NG")) ng = std::max(1, std::min(ngmax, atoi(e)));   // experiments
     fa.ng = ng;
     const dim3 grid(gx, (pv->ngroups + ng - 1) / ng);
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
-    switch (ph->NV) {
-    case 2: hipLaunchKernelGGL(resize_fused_kernel<2>, grid, dim3(256), 0, ctx->stream, fa); break;
-    case 3: hipLaunchKernelGGL(resize_fused_kernel<3>, grid, dim3(256), 0, ctx->stream, fa); break;
-    default: hipLaunchKernelGGL(resize_fused_kernel<4>, grid, dim3(256), 0, ctx->stream, fa); break;
+    if (low) {
+        hipLaunchKernelGGL((resize_fused_kernel<2, 32>), grid, dim3(256), 0, ctx->stream, fa);
+    } else {
+        switch (ph->NV) {
+        case 2: hipLaunchKernelGGL((resize_fused_kernel<2, RF_RMAX>), grid, dim3(256), 0, ctx->stream, fa); break;
+        case 3: hipLaunchKernelGGL((resize_fused_kernel<3, RF_RMAX>), grid, dim3(256), 0, ctx->stream, fa); break;
+        default: hipLaunchKernelGGL((resize_fused_kernel<4, RF_RMAX>), grid, dim3(256), 0, ctx->stream, fa); break;
+        }
     }
     FNX_HIP(hipGetLastError());
     return prof_end(ctx);
