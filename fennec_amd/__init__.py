@@ -782,6 +782,21 @@ class Context:
                       "resize_pass")
         return dst
 
+    def lanczos_resize_tables(self, img, dst_w: int, dst_h: int, table_h, table_v):
+        """fnx_lanczos_resize: lanczosResize (resize.go:37-53) with the CALLER's two CSR tap tables (what a Go caller
+        passes: its own precomputeWeights output) -- both passes, one launch where the tables allow it."""
+        s = _Img(img)
+        oh, ih, wh = table_h
+        ov, iv, wv = table_v
+        oh, poh = _i32(oh); ih, pih = _i32(ih); wh, pwh = _f64(wh)
+        ov, pov = _i32(ov); iv, piv = _i32(iv); wv, pwv = _f64(wv)
+        dst = s.like(dst_w, dst_h)
+        d = _Img(dst)
+        with self._ordered(img, dst):
+            self._chk(self._lib.fnx_lanczos_resize(self._h, s.space, s.ptr, s.stride, s.w, s.h, poh, pih, pwh, pov, piv, pwv,
+                                                   d.ptr, d.stride, dst_w, dst_h), "fnx_lanczos_resize")
+        return dst
+
     # -- exif.go ------------------------------------------------------------------------
     def ApplyOrientation(self, img, orient: int):
         """exif.go:178.  Orientation 0, 1 and unknown values return `img` itself."""

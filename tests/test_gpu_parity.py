@@ -401,6 +401,27 @@ def test_resize_passes_with_explicit_tables(ctx, orc):
         assert np.array_equal(ctx.resize_pass(img, 70, False, tab), orc.resize_h(img, 70, tab)), gap
 
 
+def test_lanczos_resize_with_the_callers_tables(ctx, orc):
+    """fnx_lanczos_resize with caller-supplied tables (compared by content: no table id) -- what the cgo shim passes.  The
+    reference's own tables take the one-launch kernel; hand-made V tables whose windows do NOT move down monotonically
+    (here: the reference's rows in reverse, a vertical flip) cannot share a tile and take the two passes; both against
+    the oracle's passes composed."""
+    img = _opaque(synth.noise_image(333, 211, 9, alpha=True))
+    img[50:80, 100:160, 3] = 40
+    for dw, dh in ((166, 105), (500, 400), (333, 300)):
+        th, tv = orc.precompute_weights(dw, 333), orc.precompute_weights(dh, 211)
+        want = orc.resize_v(orc.resize_h(img, dw, th), dh, tv)
+        assert np.array_equal(ctx.lanczos_resize_tables(img, dw, dh, th, tv), want), (dw, dh)
+        assert np.array_equal(want, orc.lanczos_resize(img, dw, dh))
+        off, idx, wt = (np.asarray(x) for x in tv)
+        roff, ridx, rwt = [0], [], []
+        for d in range(dh - 1, -1, -1):                        # output row d of the flipped table = the reference's row dh - 1 - d
+            ridx += list(idx[off[d]:off[d + 1]]); rwt += list(wt[off[d]:off[d + 1]]); roff.append(len(ridx))
+        rv = (np.array(roff, np.int32), np.array(ridx, np.int32), np.array(rwt, np.float64))
+        got = ctx.lanczos_resize_tables(img, dw, dh, th, rv)
+        assert np.array_equal(got, orc.resize_v(orc.resize_h(img, dw, th), dh, rv)) and np.array_equal(got, want[::-1]), (dw, dh, "flipped")
+
+
 def test_resize_v_with_scattered_windows(ctx, orc):
     """resizeV with hand-made contiguous tap lists whose windows are NOT monotone from one output row to the
     next (the column-walking V kernel shares source rows among 4 consecutive outputs and must still apply each
