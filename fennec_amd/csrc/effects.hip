@@ -40,8 +40,10 @@ struct FxArgs {
     const int32_t *rtab;   // device: R[d + 255], d in [-255, 255] (+ one pad entry); Sharpen, AdaptiveSharpen saturated pixels
     float amt32, k32;      // AdaptiveSharpen: (float)amount, (float)(amount / 400000)
     float guard;           // G
+    float flag_thr;        // AdaptiveSharpen, paired-row path: a sample with fract(acc) >= flag_thr has an integer within 2G above it
     int use_table;         // AdaptiveSharpen: surely saturated pixels (e == 1) take R instead of the guard
     int vec_ok;            // src base and stride 16-byte aligned
+    int pairs;             // AdaptiveSharpen: interior tiles take the paired-row form (FNX_FX_PAIRS=0: the one-row form, A/B)
 };
 
 // ------------------------------------------------------------------------------------
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void fx_ref_kernel(FxArgs a)
 // ------------------------------------------------------------------------------------
 // column-marching kernel
 // ------------------------------------------------------------------------------------
-constexpr int FX_TW = 64, FX_TH = 32, FX_RP = 8;       // tile, output rows per lane
+constexpr int FX_TW = 64, FX_TH = 24, FX_RP = 6;       // tile, output rows per lane
 constexpr int FX_LW = 72, FX_LH = FX_TH + 2;           // tile row pitch in words: image column x0 + i lives at word 4 + i,
                                                        // so that the 64-column body is 16-byte aligned; halos at 3 and 68
 constexpr int FX_FIX_CAP = 512;
@@ -141,10 +143,25 @@ __device__ __forceinline__ uint32_t lum_milli_u32(uint32_t p)
     return __builtin_amdgcn_udot4(p, 0x0072ffffu, i, false);
 }
 
+// byte N of a word as a float (v_cvt_f32_ubyteN)
+template <int N>
+__device__ __forceinline__ float ubyte_f32(uint32_t w)
+{
+    float f;
+    if (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+    else if (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+    else if (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+}
+
+// G | A << 16 of a pixel in one v_perm_b32 (the R | B << 16 word is one v_and_b32)
+__device__ __forceinline__ uint32_t ga_fields(uint32_t p) { return __builtin_amdgcn_perm(0u, p, 0x0c030c01u); }
+
 // AdaptiveSharpen is occupancy-bound (a workgroup is load tile -> barrier -> compute -> store, and what hides one
 // phase is other workgroups): 5 per CU -- <= 96 VGPRs, <= 32 KB of LDS each (16-bit table and fix-up list)
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_kernel(FxArgs a)
+__global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 6 : 1) void fx_march_kernel(FxArgs a)
 {
     constexpr int LW = FX_LW, LH = FX_LH;
     __shared__ __attribute__((aligned(16))) uint32_t s_rb[LH * LW], s_ga[LH * LW];
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_ker
     }
     auto put = [&](int cell, uint32_t p) {
         s_rb[cell] = p & 0x00ff00ffu;
-        s_ga[cell] = (p >> 8) & 0x00ff00ffu;
+        s_ga[cell] = ga_fields(p);
         if constexpr (MODE == FX_ADAPTIVE) s_lum[cell] = lum_milli_u32(p);
     };
     // ---- stage the (TH + 2) x (TW + 2) source tile: clamped reads -- out-of-image cells are only ever
@@ -192,8 +209,7 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_ker
                 const int ly = i >> 4, c = i & 15;
                 const int cell = ly * LW + 4 + 4 * c;
                 *reinterpret_cast<u32x4 *>(&s_rb[cell]) = (u32x4){v[k][0] & 0x00ff00ffu, v[k][1] & 0x00ff00ffu, v[k][2] & 0x00ff00ffu, v[k][3] & 0x00ff00ffu};
-                *reinterpret_cast<u32x4 *>(&s_ga[cell]) = (u32x4){(v[k][0] >> 8) & 0x00ff00ffu, (v[k][1] >> 8) & 0x00ff00ffu,
-                                                                  (v[k][2] >> 8) & 0x00ff00ffu, (v[k][3] >> 8) & 0x00ff00ffu};
+                *reinterpret_cast<u32x4 *>(&s_ga[cell]) = (u32x4){ga_fields(v[k][0]), ga_fields(v[k][1]), ga_fields(v[k][2]), ga_fields(v[k][3])};
                 if constexpr (MODE == FX_ADAPTIVE)
                     *reinterpret_cast<u32x4 *>(&s_lum[cell]) = (u32x4){lum_milli_u32(v[k][0]), lum_milli_u32(v[k][1]), lum_milli_u32(v[k][2]), lum_milli_u32(v[k][3])};
             }
@@ -214,8 +230,7 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_ker
     // per tile row: horizontal [1 2 1] of both field words; Sobel column difference and [1 2 1] row sum of I
     uint32_t hrb[FX_RP + 2], hga[FX_RP + 2];
     int32_t dxr[MODE == FX_ADAPTIVE ? FX_RP + 2 : 1], sxr[MODE == FX_ADAPTIVE ? FX_RP + 2 : 1];
-#pragma unroll
-    for (int r = 0; r < FX_RP + 2; r++) {
+    auto tile_row = [&](int r) {
         const int c = base + r * LW;
         hrb[r] = s_rb[c - 1] + s_rb[c + 1] + 2 * s_rb[c];
         hga[r] = s_ga[c - 1] + s_ga[c + 1] + 2 * s_ga[c];
@@ -224,12 +239,15 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_ker
             dxr[r] = rr - l;
             sxr[r] = l + rr + 2 * m;
         }
-    }
+    };
     const float seed = 0.5f - a.guard, g2 = 2.0f * a.guard;
+    const uint32_t doff0 = static_cast<uint32_t>(y0 + rg * FX_RP) * static_cast<uint32_t>(a.dstride) + 4u * static_cast<uint32_t>(x);
     // tiles that touch no image border (all but the frame) skip the per-pixel edge tests
     const bool interior = x0 >= 1 && y0 >= 1 && x0 + FX_TW < a.w && y0 + FX_TH < a.h;
     auto rows = [&](auto tag) {
         constexpr bool INTERIOR = decltype(tag)::value;
+#pragma unroll
+        for (int r = 0; r < FX_RP + 2; r++) tile_row(r);
 #pragma unroll
         for (int j = 0; j < FX_RP; j++) {
             const int y = y0 + rg * FX_RP + j;
@@ -288,12 +306,95 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 5 : 1) void fx_march_ker
                     }
                 }
             }
+            // (32-bit offsets: the store takes the scalar base + one VGPR; launch_fx sends images of 2 GiB and more elsewhere)
             if ((INTERIOR || (x < a.w && y < a.h)) && !flagged)
-                *(g_u32w *)(a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x)) = out;
+                *(g_u32w *)(a.dst + (doff0 + static_cast<uint32_t>(j) * static_cast<uint32_t>(a.dstride))) = out;
         }
     };
-    if (interior) rows(std::true_type{});
-    else rows(std::false_type{});
+    // AdaptiveSharpen, interior tiles: two rows at a time, so that the fp32 chain runs as v_pk_* on (row j, row j + 1)
+    // pairs -- the same operations in the same order per sample as the one-row form above (same guard proof), with
+    // one boundary test per sample instead of a second pack: acc = V~ + 0.5 - G is within E < G of V + 0.5 - G, so
+    // V + 0.5 lies in (acc, acc + 2G) and floor(V + 0.5) == floor(acc) unless an integer does too, i.e. unless
+    // fract(acc) >= 1 - 2G (flag_thr is that bound rounded down); v_fract_f32 is exact.  Negative acc and acc > 255
+    // only ever flag too much: both forms saturate.
+    auto rows2 = [&]() {
+        const v2f seed2 = {seed, seed};
+        const float amt = __builtin_canonicalizef(a.amt32), thr = a.flag_thr;
+        const v2f k2 = {a.k32, a.k32};
+        const bool use_table = a.use_table != 0;
+        // the tile rows roll with the pairs (rows j + 2, j + 3 are read while pair j is computed) and nothing is
+        // scheduled across a pair's end: with all ten rows read up front the kernel spilled six registers at its
+        // 96-VGPR budget, and a reload inside this loop waits for vmcnt(0) -- i.e. for the previous pair's stores
+        tile_row(0);
+        tile_row(1);
+#pragma unroll
+        for (int j = 0; j < FX_RP; j += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            tile_row(j + 2);
+            tile_row(j + 3);
+            const int ci = base + (j + 1) * LW;
+            const uint32_t crb0 = s_rb[ci], cga0 = s_ga[ci], crb1 = s_rb[ci + LW], cga1 = s_ga[ci + LW];
+            const uint32_t srb0 = hrb[j] + hrb[j + 2] + 2 * hrb[j + 1] + 0x00080008u;
+            const uint32_t sga0 = hga[j] + hga[j + 2] + 2 * hga[j + 1] + 0x00080008u;
+            const uint32_t srb1 = hrb[j + 1] + hrb[j + 3] + 2 * hrb[j + 2] + 0x00080008u;
+            const uint32_t sga1 = hga[j + 1] + hga[j + 3] + 2 * hga[j + 2] + 0x00080008u;
+            const uint32_t brb0 = srb0 >> 4, bga0 = sga0 >> 4, brb1 = srb1 >> 4, bga1 = sga1 >> 4;
+            const v2f gx = {static_cast<float>(dxr[j] + dxr[j + 2] + 2 * dxr[j + 1]), static_cast<float>(dxr[j + 1] + dxr[j + 3] + 2 * dxr[j + 2])};
+            const v2f gy = {static_cast<float>(sxr[j + 2] - sxr[j]), static_cast<float>(sxr[j + 3] - sxr[j + 1])};
+            const v2f m2 = __builtin_elementwise_fma(gy, gy, gx * gx);
+            const v2f sq = {__builtin_amdgcn_sqrtf(m2.x), __builtin_amdgcn_sqrtf(m2.y)};
+            const v2f tk = sq * k2;
+            const v2f t = {fminf(amt, tk.x), fminf(amt, tk.y)};
+            auto chan = [&](float o0, float o1, float b0, float b1) {
+                const v2f f = {o0, o1}, bl = {b0, b1};
+                return __builtin_elementwise_fma(t, f - bl, f + seed2);
+            };
+            // bytes to floats straight from the field words (opaque to the compiler, which otherwise subtracts in integers
+            // behind byte masks: 7 instructions per sample where this is 2 + 1.5)
+            const v2f ar = chan(ubyte_f32<0>(crb0), ubyte_f32<0>(crb1), ubyte_f32<0>(brb0), ubyte_f32<0>(brb1));
+            const v2f ag = chan(ubyte_f32<0>(cga0), ubyte_f32<0>(cga1), ubyte_f32<0>(bga0), ubyte_f32<0>(bga1));
+            const v2f ab = chan(ubyte_f32<2>(crb0), ubyte_f32<2>(crb1), ubyte_f32<2>(brb0), ubyte_f32<2>(brb1));
+            const float f0 = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar.x), __builtin_amdgcn_fractf(ag.x)), __builtin_amdgcn_fractf(ab.x));
+            const float f1 = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar.y), __builtin_amdgcn_fractf(ag.y)), __builtin_amdgcn_fractf(ab.y));
+            fp32_round_toward_zero();
+            uint32_t out0 = pk8(ab.x, 2, pk8(ag.x, 1, pk8(ar.x, 0, cga0 << 8)));
+            uint32_t out1 = pk8(ab.y, 2, pk8(ag.y, 1, pk8(ar.y, 0, cga1 << 8)));
+            fp32_round_nearest();
+            bool flag0 = f0 >= thr, flag1 = f1 >= thr;
+            if (use_table) {                                     // e == 1 for certain: exact by table (see the one-row form)
+                auto tab = [&](uint32_t crb, uint32_t cga, uint32_t brb, uint32_t bga) {
+                    const int br = brb & 0xffu, bg = bga & 0xffu, bb = (brb >> 16) & 0xffu;
+                    const int o_r = crb & 0xffu, o_g = cga & 0xffu, o_b = (crb >> 16) & 0xffu;
+                    const int vr = clampi(o_r + s_tab[o_r - br + 255], 0, 255), vg = clampi(o_g + s_tab[o_g - bg + 255], 0, 255),
+                              vb = clampi(o_b + s_tab[o_b - bb + 255], 0, 255);
+                    return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | ((cga << 8) & 0xff000000u);
+                };
+                if (m2.x > 1.6000016e11f) { out0 = tab(crb0, cga0, brb0, bga0); flag0 = false; }
+                if (m2.y > 1.6000016e11f) { out1 = tab(crb1, cga1, brb1, bga1); flag1 = false; }
+            }
+            if (flag0 || flag1) {
+                if (flag0) {
+                    const int e = atomicAdd(&s_nfix, 1);
+                    if (e < FX_FIX_CAP) s_fix[e] = static_cast<uint16_t>(((rg * FX_RP + j) << 8) | cx);
+                }
+                if (flag1) {
+                    const int e = atomicAdd(&s_nfix, 1);
+                    if (e < FX_FIX_CAP) s_fix[e] = static_cast<uint16_t>(((rg * FX_RP + j + 1) << 8) | cx);
+                }
+            }
+            const uint32_t d0 = doff0 + static_cast<uint32_t>(j) * static_cast<uint32_t>(a.dstride);
+            if (!flag0) *(g_u32w *)(a.dst + d0) = out0;
+            if (!flag1) *(g_u32w *)(a.dst + (d0 + static_cast<uint32_t>(a.dstride))) = out1;
+        }
+    };
+    if constexpr (MODE == FX_ADAPTIVE) {
+        if (interior && a.pairs) rows2();
+        else if (interior) rows(std::true_type{});
+        else rows(std::false_type{});
+    } else {
+        if (interior) rows(std::true_type{});
+        else rows(std::false_type{});
+    }
     if constexpr (MODE == FX_ADAPTIVE) {
         // flagged pixels (a rounding boundary within G of the fp32 value): the reference's own fp64 arithmetic.
         // A list overflow recomputes every interior pixel of the tile.
@@ -415,6 +516,15 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
             march = tab_ok;
         } else {
             march = fx_guard(amount, &a.guard);
+            {
+                // 1 - 2G, rounded down, with a margin far above the rounding of `seed` and of this subtraction
+                const double thr = 1.0 - 2.0 * static_cast<double>(a.guard) - 1e-6;
+                float t32 = static_cast<float>(thr);
+                if (static_cast<double>(t32) > thr) t32 = std::nextafterf(t32, 0.0f);
+                a.flag_thr = t32;
+                static const int pairs = [] { const char *e = getenv("FNX_FX_PAIRS"); return e ? atoi(e) : 1; }();
+                a.pairs = pairs;
+            }
             a.amt32 = static_cast<float>(amount);
             a.k32 = static_cast<float>(amount / 400000.0);
             a.use_table = (tab_ok && ties) ? 1 : 0;     // tie-prone amounts (1.5, 2.5, ...): saturated pixels skip the guard
@@ -426,6 +536,8 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
         }
     }
     if (force_ref && force_ref[0] == '1') march = false;
+    // the tile kernels address the destination with 32-bit offsets
+    if (static_cast<long long>(h) * dstride >= (1ll << 31)) march = false;
     FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
     if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
