@@ -43,6 +43,7 @@ struct FxArgs {
     float flag_thr;        // AdaptiveSharpen, paired-row path: a sample with fract(acc) >= flag_thr has an integer within 2G above it
     int use_table;         // AdaptiveSharpen: surely saturated pixels (e == 1) take R instead of the guard
     int vec_ok;            // src base and stride 16-byte aligned
+    int strips, segs, seg_rows;   // streaming form: per image strips x segs wave-sized items of seg_rows output rows
     int pairs;             // AdaptiveSharpen: interior tiles take the paired-row form (FNX_FX_PAIRS=0: the one-row form, A/B)
 };
 
@@ -421,6 +422,191 @@ __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 6 : 1) void fx_march_ker
     }
 }
 
+// one flagged interior sample of AdaptiveSharpen, recomputed from the source image in the reference's own fp64 arithmetic
+__device__ __forceinline__ void fx_fix_from_source(const FxArgs &a, int px, int py)
+{
+    uint32_t nrb[9], nga[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const uint32_t p = ld_px(a.src + static_cast<size_t>(py + j - 1) * a.sstride, px + i - 1);
+            nrb[3 * j + i] = p & 0x00ff00ffu;
+            nga[3 * j + i] = (p >> 8) & 0x00ff00ffu;
+        }
+    *(g_u32w *)(a.dst + static_cast<size_t>(py) * a.dstride + 4 * static_cast<size_t>(px)) = fx_exact_px<FX_ADAPTIVE>(nrb, nga, a.amount);
+}
+
+// ------------------------------------------------------------------------------------
+// streaming form (round 3): a WAVE marches down a strip of the image -- what every tight or strided image takes
+// ------------------------------------------------------------------------------------
+// The tile kernel above is phases -- load tile, barrier, compute, store -- and what hides one workgroup's phase is other
+// workgroups: gaussianBlur3x3, with next to no arithmetic, takes 58 us per 8K image (4.5 TB/s against a 6.2-7 TB/s copy),
+// AdaptiveSharpen 74-82 us at 70-80 % VALU issue, and neither moved with fewer instructions or more workgroups per CU.
+// Here nothing waits for a tile: a wave owns FXS_COLS = 62 output columns (64 pixel columns, one per lane) and walks
+// down a segment of rows with FXS_PF rows of loads in flight; per row a lane turns ITS pixel into the field words and the
+// integer milli-luminance once, hands them to its two neighbours through a per-wave LDS row (no barrier: one wave, LDS
+// is in order), and keeps the horizontal sums of the last three rows in a register ring (unrolled over the ring's
+// phases, so every index is static).  Column halo 64 / 62, row halo (S + 2) / S; the arithmetic per output is the tile
+// kernel's one-row form with the boundary test of its paired form (same guard, same proof).  Flagged samples go to a
+// per-wave list and are recomputed at the end of the segment -- in fp64, in the reference's order, from the source.
+constexpr int FXS_COLS = 62;
+constexpr int FXS_PF = 6;                  // rows in flight per lane; the unroll is lcm(PF, 3 ring phases, 2 LDS slots)
+constexpr int FXS_LW = 68;
+constexpr int FXS_FIX = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
+{
+    __shared__ uint32_t s_x[4][2][3][FXS_LW];                            // [wave][slot][R|B, G|A, I][lane + 1]
+    __shared__ int16_t s_tab[MODE != FX_BLUR3 ? 512 : 2];
+    __shared__ uint32_t s_fix[4][MODE == FX_ADAPTIVE ? FXS_FIX : 1];
+    __shared__ int s_nfix[4];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (MODE == FX_SHARPEN || (MODE == FX_ADAPTIVE && a.use_table)) {
+        s_tab[tid] = static_cast<int16_t>(a.rtab[tid]);
+        s_tab[256 + tid] = static_cast<int16_t>(a.rtab[256 + tid]);
+    }
+    if (tid < 4) s_nfix[tid] = 0;
+    __syncthreads();                                                     // the only barrier
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.strips * a.segs) return;                               // wave-uniform
+    const int seg = item / a.strips, strip = item - seg * a.strips;
+    const int x = strip * FXS_COLS - 1 + lane;
+    const uint32_t xoff = 4u * static_cast<uint32_t>(clampi(x, 0, a.w - 1));   // clamped reads: see the tile kernel
+    const uint32_t xo = 4u * static_cast<uint32_t>(x);                   // (only lanes with 0 <= x < w store)
+    const int y0 = seg * a.seg_rows;
+    const int nout = min(a.seg_rows, a.h - y0), nrows = nout + 2;        // rows y0 - 1 .. y0 + nout
+    const bool mine = lane >= 1 && lane <= FXS_COLS && x < a.w;          // lanes 0 and 63 are taps only
+    const bool xborder = x <= 0 || x >= a.w - 1;
+    auto load_row = [&](int r) {                                         // r is wave-uniform: a scalar row base + one VGPR
+        const int yy = clampi(y0 - 1 + min(r, nrows - 1), 0, a.h - 1);
+        return *(g_u32 *)(a.src + (static_cast<uint32_t>(yy) * static_cast<uint32_t>(a.sstride) + xoff));
+    };
+    uint32_t q[FXS_PF];
+#pragma unroll
+    for (int k = 0; k < FXS_PF; k++) q[k] = load_row(k);
+    uint32_t hrb[3], hga[3], crb[3], cga[3];
+    int32_t dxr[3], sxr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) hrb[k] = hga[k] = crb[k] = cga[k] = 0u, dxr[k] = sxr[k] = 0;
+    const float seed = 0.5f - a.guard;
+    const float amt = __builtin_canonicalizef(a.amt32), k32 = a.k32, thr = a.flag_thr;
+    const bool use_table = a.use_table != 0;
+    // per-lane forms of the amount and of the saturation bound: the image's border columns are copies of the source
+    const float amt_lane = xborder ? 0.0f : amt, sat_lane = xborder ? __builtin_inff() : 1.6000016e11f;
+    uint32_t(*sw)[3][FXS_LW] = s_x[wave];
+
+    for (int r0 = 0; r0 < nrows; r0 += 6) {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int r = r0 + p;
+            if (r < nrows) {                                             // wave-uniform
+                const int k = p % 3, slot = p & 1;
+                const uint32_t px = q[p % FXS_PF];
+                q[p % FXS_PF] = load_row(r + FXS_PF);                    // no branch around the load
+                const uint32_t rb = px & 0x00ff00ffu, ga = ga_fields(px);
+                sw[slot][0][lane + 1] = rb;
+                sw[slot][1][lane + 1] = ga;
+                uint32_t lum = 0;
+                if constexpr (MODE == FX_ADAPTIVE) {
+                    lum = lum_milli_u32(px);
+                    sw[slot][2][lane + 1] = lum;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                hrb[k] = sw[slot][0][lane] + sw[slot][0][lane + 2] + 2 * rb;
+                hga[k] = sw[slot][1][lane] + sw[slot][1][lane + 2] + 2 * ga;
+                crb[k] = rb;
+                cga[k] = ga;
+                if constexpr (MODE == FX_ADAPTIVE) {
+                    const int32_t l = static_cast<int32_t>(sw[slot][2][lane]), rr = static_cast<int32_t>(sw[slot][2][lane + 2]);
+                    dxr[k] = rr - l;
+                    sxr[k] = l + rr + 2 * static_cast<int32_t>(lum);
+                }
+                if (r >= 2) {
+                    // output row yo: its three tile rows are ring entries T (yo - 1), M (yo), B (yo + 1) = the newest
+                    const int T = (p + 1) % 3, M = (p + 2) % 3, B = p % 3;
+                    const int yo = y0 + r - 2;
+                    const uint32_t c = crb[M] | (cga[M] << 8);
+                    uint32_t out = c;                                    // borders and alpha are copies of the source (effects.go:68,120)
+                    bool flagged = false;
+                    if (yo >= 1 && yo < a.h - 1) {                       // wave-uniform
+                        const uint32_t srb = hrb[T] + hrb[B] + 2 * hrb[M] + 0x00080008u;
+                        const uint32_t sga = hga[T] + hga[B] + 2 * hga[M] + 0x00080008u;
+                        const uint32_t brb = srb >> 4, bga = sga >> 4;   // blurred R | B << 16 (bytes 0, 2), blurred G in byte 0
+                        auto tab = [&]() {
+                            const int br = brb & 0xffu, bg = bga & 0xffu, bb = (brb >> 16) & 0xffu;
+                            const int o_r = crb[M] & 0xffu, o_g = cga[M] & 0xffu, o_b = (crb[M] >> 16) & 0xffu;
+                            const int vr = clampi(o_r + s_tab[o_r - br + 255], 0, 255), vg = clampi(o_g + s_tab[o_g - bg + 255], 0, 255),
+                                      vb = clampi(o_b + s_tab[o_b - bb + 255], 0, 255);
+                            return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | (c & 0xff000000u);
+                        };
+                        uint32_t v;
+                        if constexpr (MODE == FX_BLUR3) {
+                            v = __builtin_amdgcn_perm(bga, brb, 0x0c020400u) | (c & 0xff000000u);   // R, G, B bytes of the sums
+                        } else if constexpr (MODE == FX_SHARPEN) {
+                            v = tab();
+                        } else {
+                            const float gx = static_cast<float>(dxr[T] + dxr[B] + 2 * dxr[M]);
+                            const float gy = static_cast<float>(sxr[B] - sxr[T]);
+                            const float m2 = fmaf(gy, gy, gx * gx);
+                            float t;                                     // min(amount, amount * |Sobel| / 400000); 0 on the image's border columns
+                            asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(__builtin_amdgcn_sqrtf(m2) * k32), "v"(amt_lane));
+                            const float fr = ubyte_f32<0>(crb[M]), fg = ubyte_f32<0>(cga[M]), fb = ubyte_f32<2>(crb[M]);
+                            const float ar = fmaf(t, fr - ubyte_f32<0>(brb), fr + seed);
+                            const float ag = fmaf(t, fg - ubyte_f32<0>(bga), fg + seed);
+                            const float ab = fmaf(t, fb - ubyte_f32<2>(brb), fb + seed);
+                            const float fmx = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar), __builtin_amdgcn_fractf(ag)), __builtin_amdgcn_fractf(ab));
+                            fp32_round_toward_zero();
+                            v = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, cga[M] << 8)));
+                            fp32_round_nearest();
+                            flagged = fmx >= thr;
+                            if (use_table && m2 > sat_lane) {            // e == 1 for certain: exact by table
+                                v = tab();
+                                flagged = false;
+                            }
+                        }
+                        // (AdaptiveSharpen: a border column runs with amount 0 -- acc = orig + 0.5 - G packs to orig and never flags)
+                        out = (MODE != FX_ADAPTIVE && xborder) ? c : v;
+                        flagged = flagged && mine;
+                        if constexpr (MODE == FX_ADAPTIVE) {
+                            if (flagged) {
+                                const int e = atomicAdd(&s_nfix[wave], 1);
+                                if (e < FXS_FIX) s_fix[wave][e] = (static_cast<uint32_t>(yo) << 16) | static_cast<uint32_t>(x);
+                            }
+                        }
+                    }
+                    if (mine && !flagged) *(g_u32w *)(a.dst + (static_cast<uint32_t>(yo) * static_cast<uint32_t>(a.dstride) + xo)) = out;
+                }
+            }
+        }
+    }
+    if constexpr (MODE == FX_ADAPTIVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // a list that overflowed (an amount / image that flags nearly everything): every interior sample of the segment
+        const int nfix = s_nfix[wave];
+        const bool over = nfix > FXS_FIX;
+        const int total = over ? nout * FXS_COLS : nfix;
+        for (int e = lane; e < total; e += 64) {
+            int fx, fy;
+            if (over) {
+                fy = y0 + e / FXS_COLS;
+                fx = strip * FXS_COLS + (e - (e / FXS_COLS) * FXS_COLS);
+            } else {
+                const uint32_t ent = s_fix[wave][e];
+                fx = static_cast<int>(ent & 0xffffu);
+                fy = static_cast<int>(ent >> 16);
+            }
+            if (fx >= 1 && fy >= 1 && fx < a.w - 1 && fy < a.h - 1) fx_fix_from_source(a, fx, fy);
+        }
+    }
+}
+
 // R[d + 255] = floor(fl(amount * d) + 0.5), d in [-255, 255].  false: some product is within 1e-6 of a
 // half-integer without being one (the sum's fp64 rounding could then decide), or the table would not fit.
 // *ties: some product IS a half-integer (only the guard's statistics care).
@@ -522,8 +708,8 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
                 float t32 = static_cast<float>(thr);
                 if (static_cast<double>(t32) > thr) t32 = std::nextafterf(t32, 0.0f);
                 a.flag_thr = t32;
-                static const int pairs = [] { const char *e = getenv("FNX_FX_PAIRS"); return e ? atoi(e) : 1; }();
-                a.pairs = pairs;
+                const char *pe = getenv("FNX_FX_PAIRS");          // tile kernel, A/B and tests: "0" takes the one-row form
+                a.pairs = pe ? atoi(pe) : 1;
             }
             a.amt32 = static_cast<float>(amount);
             a.k32 = static_cast<float>(amount / 400000.0);
@@ -539,7 +725,26 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     // the tile kernels address the destination with 32-bit offsets
     if (static_cast<long long>(h) * dstride >= (1ll << 31)) march = false;
     FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
-    if (march) {
+    const char *stream_env = getenv("FNX_FX_STREAM");            // A/B and tests: "0" takes the tile kernel
+    const int stream_on = stream_env ? atoi(stream_env) : 1;
+    if (march && stream_on && w < 65536 && h < 65536 && static_cast<long long>(h) * sstride < (1ll << 31)) {
+        // one wave per (strip, segment); segments sized so that the launch is one round of resident waves
+        static const int per_cu = [] {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fx_stream_kernel<MODE>, 256, 0) != hipSuccess || nb < 1) nb = 4;
+            return nb;
+        }();
+        static const int rounds = [] { const char *e = getenv("FNX_FX_ROUNDS"); return e ? atoi(e) : 1; }();
+        a.strips = (w + FXS_COLS - 1) / FXS_COLS;
+        const long capacity = static_cast<long>(ctx->num_cus) * per_cu * 4 * rounds;
+        int segs = static_cast<int>(capacity / a.strips);
+        segs = segs < 1 ? 1 : segs;
+        a.seg_rows = (h + segs - 1) / segs;
+        if (a.seg_rows < 16) a.seg_rows = h < 16 ? h : 16;
+        a.segs = (h + a.seg_rows - 1) / a.seg_rows;
+        const int items = a.strips * a.segs;
+        hipLaunchKernelGGL((fx_stream_kernel<MODE>), dim3((items + 3) / 4), dim3(256), 0, ctx->stream, a);
+    } else if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
         // FNX_FX_LDS_PAD=<bytes> of unused dynamic LDS: an A/B knob for workgroups per CU (8192 -> 4 instead of 5)
         static const unsigned pad = [] { const char *e = getenv("FNX_FX_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();

@@ -993,6 +993,7 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
         m1[s][0] = m1[s][1] = m1[s][2] = m1[s][3] = 0.0;
     }
     double val0 = 0.0, val1 = 0.0;
+    double P0 = 0.0, Q0 = 1.0, P1 = 0.0, Q1 = 1.0;                 // the fraction of the windows not yet divided
     typedef __attribute__((address_space(1))) const u32x2 g_u32x2;
     u32x2 qa[WM_PF], qb[WM_PF];
 #pragma unroll
@@ -1068,19 +1069,42 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
                 }
                 if (i >= 7) {
                     const int s = (p + 1) & 7;
-                    auto score = [&](const double (&mm)[4]) {
+                    // numerator and denominator of one window's SSIM (ssim.go:150-155, scaled by 1e6 twice)
+                    auto numden = [&](const double (&mm)[4], double &num, double &den) {
                         const double muA = mm[0], muB = mm[1];
                         const double mu2 = fma(muB, muB, muA * muA), muAB = muA * muB;
                         const double sSum = mm[2] - mu2, sAB = mm[3] - muAB;
-                        const double num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
-                        const double den = (mu2 + C1) * (sSum + C2);
+                        num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
+                        den = (mu2 + C1) * (sSum + C2);
+                    };
+                    auto quot = [&](double num, double den) {
                         double rc = __builtin_amdgcn_rcp(den);
                         rc = fma(fma(-den, rc, 1.0), rc, rc);
                         rc = fma(fma(-den, rc, 1.0), rc, rc);
                         return num * rc;
                     };
-                    val0 += score(m0[s]);
-                    val1 += score(m1[s]);
+                    // ONE division per four windows of a column: n1/d1 + ... + n4/d4 as a single fraction, built up as
+                    // P <- P d + n Q, Q <- Q d (den <= 1.7e22, so Q stays below 1e89; every term is positive and the
+                    // whole is a few ulp from the sum of the four quotients -- the bar is 1e-9).  v_rcp_f64 and its two
+                    // Newton steps were 9 of the 21 instruction slots a window's score took.
+                    double n0, d0, n1, d1;
+                    numden(m0[s], n0, d0);
+                    numden(m1[s], n1, d1);
+                    if (r == 0) {                                 // the first ring fill: only p == 7 has a complete window
+                        val0 += quot(n0, d0);
+                        val1 += quot(n1, d1);
+                    } else {
+                        if ((p & 3) == 0) {
+                            P0 = n0; Q0 = d0; P1 = n1; Q1 = d1;
+                        } else {
+                            P0 = fma(P0, d0, n0 * Q0); Q0 *= d0;
+                            P1 = fma(P1, d1, n1 * Q1); Q1 *= d1;
+                        }
+                        if ((p & 3) == 3 || i == nrows - 1) {     // wave-uniform
+                            val0 += quot(P0, Q0);
+                            val1 += quot(P1, Q1);
+                        }
+                    }
                 }
             }
         }

@@ -168,6 +168,41 @@ def test_sharpen_adaptive_guarded_kernels(ctx, orc, w, h):
             assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), ("adaptive", s)
 
 
+@pytest.mark.parametrize("form", ["stream", "tile_pairs", "tile_rows"])
+@pytest.mark.parametrize("w,h", [(64, 24), (62, 16), (63, 17), (125, 100), (200, 150), (1000, 37), (3, 3), (2, 9), (9, 2), (1, 1), (4, 700), (517, 389)])
+def test_fx_kernel_forms(ctx, orc, monkeypatch, form, w, h):
+    """Round 3: the streaming kernel (a wave marches down a strip of 62 columns) and both forms of the tile kernel
+    (paired rows on v_pk_* with the fract boundary test; one row at a time with the second pack) against the
+    oracle -- sizes around the strip width, the segment length and the tile."""
+    monkeypatch.setenv("FNX_FX_STREAM", "1" if form == "stream" else "0")
+    monkeypatch.setenv("FNX_FX_PAIRS", "0" if form == "tile_rows" else "1")
+    soft = _soft_image(orc, w, h, 3 * w + h)
+    hard = synth.large_photo(w, h, 5)
+    for img in (soft, hard):
+        assert np.array_equal(ctx.blur3x3(img), orc.blur3x3(img))
+        for s in (0.25, 0.5, 0.6180339887, 1.5):
+            assert np.array_equal(ctx.Sharpen(img, s), orc.sharpen(img, s)), ("sharpen", s)
+            assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), ("adaptive", s)
+
+
+@pytest.mark.parametrize("form", ["stream", "tile_pairs"])
+def test_fx_kernel_forms_4k_and_views(ctx, orc, monkeypatch, form):
+    """The same at 4K (many segments per strip) and on strided device views (the flat-copy pass runs behind either form)."""
+    import torch
+    monkeypatch.setenv("FNX_FX_STREAM", "1" if form == "stream" else "0")
+    img = _soft_image(orc, 3840, 2160, 11)
+    assert np.array_equal(ctx.AdaptiveSharpen(img, 0.5), orc.adaptive_sharpen(img, 0.5, procs=32))
+    assert np.array_equal(ctx.Sharpen(img, 0.5), orc.sharpen(img, 0.5, procs=32))
+    assert np.array_equal(ctx.blur3x3(img), orc.blur3x3(img))
+    big = torch.from_numpy(synth.large_photo(700, 300, 2)).cuda()
+    sub = big[10:250, 33:600]
+    want = sub.contiguous().cpu().numpy()
+    for got, ref in ((ctx.AdaptiveSharpen(sub, 0.5), orc.adaptive_sharpen), (ctx.Sharpen(sub, 0.5), orc.sharpen)):
+        ctx.sync()
+        g = got.cpu().numpy()
+        assert np.array_equal(g[1:-1, 1:-1], ref(want, 0.5)[1:-1, 1:-1])     # (the frame follows the flat-copy semantics: A19 tests)
+
+
 def test_sharpen_amounts_against_reference_order_kernel(ctx, orc, monkeypatch):
     """Kernel-level amounts outside what the reference ever passes (and an unaligned strided view): the marching
     kernels against the round-1 fp64 kernel, which follows the reference's operation order (FNX_FX_REF=1)."""
