@@ -1159,7 +1159,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         // rows (row halo (S + 7) / S <= 1.22)
         const int cols = march2 ? WM2_COLS : WM_COLS;
         ma.strips = (ww + cols - 1) / cols;
-        const long target = (march2 ? 8L : 16L) * ctx->num_cus;
+        static const long m2_per_cu = [] { const char *e = getenv("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 8L; }();   // experiments
+        const long target = (march2 ? m2_per_cu : 16L) * ctx->num_cus;
         long segs = target / (static_cast<long>(n) * ma.strips);
         const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
         if (segs > max_segs) segs = max_segs;
