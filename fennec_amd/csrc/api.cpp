@@ -848,8 +848,9 @@ int fnx_ssim_fast_prepare(fnx_ctx *ctx, int space, const uint8_t *a, int astride
 }
 
 // SSIMFast(prepared reference, device-resident candidate)
+// b_is_plane: b is already the candidate's pw x ph plane (launch_box_downsample_ycc made it from the JPEG planes)
 static int against_device(fnx_ctx *ctx, const fnx_prepared *ref, const uint8_t *b, int bstride, const double *window,
-                          double *out)
+                          double *out, bool b_is_plane = false)
 {
     const int w = ref->w, h = ref->h, pw = ref->pw, ph = ref->ph;
     void *dwin = nullptr;
@@ -858,7 +859,7 @@ static int against_device(fnx_ctx *ctx, const fnx_prepared *ref, const uint8_t *
     FNX_TRY(result_slot(ctx, 1, &dres));
     const uint8_t *cb = b;
     int cbs = bstride;
-    if (pw != w || ph != h) {
+    if (!b_is_plane && (pw != w || ph != h)) {
         void *t = nullptr;
         FNX_TRY(scratch(ctx, SLOT_TMP2, static_cast<size_t>(pw) * ph * 4 + 16, &t));
         FNX_TRY(launch_box_downsample(ctx, 1, b, nullptr, bstride, w, h, static_cast<uint8_t *>(t), pw * 4, 0, pw, ph));
@@ -965,6 +966,18 @@ int fnx_ssim_fast_against_ycbcr(fnx_ctx *ctx, const fnx_prepared *ref, int space
     const int w = ref->w, h = ref->h;
     FNX_REQUIRE(w > 0 && h > 0, "empty reference");
     void *t = nullptr;
+    if (space == FNX_DEVICE && cb && cr && (ref->pw != w || ref->ph != h)) {
+        // the candidate's plane straight from its planes: no NRGBA image (launch_box_downsample_ycc)
+        FNX_REQUIRE(y != nullptr && ystride >= w, "Y plane");
+        int cw = 0, ch = 0;
+        FNX_TRY(chroma_dims(ratio, w, h, &cw, &ch));
+        FNX_REQUIRE(cstride >= cw, "chroma stride");
+        bool fused = false;
+        FNX_TRY(scratch(ctx, SLOT_TMP2, static_cast<size_t>(ref->pw) * ref->ph * 4 + 16, &t));
+        FNX_TRY(launch_box_downsample_ycc(ctx, y, ystride, cb, cr, cstride, ratio, w, h, static_cast<uint8_t *>(t), ref->pw * 4, ref->pw,
+                                          ref->ph, &fused));
+        if (fused) return against_device(ctx, ref, static_cast<const uint8_t *>(t), ref->pw * 4, window, out, true);
+    }
     FNX_TRY(scratch(ctx, SLOT_IN_B, static_cast<size_t>(w) * h * 4 + 16, &t));
     FNX_TRY(ycbcr_stage_convert(ctx, space, y, ystride, cb, cr, cstride, ratio, w, h, static_cast<uint8_t *>(t), w * 4));
     return against_device(ctx, ref, static_cast<const uint8_t *>(t), w * 4, window, out);
@@ -1045,11 +1058,26 @@ static int jpeg_search_device(fnx_ctx *ctx, const DevImg &s, const JpegPlanes &o
     else if (target_ssim >= 0.97) lo = 50;
     else if (target_ssim >= 0.94) lo = 30;
     else if (target_ssim >= 0.90) lo = 15;
+    void *cand = nullptr;                                         // the candidate's SSIMFast plane
+    if (ds) FNX_TRY(scratch(ctx, SLOT_TMP2, static_cast<size_t>(ref.pw) * ref.ph * 4 + 16, &cand));
     while (lo <= hi) {
         const int mid = (lo + hi) / 2;
-        FNX_TRY(jpeg_decode_at(ctx, orig, w, h, mid, static_cast<uint8_t *>(dec), w * 4));
         double v = 0;
-        FNX_TRY(against_device(ctx, &ref, static_cast<const uint8_t *>(dec), w * 4, window, &v));
+        // the candidate: planes at quality `mid`; its <= 256 px plane straight from them where the image would only be
+        // written to be box-summed (r3), else toNRGBARef's image
+        JpegPlanes work;
+        FNX_TRY(jpeg_planes(ctx, SLOT_JPEG1, w, h, &work));
+        const uint8_t *in[3] = {orig.p[0], orig.p[1], orig.p[2]};
+        FNX_TRY(launch_jpeg_blocks(ctx, w, h, mid, in, work.p));
+        bool fused = false;
+        if (ds) FNX_TRY(launch_box_downsample_ycc(ctx, work.p[0], work.ys, work.p[1], work.p[2], work.cs, 2, w, h, static_cast<uint8_t *>(cand),
+                                                  ref.pw * 4, ref.pw, ref.ph, &fused));
+        if (fused) {
+            FNX_TRY(against_device(ctx, &ref, static_cast<const uint8_t *>(cand), ref.pw * 4, window, &v, true));
+        } else {
+            FNX_TRY(launch_ycbcr_to_nrgba(ctx, work.p[0], work.ys, work.p[1], work.p[2], work.cs, 2, w, h, static_cast<uint8_t *>(dec), w * 4));
+            FNX_TRY(against_device(ctx, &ref, static_cast<const uint8_t *>(dec), w * 4, window, &v));
+        }
         n++;
         if (v >= target_ssim) {
             best_q = mid; best_ssim = v; found = true;

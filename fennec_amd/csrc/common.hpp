@@ -328,6 +328,9 @@ int launch_sample_pixels(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, i
 int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, const uint8_t *palette, int n,
                          uint8_t *idx, int istride, uint8_t *quant, int qstride);
 // image.YCbCr / image.Gray planes -> NRGBA (convert.hip); device pointers; cb == cr == nullptr: Gray
+// boxDownsample(toNRGBARef(planes)) without the image (ssim.hip); *done = false: not its case, convert and downsample instead
+int launch_box_downsample_ycc(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr, int cstride,
+                              int ratio, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH, bool *done);
 int launch_ycbcr_to_nrgba(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr,
                           int cstride, int ratio, int w, int h, uint8_t *dst, int dstride);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,

@@ -16,12 +16,7 @@ struct YccArgs {
     int xshift, yshift;           // chroma sample of (x, y) = (x >> xshift, y >> yshift): image.YCbCr.COffset
 };
 
-// color.YCbCr.RGBA() channel, then convertToNRGBA's uint8(c >> 8): v >> 16 inside [0, 2^24), else 0 / 255
-__device__ __forceinline__ uint32_t ycc_u8(int v)
-{
-    return (static_cast<uint32_t>(v) & 0xff000000u) == 0 ? static_cast<uint32_t>(v) >> 16 : (v < 0 ? 0u : 255u);
-}
-
+// (the per-pixel arithmetic is devutil.hpp's ycc_nrgba_px)
 __global__ __launch_bounds__(256) void ycbcr_to_nrgba_kernel(YccArgs a)
 {
     const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
@@ -39,13 +34,7 @@ __global__ __launch_bounds__(256) void ycbcr_to_nrgba_kernel(YccArgs a)
         const size_t crow = static_cast<size_t>(y >> a.yshift) * a.cstride;
         for (int e = 0; e < cnt; e++) {
             const int x = x0 + e;
-            const int yy1 = static_cast<int>(yrow[x]) * 0x10101;
-            const int cb1 = static_cast<int>(a.cb[crow + (x >> a.xshift)]) - 128;
-            const int cr1 = static_cast<int>(a.cr[crow + (x >> a.xshift)]) - 128;
-            const uint32_t r = ycc_u8(yy1 + 91881 * cr1);
-            const uint32_t g = ycc_u8(yy1 - 22554 * cb1 - 46802 * cr1);
-            const uint32_t b = ycc_u8(yy1 + 116130 * cb1);
-            out[e] = r | (g << 8) | (b << 16) | 0xff000000u;
+            out[e] = ycc_nrgba_px(yrow[x], a.cb[crow + (x >> a.xshift)], a.cr[crow + (x >> a.xshift)]);
         }
     }
     uint8_t *dp = a.dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(x0);

@@ -68,6 +68,22 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
     return __builtin_amdgcn_cvt_pk_u8_f32(x, sel, old);
 }
 
+// color.YCbCr.RGBA() (Go image/color, the published integer form) then convertToNRGBA's uint8(c >> 8), convert.go:22-64:
+// one NRGBA pixel of a decoded JPEG sample (convert.hip's kernel and ssim.hip's box sums straight from the planes)
+__device__ __forceinline__ uint32_t ycc_u8(int v)
+{
+    return (static_cast<uint32_t>(v) & 0xff000000u) == 0 ? static_cast<uint32_t>(v) >> 16 : (v < 0 ? 0u : 255u);
+}
+__device__ __forceinline__ uint32_t ycc_nrgba_px(uint32_t yv, uint32_t cbv, uint32_t crv)
+{
+    const int yy1 = static_cast<int>(yv) * 0x10101;
+    const int cb1 = static_cast<int>(cbv) - 128, cr1 = static_cast<int>(crv) - 128;
+    const uint32_t r = ycc_u8(yy1 + 91881 * cr1);
+    const uint32_t g = ycc_u8(yy1 - 22554 * cb1 - 46802 * cr1);
+    const uint32_t b = ycc_u8(yy1 + 116130 * cb1);
+    return r | (g << 8) | (b << 16) | 0xff000000u;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ uint32_t ld_px(const uint8_t *row, int x)

@@ -185,6 +185,147 @@ __global__ __launch_bounds__(256) void box_tiled_kernel(BoxArgs a)
     box_tiled_body<VEC>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// ------------------------------------------------------------------------------------
+// boxDownsample of a decoded JPEG straight from its planes (r3): SSIMFast's <= 256 px plane of toNRGBARef's image
+// (convert.go:22-64, ssim.go:52-58) without the image.  The quality search (compress.go:45-74) compares EVERY candidate
+// that way -- ycbcr_to_nrgba_kernel wrote 33 MB per 4K candidate and box_tiled_kernel read them back for a 144 KB plane:
+// 54 us of the search step's ~130 -- while the planes are 12 MB at 4:2:0.  Same workgroup shape, box edges and sums as
+// box_tiled_body; a lane converts its 4-pixel chunk's samples in registers (devutil.hpp's ycc_nrgba_px: the kernel's own
+// arithmetic) and adds the packed fields.  XS = the chroma x shift (0, 1, 2).
+// ------------------------------------------------------------------------------------
+struct BoxYccArgs {
+    BoxArgs box;                    // geometry, destination (src fields unused)
+    const uint8_t *y, *cb, *cr;
+    int ystride, cstride, yshift;
+};
+
+template <int XS>
+__global__ __launch_bounds__(256) void box_tiled_ycc_kernel(BoxYccArgs ya)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
+    const BoxArgs &a = ya.box;
+    const int bx = blockIdx.x, dy = blockIdx.y;
+    const int dx_lo = bx * a.seg;
+    const int dx_hi = min(dx_lo + a.seg, a.dstW);
+    int sy0, sy1, sxa, sxb, t0, t1;
+    box_edge(dy, a.yRatio, a.srcH, sy0, sy1);
+    box_edge(dx_lo, a.xRatio, a.srcW, sxa, t1);
+    box_edge(dx_hi - 1, a.xRatio, a.srcW, t0, sxb);
+    const int c0 = sxa >> 2;
+    const int nchunk = ((sxb + 3) >> 2) - c0;
+    const int tid = threadIdx.x;
+    if (tid < nchunk) {
+        const int x = 4 * (c0 + tid);
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        const bool whole = x + 3 < a.srcW;
+        if (whole) {
+            // the chunk's Y bytes are one aligned word (the launcher checks), its chroma bytes one word / half word / byte
+            const uint8_t *yp = ya.y + x;
+            const uint8_t *cbp = ya.cb + (x >> XS), *crp = ya.cr + (x >> XS);
+            auto row = [&](int sy, uint32_t &yw, uint32_t &cbw, uint32_t &crw) {
+                yw = *(g_u32 *)(yp + static_cast<size_t>(sy) * ya.ystride);
+                const size_t co = static_cast<size_t>(sy >> ya.yshift) * ya.cstride;
+                if (XS == 0) {
+                    cbw = *(g_u32 *)(cbp + co);
+                    crw = *(g_u32 *)(crp + co);
+                } else if (XS == 1) {
+                    cbw = *(__attribute__((address_space(1))) const uint16_t *)(cbp + co);
+                    crw = *(__attribute__((address_space(1))) const uint16_t *)(crp + co);
+                } else {
+                    cbw = cbp[co];
+                    crw = crp[co];
+                }
+            };
+            auto add = [&](uint32_t yw, uint32_t cbw, uint32_t crw) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ce = XS == 0 ? e : (XS == 1 ? e >> 1 : 0);
+                    const uint32_t p = ycc_nrgba_px((yw >> (8 * e)) & 0xffu, (cbw >> (8 * ce)) & 0xffu, (crw >> (8 * ce)) & 0xffu);
+                    lo[e] += p & 0x00ff00ffu;
+                    hi[e] += __builtin_amdgcn_perm(0u, p, 0x0c030c01u);
+                }
+            };
+            int sy = sy0;
+            for (; sy + 4 <= sy1; sy += 4) {                      // four rows of loads in flight
+                uint32_t yw[4], cbw[4], crw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) row(sy + u, yw[u], cbw[u], crw[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) add(yw[u], cbw[u], crw[u]);
+            }
+            for (; sy < sy1; sy++) {
+                uint32_t yw, cbw, crw;
+                row(sy, yw, cbw, crw);
+                add(yw, cbw, crw);
+            }
+        } else {
+            // the one chunk that sticks out of the row: sample by sample, clamped (the surplus columns belong to no box)
+            for (int sy = sy0; sy < sy1; sy++) {
+                const size_t co = static_cast<size_t>(sy >> ya.yshift) * ya.cstride;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int xx = min(x + e, a.srcW - 1);
+                    const uint32_t p = ycc_nrgba_px(ya.y[static_cast<size_t>(sy) * ya.ystride + xx], ya.cb[co + (xx >> XS)], ya.cr[co + (xx >> XS)]);
+                    lo[e] += p & 0x00ff00ffu;
+                    hi[e] += (p >> 8) & 0x00ff00ffu;
+                }
+            }
+        }
+        uint4 *sp = reinterpret_cast<uint4 *>(s_col + tid * 8);
+        sp[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+        sp[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]);
+    }
+    __syncthreads();
+    const int dx = dx_lo + tid;
+    if (dx < dx_hi) {
+        int sx0, sx1;
+        box_edge(dx, a.xRatio, a.srcW, sx0, sx1);
+        uint32_t r = 0, g = 0, b = 0, al = 0;
+        for (int sx = sx0; sx < sx1; sx++) {
+            const uint2 c = *reinterpret_cast<const uint2 *>(s_col + (sx - 4 * c0) * 2);
+            r += c.x & 0xffffu; b += c.x >> 16;
+            g += c.y & 0xffffu; al += c.y >> 16;
+        }
+        const int count = (sy1 - sy0) * (sx1 - sx0);
+        *reinterpret_cast<uint32_t *>(a.dst + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) = box_finish(r, g, b, al, count);
+    }
+}
+
+// *done = false: not this kernel's case (grey, an upscale, huge boxes, unaligned planes) -- the caller converts and downsamples
+int launch_box_downsample_ycc(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr, int cstride,
+                              int ratio, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH, bool *done)
+{
+    *done = false;
+    static const bool off = [] { const char *e = getenv("FNX_BOX_YCC"); return e && e[0] == '0'; }();   // A/B and tests
+    if (off || !cb || !cr || ratio < 0 || ratio > 5 || srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_OK;
+    static const int xs[6] = {0, 1, 1, 0, 2, 2}, ys[6] = {0, 0, 1, 1, 0, 1};
+    BoxYccArgs ya{};
+    BoxArgs &a = ya.box;
+    a.dst = dst; a.srcW = srcW; a.srcH = srcH; a.dstride = dstride; a.dstW = dstW; a.dstH = dstH;
+    a.xRatio = static_cast<double>(srcW) / static_cast<double>(dstW);   // ssim.go:251-252
+    a.yRatio = static_cast<double>(srcH) / static_cast<double>(dstH);
+    const bool tiled = srcW >= dstW && srcH >= dstH && a.yRatio + 1.0 < BOX_MAXROWS &&
+                       a.xRatio + 1.0 < BOX_MAXROWS && a.xRatio * 2 + 8 < 4 * BOX_CHUNKS;
+    const int cal = 4 >> xs[ratio];                               // bytes of a chunk's chroma
+    const bool aligned = (reinterpret_cast<uintptr_t>(y) & 3u) == 0 && (ystride & 3) == 0 &&
+                         (reinterpret_cast<uintptr_t>(cb) % cal) == 0 && (reinterpret_cast<uintptr_t>(cr) % cal) == 0 && (cstride % cal) == 0;
+    if (!tiled || !aligned) return FNX_OK;
+    int seg = static_cast<int>((4 * BOX_CHUNKS - 8) / a.xRatio);
+    if (seg > 256) seg = 256;
+    if (seg < 1) seg = 1;
+    a.seg = seg;
+    ya.y = y; ya.cb = cb; ya.cr = cr; ya.ystride = ystride; ya.cstride = cstride; ya.yshift = ys[ratio];
+    const dim3 grid((dstW + seg - 1) / seg, dstH);
+    switch (xs[ratio]) {
+    case 0: hipLaunchKernelGGL(box_tiled_ycc_kernel<0>, grid, dim3(256), 0, ctx->stream, ya); break;
+    case 1: hipLaunchKernelGGL(box_tiled_ycc_kernel<1>, grid, dim3(256), 0, ctx->stream, ya); break;
+    default: hipLaunchKernelGGL(box_tiled_ycc_kernel<2>, grid, dim3(256), 0, ctx->stream, ya); break;
+    }
+    FNX_HIP(hipGetLastError());
+    *done = true;
+    return FNX_OK;
+}
+
 // several independent pair downsamples in one launch (MSSSIM: the <= 512 px planes of every level that needs
 // them): blockIdx.z = 2 * job + side, grid x / y = the largest job's
 constexpr int BOX_MAXJOBS = 4;

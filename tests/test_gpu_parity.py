@@ -1154,6 +1154,25 @@ def test_ssim_fast_against_ycbcr_4k(ctx, orc):
     prep.close()
 
 
+@pytest.mark.parametrize("ratio", [0, 1, 2, 3, 4, 5])
+def test_ssim_fast_against_ycbcr_device_planes(ctx, orc, ratio):
+    """Round 3: with the planes on the device the candidate's <= 256 px plane is summed straight from them
+    (box_tiled_ycc_kernel: no NRGBA image).  Bit-identical to convert-then-downsample -- sizes whose last chunk
+    sticks out of the row, every subsample ratio, unaligned plane views (which take the two-kernel path)."""
+    import torch
+    for (w, h) in [(1283, 719), (3840, 2160), (1030, 517), (600, 258)]:
+        y, cb, cr = synth.ycbcr_planes(w, h, ratio, 11 * ratio + w)
+        dec = orc.ycbcr_to_nrgba(y, cb, cr, ratio)
+        src = synth.large_photo(w, h, 3)
+        prep = ctx.ssim_fast_prepare(src)
+        want = prep.against(dec)
+        dy, dcb, dcr = (torch.from_numpy(p).cuda() for p in (y, cb, cr))
+        assert prep.against_ycbcr(dy, dcb, dcr, ratio) == want
+        assert prep.against_ycbcr(y, cb, cr, ratio) == want                      # host planes: staged, converted
+        assert abs(want - orc.ssim_fast(src, dec, procs=16)) <= SSIM_TOL
+        prep.close()
+
+
 def test_ctx_profile_hook(ctx):
     """fnx_ctx_profile / fnx_ctx_kernel_ms: the library's own HIP events around its dominant kernel."""
     import torch
