@@ -1035,8 +1035,16 @@ int fnx_jpeg_roundtrip(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
 }
 
 // compressJPEGOptimal's search (compress.go:24-74) on a device-resident source whose unquantised planes are `orig`
+// src_planes != nullptr (fnx_jpeg_recompress, r3): the source is a decoded JPEG still in its planes {Y, Cb, Cr, ystride, cstride,
+// ratio} and s.p may be null -- the reference plane comes straight from them (launch_box_downsample_ycc); *fell_back = true
+// says the planes' layout was not that kernel's case and nothing was done (the caller makes the image and calls again)
+struct SrcPlanes {
+    const uint8_t *y, *cb, *cr;
+    int ys, cs, ratio;
+};
 static int jpeg_search_device(fnx_ctx *ctx, const DevImg &s, const JpegPlanes &orig, int w, int h, double target_ssim,
-                              const double *window, int *quality, double *ssim, int *steps, bool *found_out)
+                              const double *window, int *quality, double *ssim, int *steps, bool *found_out,
+                              const SrcPlanes *src_planes = nullptr, bool *fell_back = nullptr)
 {
     // the source side of every SSIMFast of the search: prepared once (ssim.go:57 on the reference side)
     fnx_prepared ref;
@@ -1045,8 +1053,20 @@ static int jpeg_search_device(fnx_ctx *ctx, const DevImg &s, const JpegPlanes &o
     void *rp = nullptr;
     FNX_TRY(scratch(ctx, SLOT_JPEG3, static_cast<size_t>(ref.pw) * ref.ph * 4 + 16, &rp));
     ref.pix = static_cast<uint8_t *>(rp);
-    if (ds) FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, w, h, ref.pix, ref.pw * 4, 0, ref.pw, ref.ph));
-    else FNX_HIP(hipMemcpy2DAsync(ref.pix, size_t(w) * 4, s.p, s.stride, size_t(w) * 4, h, hipMemcpyDeviceToDevice, ctx->stream));
+    if (src_planes) {
+        bool done = false;
+        if (ds) FNX_TRY(launch_box_downsample_ycc(ctx, src_planes->y, src_planes->ys, src_planes->cb, src_planes->cr, src_planes->cs,
+                                                  src_planes->ratio, w, h, ref.pix, ref.pw * 4, ref.pw, ref.ph, &done));
+        *fell_back = !done;
+        if (!done) {
+            ref.pix = nullptr;
+            return FNX_OK;
+        }
+    } else if (ds) {
+        FNX_TRY(launch_box_downsample(ctx, 1, s.p, nullptr, s.stride, w, h, ref.pix, ref.pw * 4, 0, ref.pw, ref.ph));
+    } else {
+        FNX_HIP(hipMemcpy2DAsync(ref.pix, size_t(w) * 4, s.p, s.stride, size_t(w) * 4, h, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     void *dec = nullptr;
     FNX_TRY(scratch(ctx, SLOT_JPEG2, static_cast<size_t>(w) * h * 4 + 16, &dec));
     // compress.go:24-74
@@ -1237,18 +1257,6 @@ int fnx_jpeg_compress(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
 
 // ---- image.Decode of a baseline JPEG on the device (third slice: jpeg_dec.hip) ----------------
 // toNRGBARef(jpeg.Decode(data)) into SLOT_JPEG_DEC_IMG (tight rows); *f describes the file
-static int jpeg_decode_device(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t **img)
-{
-    uint8_t *pl[3];
-    int ys = 0, cs = 0;
-    FNX_TRY(jpeg_decode_planes(ctx, data, n, f, pl, &ys, &cs));
-    void *t = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_IMG, static_cast<size_t>(f->w) * f->h * 4 + 16, &t));
-    *img = static_cast<uint8_t *>(t);
-    const bool grey = f->ncomp == 1;         // image.Gray: convert.hip's cb == cr == NULL form
-    return launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f->ratio, f->w, f->h, *img, f->w * 4);
-}
-
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h)
 {
     FNX_REQUIRE(data != nullptr && w != nullptr && h != nullptr, "decode arguments");
@@ -1280,15 +1288,31 @@ int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double targ
     FNX_REQUIRE(data && window && nbytes && quality && ssim && w && h, "recompress arguments");
     *nbytes = 0;
     JpegFile f;
-    uint8_t *img = nullptr;
-    FNX_TRY(jpeg_decode_device(ctx, data, n, &f, &img));
+    uint8_t *pl[3];
+    int ys = 0, cs = 0;
+    FNX_TRY(jpeg_decode_planes(ctx, data, n, &f, pl, &ys, &cs));
     *w = f.w; *h = f.h;
-    DevImg s;
-    s.p = img; s.stride = f.w * 4;
     JpegPlanes orig;
     FNX_TRY(jpeg_planes(ctx, SLOT_JPEG0, f.w, f.h, &orig));
-    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, f.w, f.h, orig.p[0], orig.p[1], orig.p[2]));
     bool found = false;
+    DevImg s;
+    s.p = nullptr; s.stride = f.w * 4;
+    if (f.ncomp == 3) {
+        // r3: toNRGBARef's image of the decoded planes (33 MB at 4K) was written for two readers only -- the encoder's colour
+        // conversion and the reference plane's box sums; both take the planes themselves now (same per-pixel arithmetic)
+        const SrcPlanes sp{pl[0], pl[1], pl[2], ys, cs, f.ratio};
+        bool fell_back = false;
+        FNX_TRY(launch_jpeg_ycc_planes(ctx, pl[0], ys, pl[1], pl[2], cs, f.ratio, f.w, f.h, orig.p[0], orig.p[1], orig.p[2]));
+        FNX_TRY(jpeg_search_device(ctx, s, orig, f.w, f.h, target_ssim, window, quality, ssim, steps, &found, &sp, &fell_back));
+        if (!fell_back) return jpeg_file_from_planes(ctx, orig, f.w, f.h, *quality, out, cap, nbytes);
+    }
+    void *t = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_IMG, static_cast<size_t>(f.w) * f.h * 4 + 16, &t));
+    uint8_t *img = static_cast<uint8_t *>(t);
+    s.p = img;
+    const bool grey = f.ncomp == 1;
+    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, img, s.stride));
+    FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, f.w, f.h, orig.p[0], orig.p[1], orig.p[2]));
     FNX_TRY(jpeg_search_device(ctx, s, orig, f.w, f.h, target_ssim, window, quality, ssim, steps, &found));
     return jpeg_file_from_planes(ctx, orig, f.w, f.h, *quality, out, cap, nbytes);
 }

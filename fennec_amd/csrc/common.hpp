@@ -339,6 +339,8 @@ int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, i
 // conversion + chroma averaging, and fdct / quantise / dequantise / idct of every block at `quality` (in -> out)
 void jpeg_plane_dims(int w, int h, int *ys, int *yh, int *cs, int *ch);
 int launch_jpeg_ycc(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *yp, uint8_t *cbp, uint8_t *crp);
+int launch_jpeg_ycc_planes(fnx_ctx *ctx, const uint8_t *dy, int dys, const uint8_t *dcb, const uint8_t *dcr, int dcs, int ratio, int w, int h,
+                           uint8_t *yp, uint8_t *cbp, uint8_t *crp);
 void jpeg_header(int w, int h, int quality, std::vector<uint8_t> &out);
 int jpeg_entropy_code(fnx_ctx *ctx, int w, int h, int quality, const uint8_t *const planes[3], unsigned long long *totals);
 size_t jpeg_ecs_capacity(unsigned long long total_bits);

@@ -24,6 +24,11 @@ struct YccArgs {
     int sstride, w, h;
     uint8_t *yp, *cbp, *crp;     // Y: ys x 16 my; Cb, Cr: cs x 8 my
     int ys, cs, my;
+    // r3: the source as a DECODED JPEG's planes (dy != nullptr): a pixel is toNRGBARef's (devutil.hpp's ycc_nrgba_px of
+    // its samples), computed here instead of read from an image that fnx_jpeg_recompress would write only for this kernel
+    // and the reference plane's box sums
+    const uint8_t *dy, *dcb, *dcr;
+    int dys, dcs, dxs, dysh;
 };
 
 // color.RGBToYCbCr on a (possibly premultiplied) pixel: Y | Cb << 8 | Cr << 16
@@ -53,9 +58,20 @@ __global__ __launch_bounds__(256) void jpeg_ycc_kernel(YccArgs a)
     uint32_t ycc[2][4];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const uint8_t *row = a.src + static_cast<size_t>(min(py + j, a.h - 1)) * a.sstride;     // toYCbCr clamps to the last row / column
+        const int yy = min(py + j, a.h - 1);                                                     // toYCbCr clamps to the last row / column
+        if (a.dy) {
+            const uint8_t *yr = a.dy + static_cast<size_t>(yy) * a.dys;
+            const size_t co = static_cast<size_t>(yy >> a.dysh) * a.dcs;
 #pragma unroll
-        for (int i = 0; i < 4; i++) ycc[j][i] = rgb_to_ycc(ld_px(row, min(px + i, a.w - 1)));
+            for (int i = 0; i < 4; i++) {
+                const int xx = min(px + i, a.w - 1);
+                ycc[j][i] = rgb_to_ycc(ycc_nrgba_px(yr[xx], a.dcb[co + (xx >> a.dxs)], a.dcr[co + (xx >> a.dxs)]));
+            }
+        } else {
+            const uint8_t *row = a.src + static_cast<size_t>(yy) * a.sstride;
+#pragma unroll
+            for (int i = 0; i < 4; i++) ycc[j][i] = rgb_to_ycc(ld_px(row, min(px + i, a.w - 1)));
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; j++)
@@ -182,6 +198,21 @@ int launch_jpeg_ycc(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h,
     int yh, chh;
     jpeg_plane_dims(w, h, &a.ys, &yh, &a.cs, &chh);
     a.src = src; a.sstride = sstride; a.w = w; a.h = h; a.yp = yp; a.cbp = cbp; a.crp = crp; a.my = yh / 16;
+    hipLaunchKernelGGL(jpeg_ycc_kernel, dim3((a.ys / 4 + 63) / 64, (yh / 2 + 3) / 4), dim3(256), 0, ctx->stream, a);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// the same from a decoded JPEG's planes (ratio: image.YCbCrSubsampleRatio), the NRGBA image in between never written
+int launch_jpeg_ycc_planes(fnx_ctx *ctx, const uint8_t *dy, int dys, const uint8_t *dcb, const uint8_t *dcr, int dcs, int ratio, int w, int h,
+                           uint8_t *yp, uint8_t *cbp, uint8_t *crp)
+{
+    static const int xs[6] = {0, 1, 1, 0, 2, 2}, ysh[6] = {0, 0, 1, 1, 0, 1};
+    YccArgs a{};
+    int yh, chh;
+    jpeg_plane_dims(w, h, &a.ys, &yh, &a.cs, &chh);
+    a.w = w; a.h = h; a.yp = yp; a.cbp = cbp; a.crp = crp; a.my = yh / 16;
+    a.dy = dy; a.dcb = dcb; a.dcr = dcr; a.dys = dys; a.dcs = dcs; a.dxs = xs[ratio]; a.dysh = ysh[ratio];
     hipLaunchKernelGGL(jpeg_ycc_kernel, dim3((a.ys / 4 + 63) / 64, (yh / 2 + 3) / 4), dim3(256), 0, ctx->stream, a);
     FNX_HIP(hipGetLastError());
     return FNX_OK;

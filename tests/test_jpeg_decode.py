@@ -332,6 +332,14 @@ def test_gpu_recompress_is_decode_plus_compress(ctx):
         out2, q2, s2, steps2 = ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
         assert (q, steps) == (q2, steps2) and s == s2 and out == out2
         assert out[:2] == b"\xff\xd8" and out[-2:] == b"\xff\xd9"
+    # r3: the item never makes the decoded NRGBA image (the encoder's colour conversion and the reference plane read the
+    # decoded planes): every subsampling, odd sizes whose last chunk / MCU sticks out, grey (which still takes the image)
+    for (w, h) in [(1283, 719), (203, 117), (600, 258)]:
+        src = _photo(w, h, w + 1)
+        d422 = _pil(src, quality=91, subsampling=1)
+        for data in (d422, _as_440(d422), _pil(src, quality=91, subsampling=2), _pil(src, quality=91, subsampling=0), _pil_grey(src, quality=91)):
+            out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
+            assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94) and dims == (w, h)
 
 
 @pytest.mark.gpu
