@@ -493,6 +493,11 @@ struct WinSepArgs {
     // has to write them first
     int boxed, srcW, srcH;
     double xRatio, yRatio;
+    // out != nullptr (windowed_ssim_sep_kernel): the LAST workgroup of an image to finish takes the image's mean -- the sum
+    // ssim_finish_kernel would take, in the same order (the quality search's planes: a launch less per candidate)
+    double *out;
+    unsigned *done;          // [n], zero before and after the launch
+    double count;
 };
 
 // the box of at most MB x MB pixels behind plane pixel (x, y): every load is issued before the first is used (indices
@@ -663,10 +668,35 @@ __device__ __forceinline__ double ssim_sep_body(const WinSepArgs &a, const int t
     return t;                                            // the tile's sum (thread 0)
 }
 
+__device__ __forceinline__ double finish_sum_256(const double *p, int tiles, double *s_red);
+
 template <int TY, int NTHR>
 __global__ __launch_bounds__(NTHR) void windowed_ssim_sep_kernel(WinSepArgs a)
 {
-    ssim_sep_body<TY, NTHR>(a, blockIdx.x, blockIdx.y);
+    __shared__ double s_fin[4];
+    __shared__ int s_last;
+    const int z = blockIdx.y;
+    const double t = ssim_sep_body<TY, NTHR, false>(a, blockIdx.x, z);
+    double *pp = a.partial + static_cast<size_t>(z) * a.tiles + blockIdx.x;
+    if (!a.out) {
+        if (threadIdx.x == 0) *pp = t;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        // written through, then the image's counter (see march_finish)
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" ::"v"(pp), "v"(t) : "memory");
+        const unsigned prev = __hip_atomic_fetch_add(a.done + z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == static_cast<unsigned>(a.tiles) - 1u;
+    }
+    __syncthreads();
+    if (s_last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double sum = finish_sum_256(a.partial + static_cast<size_t>(z) * a.tiles, a.tiles, s_fin);
+        if (threadIdx.x == 0) {
+            a.out[z] = a.count > 0 ? sum / a.count : 1.0;
+            __hip_atomic_store(a.done + z, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // several single-pair window jobs of different sizes in one launch (MSSSIM's levels): blockIdx.y = job
@@ -1357,6 +1387,15 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
+        static const bool nofold = [] { const char *e = getenv("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
+        if (!big && !defer && !nofold && n <= 4096) {
+            unsigned *dn = nullptr;
+            FNX_TRY(ssim_done_counters(ctx, &dn));
+            sa.done = dn + (ctx->partial_slot >= 0 ? 4096 : 0);
+            sa.out = d_out;
+            sa.count = static_cast<double>(ww) * static_cast<double>(wh);
+            folded = true;
+        }
         if (big) hipLaunchKernelGGL(windowed_ssim_sep24_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         else hipLaunchKernelGGL((windowed_ssim_sep_kernel<WSS_TY, 256>), dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         FNX_HIP(hipGetLastError());

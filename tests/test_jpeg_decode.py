@@ -339,7 +339,8 @@ def test_gpu_recompress_is_decode_plus_compress(ctx):
         d422 = _pil(src, quality=91, subsampling=1)
         for data in (d422, _as_440(d422), _pil(src, quality=91, subsampling=2), _pil(src, quality=91, subsampling=0), _pil_grey(src, quality=91)):
             out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
-            assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94) and dims == (w, h)
+            dec = orc.jpeg_decode(data)                                  # (the relabelled 4:4:0 file is h x w)
+            assert (out, q, s, steps) == ctx.jpeg_compress(dec, 0.94) and dims == (dec.shape[1], dec.shape[0])
 
 
 @pytest.mark.gpu
