@@ -236,11 +236,25 @@ __global__ __launch_bounds__(256) void box_tiled_ycc_kernel(BoxYccArgs ya)
                     crw = crp[co];
                 }
             };
-            auto add = [&](uint32_t yw, uint32_t cbw, uint32_t crw) {
+            // a chroma sample's three terms of color.YCbCr.RGBA() serve every pixel it covers: the chunk's (4 >> XS) samples
+            // once per chroma ROW (two image rows at 4:2:0), then one multiply and three adds per pixel
+            constexpr int NC = 4 >> XS;
+            int tr[NC], tg[NC], tb[NC];
+            auto terms = [&](uint32_t cbw, uint32_t crw) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int cb1 = static_cast<int>((cbw >> (8 * c)) & 0xffu) - 128, cr1 = static_cast<int>((crw >> (8 * c)) & 0xffu) - 128;
+                    tr[c] = 91881 * cr1;
+                    tg[c] = -22554 * cb1 - 46802 * cr1;
+                    tb[c] = 116130 * cb1;
+                }
+            };
+            auto add = [&](uint32_t yw) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int ce = XS == 0 ? e : (XS == 1 ? e >> 1 : 0);
-                    const uint32_t p = ycc_nrgba_px((yw >> (8 * e)) & 0xffu, (cbw >> (8 * ce)) & 0xffu, (crw >> (8 * ce)) & 0xffu);
+                    const int c = e >> XS;
+                    const int yy1 = static_cast<int>((yw >> (8 * e)) & 0xffu) * 0x10101;
+                    const uint32_t p = ycc_u8(yy1 + tr[c]) | (ycc_u8(yy1 + tg[c]) << 8) | (ycc_u8(yy1 + tb[c]) << 16) | 0xff000000u;
                     lo[e] += p & 0x00ff00ffu;
                     hi[e] += __builtin_amdgcn_perm(0u, p, 0x0c030c01u);
                 }
@@ -256,7 +270,10 @@ __global__ __launch_bounds__(256) void box_tiled_ycc_kernel(BoxYccArgs ya)
                 for (int u = 0; u < 8; u++) row(min(sy + u, sy1 - 1), yw[u], cbw[u], crw[u]);
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    if (sy + u < sy1) add(yw[u], cbw[u], crw[u]);             // wave-uniform: a workgroup is one row of boxes
+                    if (sy + u < sy1) {                                       // wave-uniform: a workgroup is one row of boxes
+                        if (u == 0 || ((sy + u) >> ya.yshift) != ((sy + u - 1) >> ya.yshift)) terms(cbw[u], crw[u]);
+                        add(yw[u]);
+                    }
                 }
             }
         } else {
