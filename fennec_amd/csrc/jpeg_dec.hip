@@ -67,6 +67,9 @@ struct DecArgs {
     const uint32_t *rst;                             // byte offsets at which restart intervals 1, 2, ... start (ascending)
     int nrst;
     int ri_blocks;                                   // blocks per restart interval
+    // per boundary k: (the lane that stood on it) << 32 | the blocks that lane had counted before it -- written by the sync
+    // passes, read by the write pass (see jpeg_dwrite_kernel: block numbers are counted from the interval's start)
+    unsigned long long *rst_rec;
 };
 
 // Restart intervals (DRI): interval k starts on a byte boundary, in the state (block start, slot 0), with every DC
@@ -148,6 +151,7 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
             // (write pass: exactly the intervals before it must be complete -- a damaged interval that yields a block too
             // many or too few would shift every block behind it)
             if (WRITE && blk + cnt != static_cast<long long>(rk + 1) * a.ri_blocks) bad |= 16u;
+            if (!WRITE && blk >= 0) a.rst_rec[rk] = (static_cast<unsigned long long>(blk) << 32) | cnt;   // (sync passes: blk = the lane, or -1)
             z = 0; slot = 0;
             bnext = rst_rel(a, ++rk, wg_bit);
         }
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
             int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
             uint32_t bad = 0;
             my_cnt = 0;
-            dec_span<false, RST>(sh, a, rel, z, slot, end, my_cnt, 0, bad, wg_bit);
+            dec_span<false, RST>(sh, a, rel, z, slot, end, my_cnt, (FIX || t >= DEC_WARM) ? gs : -1ll, bad, wg_bit);
             my_out = dec_state(static_cast<unsigned long long>(wg_bit + rel), z, slot);
             sh.out[t] = my_out;
         }
@@ -338,7 +342,27 @@ __global__ __launch_bounds__(256) void jpeg_dwrite_kernel(DecArgs a)
     __syncthreads();
     if (gt >= a.nlanes) return;
     const unsigned long long st = a.s_in[gt];
-    const long long blk = static_cast<long long>(a.first_blk[gt]);
+    long long blk = static_cast<long long>(a.first_blk[gt]);
+    if (RST && a.nrst > 0) {
+        // Block numbers are counted from the restart interval's start, not from the file's: the sync passes go by position and
+        // cannot know when an interval's blocks are complete, so the <= 7 bits a DAMAGED interval leaves before its boundary
+        // can read as one more complete block there (DC category 0 + EOB is 4 bits) -- a block no decoder that counts MCUs
+        // ever sees, and one that would shift every block number behind it (the fuzzer's find, seed 77:
+        // tests/golden/damaged_interval_phantom_block.jpg).  With j the last boundary at or before this lane's start:
+        // blocks before it = (j + 1) ri_blocks by definition, blocks since = the prefix sums' difference.
+        const unsigned long long at = st & 0xffffffffffull;
+        int lo_k = 0, hi_k = a.nrst;                               // first boundary AFTER the start
+        while (lo_k < hi_k) {
+            const int mid = (lo_k + hi_k) >> 1;
+            if (8ull * a.rst[mid] <= at) lo_k = mid + 1; else hi_k = mid;
+        }
+        const int j = lo_k - 1;
+        if (j >= 0) {
+            const unsigned long long rec = a.rst_rec[j];
+            const long long before = static_cast<long long>(a.first_blk[rec >> 32]) + static_cast<long long>(rec & 0xffffffffull);
+            blk = static_cast<long long>(j + 1) * a.ri_blocks + (blk - before);
+        }
+    }
     if (blk >= a.nblk) return;                                     // padding behind the last block
     const unsigned long long wg_bit = static_cast<unsigned long long>(g) * 256u * DEC_SPAN;
     uint32_t rel = static_cast<uint32_t>((st & 0xffffffffffull) - wg_bit);
@@ -475,9 +499,10 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     const size_t b_ecs = al(nwords * 4 + 64), b_tab = al(sizeof(DecTables) + sizeof(DecSyncTables) + 4 * rst_max + 16), b_state = al(8 * lanes_pad), b_cnt = al(4 * lanes_pad),
                  b_first = al(8 * lanes_pad), b_tot = al(8 * (lanes_pad / SCAN_PER_WG_D + 2)), b_flag = al(4 * 64 + 16),
                  b_coef = al(sizeof(int16_t) * 64 * static_cast<size_t>(nblk)), b_dcb = al(4 * static_cast<size_t>(nblk)),
-                 b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2));
+                 b_dcs = al(8 * static_cast<size_t>(nblk)), b_tot2 = al(8 * (static_cast<size_t>(nblk) / SCAN_PER_WG_D + 2)),
+                 b_rec = al(8 * (rst.size() + 1));
     void *sc = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC, b_ecs + b_tab + 2 * b_state + b_cnt + b_first + b_tot + b_flag + b_coef + b_dcb + b_dcs + b_tot2, &sc));
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC, b_ecs + b_tab + 2 * b_state + b_cnt + b_first + b_tot + b_flag + b_coef + b_dcb + b_dcs + b_tot2 + b_rec, &sc));
     unsigned char *p = static_cast<unsigned char *>(sc);
     uint32_t *d_ecs = reinterpret_cast<uint32_t *>(p); p += b_ecs;
     DecTables *d_tab = reinterpret_cast<DecTables *>(p); p += b_tab;
@@ -490,7 +515,8 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     int16_t *d_coef = reinterpret_cast<int16_t *>(p); p += b_coef;
     uint32_t *d_dcb = reinterpret_cast<uint32_t *>(p); p += b_dcb;
     unsigned long long *d_dcs = reinterpret_cast<unsigned long long *>(p); p += b_dcs;
-    unsigned long long *d_tot2 = reinterpret_cast<unsigned long long *>(p);
+    unsigned long long *d_tot2 = reinterpret_cast<unsigned long long *>(p); p += b_tot2;
+    unsigned long long *d_rec = reinterpret_cast<unsigned long long *>(p);
     void *pl = nullptr;
     const size_t b_y = al(static_cast<size_t>(ys) * yh), b_c = al(static_cast<size_t>(cs) * chh);
     FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_PLANES, b_y + 2 * b_c, &pl));
@@ -554,7 +580,9 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
     a.dcpack = f->dcpack; a.acpack = f->acpack;
     a.rst = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(d_tab) + sizeof(DecTables) + sizeof(DecSyncTables)); a.nrst = static_cast<int>(rst.size());
     a.ri_blocks = f->ri * f->nslots;
+    a.rst_rec = d_rec;
     const bool has_rst = !rst.empty();
+    if (has_rst) FNX_HIP(hipMemsetAsync(d_rec, 0, 8 * rst.size(), ctx->stream));
     FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
     if (has_rst) hipLaunchKernelGGL((jpeg_dsync_kernel<false, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL((jpeg_dsync_kernel<false, false>), dim3(nwg), dim3(256), 0, ctx->stream, a);
