@@ -97,6 +97,11 @@ __device__ __constant__ uint8_t c_unzig[64] = {0,  1,  8,  16, 9,  2,  3,  10, 1
 struct DecShared {
     uint32_t seg[DEC_SEGW];
     unsigned long long out[256];
+    // the first sync kernel's later passes: the few lanes that decode again, packed into the workgroup's first wave
+    unsigned long long tin[64], rout[64];
+    uint32_t rcnt[64];
+    uint16_t todo[64];
+    uint32_t wcnt[4];
     union {
         DecTables tab;                               // write pass
         DecSyncTables stab;                          // sync passes
@@ -298,7 +303,49 @@ __global__ __launch_bounds__(256) void jpeg_dsync_kernel(DecArgs a)
     for (;;) {
         passes++;
         decodes += need ? 1u : 0u;
-        if (need) {
+        // After the first pass only a few lanes decode again -- one per chain of corrections, anywhere in the workgroup --
+        // and a wave with ONE such lane issues the whole span's instructions all the same: PMC counted 45 M VALU
+        // wave-instructions per 4K file against 13 M for one full decode (the write pass).  When at most 64 lanes need
+        // it, they hand their (span, start state) to the workgroup's first wave, which decodes them side by side; the
+        // other three waves wait at the barrier.  Same decodes, same order of passes: the fixed point is untouched.
+        bool packed = false;
+        int slot_c = 0;
+        if (!FIX && passes > 1) {
+            const unsigned long long bal = __ballot(need);
+            if ((t & 63) == 0) sh.wcnt[t >> 6] = static_cast<uint32_t>(__popcll(bal));
+            __syncthreads();
+            const uint32_t k0 = sh.wcnt[0], k1 = sh.wcnt[1], k2 = sh.wcnt[2], k3 = sh.wcnt[3];
+            const uint32_t total = k0 + k1 + k2 + k3;
+            packed = total <= 64u;                                  // workgroup-uniform
+            if (packed) {
+                const int wv = t >> 6;
+                const uint32_t base = (wv > 0 ? k0 : 0u) + (wv > 1 ? k1 : 0u) + (wv > 2 ? k2 : 0u);
+                slot_c = static_cast<int>(base) + __popcll(bal & ((1ull << (t & 63)) - 1ull));
+                if (need) {
+                    sh.todo[slot_c] = static_cast<uint16_t>(t);
+                    sh.tin[slot_c] = my_in;
+                }
+                __syncthreads();
+                if (t < static_cast<int>(total)) {
+                    const int src = sh.todo[t];
+                    const unsigned long long in = sh.tin[t];
+                    uint32_t rel = static_cast<uint32_t>(static_cast<long long>(in & 0xffffffffffull) - wg_bit);
+                    int z = static_cast<int>((in >> 40) & 0xffu), slot = static_cast<int>(in >> 48);
+                    uint32_t bad = 0, cnt = 0;
+                    dec_span<false, RST>(sh, a, rel, z, slot, static_cast<uint32_t>(src + 1) * DEC_SPAN, cnt,
+                                         src >= DEC_WARM ? span0 + src : -1ll, bad, wg_bit);
+                    sh.rout[t] = dec_state(static_cast<unsigned long long>(wg_bit + rel), z, slot);
+                    sh.rcnt[t] = cnt;
+                }
+                __syncthreads();
+                if (need) {
+                    my_out = sh.rout[slot_c];
+                    my_cnt = sh.rcnt[slot_c];
+                    sh.out[t] = my_out;
+                }
+            }
+        }
+        if (!packed && need) {
             uint32_t rel = static_cast<uint32_t>(static_cast<long long>(my_in & 0xffffffffffull) - wg_bit);
             int z = static_cast<int>((my_in >> 40) & 0xffu), slot = static_cast<int>(my_in >> 48);
             uint32_t bad = 0;
