@@ -72,7 +72,9 @@ __device__ __forceinline__ uint32_t pk8(float x, uint32_t sel, uint32_t old)
 // one NRGBA pixel of a decoded JPEG sample (convert.hip's kernel and ssim.hip's box sums straight from the planes)
 __device__ __forceinline__ uint32_t ycc_u8(int v)
 {
-    return (static_cast<uint32_t>(v) & 0xff000000u) == 0 ? static_cast<uint32_t>(v) >> 16 : (v < 0 ? 0u : 255u);
+    // v >> 16 inside [0, 2^24), else 0 / 255: one v_med3_i32 and a shift
+    const int c = v < 0 ? 0 : (v > 0xffffff ? 0xffffff : v);
+    return static_cast<uint32_t>(c) >> 16;
 }
 __device__ __forceinline__ uint32_t ycc_nrgba_px(uint32_t yv, uint32_t cbv, uint32_t crv)
 {

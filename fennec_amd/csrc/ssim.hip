@@ -254,9 +254,13 @@ __global__ __launch_bounds__(256) void box_tiled_ycc_kernel(BoxYccArgs ya)
                 for (int e = 0; e < 4; e++) {
                     const int c = e >> XS;
                     const int yy1 = static_cast<int>((yw >> (8 * e)) & 0xffu) * 0x10101;
-                    const uint32_t p = ycc_u8(yy1 + tr[c]) | (ycc_u8(yy1 + tg[c]) << 8) | (ycc_u8(yy1 + tb[c]) << 16) | 0xff000000u;
-                    lo[e] += p & 0x00ff00ffu;
-                    hi[e] += __builtin_amdgcn_perm(0u, p, 0x0c030c01u);
+                    // ycc_u8(v) == med3(v, 0, 2^24 - 1) >> 16 (v >> 16 inside [0, 2^24), else 0 / 255); the channels go
+                    // straight into the packed sums' fields (R | B << 16, G | A << 16 with A = 255)
+                    const uint32_t r = static_cast<uint32_t>(clampi(yy1 + tr[c], 0, 0xffffff)) >> 16;
+                    const uint32_t g = static_cast<uint32_t>(clampi(yy1 + tg[c], 0, 0xffffff)) >> 16;
+                    const uint32_t b = static_cast<uint32_t>(clampi(yy1 + tb[c], 0, 0xffffff)) & 0x00ff0000u;
+                    lo[e] += r | b;
+                    hi[e] += g + 0x00ff0000u;
                 }
             };
             // eight rows of loads in flight per trip (24 loads); a short last trip re-reads the box's last row and adds nothing
