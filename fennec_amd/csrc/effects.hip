@@ -13,10 +13,14 @@
 //    own error), and a sample whose two bytes differ -- a rounding boundary within G -- is recomputed in fp64,
 //    in the reference's operation order, from the staged tile.  Proven, not sampled; see fx_guard().
 //
-// Tile: 64 x 32 outputs per 256-lane workgroup; the 66 x 34 source tile is staged once as two words per pixel
-// with the channels spread into 16-bit fields (R | B << 16, G | A << 16) plus I; a lane then owns one column
-// and walks down 8 output rows: the horizontal [1 2 1] sums, the Sobel column differences and row sums are
-// computed once per tile row and shared by the three output rows they feed.
+// Two forms of the same arithmetic.  fx_stream_kernel (round 3, what every image takes): a WAVE marches down a strip of
+// 62 output columns with six rows of loads in flight, neighbours through a per-wave LDS row, the last three rows'
+// horizontal sums in a register ring -- no tile, no barrier in the loop (see its own header below).  fx_march_kernel
+// (round 2, kept for destinations past the 32-bit offsets and as the A/B): 64 x 24 outputs per 256-lane workgroup; the
+// 66 x 26 source tile is staged once as two words per pixel with the channels spread into 16-bit fields
+// (R | B << 16, G | A << 16) plus I; a lane then owns one column and walks down 6 output rows: the horizontal [1 2 1]
+// sums, the Sobel column differences and row sums are computed once per tile row and shared by the three output rows
+// they feed.
 //
 // fx_ref_kernel (the round-1 kernel: fp64, the reference's operation order) remains for amounts outside the
 // guard's bound and for Sharpen amounts with a near-tie product.
@@ -160,7 +164,7 @@ __device__ __forceinline__ float ubyte_f32(uint32_t w)
 __device__ __forceinline__ uint32_t ga_fields(uint32_t p) { return __builtin_amdgcn_perm(0u, p, 0x0c030c01u); }
 
 // AdaptiveSharpen is occupancy-bound (a workgroup is load tile -> barrier -> compute -> store, and what hides one
-// phase is other workgroups): 5 per CU -- <= 96 VGPRs, <= 32 KB of LDS each (16-bit table and fix-up list)
+// phase is other workgroups): 6 per CU -- <= 80 VGPRs, <= 26 KB of LDS each (16-bit table and fix-up list)
 template <int MODE>
 __global__ __launch_bounds__(256, MODE == FX_ADAPTIVE ? 6 : 1) void fx_march_kernel(FxArgs a)
 {
