@@ -167,7 +167,7 @@ constexpr int guard_fix_cap(bool score) { return score ? 512 : 2048; }   // SCOR
 template <int R, int NTH, int IH, bool SCORE, int RA = 1, int RB = 1, bool GUARD = false>
 // (guarded at R > 8: two waves per SIMD -- at four the compiler spilled 200-540 bytes per lane and sigma = 5 took 369 us
 // per 4K image; at 200+ registers it takes ~85)
-__global__ __launch_bounds__(NTH, (GUARD && R > 8) ? 2 : (GUARD && NTH == 128) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
+__global__ __launch_bounds__(NTH, (GUARD && R > 8) ? 2 : ((GUARD && (NTH == 128 || R >= 7)) || (!GUARD && R >= 15)) ? 3 : 4) void blur_direct_kernel(FusedArgs a)
 {
     constexpr int FIX_CAP = guard_fix_cap(SCORE);
     constexpr float GUARD_G = guard_g(R);
