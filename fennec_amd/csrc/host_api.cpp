@@ -404,6 +404,11 @@ int fennec_CompressFileJPEG(fnx_ctx *ctx, const uint8_t *data, size_t n, const f
     *nbytes = 0;
     int w = 0, h = 0;
     FNX_TRY(fnx_jpeg_decode(ctx, data, n, FNX_HOST, nullptr, 0, &w, &h));          // dimensions; refuses what the device decoder does not take
+    if (!(o->orient > 1 && o->orient <= 8) && o->max_w <= 0 && o->max_h <= 0 && !o->auto_format) {
+        // nothing between the decode and the search: the item body without the decoded image (fnx_jpeg_recompress, r3)
+        dims[0] = dims[2] = w; dims[1] = dims[3] = h;
+        return fnx_jpeg_recompress(ctx, data, n, o->target_ssim, ssim_window(), out, cap, nbytes, quality, ssim, steps, &w, &h);
+    }
     void *b0 = nullptr;
     FNX_TRY(scratch(ctx, SLOT_FILE0, static_cast<size_t>(w) * h * 4 + 16, &b0));
     FNX_TRY(fnx_jpeg_decode(ctx, data, n, FNX_DEVICE, static_cast<uint8_t *>(b0), w * 4, &w, &h));
