@@ -570,9 +570,11 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
 
     n_items = args.batch_items
     n_files = max(1, min(args.batch_files, n_items))
-    # 12 host threads per rank: 8 -> 12 -> 16 -> 24 threads measured 1 526 -> 1 944 -> 1 966 -> 1 548 images/s on one GPU (the
-    # GPU runs 2-4 files' kernels side by side; past that the threads only contend for the interpreter lock)
-    workers = args.workers or max(1, min(12, (os.cpu_count() or 8) // max(world, 1)))
+    # 16 host threads per rank.  Round 2's kernels: 8 -> 12 -> 16 -> 24 threads measured 1 526 -> 1 944 -> 1 966 -> 1 548 images/s on
+    # one GPU (the GPU runs 2-4 files' kernels side by side; past that the threads only contend for the interpreter lock); with
+    # round 3's shorter GPU side of an item (no decoded / candidate images, the packed sync passes) 12 -> 16 -> 20 threads measure
+    # 1 990-2 100 -> 2 410-2 440 -> 2 340 on one box
+    workers = args.workers or max(1, min(16, (os.cpu_count() or 8) // max(world, 1)))
     target = fbatch.TARGET_SSIM["Balanced"]
     # the same file list on every rank (any rank may take any item)
     files = []
