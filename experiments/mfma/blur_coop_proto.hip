@@ -1,0 +1,368 @@
+// Prototype (experiments only): GaussianBlur R <= 6 with both separable passes on the i8 matrix pipe.
+// Weights are 24-bit fixed point split into three signed base-256 digits; the integer sums are exact.
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include <type_traits>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// (hi * 256 + mid) * 256 + lo as two v_lshl_add_u32 (left alone the compiler builds two shifts and an add3)
+__device__ __forceinline__ int comb3(int hi, int mid, int lo)
+{
+    int t = hi * 256 + mid;
+    asm volatile("" : "+v"(t));
+    return t * 256 + lo;
+}
+
+struct MArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    size_t img_bytes;
+    int sstride, dstride, w, h, tiles_x, tiles;
+    int mode;
+    const uint32_t *tab;   // BH[3][64][4] | BV[3][64][2] | seedH | seedV
+};
+
+__device__ __forceinline__ int xcd_tile(int bid, int total)
+{
+    int per = (total + 7) >> 3;
+    int t = (bid & 7) * per + (bid >> 3);
+    return ((bid >> 3) < per && t < total) ? t : -1;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Workgroup = 64 px wide column strip marched down SEG rows, 16 rows per step.  Global loads and stores are workgroup-wide
+// (whole 304 / 256 byte row pieces per wave instruction) through LDS stages; each wave filters its own 16-px strip:
+// H set s (16 staged rows -> two-slot ring of the uint8 intermediate), then V set s-1 (16 output rows).
+struct RArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    size_t img_bytes;
+    int sstride, dstride, w, h, tiles_x, tiles, seg;   // seg: output rows per workgroup, multiple of 16
+    int mode;
+    const uint32_t *tab;   // BH[3][64][4] | BVeven[3][64][2] | BVodd[3][64][2] | seedH | seedV
+};
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void blur_march_kernel(RArgs a)
+{
+    constexpr int P = 48;                                 // pitch of a byte column of the ring: 32 rows + 16 (= 16 mod 32)
+    constexpr int WT = 64 * P + 256;
+    constexpr int SP = 336;                               // pitch of a staged source row: 19 chunks of 16 bytes (76 px) + pad
+    constexpr int OP = 272;                               // pitch of an output row in its stage
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[2 * 16 * SP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[2 * 16 * OP];
+
+    const int tile = xcd_tile(blockIdx.x, a.tiles);
+    if (tile < 0) return;
+    const int z = blockIdx.y;
+    const uint8_t *src = a.src + a.img_bytes * z;
+    uint8_t *dst = a.dst + a.img_bytes * z;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * 64, y0 = ty * a.seg;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int NJ = min(a.seg, ((a.h - y0 + 15) >> 4) << 4) >> 4;   // V sets of this segment
+    const int NI = NJ + 1;                                          // H sets
+
+    const v4i *tbh = reinterpret_cast<const v4i *>(a.tab);
+    const long *tbv = reinterpret_cast<const long *>(a.tab + 3 * 64 * 4);
+    const v4i bh2 = tbh[lane], bh1 = tbh[64 + lane], bh0 = tbh[128 + lane];
+    const long bve2 = tbv[lane], bve1 = tbv[64 + lane], bve0 = tbv[128 + lane];
+    const long bvo2 = tbv[192 + lane], bvo1 = tbv[256 + lane], bvo0 = tbv[320 + lane];
+    const int seedH = a.tab[3 * 64 * 4 + 6 * 64 * 2], seedV = a.tab[3 * 64 * 4 + 6 * 64 * 2 + 1];
+    const int seedHl = seedH + ((r & 3) == 3 ? 128 : 0);
+    const v4i sh = {seedHl, seedHl, seedHl, seedHl}, sv = {seedV, seedV, seedV, seedV};
+    const v4i zero = {0, 0, 0, 0};
+    const uint32_t sel01 = (r & 3) == 3 ? 0x0c0c0400u : 0x0c0c0703u, sel23 = (r & 3) == 3 ? 0x04000c0cu : 0x07030c0cu;
+
+    uint8_t *tw = s_t + wave * WT;
+    // stage: chunk ids 0..303 = 16 rows x 19 chunks; thread tid takes id tid and (tid < 48) id 256 + tid
+    const int id1 = 256 + tid;
+    const int srow0 = tid / 19, sch0 = tid - 19 * srow0, srow1 = id1 / 19, sch1 = id1 - 19 * srow1;
+    const bool two = tid < 48;
+    const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
+    const int st_r = r * SP + 64 * wave + 16 * g;
+    uint8_t *t_w = tw + r * P + 4 * g;
+    const int m4 = r >> 2, mi = r & 3;
+    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4 + 8 * g;
+    const uint8_t *t_ae = tw + (16 * g + 3) * P + 64 * g + r + 6;
+    const uint8_t *t_ao = tw + (16 * g + 3) * P + 64 * g + ((r + 22) & 31);
+    const int o_w = r * OP + 64 * wave + 16 * g;
+    const int orow = tid >> 4, och = tid & 15;
+    const int o_r = orow * OP + 16 * och;
+    const int xo = x0 + 4 * och;
+
+    const bool inner = x0 - 6 >= 0 && x0 + 70 <= a.w && y0 - 6 >= 0 && y0 - 6 + 16 * NI <= a.h;
+
+    auto march = [&](auto edge) {
+        constexpr bool EDGE = decltype(edge)::value;
+        const int loff0 = srow0 * a.sstride + 16 * sch0, loff1 = srow1 * a.sstride + 16 * sch1;
+        auto hload = [&](int i, u32x4 (&d)[2]) {
+            if constexpr (!EDGE) {
+                const uint8_t *sb = src + static_cast<ptrdiff_t>(y0 - 6 + 16 * i) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - 6);
+                d[0] = *reinterpret_cast<const u32x4 *>(sb + loff0);
+                if (two) d[1] = *reinterpret_cast<const u32x4 *>(sb + loff1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (k == 1 && !two) break;
+                    const int y = clampi(y0 - 6 + 16 * i + (k ? srow1 : srow0), 0, a.h - 1);
+                    const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        d[k][e] = *reinterpret_cast<const uint32_t *>(rowp + 4 * static_cast<size_t>(clampi(x0 - 6 + 4 * (k ? sch1 : sch0) + e, 0, a.w - 1)));
+                }
+            }
+        };
+        auto stage_write = [&](const u32x4 (&d)[2], int buf) {
+            uint8_t *sb = s_stage + buf * 16 * SP;
+            *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
+            if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
+        };
+        auto out_store = [&](int j, int buf) {          // V set j's 16 rows, from the out stage
+            const u32x4 o = *reinterpret_cast<const u32x4 *>(s_out + buf * 16 * OP + o_r);
+            const int y = y0 + 16 * j + orow;
+            if (y < a.h && (!(a.mode & 4) || o[0] == 0x12345678u)) {
+                uint8_t *dp = dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xo);
+                if (!EDGE || xo + 3 < a.w) *reinterpret_cast<u32x4 *>(dp) = o;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (xo + e < a.w) reinterpret_cast<uint32_t *>(dp)[e] = o[e];
+                }
+            }
+        };
+        auto hset = [&](int buf, int slot) {
+            const uint8_t *sb = s_stage + buf * 16 * SP + st_r;
+            v4i c2[4], c1[4], c0[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const v4i A = *reinterpret_cast<const v4i *>(sb + 16 * qq);
+                c2[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh2, zero, 0, 0, 0);
+                c1[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh1, zero, 0, 0, 0);
+                c0[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh0, sh, 0, 0, 0);
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                v4i u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) u[k] = comb3(c2[qq][k], c1[qq][k], c0[qq][k]);
+                const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], sel01);
+                const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[3], (uint32_t)u[2], sel23);
+                *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
+            }
+        };
+        auto vset = [&](int buf, auto oddt) {
+            constexpr bool ODD = decltype(oddt)::value;
+            long A[4];
+            uint32_t al[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const long *>(t_r + (4 * q) * P);
+#pragma unroll
+            for (int q = 0; q < 4; q++) al[q] = *((ODD ? t_ao : t_ae) + (4 * q) * P);
+            v4i c2[4], c1[4], c0[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo2 : bve2, zero, 0, 0, 0);
+                c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo1 : bve1, zero, 0, 0, 0);
+                c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo0 : bve0, sv, 0, 0, 0);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int u0 = comb3(c2[q][0], c1[q][0], c0[q][0]);
+                const int u1 = comb3(c2[q][1], c1[q][1], c0[q][1]);
+                const int u2 = comb3(c2[q][2], c1[q][2], c0[q][2]);
+                const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u1, (uint32_t)u0, 0x0c0c0703u);
+                const uint32_t t23 = __builtin_amdgcn_perm(al[q], (uint32_t)u2, 0x04030c0cu);
+                o[q] = t01 | t23;
+            }
+            *reinterpret_cast<u32x4 *>(s_out + buf * 16 * OP + o_w) = o;
+        };
+        // step s: [stage write of H set s | store of V set s-3] barrier [H set s -> ring slot s&1 | V set s-1 -> out stage s&1]
+        u32x4 ra[2], rb[2];
+        hload(0, ra);
+        if (1 < NI) hload(1, rb);
+        auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
+            constexpr int par = decltype(oddv)::value ? 0 : 1;       // s & 1 (V set s-1 is odd when s is even)
+            if (s < NI) stage_write(d, par);
+            if (s + 2 < NI) hload(s + 2, d);
+            if (s >= 3 && s - 3 < NJ) out_store(s - 3, par);         // written in step s-2 (same parity)
+            __syncthreads();
+            if (s < NI) hset(par, par);
+            if (s >= 1 && s - 1 < NJ) vset(par, oddv);
+        };
+#pragma unroll 1
+        for (int s = 0; s < NJ + 3; s += 2) {
+            step(s, ra, std::true_type{});      // s even: V set s-1 is odd
+            step(s + 1, rb, std::false_type{});
+        }
+    };
+    if (inner) march(std::false_type{}); else march(std::true_type{});
+}
+
+// ------------------------------- host -------------------------------
+static void digits(int64_t v, int d[3])
+{
+    for (int i = 0; i < 3; i++) {
+        int64_t lo = ((v % 256) + 256) % 256;
+        if (lo >= 128) lo -= 256;
+        d[i] = (int)lo;
+        v = (v - lo) / 256;
+    }
+    if (v != 0) { fprintf(stderr, "weight does not fit three signed digits\n"); exit(1); }
+}
+
+static std::vector<uint32_t> build_tab(const std::vector<double> &k, int R, std::vector<int64_t> &wq)
+{
+    const int NT = 2 * R + 1;
+    wq.assign(NT, 0);
+    int64_t sum = 0;
+    for (int i = 0; i < NT; i++) { wq[i] = (int64_t)llround(k[i] * 16777216.0); sum += wq[i]; }
+    wq[R] += 16777216 - sum;
+    std::vector<uint32_t> tab(3 * 64 * 4 + 6 * 64 * 2 + 2, 0);
+    int8_t *bh = reinterpret_cast<int8_t *>(tab.data());
+    int8_t *bv = reinterpret_cast<int8_t *>(tab.data() + 3 * 64 * 4);
+    const int off = 6 - R;
+    for (int lane = 0; lane < 64; lane++) {
+        const int n = lane & 15, kc = lane >> 4;
+        for (int b = 0; b < 16; b++) {   // H: K index 16 kc + b = byte of the 64-byte window
+            const int px = 4 * kc + b / 4, ch = b % 4, c = n % 4, pj = n / 4;
+            const int t = px - pj - off;
+            int d[3] = {0, 0, 0};
+            if (ch == c && c < 3 && t >= 0 && t < NT) digits(wq[t], d);
+            if (ch == c && c == 3 && px == pj + 6) d[0] = 1;   // alpha column: the centre pixel's alpha, as it is
+            for (int l = 0; l < 3; l++) bh[((2 - l) * 64 + lane) * 16 + b] = (int8_t)d[l];   // table order: hi, mid, lo
+        }
+        for (int b = 0; b < 8; b++) {    // V: K index 8 kc + b = staged row relative to the set's first
+            const int t = 8 * kc + b - n - off;
+            int d[3] = {0, 0, 0};
+            if (t >= 0 && t < NT) digits(wq[t], d);
+            for (int l = 0; l < 3; l++) bv[((2 - l) * 64 + lane) * 8 + b] = (int8_t)d[l];
+            {   // odd sets: ring row 8 kc + b holds staged row (8 kc + b + 16) % 32 of the set
+                const int to = ((8 * kc + b + 16) & 31) - n - off;
+                int e[3] = {0, 0, 0};
+                if (to >= 0 && to < NT) digits(wq[to], e);
+                for (int l = 0; l < 3; l++) bv[((3 + 2 - l) * 64 + lane) * 8 + b] = (int8_t)e[l];
+            }
+        }
+    }
+    tab[3 * 64 * 4 + 6 * 64 * 2] = 1u << 23;                    // H: staged bytes come out as (value ^ 0x80)
+    tab[3 * 64 * 4 + 6 * 64 * 2 + 1] = (1u << 23) + (1u << 31); // V: plain bytes
+    return tab;
+}
+
+static inline uint8_t clampF(double x)
+{
+    double t = std::trunc(x);
+    if (std::fabs(x - t) >= 0.5) t += std::copysign(1.0, x);
+    if (t < 0) t = 0;
+    if (t > 255) t = 255;
+    return (uint8_t)t;
+}
+
+static void ref_blur(const uint8_t *src, uint8_t *dst, int w, int h, const std::vector<double> &k, int R)
+{
+    std::vector<uint8_t> tmp((size_t)w * h * 4);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double acc[3] = {0, 0, 0};
+            for (int t = 0; t <= 2 * R; t++) {
+                int sx = std::min(std::max(x + t - R, 0), w - 1);
+                for (int c = 0; c < 3; c++) acc[c] = acc[c] + (double)src[((size_t)y * w + sx) * 4 + c] * k[t];
+            }
+            for (int c = 0; c < 3; c++) tmp[((size_t)y * w + x) * 4 + c] = clampF(acc[c]);
+            tmp[((size_t)y * w + x) * 4 + 3] = src[((size_t)y * w + x) * 4 + 3];
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double acc[3] = {0, 0, 0};
+            for (int t = 0; t <= 2 * R; t++) {
+                int sy = std::min(std::max(y + t - R, 0), h - 1);
+                for (int c = 0; c < 3; c++) acc[c] = acc[c] + (double)tmp[((size_t)sy * w + x) * 4 + c] * k[t];
+            }
+            for (int c = 0; c < 3; c++) dst[((size_t)y * w + x) * 4 + c] = clampF(acc[c]);
+            dst[((size_t)y * w + x) * 4 + 3] = src[((size_t)y * w + x) * 4 + 3];
+        }
+}
+
+static void run(int seg, int w, int h, double sigma, int nimg, int reps)
+{
+    const int R = (int)std::ceil(3 * sigma);
+    std::vector<double> k(2 * R + 1);
+    double s = 0;
+    for (int i = 0; i <= 2 * R; i++) { double x = i - R; k[i] = std::exp(-(x * x) / (2 * sigma * sigma)); s += k[i]; }
+    for (auto &v : k) v /= s;
+    std::vector<int64_t> wq;
+    std::vector<uint32_t> tab = build_tab(k, R, wq);
+    const size_t ib = (size_t)w * h * 4;
+    std::vector<uint8_t> img(ib * nimg);
+    uint32_t st = 12345;
+    for (size_t i = 0; i < img.size(); i++) { st = st * 1664525u + 1013904223u; img[i] = (uint8_t)(st >> 24); }
+    // smooth-ish content in image 0's left half so that rounding ties are not the only thing tested
+    for (int y = 0; y < h; y++) for (int x = 0; x < w / 2; x++) for (int c = 0; c < 4; c++)
+        img[((size_t)y * w + x) * 4 + c] = (uint8_t)((x * y + 3 * x + 7 * y * c + c * 31) % 256);
+    uint8_t *dsrc, *ddst; uint32_t *dtab;
+    hipMalloc(&dsrc, ib * nimg); hipMalloc(&ddst, ib * nimg); hipMalloc(&dtab, tab.size() * 4);
+    hipMemcpy(dsrc, img.data(), ib * nimg, hipMemcpyHostToDevice);
+    hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(ddst, 0xcd, ib * nimg);
+    RArgs a{};
+    a.src = dsrc; a.dst = ddst; a.img_bytes = ib; a.sstride = 4 * w; a.dstride = 4 * w; a.w = w; a.h = h;
+    a.seg = seg; a.tiles_x = (w + 63) / 64; a.tiles = a.tiles_x * ((h + seg - 1) / seg); a.tab = dtab;
+    dim3 grid(8 * ((a.tiles + 7) / 8), nimg);
+    blur_march_kernel<0><<<grid, 256>>>(a);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(e)); exit(1); }
+    std::vector<uint8_t> out(ib), ref(ib);
+    hipMemcpy(out.data(), ddst, ib, hipMemcpyDeviceToHost);
+    if (nimg == 1 || reps >= 20) ref_blur(img.data(), ref.data(), w, h, k, R); else ref = out;
+    size_t diff = 0, big = 0; int firstx = -1, firsty = -1;
+    for (size_t i = 0; i < ib; i++) if (out[i] != ref[i]) {
+        diff++;
+        if (std::abs((int)out[i] - (int)ref[i]) > 1) { big++; if (firstx < 0) { firstx = (int)((i / 4) % w); firsty = (int)((i / 4) / w); } }
+    }
+    printf("SEG=%d %dx%d sigma=%.2f R=%d: %zu of %zu samples differ (%.5f %%), %zu by more than 1", seg, w, h, sigma, R, diff, ib, 100.0 * diff / ib, big);
+    if (big) printf(" first at (%d,%d)", firstx, firsty);
+    printf("\n");
+    if (reps > 0) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 80; i++) blur_march_kernel<0><<<grid, 256>>>(a);
+        hipEventRecord(e0);
+        for (int i = 0; i < 5 * reps; i++) blur_march_kernel<0><<<grid, 256>>>(a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1000.0 / (5 * reps) / nimg;
+        printf("   %.2f us per image, %.0f MP/s, %.2f TB/s of 2S\n", us, (double)w * h / us, 2.0 * ib / us / 1e6);
+        for (int mode : {1, 2, 4, 5}) {
+            a.mode = mode;
+            for (int i = 0; i < 30; i++) blur_march_kernel<0><<<grid, 256>>>(a);
+            hipEventRecord(e0);
+            for (int i = 0; i < 5 * reps; i++) blur_march_kernel<0><<<grid, 256>>>(a);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("   mode %d (1: no H, 2: no V, 4: no store): %.2f us per image\n", mode, ms * 1000.0 / (5 * reps) / nimg);
+        }
+        a.mode = 0;
+    }
+    hipFree(dsrc); hipFree(ddst); hipFree(dtab);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) { run(atoi(argv[1]), 3840, 2160, 2.0, 32, 5); return 0; }
+    run(32, 640, 480, 2.0, 1, 0);
+    run(96, 640, 480, 2.0, 1, 0);
+    run(128, 641, 479, 1.5, 1, 0);
+    run(64, 100, 50, 2.0, 1, 0);
+    for (int seg : {96, 128, 192, 288, 544, 1088}) run(seg, 3840, 2160, 2.0, 32, 20);
+    return 0;
+}

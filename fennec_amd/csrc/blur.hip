@@ -842,7 +842,7 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
 // SCORE kernel is built for (the caller then runs the two ops separately).
 // Geometry of a one-pass launch: tile shape, box tables.  Cached on the ctx (batches repeat it).
 constexpr int NHEAD = 260 + 257 * 8;   // uint32 words at the head of the table blob: magic[c] (c <= 256, padded to 260), tiedown[8 c + w]
-static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH)
+static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH, int th_fixed = 0)
 {
     if (radius < 1 || radius > SCORE_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
         h >= (1 << 24))
@@ -896,8 +896,8 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
     // most boxes a tile touches, for the preferred tile shape and then the other one
     bool tall = g.tall_pref;
     int th = 0, nbx = 0, nby = 0;
-    for (int attempt = 0; attempt < 2; attempt++, tall = !tall) {
-        th = direct_tile_rows(radius, tall);
+    for (int attempt = 0; attempt < (th_fixed ? 1 : 2); attempt++, tall = !tall) {
+        th = th_fixed ? th_fixed : direct_tile_rows(radius, tall);
         nbx = nby = 1;
         auto span = [](const int32_t *m, int lo, int hi) {   // boxes touched by [lo, hi)
             int first = -1, last = -1;
@@ -912,6 +912,15 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
     }
     if (!th) return false;
     tall = th == direct_tile_rows(radius, true);
+    if (th_fixed) {
+        // blur_mfma_kernel's indicator matrix has five box columns per 16-px group of a tile
+        for (int x0 = 0; x0 < w; x0 += 16) {
+            int first = -1, last = -1;
+            for (int x = x0; x < std::min(w, x0 + 16); x++)
+                if (bx[x] >= 0) { if (first < 0) first = bx[x]; last = bx[x]; }
+            if (first >= 0 && last - first > 4) return false;
+        }
+    }
     // a tile whose first column / row is in no box must not hold boxed pixels (kernel uses bx[x0])
     for (int x0 = 0; x0 < w; x0 += 64)
         if (bx[x0] < 0) for (int x = x0; x < std::min(w, x0 + 64); x++) if (bx[x] >= 0) return false;
@@ -953,10 +962,13 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     const bool exact = flags & FNX_BLUR_EXACT;
     if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);
+    // the matrix-pipe kernel (blur_mfma.hip) where its table and its box geometry fit; its tile is 64 px x seg rows
+    const int seg = blur_mfma_covers(kernel, radius, w, h) ? blur_mfma_segment(ctx, n, w, h, 272) : 0;
     ScoreGeom &g = ctx->score_geom;
-    if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref)) {
-        g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref;
-        g.ok = build_score_geom(g, w, h, radius, dstW, dstH);
+    if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref && g.seg == seg)) {
+        g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref; g.seg = seg;
+        g.mfma = seg > 0 && build_score_geom(g, w, h, radius, dstW, dstH, seg);
+        g.ok = g.mfma || build_score_geom(g, w, h, radius, dstW, dstH);
     }
     if (!g.ok) return FNX_NOOP;
     const std::vector<int32_t> &map = g.map;
@@ -980,8 +992,14 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     void *slabs = nullptr;
     FNX_TRY(scratch(ctx, ctx->parity ? SLOT_SLABS1 : SLOT_SLABS, sizeof(unsigned long long) * 2 * slabn * static_cast<size_t>(tiles) * n, &slabs));
     fa.slabs = static_cast<unsigned long long *>(slabs);
-    const int st = exact ? launch_direct_radius<true, true>(ctx, radius, n, fa, tall)
-                         : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
+    int st;
+    if (g.mfma) {
+        st = launch_blur_mfma_scored(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride, fa.bx, fa.by, fa.slabs, nbx, nby, th);
+        if (st == FNX_NOOP) return FNX_NOOP;   // (blur_mfma_covers said yes: not reached) the caller runs the two ops back to back
+    } else {
+        st = exact ? launch_direct_radius<true, true>(ctx, radius, n, fa, tall)
+                   : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
+    }
     if (st < 0) return st;
     // the rest of the step runs on the ctx's second stream, behind this blur (api.cpp: one-pass enqueue)
     FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->blur_done, 0));   // bound to the blur dispatch: no packet on `stream`
@@ -1193,6 +1211,10 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
                 uint8_t *const *dsts, int dstride)
 {
     if (w <= 0 || h <= 0 || n <= 0) return FNX_OK;
+    {   // radius <= 6, non-negative weights summing to 1: both passes on the matrix pipe (blur_mfma.hip), fast or exact
+        const int st = launch_blur_mfma(ctx, n, src, srcs, sstride, w, h, kernel, radius, flags, dst, dsts, dstride);
+        if (st != FNX_NOOP) return st;
+    }
     if (flags & FNX_BLUR_EXACT) {
         if (radius < 1 || radius > FUSED_RMAX)
             return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);

@@ -1,0 +1,529 @@
+// GaussianBlur (effects.go:146-220), radius <= 6 (sigma <= 2), with both separable passes on the gfx950 i8 matrix pipe --
+// and, with SCORE, SSIMFast's boxDownsample sums (ssim.go:244-309) of the source and of the blurred image in the same pass.
+//
+// Why the matrix pipe for a stencil.  The direct form (blur.hip: blur_direct_kernel) spends 83 VALU instructions per pixel
+// -- 39 packed fp32 FMAs, 14 byte->float converts, 6 packs, 11 for the box sums -- and is VALU-issue bound at 0.36 of the
+// HBM peak (profiles/r03_onepass_sq_counters.txt).  Here the 13-tap sums are INTEGER dot products on
+// v_mfma_i32_16x16x64_i8 / 16x16x32_i8: the bytes go in as they lie in memory (no converts), the weights are 24-bit fixed
+// point split into three signed base-256 digits (three matrix instructions, two v_lshl_add_u32 per sample to add the
+// digits' sums), and the rounding is "+2^23, take the top byte".  The integer sum S = sum wq[k] p[k] is EXACT; with
+// sum wq = 2^24 it never leaves [0, 255 * 2^24], so there is no clamp and no overflow.
+//
+//  * H pass, one set = 16 rows x 4 output px: A = source bytes (M = row, K = the 64 bytes of the 16-px window), B = the
+//    weights as a Toeplitz matrix over the RGBA-interleaved bytes (K x N = 16 output bytes: 4 px x RGBA; 13 of 64 K
+//    entries are non-zero per column).  C comes out with 4 CONSECUTIVE ROWS of one byte column per lane: packed, that is
+//    one dword of the TRANSPOSED uint8 intermediate (effects.go:186-188) T[byte column][row].
+//  * V pass, one set = 16 output rows x 16 byte columns: A = T (M = byte column, K = 32 staged rows, 8 contiguous bytes per
+//    lane), B = the weights (K x N = 16 output rows).  C is row-major again: lane (row, chunk) ends up with 4 px = 16 bytes.
+//  * alpha: the H sets' alpha columns carry the centre pixel's alpha through (weight digit 1, byte 0 of the sum), the V
+//    sets fetch it from the intermediate's alpha columns (effects.go:215: alpha comes from the ORIGINAL).
+//  * SCORE: lane (row, chunk) layouts ARE matrix A operands, so the box sums are two more matrix instructions per 16 x 16
+//    px block (B = 0/1 indicator of up to 5 box columns x RGB over the 64 bytes) and 4 + 4 LDS atomics on what is left.
+//  * GUARD (FNX_BLUR_EXACT): |S / 2^24 - exact sum| <= E = 255 * sum |wq[k] / 2^24 - w[k]| (computed per call).  A sample
+//    whose fraction lies within G >= E of the rounding boundary is recomputed in fp64 in the reference's tap order
+//    (effects.go:169-217), in place: with G ~ 1e-4 one 256-sample set in twenty takes that branch.  Everything else is
+//    proven equal to the reference's clampF, not sampled.
+//
+// Memory shape.  A workgroup (4 waves) owns a 64-px column strip of SEG rows and marches down it 16 rows per step.
+// Loads and stores are workgroup-wide through LDS stages -- 304 / 256 contiguous bytes per row and wave instruction: with
+// each wave fetching its own 16-px strip (64 bytes per row) the same kernel ran at 3 TB/s, the tiled-copy floor of that
+// shape.  Each wave filters its own 16 px: H set s (16 staged rows) into a two-slot ring of T (32 rows, 3.3 KB per wave),
+// then V set s-1; one barrier per step; stores trail by two more steps.  The H halo is 22 rows per SEG, not 12 per 104.
+#include <hip/hip_ext.h>
+
+#include "common.hpp"
+#include "devutil.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+namespace fnx {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int MF_RMAX = 6;           // 4 output px + 2 R <= 16 px = the 64-byte K of one H instruction
+constexpr int MF_P = 48;             // bytes per byte column of the ring: 32 rows + 16 (= 16 mod 32: conflict-free 4-row dword writes)
+constexpr int MF_WT = 64 * MF_P + 256;   // ring bytes per wave: 64 byte columns + the 64-byte skew of each 16-column group
+constexpr int MF_SP = 352;           // pitch of a staged source row (19 chunks of 16 bytes): conflict-free as the A operand (tools/lds_conflicts.py)
+constexpr int MF_OP = 272;           // pitch of an output row in its stage
+constexpr int MF_SEG_SCORE = 272;    // most rows per workgroup with SCORE (row tables and box tables in LDS)
+
+struct MfmaArgs {
+    const uint8_t *src;
+    const uint8_t *const *srcs;
+    uint8_t *dst;
+    uint8_t *const *dsts;
+    int sstride, dstride, w, h;
+    int tiles_x, tiles, seg;          // per image; seg = output rows per workgroup (multiple of 16)
+    int radius;
+    const uint32_t *tab;              // BH[3][64] x 16 B | BV even[3][64] x 8 B | BV odd[3][64] x 8 B | the caller's 13 fp64 weights (GUARD)
+    int seed_h, seed_v, thr;          // rounding seeds (+ G in units of 2^-24 with GUARD), 2 G
+    // SCORE
+    const int32_t *bx, *by;           // box column / row of each source column / row (-1: none)
+    unsigned long long *slabs;        // [image][tile][2][slabn] packed 4 x u16 channel sums (blur.hip: box_from_slabs_kernel)
+    int nbx, nby;
+};
+
+// (hi * 256 + mid) * 256 + lo as two v_lshl_add_u32 (left alone the compiler builds two shifts and a v_add3)
+__device__ __forceinline__ int mf_comb3(int hi, int mid, int lo)
+{
+    int t = hi * 256 + mid;
+    asm volatile("" : "+v"(t));
+    return t * 256 + lo;
+}
+
+template <bool SCORE, bool GUARD>
+__global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
+{
+    constexpr int P = MF_P, WT = MF_WT, SP = MF_SP, OP = MF_OP;
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[2 * 16 * SP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[2 * 16 * OP];
+    // SCORE: byte offset of a staged row's / an output row's box row in the tables (spare row: outside the segment or the image)
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowh[SCORE ? MF_SEG_SCORE + 32 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowv[SCORE ? MF_SEG_SCORE + 16 : 4];
+    __shared__ uint32_t s_colbox[SCORE ? 64 : 1];         // box column (relative to the tile's first) of each tile column, 255: none
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_box[];   // SCORE: [source | blurred][(nby+1)(nbx+1)][R, G, B, -]
+
+    const int tile = xcd_tile(blockIdx.x, a.tiles);
+    if (tile < 0) return;
+    const int z = blockIdx.y;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    uint8_t *dst = a.dsts ? a.dsts[z] : a.dst;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * 64, y0 = ty * a.seg;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int NJ = min(a.seg, ((a.h - y0 + 15) >> 4) << 4) >> 4;   // V sets of this segment (the image's last one may be short)
+    const int NI = NJ + 1;                                          // H sets: staged rows y0 - 6 .. y0 + 16 NJ + 9
+    const int off = MF_RMAX - a.radius;                             // taps sit centred in the radius-6 frame
+    const bool xedge = x0 - 6 < 0 || x0 + 70 > a.w;                 // the strip's source window leaves the image: clamped px loads, masked stores
+
+    const v4i *tbh = reinterpret_cast<const v4i *>(a.tab);
+    const long *tbv = reinterpret_cast<const long *>(a.tab + 3 * 64 * 4);
+    const v4i bh2 = tbh[lane], bh1 = tbh[64 + lane], bh0 = tbh[128 + lane];
+    const long bve2 = tbv[lane], bve1 = tbv[64 + lane], bve0 = tbv[128 + lane];
+    const long bvo2 = tbv[192 + lane], bvo1 = tbv[256 + lane], bvo0 = tbv[320 + lane];
+    const bool alane = (r & 3) == 3;                                // H sets: this lane's output byte column is an alpha column
+    const int seed_hl = alane ? (1 << 23) + 128 : a.seed_h;         // alpha lanes: (a - 128) + 128 in byte 0, no guard offset
+    const v4i sh = {seed_hl, seed_hl, seed_hl, seed_hl}, sv = {a.seed_v, a.seed_v, a.seed_v, a.seed_v};
+    const v4i zero = {0, 0, 0, 0};
+    const uint32_t sel01 = alane ? 0x0c0c0400u : 0x0c0c0703u, sel23 = alane ? 0x04000c0cu : 0x07030c0cu;
+    const uint32_t amask = alane ? 0x00ffffffu : 0u;                // GUARD: alpha lanes never flag
+
+    uint8_t *tw = s_t + wave * WT;
+    // stage: chunk ids 0..303 = 16 rows x 19 chunks of 16 bytes (px x0 - 6 .. x0 + 69); thread tid takes id tid and, tid < 48, id 256 + tid
+    const int id1 = 256 + tid;
+    const int srow0 = tid / 19, sch0 = tid - 19 * srow0, srow1 = id1 / 19, sch1 = id1 - 19 * srow1;
+    const bool two = tid < 48;
+    const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
+    const int st_r = r * SP + 64 * wave + 16 * g;                   // A operand of H set qq: + 16 qq
+    uint8_t *t_w = tw + r * P + 4 * g;                              // + (16 qq) P + 64 qq + 16 slot
+    const int m4 = r >> 2, mi = r & 3;
+    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4 + 8 * g; // A operand of V column set q: + 4 q P
+    const uint8_t *t_ae = tw + (16 * g + 3) * P + 64 * g + r + 6;   // centre row's alpha, even / odd V sets: + 4 q P
+    const uint8_t *t_ao = tw + (16 * g + 3) * P + 64 * g + ((r + 22) & 31);
+    const int o_w = r * OP + 64 * wave + 16 * g;
+    const int orow = tid >> 4, och = tid & 15;
+    const int o_r = orow * OP + 16 * och;
+    const int xo = x0 + 4 * och;
+
+    // ---- SCORE set-up: row / column -> table offsets, this wave's indicator matrix ----
+    v4i bbox = {0, 0, 0, 0}, sbox = {0, 0, 0, 0};
+    uint32_t coln = 0;                                              // byte offset of this lane's (box column, channel) in a table row
+    const int slabn = SCORE ? (a.nbx + 1) * (a.nby + 1) : 0;
+    uint32_t *tbl_s = s_box, *tbl_b = s_box + 4 * slabn;
+    if constexpr (SCORE) {
+        for (int e = tid; e < 8 * slabn; e += 256) s_box[e] = 0;
+        const int rowbytes = 16 * (a.nbx + 1);
+        const int b0y = a.by[y0];
+        for (int u = tid; u < 16 * NI; u += 256) {                  // staged row u = tile row u - 6
+            const int t = u - 6;
+            const int v = (t >= 0 && t < a.seg && y0 + t < a.h) ? a.by[y0 + t] : -1;
+            s_rowh[u] = rowbytes * ((v >= 0 && b0y >= 0) ? v - b0y : a.nby);
+        }
+        for (int t = tid; t < 16 * NJ; t += 256) {
+            const int v = (t < a.seg && y0 + t < a.h) ? a.by[y0 + t] : -1;
+            s_rowv[t] = rowbytes * ((v >= 0 && b0y >= 0) ? v - b0y : a.nby);
+        }
+        if (tid < 64) {
+            const int b0x = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
+            s_colbox[tid] = (v >= 0 && b0x >= 0) ? v - b0x : 255u;
+        }
+        __syncthreads();
+        // the wave's 16 px: first box column present -> slot 0; lane n = 3 slot + channel (n = 15: nothing)
+        uint32_t first = 255u;
+        for (int i = 0; i < 16; i++) first = min(first, s_colbox[16 * wave + i]);
+        const int slot = r / 3, ch = r - 3 * slot;
+        int cnt = 0;
+        for (int i = 0; i < 16; i++) cnt += (r < 15 && s_colbox[16 * wave + i] == first + slot) ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {                               // K = byte 16 g + 4 e + ch' of the row's 64 bytes
+            const bool in = r < 15 && first != 255u && s_colbox[16 * wave + 4 * g + e] == first + slot;
+            bbox[e] = in ? (1 << (8 * ch)) : 0;
+        }
+        const int seed = 128 * cnt;                                 // the A operands are (p - 128): the sums come out as sums of p
+        sbox = (v4i){seed, seed, seed, seed};
+        const uint32_t bc = (r < 15 && first != 255u && cnt > 0) ? first + slot : static_cast<uint32_t>(a.nbx);
+        coln = 16u * bc + 4u * (r < 15 ? ch : 3);
+    }
+
+    // ---- exact recomputation of flagged samples (GUARD), the reference's own arithmetic (effects.go:169-217) ----
+    const int nt = 2 * a.radius + 1;
+    const double *wd = reinterpret_cast<const double *>(a.tab + 3 * 64 * 4 + 6 * 64 * 2);
+    auto exact_h = [&](const uint8_t *sb, int row, int px, int c) -> uint32_t {     // staged bytes are (p ^ 0x80)
+        double acc = 0;
+        const uint8_t *p = sb + row * SP + 4 * (px + off) + c;
+        for (int t = 0; t < nt; t++) acc = acc + u8_to_f64(p[4 * t] ^ 0x80u) * wd[t];
+        return clampF_dev(acc);
+    };
+    auto exact_v = [&](int cl, int grp, int ring0) -> uint32_t {                     // ring bytes are (t ^ 0x80)
+        double acc = 0;
+        const uint8_t *p = tw + cl * P + 64 * grp;
+        for (int t = 0; t < nt; t++) acc = acc + u8_to_f64(p[(ring0 + t) & 31] ^ 0x80u) * wd[t];
+        return clampF_dev(acc);
+    };
+
+    auto hload = [&](int i, u32x4 (&d)[2]) {
+        const int ys = y0 - 6 + 16 * i;
+        if (!xedge && ys >= 0 && ys + 16 <= a.h) {                  // uniform: no clamp in this set
+            const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - 6);
+            d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
+            if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (k == 1 && !two) break;
+                const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);   // clamp-to-edge (effects.go:174-178, 200-204)
+                const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
+                const int xc = x0 - 6 + 4 * (k ? sch1 : sch0);
+                if (!xedge) {
+                    d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
+                }
+            }
+        }
+    };
+    auto stage_write = [&](const u32x4 (&d)[2], int buf) {
+        uint8_t *sb = s_stage + buf * 16 * SP;
+        *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
+        if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
+    };
+    auto out_store = [&](int j, int buf) {                          // V set j's 16 rows, from the out stage
+        const u32x4 o = *reinterpret_cast<const u32x4 *>(s_out + buf * 16 * OP + o_r);
+        const int y = y0 + 16 * j + orow;
+        if (y < a.h) {
+            uint8_t *dp = dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xo);
+            if (!xedge || xo + 3 < a.w) *(g_u32x4w *)(dp) = o;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) if (xo + e < a.w) *(g_u32w *)(dp + 4 * e) = o[e];
+            }
+        }
+    };
+    // H set s: 16 staged rows from stage `buf` into ring slot `slot`
+    auto hset = [&](int s, int buf, int slot) {
+        const uint8_t *sbuf = s_stage + buf * 16 * SP;
+        const uint8_t *sb = sbuf + st_r;
+        v4i c2[4], c1[4], c0[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const v4i A = *reinterpret_cast<const v4i *>(sb + 16 * qq);
+            c2[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh2, zero, 0, 0, 0);
+            c1[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh1, zero, 0, 0, 0);
+            c0[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh0, sh, 0, 0, 0);
+        }
+        if constexpr (SCORE) {   // source side of the box sums: the strip's own 16 px of these 16 rows (24 bytes into the window)
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(sb + 24), hi = *reinterpret_cast<const u32x2 *>(sb + 32);
+            const v4i A = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+            const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
+            const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowh + 16 * s + 4 * g);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_s) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            v4i u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) u[k] = mf_comb3(c2[qq][k], c1[qq][k], c0[qq][k]);
+            if constexpr (GUARD) {
+                uint32_t f[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) f[k] = (static_cast<uint32_t>(u[k]) & 0x00ffffffu) | amask;
+                const uint32_t m = min(min(f[0], f[1]), min(f[2], f[3]));
+                if (__builtin_amdgcn_ballot_w64(m < static_cast<uint32_t>(a.thr))) {   // ~1 set in 20: a lane walks its flagged samples
+                    uint32_t fl = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) fl |= (f[k] < static_cast<uint32_t>(a.thr) ? 1u : 0u) << k;
+                    while (fl) {
+                        const int k = __builtin_ctz(fl);
+                        fl &= fl - 1;
+                        const int e = static_cast<int>((exact_h(sbuf, 4 * g + k, 16 * wave + 4 * qq + (r >> 2), r & 3) ^ 0x80u) << 24);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) u[i] = k == i ? e : u[i];
+                    }
+                }
+            }
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], sel01);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[3], (uint32_t)u[2], sel23);
+            *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
+        }
+    };
+    // V set j: 16 output rows into out stage `buf`; odd sets find their first 16 staged rows in ring rows 16..31
+    auto vset = [&](int j, int buf, auto oddt) {
+        constexpr bool ODD = decltype(oddt)::value;
+        long A[4];
+        uint32_t al[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const long *>(t_r + (4 * q) * P);
+#pragma unroll
+        for (int q = 0; q < 4; q++) al[q] = *((ODD ? t_ao : t_ae) + (4 * q) * P);
+        v4i c2[4], c1[4], c0[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo2 : bve2, zero, 0, 0, 0);
+            c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo1 : bve1, zero, 0, 0, 0);
+            c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo0 : bve0, sv, 0, 0, 0);
+        }
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int u[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
+            if constexpr (GUARD) {
+                uint32_t f[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) f[i] = static_cast<uint32_t>(u[i]) & 0x00ffffffu;
+                const uint32_t m = min(min(f[0], f[1]), f[2]);
+                if (__builtin_amdgcn_ballot_w64(m < static_cast<uint32_t>(a.thr))) {
+                    uint32_t fl = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) fl |= (f[i] < static_cast<uint32_t>(a.thr) ? 1u : 0u) << i;
+                    while (fl) {
+                        const int i = __builtin_ctz(fl);
+                        fl &= fl - 1;
+                        const int e = static_cast<int>(exact_v(16 * g + 4 * q + i, g, (ODD ? 16 : 0) + r + off) << 24);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) u[c] = i == c ? e : u[c];
+                    }
+                }
+            }
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], 0x0c0c0703u);
+            const uint32_t t23 = __builtin_amdgcn_perm(al[q], (uint32_t)u[2], 0x04030c0cu);
+            o[q] = t01 | t23;
+        }
+        if constexpr (SCORE) {   // blurred side: lane (row r, chunk g) holds 4 px of row r -- an A operand as it is
+            const u32x4 os = o ^ 0x80808080u;
+            const v4i A = {(int)os[0], (int)os[1], (int)os[2], (int)os[3]};
+            const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
+            const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowv + 16 * j + 4 * g);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_b) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        *reinterpret_cast<u32x4 *>(s_out + buf * 16 * OP + o_w) = o;
+    };
+
+    // step s: [stage write of H set s | store of V set s-3]  barrier  [H set s -> ring slot s&1 | V set s-1 -> out stage s&1]
+    u32x4 ra[2], rb[2];
+    hload(0, ra);
+    if (1 < NI) hload(1, rb);
+    auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
+        constexpr int par = decltype(oddv)::value ? 0 : 1;          // s & 1 (V set s-1 is odd when s is even)
+        if (s < NI) stage_write(d, par);
+        if (s + 2 < NI) hload(s + 2, d);
+        if (s >= 3 && s - 3 < NJ) out_store(s - 3, par);           // written in step s-2 (same parity)
+        __syncthreads();
+        if (s < NI) hset(s, par, par);
+        if (s >= 1 && s - 1 < NJ) vset(s - 1, par, oddv);
+    };
+#pragma unroll 1
+    for (int s = 0; s < NJ + 3; s += 2) {
+        step(s, ra, std::true_type{});
+        step(s + 1, rb, std::false_type{});
+    }
+
+    if constexpr (SCORE) {   // the tile's slab: [0, slabn) source, [slabn, 2 slabn) blurred, 4 x u16 per entry (a box is <= 256 px)
+        __syncthreads();
+        unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
+        for (int e = tid; e < 2 * slabn; e += 256) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(s_box + 4 * e);
+            slab[e] = static_cast<unsigned long long>(v.x | (v.y << 16)) | (static_cast<unsigned long long>(v.z) << 32);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+// Fixed-point form of a blur kernel: wq[k] = round(w[k] 2^24), the centre takes what is left of 2^24.
+// Returns false when the table is outside what the three-digit form or the error bound covers.
+struct MfmaWeights {
+    long long wq[2 * MF_RMAX + 1];
+    double err255;                // 255 * sum |wq[k] - w[k] 2^24|: bound of |S - exact sum * 2^24|
+};
+static bool mfma_quantise(const double *kernel, int radius, MfmaWeights *q)
+{
+    if (radius < 1 || radius > MF_RMAX) return false;
+    const int nt = 2 * radius + 1;
+    double sum = 0;
+    for (int i = 0; i < nt; i++) {
+        if (!(kernel[i] >= 0) || !(kernel[i] < 0.49)) return false;   // three signed digits reach 127 * 65793 = 0.498 * 2^24
+        sum += kernel[i];
+    }
+    if (!(std::fabs(sum - 1.0) <= 1e-6)) return false;
+    long long tot = 0;
+    for (int i = 0; i < nt; i++) {
+        q->wq[i] = std::llround(kernel[i] * 16777216.0);
+        tot += q->wq[i];
+    }
+    q->wq[radius] += 16777216 - tot;
+    if (q->wq[radius] < 0 || q->wq[radius] > 8355711) return false;
+    long double e = 0;
+    for (int i = 0; i < nt; i++) e += fabsl(static_cast<long double>(q->wq[i]) - static_cast<long double>(kernel[i]) * 16777216.0L);
+    q->err255 = static_cast<double>(255.0L * e);
+    return true;
+}
+static void mfma_digits(long long v, int d[3])
+{
+    for (int i = 0; i < 3; i++) {
+        long long lo = ((v % 256) + 256) % 256;
+        if (lo >= 128) lo -= 256;
+        d[i] = static_cast<int>(lo);
+        v = (v - lo) / 256;
+    }
+}
+
+// device table: BH[3][64] x 16 bytes (digits hi, mid, lo) | BV even[3][64] x 8 | BV odd[3][64] x 8
+constexpr size_t MF_TAB_WORDS = 3 * 64 * 4 + 6 * 64 * 2;
+constexpr size_t MF_TAB_ALL = MF_TAB_WORDS + 2 * (2 * MF_RMAX + 1);   // + the fp64 weights
+static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
+{
+    std::fill(tab, tab + MF_TAB_WORDS, 0u);
+    int8_t *bh = reinterpret_cast<int8_t *>(tab);
+    int8_t *bv = reinterpret_cast<int8_t *>(tab + 3 * 64 * 4);
+    const int nt = 2 * radius + 1, off = MF_RMAX - radius;
+    for (int lane = 0; lane < 64; lane++) {
+        const int n = lane & 15, kc = lane >> 4;
+        for (int b = 0; b < 16; b++) {   // H: K index 16 kc + b = byte of the 64-byte window; output byte n = 4 px + channel
+            const int px = 4 * kc + b / 4, ch = b % 4, c = n % 4, pj = n / 4;
+            const int t = px - pj - off;
+            int d[3] = {0, 0, 0};
+            if (ch == c && c < 3 && t >= 0 && t < nt) mfma_digits(q.wq[t], d);
+            if (ch == c && c == 3 && px == pj + MF_RMAX) d[0] = 1;   // alpha column: the centre pixel's alpha as it is (effects.go:189)
+            for (int l = 0; l < 3; l++) bh[((2 - l) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
+        }
+        for (int b = 0; b < 8; b++) {    // V: K index 8 kc + b = staged row of the set's 32; output row n
+            const int te = 8 * kc + b - n - off;                    // even sets: ring row = staged row
+            const int to = ((8 * kc + b + 16) & 31) - n - off;      // odd sets: ring row k holds staged row (k + 16) % 32
+            int de[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
+            if (te >= 0 && te < nt) mfma_digits(q.wq[te], de);
+            if (to >= 0 && to < nt) mfma_digits(q.wq[to], dd);
+            for (int l = 0; l < 3; l++) {
+                bv[((2 - l) * 64 + lane) * 8 + b] = static_cast<int8_t>(de[l]);
+                bv[((3 + 2 - l) * 64 + lane) * 8 + b] = static_cast<int8_t>(dd[l]);
+            }
+        }
+    }
+}
+
+bool blur_mfma_covers(const double *kernel, int radius, int w, int h)
+{
+    static const bool off = [] { const char *e = getenv("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
+    if (off || w < 64 || h < 32) return false;
+    MfmaWeights q;
+    return mfma_quantise(kernel, radius, &q);
+}
+
+// rows per workgroup: as long as the halo (22 staged rows per segment beyond its own) stays small and there
+// are enough workgroups for every CU's three or four slots
+int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap)
+{
+    const long tiles_x = (w + 63) / 64;
+    int nseg = (h + cap - 1) / cap;
+    while (nseg < (h + 63) / 64 && tiles_x * nseg * n < 8L * ctx->num_cus) nseg++;
+    const int seg = 16 * ((((h + 15) / 16) + nseg - 1) / nseg);
+    return std::max(16, std::min(seg, cap));
+}
+
+template <bool SCORE, bool GUARD>
+static int launch_mfma_cfg(fnx_ctx *ctx, int n, MfmaArgs &ma, size_t lds)
+{
+    ma.tiles_x = (ma.w + 63) / 64;
+    ma.tiles = ma.tiles_x * ((ma.h + ma.seg - 1) / ma.seg);
+    dim3 grid(8 * ((ma.tiles + 7) / 8), n);
+    // the launch's events ride on its own packet (common.hpp: LaunchEvents); SCORE launches always carry a stop event:
+    // the step's tail on the ctx's second stream waits for it (blur.hip: launch_blur_scored)
+    LaunchEvents ev;
+    FNX_TRY(prof_bind(ctx, FNX_PROF_MAIN, &ev));
+    if constexpr (SCORE) {
+        if (!ev.stop) ev.stop = ctx->ev_blur[ctx->parity];
+        ctx->blur_done = ev.stop;
+    }
+    hipExtLaunchKernelGGL((blur_mfma_kernel<SCORE, GUARD>), grid, dim3(256), lds, ctx->stream, ev.start, ev.stop, 0, ma);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
+// weights, seeds and the guard distance of one call; the matrix table goes to its own table slot
+static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exact, MfmaArgs *ma)
+{
+    MfmaWeights q;
+    if (!mfma_quantise(kernel, radius, &q)) return FNX_NOOP;
+    uint32_t tab[MF_TAB_ALL] = {};
+    mfma_build_table(q, radius, tab);
+    memcpy(tab + MF_TAB_WORDS, kernel, sizeof(double) * (2 * radius + 1));
+    void *dt = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab, sizeof(tab), &dt));
+    ma->tab = static_cast<const uint32_t *>(dt);
+    ma->radius = radius;
+    // G (units of 2^-24): the fixed-point error bound, the reference's own fp64 chain error (13 roundings below 256:
+    // < 4e-13 = 7e-6 units) and one unit for the bound's own arithmetic
+    const long long gq = exact ? static_cast<long long>(std::ceil(q.err255)) + 2 : 0;
+    if (gq > (1 << 20)) return FNX_NOOP;
+    ma->seed_h = static_cast<int>((1u << 23) + static_cast<uint32_t>(gq));                 // staged bytes come out as (value ^ 0x80)
+    ma->seed_v = static_cast<int>((1u << 23) + (1u << 31) + static_cast<uint32_t>(gq));    // plain bytes
+    ma->thr = static_cast<int>(2 * gq);
+    return FNX_OK;
+}
+
+// GaussianBlur of n images; FNX_NOOP (nothing launched): the table or the shape is not this kernel's
+int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
+                     const double *kernel, int radius, int flags, uint8_t *dst, uint8_t *const *dsts, int dstride)
+{
+    if (!blur_mfma_covers(kernel, radius, w, h) || n > 65535) return FNX_NOOP;
+    const bool exact = flags & FNX_BLUR_EXACT;
+    MfmaArgs ma{};
+    const int st = mfma_prepare(ctx, kernel, radius, exact, &ma);
+    if (st != FNX_OK) return st;
+    ma.src = src; ma.srcs = srcs; ma.dst = dst; ma.dsts = dsts;
+    ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
+    ma.seg = blur_mfma_segment(ctx, n, w, h, 544);
+    return exact ? launch_mfma_cfg<false, true>(ctx, n, ma, 0) : launch_mfma_cfg<false, false>(ctx, n, ma, 0);
+}
+
+// the one-pass form: blur + the tile slabs of both box-sum sides (blur.hip's launch_blur_scored owns the geometry)
+int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
+                            int radius, int flags, uint8_t *const *dsts, int dstride, const int32_t *bx, const int32_t *by,
+                            unsigned long long *slabs, int nbx, int nby, int seg)
+{
+    const bool exact = flags & FNX_BLUR_EXACT;
+    MfmaArgs ma{};
+    const int st = mfma_prepare(ctx, kernel, radius, exact, &ma);
+    if (st != FNX_OK) return st;
+    ma.srcs = srcs; ma.dsts = dsts;
+    ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
+    ma.seg = seg;
+    ma.bx = bx; ma.by = by; ma.slabs = slabs; ma.nbx = nbx; ma.nby = nby;
+    const size_t lds = sizeof(uint32_t) * 8 * static_cast<size_t>(nbx + 1) * (nby + 1);
+    return exact ? launch_mfma_cfg<true, true>(ctx, n, ma, lds) : launch_mfma_cfg<true, false>(ctx, n, ma, lds);
+}
+
+}  // namespace fnx

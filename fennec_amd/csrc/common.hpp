@@ -49,6 +49,7 @@ enum Slot {
     SLOT_TMP3,
     SLOT_TABLE0,     // weight tables
     SLOT_TABLE1,
+    SLOT_TABLE_MFMA, // blur_mfma.hip: the weight matrices of the matrix-pipe blur
     SLOT_PARTIAL,    // reduction partials
     SLOT_RESULT,     // scalar results
     SLOT_PTRS,       // pointer arrays of batched ops
@@ -89,6 +90,8 @@ struct TableCache {
 struct ScoreGeom {
     int w = 0, h = 0, dstW = 0, dstH = 0, radius = 0;
     bool tall_pref = false, tall = false, ok = false;
+    bool mfma = false;          // the geometry is blur_mfma_kernel's (tile = 64 px x seg rows)
+    int seg = 0;
     int th = 0, nbx = 0, nby = 0;
     std::vector<int32_t> map;   // the table blob uploaded to SLOT_BOXMAP
 };
@@ -252,6 +255,14 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
 int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h,
                        const double *kernel, int radius, int flags, uint8_t *const *dsts, int dstride,
                        uint8_t *planes, size_t plane, int dstW, int dstH);
+// blur_mfma.hip: GaussianBlur on the i8 matrix pipe (radius <= 6, non-negative weights summing to 1, w >= 64, h >= 32)
+bool blur_mfma_covers(const double *kernel, int radius, int w, int h);
+int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap);
+int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
+                     const double *kernel, int radius, int flags, uint8_t *dst, uint8_t *const *dsts, int dstride);
+int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
+                            int radius, int flags, uint8_t *const *dsts, int dstride, const int32_t *bx, const int32_t *by,
+                            unsigned long long *slabs, int nbx, int nby, int seg);
 int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *dst,
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,
