@@ -63,6 +63,7 @@ struct MfmaArgs {
     const int32_t *bx, *by;           // box column / row of each source column / row (-1: none)
     unsigned long long *slabs;        // [image][tile][2][slabn] packed 4 x u16 channel sums (blur.hip: box_from_slabs_kernel)
     int nbx, nby;
+    int dbg;                          // development switches (FNX_MFMA_DBG)
 };
 
 // (hi * 256 + mid) * 256 + lo as two v_lshl_add_u32 (left alone the compiler builds two shifts and a v_add3)
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
     const int slabn = SCORE ? (a.nbx + 1) * (a.nby + 1) : 0;
     uint32_t *tbl_s = s_box, *tbl_b = s_box + 4 * slabn;
     if constexpr (SCORE) {
-        for (int e = tid; e < 8 * slabn; e += 256) s_box[e] = 0;
+        if (!(a.dbg & 4)) for (int e = tid; e < 8 * slabn; e += 256) s_box[e] = 0;
         const int rowbytes = 16 * (a.nbx + 1);
         const int b0y = a.by[y0];
         for (int u = tid; u < 16 * NI; u += 256) {                  // staged row u = tile row u - 6
@@ -185,44 +186,10 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
         return clampF_dev(acc);
     };
 
-    auto hload = [&](int i, u32x4 (&d)[2]) {
-        const int ys = y0 - 6 + 16 * i;
-        if (!xedge && ys >= 0 && ys + 16 <= a.h) {                  // uniform: no clamp in this set
-            const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - 6);
-            d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
-            if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (k == 1 && !two) break;
-                const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);   // clamp-to-edge (effects.go:174-178, 200-204)
-                const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
-                const int xc = x0 - 6 + 4 * (k ? sch1 : sch0);
-                if (!xedge) {
-                    d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
-                }
-            }
-        }
-    };
     auto stage_write = [&](const u32x4 (&d)[2], int buf) {
         uint8_t *sb = s_stage + buf * 16 * SP;
         *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
         if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
-    };
-    auto out_store = [&](int j, int buf) {                          // V set j's 16 rows, from the out stage
-        const u32x4 o = *reinterpret_cast<const u32x4 *>(s_out + buf * 16 * OP + o_r);
-        const int y = y0 + 16 * j + orow;
-        if (y < a.h) {
-            uint8_t *dp = dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xo);
-            if (!xedge || xo + 3 < a.w) *(g_u32x4w *)(dp) = o;
-            else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) if (xo + e < a.w) *(g_u32w *)(dp + 4 * e) = o[e];
-            }
-        }
     };
     // H set s: 16 staged rows from stage `buf` into ring slot `slot`
     auto hset = [&](int s, int buf, int slot) {
@@ -241,6 +208,7 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
             const v4i A = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
             const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
             const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowh + 16 * s + 4 * g);
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_s) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
@@ -323,6 +291,7 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
             const v4i A = {(int)os[0], (int)os[1], (int)os[2], (int)os[3]};
             const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
             const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowv + 16 * j + 4 * g);
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_b) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
@@ -331,26 +300,67 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
         *reinterpret_cast<u32x4 *>(s_out + buf * 16 * OP + o_w) = o;
     };
 
-    // step s: [stage write of H set s | store of V set s-3]  barrier  [H set s -> ring slot s&1 | V set s-1 -> out stage s&1]
-    u32x4 ra[2], rb[2];
-    hload(0, ra);
-    if (1 < NI) hload(1, rb);
-    auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
-        constexpr int par = decltype(oddv)::value ? 0 : 1;          // s & 1 (V set s-1 is odd when s is even)
-        if (s < NI) stage_write(d, par);
-        if (s + 2 < NI) hload(s + 2, d);
-        if (s >= 3 && s - 3 < NJ) out_store(s - 3, par);           // written in step s-2 (same parity)
-        __syncthreads();
-        if (s < NI) hset(s, par, par);
-        if (s >= 1 && s - 1 < NJ) vset(s - 1, par, oddv);
-    };
-#pragma unroll 1
-    for (int s = 0; s < NJ + 3; s += 2) {
-        step(s, ra, std::true_type{});
-        step(s + 1, rb, std::false_type{});
-    }
+    // the march itself, in two forms: strips whose source window stays inside the image's columns (16-byte loads, rows
+    // clamped where a set leaves the image) and the first / last strips (clamped px loads, masked stores)
+    auto march = [&](auto xedget) {
+        constexpr bool XEDGE = decltype(xedget)::value;
+        auto hload = [&](int i, u32x4 (&d)[2]) {
+            const int ys = y0 - 6 + 16 * i;
+            if (!XEDGE && ys >= 0 && ys + 16 <= a.h) {                  // uniform: no clamp in this set
+                const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - 6);
+                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
+                if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
+            } else {
+    #pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (k == 1 && !two) break;
+                    const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);   // clamp-to-edge (effects.go:174-178, 200-204)
+                    const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
+                    const int xc = x0 - 6 + 4 * (k ? sch1 : sch0);
+                    if constexpr (!XEDGE) {
+                        d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
+                    }
+                }
+            }
+        };
+        auto out_store = [&](int j, int buf) {                          // V set j's 16 rows, from the out stage
+            const u32x4 o = *reinterpret_cast<const u32x4 *>(s_out + buf * 16 * OP + o_r);
+            const int y = y0 + 16 * j + orow;
+            if (y < a.h) {
+                uint8_t *dp = dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xo);
+                if (!XEDGE || xo + 3 < a.w) *(g_u32x4w *)(dp) = o;
+                else {
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) if (xo + e < a.w) *(g_u32w *)(dp + 4 * e) = o[e];
+                }
+            }
+        };
+        // step s: [stage write of H set s | store of V set s-3]  barrier  [H set s -> ring slot s&1 | V set s-1 -> out stage s&1]
+        u32x4 ra[2], rb[2];
+        hload(0, ra);
+        if (1 < NI) hload(1, rb);
+        auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
+            constexpr int par = decltype(oddv)::value ? 0 : 1;          // s & 1 (V set s-1 is odd when s is even)
+            if (s < NI) stage_write(d, par);
+            if (s + 2 < NI) hload(s + 2, d);
+            if (s >= 3 && s - 3 < NJ) out_store(s - 3, par);           // written in step s-2 (same parity)
+            __syncthreads();
+            if (s < NI) hset(s, par, par);
+            if (s >= 1 && s - 1 < NJ) vset(s - 1, par, oddv);
+        };
+    #pragma unroll 1
+        for (int s = 0; s < NJ + 3; s += 2) {
+            step(s, ra, std::true_type{});
+            step(s + 1, rb, std::false_type{});
+        }
 
-    if constexpr (SCORE) {   // the tile's slab: [0, slabn) source, [slabn, 2 slabn) blurred, 4 x u16 per entry (a box is <= 256 px)
+    };
+    if (xedge) march(std::true_type{}); else march(std::false_type{});
+
+    if (SCORE && !(a.dbg & 2)) {   // the tile's slab: [0, slabn) source, [slabn, 2 slabn) blurred, 4 x u16 per entry (a box is <= 256 px)
         __syncthreads();
         unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
         for (int e = tid; e < 2 * slabn; e += 256) {
@@ -483,6 +493,7 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
     void *dt = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab, sizeof(tab), &dt));
     ma->tab = static_cast<const uint32_t *>(dt);
+    { const char *e = getenv("FNX_MFMA_DBG"); ma->dbg = e ? atoi(e) : 0; }
     ma->radius = radius;
     // G (units of 2^-24): the fixed-point error bound, the reference's own fp64 chain error (13 roundings below 256:
     // < 4e-13 = 7e-6 units) and one unit for the bound's own arithmetic
