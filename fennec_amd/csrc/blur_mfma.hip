@@ -444,6 +444,15 @@ static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
     }
 }
 
+// FNX_BLUR_EXACT through this kernel: its in-place fp64 recomputation couples the four waves of a workgroup (one flagged
+// sample stalls a whole 16-row step), 25 us per 4K image against 15 fast; blur.hip's guarded fp32 kernel takes exact
+// calls until the flagged samples leave the hot loop (FNX_BLUR_MFMA_EXACT=1 forces this one: the tests do)
+bool blur_mfma_exact_enabled()
+{
+    static const bool on = [] { const char *e = getenv("FNX_BLUR_MFMA_EXACT"); return e && e[0] == '1'; }();
+    return on;
+}
+
 bool blur_mfma_covers(const double *kernel, int radius, int w, int h)
 {
     static const bool off = [] { const char *e = getenv("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
@@ -511,6 +520,7 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
 {
     if (!blur_mfma_covers(kernel, radius, w, h) || n > 65535) return FNX_NOOP;
     const bool exact = flags & FNX_BLUR_EXACT;
+    if (exact && !blur_mfma_exact_enabled()) return FNX_NOOP;
     MfmaArgs ma{};
     const int st = mfma_prepare(ctx, kernel, radius, exact, &ma);
     if (st != FNX_OK) return st;
