@@ -301,17 +301,22 @@ def main() -> int:
         rest_ms = ms_per_step - blur_ms
         blur_bytes = 4.0 * S * nb0
         blur_gbs = blur_bytes / (blur_ms * 1e-3) / 1e9
+        mfma = not exact and os.environ.get("FNX_BLUR_MFMA", "1") != "0"
+        kname = "blur_mfma_kernel" if mfma else "blur_direct_kernel"
         roofline = {
-            "kernel": f"blur_direct_kernel<R=6, SCORE> (GaussianBlur sigma=2 + both boxDownsample sums of SSIMFast, "
-                      f"one launch of {nb0} images)",
-            # achieved / peak / frac are SURVEY 8(d)'s HBM figures (the contract of this object); what actually
-            # bounds the kernel is VALU issue (80.8 wave-instructions per pixel)
-            "bound": "valu",
+            "kernel": (f"blur_mfma_kernel<SCORE> (GaussianBlur sigma=2 on the i8 matrix pipe + both boxDownsample sums of SSIMFast, "
+                       f"one launch of {nb0} images)") if mfma else
+                      (f"blur_direct_kernel<R=6, SCORE, GUARD> (GaussianBlur sigma=2, guarded fp32 + fp64 fix-ups, + both boxDownsample "
+                       f"sums of SSIMFast, one launch of {nb0} images)"),
+            # achieved / peak / frac are SURVEY 8(d)'s HBM figures (the contract of this object).  The matrix-pipe kernel moves
+            # 2.2 S per image at ~3.5 TB/s; the tiled-copy floor of its access shape (64-px column strips, read S + write S)
+            # is ~13 us per 4K image on this part (experiments/mfma/pattern2.hip), the kernel takes ~19.5
+            "bound": "hbm" if mfma else "valu",
             "achieved": round(blur_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
-            "traffic": committed_traffic("blur_direct_kernel", nb0, scored=True, exact=exact),
+            "traffic": committed_traffic(kname, nb0, scored=True, exact=exact),
             "traffic_source": "profiles/*onepass*_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of this command (committed; "
                               "not measured in this run -- the driver's run has no profiler attached)",
             "algorithmic_bytes_per_launch": blur_bytes,
@@ -321,12 +326,12 @@ def main() -> int:
             "avg_launch_ms": round(blur_ms, 4),
             "launch_ms_min_median_max": [round(float(np.min(kernel_ms)), 4), round(float(np.median(kernel_ms)), 4),
                                          round(float(np.max(kernel_ms)), 4)],
-            "valu_issue_frac": committed_valu_issue("blur_direct_kernel", blur_ms, scored=True, exact=exact),
+            "valu_issue_frac": committed_valu_issue(kname, blur_ms, scored=True, exact=exact),
             "valu_issue_source": "SQ_ACTIVE_INST_VALU and the shader clock from profiles/*onepass*_sq_counters.txt (committed PMC pass) over THIS run's launch time",
             "avg_launch_how": "HIP events bound to the dispatch itself (hipExtLaunchKernelGGL start / stop events: the kernel packet's own "
                               "timestamps, no barrier packets on the stream), every launch of the timed region",
             "note": "the previous step's tail (box_from_slabs, windowed SSIM with its finish) runs on the ctx's second stream "
-                    "under this launch -- beside its waves: the blur keeps 96 VGPRs per SIMD free for them -- so its duration "
+                    "under this launch, beside its waves (three 154-register waves per SIMD leave room for them), so its duration "
                     "includes their share of the GPU",
         }
         if depth > 1:
@@ -381,14 +386,14 @@ def main() -> int:
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8 (fp32 accumulate blur, fp64 SSIM)",
+        "dtype": "u8 (blur: exact int32 sums of 24-bit fixed-point weights on the i8 matrix pipe; fp64 SSIM)" if not exact else "u8 (fp32 accumulate blur under a rounding guard + fp64 fix-ups, fp64 SSIM)",
         "data": "synthetic",
         "config": {
             "workload": "config2: 4K (3840x2160) NRGBA GaussianBlur sigma=2.0 + SSIMFast(orig, blurred)",
             "images_per_step_per_gpu": B,
             "width": W4K, "height": H4K, "sigma": SIGMA,
             "blur_mode": "exact (guarded fp32 kernel + fp64 fix-ups: bit-identical to the reference)" if exact else
-                         "fast (fp32 FMA, <=1 LSB on <=0.1% samples)",
+                         "fast (24-bit fixed-point weights, exact integer sums: <=1 LSB on <=0.001% samples)",
             "inputs": "device-resident (HBM), batched C-ABI entry points",
             "pipeline": args.pipeline + (" (fnx_gaussian_blur_ssim_fast_batch)" if one_pass else
                                          " (fnx_gaussian_blur_batch, fnx_ssim_fast_batch)"),
@@ -493,6 +498,36 @@ def main() -> int:
                                      "bit-identical to the reference's, scores from exactly those images; same protocol as the "
                                      "timed region (warm-up, synchronize on both sides), run right after it; "
                                      "`python bench.py --blur-mode exact` makes it the headline line"}
+    if rank == 0 and world == 1 and one_pass and nctx == 1 and depth == 1 and not args.no_extras:
+        # (a) the timed loop again over 500 steps: the driver's 20 steps last 14 ms, inside the clock governor's settling time
+        ctx.profile(False)
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
+        run_steps(500)
+        torch.cuda.synchronize()
+        t_l = (time.perf_counter() - t_l) / 500
+        out["long_run"] = {"value": round(mp_per_image * B / t_l, 1), "unit": "MP/s", "ms_per_step": round(t_l * 1e3, 4), "steps": 500,
+                           "note": "the timed region's loop over 500 steps, right after it (steady clocks); never `value`"}
+        # (b) the reference's own shape: GaussianBlur(img) -> img (effects.go:146), then SSIMFast(a, b) (ssim.go:48), as two batched calls
+        def two_call_steps(n):
+            for _ in range(n):
+                blur_plans[0].run()                            # fnx_gaussian_blur_batch
+                ssim_plans[0].enqueue()                        # fnx_ssim_fast_batch_enqueue
+                ssim_plans[0].fetch()
+        t_c = time.perf_counter()
+        while time.perf_counter() - t_c < 0.1:
+            two_call_steps(2)
+        two_call_steps(args.warmup)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        two_call_steps(args.steps)
+        torch.cuda.synchronize()
+        t_c = (time.perf_counter() - t_c) / args.steps
+        out["two_call"] = {"value": round(mp_per_image * B / t_c, 1), "unit": "MP/s", "ms_per_step": round(t_c * 1e3, 4),
+                           "steps": args.steps, "warmup": args.warmup, "roofline_frac": round(4.0 * S * B / t_c / 1e9 / HBM_PEAK_GBS, 4),
+                           "note": "fnx_gaussian_blur_batch then fnx_ssim_fast_batch on the same 32 images: the reference's two calls, "
+                                   "4*S of HBM traffic per image; same protocol as the timed region, run after it"}
+        ctx.profile(True)
     host0 = srcs[0].cpu().numpy() if rank == 0 else None
     if rank == 0 and not args.no_extras:
         host = host0
@@ -549,7 +584,8 @@ def other_configs(args) -> dict:
         except Exception as e:                  # a failure here must not cost the headline line
             out[wl] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("bounded passes after the timed region, the protocol of `bench.py --workload configN` at smaller batches; "
-                   "config5 is the --device-decode path (file bytes up, decoder + search + encoder on the device, new file down)")
+                   "config5 here is ONE host thread over 16 files (a per-item latency figure with its kernels' roofline); BASELINE config 5 "
+                   "-- 4096 items, the worker pool -- is the `batch` object of this line")
     return out
 
 
@@ -602,7 +638,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     # untimed: worker contexts, scratch growth, clocks
     fbatch.compress_batch(min(n_items, 8 * workers), work, make_state, workers=workers)
     # N = 1 reference inside this job: rank 0 alone over a slice of the items, the other ranks idle
-    n_ref = min(n_items, 384)
+    n_ref = min(n_items, 1024)       # >= 1024 items (~0.45 s): at 384 the reference itself carried an 8 % error bar
     barrier()
     ref_rate = None
     if rank == 0:
@@ -640,6 +676,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     total = n_items / elapsed
     return {
         "metric": "images/sec: CompressBatch 4K JPEG, SSIM-guided quality search",
+        "is": "BASELINE config 5 (the whole job; `other_configs.config5` is a one-thread, 16-file pass kept for its kernels' figures)",
         "value": round(total, 1), "unit": "images/s", "n_gpus": world, "items": n_items, "seconds": round(elapsed, 3),
         "images_per_s_per_rank": [round(c / elapsed, 1) for c in per_rank], "items_per_rank": per_rank,
         "n1_reference_images_per_s": round(ref_rate, 1),
@@ -1290,9 +1327,11 @@ def cpu_baseline_config5(files, target: float) -> dict:
 
 
 def _template_flags(kernel_name: str):
-    """(SCORE, GUARD) of a blur_direct_kernel<R, NTH, IH, SCORE, RA, RB, GUARD> instantiation name."""
+    """(SCORE, GUARD) of a blur_mfma_kernel<SCORE, GUARD> or blur_direct_kernel<R, NTH, IH, SCORE, RA, RB, GUARD> instantiation name."""
     try:
         args = [a.strip() for a in kernel_name[kernel_name.index("<") + 1:kernel_name.index(">")].split(",")]
+        if "blur_mfma_kernel" in kernel_name:
+            return args[0] == "true", args[1] == "true"
         return args[3] == "true", (len(args) > 6 and args[6] == "true")
     except (ValueError, IndexError):
         return False, False
