@@ -480,7 +480,8 @@ class Context:
         return out.value
 
     def MSSSIM(self, img1, img2) -> float:
-        """ssim.go:313 -- 5-level multi-scale SSIM."""
+        """ssim.go:313 -- 5-level multi-scale SSIM.  A strided / cropped view is treated as a Go SubImage: the pyramid starts from
+        the first 4*w*h flat bytes (convert.go:16), not from the view's rows; pass a contiguous copy for row-wise semantics."""
         a, b = self._pair(img1, img2)
         out = C.c_double()
         with self._ordered(img1, img2):
@@ -714,7 +715,9 @@ class Context:
         return dst
 
     def blur3x3(self, img):
-        """effects.go:116 gaussianBlur3x3"""
+        """effects.go:116 gaussianBlur3x3.  A strided / cropped view is a Go SubImage here (as for Sharpen / AdaptiveSharpen):
+        borders and alpha come from the first 4*w*h flat bytes (effects.go:120), as in the reference; pass a contiguous copy
+        for row-wise semantics."""
         s = _Img(img)
         dst = s.like(s.w, s.h)
         d = _Img(dst)
@@ -742,11 +745,11 @@ class Context:
         return dst
 
     def Sharpen(self, img, strength: float):
-        """effects.go:10.  strength <= 0 or an image under 3x3 returns `img` itself."""
+        """effects.go:10.  strength <= 0 or an image under 3x3 returns `img` itself.  Strided views: see blur3x3."""
         return self._sharpen(self._lib.fennec_Sharpen, "Sharpen", img, strength)
 
     def AdaptiveSharpen(self, img, strength: float):
-        """effects.go:49"""
+        """effects.go:49.  Strided views: see blur3x3."""
         return self._sharpen(self._lib.fennec_AdaptiveSharpen, "AdaptiveSharpen", img, strength)
 
     # -- resize.go ----------------------------------------------------------------------

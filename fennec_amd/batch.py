@@ -109,13 +109,14 @@ class _RankQueue:
     store hands out the next `chunk` indices to whichever worker of whichever rank asks first, so a rank with slower
     items (or a slower GPU) simply takes fewer -- no data-path collective, one small TCP round trip per chunk."""
     _seq = 0
+    _uses: dict = {}
 
-    def __init__(self, n_items: int, chunk: int = 1, group=None, batch_id: Optional[str] = None):
+    def __init__(self, n_items: int, chunk: int = 1, group=None, batch_id: Optional[str] = None, world: Optional[int] = None):
         import torch.distributed as dist
         from torch.distributed import distributed_c10d as c10d
 
         self.n, self.chunk = n_items, max(1, int(chunk))
-        self.world = dist.get_world_size(group)
+        self.world = int(world) if world else dist.get_world_size(group)   # the job's ranks: who is "last to leave" in close()
         # The counter's name must be the same batch on every rank.  A caller-supplied batch_id says so outright (use one
         # whenever ranks may call compress_batch a different number of times -- an exception before a batch, a mix of
         # static and dynamic calls); without it the per-process count of DYNAMIC batches names it, which holds as long as
@@ -123,6 +124,14 @@ class _RankQueue:
         if batch_id is None:
             _RankQueue._seq += 1
             batch_id = f"seq{_RankQueue._seq}"
+        else:
+            # a batch_id names ONE job.  Reused for back-to-back jobs without a barrier, a fast rank could re-enter while a
+            # slow one has not left: it would read the exhausted counter, take nothing, and the slow rank's close() would
+            # then wipe keys both jobs share.  The per-process use count keeps the jobs apart (every rank calls
+            # compress_batch with the same id the same number of times -- the contract batch_id had already).
+            use = _RankQueue._uses.get(batch_id, 0) + 1
+            _RankQueue._uses[batch_id] = use
+            batch_id = f"{batch_id}#{use}"
         self.key = f"next_{batch_id}"
         self.store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())
         self.lock = threading.Lock()
@@ -170,7 +179,7 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
         return []
     workers = max(1, min(workers, len(mine)))       # batch.go:63-69
     q: "queue.Queue[int]" = queue.Queue()
-    rq = _RankQueue(n_items, chunk, batch_id=batch_id) if dynamic else None
+    rq = _RankQueue(n_items, chunk, batch_id=batch_id, world=world) if dynamic else None
     if not dynamic:
         for i in mine:
             q.put(i)

@@ -461,7 +461,9 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
     }
     // a one-pass batch whose results have arrived has read its slabs / planes / partial sums for the last time: the
     // step that reuses the buffer set needs no stream-side wait for this tail (one barrier packet less per step)
-    if (q.tail_parity >= 0 && q.tail_gen == ctx->tail_gen[q.tail_parity]) ctx->tail_pending[q.tail_parity] = false;
+    // -- only when ALL of the batch's results were polled: a partial fetch (n < q.n) has seen images 0..n-1 done while the
+    // tail may still be reading the slabs and planes of the others (each image's last workgroup publishes its own mean)
+    if (q.tail_parity >= 0 && q.tail_gen == ctx->tail_gen[q.tail_parity] && (q.nraw > 0 || n == q.n)) ctx->tail_pending[q.tail_parity] = false;
     ctx->res_head = (ctx->res_head + 1) % fnx_ctx::RES_DEPTH;
     ctx->res_count--;
     return FNX_OK;

@@ -526,7 +526,8 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
     if (st != FNX_OK) return st;
     ma.src = src; ma.srcs = srcs; ma.dst = dst; ma.dsts = dsts;
     ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
-    ma.seg = blur_mfma_segment(ctx, n, w, h, 544);
+    static const int cap = [] { const char *e = getenv("FNX_MFMA_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
+    ma.seg = blur_mfma_segment(ctx, n, w, h, cap);
     return exact ? launch_mfma_cfg<false, true>(ctx, n, ma, 0) : launch_mfma_cfg<false, false>(ctx, n, ma, 0);
 }
 

@@ -352,8 +352,13 @@ int fnx_device_count(void)
     return static_cast<int>(g_devmap.size());
 }
 
+extern "C" void fennec_pool_release(void);   // host_api.cpp: idle worker contexts, keyed by LOGICAL device index
+
 int fnx_set_devices(const int *devices, int n)
 {
+    // pooled worker contexts were created under the old mapping: they would keep running on GPUs the caller just
+    // excluded (and report logical indices of a list that no longer exists)
+    fennec_pool_release();
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (n < 0 || (n > 0 && !devices)) {
         if (n < 0 && !devices) {               // (NULL, -1): back to the environment / every device

@@ -135,6 +135,11 @@ int fnx_download(fnx_ctx *ctx, void *host, int hstride, const void *dptr, int ds
  * (effects.go:147-149) belongs to the caller. */
 int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                       const double *kernel, int radius, int flags, uint8_t *dst, int dstride);
+/* A source with sstride != 4*w is a Go SubImage to fnx_blur3x3 / fnx_sharpen / fnx_adaptive_sharpen (and to fnx_msssim):
+ * the reference copies borders and alpha -- and MSSSIM its whole pyramid base -- from the FIRST 4*w*h bytes of the flat
+ * Pix slice (effects.go:68,120; convert.go:16; ssim.go:345), not row by row, and so do these entry points.  A caller
+ * that passes an ordinary pitched or cropped view and wants row-wise semantics must hand over a tight copy.  dst must
+ * not alias src (the flat-copy pass rewrites dst after the filter). */
 /* gaussianBlur3x3 (effects.go:116-141). */
 int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                 uint8_t *dst, int dstride);
@@ -188,7 +193,8 @@ int fnx_pixel_ssim(fnx_ctx *ctx, int space, const uint8_t *a_pix, size_t a_pix_l
 int fnx_ssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
              int bstride, int w, int h, const double *window, double *out);
 /* MSSSIM (ssim.go:313-365) for equal dims; per_level (NULL or 5 doubles)
- * receives each level's SSIMFast, NaN where the reference stops early. */
+ * receives each level's SSIMFast, NaN where the reference stops early.  Strides are NOT honoured for the pyramid base:
+ * toNRGBA copies the first 4*w*h flat bytes (convert.go:16, ssim.go:345) -- see the SubImage note at fnx_blur3x3. */
 int fnx_msssim(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                int bstride, int w, int h, const double *window, double *out, double *per_level);
 
