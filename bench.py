@@ -59,7 +59,9 @@ def _dist_setup(torch, dist, local_rank, world):
     backend = os.environ.get("FENNEC_BENCH_BACKEND", "nccl")
     dev = 0 if os.environ.get("FENNEC_BENCH_SINGLE_DEVICE") == "1" else local_rank
     torch.cuda.set_device(dev)
-    if world > 1:
+    # FENNEC_BENCH_FORCE_DIST=1: bring the process group up at world size 1 too (one rank, RCCL initialised, every
+    # reduction below really issued): what a 1-GPU box can prove about the N > 1 launch before an 8-GPU lease is spent
+    if world > 1 or os.environ.get("FENNEC_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -253,7 +255,7 @@ def main() -> int:
                 vals[halves[k]] = ssim_plans[k].fetch()        # fnx_results_fetch: the step's only syncs
 
     def barrier():
-        if world > 1:
+        if world > 1 or dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -272,7 +274,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -551,7 +553,7 @@ def main() -> int:
         out["cpu_baseline"] = cpu_baseline(host0)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return 0
 
@@ -655,7 +657,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     up = sum(r.OriginalSize for r in res)
     down = sum(r.CompressedSize for r in res)
     host_dec = sum(1 for r in res if getattr(r, "host_decoded", False))
-    summ = fbatch.summarize_distributed(res, device=red_dev if world > 1 else None)
+    summ = fbatch.summarize_distributed(res, device=red_dev if (world > 1 or dist.is_initialized()) else None, force=dist.is_initialized())
     per_rank = [mine]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -688,7 +690,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
         "distinct_files": n_files, "file_bytes_mean": round(sum(len(f) for f in files) / n_files),
         "pcie_bytes": {"up": up, "down": down, "per_item_up": round(up / n_items), "per_item_down": round(down / n_items)},
         "summarize": {"Total": summ.Total, "Succeeded": summ.Succeeded, "Failed": summ.Failed, "TotalSaved": summ.TotalSaved,
-                      "AvgSSIM": summ.AvgSSIM, "how": (f"batch.go:140-158; all-reduce over {'RCCL' if red_dev == 'cuda' else 'gloo (test hook)'}" if world > 1 else "batch.go:140-158")},
+                      "AvgSSIM": summ.AvgSSIM, "how": (f"batch.go:140-158; all-reduce over {'RCCL' if red_dev == 'cuda' else 'gloo (test hook)'}" if (world > 1 or dist.is_initialized()) else "batch.go:140-158")},
         "target_ssim": target,
         "note": f"the job is the same {n_items} items at every N (strong scaling: `efficiency_vs_n1` is the figure to read); run after the config-2 timed region, never `value`",
     }

@@ -387,13 +387,14 @@ def summarize_local(results: Sequence[BatchResult]) -> BatchSummary:
     return s
 
 
-def summarize_distributed(results: Sequence[BatchResult], device=None, group=None) -> BatchSummary:
-    """Summarize across all ranks: the path's one collective (two tiny all-reduces)."""
+def summarize_distributed(results: Sequence[BatchResult], device=None, group=None, force: bool = False) -> BatchSummary:
+    """Summarize across all ranks: the path's one collective (two tiny all-reduces).  `force`: issue the all-reduces in a
+    one-rank group too (legal, and the only way a 1-GPU box can run the RCCL branch)."""
     import torch
     import torch.distributed as dist
 
     s = summarize_local(results)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return s
     ints = torch.tensor([s.Total, s.Succeeded, s.Failed, s.TotalSaved], dtype=torch.int64, device=device)
     flt = torch.tensor([s.ssim_sum], dtype=torch.float64, device=device)
