@@ -57,7 +57,7 @@ struct MfmaArgs {
     int sstride, dstride, w, h;
     int tiles_x, tiles, seg;          // per image; seg = output rows per workgroup (multiple of 16)
     int radius;
-    const uint32_t *tab;              // BH[3][64] x 16 B | BV even[3][64] x 8 B | BV odd[3][64] x 8 B | the caller's 13 fp64 weights (GUARD)
+    const uint32_t *tab;              // BH[3][64] x 16 B | BV[3][64] x 8 B | the caller's 13 fp64 weights, centred (GUARD)
     int seed_h, seed_v, thr;          // rounding seeds (+ G in units of 2^-24 with GUARD), 2 G
     // SCORE
     const int32_t *bx, *by;           // box column / row of each source column / row (-1: none)
@@ -74,8 +74,35 @@ __device__ __forceinline__ int mf_comb3(int hi, int mid, int lo)
     return t * 256 + lo;
 }
 
+// One flagged sample again, in the reference's own arithmetic (effects.go:169-217): acc = acc + float64(p) * w, taps ascending,
+// clampF.  Always 13 taps: the table holds the caller's weights centred in the radius-6 frame with zeros around them, and
+// adding p * 0.0 = +0.0 to the non-negative running sum leaves it as it is.  Out of line (eight call sites), and every byte
+// is fetched before the first use: read one by one inside the hot loop the 13 LDS round trips made one flagged sample
+// cost its workgroup a whole 16-row step (the four waves meet at a barrier every step).
+// H: the staged source bytes (p ^ 0x80) at p[4 t]; V: the ring's bytes (t ^ 0x80) at p[(ring0 + t) & 31].
+__device__ __noinline__ uint32_t mf_exact_h(const uint8_t *p, const double *wd)
+{
+    uint32_t v[13];
+#pragma unroll
+    for (int t = 0; t < 13; t++) v[t] = p[4 * t];
+    double acc = 0;
+#pragma unroll
+    for (int t = 0; t < 13; t++) acc = acc + u8_to_f64(v[t] ^ 0x80u) * wd[t];
+    return clampF_dev(acc);
+}
+__device__ __noinline__ uint32_t mf_exact_v(const uint8_t *p, int ring0, const double *wd)
+{
+    uint32_t v[13];
+#pragma unroll
+    for (int t = 0; t < 13; t++) v[t] = p[(ring0 + t) & 31];
+    double acc = 0;
+#pragma unroll
+    for (int t = 0; t < 13; t++) acc = acc + u8_to_f64(v[t] ^ 0x80u) * wd[t];
+    return clampF_dev(acc);
+}
+
 template <bool SCORE, bool GUARD>
-__global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
+__global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs a)
 {
     constexpr int P = MF_P, WT = MF_WT, SP = MF_SP, OP = MF_OP;
     __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
@@ -98,20 +125,17 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
     const int r = lane & 15, g = lane >> 4;
     const int NJ = min(a.seg, ((a.h - y0 + 15) >> 4) << 4) >> 4;   // V sets of this segment (the image's last one may be short)
     const int NI = NJ + 1;                                          // H sets: staged rows y0 - 6 .. y0 + 16 NJ + 9
-    const int off = MF_RMAX - a.radius;                             // taps sit centred in the radius-6 frame
     const bool xedge = x0 - 6 < 0 || x0 + 70 > a.w;                 // the strip's source window leaves the image: clamped px loads, masked stores
 
     const v4i *tbh = reinterpret_cast<const v4i *>(a.tab);
     const long *tbv = reinterpret_cast<const long *>(a.tab + 3 * 64 * 4);
     const v4i bh2 = tbh[lane], bh1 = tbh[64 + lane], bh0 = tbh[128 + lane];
-    const long bve2 = tbv[lane], bve1 = tbv[64 + lane], bve0 = tbv[128 + lane];
-    const long bvo2 = tbv[192 + lane], bvo1 = tbv[256 + lane], bvo0 = tbv[320 + lane];
+    const long bv2 = tbv[lane], bv1 = tbv[64 + lane], bv0 = tbv[128 + lane];
     const bool alane = (r & 3) == 3;                                // H sets: this lane's output byte column is an alpha column
     const int seed_hl = alane ? (1 << 23) + 128 : a.seed_h;         // alpha lanes: (a - 128) + 128 in byte 0, no guard offset
     const v4i sh = {seed_hl, seed_hl, seed_hl, seed_hl}, sv = {a.seed_v, a.seed_v, a.seed_v, a.seed_v};
     const v4i zero = {0, 0, 0, 0};
     const uint32_t sel01 = alane ? 0x0c0c0400u : 0x0c0c0703u, sel23 = alane ? 0x04000c0cu : 0x07030c0cu;
-    const uint32_t amask = alane ? 0x00ffffffu : 0u;                // GUARD: alpha lanes never flag
 
     uint8_t *tw = s_t + wave * WT;
     // stage: chunk ids 0..303 = 16 rows x 19 chunks of 16 bytes (px x0 - 6 .. x0 + 69); thread tid takes id tid and, tid < 48, id 256 + tid
@@ -122,7 +146,10 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
     const int st_r = r * SP + 64 * wave + 16 * g;                   // A operand of H set qq: + 16 qq
     uint8_t *t_w = tw + r * P + 4 * g;                              // + (16 qq) P + 64 qq + 16 slot
     const int m4 = r >> 2, mi = r & 3;
-    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4 + 8 * g; // A operand of V column set q: + 4 q P
+    // A operand of V column set q (+ 4 q P): lane chunk g holds staged rows 8 g .. 8 g + 7 of the set's 32; an odd set's first
+    // 16 staged rows sit in ring rows 16..31, its last 16 in rows 0..15 -- a second lane address, the same weights
+    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4 + 8 * g;
+    const uint8_t *t_ro = tw + (16 * m4 + mi) * P + 64 * m4 + ((8 * g + 16) & 31);
     const uint8_t *t_ae = tw + (16 * g + 3) * P + 64 * g + r + 6;   // centre row's alpha, even / odd V sets: + 4 q P
     const uint8_t *t_ao = tw + (16 * g + 3) * P + 64 * g + ((r + 22) & 31);
     const int o_w = r * OP + 64 * wave + 16 * g;
@@ -171,20 +198,9 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
     }
 
     // ---- exact recomputation of flagged samples (GUARD), the reference's own arithmetic (effects.go:169-217) ----
-    const int nt = 2 * a.radius + 1;
-    const double *wd = reinterpret_cast<const double *>(a.tab + 3 * 64 * 4 + 6 * 64 * 2);
-    auto exact_h = [&](const uint8_t *sb, int row, int px, int c) -> uint32_t {     // staged bytes are (p ^ 0x80)
-        double acc = 0;
-        const uint8_t *p = sb + row * SP + 4 * (px + off) + c;
-        for (int t = 0; t < nt; t++) acc = acc + u8_to_f64(p[4 * t] ^ 0x80u) * wd[t];
-        return clampF_dev(acc);
-    };
-    auto exact_v = [&](int cl, int grp, int ring0) -> uint32_t {                     // ring bytes are (t ^ 0x80)
-        double acc = 0;
-        const uint8_t *p = tw + cl * P + 64 * grp;
-        for (int t = 0; t < nt; t++) acc = acc + u8_to_f64(p[(ring0 + t) & 31] ^ 0x80u) * wd[t];
-        return clampF_dev(acc);
-    };
+    const double *wd = reinterpret_cast<const double *>(a.tab + 3 * 64 * 4 + 3 * 64 * 2);   // 13 fp64 weights, centred
+    auto exact_h = [&](const uint8_t *sb, int row, int px, int c) -> uint32_t { return mf_exact_h(sb + row * SP + 4 * px + c, wd); };
+    auto exact_v = [&](int cl, int grp, int ring0) -> uint32_t { return mf_exact_v(tw + cl * P + 64 * grp, ring0, wd); };
 
     auto stage_write = [&](const u32x4 (&d)[2], int buf) {
         uint8_t *sb = s_stage + buf * 16 * SP;
@@ -214,32 +230,42 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
                 __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_s) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        v4i u[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) u[qq][k] = mf_comb3(c2[qq][k], c1[qq][k], c0[qq][k]);
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
-            v4i u;
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[qq][1], (uint32_t)u[qq][0], sel01);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[qq][3], (uint32_t)u[qq][2], sel23);
+            *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
+        }
+        if constexpr (GUARD) {
+            // one test for the lane's 16 samples: the smallest fraction field (alpha lanes: their seed puts 2^23 + alpha there).
+            // Flagged samples are recomputed AFTER the provisional dword went to the ring and patched there byte by byte: the
+            // accumulators are dead by then, so the out-of-line recomputation does not add its registers to theirs.
+            uint32_t m[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) u[k] = mf_comb3(c2[qq][k], c1[qq][k], c0[qq][k]);
-            if constexpr (GUARD) {
-                uint32_t f[4];
+            for (int qq = 0; qq < 4; qq++) {
+                const uint32_t f0 = static_cast<uint32_t>(u[qq][0]) & 0x00ffffffu, f1 = static_cast<uint32_t>(u[qq][1]) & 0x00ffffffu;
+                const uint32_t f2 = static_cast<uint32_t>(u[qq][2]) & 0x00ffffffu, f3 = static_cast<uint32_t>(u[qq][3]) & 0x00ffffffu;
+                m[qq] = min(min(min(f0, f1), f2), f3);
+            }
+            const uint32_t mm = min(min(min(m[0], m[1]), m[2]), m[3]);
+            if (__builtin_amdgcn_ballot_w64(mm < static_cast<uint32_t>(a.thr))) {   // ~1 set group in 10
+                uint32_t fl = 0;                                                     // bit 4 qq + k
 #pragma unroll
-                for (int k = 0; k < 4; k++) f[k] = (static_cast<uint32_t>(u[k]) & 0x00ffffffu) | amask;
-                const uint32_t m = min(min(f[0], f[1]), min(f[2], f[3]));
-                if (__builtin_amdgcn_ballot_w64(m < static_cast<uint32_t>(a.thr))) {   // ~1 set in 20: a lane walks its flagged samples
-                    uint32_t fl = 0;
+                for (int qq = 0; qq < 4; qq++)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) fl |= (f[k] < static_cast<uint32_t>(a.thr) ? 1u : 0u) << k;
-                    while (fl) {
-                        const int k = __builtin_ctz(fl);
-                        fl &= fl - 1;
-                        const int e = static_cast<int>((exact_h(sbuf, 4 * g + k, 16 * wave + 4 * qq + (r >> 2), r & 3) ^ 0x80u) << 24);
-#pragma unroll
-                        for (int i = 0; i < 4; i++) u[i] = k == i ? e : u[i];
-                    }
+                    for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[qq][k]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * qq + k);
+                while (fl) {
+                    const int b = __builtin_ctz(fl), qq = b >> 2, k = b & 3;
+                    fl &= fl - 1;
+                    const uint32_t e = exact_h(sbuf, 4 * g + k, 16 * wave + 4 * qq + (r >> 2), r & 3) ^ 0x80u;
+                    *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
                 }
             }
-            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], sel01);
-            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[3], (uint32_t)u[2], sel23);
-            *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
         }
     };
     // V set j: 16 output rows into out stage `buf`; odd sets find their first 16 staged rows in ring rows 16..31
@@ -248,43 +274,49 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
         long A[4];
         uint32_t al[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const long *>(t_r + (4 * q) * P);
+        for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const long *>((ODD ? t_ro : t_r) + (4 * q) * P);
 #pragma unroll
         for (int q = 0; q < 4; q++) al[q] = *((ODD ? t_ao : t_ae) + (4 * q) * P);
         v4i c2[4], c1[4], c0[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo2 : bve2, zero, 0, 0, 0);
-            c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo1 : bve1, zero, 0, 0, 0);
-            c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], ODD ? bvo0 : bve0, sv, 0, 0, 0);
+            c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv2, zero, 0, 0, 0);
+            c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv1, zero, 0, 0, 0);
+            c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv0, sv, 0, 0, 0);
         }
+        int u[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[q][i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int u[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) u[i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
-            if constexpr (GUARD) {
-                uint32_t f[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) f[i] = static_cast<uint32_t>(u[i]) & 0x00ffffffu;
-                const uint32_t m = min(min(f[0], f[1]), f[2]);
-                if (__builtin_amdgcn_ballot_w64(m < static_cast<uint32_t>(a.thr))) {
-                    uint32_t fl = 0;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) fl |= (f[i] < static_cast<uint32_t>(a.thr) ? 1u : 0u) << i;
-                    while (fl) {
-                        const int i = __builtin_ctz(fl);
-                        fl &= fl - 1;
-                        const int e = static_cast<int>(exact_v(16 * g + 4 * q + i, g, (ODD ? 16 : 0) + r + off) << 24);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) u[c] = i == c ? e : u[c];
-                    }
-                }
-            }
-            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], 0x0c0c0703u);
-            const uint32_t t23 = __builtin_amdgcn_perm(al[q], (uint32_t)u[2], 0x04030c0cu);
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[q][1], (uint32_t)u[q][0], 0x0c0c0703u);
+            const uint32_t t23 = __builtin_amdgcn_perm(al[q], (uint32_t)u[q][2], 0x04030c0cu);
             o[q] = t01 | t23;
+        }
+        uint8_t *op = s_out + buf * 16 * OP + o_w;
+        *reinterpret_cast<u32x4 *>(op) = o;
+        if constexpr (GUARD) {   // as in the H sets: provisional pixels to the out stage first, flagged bytes patched there
+            uint32_t m[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                m[q] = min(min(static_cast<uint32_t>(u[q][0]) & 0x00ffffffu, static_cast<uint32_t>(u[q][1]) & 0x00ffffffu), static_cast<uint32_t>(u[q][2]) & 0x00ffffffu);
+            const uint32_t mm = min(min(min(m[0], m[1]), m[2]), m[3]);
+            if (__builtin_amdgcn_ballot_w64(mm < static_cast<uint32_t>(a.thr))) {
+                uint32_t fl = 0;                                                     // bit 4 q + i
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) fl |= ((static_cast<uint32_t>(u[q][i]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * q + i);
+                while (fl) {
+                    const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
+                    fl &= fl - 1;
+                    op[4 * q + i] = static_cast<uint8_t>(exact_v(16 * g + 4 * q + i, g, (ODD ? 16 : 0) + r));
+                }
+                if constexpr (SCORE) o = *reinterpret_cast<const u32x4 *>(op);       // the box sums are those of the exact image
+            }
         }
         if constexpr (SCORE) {   // blurred side: lane (row r, chunk g) holds 4 px of row r -- an A operand as it is
             const u32x4 os = o ^ 0x80808080u;
@@ -297,7 +329,6 @@ __global__ __launch_bounds__(256) void blur_mfma_kernel(MfmaArgs a)
                 __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_b) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        *reinterpret_cast<u32x4 *>(s_out + buf * 16 * OP + o_w) = o;
     };
 
     // the march itself, in two forms: strips whose source window stays inside the image's columns (16-byte loads, rows
@@ -411,8 +442,8 @@ static void mfma_digits(long long v, int d[3])
     }
 }
 
-// device table: BH[3][64] x 16 bytes (digits hi, mid, lo) | BV even[3][64] x 8 | BV odd[3][64] x 8
-constexpr size_t MF_TAB_WORDS = 3 * 64 * 4 + 6 * 64 * 2;
+// device table: BH[3][64] x 16 bytes (digits hi, mid, lo) | BV[3][64] x 8 | 13 fp64 weights
+constexpr size_t MF_TAB_WORDS = 3 * 64 * 4 + 3 * 64 * 2;
 constexpr size_t MF_TAB_ALL = MF_TAB_WORDS + 2 * (2 * MF_RMAX + 1);   // + the fp64 weights
 static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
 {
@@ -431,25 +462,19 @@ static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
             for (int l = 0; l < 3; l++) bh[((2 - l) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
         }
         for (int b = 0; b < 8; b++) {    // V: K index 8 kc + b = staged row of the set's 32; output row n
-            const int te = 8 * kc + b - n - off;                    // even sets: ring row = staged row
-            const int to = ((8 * kc + b + 16) & 31) - n - off;      // odd sets: ring row k holds staged row (k + 16) % 32
-            int de[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
+            const int te = 8 * kc + b - n - off;
+            int de[3] = {0, 0, 0};
             if (te >= 0 && te < nt) mfma_digits(q.wq[te], de);
-            if (to >= 0 && to < nt) mfma_digits(q.wq[to], dd);
-            for (int l = 0; l < 3; l++) {
-                bv[((2 - l) * 64 + lane) * 8 + b] = static_cast<int8_t>(de[l]);
-                bv[((3 + 2 - l) * 64 + lane) * 8 + b] = static_cast<int8_t>(dd[l]);
-            }
+            for (int l = 0; l < 3; l++) bv[((2 - l) * 64 + lane) * 8 + b] = static_cast<int8_t>(de[l]);
         }
     }
 }
 
-// FNX_BLUR_EXACT through this kernel: its in-place fp64 recomputation couples the four waves of a workgroup (one flagged
-// sample stalls a whole 16-row step), 25 us per 4K image against 15 fast; blur.hip's guarded fp32 kernel takes exact
-// calls until the flagged samples leave the hot loop (FNX_BLUR_MFMA_EXACT=1 forces this one: the tests do)
+// FNX_BLUR_EXACT takes this kernel too (FNX_BLUR_MFMA_EXACT=0: blur.hip's guarded fp32 kernel, kept for A/B runs):
+// 4K plain 18.7 us against 23.8, one-pass 26.4 against 29.2 per image
 bool blur_mfma_exact_enabled()
 {
-    static const bool on = [] { const char *e = getenv("FNX_BLUR_MFMA_EXACT"); return e && e[0] == '1'; }();
+    static const bool on = [] { const char *e = getenv("FNX_BLUR_MFMA_EXACT"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -498,7 +523,7 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
     if (!mfma_quantise(kernel, radius, &q)) return FNX_NOOP;
     uint32_t tab[MF_TAB_ALL] = {};
     mfma_build_table(q, radius, tab);
-    memcpy(tab + MF_TAB_WORDS, kernel, sizeof(double) * (2 * radius + 1));
+    memcpy(reinterpret_cast<double *>(tab + MF_TAB_WORDS) + (MF_RMAX - radius), kernel, sizeof(double) * (2 * radius + 1));   // centred, zeros around
     void *dt = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab, sizeof(tab), &dt));
     ma->tab = static_cast<const uint32_t *>(dt);
