@@ -140,6 +140,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
         _sig(L, "fnx_download", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
         _sig(L, "fnx_gaussian_blur", i, [ctx, i] + img + [i, i, _f64p, i, i] + img)
+        _sig(L, "fnx_blur_fixed_point", i, [_f64p, i, C.POINTER(C.c_longlong), C.POINTER(d)])
         _sig(L, "fnx_blur3x3", i, [ctx, i] + img + [i, i] + img)
         _sig(L, "fnx_sharpen", i, [ctx, i] + img + [i, i, d] + img)
         _sig(L, "fnx_adaptive_sharpen", i, [ctx, i] + img + [i, i, d] + img)
@@ -1190,6 +1191,21 @@ def gaussianKernel(size=8, sigma=1.5):
     k = np.empty(size * size, dtype=np.float64)
     load_library().fennec_gaussianKernel(size, sigma, k.ctypes.data_as(_f64p))
     return k
+
+
+def blur_fixed_point(kernel):
+    """fnx_blur_fixed_point: (wq, err255) of a blur table as the matrix-pipe kernel quantises it, or None when the table is not
+    that kernel's.  Host arithmetic only."""
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    radius = (len(k) - 1) // 2
+    wq = (C.c_longlong * len(k))()
+    err = C.c_double()
+    rc = load_library().fnx_blur_fixed_point(k.ctypes.data_as(_f64p), radius, wq, C.byref(err))
+    if rc == FNX_NOOP:
+        return None
+    if rc != 0:
+        raise RuntimeError("fnx_blur_fixed_point failed")
+    return np.array(list(wq), dtype=np.int64), float(err.value)
 
 
 def blurKernel(sigma):

@@ -574,3 +574,16 @@ int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
 }
 
 }  // namespace fnx
+
+extern "C" int fnx_blur_fixed_point(const double *kernel, int radius, long long *wq, double *err255)
+{
+    if (!kernel || !wq || !err255) {
+        fnx::set_error("invalid argument: fnx_blur_fixed_point");
+        return FNX_ERR_INVALID;
+    }
+    fnx::MfmaWeights q;
+    if (!fnx::mfma_quantise(kernel, radius, &q)) return FNX_NOOP;
+    for (int i = 0; i < 2 * radius + 1; i++) wq[i] = q.wq[i];
+    *err255 = q.err255;
+    return FNX_OK;
+}
