@@ -18,6 +18,7 @@ PCMD="$CMD --prewarm 0"     # counters do not depend on the clock ramp; keep the
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o bench -- $PCMD > /dev/null 2> "$OUT/pmc_fetch.log"
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o bench -- $PCMD > /dev/null 2> "$OUT/pmc_write.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o bench -- $PCMD > /dev/null 2> "$OUT/pmc_sq.log"
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -o bench -- $PCMD > /dev/null 2> "$OUT/pmc_sq2.log"
 python "$ROOT/bench.py" --steps ${PLAIN_STEPS:-20} --warmup 3 $EXTRA > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.log"
 find "$OUT" -name "*.csv" | head -20
 tail -1 "$OUT/bench_plain.json"

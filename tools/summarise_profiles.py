@@ -60,6 +60,12 @@ with open(os.path.join(dst, f"{tag}_sq_counters.txt"), "w") as fo:
         for k, (v, n) in sorted(per_launch("pmc_sq", c).items()):
             if "fnx::" in k or "fnx_" in k:
                 fo.write(f"{c:24s} {v:16.0f}  (mean of {n} launches)  {k[:90]}\n")
+    # r4: the matrix pipe's share (its own pass: eight SQ slots per pass)
+    for c in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+              "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_BUSY_CYCLES"):
+        for k, (v, n) in sorted(per_launch("pmc_sq2", c).items()):
+            if "fnx::" in k or "fnx_" in k:
+                fo.write(f"{c:24s} {v:16.0f}  (mean of {n} launches)  {k[:90]}\n")
 # shader clock during the profiled launches: GRBM_GUI_ACTIVE is summed over the 8 XCD rows of a dispatch; the
 # launch durations come from the same pass's kernel trace
 try:
