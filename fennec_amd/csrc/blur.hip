@@ -961,6 +961,9 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     if (radius < 1 || radius > SCORE_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
     const bool exact = flags & FNX_BLUR_EXACT;
     if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
+    // radius 7, 8: GaussianBlur alone runs on the matrix pipe (blur_mfma_wide_kernel), whose fast-mode bytes are not this
+    // file's fp32 kernel's: the one-pass form must return what the two calls return, so it leaves these radii to them
+    if (radius > 6 && blur_mfma_takes(kernel, radius, w, h, exact)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);
     // the matrix-pipe kernel (blur_mfma.hip) where its table and its box geometry fit; its tile is 64 px x seg rows
     const int seg = blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272) : 0;

@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <vector>
 
 namespace fnx {
 
@@ -402,17 +403,267 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
 }
 
 // ------------------------------------------------------------------------------------
+// radii 7 .. 24 (sigma <= 8): the same march with a wider frame
+// ------------------------------------------------------------------------------------
+// H window 4 + 2 RF px = NKH chunks of 64 bytes: NKH chained matrix instructions per digit and set (RF = 14, 22, 24 for
+// NKH = 2, 3, 4).  V: v_mfma_i32_16x16x64_i8 over a 64-row window (16 + 2 RF <= 64), the ring holds four 16-row slots, a V
+// set runs three steps behind its first H set.  Same stages, same barrier per step, same exactness argument (the guard
+// distance grows with the tap count: G ~ 3e-4 at 45 taps).  Plain blur only (the one-pass SSIMFast form stops at radius 6).
+template <int NKH> struct MfWide {
+    static constexpr int RF = (8 * NKH - 2) < 24 ? (8 * NKH - 2) : 24;   // frame radius: taps sit centred in it
+    static constexpr int NC = 16 + RF / 2;                                // 16-byte chunks of a staged row: px x0 - RF .. x0 + 63 + RF
+    static constexpr int SP = 16 * NC + 48;                               // staged row pitch, conflict-free as the A operand (tools/lds_conflicts.py)
+    static constexpr int NT = 2 * RF + 1;
+    static constexpr int P = 80;                                          // ring: 64 rows + 16 per byte column
+    static constexpr int WT = 64 * P + 256;
+};
+
+template <int NT>
+__device__ __noinline__ uint32_t mf_exact_h_n(const uint8_t *p, const double *wd)
+{
+    double acc = 0;
+#pragma unroll 15
+    for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[4 * t] ^ 0x80u) * wd[t];
+    return clampF_dev(acc);
+}
+template <int NT>
+__device__ __noinline__ uint32_t mf_exact_v_n(const uint8_t *p, int ring0, const double *wd)
+{
+    double acc = 0;
+#pragma unroll 15
+    for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[(ring0 + t) & 63] ^ 0x80u) * wd[t];
+    return clampF_dev(acc);
+}
+
+template <int NKH, bool GUARD>
+__global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
+{
+    using C = MfWide<NKH>;
+    constexpr int RF = C::RF, NC = C::NC, SP = C::SP, P = C::P, WT = C::WT, OP = MF_OP, NT = C::NT;
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[2 * 16 * SP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[2 * 16 * OP];
+
+    const int tile = xcd_tile(blockIdx.x, a.tiles);
+    if (tile < 0) return;
+    const int z = blockIdx.y;
+    const uint8_t *src = a.srcs ? a.srcs[z] : a.src;
+    uint8_t *dst = a.dsts ? a.dsts[z] : a.dst;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * 64, y0 = ty * a.seg;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int NJ = min(a.seg, ((a.h - y0 + 15) >> 4) << 4) >> 4;
+    const int NI = NJ + 3;                                          // a V set reads the four H sets from its own on
+    const bool xedge = x0 - RF < 0 || x0 + 64 + RF > a.w;
+
+    const v4i *tbh = reinterpret_cast<const v4i *>(a.tab);
+    v4i bh[NKH][3];
+#pragma unroll
+    for (int kk = 0; kk < NKH; kk++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) bh[kk][l] = tbh[(3 * kk + l) * 64 + lane];   // digits hi, mid, lo
+    const v4i *tbv = tbh + 3 * NKH * 64;
+    const v4i bv2 = tbv[lane], bv1 = tbv[64 + lane], bv0 = tbv[128 + lane];
+    const double *wd = reinterpret_cast<const double *>(tbv + 192);
+    const bool alane = (r & 3) == 3;
+    const int seed_hl = alane ? (1 << 23) + 128 : a.seed_h;
+    const v4i sh = {seed_hl, seed_hl, seed_hl, seed_hl}, sv = {a.seed_v, a.seed_v, a.seed_v, a.seed_v};
+    const v4i zero = {0, 0, 0, 0};
+    const uint32_t sel01 = alane ? 0x0c0c0400u : 0x0c0c0703u, sel23 = alane ? 0x04000c0cu : 0x07030c0cu;
+
+    uint8_t *tw = s_t + wave * WT;
+    const int id1 = 256 + tid;
+    const int srow0 = tid / NC, sch0 = tid - NC * srow0, srow1 = id1 / NC, sch1 = id1 - NC * srow1;
+    const bool two = id1 < 16 * NC;
+    const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
+    const int st_r = r * SP + 64 * wave + 16 * g;                   // A operand of H set qq, K chunk kk: + 16 qq + 64 kk
+    uint8_t *t_w = tw + r * P + 4 * g;                              // + (16 qq) P + 64 qq + 16 slot
+    const int m4 = r >> 2, mi = r & 3;
+    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4;         // + 4 q P + 16 ((j + g) & 3)
+    const uint8_t *t_a = tw + (16 * g + 3) * P + 64 * g;            // + 4 q P + ((16 j + r + RF) & 63)
+    const int o_w = r * OP + 64 * wave + 16 * g;
+    const int orow = tid >> 4, och = tid & 15;
+    const int o_r = orow * OP + 16 * och;
+    const int xo = x0 + 4 * och;
+
+    auto stage_write = [&](const u32x4 (&d)[2], int buf) {
+        uint8_t *sb = s_stage + buf * 16 * SP;
+        *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
+        if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
+    };
+    auto hset = [&](int buf, int slot) {
+        const uint8_t *sbuf = s_stage + buf * 16 * SP;
+        const uint8_t *sb = sbuf + st_r;
+        v4i c2[4], c1[4], c0[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) { c2[qq] = zero; c1[qq] = zero; c0[qq] = sh; }
+#pragma unroll
+        for (int kk = 0; kk < NKH; kk++)
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const v4i A = *reinterpret_cast<const v4i *>(sb + 16 * qq + 64 * kk);
+                c2[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh[kk][0], c2[qq], 0, 0, 0);
+                c1[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh[kk][1], c1[qq], 0, 0, 0);
+                c0[qq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh[kk][2], c0[qq], 0, 0, 0);
+            }
+        v4i u[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) u[qq][k] = mf_comb3(c2[qq][k], c1[qq][k], c0[qq][k]);
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[qq][1], (uint32_t)u[qq][0], sel01);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[qq][3], (uint32_t)u[qq][2], sel23);
+            *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
+        }
+        if constexpr (GUARD) {
+            uint32_t m[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const uint32_t f0 = static_cast<uint32_t>(u[qq][0]) & 0x00ffffffu, f1 = static_cast<uint32_t>(u[qq][1]) & 0x00ffffffu;
+                const uint32_t f2 = static_cast<uint32_t>(u[qq][2]) & 0x00ffffffu, f3 = static_cast<uint32_t>(u[qq][3]) & 0x00ffffffu;
+                m[qq] = min(min(min(f0, f1), f2), f3);
+            }
+            const uint32_t mm = min(min(min(m[0], m[1]), m[2]), m[3]);
+            if (__builtin_amdgcn_ballot_w64(mm < static_cast<uint32_t>(a.thr))) {
+                uint32_t fl = 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[qq][k]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * qq + k);
+                while (fl) {
+                    const int b = __builtin_ctz(fl), qq = b >> 2, k = b & 3;
+                    fl &= fl - 1;
+                    const uint32_t e = mf_exact_h_n<NT>(sbuf + (4 * g + k) * SP + 4 * (16 * wave + 4 * qq + (r >> 2)) + (r & 3), wd) ^ 0x80u;
+                    *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                }
+            }
+        }
+    };
+    auto vset = [&](int j, int buf) {
+        v4i A[4];
+        uint32_t al[4];
+        const int ro = 16 * ((j + g) & 3);
+        const int ra_ = (16 * j + r + RF) & 63;
+#pragma unroll
+        for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const v4i *>(t_r + (4 * q) * P + ro);
+#pragma unroll
+        for (int q = 0; q < 4; q++) al[q] = *(t_a + (4 * q) * P + ra_);
+        v4i c2[4], c1[4], c0[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            c2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv2, zero, 0, 0, 0);
+            c1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv1, zero, 0, 0, 0);
+            c0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv0, sv, 0, 0, 0);
+        }
+        int u[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) u[q][i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[q][1], (uint32_t)u[q][0], 0x0c0c0703u);
+            const uint32_t t23 = __builtin_amdgcn_perm(al[q], (uint32_t)u[q][2], 0x04030c0cu);
+            o[q] = t01 | t23;
+        }
+        uint8_t *op = s_out + buf * 16 * OP + o_w;
+        *reinterpret_cast<u32x4 *>(op) = o;
+        if constexpr (GUARD) {
+            uint32_t m[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                m[q] = min(min(static_cast<uint32_t>(u[q][0]) & 0x00ffffffu, static_cast<uint32_t>(u[q][1]) & 0x00ffffffu), static_cast<uint32_t>(u[q][2]) & 0x00ffffffu);
+            const uint32_t mm = min(min(min(m[0], m[1]), m[2]), m[3]);
+            if (__builtin_amdgcn_ballot_w64(mm < static_cast<uint32_t>(a.thr))) {
+                uint32_t fl = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) fl |= ((static_cast<uint32_t>(u[q][i]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * q + i);
+                while (fl) {
+                    const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
+                    fl &= fl - 1;
+                    op[4 * q + i] = static_cast<uint8_t>(mf_exact_v_n<NT>(tw + (16 * g + 4 * q + i) * P + 64 * g, 16 * j + r, wd));
+                }
+            }
+        }
+    };
+
+    auto march = [&](auto xedget) {
+        constexpr bool XEDGE = decltype(xedget)::value;
+        auto hload = [&](int i, u32x4 (&d)[2]) {
+            const int ys = y0 - RF + 16 * i;
+            if (!XEDGE && ys >= 0 && ys + 16 <= a.h) {
+                const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - RF);
+                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
+                if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (k == 1 && !two) break;
+                    const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);
+                    const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
+                    const int xc = x0 - RF + 4 * (k ? sch1 : sch0);
+                    if constexpr (!XEDGE) {
+                        d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
+                    }
+                }
+            }
+        };
+        auto out_store = [&](int j, int buf) {
+            const u32x4 o = *reinterpret_cast<const u32x4 *>(s_out + buf * 16 * OP + o_r);
+            const int y = y0 + 16 * j + orow;
+            if (y < a.h) {
+                uint8_t *dp = dst + static_cast<size_t>(y) * a.dstride + 4 * static_cast<size_t>(xo);
+                if (!XEDGE || xo + 3 < a.w) *(g_u32x4w *)(dp) = o;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) if (xo + e < a.w) *(g_u32w *)(dp + 4 * e) = o[e];
+                }
+            }
+        };
+        // step s: [stage write of H set s | store of V set s-5]  barrier  [H set s -> ring slot s&3 | V set s-3 -> out stage s&1]
+        u32x4 ra[2], rb[2];
+        hload(0, ra);
+        hload(1, rb);
+        auto step = [&](int s, u32x4 (&d)[2], auto part) {
+            constexpr int par = decltype(part)::value;
+            if (s < NI) stage_write(d, par);
+            if (s + 2 < NI) hload(s + 2, d);
+            if (s >= 5 && s - 5 < NJ) out_store(s - 5, par);
+            __syncthreads();
+            if (s < NI) hset(par, s & 3);
+            if (s >= 3 && s - 3 < NJ) vset(s - 3, par);
+        };
+#pragma unroll 1
+        for (int s = 0; s < NJ + 5; s += 2) {
+            step(s, ra, std::integral_constant<int, 0>{});
+            step(s + 1, rb, std::integral_constant<int, 1>{});
+        }
+    };
+    if (xedge) march(std::true_type{}); else march(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
 // Fixed-point form of a blur kernel: wq[k] = round(w[k] 2^24), the centre takes what is left of 2^24.
 // Returns false when the table is outside what the three-digit form or the error bound covers.
+constexpr int MF_RWIDE = 24;         // blur_mfma_wide_kernel: 16 + 2 R <= the 64 rows of one V instruction
 struct MfmaWeights {
-    long long wq[2 * MF_RMAX + 1];
+    long long wq[2 * MF_RWIDE + 1];
     double err255;                // 255 * sum |wq[k] - w[k] 2^24|: bound of |S - exact sum * 2^24|
 };
-static bool mfma_quantise(const double *kernel, int radius, MfmaWeights *q)
+static bool mfma_quantise(const double *kernel, int radius, MfmaWeights *q, int rmax = MF_RMAX)
 {
-    if (radius < 1 || radius > MF_RMAX) return false;
+    if (radius < 1 || radius > rmax) return false;
     const int nt = 2 * radius + 1;
     double sum = 0;
     for (int i = 0; i < nt; i++) {
@@ -485,6 +736,20 @@ bool blur_mfma_covers(const double *kernel, int radius, int w, int h)
     MfmaWeights q;
     return mfma_quantise(kernel, radius, &q);
 }
+static bool blur_mfma_wide_covers(const double *kernel, int radius, int w, int h)
+{
+    static const bool off = [] { const char *e = getenv("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
+    if (off || w < 64 || h < 32 || radius <= MF_RMAX) return false;
+    MfmaWeights q;
+    return mfma_quantise(kernel, radius, &q, MF_RWIDE);
+}
+
+// does launch_blur_mfma take this call?  (blur.hip's one-pass form asks: its fast-mode images must be the two-call route's)
+bool blur_mfma_takes(const double *kernel, int radius, int w, int h, bool exact)
+{
+    if (exact && !blur_mfma_exact_enabled()) return false;
+    return blur_mfma_covers(kernel, radius, w, h) || blur_mfma_wide_covers(kernel, radius, w, h);
+}
 
 // rows per workgroup: as long as the halo (22 staged rows per segment beyond its own) stays small and there
 // are enough workgroups for every CU's three or four slots
@@ -539,13 +804,75 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
     return FNX_OK;
 }
 
+// blur_mfma_wide_kernel's table: BH[NKH][3][64] x 16 bytes | BV[3][64] x 16 bytes | 2 RF + 1 fp64 weights, centred
+template <int NKH>
+static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights &q, const double *kernel, int radius, bool exact)
+{
+    using C = MfWide<NKH>;
+    constexpr int RF = C::RF;
+    constexpr size_t words = (3 * NKH + 3) * 64 * 4 + 2 * C::NT;
+    std::vector<uint32_t> tab(words, 0u);
+    int8_t *bh = reinterpret_cast<int8_t *>(tab.data());
+    int8_t *bv = bh + 3 * NKH * 64 * 16;
+    const int nt = 2 * radius + 1, off = RF - radius;
+    for (int lane = 0; lane < 64; lane++) {
+        const int nn = lane & 15, kc = lane >> 4;
+        for (int kk = 0; kk < NKH; kk++)
+            for (int b = 0; b < 16; b++) {   // H: K index 64 kk + 16 kc + b = byte of the window
+                const int px = 16 * kk + 4 * kc + b / 4, ch = b % 4, c = nn % 4, pj = nn / 4;
+                const int t = px - pj - off;
+                int d[3] = {0, 0, 0};
+                if (ch == c && c < 3 && t >= 0 && t < nt) mfma_digits(q.wq[t], d);
+                if (ch == c && c == 3 && px == pj + RF) d[0] = 1;
+                for (int l = 0; l < 3; l++) bh[((3 * kk + (2 - l)) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
+            }
+        for (int b = 0; b < 16; b++) {       // V: K index 16 kc + b = staged row of the set's 64; output row nn
+            const int t = 16 * kc + b - nn - off;
+            int d[3] = {0, 0, 0};
+            if (t >= 0 && t < nt) mfma_digits(q.wq[t], d);
+            for (int l = 0; l < 3; l++) bv[((2 - l) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
+        }
+    }
+    memcpy(reinterpret_cast<double *>(tab.data() + (3 * NKH + 3) * 64 * 4) + off, kernel, sizeof(double) * nt);
+    void *dt = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab.data(), sizeof(uint32_t) * words, &dt));
+    ma.tab = static_cast<const uint32_t *>(dt);
+    ma.radius = radius;
+    ma.tiles_x = (ma.w + 63) / 64;
+    ma.tiles = ma.tiles_x * ((ma.h + ma.seg - 1) / ma.seg);
+    dim3 grid(8 * ((ma.tiles + 7) / 8), n);
+    LaunchEvents ev;
+    FNX_TRY(prof_bind(ctx, FNX_PROF_MAIN, &ev));
+    if (exact) hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, true>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
+    else hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, false>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
+    FNX_HIP(hipGetLastError());
+    return FNX_OK;
+}
+
 // GaussianBlur of n images; FNX_NOOP (nothing launched): the table or the shape is not this kernel's
 int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
                      const double *kernel, int radius, int flags, uint8_t *dst, uint8_t *const *dsts, int dstride)
 {
-    if (!blur_mfma_covers(kernel, radius, w, h) || n > 65535) return FNX_NOOP;
     const bool exact = flags & FNX_BLUR_EXACT;
     if (exact && !blur_mfma_exact_enabled()) return FNX_NOOP;
+    if (n > 65535) return FNX_NOOP;
+    if (blur_mfma_wide_covers(kernel, radius, w, h)) {     // radius 7 .. 24
+        MfmaWeights q;
+        mfma_quantise(kernel, radius, &q, MF_RWIDE);
+        const long long gq = exact ? static_cast<long long>(std::ceil(q.err255)) + 2 : 0;
+        if (gq > (1 << 20)) return FNX_NOOP;
+        MfmaArgs ma{};
+        ma.src = src; ma.srcs = srcs; ma.dst = dst; ma.dsts = dsts;
+        ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
+        ma.seed_h = static_cast<int>((1u << 23) + static_cast<uint32_t>(gq));
+        ma.seed_v = static_cast<int>((1u << 23) + (1u << 31) + static_cast<uint32_t>(gq));
+        ma.thr = static_cast<int>(2 * gq);
+        ma.seg = blur_mfma_segment(ctx, n, w, h, 544);
+        if (radius <= MfWide<2>::RF) return launch_mfma_wide<2>(ctx, n, ma, q, kernel, radius, exact);
+        if (radius <= MfWide<3>::RF) return launch_mfma_wide<3>(ctx, n, ma, q, kernel, radius, exact);
+        return launch_mfma_wide<4>(ctx, n, ma, q, kernel, radius, exact);
+    }
+    if (!blur_mfma_covers(kernel, radius, w, h)) return FNX_NOOP;
     MfmaArgs ma{};
     const int st = mfma_prepare(ctx, kernel, radius, exact, &ma);
     if (st != FNX_OK) return st;

@@ -258,6 +258,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
 // blur_mfma.hip: GaussianBlur on the i8 matrix pipe (radius <= 6, non-negative weights summing to 1, w >= 64, h >= 32)
 bool blur_mfma_covers(const double *kernel, int radius, int w, int h);
 bool blur_mfma_exact_enabled();
+bool blur_mfma_takes(const double *kernel, int radius, int w, int h, bool exact);
 int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap);
 int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
                      const double *kernel, int radius, int flags, uint8_t *dst, uint8_t *const *dsts, int dstride);

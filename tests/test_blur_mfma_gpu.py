@@ -131,3 +131,30 @@ def test_one_pass_equals_two_calls(ctx, orc, w, h):
             assert abs(ss[0] - orc.ssim_fast(imgs[0], outs[0].cpu().numpy(), procs=16)) <= 1e-9
             if exact:
                 assert np.array_equal(outs[0].cpu().numpy(), orc.gaussian_blur(imgs[0], 2.0, procs=16))
+
+
+@pytest.mark.parametrize("sigma", [2.4, 3.0, 4.6, 4.7, 5.0, 6.0, 7.3, 7.4, 8.0, 8.1])
+def test_wide_radii(ctx, orc, sigma):
+    """radius 8 .. 24 on blur_mfma_wide_kernel (two, three, four 64-byte K chunks per H set; 64-row V window), 25: blur.hip"""
+    for img in (synth.noise_image(517, 301, int(sigma * 10), alpha=True), synth.large_photo(1030, 620, 3)):
+        want = orc.gaussian_blur(img, sigma, procs=8)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want)
+        _close(ctx.GaussianBlur(img, sigma), want)
+
+
+@pytest.mark.parametrize("radius", [7, 10, 14, 15, 19, 22, 23, 24])
+def test_wide_every_sample_a_tie(ctx, orc, radius):
+    k = _binomial(radius)
+    w, h = 320, 176
+    cols = np.zeros((h, w, 4), np.uint8); cols[:, 1::2, :3] = 1; cols[..., 3] = 255
+    rows = np.zeros((h, w, 4), np.uint8); rows[1::2, :, :3] = 1; rows[..., 3] = 9
+    mixed = synth.noise_image(w, h, radius, alpha=True); mixed[40:140, 100:260, :3] &= 1
+    for img in (cols, rows, mixed):
+        assert np.array_equal(ctx.GaussianBlur(img, 1.0, exact=True, kernel=k), orc.gaussian_blur(img, 1.0, kernel=k, procs=4))
+
+
+def test_wide_4k_sigma6(ctx, orc):
+    img = synth.noise_image(3840, 2160, 66, alpha=True)
+    want = orc.gaussian_blur(img, 6.0, procs=32)
+    assert np.array_equal(ctx.GaussianBlur(img, 6.0, exact=True), want)
+    _close(ctx.GaussianBlur(img, 6.0), want)
