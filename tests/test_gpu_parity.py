@@ -840,6 +840,8 @@ def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
     assert abs(ctx.SSIM(crop, scrop) - orc.ssim(crop, scrop, procs=16)) <= SSIM_TOL
     s = ctx.SSIM(img, sharp)
     assert 0.0 < s < 1.0 and ctx.SSIM(img, img) == 1.0
+    # r4: the full 8K pair against the oracle (33 M windows, ~30 s of host time on 64 threads): config 4 at its own size
+    assert abs(s - orc.ssim(img, sharp, procs=64)) <= SSIM_TOL
 
 
 # ------------------------------------------------------------------ fused blur kernel: every radius, odd shapes
