@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
     uint32_t coln = 0;                                              // byte offset of this lane's (box column, channel) in a table row
     const int slabn = SCORE ? (a.nbx + 1) * (a.nby + 1) : 0;
     uint32_t *tbl_s = s_box, *tbl_b = s_box + 4 * slabn;
-    if constexpr (SCORE) {
+    // (called from the march once the first two row sets' loads are in flight: its table look-ups then wait beside them)
+    auto score_setup = [&]() {
         if (!(a.dbg & 4)) for (int e = tid; e < 8 * slabn; e += 256) s_box[e] = 0;
         const int rowbytes = 16 * (a.nbx + 1);
         const int b0y = a.by[y0];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
         sbox = (v4i){seed, seed, seed, seed};
         const uint32_t bc = (r < 15 && first != 255u && cnt > 0) ? first + slot : static_cast<uint32_t>(a.nbx);
         coln = 16u * bc + 4u * (r < 15 ? ch : 3);
-    }
+    };
 
     // ---- exact recomputation of flagged samples (GUARD), the reference's own arithmetic (effects.go:169-217) ----
     const double *wd = reinterpret_cast<const double *>(a.tab + 3 * 64 * 4 + 3 * 64 * 2);   // 13 fp64 weights, centred
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
         u32x4 ra[2], rb[2];
         hload(0, ra);
         if (1 < NI) hload(1, rb);
+        if constexpr (SCORE) score_setup();
         auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
             constexpr int par = decltype(oddv)::value ? 0 : 1;          // s & 1 (V set s-1 is odd when s is even)
             if (s < NI) stage_write(d, par);
