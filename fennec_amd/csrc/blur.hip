@@ -971,7 +971,10 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref && g.seg == seg)) {
         g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref; g.seg = seg;
         g.mfma = seg > 0 && build_score_geom(g, w, h, radius, dstW, dstH, seg);
-        g.ok = g.mfma || build_score_geom(g, w, h, radius, dstW, dstH);
+        // where GaussianBlur alone runs on the matrix pipe but its one-pass geometry does not fit (boxes under 4 px: long side
+        // 1843..2047), this file's fp32 kernel would return fast-mode bytes the two calls do not: the two calls take the step
+        // (tools/fuzz_blur.py: 72 such shapes in 6 528)
+        g.ok = g.mfma || (seg == 0 && build_score_geom(g, w, h, radius, dstW, dstH));
     }
     if (!g.ok) return FNX_NOOP;
     const std::vector<int32_t> &map = g.map;

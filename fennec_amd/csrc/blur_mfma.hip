@@ -213,6 +213,35 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
     auto hset = [&](int s, int buf, int slot) {
         const uint8_t *sbuf = s_stage + buf * 16 * SP;
         const uint8_t *sb = sbuf + st_r;
+        if constexpr (!GUARD && !SCORE) {
+            // plain fast blur: two halves of two sets each -- 24 accumulator registers live instead of 48, 113 VGPRs in all:
+            // FOUR workgroups per CU (4K: 15.8 -> 14.75 us per image, same box).  The one-pass form lost 3 % with it (129
+            // registers, still three workgroups, less room for the scheduler), the exact form 1 % (143): both keep the
+            // whole-group form.
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                v4i c2[2], c1[2], c0[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; q2++) {
+                    const v4i A = *reinterpret_cast<const v4i *>(sb + 16 * (2 * hf + q2));
+                    c2[q2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh2, zero, 0, 0, 0);
+                    c1[q2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh1, zero, 0, 0, 0);
+                    c0[q2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bh0, sh, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 2; q2++) {
+                    const int qq = 2 * hf + q2;
+                    v4i u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) u[k] = mf_comb3(c2[q2][k], c1[q2][k], c0[q2][k]);
+                    const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)u[1], (uint32_t)u[0], sel01);
+                    const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)u[3], (uint32_t)u[2], sel23);
+                    *reinterpret_cast<uint32_t *>(t_w + (16 * qq) * P + 64 * qq + 16 * slot) = t01 | t23;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
         v4i c2[4], c1[4], c0[4];
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
@@ -279,18 +308,36 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
         for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const long *>((ODD ? t_ro : t_r) + (4 * q) * P);
 #pragma unroll
         for (int q = 0; q < 4; q++) al[q] = *((ODD ? t_ao : t_ae) + (4 * q) * P);
-        v4i c2[4], c1[4], c0[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv2, zero, 0, 0, 0);
-            c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv1, zero, 0, 0, 0);
-            c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv0, sv, 0, 0, 0);
-        }
         int u[4][3];
+        if constexpr (!GUARD && !SCORE) {   // plain fast blur: two halves of two column sets (see the H sets)
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+            for (int hf = 0; hf < 2; hf++) {
+                v4i c2[2], c1[2], c0[2];
 #pragma unroll
-            for (int i = 0; i < 3; i++) u[q][i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
+                for (int q2 = 0; q2 < 2; q2++) {
+                    c2[q2] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[2 * hf + q2], bv2, zero, 0, 0, 0);
+                    c1[q2] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[2 * hf + q2], bv1, zero, 0, 0, 0);
+                    c0[q2] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[2 * hf + q2], bv0, sv, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 2; q2++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) u[2 * hf + q2][i] = mf_comb3(c2[q2][i], c1[q2][i], c0[q2][i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            v4i c2[4], c1[4], c0[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c2[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv2, zero, 0, 0, 0);
+                c1[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv1, zero, 0, 0, 0);
+                c0[q] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A[q], bv0, sv, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) u[q][i] = mf_comb3(c2[q][i], c1[q][i], c0[q][i]);
+        }
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; q++) {

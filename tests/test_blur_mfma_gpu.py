@@ -158,3 +158,20 @@ def test_wide_4k_sigma6(ctx, orc):
     want = orc.gaussian_blur(img, 6.0, procs=32)
     assert np.array_equal(ctx.GaussianBlur(img, 6.0, exact=True), want)
     _close(ctx.GaussianBlur(img, 6.0), want)
+
+
+@pytest.mark.parametrize("w,h", [(1860, 1002), (1849, 855), (640, 1880), (1887, 1760), (2040, 600)])
+def test_one_pass_where_the_box_geometry_does_not_fit(ctx, orc, w, h):
+    """long side 1843..2047: SSIMFast downsamples by 3.6..4 (3-px boxes), outside the matrix kernel's indicator matrix; the
+    one-pass entry point must still return the two-call route's bytes (found by tools/fuzz_blur.py)"""
+    import torch
+    imgs = [synth.noise_image(w, h, w + h, alpha=True), synth.large_photo(w, h, 1)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    for sigma in (1.0, 2.0):
+        for exact in (False, True):
+            outs, ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=exact)
+            ref = ctx.GaussianBlurBatch(d, sigma, exact=exact)
+            ref_ss = ctx.SSIMFastBatch(d, ref)
+            for k in range(len(imgs)):
+                assert torch.equal(outs[k], ref[k]) and ss[k] == ref_ss[k]
