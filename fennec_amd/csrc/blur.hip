@@ -966,7 +966,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     if (radius > 6 && blur_mfma_takes(kernel, radius, w, h, exact)) return FNX_NOOP;
     const bool tall_pref = direct_tall(ctx, radius, n, w, h);
     // the matrix-pipe kernel (blur_mfma.hip) where its table and its box geometry fit; its tile is 64 px x seg rows
-    const int seg = blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272) : 0;
+    const int seg = blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272, 3) : 0;
     ScoreGeom &g = ctx->score_geom;
     if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref && g.seg == seg)) {
         g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref; g.seg = seg;

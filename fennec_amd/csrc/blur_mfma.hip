@@ -800,15 +800,24 @@ bool blur_mfma_takes(const double *kernel, int radius, int w, int h, bool exact)
     return blur_mfma_covers(kernel, radius, w, h) || blur_mfma_wide_covers(kernel, radius, w, h);
 }
 
-// rows per workgroup: as long as the halo (22 staged rows per segment beyond its own) stays small and there
-// are enough workgroups for every CU's three or four slots
-int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap)
+// Rows per workgroup.  A workgroup of NJ 16-row sets runs NJ + 4 steps (the pipeline's fill and drain); the grid runs in
+// rounds of occ workgroups per CU.  The segment count that minimises rounds x steps: long segments for batches (the halo
+// is 22 staged rows per segment), one full round of short ones for a single image (4K alone: 17 segments of 128 rows,
+// 18 us against 23 with "at least eight workgroups per CU").
+int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap, int occ)
 {
-    const long tiles_x = (w + 63) / 64;
-    int nseg = (h + cap - 1) / cap;
-    while (nseg < (h + 63) / 64 && tiles_x * nseg * n < 8L * ctx->num_cus) nseg++;
-    const int seg = 16 * ((((h + 15) / 16) + nseg - 1) / nseg);
-    return std::max(16, std::min(seg, cap));
+    const long tiles_x = (w + 63) / 64, slots = static_cast<long>(occ) * ctx->num_cus;
+    const int sets = (h + 15) / 16;
+    int best_seg = 16, first = 1;
+    double best = 0;
+    for (int nseg = std::max(1, (h + cap - 1) / cap); nseg <= std::max(1, sets / 2); nseg++) {
+        const int nj = (sets + nseg - 1) / nseg, seg = 16 * nj;
+        if (seg > cap) continue;
+        const long segs = (h + seg - 1) / seg, wgs = tiles_x * segs * n;
+        const double cost = static_cast<double>((wgs + slots - 1) / slots) * (nj + 4);
+        if (first || cost < best * 0.98) { best = cost; best_seg = seg; first = 0; }   // ties go to the longer segment
+    }
+    return best_seg;
 }
 
 template <bool SCORE, bool GUARD>
@@ -916,7 +925,7 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
         ma.seed_h = static_cast<int>((1u << 23) + static_cast<uint32_t>(gq));
         ma.seed_v = static_cast<int>((1u << 23) + (1u << 31) + static_cast<uint32_t>(gq));
         ma.thr = static_cast<int>(2 * gq);
-        ma.seg = blur_mfma_segment(ctx, n, w, h, 544);
+        ma.seg = blur_mfma_segment(ctx, n, w, h, 544, 3);
         if (radius <= MfWide<2>::RF) return launch_mfma_wide<2>(ctx, n, ma, q, kernel, radius, exact);
         if (radius <= MfWide<3>::RF) return launch_mfma_wide<3>(ctx, n, ma, q, kernel, radius, exact);
         return launch_mfma_wide<4>(ctx, n, ma, q, kernel, radius, exact);
@@ -928,7 +937,7 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
     ma.src = src; ma.srcs = srcs; ma.dst = dst; ma.dsts = dsts;
     ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
     static const int cap = [] { const char *e = getenv("FNX_MFMA_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
-    ma.seg = blur_mfma_segment(ctx, n, w, h, cap);
+    ma.seg = blur_mfma_segment(ctx, n, w, h, cap, exact ? 3 : 4);
     return exact ? launch_mfma_cfg<false, true>(ctx, n, ma, 0) : launch_mfma_cfg<false, false>(ctx, n, ma, 0);
 }
 

@@ -259,7 +259,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
 bool blur_mfma_covers(const double *kernel, int radius, int w, int h);
 bool blur_mfma_exact_enabled();
 bool blur_mfma_takes(const double *kernel, int radius, int w, int h, bool exact);
-int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap);
+int blur_mfma_segment(const fnx_ctx *ctx, int n, int w, int h, int cap, int occ);
 int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
                      const double *kernel, int radius, int flags, uint8_t *dst, uint8_t *const *dsts, int dstride);
 int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
