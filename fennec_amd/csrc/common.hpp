@@ -155,6 +155,13 @@ struct fnx_ctx {
     } res_buf[RES_DEPTH];
     fnx::ScoreGeom score_geom;
     std::vector<fnx_resize_plan *> rplans;   // at most 8, least recently used evicted (resize.hip)
+    uint32_t *rz_todo = nullptr;             // resize_mfma.hip -> resize_fused_kernel: tiles to redo, stamped with rz_gen
+    size_t rz_todo_cap = 0;
+    uint32_t rz_gen = 0;
+    unsigned long long *rz_report = nullptr; // host-mapped: what resize_fused_sparse_kernel redid (gen << 32 | tiles)
+    uint32_t rz_last_gen = 0;                // the last matrix launch whose report has not been read
+    size_t rz_last_cells = 0;
+    const fnx_resize_plan *rz_last_h = nullptr;
     // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
     static constexpr int PROF_DEPTH = 32;
     int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)
@@ -285,6 +292,26 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
 int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
                  uint8_t *dst, int dstride);
 void free_resize_plans(fnx_ctx *ctx);
+// resize_mfma.hip: lanczosResize on the i8 matrix pipe (opaque images, ratios up to ~2.3).  One tap table in matrix form:
+struct RzMfTable {
+    bool ok = false;
+    int KH = 0;                    // H tables: 64-byte chunks of a group's window (1, 2)
+    int NC = 0;                    // H tables: 16-byte chunks of a staged source row
+    int ngroups = 0;               // H: groups of 4 outputs, 16 per 64-column strip; V: groups of 16 output rows
+    int nmat = 0;                  // distinct matrices
+    int seed = 0, thr = 0;         // rounding seed + G, 2 G (units of 2^-22)
+    void *blob = nullptr;          // device: matrices | per-group records | per-strip source offsets
+    const void *mats = nullptr;
+    const int32_t *meta = nullptr, *sbase = nullptr;
+    const void *ex = nullptr;      // per output: the operands of the fp64 fix-ups
+};
+bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double *inv, RzMfTable *out);
+void resize_mfma_free(RzMfTable *t);
+// Launches the matrix kernel; regions it gives up are marked todo[tile] = gen for resize_fused_kernel's tiles
+// (old_tw x old_th output px, old_gx per row), which the caller launches next.
+int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
+                       const uint8_t *src, int sstride, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH,
+                       uint32_t *todo, unsigned *gave_up, uint32_t gen, int old_tw, int old_th, int old_gx, int *workgroups);
 // lanczosResize (resize.go:37-53) with both tables given: the body of fnx_lanczos_resize
 int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
                           const TapTable &th, const TapTable &tv, uint8_t *dst, int dstride, int dstW, int dstH);

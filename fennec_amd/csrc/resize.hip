@@ -951,6 +951,11 @@ struct ResizeFusedArgs {
     ResizeGuardArgs h;               // src = the source image, nout = dstW, other = srcH (dst unused)
     ResizeGuardArgs v;               // dst = the destination, nout = dstH, other = dstW, srcN = srcH (src unused)
     int ng;                          // V groups per tile
+    const uint32_t *todo;            // resize_fused_sparse_kernel: only tiles with todo[tile] == gen run (the rest is resize_mfma_kernel's)
+    uint32_t gen;
+    int cells, gx;                   // tiles, tiles per row
+    unsigned *counter;               // resize_mfma_kernel's workgroups that gave up (zeroed again by the reader)
+    unsigned long long *report;      // host-mapped: gen << 32 | that count
 };
 
 // one output of resizeV exactly as the reference computes it (resize.go:137-156), its taps read from the tile
@@ -971,7 +976,7 @@ __device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &
 // RMAX: the tile's rows.  64 (32 KB: three workgroups per CU) where a 2:1 downscale needs them; 32 (16 KB) for upscales,
 // whose V groups read few tmp rows: with the phase buffers sized by the window (NV = 2: 13 KB) four workgroups fit a CU.
 template <int NV, int RMAX>
-__global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(ResizeFusedArgs fa)
+__device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, const int bx, const int by)
 {
     constexpr int HO = RG_HO, NPX = 4 * NV, VG = RG_VG;
     static_assert(NV <= 4 && HO == 2, "weights in registers; two outputs per lane");
@@ -988,11 +993,11 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(R
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid == 0) { s_nfix = 0; s_nfix2 = 0; s_ndense = 0; }
     // the tile's tmp rows [r0, r1): the union of its V groups' windows (monotone tables: the host checks)
-    const int gfirst = blockIdx.y * fa.ng, glast = min(gfirst + fa.ng, v.ngroups) - 1;
+    const int gfirst = by * fa.ng, glast = min(gfirst + fa.ng, v.ngroups) - 1;
     const int r0 = v.s0[gfirst], r1 = v.s0[glast] + v.cnt[glast];
     const int rpw = (r1 - r0 + 3) >> 2;
     const int yw = r0 + wave * rpw, y1 = min(yw + rpw, r1);        // this wave's rows (<= 16)
-    const int g = blockIdx.x * 64 + lane;
+    const int g = bx * 64 + lane;
     const int gc = min(g, a.ngroups - 1);                           // idle lanes shadow the last group (their columns are never stored)
     const bool active = g < a.ngroups;
     const int s0 = a.s0[gc];
@@ -1096,7 +1101,7 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(R
     // the exact loop of resize_h_guard_kernel (see there): fp64 weights staged only if some wave marked a row
     double *s_aw = reinterpret_cast<double *>(s_u);
     if (__syncthreads_or(exact_rows != 0)) {
-        const int g0 = blockIdx.x * 64;
+        const int g0 = bx * 64;
         for (int e = tid; e < HO * NPX * 64; e += 256) {
             const int gl = e & 63, ji = e >> 6;
             s_aw[e] = g0 + gl < a.ngroups ? a.aw[static_cast<size_t>(ji) * a.ngroups + g0 + gl] : 0.0;
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(R
         const int nfix = s_nfix;
         for (int e = tid; e < nfix; e += 256) {
             const int row = static_cast<int>(s_fix[e] >> 8), col = static_cast<int>(s_fix[e] & 0xffu);
-            s_tile[row * RF_TW + col] = resize_exact_px<false>(a, blockIdx.x * RF_TW + col, r0 + row);
+            s_tile[row * RF_TW + col] = resize_exact_px<false>(a, bx * RF_TW + col, r0 + row);
         }
     }
     __syncthreads();
@@ -1169,7 +1174,7 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(R
     float *s_wv = reinterpret_cast<float *>(s_u) + wave * (64 * VG);
     double *s_awv = reinterpret_cast<double *>(s_u + 4 * sizeof(float) * 64 * VG) + wave * (68 * VG);
     uint32_t *s_tm = reinterpret_cast<uint32_t *>(s_u + 4 * (sizeof(float) * 64 * VG + sizeof(double) * 68 * VG)) + wave * 20;
-    const int x = blockIdx.x * RF_TW + 2 * lane;
+    const int x = bx * RF_TW + 2 * lane;
     const int ncol = x + 1 < v.other ? 2 : (x < v.other ? 1 : 0);
     const uint32_t own = (1u << ncol) - 1u;
     const bool st8 = ((reinterpret_cast<uintptr_t>(v.dst) | static_cast<uintptr_t>(v.dstride)) & 7u) == 0;
@@ -1340,9 +1345,33 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(R
         const int nfix = s_nfix2;
         for (int e = tid; e < nfix; e += 256) {
             const int y = static_cast<int>(s_fix[e] >> 8), col = static_cast<int>(s_fix[e] & 0xffu);
-            *(g_u32w *)(v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(blockIdx.x * RF_TW + col)) =
+            *(g_u32w *)(v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(bx * RF_TW + col)) =
                 resize_exact_px_tile(v, s_tile, r0, col, y);
         }
+    }
+}
+
+template <int NV, int RMAX>
+__global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(ResizeFusedArgs fa)
+{
+    resize_fused_tile<NV, RMAX>(fa, blockIdx.x, blockIdx.y);
+}
+
+// After resize_mfma_kernel: the tiles it handed back, and only those.  A fixed grid of workgroups walks the stamps (a launch
+// of every tile's workgroup that looks and leaves took 4 us of an 18 us call); the first one also passes on to the host
+// how many of the matrix kernel's workgroups gave up (a hint for the next call with these tables: resize_fused's cool-down).
+template <int NV, int RMAX>
+__global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_sparse_kernel(ResizeFusedArgs fa)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // how many of resize_mfma_kernel's workgroups gave up (it has finished: stream order), for the host's next call
+        const unsigned total = atomicExch(fa.counter, 0u);
+        *reinterpret_cast<volatile unsigned long long *>(fa.report) = (static_cast<unsigned long long>(fa.gen) << 32) | total;
+    }
+    for (int t = blockIdx.x; t < fa.cells; t += gridDim.x) {
+        if (fa.todo[t] != fa.gen) continue;
+        resize_fused_tile<NV, RMAX>(fa, t % fa.gx, t / fa.gx);
+        __syncthreads();
     }
 }
 
@@ -1386,6 +1415,8 @@ struct fnx_resize_plan {
     const int32_t *d_s0 = nullptr, *d_cnt = nullptr;
     const uint32_t *d_alpha = nullptr;
     const double *d_aw = nullptr, *d_inv = nullptr;
+    fnx::RzMfTable mf;               // resize_mfma.hip: the matrix form (mf.ok: covered)
+    int mf_cool = 0;                 // H plans: calls left to skip the matrix kernel (it handed most of an image back)
 };
 
 namespace fnx {
@@ -1394,9 +1425,16 @@ void free_resize_plans(fnx_ctx *ctx)
 {
     for (fnx_resize_plan *p : ctx->rplans) {
         if (p->blob) (void)hipFree(p->blob);
+        resize_mfma_free(&p->mf);
         delete p;
     }
     ctx->rplans.clear();
+    if (ctx->rz_todo) (void)hipFree(ctx->rz_todo);
+    ctx->rz_todo = nullptr;
+    ctx->rz_todo_cap = 0;
+    if (ctx->rz_report) (void)hipHostFree(ctx->rz_report);
+    ctx->rz_report = nullptr;
+    ctx->rz_last_gen = 0;
 }
 
 static bool resize_guard_disabled()
@@ -1578,6 +1616,7 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
             if (ctx->rplans[i]->last_use < ctx->rplans[victim]->last_use) victim = i;
         FNX_HIP(hipStreamSynchronize(ctx->stream));                  // queued kernels may still read its tables
         if (ctx->rplans[victim]->blob) FNX_HIP(hipFree(ctx->rplans[victim]->blob));
+        resize_mfma_free(&ctx->rplans[victim]->mf);
         delete ctx->rplans[victim];
         ctx->rplans.erase(ctx->rplans.begin() + victim);
     }
@@ -1638,6 +1677,7 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
     p->d_alpha = reinterpret_cast<const uint32_t *>(base + o_alpha);
     p->d_aw = reinterpret_cast<const double *>(base + o_aw);
     p->d_inv = reinterpret_cast<const double *>(base + o_inv);
+    if (p->guard_ok) (void)resize_mfma_build(t, srcN, vertical, invv.data(), &p->mf);
     p->last_use = tick++;
     *out = p.get();
     ctx->rplans.push_back(p.release());
@@ -1697,6 +1737,76 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     fa.ng = ng;
     const dim3 grid(gx, (pv->ngroups + ng - 1) / ng);
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
+    // The matrix kernel first (resize_mfma.hip); resize_fused_sparse_kernel then redoes the tiles it gave up (translucent
+    // or tie-dense regions).  When it gave up most of an image -- the count comes back through host-mapped memory, read
+    // here one call later -- the next 64 calls with this H plan skip it: a heuristic about cost, both kernels are exact.
+    bool use_mf = ph->mf.ok && pv->mf.ok;
+    static const bool adapt = [] { const char *e = getenv("FNX_RM_ADAPT"); return !(e && e[0] == '0'); }();
+    if (use_mf && adapt && ctx->rz_report && ctx->rz_last_gen != 0) {
+        const unsigned long long repv = *reinterpret_cast<volatile unsigned long long *>(ctx->rz_report);
+        if (static_cast<uint32_t>(repv >> 32) == ctx->rz_last_gen) {
+            if (ctx->rz_last_h == ph && 2 * (repv & 0xffffffffull) > ctx->rz_last_cells) ph->mf_cool = 64;
+            ctx->rz_last_gen = 0;
+        }
+    }
+    if (use_mf && ph->mf_cool > 0) { ph->mf_cool--; use_mf = false; }
+    if (use_mf) {
+        const size_t cells = static_cast<size_t>(grid.x) * grid.y;
+        if (cells + 2 > ctx->rz_todo_cap) {
+            FNX_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->rz_todo) FNX_HIP(hipFree(ctx->rz_todo));
+            ctx->rz_todo = nullptr;
+            ctx->rz_todo_cap = 0;
+            FNX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->rz_todo), sizeof(uint32_t) * (cells + 2)));
+            FNX_HIP(hipMemsetAsync(ctx->rz_todo, 0, sizeof(uint32_t) * (cells + 2), ctx->stream));
+            ctx->rz_todo_cap = cells + 2;
+            ctx->rz_gen = 0;
+        }
+        if (!ctx->rz_report) {
+            FNX_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->rz_report), sizeof(unsigned long long), hipHostMallocMapped));
+            *ctx->rz_report = 0;
+        }
+        if (++ctx->rz_gen == 0) {                                   // 2^32 calls later: start the stamps over
+            FNX_HIP(hipMemsetAsync(ctx->rz_todo, 0, sizeof(uint32_t) * ctx->rz_todo_cap, ctx->stream));
+            ctx->rz_gen = 1;
+        }
+        int mf_wgs = 0;
+        FNX_TRY(resize_mfma_launch(ctx, ph->mf, pv->mf, src, sstride, srcW, srcH, dst, dstride, th.nout, tv.nout,
+                                   ctx->rz_todo + 2, ctx->rz_todo, ctx->rz_gen, 64 * RG_HO, RG_VG * ng, static_cast<int>(grid.x), &mf_wgs));
+        fa.todo = ctx->rz_todo + 2;
+        fa.gen = ctx->rz_gen;
+        fa.cells = static_cast<int>(cells);
+        fa.gx = static_cast<int>(grid.x);
+        fa.counter = ctx->rz_todo;
+        void *dev_report = nullptr;
+        FNX_HIP(hipHostGetDevicePointer(&dev_report, ctx->rz_report, 0));
+        fa.report = static_cast<unsigned long long *>(dev_report);
+        ctx->rz_last_gen = ctx->rz_gen;
+        ctx->rz_last_cells = static_cast<size_t>(mf_wgs);
+        ctx->rz_last_h = ph;
+        if (const char *e = getenv("FNX_RM_STATS")) {                // development: how many tiles came back; "2": stop here
+            std::vector<uint32_t> cells_h(cells);
+            FNX_HIP(hipStreamSynchronize(ctx->stream));
+            FNX_HIP(hipMemcpy(cells_h.data(), ctx->rz_todo + 2, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
+            size_t back = 0;
+            for (uint32_t c : cells_h) back += c == ctx->rz_gen;
+            fprintf(stderr, "resize_mfma: NC %d, %d + %d matrices, G %d / %d, %zu of %zu tiles handed back\n", ph->mf.NC,
+                    ph->mf.nmat, pv->mf.nmat, ph->mf.thr / 2, pv->mf.thr / 2, back, cells);
+            if (e[0] == '2') return prof_end(ctx);
+        }
+        const dim3 sgrid(static_cast<unsigned>(std::min<size_t>(cells, static_cast<size_t>(2) * ctx->num_cus)));
+        if (low) {
+            hipLaunchKernelGGL((resize_fused_sparse_kernel<2, 32>), sgrid, dim3(256), 0, ctx->stream, fa);
+        } else {
+            switch (ph->NV) {
+            case 2: hipLaunchKernelGGL((resize_fused_sparse_kernel<2, RF_RMAX>), sgrid, dim3(256), 0, ctx->stream, fa); break;
+            case 3: hipLaunchKernelGGL((resize_fused_sparse_kernel<3, RF_RMAX>), sgrid, dim3(256), 0, ctx->stream, fa); break;
+            default: hipLaunchKernelGGL((resize_fused_sparse_kernel<4, RF_RMAX>), sgrid, dim3(256), 0, ctx->stream, fa); break;
+            }
+        }
+        FNX_HIP(hipGetLastError());
+        return prof_end(ctx);
+    }
     if (low) {
         hipLaunchKernelGGL((resize_fused_kernel<2, 32>), grid, dim3(256), 0, ctx->stream, fa);
     } else {
