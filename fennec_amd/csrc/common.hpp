@@ -412,12 +412,12 @@ struct DecSyncTables {
 struct JpegFile {
     int w = 0, h = 0;
     int ncomp = 3;               // 3: image.YCbCr; 1: image.Gray
-    int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0; -1: one component
+    int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0, 4 4:1:1, 5 4:1:0; -1: one component
     int hy = 1, vy = 1;          // Y blocks per MCU across / down
     int nslots = 3;              // blocks per MCU
     int ri = 0;                  // MCUs per restart interval (DRI); 0: none
     int mx = 0, my = 0;          // MCUs per row / column
-    uint32_t dcpack = 0, acpack = 0;
+    uint64_t dcpack = 0, acpack = 0;   // Huffman table of MCU slot s: (pack >> 4 s) & 15 (up to 4 x 2 + 2 slots)
     uint16_t q[3][64];           // per component, natural order
     size_t scan = 0;             // offset of the entropy-coded segment in the file
     int rounds = 0;              // cross-workgroup synchronisation rounds the decode took

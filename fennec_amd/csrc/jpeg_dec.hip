@@ -26,7 +26,7 @@
 // copies the scan into pinned memory (one memchr pass).
 //
 // Handled: what jpeg.Encode, libjpeg and most cameras write -- baseline (SOF0), 8 bit, three components (4:4:4, 4:2:2,
-// 4:2:0, 4:4:0) or one (image.Gray), one scan, with or without restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
+// 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one (image.Gray), one scan, with or without restart intervals.  Anything else is FNX_ERR_UNSUPPORTED (the caller decodes on the
 // host); a scan that ends early or holds a code outside its table is FNX_ERR_INVALID.  Restated from ITU T.81 and
 // reader.go / scan.go / huffman.go's published behaviour, not from Go's source: bit-exact against the CPU restatement
 // the tests hold (which libjpeg-turbo's files exercise), parity with Go unpinned.
@@ -63,7 +63,7 @@ struct DecArgs {
     unsigned long long nbits;                        // length of the string
     int nlanes;                                      // spans in the string
     int nblk, nslots;
-    uint32_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
+    uint64_t dcpack, acpack;                         // table of slot s: (pack >> 4 s) & 15
     const uint32_t *rst;                             // byte offsets at which restart intervals 1, 2, ... start (ascending)
     int nrst;
     int ri_blocks;                                   // blocks per restart interval
@@ -169,7 +169,7 @@ __device__ __forceinline__ void dec_span(const DecShared &sh, const DecArgs &a, 
         nxt = dec_word(sh.seg, wi + 2);
         const unsigned long long pair = (static_cast<unsigned long long>(hi) << 32) | lo;
         const uint32_t c16 = static_cast<uint32_t>((pair << off) >> 48);
-        const int t = static_cast<int>(((z == 0 ? a.dcpack : a.acpack) >> (4 * slot)) & 15u);
+        const int t = static_cast<int>(((z == 0 ? a.dcpack : a.acpack) >> (4 * slot)) & 15ull);
         uint32_t e;
         if constexpr (!WRITE) {
             // the sync passes' tables hold what a symbol does to the state, ready made -- and, for the AC tables, what the

@@ -131,11 +131,14 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 // a one-component scan is not interleaved (T.81 A.2.2): one block per MCU whatever the factors say; image.Gray
                 f->ratio = -1; f->hy = 1; f->vy = 1;
             } else {
-                if (!(comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1) || comp_h[0] < 1 || comp_h[0] > 2 ||
-                    comp_v[0] < 1 || comp_v[0] > 2)
-                    return jpeg_unsupported("a subsampling other than 4:4:4, 4:2:2, 4:2:0 and 4:4:0");
+                // image/jpeg takes luminance factors 1, 2, 4 across and 1, 2 down (reader.go: v == 4 is unsupported there too);
+                // the chroma planes at 1 x 1 are what every encoder writes
+                if (!(comp_h[1] == 1 && comp_v[1] == 1 && comp_h[2] == 1 && comp_v[2] == 1) ||
+                    !(comp_h[0] == 1 || comp_h[0] == 2 || comp_h[0] == 4) || comp_v[0] < 1 || comp_v[0] > 2)
+                    return jpeg_unsupported("a subsampling other than 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1 and 4:1:0");
                 f->hy = comp_h[0]; f->vy = comp_v[0];
-                f->ratio = f->hy == 2 ? (f->vy == 2 ? 2 : 1) : (f->vy == 2 ? 3 : 0);       // image.YCbCrSubsampleRatio
+                // image.YCbCrSubsampleRatio: 444, 422, 420, 440, 411, 410
+                f->ratio = f->hy == 4 ? (f->vy == 2 ? 5 : 4) : f->hy == 2 ? (f->vy == 2 ? 2 : 1) : (f->vy == 2 ? 3 : 0);
             }
             f->ncomp = ncomp;
             const int ny = f->hy * f->vy;
@@ -143,8 +146,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             f->dcpack = f->acpack = 0;
             for (int s = 0; s < f->nslots; s++) {
                 const int c = s < ny ? 0 : s - ny + 1;
-                f->dcpack |= static_cast<uint32_t>(td[c]) << (4 * s);
-                f->acpack |= static_cast<uint32_t>(2 + ta[c]) << (4 * s);
+                f->dcpack |= static_cast<uint64_t>(td[c]) << (4 * s);
+                f->acpack |= static_cast<uint64_t>(2 + ta[c]) << (4 * s);
             }
             for (int c = 0; c < 3; c++)
                 for (int k = 0; k < 64; k++) f->q[c][k] = c < ncomp ? q[comp_q[c]][k] : 1;

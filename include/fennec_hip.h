@@ -254,7 +254,7 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
  * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
  * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all (host work: ctx may be
  * NULL and no device is touched).  Handled: baseline
- * (SOF0), 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0) or one (image.Gray), one scan, with or without restart intervals; anything else returns
+ * (SOF0), 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one (image.Gray), one scan, with or without restart intervals; anything else returns
  * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
  * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Huffman decoding is parallel over
  * 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how

@@ -2038,16 +2038,17 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
                 if (!have_t[0][td[c]] || !have_t[1][ta[c]] || !have_q[comp_q[c]]) return -8;
             }
             if (W <= 0 || H <= 0) return -4;
-            /* Y blocks per MCU across / down: 1 or 2 each (4:4:4, 4:2:2, 4:2:0, 4:4:0); one component: a block per MCU,
+            /* Y blocks per MCU across (1, 2, 4) / down (1, 2): 4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0; one component: a block per MCU,
              * whatever its factors say (T.81 A.2.2: a one-component scan is not interleaved) */
             int hy = 1, vy = 1;
             if (ncomp == 3) {
                 if (comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) return -9;
                 hy = comp_h[0]; vy = comp_v[0];
-                if (hy < 1 || hy > 2 || vy < 1 || vy > 2) return -9;
+                if (!(hy == 1 || hy == 2 || hy == 4) || vy < 1 || vy > 2) return -9;   /* reader.go processSOF: h, v in {1, 2, 4}, luminance v == 4 unsupported */
             }
             *wd = W; *ht = H;
-            *ratio = ncomp == 1 ? -1 : (hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));     /* image.YCbCrSubsampleRatio; -1: image.Gray */
+            /* image.YCbCrSubsampleRatio (reader.go makeImg: 444, 422, 420, 440, 411, 410); -1: image.Gray */
+            *ratio = ncomp == 1 ? -1 : (hy == 4 ? (vy == 2 ? 5 : 4) : hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));
             if (!yp) return 1;
             const int msx = 8 * hy, msy = 8 * vy, mx = (W + msx - 1) / msx, my = (H + msy - 1) / msy, ys = msx * mx, cs = 8 * mx;
             jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};

@@ -496,7 +496,7 @@ def jpeg_encode(img: np.ndarray, quality: int, with_coefficients: bool = False):
 
 
 def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
-    """A baseline one- or three-component file (4:4:4, 4:2:2, 4:2:0, 4:4:0) -> (w, h, ratio, Y, Cb, Cr) MCU-padded planes as
+    """A baseline one- or three-component file (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) -> (w, h, ratio, Y, Cb, Cr) MCU-padded planes as
     reader.go would hold them [, coefficients]; ratio -1 and Cb = Cr = None: one component (image.Gray)."""
     buf = np.frombuffer(data, dtype=np.uint8)
     L = lib()
@@ -508,7 +508,7 @@ def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
     rc = L.orc_jpeg_decode_planes(bp, len(data), C.byref(w), C.byref(h), C.byref(ratio), None, None, None, None)
     if rc != 1:
         raise RuntimeError(f"orc_jpeg_decode_planes: {rc}")
-    hy, vy = {-1: (1, 1), 0: (1, 1), 1: (2, 1), 2: (2, 2), 3: (1, 2)}[ratio.value]
+    hy, vy = {-1: (1, 1), 0: (1, 1), 1: (2, 1), 2: (2, 2), 3: (1, 2), 4: (4, 1), 5: (4, 2)}[ratio.value]
     mx, my = (w.value + 8 * hy - 1) // (8 * hy), (h.value + 8 * vy - 1) // (8 * vy)
     y = np.empty((8 * vy * my, 8 * hy * mx), dtype=np.uint8)
     cb = np.empty((8 * my, 8 * mx), dtype=np.uint8)

@@ -97,6 +97,27 @@ def test_oracle_decoder_reads_422_440_and_grey_files():
     assert orc.jpeg_decode_planes(grey)[2] == -1
 
 
+def test_oracle_decoder_reads_411_and_410_files():
+    """luminance 4 x 1 and 4 x 2 (image.YCbCrSubsampleRatio411 / 410; reader.go takes h in {1, 2, 4}, v in {1, 2}): files from
+    tests/jpeg_mini.py, checked against libjpeg, which replicates such chroma as Go does (no smoothing: within the IDCTs'
+    and the colour conversions' rounding)"""
+    import jpeg_mini
+    src = _photo(203, 117, 3)
+    for (hy, vy, ratio) in ((4, 1, 4), (4, 2, 5)):
+        for rst in (0, 5):
+            data = jpeg_mini.encode(src, hy, vy, 85, rst)
+            got = orc.jpeg_decode(data)
+            d = np.abs(got[..., :3].astype(int) - _pil_decode(data).astype(int))
+            assert got.shape == (117, 203, 4) and d.mean() < 0.3 and d.max() <= 4, (hy, vy, rst, d.mean(), d.max())
+            w, h, r, y, cb, cr = orc.jpeg_decode_planes(data)
+            assert (w, h, r) == (203, 117, ratio) and y.shape == (8 * vy * ((117 + 8 * vy - 1) // (8 * vy)), 224) and cb.shape == (y.shape[0] // vy, 56)
+    # and the factors 1 and 2 from the same writer agree with what libjpeg wrote itself being decoded by the same code path
+    for (hy, vy) in ((1, 1), (2, 1), (2, 2), (1, 2)):
+        data = jpeg_mini.encode(src, hy, vy, 90)
+        d = np.abs(orc.jpeg_decode(data)[..., :3].astype(int) - _pil_decode(data).astype(int))
+        assert d.mean() < 1.3 and np.percentile(d, 99) <= 10
+
+
 @pytest.mark.parametrize("kw", [dict(quality=85, subsampling=2), dict(quality=60, subsampling=0), dict(quality=92, subsampling=2, optimize=True)])
 def test_oracle_decoder_reads_libjpeg_files(kw):
     src = _photo(203, 117, 3)
@@ -151,7 +172,9 @@ def test_segment_parser_answers_or_refuses_never_crashes():
     assert parse(_pil(src, quality=80, restart_marker_blocks=2)) == (96, 64)
     with pytest.raises(fennec_amd.FennecUnsupported):
         parse(_pil(src, quality=80, progressive=True))
-    for hv in (0x41, 0x42, 0x14, 0x31):                       # 4:1:1, 4:1:0 and friends
+    for hv in (0x41, 0x42):                                   # 4:1:1, 4:1:0: taken since r4 (the geometry is the header's)
+        assert parse(_with_luma_factors(good[0], hv)) == (96, 64)
+    for hv in (0x14, 0x31, 0x44, 0x24):                       # four down (image/jpeg refuses it too), three across
         with pytest.raises(fennec_amd.FennecUnsupported):
             parse(_with_luma_factors(good[0], hv))
     buf = io.BytesIO()
@@ -215,6 +238,26 @@ def test_gpu_decode_422_440_and_grey(ctx):
     data = _pil(_photo(640, 480, 2), quality=93, subsampling=1)
     out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
     assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94) and dims == (640, 480)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_411_and_410(ctx):
+    """ten blocks per MCU at 4:1:0: the slot tables, the block placement and the colour conversion at a 4:1 chroma step,
+    with and without restart intervals, odd sizes, and through the recompress entry"""
+    import jpeg_mini
+    for (w, h, seed) in ((203, 117, 3), (64, 16, 1), (33, 9, 2), (640, 480, 4)):
+        src = _photo(w, h, seed)
+        for (hy, vy) in ((4, 1), (4, 2)):
+            for rst in (0, 1, 7):
+                data = jpeg_mini.encode(src, hy, vy, 88, rst)
+                want = orc.jpeg_decode(data)
+                assert np.array_equal(ctx.jpeg_decode(data), want), (w, h, hy, vy, rst)
+                assert ctx.jpeg_decode_config(data) == (w, h)
+    src = _photo(320, 200, 6)
+    for (hy, vy) in ((4, 1), (4, 2)):
+        data = jpeg_mini.encode(src, hy, vy, 91)
+        out, q, sc, steps, dims = ctx.jpeg_recompress(data, 0.94)
+        assert (out, q, sc, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94) and dims == (320, 200)
 
 
 @pytest.mark.gpu
@@ -313,8 +356,9 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
         with pytest.raises(fennec_amd.FennecError) as e:
             ctx.jpeg_decode(bad)
         assert not isinstance(e.value, fennec_amd.FennecUnsupported)
-    with pytest.raises(fennec_amd.FennecUnsupported):
-        ctx.jpeg_decode(_with_luma_factors(_pil(src, quality=80, subsampling=2), 0x41))
+    for hv in (0x31, 0x14, 0x44):                      # three across; four down (image/jpeg refuses that too)
+        with pytest.raises(fennec_amd.FennecUnsupported):
+            ctx.jpeg_decode(_with_luma_factors(_pil(src, quality=80, subsampling=2), hv))
     buf = io.BytesIO()
     Image.fromarray(src, "RGBA").convert("CMYK").save(buf, "JPEG", quality=80)
     with pytest.raises(fennec_amd.FennecUnsupported):
