@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
 
     uint8_t *tw = s_t + wave * WT;
     // stage: chunk ids 0..303 = 16 rows x 19 chunks of 16 bytes (px x0 - 6 .. x0 + 69); thread tid takes id tid and, tid < 48, id 256 + tid
-    const int id1 = 256 + tid;
+    const int id1 = min(256 + tid, 16 * 19 - 1);                    // (lanes 48.. fetch the last chunk again and drop it: see hload)
     const int srow0 = tid / 19, sch0 = tid - 19 * srow0, srow1 = id1 / 19, sch1 = id1 - 19 * srow1;
     const bool two = tid < 48;
     const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
@@ -384,25 +384,25 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
     // clamped where a set leaves the image) and the first / last strips (clamped px loads, masked stores)
     auto march = [&](auto xedget) {
         constexpr bool XEDGE = decltype(xedget)::value;
+        // Interior strips: every lane issues both loads of every set, rows clamped per lane, no branch anywhere -- a load under
+        // a branch (the few lanes of the second chunk, a set that touches the image's edge, the last sets of the march)
+        // makes the compiler wait for ALL outstanding loads at the joins, and the march then runs one set ahead, not two.
         auto hload = [&](int i, u32x4 (&d)[2]) {
             const int ys = y0 - 6 + 16 * i;
-            if (!XEDGE && ys >= 0 && ys + 16 <= a.h) {                  // uniform: no clamp in this set
-                const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - 6);
-                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
-                if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
+            if constexpr (!XEDGE) {
+                const uint8_t *sb = src + 4 * static_cast<ptrdiff_t>(x0 - 6);
+                const int ya = clampi(ys + srow0, 0, a.h - 1), yb = clampi(ys + srow1, 0, a.h - 1);   // clamp-to-edge (effects.go:174-178, 200-204)
+                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(ya) * a.sstride + 16 * sch0);
+                d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(yb) * a.sstride + 16 * sch1);
             } else {
     #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     if (k == 1 && !two) break;
-                    const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);   // clamp-to-edge (effects.go:174-178, 200-204)
+                    const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);
                     const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
                     const int xc = x0 - 6 + 4 * (k ? sch1 : sch0);
-                    if constexpr (!XEDGE) {
-                        d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
-                    } else {
     #pragma unroll
-                        for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
-                    }
+                    for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
                 }
             }
         };
@@ -421,12 +421,14 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
         // step s: [stage write of H set s | store of V set s-3]  barrier  [H set s -> ring slot s&1 | V set s-1 -> out stage s&1]
         u32x4 ra[2], rb[2];
         hload(0, ra);
-        if (1 < NI) hload(1, rb);
+        __builtin_amdgcn_sched_barrier(0);                              // ra's loads first: the loop's vmcnt waits count on the order
+        hload(min(1, NI - 1), rb);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (SCORE) score_setup();
         auto step = [&](int s, u32x4 (&d)[2], auto oddv) {
             constexpr int par = decltype(oddv)::value ? 0 : 1;          // s & 1 (V set s-1 is odd when s is even)
             if (s < NI) stage_write(d, par);
-            if (s + 2 < NI) hload(s + 2, d);
+            if (XEDGE) { if (s + 2 < NI) hload(s + 2, d); } else hload(min(s + 2, NI - 1), d);
             if (s >= 3 && s - 3 < NJ) out_store(s - 3, par);           // written in step s-2 (same parity)
             __syncthreads();
             if (s < NI) hset(s, par, par);
@@ -522,9 +524,9 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
     const uint32_t sel01 = alane ? 0x0c0c0400u : 0x0c0c0703u, sel23 = alane ? 0x04000c0cu : 0x07030c0cu;
 
     uint8_t *tw = s_t + wave * WT;
-    const int id1 = 256 + tid;
+    const int id1 = min(256 + tid, 16 * NC - 1);                    // (lanes past the last chunk fetch it again and drop it: see hload)
     const int srow0 = tid / NC, sch0 = tid - NC * srow0, srow1 = id1 / NC, sch1 = id1 - NC * srow1;
-    const bool two = id1 < 16 * NC;
+    const bool two = 256 + tid < 16 * NC;
     const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
     const int st_r = r * SP + 64 * wave + 16 * g;                   // A operand of H set qq, K chunk kk: + 16 qq + 64 kk
     uint8_t *t_w = tw + r * P + 4 * g;                              // + (16 qq) P + 64 qq + 16 slot
@@ -644,12 +646,14 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
 
     auto march = [&](auto xedget) {
         constexpr bool XEDGE = decltype(xedget)::value;
+        // (interior strips: both loads of every set from every lane, rows clamped per lane, no branch -- blur_mfma_kernel's hload)
         auto hload = [&](int i, u32x4 (&d)[2]) {
             const int ys = y0 - RF + 16 * i;
-            if (!XEDGE && ys >= 0 && ys + 16 <= a.h) {
-                const uint8_t *sb = src + static_cast<ptrdiff_t>(ys) * a.sstride + 4 * static_cast<ptrdiff_t>(x0 - RF);
-                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow0) * a.sstride + 16 * sch0);
-                if (two) d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(srow1) * a.sstride + 16 * sch1);
+            if constexpr (!XEDGE) {
+                const uint8_t *sb = src + 4 * static_cast<ptrdiff_t>(x0 - RF);
+                const int ya = clampi(ys + srow0, 0, a.h - 1), yb = clampi(ys + srow1, 0, a.h - 1);
+                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(ya) * a.sstride + 16 * sch0);
+                d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(yb) * a.sstride + 16 * sch1);
             } else {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -657,12 +661,8 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                     const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);
                     const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
                     const int xc = x0 - RF + 4 * (k ? sch1 : sch0);
-                    if constexpr (!XEDGE) {
-                        d[k] = *(g_u32x4 *)(rowp + 4 * static_cast<ptrdiff_t>(xc));
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
-                    }
+                    for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
                 }
             }
         };
@@ -681,11 +681,13 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
         // step s: [stage write of H set s | store of V set s-5]  barrier  [H set s -> ring slot s&3 | V set s-3 -> out stage s&1]
         u32x4 ra[2], rb[2];
         hload(0, ra);
+        __builtin_amdgcn_sched_barrier(0);
         hload(1, rb);
+        __builtin_amdgcn_sched_barrier(0);
         auto step = [&](int s, u32x4 (&d)[2], auto part) {
             constexpr int par = decltype(part)::value;
             if (s < NI) stage_write(d, par);
-            if (s + 2 < NI) hload(s + 2, d);
+            if (XEDGE) { if (s + 2 < NI) hload(s + 2, d); } else hload(min(s + 2, NI - 1), d);
             if (s >= 5 && s - 5 < NJ) out_store(s - 5, par);
             __syncthreads();
             if (s < NI) hset(par, s & 3);
