@@ -5,6 +5,7 @@
 // separable moments with explicit fma -- both within 1e-9 of the reference's mean, whose own
 // summation order depends on GOMAXPROCS (ssim.go:84-94,155-160).
 #include "common.hpp"
+#include <type_traits>
 #include "devutil.hpp"
 
 #include <algorithm>
@@ -1207,101 +1208,111 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
     // the launch 139 -> 136 us -- the LDS queue still serves the older wave first, and a SIMD delivers about the same
     // rows per microsecond with one wave as with two (the bound is the chain write -> reads -> FMAs, not the arbiter).
     const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;   // HW_REG_HW_ID.WAVE_ID bit 0
-    for (int r = 0; r < nrows; r += 8) {
-        if (a.prio && (((r >> 3) ^ slot) & 1u) != 0) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+    // One row of the march.  Groups of eight full rows run WITHOUT a branch around the row (GUARD = false): with the
+    // wave-uniform "if (i < nrows)" around every unrolled row the compiler cannot tell how many loads are in flight at the
+    // joins and drains the queue (s_waitcnt vmcnt(0)) before each row's taps -- the four rows of prefetch were none
+    // (8K pair: 135 -> 131 us; the one-column kernel keeps its loop: the same change costs its 96-register form 22 spills).
+    auto rowbody = [&](const int r, auto pc, auto guardc) {
+        constexpr int p = decltype(pc)::value;
+        const int i = r + p;
+        if (decltype(guardc)::value && i >= nrows) return;        // wave-uniform
+            const double va0 = lum_milli(qa[p % WM_PF][0]), va1 = lum_milli(qa[p % WM_PF][1]);
+            const double vb0 = lum_milli(qb[p % WM_PF][0]), vb1 = lum_milli(qb[p % WM_PF][1]);
+            qa[p % WM_PF] = *(g_u32x2 *)pa;                   // no branch around the loads (see the one-column kernel)
+            qb[p % WM_PF] = *(g_u32x2 *)pb;
+            if (i + WM_PF + 1 < nrows) {
+                pa += a.astride;
+                pb += a.bstride;
+            }
+            s_e1[lane] = make_double2(va0, vb0);
+            s_o1[lane] = make_double2(va1, vb1);
+            s_e2[lane] = make_double2(fma(vb0, vb0, va0 * va0), va0 * vb0);
+            s_o2[lane] = make_double2(fma(vb1, vb1, va1 * va1), va1 * vb1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // pixel 2l + t: even t -> even[l + t / 2], odd t -> odd[l + t / 2].  Column 0's tap t is pixel 2l + t,
+            // column 1's tap t is pixel 2l + 1 + t.
+            double h00 = 0.0, h01 = 0.0, h02 = 0.0, h03 = 0.0, h10 = 0.0, h11 = 0.0, h12 = 0.0, h13 = 0.0;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int i = r + p;
-            if (i < nrows) {                                      // wave-uniform
-                const double va0 = lum_milli(qa[p % WM_PF][0]), va1 = lum_milli(qa[p % WM_PF][1]);
-                const double vb0 = lum_milli(qb[p % WM_PF][0]), vb1 = lum_milli(qb[p % WM_PF][1]);
-                qa[p % WM_PF] = *(g_u32x2 *)pa;                   // no branch around the loads (see the one-column kernel)
-                qb[p % WM_PF] = *(g_u32x2 *)pb;
-                if (i + WM_PF + 1 < nrows) {
-                    pa += a.astride;
-                    pb += a.bstride;
+            for (int q = 0; q < 9; q++) {                     // pixel 2l + q
+                const double2 u = (q & 1) ? s_o1[lane + q / 2] : s_e1[lane + q / 2];
+                const double2 v = (q & 1) ? s_o2[lane + q / 2] : s_e2[lane + q / 2];
+                if (q < 8) {
+                    const double c = a.col[q];
+                    h00 = fma(u.x, c, h00); h01 = fma(u.y, c, h01); h02 = fma(v.x, c, h02); h03 = fma(v.y, c, h03);
                 }
-                s_e1[lane] = make_double2(va0, vb0);
-                s_o1[lane] = make_double2(va1, vb1);
-                s_e2[lane] = make_double2(fma(vb0, vb0, va0 * va0), va0 * vb0);
-                s_o2[lane] = make_double2(fma(vb1, vb1, va1 * va1), va1 * vb1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // pixel 2l + t: even t -> even[l + t / 2], odd t -> odd[l + t / 2].  Column 0's tap t is pixel 2l + t,
-                // column 1's tap t is pixel 2l + 1 + t.
-                double h00 = 0.0, h01 = 0.0, h02 = 0.0, h03 = 0.0, h10 = 0.0, h11 = 0.0, h12 = 0.0, h13 = 0.0;
-#pragma unroll
-                for (int q = 0; q < 9; q++) {                     // pixel 2l + q
-                    const double2 u = (q & 1) ? s_o1[lane + q / 2] : s_e1[lane + q / 2];
-                    const double2 v = (q & 1) ? s_o2[lane + q / 2] : s_e2[lane + q / 2];
-                    if (q < 8) {
-                        const double c = a.col[q];
-                        h00 = fma(u.x, c, h00); h01 = fma(u.y, c, h01); h02 = fma(v.x, c, h02); h03 = fma(v.y, c, h03);
-                    }
-                    if (q >= 1) {
-                        const double c = a.col[q - 1];
-                        h10 = fma(u.x, c, h10); h11 = fma(u.y, c, h11); h12 = fma(v.x, c, h12); h13 = fma(v.y, c, h13);
-                    }
+                if (q >= 1) {
+                    const double c = a.col[q - 1];
+                    h10 = fma(u.x, c, h10); h11 = fma(u.y, c, h11); h12 = fma(v.x, c, h12); h13 = fma(v.y, c, h13);
                 }
-                __builtin_amdgcn_wave_barrier();                  // the row is consumed before the next one overwrites it
+            }
+            __builtin_amdgcn_wave_barrier();                  // the row is consumed before the next one overwrites it
 #pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const int k = (p - s) & 7;
-                    const double rk = a.row[k];
-                    if (k == 0) {
-                        m0[s][0] = h00 * rk; m0[s][1] = h01 * rk; m0[s][2] = h02 * rk; m0[s][3] = h03 * rk;
-                        m1[s][0] = h10 * rk; m1[s][1] = h11 * rk; m1[s][2] = h12 * rk; m1[s][3] = h13 * rk;
+            for (int s = 0; s < 8; s++) {
+                const int k = (p - s) & 7;
+                const double rk = a.row[k];
+                if (k == 0) {
+                    m0[s][0] = h00 * rk; m0[s][1] = h01 * rk; m0[s][2] = h02 * rk; m0[s][3] = h03 * rk;
+                    m1[s][0] = h10 * rk; m1[s][1] = h11 * rk; m1[s][2] = h12 * rk; m1[s][3] = h13 * rk;
+                } else {
+                    m0[s][0] = fma(h00, rk, m0[s][0]); m0[s][1] = fma(h01, rk, m0[s][1]);
+                    m0[s][2] = fma(h02, rk, m0[s][2]); m0[s][3] = fma(h03, rk, m0[s][3]);
+                    m1[s][0] = fma(h10, rk, m1[s][0]); m1[s][1] = fma(h11, rk, m1[s][1]);
+                    m1[s][2] = fma(h12, rk, m1[s][2]); m1[s][3] = fma(h13, rk, m1[s][3]);
+                }
+            }
+            if (i >= 7) {
+                const int s = (p + 1) & 7;
+                // numerator and denominator of one window's SSIM (ssim.go:150-155, scaled by 1e6 twice)
+                auto numden = [&](const double (&mm)[4], double &num, double &den) {
+                    const double muA = mm[0], muB = mm[1];
+                    const double mu2 = fma(muB, muB, muA * muA), muAB = muA * muB;
+                    const double sSum = mm[2] - mu2, sAB = mm[3] - muAB;
+                    num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
+                    den = (mu2 + C1) * (sSum + C2);
+                };
+                auto quot = [&](double num, double den) {
+                    double rc = __builtin_amdgcn_rcp(den);
+                    rc = fma(fma(-den, rc, 1.0), rc, rc);
+                    rc = fma(fma(-den, rc, 1.0), rc, rc);
+                    return num * rc;
+                };
+                // ONE division per four windows of a column: n1/d1 + ... + n4/d4 as a single fraction, built up as
+                // P <- P d + n Q, Q <- Q d (den <= 1.7e22, so Q stays below 1e89; every term is positive and the
+                // whole is a few ulp from the sum of the four quotients -- the bar is 1e-9).  v_rcp_f64 and its two
+                // Newton steps were 9 of the 21 instruction slots a window's score took.
+                double n0, d0, n1, d1;
+                numden(m0[s], n0, d0);
+                numden(m1[s], n1, d1);
+                if (r == 0) {                                 // the first ring fill: only p == 7 has a complete window
+                    val0 += quot(n0, d0);
+                    val1 += quot(n1, d1);
+                } else {
+                    if ((p & 3) == 0) {
+                        P0 = n0; Q0 = d0; P1 = n1; Q1 = d1;
                     } else {
-                        m0[s][0] = fma(h00, rk, m0[s][0]); m0[s][1] = fma(h01, rk, m0[s][1]);
-                        m0[s][2] = fma(h02, rk, m0[s][2]); m0[s][3] = fma(h03, rk, m0[s][3]);
-                        m1[s][0] = fma(h10, rk, m1[s][0]); m1[s][1] = fma(h11, rk, m1[s][1]);
-                        m1[s][2] = fma(h12, rk, m1[s][2]); m1[s][3] = fma(h13, rk, m1[s][3]);
+                        P0 = fma(P0, d0, n0 * Q0); Q0 *= d0;
+                        P1 = fma(P1, d1, n1 * Q1); Q1 *= d1;
                     }
-                }
-                if (i >= 7) {
-                    const int s = (p + 1) & 7;
-                    // numerator and denominator of one window's SSIM (ssim.go:150-155, scaled by 1e6 twice)
-                    auto numden = [&](const double (&mm)[4], double &num, double &den) {
-                        const double muA = mm[0], muB = mm[1];
-                        const double mu2 = fma(muB, muB, muA * muA), muAB = muA * muB;
-                        const double sSum = mm[2] - mu2, sAB = mm[3] - muAB;
-                        num = fma(2.0, muAB, C1) * fma(2.0, sAB, C2);
-                        den = (mu2 + C1) * (sSum + C2);
-                    };
-                    auto quot = [&](double num, double den) {
-                        double rc = __builtin_amdgcn_rcp(den);
-                        rc = fma(fma(-den, rc, 1.0), rc, rc);
-                        rc = fma(fma(-den, rc, 1.0), rc, rc);
-                        return num * rc;
-                    };
-                    // ONE division per four windows of a column: n1/d1 + ... + n4/d4 as a single fraction, built up as
-                    // P <- P d + n Q, Q <- Q d (den <= 1.7e22, so Q stays below 1e89; every term is positive and the
-                    // whole is a few ulp from the sum of the four quotients -- the bar is 1e-9).  v_rcp_f64 and its two
-                    // Newton steps were 9 of the 21 instruction slots a window's score took.
-                    double n0, d0, n1, d1;
-                    numden(m0[s], n0, d0);
-                    numden(m1[s], n1, d1);
-                    if (r == 0) {                                 // the first ring fill: only p == 7 has a complete window
-                        val0 += quot(n0, d0);
-                        val1 += quot(n1, d1);
-                    } else {
-                        if ((p & 3) == 0) {
-                            P0 = n0; Q0 = d0; P1 = n1; Q1 = d1;
-                        } else {
-                            P0 = fma(P0, d0, n0 * Q0); Q0 *= d0;
-                            P1 = fma(P1, d1, n1 * Q1); Q1 *= d1;
-                        }
-                        if ((p & 3) == 3 || i == nrows - 1) {     // wave-uniform
-                            val0 += quot(P0, Q0);
-                            val1 += quot(P1, Q1);
-                        }
+                    if ((p & 3) == 3 || i == nrows - 1) {     // wave-uniform
+                        val0 += quot(P0, Q0);
+                        val1 += quot(P1, Q1);
                     }
                 }
             }
-        }
-    }
+    };
+    auto group = [&](const int r, auto guardc) {
+        if (a.prio && (((r >> 3) ^ slot) & 1u) != 0) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        rowbody(r, std::integral_constant<int, 0>{}, guardc); rowbody(r, std::integral_constant<int, 1>{}, guardc);
+        rowbody(r, std::integral_constant<int, 2>{}, guardc); rowbody(r, std::integral_constant<int, 3>{}, guardc);
+        rowbody(r, std::integral_constant<int, 4>{}, guardc); rowbody(r, std::integral_constant<int, 5>{}, guardc);
+        rowbody(r, std::integral_constant<int, 6>{}, guardc); rowbody(r, std::integral_constant<int, 7>{}, guardc);
+    };
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) group(r, std::false_type{});
+    if (r < nrows) group(r, std::true_type{});
     val = (live0 ? val0 : 0.0) + (live1 ? val1 : 0.0);
     }
     march_finish(a, z, item, items, val, s_red, &s_last);
