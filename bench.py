@@ -1161,6 +1161,8 @@ def other_workload_line(args, embedded: bool = False):
                                        "kernel runs its fp64 reference-order loops (VALU-bound); the step is 7-9 kernels per image (1-2 launches "
                                        "per resize, level 0 + level 1 in one pass, pyramid, boxes, windows, finish): see roofline_step for the "
                                        "whole step against SURVEY 8(d)'s 193.4 MB"}
+            if rank == 0:
+                out["roofline"]["photo_like"] = resize_photo_like(ctx, W, H)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_other(wl, W, H)
     if wl == "config5" and rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1278,6 +1280,41 @@ def committed_traffic_named(kernel_substr: str, tag: str):
         except Exception:
             continue
     return None
+
+
+def resize_photo_like(ctx, W, H):
+    """config 3's two resizes on content WITHOUT exact rounding ties (blurred noise): the kernel time of one call at a time, from
+    the library's own event pairs, after the timed region.  The 2:1 downscale takes resize_mfma_kernel (csrc/resize_mfma.hip) +
+    resize_fused_sparse_kernel here; on SURVEY 8(d)'s ramp it is handed back whole and the ctx goes back to resize_fused_kernel."""
+    import torch
+    import fennec_amd
+    from fennec_amd import synth
+    img = ctx.GaussianBlur(ctx.GaussianBlur(torch.from_numpy(synth.noise_image(W, H, 5)).cuda(), 2.0), 1.2)
+    small = ctx.lanczosResize(img, W // 2, H // 2)
+    ctx.sync()
+    res = {}
+    for name, (src, dw, dh) in (("down", (img, W // 2, H // 2)), ("up", (small, W, H))):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.15:
+            ctx.lanczosResize(src, dw, dh)
+            ctx.sync()
+        ctx.profile(fennec_amd.PROF_RESIZE)
+        ts = []
+        for _ in range(9):
+            ctx.lanczosResize(src, dw, dh)
+            t = 0.0
+            while True:
+                try:
+                    t += ctx.kernel_ms()
+                except fennec_amd.FennecError:
+                    break
+            ts.append(t)
+        ctx.profile(0)
+        ms = float(np.mean(ts))
+        S = 4.0 * (W * H + (W // 2) * (H // 2))
+        res[name] = {"kernel_ms": round(ms, 4), "GB/s": round(S / (ms * 1e-3) / 1e9, 1), "frac": round(S / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    res["note"] = "one call at a time (no other stream running), kernels only; algorithmic bytes = source + destination"
+    return res
 
 
 def cpu_baseline_other(wl: str, W: int, H: int) -> dict:

@@ -1417,6 +1417,7 @@ struct fnx_resize_plan {
     const double *d_aw = nullptr, *d_inv = nullptr;
     fnx::RzMfTable mf;               // resize_mfma.hip: the matrix form (mf.ok: covered)
     int mf_cool = 0;                 // H plans: calls left to skip the matrix kernel (it handed most of an image back)
+    int mf_cool_len = 32;            // half the length of the next such pause
 };
 
 namespace fnx {
@@ -1739,13 +1740,17 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
     // The matrix kernel first (resize_mfma.hip); resize_fused_sparse_kernel then redoes the tiles it gave up (translucent
     // or tie-dense regions).  When it gave up most of an image -- the count comes back through host-mapped memory, read
-    // here one call later -- the next 64 calls with this H plan skip it: a heuristic about cost, both kernels are exact.
+    // here one call later -- the next 64 .. 4096 calls with this H plan skip it: a heuristic about cost, both kernels are exact.
     bool use_mf = ph->mf.ok && pv->mf.ok;
     static const bool adapt = [] { const char *e = getenv("FNX_RM_ADAPT"); return !(e && e[0] == '0'); }();
     if (use_mf && adapt && ctx->rz_report && ctx->rz_last_gen != 0) {
         const unsigned long long repv = *reinterpret_cast<volatile unsigned long long *>(ctx->rz_report);
         if (static_cast<uint32_t>(repv >> 32) == ctx->rz_last_gen) {
-            if (ctx->rz_last_h == ph && 2 * (repv & 0xffffffffull) > ctx->rz_last_cells) ph->mf_cool = 64;
+            if (ctx->rz_last_h == ph) {
+                // 64 calls off, twice as many each time it happens again in a row (a stream of such images), up to 4096
+                if (2 * (repv & 0xffffffffull) > ctx->rz_last_cells) ph->mf_cool = ph->mf_cool_len = std::min(4096, 2 * ph->mf_cool_len);
+                else ph->mf_cool_len = 32;
+            }
             ctx->rz_last_gen = 0;
         }
     }
