@@ -92,7 +92,7 @@ def main() -> int:
     ap.add_argument("--blur-mode", default="fast", choices=["fast", "exact"],
                     help="fast (default): fp32 FMA blur, <= 1 LSB on <= 0.1 %% of samples (the tolerance north_star "
                          "allows); exact: the guarded kernel, blurred images bit-identical to the reference's")
-    ap.add_argument("--prewarm", type=float, default=PREWARM_S,
+    ap.add_argument("--prewarm", type=float, default=None,
                     help="seconds of untimed steps before the warm-up steps (GPU clock ramp; setup, not measurement)")
     ap.add_argument("--workers", type=int, default=0, help="config5: host worker threads per GPU (0 = min(8, cores))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,6 +120,8 @@ def main() -> int:
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
+    if args.prewarm is None:                # configs 3 and 4: the governor needs > 1 s of these lighter loads (see other_configs)
+        args.prewarm = 1.5 if args.workload in ("config3", "config4") else PREWARM_S
     if args.contexts is None:
         args.contexts = 4 if args.workload == "config3" else 1
     if args.threads is None:
@@ -571,7 +573,10 @@ def other_configs(args) -> dict:
             ("config5", dict(batch=16, steps=3, warmup=1, contexts=1, threads=1, device_decode=True))]
     for wl, over in plan:
         a = copy.copy(args)
-        a.workload, a.prewarm, a.no_cpu_baseline, a.no_extras = wl, 0.15, True, True
+        # pre-warm: configs 3 and 4 are light loads (many small kernels on a few streams) and the clock governor takes more
+        # than a second of THEM to settle -- measured in this position: 0.15 s -> 69.7 k MP/s, 0.6 s -> 67.4 k, 1.5 s -> 79.1 k
+        # for config 3, whatever ran before (r4; `--workload config3` alone: 67.7 k cold, 81.0 k right after a heavy run)
+        a.workload, a.prewarm, a.no_cpu_baseline, a.no_extras = wl, (0.15 if wl == "config5" else 1.5), True, True
         a.device_codec = a.device_search = False
         a.device_decode = False
         for k, v in over.items():
@@ -1121,6 +1126,7 @@ def other_workload_line(args, embedded: bool = False):
     }
     if wl in ("config3", "config4"):
         out["config"]["contexts_per_gpu"] = max(1, min(args.contexts, B))
+        out["config"]["prewarm"] = f"{args.prewarm} s of untimed steps before the {args.warmup} warm-up steps (GPU clock ramp)"
         out["config"]["host_threads_per_gpu"] = max(1, min(args.threads or args.contexts, args.contexts, B))
         out["roofline_step"] = out["roofline"]
         S_img = 4.0 * W * H
