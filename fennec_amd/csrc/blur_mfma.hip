@@ -77,28 +77,26 @@ __device__ __forceinline__ int mf_comb3(int hi, int mid, int lo)
 
 // One flagged sample again, in the reference's own arithmetic (effects.go:169-217): acc = acc + float64(p) * w, taps ascending,
 // clampF.  Always 13 taps: the table holds the caller's weights centred in the radius-6 frame with zeros around them, and
-// adding p * 0.0 = +0.0 to the non-negative running sum leaves it as it is.  Out of line (eight call sites), and every byte
-// is fetched before the first use: read one by one inside the hot loop the 13 LDS round trips made one flagged sample
-// cost its workgroup a whole 16-row step (the four waves meet at a barrier every step).
-// H: the staged source bytes (p ^ 0x80) at p[4 t]; V: the ring's bytes (t ^ 0x80) at p[(ring0 + t) & 31].
-__device__ __noinline__ uint32_t mf_exact_h(const uint8_t *p, const double *wd)
+// adding p * 0.0 = +0.0 to the non-negative running sum leaves it as it is.  H: the staged source bytes (p ^ 0x80) at
+// base[4 t]; V: the ring's bytes at base[(ring0 + t) & 31].
+// UNIFORM: the whole wave recomputes ONE flagged sample -- the 13 weights (padded to 16 with zeros) arrive through the scalar
+// cache (two s_load, one wait), the bytes are LDS broadcasts from base[((ring0 + t) & mask) * step].  No call, no per-lane
+// weight loads: the out-of-line per-lane version this replaces cost 20 VGPRs and ~1.5 us of a wave per sample (the other three
+// waves of the workgroup standing at the barrier meanwhile); resize_mfma.hip's fix-ups work the same way.
+typedef int mf_s16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ uint32_t mf_exact_u(const double *wd, const uint8_t *base, int step, int ring0, int mask)
 {
+    mf_s16i w0, w1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w0), "=&s"(w1) : "s"(wd) : "memory");
     uint32_t v[13];
 #pragma unroll
-    for (int t = 0; t < 13; t++) v[t] = p[4 * t];
+    for (int t = 0; t < 13; t++) v[t] = base[((ring0 + t) & mask) * step];
     double acc = 0;
 #pragma unroll
-    for (int t = 0; t < 13; t++) acc = acc + u8_to_f64(v[t] ^ 0x80u) * wd[t];
-    return clampF_dev(acc);
-}
-__device__ __noinline__ uint32_t mf_exact_v(const uint8_t *p, int ring0, const double *wd)
-{
-    uint32_t v[13];
-#pragma unroll
-    for (int t = 0; t < 13; t++) v[t] = p[(ring0 + t) & 31];
-    double acc = 0;
-#pragma unroll
-    for (int t = 0; t < 13; t++) acc = acc + u8_to_f64(v[t] ^ 0x80u) * wd[t];
+    for (int t = 0; t < 13; t++) {
+        const int lo = t < 8 ? w0[2 * (t & 7)] : w1[2 * (t & 7)], hi = t < 8 ? w0[2 * (t & 7) + 1] : w1[2 * (t & 7) + 1];
+        acc = acc + u8_to_f64(v[t] ^ 0x80u) * __hiloint2double(hi, lo);
+    }
     return clampF_dev(acc);
 }
 
@@ -201,8 +199,6 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
 
     // ---- exact recomputation of flagged samples (GUARD), the reference's own arithmetic (effects.go:169-217) ----
     const double *wd = reinterpret_cast<const double *>(a.tab + 3 * 64 * 4 + 3 * 64 * 2);   // 13 fp64 weights, centred
-    auto exact_h = [&](const uint8_t *sb, int row, int px, int c) -> uint32_t { return mf_exact_h(sb + row * SP + 4 * px + c, wd); };
-    auto exact_v = [&](int cl, int grp, int ring0) -> uint32_t { return mf_exact_v(tw + cl * P + 64 * grp, ring0, wd); };
 
     auto stage_write = [&](const u32x4 (&d)[2], int buf) {
         uint8_t *sb = s_stage + buf * 16 * SP;
@@ -290,11 +286,18 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
                 for (int qq = 0; qq < 4; qq++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[qq][k]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * qq + k);
-                while (fl) {
-                    const int b = __builtin_ctz(fl), qq = b >> 2, k = b & 3;
-                    fl &= fl - 1;
-                    const uint32_t e = exact_h(sbuf, 4 * g + k, 16 * wave + 4 * qq + (r >> 2), r & 3) ^ 0x80u;
-                    *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(fl != 0);
+                while (todo) {                                                       // wave-uniform: one sample at a time, all lanes on it
+                    const int L = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    uint32_t flL = __builtin_amdgcn_readlane(fl, L);
+                    const int rL = L & 15, gL = L >> 4;
+                    while (flL) {
+                        const int b = __builtin_ctz(flL), qq = b >> 2, k = b & 3;
+                        flL &= flL - 1;
+                        const uint32_t e = mf_exact_u(wd, sbuf + (4 * gL + k) * SP + 4 * (16 * wave + 4 * qq + (rL >> 2)) + (rL & 3), 4, 0, 0xffff) ^ 0x80u;
+                        if (lane == L) *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                    }
                 }
             }
         }
@@ -359,10 +362,18 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
                 for (int q = 0; q < 4; q++)
 #pragma unroll
                     for (int i = 0; i < 3; i++) fl |= ((static_cast<uint32_t>(u[q][i]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * q + i);
-                while (fl) {
-                    const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
-                    fl &= fl - 1;
-                    op[4 * q + i] = static_cast<uint8_t>(exact_v(16 * g + 4 * q + i, g, (ODD ? 16 : 0) + r));
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(fl != 0);
+                while (todo) {
+                    const int L = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    uint32_t flL = __builtin_amdgcn_readlane(fl, L);
+                    const int rL = L & 15, gL = L >> 4;
+                    while (flL) {
+                        const int b = __builtin_ctz(flL), q = b >> 2, i = b & 3;
+                        flL &= flL - 1;
+                        const uint32_t e = mf_exact_u(wd, tw + (16 * gL + 4 * q + i) * P + 64 * gL, 1, (ODD ? 16 : 0) + rL, 31);
+                        if (lane == L) op[4 * q + i] = static_cast<uint8_t>(e);
+                    }
                 }
                 if constexpr (SCORE) o = *reinterpret_cast<const u32x4 *>(op);       // the box sums are those of the exact image
             }
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
 constexpr int MF_RWIDE = 24;         // blur_mfma_wide_kernel: 16 + 2 R <= the 64 rows of one V instruction
 struct MfmaWeights {
     long long wq[2 * MF_RWIDE + 1];
-    double err255;                // 255 * sum |wq[k] - w[k] 2^24|: bound of |S - exact sum * 2^24|
+    double err255;                // 255 * max(sum of the positive, sum of the negative wq[k] - w[k] 2^24): bound of |S - exact sum * 2^24|
 };
 static bool mfma_quantise(const double *kernel, int radius, MfmaWeights *q, int rmax = MF_RMAX)
 {
@@ -729,9 +740,14 @@ static bool mfma_quantise(const double *kernel, int radius, MfmaWeights *q, int 
     }
     q->wq[radius] += 16777216 - tot;
     if (q->wq[radius] < 0 || q->wq[radius] > 8355711) return false;
-    long double e = 0;
-    for (int i = 0; i < nt; i++) e += fabsl(static_cast<long double>(q->wq[i]) - static_cast<long double>(kernel[i]) * 16777216.0L);
-    q->err255 = static_cast<double>(255.0L * e);
+    // S - (exact sum) 2^24 = sum_k (wq[k] - w[k] 2^24) p[k] with 0 <= p[k] <= 255: between -255 (sum of the negative
+    // differences) and +255 (sum of the positive ones) -- half of 255 sum |.| when the differences cancel, as they nearly do
+    long double ep = 0, en = 0;
+    for (int i = 0; i < nt; i++) {
+        const long double d = static_cast<long double>(q->wq[i]) - static_cast<long double>(kernel[i]) * 16777216.0L;
+        if (d > 0) ep += d; else en -= d;
+    }
+    q->err255 = static_cast<double>(255.0L * std::max(ep, en));
     return true;
 }
 static void mfma_digits(long long v, int d[3])
@@ -746,7 +762,7 @@ static void mfma_digits(long long v, int d[3])
 
 // device table: BH[3][64] x 16 bytes (digits hi, mid, lo) | BV[3][64] x 8 | 13 fp64 weights
 constexpr size_t MF_TAB_WORDS = 3 * 64 * 4 + 3 * 64 * 2;
-constexpr size_t MF_TAB_ALL = MF_TAB_WORDS + 2 * (2 * MF_RMAX + 1);   // + the fp64 weights
+constexpr size_t MF_TAB_ALL = MF_TAB_WORDS + 2 * 16;   // + the fp64 weights: 13, padded to 16 with zeros (mf_exact_u's two s_load_dwordx16)
 static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
 {
     std::fill(tab, tab + MF_TAB_WORDS, 0u);

@@ -142,8 +142,9 @@ int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
  * not alias src (the flat-copy pass rewrites dst after the filter). */
 /* The fixed-point form the matrix-pipe kernel (csrc/blur_mfma.hip) gives a GaussianBlur table (effects.go:153-165), for
  * callers and tests that want to reason about it: wq[k] = round(kernel[k] * 2^24) with the centre tap taking what is left
- * of 2^24 (so sum wq == 2^24 exactly), and *err255 = 255 * sum |wq[k] - kernel[k] * 2^24| -- the largest distance, in units
- * of 2^-24, between the integer sum sum wq[k] * p[k] and the real sum sum kernel[k] * p[k] * 2^24 over bytes p.  A sample
+ * of 2^24 (so sum wq == 2^24 exactly), and *err255 = 255 * max(P, N), P / N the sums of the positive / negative differences
+ * wq[k] - kernel[k] * 2^24 -- the largest distance, in units of 2^-24, between the integer sum sum wq[k] * p[k] and the real
+ * sum sum kernel[k] * p[k] * 2^24 over bytes 0 <= p <= 255.  A sample
  * whose (sum + 2^23) mod 2^24 lies at least ceil(*err255) + 2 away from 0 and from 2^24 rounds to the same byte as the
  * reference's clampF of its fp64 chain; the others are recomputed in fp64 (FNX_BLUR_EXACT).  Host arithmetic only, no
  * device.  FNX_NOOP: the table is not that kernel's (radius outside 1..6, a negative or >= 0.49 weight, sum != 1). */
