@@ -83,11 +83,18 @@ __device__ __forceinline__ int mf_comb3(int hi, int mid, int lo)
 // cache (two s_load, one wait), the bytes are LDS broadcasts from base[((ring0 + t) & mask) * step].  No call, no per-lane
 // weight loads: the out-of-line per-lane version this replaces cost 20 VGPRs and ~1.5 us of a wave per sample (the other three
 // waves of the workgroup standing at the barrier meanwhile); resize_mfma.hip's fix-ups work the same way.
+// a wave-uniform pointer the compiler may hold in VGPRs, moved to SGPRs for the s_load's of the fix-ups
+__device__ __forceinline__ const double *mf_scalar_ptr(const double *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<const double *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
 typedef int mf_s16i __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t mf_exact_u(const double *wd, const uint8_t *base, int step, int ring0, int mask)
 {
     mf_s16i w0, w1;
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w0), "=&s"(w1) : "s"(wd) : "memory");
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w0), "=&s"(w1) : "s"(mf_scalar_ptr(wd)) : "memory");
     uint32_t v[13];
 #pragma unroll
     for (int t = 0; t < 13; t++) v[t] = base[((ring0 + t) & mask) * step];
@@ -480,6 +487,7 @@ template <int NKH> struct MfWide {
     static constexpr int WT = 64 * P + 256;
 };
 
+// per-lane, out of line: what the widest tables keep (NKH >= 3: 37+ taps; inlined uniform chains of that length did not pay)
 template <int NT>
 __device__ __noinline__ uint32_t mf_exact_h_n(const uint8_t *p, const double *wd)
 {
@@ -494,6 +502,25 @@ __device__ __noinline__ uint32_t mf_exact_v_n(const uint8_t *p, int ring0, const
     double acc = 0;
 #pragma unroll 15
     for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[(ring0 + t) & 63] ^ 0x80u) * wd[t];
+    return clampF_dev(acc);
+}
+
+// mf_exact_u for NT taps (the table is padded with zeros to a multiple of 8 doubles): eight weights per s_load
+template <int NT>
+__device__ __forceinline__ uint32_t mf_exact_u_n(const double *wd, const uint8_t *base, int step, int ring0, int mask)
+{
+    double acc = 0;
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += 8) {
+        mf_s16i w;
+        asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(w) : "s"(mf_scalar_ptr(wd)), "n"(8 * t0) : "memory");
+        uint32_t v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = base[((ring0 + t0 + min(t, NT - 1 - t0)) & mask) * step];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t0 + t < NT) acc = acc + u8_to_f64(v[t] ^ 0x80u) * __hiloint2double(w[2 * t + 1], w[2 * t]);
+    }
     return clampF_dev(acc);
 }
 
@@ -595,11 +622,26 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                 for (int qq = 0; qq < 4; qq++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[qq][k]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * qq + k);
-                while (fl) {
-                    const int b = __builtin_ctz(fl), qq = b >> 2, k = b & 3;
-                    fl &= fl - 1;
-                    const uint32_t e = mf_exact_h_n<NT>(sbuf + (4 * g + k) * SP + 4 * (16 * wave + 4 * qq + (r >> 2)) + (r & 3), wd) ^ 0x80u;
-                    *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                if constexpr (NKH > 2) {
+                    while (fl) {
+                        const int b = __builtin_ctz(fl), qq = b >> 2, k = b & 3;
+                        fl &= fl - 1;
+                        const uint32_t e = mf_exact_h_n<NT>(sbuf + (4 * g + k) * SP + 4 * (16 * wave + 4 * qq + (r >> 2)) + (r & 3), wd) ^ 0x80u;
+                        *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                    }
+                }
+                unsigned long long todo = NKH > 2 ? 0ull : __builtin_amdgcn_ballot_w64(fl != 0);
+                while (todo) {                                       // wave-uniform (blur_mfma_kernel's fix-ups)
+                    const int L = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    uint32_t flL = __builtin_amdgcn_readlane(fl, L);
+                    const int rL = L & 15, gL = L >> 4;
+                    while (flL) {
+                        const int b = __builtin_ctz(flL), qq = b >> 2, k = b & 3;
+                        flL &= flL - 1;
+                        const uint32_t e = mf_exact_u_n<NT>(wd, sbuf + (4 * gL + k) * SP + 4 * (16 * wave + 4 * qq + (rL >> 2)) + (rL & 3), 4, 0, 0xffff) ^ 0x80u;
+                        if (lane == L) *(t_w + (16 * qq) * P + 64 * qq + 16 * slot + k) = static_cast<uint8_t>(e);
+                    }
                 }
             }
         }
@@ -646,10 +688,25 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                 for (int q = 0; q < 4; q++)
 #pragma unroll
                     for (int i = 0; i < 3; i++) fl |= ((static_cast<uint32_t>(u[q][i]) & 0x00ffffffu) < static_cast<uint32_t>(a.thr) ? 1u : 0u) << (4 * q + i);
-                while (fl) {
-                    const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
-                    fl &= fl - 1;
-                    op[4 * q + i] = static_cast<uint8_t>(mf_exact_v_n<NT>(tw + (16 * g + 4 * q + i) * P + 64 * g, 16 * j + r, wd));
+                if constexpr (NKH > 2) {
+                    while (fl) {
+                        const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
+                        fl &= fl - 1;
+                        op[4 * q + i] = static_cast<uint8_t>(mf_exact_v_n<NT>(tw + (16 * g + 4 * q + i) * P + 64 * g, 16 * j + r, wd));
+                    }
+                }
+                unsigned long long todo = NKH > 2 ? 0ull : __builtin_amdgcn_ballot_w64(fl != 0);
+                while (todo) {
+                    const int L = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    uint32_t flL = __builtin_amdgcn_readlane(fl, L);
+                    const int rL = L & 15, gL = L >> 4;
+                    while (flL) {
+                        const int b = __builtin_ctz(flL), q = b >> 2, i = b & 3;
+                        flL &= flL - 1;
+                        const uint32_t e = mf_exact_u_n<NT>(wd, tw + (16 * gL + 4 * q + i) * P + 64 * gL, 1, 16 * j + rL, 63);
+                        if (lane == L) op[4 * q + i] = static_cast<uint8_t>(e);
+                    }
                 }
             }
         }
@@ -886,7 +943,7 @@ static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights
 {
     using C = MfWide<NKH>;
     constexpr int RF = C::RF;
-    constexpr size_t words = (3 * NKH + 3) * 64 * 4 + 2 * C::NT;
+    constexpr size_t words = (3 * NKH + 3) * 64 * 4 + 2 * ((C::NT + 7) / 8 * 8);   // (weights padded to whole s_load_dwordx16's)
     std::vector<uint32_t> tab(words, 0u);
     int8_t *bh = reinterpret_cast<int8_t *>(tab.data());
     int8_t *bv = bh + 3 * NKH * 64 * 16;
