@@ -19,10 +19,11 @@
 //    sets fetch it from the intermediate's alpha columns (effects.go:215: alpha comes from the ORIGINAL).
 //  * SCORE: lane (row, chunk) layouts ARE matrix A operands, so the box sums are two more matrix instructions per 16 x 16
 //    px block (B = 0/1 indicator of up to 5 box columns x RGB over the 64 bytes) and 4 + 4 LDS atomics on what is left.
-//  * GUARD (FNX_BLUR_EXACT): |S / 2^24 - exact sum| <= E = 255 * sum |wq[k] / 2^24 - w[k]| (computed per call).  A sample
-//    whose fraction lies within G >= E of the rounding boundary is recomputed in fp64 in the reference's tap order
-//    (effects.go:169-217), in place: with G ~ 1e-4 one 256-sample set in twenty takes that branch.  Everything else is
-//    proven equal to the reference's clampF, not sampled.
+//  * GUARD (FNX_BLUR_EXACT): S / 2^24 - exact sum lies in [-255 N, 255 P], N / P the sums of the negative / positive
+//    differences wq[k] / 2^24 - w[k] (computed per call).  A sample whose fraction lies within G >= max of the two of the
+//    rounding boundary is recomputed in fp64 in the reference's tap order (effects.go:169-217) and patched in place -- one
+//    sample at a time by the whole wave, weights through the scalar cache (mf_exact_u).  Everything else is proven equal
+//    to the reference's clampF, not sampled.
 //
 // Memory shape.  A workgroup (4 waves) owns a 64-px column strip of SEG rows and marches down it 16 rows per step.
 // Loads and stores are workgroup-wide through LDS stages -- 304 / 256 contiguous bytes per row and wave instruction: with
