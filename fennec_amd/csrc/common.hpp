@@ -299,7 +299,8 @@ struct RzMfTable {
     int NC = 0;                    // H tables: 16-byte chunks of a staged source row
     int ngroups = 0;               // H: groups of 4 outputs, 16 per 64-column strip; V: groups of 16 output rows
     int nmat = 0;                  // distinct matrices
-    int seed = 0, thr = 0;         // rounding seed + G, 2 G (units of 2^-22)
+    int S = 22;                    // fixed point of the weights: 2^22 or 2^23
+    int seed = 0, thr = 0;         // rounding seed + G, 2 G (units of 2^-S)
     void *blob = nullptr;          // device: matrices | per-group records | per-strip source offsets
     const void *mats = nullptr;
     const int32_t *meta = nullptr, *sbase = nullptr;

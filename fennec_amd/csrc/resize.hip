@@ -1795,7 +1795,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             FNX_HIP(hipMemcpy(cells_h.data(), ctx->rz_todo + 2, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
             size_t back = 0;
             for (uint32_t c : cells_h) back += c == ctx->rz_gen;
-            fprintf(stderr, "resize_mfma: NC %d, %d + %d matrices, G %d / %d, %zu of %zu tiles handed back\n", ph->mf.NC,
+            fprintf(stderr, "resize_mfma: S %d / %d, NC %d, %d + %d matrices, G %d / %d, %zu of %zu tiles handed back\n", ph->mf.S, pv->mf.S, ph->mf.NC,
                     ph->mf.nmat, pv->mf.nmat, ph->mf.thr / 2, pv->mf.thr / 2, back, cells);
             if (e[0] == '2') return prof_end(ctx);
         }

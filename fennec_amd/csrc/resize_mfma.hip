@@ -4,12 +4,13 @@
 // What the reference computes for an output whose window is opaque (every A = 255; resize.go:93-113 / 137-156):
 //     clampF(fl(r * inv)),  r = sum_k fl(R_k * aw_k),  aw_k = fl(255 w_k),  inv = fl(1 / sum_k aw_k)
 // whose value is within 1e-12 of X = sum_k R_k W_k, W_k = aw_k inv (a real number).  Here W_k becomes the integer
-// Wq_k ~ W_k 2^22, the roundings chosen so that sum_k Wq_k = 2^22 exactly (largest remainders), split into three signed
-// base-256 digits; the bytes go in as R - 128 (R ^ 0x80 read as int8), so
-//     u = sum_k Wq_k (R_k - 128) + 128 * 2^22 + 2^21 + G  =  X' 2^22 + 2^21 + G
-// is an EXACT int32 with -255 sum_k (W_k - Wq_k 2^-22)^+ <= X' - X <= 255 sum_k (Wq_k 2^-22 - W_k)^+ (0 <= R_k <= 255; the
-// host computes both per output; G >= the largest + 2 units).  The output byte is sat_u8(u >> 22) -- floor(X + 1/2)
-// clamped, clampF -- unless u's 22 fraction bits lie below 2 G: such a sample (one in ~5 000 on photographs) is recomputed
+// Wq_k ~ W_k 2^S (S = 23 where every |W_k| < 0.996, else 22), the roundings chosen so that sum_k Wq_k = 2^S exactly (largest
+// remainders), split into three signed base-256 digits; the bytes go in as R - 128 (R ^ 0x80 read as int8), so
+//     u = sum_k Wq_k (R_k - 128) + (128 + 64) 2^S + 2^(S-1) + G  =  (X' + 64) 2^S + 2^(S-1) + G
+// is an EXACT uint32 (X' + 64 in 0 .. 511: the host checks the negative lobes) with
+// -255 sum_k (W_k - Wq_k 2^-S)^+ <= X' - X <= 255 sum_k (Wq_k 2^-S - W_k)^+ (0 <= R_k <= 255; the host computes both per
+// output; G >= the largest + 2 units).  The output byte is sat_u8((u >> S) - 64) -- floor(X + 1/2) clamped, clampF --
+// unless u's S fraction bits lie below 2 G: such a sample (one in ~10 000 on photographs) is recomputed
 // in fp64 in the reference's own order and patched.  Proven, not sampled -- the rounding-guard argument of resize.hip with
 // an integer sum in place of fp32 FMAs.
 //
@@ -54,9 +55,10 @@ namespace fnx {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
-constexpr int RM_S = 22;                 // fixed point of the weights
-constexpr uint32_t RM_FRAC = (1u << RM_S) - 1;
+// (fixed point of the weights: 2^23 where every |W| stays below 0.996 -- three signed digits reach 0.498 * 2^24 --, else 2^22;
+// per table, RzMfTable::S)
 constexpr int RM_P = 80;                 // ring: 64 rows + 16 per column (blur_mfma_wide_kernel's)
 constexpr int RM_WT = 48 * RM_P + 192;   // per wave: 3 planes x 16 columns, each plane's group skewed by 64 bytes
 constexpr int RM_OP = 272;
@@ -87,6 +89,7 @@ struct RzMfArgs {
     const v4i *vmat;
     const RmV *vmeta;                    // per V group (16 output rows): first slot, last slot, matrix index
     int seed_h, thr_h, seed_v, thr_v;
+    int sh_h, sh_v;                      // S - 16 of each pass
     const RmEx *exh, *exv;               // per output: the reference's own operands for the fp64 fix-ups
     uint32_t *todo;
     unsigned *gave_up;                   // + 1 per workgroup that hands its region back
@@ -101,26 +104,30 @@ __device__ __forceinline__ int rm_comb3(int hi, int mid, int lo)
     return t * 256 + lo;
 }
 
-// sat_u8(x >> 22) of two sums: their high halves side by side, an arithmetic shift of both, a saturating pack
-__device__ __forceinline__ uint32_t rm_bytes2(int u1, int u0)
+// sat_u8((x >> S) - 64) of two sums u = (X + 64) 2^S + ... (unsigned: X + 64 is 0 .. 511): their high halves side by side, a
+// logical shift of both, the offset off, a saturating pack
+__device__ __forceinline__ uint32_t rm_bytes2(int u1, int u0, int sh)
 {
     const uint32_t hi = __builtin_amdgcn_perm(static_cast<uint32_t>(u1), static_cast<uint32_t>(u0), 0x07060302u);
-    v2s h;
+    v2us h;
     __builtin_memcpy(&h, &hi, 4);
-    h = h >> static_cast<short>(RM_S - 16);
+    h = h >> static_cast<unsigned short>(sh);
+    v2s hsg;
+    __builtin_memcpy(&hsg, &h, 4);
+    hsg = hsg - static_cast<short>(64);
     uint32_t hs, o;
-    __builtin_memcpy(&hs, &h, 4);
+    __builtin_memcpy(&hs, &hsg, 4);
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(o) : "v"(hs));
     return o;
 }
-__device__ __forceinline__ uint32_t rm_bytes4(const v4i &u)
+__device__ __forceinline__ uint32_t rm_bytes4(const v4i &u, int sh)
 {
-    return __builtin_amdgcn_perm(rm_bytes2(u[3], u[2]), rm_bytes2(u[1], u[0]), 0x05040100u);
+    return __builtin_amdgcn_perm(rm_bytes2(u[3], u[2], sh), rm_bytes2(u[1], u[0], sh), 0x05040100u);
 }
-__device__ __forceinline__ uint32_t rm_minfrac(const v4i &u)
+__device__ __forceinline__ uint32_t rm_minfrac(const v4i &u, uint32_t frac)
 {
-    const uint32_t f0 = static_cast<uint32_t>(u[0]) & RM_FRAC, f1 = static_cast<uint32_t>(u[1]) & RM_FRAC;
-    const uint32_t f2 = static_cast<uint32_t>(u[2]) & RM_FRAC, f3 = static_cast<uint32_t>(u[3]) & RM_FRAC;
+    const uint32_t f0 = static_cast<uint32_t>(u[0]) & frac, f1 = static_cast<uint32_t>(u[1]) & frac;
+    const uint32_t f2 = static_cast<uint32_t>(u[2]) & frac, f3 = static_cast<uint32_t>(u[3]) & frac;
     return min(min(min(f0, f1), f2), f3);
 }
 
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256, 3) void resize_mfma_kernel(RzMfArgs a)
     const int st_r = r * SP + hm.hb + 16 * g;                       // A operand of plane c: + 16 c SP
     const v4i sh = {a.seed_h, a.seed_h, a.seed_h, a.seed_h}, sv = {a.seed_v, a.seed_v, a.seed_v, a.seed_v};
     const v4i zero = {0, 0, 0, 0};
+    const uint32_t frac_h = (0x10000u << a.sh_h) - 1u, frac_v = (0x10000u << a.sh_v) - 1u;
 
     uint8_t *tw = s_t + wave * WT;
     int srow[NL], sch[NL], st_w[NL];
@@ -231,15 +239,15 @@ __global__ __launch_bounds__(256, 3) void resize_mfma_kernel(RzMfArgs a)
 #pragma unroll
             for (int k = 0; k < 4; k++) u[k] = rm_comb3(c2[k], c1[k], c0[k]);
             uint8_t *tp = t_w + 16 * c * P + 64 * c + 16 * slot;
-            *reinterpret_cast<uint32_t *>(tp) = rm_bytes4(u) ^ 0x80808080u;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(rm_minfrac(u) < static_cast<uint32_t>(a.thr_h));
+            *reinterpret_cast<uint32_t *>(tp) = rm_bytes4(u, a.sh_h) ^ 0x80808080u;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(rm_minfrac(u, frac_h) < static_cast<uint32_t>(a.thr_h));
             if (bal) {
                 if (__builtin_popcountll(bal) > RM_DENSE) {
                     s_bad[(it + 1) & 1] = 1;
                 } else {
                     uint32_t fl = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[k]) & RM_FRAC) < static_cast<uint32_t>(a.thr_h) ? 1u : 0u) << k;
+                    for (int k = 0; k < 4; k++) fl |= ((static_cast<uint32_t>(u[k]) & frac_h) < static_cast<uint32_t>(a.thr_h) ? 1u : 0u) << k;
                     unsigned long long todo = __builtin_amdgcn_ballot_w64(fl != 0);
                     while (todo) {
                         const int L = __builtin_ctzll(todo);
@@ -273,12 +281,12 @@ __global__ __launch_bounds__(256, 3) void resize_mfma_kernel(RzMfArgs a)
             v4i u;
 #pragma unroll
             for (int i = 0; i < 4; i++) u[i] = rm_comb3(c2[i], c1[i], c0[i]);
-            pl[c] = rm_bytes4(u);
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(rm_minfrac(u) < static_cast<uint32_t>(a.thr_v));
+            pl[c] = rm_bytes4(u, a.sh_v);
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(rm_minfrac(u, frac_v) < static_cast<uint32_t>(a.thr_v));
             if (bal) {
                 if (__builtin_popcountll(bal) > RM_DENSE) { s_bad[(it + 1) & 1] = 1; dense = true; }
 #pragma unroll
-                for (int i = 0; i < 4; i++) fl |= ((static_cast<uint32_t>(u[i]) & RM_FRAC) < static_cast<uint32_t>(a.thr_v) ? 1u : 0u) << (4 * c + i);
+                for (int i = 0; i < 4; i++) fl |= ((static_cast<uint32_t>(u[i]) & frac_v) < static_cast<uint32_t>(a.thr_v) ? 1u : 0u) << (4 * c + i);
             }
         }
         // [R0 R1 R2 R3] [G0 ..] [B0 ..] -> four RGBA px, A = 255 (resize.go:112: clampF(a), the host checked it)
@@ -451,7 +459,8 @@ bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double 
     // fixed-point weights per output
     std::vector<std::vector<long long>> wq(nout);
     std::vector<int> first(nout), cnt(nout);
-    long double emax = 0;
+    long double emax = 0, wmax = 0;
+    std::vector<std::vector<long double>> Wr(nout);
     for (int d = 0; d < nout; d++) {
         const int t0 = t.off[d], n = t.off[d + 1] - t0;
         if (n < 1 || n > RM_MAXTAPS) return false;
@@ -462,22 +471,36 @@ bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double 
         double a = 0;
         for (int k = 0; k < n; k++) a += 255.0 * t.wt[t0 + k];
         if (!(a >= 254.5) || !(a < 255.5)) return false;              // clampF(a) must be 255 (resize.go:112): the kernel writes that
+        Wr[d].resize(n);
+        long double neg = 0;
+        for (int k = 0; k < n; k++) {
+            Wr[d][k] = static_cast<long double>(255.0 * t.wt[t0 + k]) * static_cast<long double>(inv[d]);
+            wmax = std::max(wmax, fabsl(Wr[d][k]));
+            if (Wr[d][k] < 0) neg -= Wr[d][k];
+        }
+        if (255.0L * neg > 63.0L) return false;                       // the sums carry an offset of 64: X >= -64
+    }
+    const int S = wmax * 8388608.0L <= 8355000.0L ? 23 : 22;
+    const long double scale = ldexpl(1.0L, S);
+    const long long one = 1LL << S;
+    for (int d = 0; d < nout; d++) {
+        const int n = cnt[d];
         std::vector<long double> W(n);
         std::vector<std::pair<long double, int>> fr(n);
         long long tot = 0;
         wq[d].resize(n);
         for (int k = 0; k < n; k++) {
-            W[k] = static_cast<long double>(255.0 * t.wt[t0 + k]) * static_cast<long double>(inv[d]) * 4194304.0L;
+            W[k] = Wr[d][k] * scale;
             const long double f = floorl(W[k]);
             wq[d][k] = static_cast<long long>(f);
             fr[k] = {W[k] - f, k};
             tot += wq[d][k];
         }
-        const long long rem = 4194304 - tot;
+        const long long rem = one - tot;
         if (rem < 0 || rem > n) return false;
         std::sort(fr.begin(), fr.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
         for (long long i = 0; i < rem; i++) wq[d][fr[i].second] += 1;
-        // X' - X = sum_k (Wq_k - W_k 2^22) R_k 2^-22 with 0 <= R_k <= 255: between -255 (sum of the negative differences)
+        // X' - X = sum_k (Wq_k - W_k 2^S) R_k 2^-S with 0 <= R_k <= 255: between -255 (sum of the negative differences)
         // and +255 (sum of the positive ones)
         long double ep = 0, en = 0;
         for (int k = 0; k < n; k++) {
@@ -490,7 +513,8 @@ bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double 
     // G: the fixed-point bound, the reference's own fp64 chain (< 1e-11 = 4e-5 units) and two units for this arithmetic
     const long long gq = static_cast<long long>(ceill(emax)) + 2;
     if (gq > (1 << 14)) return false;
-    out->seed = static_cast<int>((128u << RM_S) + (1u << (RM_S - 1)) + static_cast<uint32_t>(gq));
+    out->S = S;
+    out->seed = static_cast<int>((192u << S) + (1u << (S - 1)) + static_cast<uint32_t>(gq));     // 128 (the bytes' offset) + 64 (the sums')
     out->thr = static_cast<int>(2 * gq);
 
     std::vector<RmEx> exv(nout);
@@ -656,6 +680,7 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
     a.vmat = static_cast<const v4i *>(v.mats);
     a.vmeta = reinterpret_cast<const RmV *>(v.meta);
     a.seed_h = h.seed; a.thr_h = h.thr; a.seed_v = v.seed; a.thr_v = v.thr;
+    a.sh_h = h.S - 16; a.sh_v = v.S - 16;
     a.exh = static_cast<const RmEx *>(h.ex); a.exv = static_cast<const RmEx *>(v.ex);
     if (getenv("FNX_RM_NOFIX")) a.thr_h = a.thr_v = 0;                 // experiments: no fix-ups (results may be off by one)
     a.todo = todo; a.gave_up = gave_up; a.gen = gen; a.old_tw = old_tw; a.old_th = old_th; a.old_gx = old_gx;
