@@ -70,6 +70,32 @@ def _dist_setup(torch, dist, local_rank, world):
     return dev, ("cuda" if backend == "nccl" else "cpu")
 
 
+def dist_identity(torch, dist, dev: int, rank: int, world: int) -> dict:
+    """Who took part: every rank's (rank, device ordinal, PCI bus id, uuid), all-gathered over the job's process group, so
+    that the line of an N-GPU run shows N ranks on N DIFFERENT devices.  Over RCCL the ids must be
+    distinct -- two ranks on one device is a launch error this run refuses to report a number for; the gloo test hook
+    (FENNEC_BENCH_SINGLE_DEVICE=1) shares GPU 0 on purpose and says so."""
+    props = torch.cuda.get_device_properties(dev)
+    bus = "%04x:%02x:%02x" % (int(getattr(props, "pci_domain_id", 0)), int(getattr(props, "pci_bus_id", -1) & 0xff if getattr(props, "pci_bus_id", -1) >= 0 else 0),
+                               int(getattr(props, "pci_device_id", 0)))
+    me = {"rank": rank, "device": dev, "pci": bus, "uuid": str(getattr(props, "uuid", "")), "name": props.name, "pid": os.getpid()}
+    seen = [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+    backend = dist.get_backend() if dist.is_initialized() else "none"
+    shared = os.environ.get("FENNEC_BENCH_SINGLE_DEVICE") == "1"
+    ids = [(s["pci"], s["uuid"]) for s in seen]
+    distinct = len(set(ids)) == len(ids)
+    if backend == "nccl" and not shared and not distinct:
+        raise RuntimeError(f"bench.py: {world} ranks but only {len(set(ids))} distinct devices: {seen}")
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world": world,
+            "rccl_ranks_seen": seen, "devices_distinct": distinct,
+            "shared_device_test_hook": shared,
+            "collectives": "barrier + MAX(elapsed) + SUM(Summarize partials): 3 small all-reduces per run, none on the data path"}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,8 +116,9 @@ def main() -> int:
                          "a second set of destinations) before step s's results are fetched (+7 %%; the default line "
                          "reports that rate as `pipelined`)")
     ap.add_argument("--blur-mode", default="fast", choices=["fast", "exact"],
-                    help="fast (default): fp32 FMA blur, <= 1 LSB on <= 0.1 %% of samples (the tolerance north_star "
-                         "allows); exact: the guarded kernel, blurred images bit-identical to the reference's")
+                    help="fast (default): 24-bit fixed-point weights on the i8 matrix pipe, exact integer sums: <= 1 LSB on "
+                         "<= 0.001 %% of samples (north_star allows a stated tolerance; the bar is 0.1 %%); exact: the same sums "
+                         "under a rounding guard + fp64 recomputation of the flagged samples, bit-identical to the reference's")
     ap.add_argument("--prewarm", type=float, default=None,
                     help="seconds of untimed steps before the warm-up steps (GPU clock ramp; setup, not measurement)")
     ap.add_argument("--workers", type=int, default=0, help="config5: host worker threads per GPU (0 = min(8, cores))")
@@ -305,24 +332,34 @@ def main() -> int:
         rest_ms = ms_per_step - blur_ms
         blur_bytes = 4.0 * S * nb0
         blur_gbs = blur_bytes / (blur_ms * 1e-3) / 1e9
-        mfma = os.environ.get("FNX_BLUR_MFMA", "1") != "0" and (not exact or os.environ.get("FNX_BLUR_MFMA_EXACT", "1") != "0")
+        route = pipe_ctx[0].last_kernel(fennec_amd.PROF_MAIN)       # what the library's dispatch launched, not what a switch suggests
+        mfma = route.startswith("blur_mfma_kernel")
         kname = "blur_mfma_kernel" if mfma else "blur_direct_kernel"
+        traffic = committed_traffic(kname, nb0, scored=True, exact=exact)
+        traffic_file = source_file("traffic")
         roofline = {
-            "kernel": (f"blur_mfma_kernel<SCORE{', GUARD' if exact else ''}> (GaussianBlur sigma=2 on the i8 matrix pipe + both boxDownsample sums of SSIMFast, "
+            "kernel": (f"{route} (GaussianBlur sigma=2 on the i8 matrix pipe + both boxDownsample sums of SSIMFast, "
                        f"one launch of {nb0} images)") if mfma else
-                      (f"blur_direct_kernel<R=6, SCORE, GUARD> (GaussianBlur sigma=2, guarded fp32 + fp64 fix-ups, + both boxDownsample "
+                      (f"{route} (GaussianBlur sigma=2, fp32 FMA{' under a rounding guard + fp64 fix-ups' if exact else ''}, + both boxDownsample "
                        f"sums of SSIMFast, one launch of {nb0} images)"),
+            "kernel_route": route,
             # achieved / peak / frac are SURVEY 8(d)'s HBM figures (the contract of this object).  The matrix-pipe kernel moves
             # 2.2 S per image at ~3.5 TB/s; the tiled-copy floor of its access shape (64-px column strips, read S + write S)
             # is ~13 us per 4K image on this part (experiments/mfma/pattern2.hip), the kernel takes ~19.5
-            "bound": "hbm" if mfma else "valu",
+            # `achieved` / `peak` / `frac` price SURVEY 8(d)'s algorithmic bytes against the HBM peak (the contract of this object).
+            # What the counters say BOUNDS the kernel is instruction issue: VALU + matrix + LDS instructions fill the SIMDs while
+            # the measured HBM rate (hbm_frac_measured: counter bytes / launch time / peak) is well under the peak.
+            "bound": "issue (VALU + i8 MFMA + LDS), priced against hbm" if mfma else "valu, priced against hbm",
+            "roofline_priced_against": "hbm",
             "achieved": round(blur_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
-            "traffic": committed_traffic(kname, nb0, scored=True, exact=exact),
-            "traffic_source": "profiles/*onepass*_traffic.json: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes of this command (committed; "
-                              "not measured in this run -- the driver's run has no profiler attached)",
+            "traffic": traffic,
+            "traffic_file": traffic_file,
+            "hbm_frac_measured": (round(traffic / (blur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+            "traffic_source": "the newest profiles/*_traffic.json holding this kernel instantiation (named in traffic_file): rocprofv3 --pmc FETCH_SIZE x 2 + "
+                              "WRITE_SIZE passes of this command (committed; not measured in this run -- the driver's run has no profiler attached)",
             "algorithmic_bytes_per_launch": blur_bytes,
             "algorithmic_bytes_note": "SURVEY 8(d): 4*S per image for GaussianBlur+SSIMFast; the one-pass kernel "
                                       "needs only 2*S of HBM traffic for it (see traffic)",
@@ -331,7 +368,8 @@ def main() -> int:
             "launch_ms_min_median_max": [round(float(np.min(kernel_ms)), 4), round(float(np.median(kernel_ms)), 4),
                                          round(float(np.max(kernel_ms)), 4)],
             "valu_issue_frac": committed_valu_issue(kname, blur_ms, scored=True, exact=exact),
-            "valu_issue_source": "SQ_ACTIVE_INST_VALU and the shader clock from profiles/*onepass*_sq_counters.txt (committed PMC pass) over THIS run's launch time",
+            "valu_issue_file": source_file("valu_issue"),
+            "valu_issue_source": "SQ_ACTIVE_INST_VALU and the shader clock from the newest profiles/*_sq_counters.txt holding this kernel (named in valu_issue_file; committed PMC pass) over THIS run's launch time",
             "avg_launch_how": "HIP events bound to the dispatch itself (hipExtLaunchKernelGGL start / stop events: the kernel packet's own "
                               "timestamps, no barrier packets on the stream), every launch of the timed region",
             "note": "the previous step's tail (box_from_slabs, windowed SSIM with its finish) runs on the ctx's second stream "
@@ -357,17 +395,20 @@ def main() -> int:
         blur_gbs = blur_bytes / (blur_ms * 1e-3) / 1e9
         ssim_bytes = 2.0 * S * nb0               # SSIMFast reads both full-size images once
         ssim_gbs = ssim_bytes / (ssim_ms * 1e-3) / 1e9
-        mfma = os.environ.get("FNX_BLUR_MFMA", "1") != "0" and (not exact or os.environ.get("FNX_BLUR_MFMA_EXACT", "1") != "0")
+        route = ctxs[0].last_kernel(fennec_amd.PROF_MAIN)
+        mfma = route.startswith("blur_mfma_kernel")
         kname = "blur_mfma_kernel" if mfma else "blur_direct_kernel"
         roofline = {
-            "kernel": f"{kname} (GaussianBlur sigma=2" + (" on the i8 matrix pipe" if mfma else "") + f", one launch of {nb0} images"
+            "kernel": f"{route} (GaussianBlur sigma=2" + (" on the i8 matrix pipe" if mfma else "") + f", one launch of {nb0} images"
                       + (", co-scheduled with the other context's SSIMFast kernels)" if nctx > 1 else ")"),
+            "kernel_route": route,
             "bound": "hbm",
             "achieved": round(blur_gbs, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(blur_gbs / HBM_PEAK_GBS, 4),
             "traffic": committed_traffic(kname, nb0, exact=exact),
+            "traffic_file": source_file("traffic"),
             "algorithmic_bytes_per_launch": blur_bytes,
             "avg_launch_ms": round(blur_ms, 4),
         }
@@ -545,6 +586,10 @@ def main() -> int:
         t_h = (time.perf_counter() - t_h) / 3
         out["pcie_inclusive"] = {"value": round(mp_per_image / t_h, 1), "unit": "MP/s", "ms_per_image": round(t_h * 1e3, 3),
                                  "note": "one context, pageable host buffers: 3 uploads + 1 download of 33 MB per image"}
+    if world > 1 or dist.is_initialized():
+        di = dist_identity(torch, dist, local_rank, rank, world)       # a collective: every rank calls it
+        di["queue"] = "config 2 (`value`): images sharded statically, no queue; `batch`: one dynamic queue for the job (store counter, chunks of 4 indices)"
+        out["dist"] = di
     if not args.no_batch:
         # BASELINE.json's second metric: CompressBatch images/s, at every N (all ranks take part: ONE queue for the job)
         ctx.profile(False)
@@ -1157,7 +1202,8 @@ def other_workload_line(args, embedded: bool = False):
                                "bound": "valu", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
                                "traffic": committed_traffic_named("windowed_ssim_march2_kernel", "config4"),
-                               "traffic_source": "profiles/*config4*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
+                               "traffic_file": source_file("traffic"),
+                               "traffic_source": "the newest profiles/*config4*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": len(kms["windowed_ssim"]),
                                "fp64_fma_floor_ms": round(win * 64 / 39.3e12 * 1e3, 4),
                                "note": "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown); "
@@ -1176,7 +1222,8 @@ def other_workload_line(args, embedded: bool = False):
                                "bound": "valu" if fused else "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
                                "traffic": committed_traffic_named("resize_fused_kernel" if fused else "resize_h_guard_kernel", "config3"),
-                               "traffic_source": "profiles/*config3*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
+                               "traffic_file": source_file("traffic"),
+                               "traffic_source": "the newest profiles/*config3*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4),
                                "launches_timed": len(kms[dom]),
                                "resize_kernels_ms": {k: round(v, 4) for k, v in means.items()},
@@ -1265,6 +1312,14 @@ def other_workload_line(args, embedded: bool = False):
     return out if rank == 0 else None
 
 
+_SOURCES: dict = {}          # which committed profile file the last committed_*() call read (newest round first)
+
+
+def source_file(kind: str):
+    """profiles/ file the last committed_traffic*() / committed_valu_issue() call took its number from (None: no file had it)"""
+    return _SOURCES.get(kind)
+
+
 def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = False, exact: bool = False):
     """Fraction of the chip's VALU issue slots the kernel fills: SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs; from the
     committed PMC pass of this same command) x 4 clocks / (1024 SIMDs x launch duration x shader clock).  The clock is
@@ -1285,6 +1340,7 @@ def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = Fa
                     clk = float(m.group(2)) * 1e3      # Hz
             if act is not None:
                 hz = clk or 2.1e9
+                _SOURCES["valu_issue"] = os.path.relpath(p, ROOT)
                 return round(act * 4.0 / (1024.0 * launch_ms * 1e-3 * hz), 4)
         except Exception:
             continue
@@ -1294,11 +1350,13 @@ def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = Fa
 def committed_traffic_named(kernel_substr: str, tag: str):
     """HBM bytes per launch of a kernel from profiles/*<tag>*_traffic.json (see committed_traffic); None if absent."""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{tag}*_traffic.json")), reverse=True):
+    _SOURCES["traffic"] = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{tag}*_traffic.json")), reverse=True):   # r05 before r04 ...
         try:
             t = json.load(open(p))
             for k, v in t["kernels"].items():
                 if kernel_substr in k:
+                    _SOURCES["traffic"] = os.path.relpath(p, ROOT)
                     return float(v["hbm_bytes_per_launch"])
         except Exception:
             continue
@@ -1423,11 +1481,14 @@ def committed_traffic(kernel_substr: str, batch: int, scored: bool = False, exac
     FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH doubled per the gfx950
     correction).  None when no profile of this batch size has been committed."""
     import glob
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+    _SOURCES["traffic"] = None
+    _SOURCES["valu_issue"] = _SOURCES.get("valu_issue")
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):          # r05 before r04 ...
         try:
             t = json.load(open(p))
             for k, v in t["kernels"].items():
                 if kernel_substr in k and _template_flags(k) == (scored, exact) and batch == int(t.get("images_per_launch", 32)):
+                    _SOURCES["traffic"] = os.path.relpath(p, ROOT)
                     return float(v["hbm_bytes_per_launch"])
         except Exception:
             continue

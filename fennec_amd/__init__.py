@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ctx_use_own_stream", i, [ctx])
         _sig(L, "fnx_ctx_profile", i, [ctx, i])
         _sig(L, "fnx_ctx_kernel_ms", i, [ctx, C.POINTER(C.c_float)])
+        _sig(L, "fnx_ctx_last_kernel", C.c_char_p, [ctx, i])
         _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
         _sig(L, "fnx_free", i, [ctx, C.c_void_p])
         _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
@@ -334,6 +335,14 @@ class Context:
         ms = C.c_float(0.0)
         self._chk(self._lib.fnx_ctx_kernel_ms(self._h, C.byref(ms)), "fnx_ctx_kernel_ms")
         return float(ms.value)
+
+    def last_kernel(self, prof_class: int = 1) -> str:
+        """The kernel this ctx's last call of a class (PROF_MAIN = GaussianBlur, PROF_SSIM, PROF_RESIZE) launched: the
+        route the library's dispatch really took (fnx_ctx_last_kernel); "" before the first such call."""
+        s = self._lib.fnx_ctx_last_kernel(self._h, int(prof_class))
+        if s is None:
+            raise FennecError("fnx_ctx_last_kernel: bad class")
+        return s.decode()
 
     @property
     def stream(self) -> int:

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import io
 import queue
+import collections
 import threading
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
@@ -109,7 +110,8 @@ class _RankQueue:
     store hands out the next `chunk` indices to whichever worker of whichever rank asks first, so a rank with slower
     items (or a slower GPU) simply takes fewer -- no data-path collective, one small TCP round trip per chunk."""
     _seq = 0
-    _uses: dict = {}
+    _uses: "collections.OrderedDict[str, int]" = collections.OrderedDict()   # per-process use count of each batch_id, newest last
+    _USES_CAP = 1024                                                          # ids remembered (a service minting a fresh id per job)
 
     def __init__(self, n_items: int, chunk: int = 1, group=None, batch_id: Optional[str] = None, world: Optional[int] = None):
         import torch.distributed as dist
@@ -129,8 +131,13 @@ class _RankQueue:
             # slow one has not left: it would read the exhausted counter, take nothing, and the slow rank's close() would
             # then wipe keys both jobs share.  The per-process use count keeps the jobs apart (every rank calls
             # compress_batch with the same id the same number of times -- the contract batch_id had already).
-            use = _RankQueue._uses.get(batch_id, 0) + 1
+            # CONTRACT: a rank that calls with an id k times must be matched by k calls on every other rank; a rank that
+            # retries a batch on its own (an exception mid-job) must mint a NEW id on all ranks, or it would build 'x#2'
+            # against the others' 'x#1' and drain that job alone.
+            use = _RankQueue._uses.pop(batch_id, 0) + 1
             _RankQueue._uses[batch_id] = use
+            while len(_RankQueue._uses) > _RankQueue._USES_CAP:     # ids are usually unique per job: forget the oldest
+                _RankQueue._uses.popitem(last=False)
             batch_id = f"{batch_id}#{use}"
         self.key = f"next_{batch_id}"
         self.store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())
@@ -167,7 +174,8 @@ def compress_batch(n_items: int, work: Callable[[int, object], BatchResult], mak
     queue_mode "static": the rank owns items i = rank (mod world) (shard_indices) -- no communication at all.
     queue_mode "dynamic" (world > 1, torch.distributed initialised): ONE queue for the whole job (_RankQueue), which
     is what batch.go's channel is to its goroutines; ranks return the items they happened to take, by index.  `batch_id`
-    names the job's counter in the store (see _RankQueue); `on_item` then reports the JOB's completed count against
+    names the job's counter in the store (see _RankQueue): every rank must call with the same id the same number of times
+    (a retry of a failed batch takes a new id on all ranks); `on_item` then reports the JOB's completed count against
     the job's total on every rank (one store round trip per item), in static mode the rank's own."""
     if n_items <= 0:
         return []

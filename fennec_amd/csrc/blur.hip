@@ -730,6 +730,8 @@ template <int R, int NTH, int IH, bool SCORE, bool GUARD = false>
 static int launch_direct_cfg(fnx_ctx *ctx, int n, FusedArgs &fa)
 {
     constexpr int TW = 64, RG = NTH / 32, TH = ((IH - 2 * R) / RG) * RG;
+    note_route(ctx, FNX_PROF_MAIN, SCORE ? (GUARD ? "blur_direct_kernel<SCORE, GUARD>" : "blur_direct_kernel<SCORE>")
+                                         : (GUARD ? "blur_direct_kernel<GUARD>" : "blur_direct_kernel"));
     fa.tiles_x = (fa.w + TW - 1) / TW;
     fa.tiles = fa.tiles_x * ((fa.h + TH - 1) / TH);
     dim3 grid(8 * ((fa.tiles + 7) / 8), n);
@@ -1031,6 +1033,7 @@ static int launch_generic(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
                           uint8_t *dst, uint8_t *const *dsts, int dstride)
 {
     const int nt = 2 * radius + 1;
+    note_route(ctx, FNX_PROF_MAIN, sizeof(T) == 8 ? "blur_pass_kernel<double> x 2" : "blur_pass_kernel<float> x 2");
     std::vector<T> hk(nt);
     for (int i = 0; i < nt; i++) hk[i] = static_cast<T>(kernel[i]);
     void *dk = nullptr;
@@ -1207,6 +1210,7 @@ static int launch_exact(fnx_ctx *ctx, int n, ExactArgs &ea)
     constexpr int TH = ((64 - 2 * R) / 4) * 4;
     ea.tiles_x = (ea.w + 63) / 64;
     ea.tiles = ea.tiles_x * ((ea.h + TH - 1) / TH);
+    note_route(ctx, FNX_PROF_MAIN, "blur_exact_kernel");
     hipLaunchKernelGGL((blur_exact_kernel<R>), dim3(8 * ((ea.tiles + 7) / 8), n), dim3(256), 0, ctx->stream, ea);
     FNX_HIP(hipGetLastError());
     return FNX_OK;

@@ -910,6 +910,8 @@ static int launch_mfma_cfg(fnx_ctx *ctx, int n, MfmaArgs &ma, size_t lds)
         if (!ev.stop) ev.stop = ctx->ev_blur[ctx->parity];
         ctx->blur_done = ev.stop;
     }
+    note_route(ctx, FNX_PROF_MAIN, SCORE ? (GUARD ? "blur_mfma_kernel<SCORE, GUARD>" : "blur_mfma_kernel<SCORE>")
+                                         : (GUARD ? "blur_mfma_kernel<GUARD>" : "blur_mfma_kernel"));
     hipExtLaunchKernelGGL((blur_mfma_kernel<SCORE, GUARD>), grid, dim3(256), lds, ctx->stream, ev.start, ev.stop, 0, ma);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
@@ -926,7 +928,11 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
     void *dt = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab, sizeof(tab), &dt));
     ma->tab = static_cast<const uint32_t *>(dt);
-    { const char *e = getenv("FNX_MFMA_DBG"); ma->dbg = e ? atoi(e) : 0; }
+#ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): bits 1 / 2 / 4 skip the box sums -- wrong scores
+    { static const int dbg = [] { const char *e = getenv("FNX_MFMA_DBG"); return e ? atoi(e) : 0; }(); ma->dbg = dbg; }
+#else
+    ma->dbg = 0;
+#endif
     ma->radius = radius;
     // G (units of 2^-24): the fixed-point error bound, the reference's own fp64 chain error (13 roundings below 256:
     // < 4e-13 = 7e-6 units) and one unit for the bound's own arithmetic
@@ -977,6 +983,7 @@ static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights
     dim3 grid(8 * ((ma.tiles + 7) / 8), n);
     LaunchEvents ev;
     FNX_TRY(prof_bind(ctx, FNX_PROF_MAIN, &ev));
+    note_route(ctx, FNX_PROF_MAIN, exact ? "blur_mfma_wide_kernel<GUARD>" : "blur_mfma_wide_kernel");
     if (exact) hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, true>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
     else hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, false>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
     FNX_HIP(hipGetLastError());

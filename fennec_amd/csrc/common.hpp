@@ -167,6 +167,9 @@ struct fnx_ctx {
     int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)
     hipEvent_t prof_ev[PROF_DEPTH][2] = {};
     int prof_head = 0, prof_count = 0, prof_open = -1;
+    // fnx_ctx_last_kernel: the kernel the last call of each class really launched (static strings), so that a report can
+    // name the route the library took instead of inferring it from environment switches
+    const char *route[8] = {"", "", "", "", "", "", "", ""};
 };
 
 struct fnx_prepared {
@@ -242,6 +245,12 @@ struct LaunchEvents {
 };
 int prof_bind(fnx_ctx *ctx, int cls, LaunchEvents *ev);
 int prof_begin(fnx_ctx *ctx, int cls = FNX_PROF_MAIN);
+inline void note_route(fnx_ctx *ctx, int cls, const char *kernel)      // cls: one FNX_PROF_* bit
+{
+    int i = 0;
+    while (i < 7 && !((cls >> i) & 1)) i++;
+    ctx->route[i] = kernel;
+}
 int prof_end(fnx_ctx *ctx);
 // Fetch n doubles from device memory into host memory (synchronises).
 int fetch_doubles(fnx_ctx *ctx, const double *dptr, double *host, int n);

@@ -12,8 +12,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) const u32x4 g_u32x4;
-typedef __attribute__((address_space(1))) u32x4 g_u32x4w;
+// 16-byte accesses at PIXEL alignment (4 bytes): image views may be pitched and windows start at any pixel, so the
+// global views say aligned(4) -- gfx950's global_load / store_dwordx4 need dword alignment only, and without the
+// attribute the compiler would be entitled to assume 16
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+typedef __attribute__((address_space(1))) const u32x4_a4 g_u32x4;
+typedef __attribute__((address_space(1))) u32x4_a4 g_u32x4w;
 typedef __attribute__((address_space(1))) const uint32_t g_u32;
 typedef __attribute__((address_space(1))) uint32_t g_u32w;
 

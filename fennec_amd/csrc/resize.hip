@@ -1789,7 +1789,9 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         ctx->rz_last_gen = ctx->rz_gen;
         ctx->rz_last_cells = static_cast<size_t>(mf_wgs);
         ctx->rz_last_h = ph;
-        if (const char *e = getenv("FNX_RM_STATS")) {                // development: how many tiles came back; "2": stop here
+#ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): "2" stops before the handed-back tiles are redone
+        static const char *const rm_stats = getenv("FNX_RM_STATS");
+        if (const char *e = rm_stats) {                              // how many tiles came back
             std::vector<uint32_t> cells_h(cells);
             FNX_HIP(hipStreamSynchronize(ctx->stream));
             FNX_HIP(hipMemcpy(cells_h.data(), ctx->rz_todo + 2, sizeof(uint32_t) * cells, hipMemcpyDeviceToHost));
@@ -1799,6 +1801,8 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
                     ph->mf.nmat, pv->mf.nmat, ph->mf.thr / 2, pv->mf.thr / 2, back, cells);
             if (e[0] == '2') return prof_end(ctx);
         }
+#endif
+        note_route(ctx, FNX_PROF_RESIZE, "resize_mfma_kernel + resize_fused_sparse_kernel");
         const dim3 sgrid(static_cast<unsigned>(std::min<size_t>(cells, static_cast<size_t>(2) * ctx->num_cus)));
         if (low) {
             hipLaunchKernelGGL((resize_fused_sparse_kernel<2, 32>), sgrid, dim3(256), 0, ctx->stream, fa);
@@ -1812,6 +1816,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         FNX_HIP(hipGetLastError());
         return prof_end(ctx);
     }
+    note_route(ctx, FNX_PROF_RESIZE, "resize_fused_kernel");
     if (low) {
         hipLaunchKernelGGL((resize_fused_kernel<2, 32>), grid, dim3(256), 0, ctx->stream, fa);
     } else {
@@ -1843,6 +1848,7 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
         ga.dense = p->d_dense; ga.s0 = p->d_s0; ga.cnt = p->d_cnt; ga.alpha = p->d_alpha;
         ga.off = p->d_off; ga.idx = p->d_idx; ga.wt = p->d_wt;
         ga.aw = p->d_aw; ga.inv = p->d_inv;
+        note_route(ctx, FNX_PROF_RESIZE, vertical ? "resize_v_guard_kernel" : "resize_h_guard_kernel");
         if (vertical) {
             if (hint && hint->valid) {                               // the H pass of this call left its verdicts
                 ga.hint = hint->cells; ga.hint_gx = hint->gx; ga.hint_gy = hint->gy; ga.hint_rows = hint->rows;
@@ -1882,6 +1888,7 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
         return prof_end(ctx);
     }
     // fp64 kernels of round 1
+    note_route(ctx, FNX_PROF_RESIZE, "fp64 resize kernels (round 1)");
     if (hint && !vertical) hint->valid = false;
     int rc;
     if (vertical) rc = launch_resize_v(ctx, src, sstride, srcW, srcH, p->d_off, p->d_idx, p->d_wt, dst, dstride, t.nout, p->contig_taps);

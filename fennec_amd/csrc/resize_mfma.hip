@@ -682,7 +682,9 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
     a.seed_h = h.seed; a.thr_h = h.thr; a.seed_v = v.seed; a.thr_v = v.thr;
     a.sh_h = h.S - 16; a.sh_v = v.S - 16;
     a.exh = static_cast<const RmEx *>(h.ex); a.exv = static_cast<const RmEx *>(v.ex);
-    if (getenv("FNX_RM_NOFIX")) a.thr_h = a.thr_v = 0;                 // experiments: no fix-ups (results may be off by one)
+#ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): no fix-ups, results may be off by one
+    { static const bool nofix = getenv("FNX_RM_NOFIX") != nullptr; if (nofix) a.thr_h = a.thr_v = 0; }
+#endif
     a.todo = todo; a.gave_up = gave_up; a.gen = gen; a.old_tw = old_tw; a.old_th = old_th; a.old_gx = old_gx;
     const dim3 grid(8 * ((a.tiles + 7) / 8));
     *workgroups = a.tiles;

@@ -480,6 +480,14 @@ int fnx_ctx_profile(fnx_ctx *ctx, int enable)
     return FNX_OK;
 }
 
+const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class)
+{
+    if (!ctx || prof_class <= 0 || prof_class > 128 || (prof_class & (prof_class - 1))) return nullptr;
+    int i = 0;
+    while (!((prof_class >> i) & 1)) i++;
+    return ctx->route[i];
+}
+
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms)
 {
     FNX_TRY(bind(ctx));

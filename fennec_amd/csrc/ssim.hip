@@ -1411,6 +1411,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         static const int prio = [] { const char *e = getenv("FNX_SSIM_PRIO"); return e ? atoi(e) : 1; }();
         ma.prio = prio;
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
+        note_route(ctx, FNX_PROF_SSIM, march2 ? "windowed_ssim_march2_kernel" : "windowed_ssim_march_kernel");
         if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else if (ctx->partial_slot >= 0) hipLaunchKernelGGL(windowed_ssim_march_kernel<true>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else hipLaunchKernelGGL(windowed_ssim_march_kernel<false>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
@@ -1429,6 +1430,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
             sa.count = static_cast<double>(ww) * static_cast<double>(wh);
             folded = true;
         }
+        note_route(ctx, FNX_PROF_SSIM, big ? "windowed_ssim_sep24_kernel" : "windowed_ssim_sep_kernel");
         if (big) hipLaunchKernelGGL(windowed_ssim_sep24_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         else hipLaunchKernelGGL((windowed_ssim_sep_kernel<WSS_TY, 256>), dim3(tiles, n), dim3(256), 0, ctx->stream, sa);
         FNX_HIP(hipGetLastError());
@@ -1437,6 +1439,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         wa.a = a; wa.b = b; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
         wa.astride = astride; wa.bstride = bstride; wa.w = w; wa.h = h; wa.window = d_window;
         wa.tiles_x = tiles_x; wa.tiles = tiles; wa.partial = static_cast<double *>(part);
+        note_route(ctx, FNX_PROF_SSIM, "windowed_ssim_kernel");
         hipLaunchKernelGGL(windowed_ssim_kernel, dim3(tiles, n), dim3(256), 0, ctx->stream, wa);
         FNX_HIP(hipGetLastError());
     }

@@ -120,6 +120,11 @@ int fnx_ctx_sync(fnx_ctx *ctx);
 #define FNX_PROF_JPEG 16   /* jpeg_block_kernel (fdct, quantise, dequantise, idct of every block) */
 int fnx_ctx_profile(fnx_ctx *ctx, int enable);
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
+/* The kernel the ctx's LAST call of one class (one FNX_PROF_* bit: MAIN = GaussianBlur, SSIM = the windowed kernel,
+ * RESIZE = lanczosResize) really launched, as a static string ("" before the first such call, NULL for a bad
+ * argument): which of the routes the dispatch took (matrix pipe, direct, generic; fused, two-pass ...).  Reporting
+ * only: bench.py names its roofline kernel with it.  No reference counterpart. */
+const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class);
 
 /* Device memory on the ctx's device (for FNX_DEVICE callers). */
 int fnx_malloc(fnx_ctx *ctx, size_t bytes, void **dptr);

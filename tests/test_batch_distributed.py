@@ -168,3 +168,46 @@ def test_dynamic_queue_single_rank_is_static():
     assert [r.Index for r in res] == list(range(20))
     with pytest.raises(ValueError):
         batch.compress_batch(3, _fake_work, lambda w: None, queue_mode="ring")
+
+
+def _rank_main_small(rank, world, port, n_items, chunk, out_q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = batch.compress_batch(n_items, _uneven_work, lambda w: rank, workers=2, rank=rank, world=world,
+                               queue_mode="dynamic", chunk=chunk, batch_id=f"small-{n_items}-{chunk}")
+    s = batch.summarize_distributed(res)
+    out_q.put((rank, ([(r.Index, r.Err is not None) for r in res], (s.Total, s.Succeeded, s.Failed, s.TotalSaved, s.AvgSSIM))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,chunk", [(7, 4), (7, 1), (1, 4), (3, 8)])
+def test_world_size_2_dynamic_queue_uneven_job_with_a_failing_item(orc, n_items, chunk):
+    """An uneven job: 7 items over 2 ranks in chunks of 4 (the second chunk is partial), item 3 fails (batch.go:100-106: the
+    error stays with its item, the batch goes on); 1 item for 2 ranks (one rank takes nothing and still joins Summarize);
+    a chunk larger than the job.  Every item exactly once, the failure counted once, the same summary on both ranks."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main_small, args=(r, 2, port, n_items, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    items = got[0][0] + got[1][0]
+    assert sorted(i for i, _ in items) == list(range(n_items))
+    assert [i for i, bad in items if bad] == ([3] if n_items > 3 else [])
+    allres = [(_fake_work(i, None) if i % 7 != 3 else batch.BatchResult(Index=i, Err="x", has_result=False)) for i in range(n_items)]
+    want = orc.summarize([r.Err is not None for r in allres], [r.has_result for r in allres],
+                         [r.OriginalSize for r in allres], [r.CompressedSize for r in allres], [r.SSIM for r in allres])
+    for r in range(2):
+        t, ok, bad, saved, avg = got[r][1]
+        assert (t, ok, bad, saved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
+        assert abs(avg - want["AvgSSIM"]) <= 1e-15 * 4

@@ -1192,6 +1192,17 @@ def test_ctx_profile_hook(ctx):
     ms_an = c.kernel_ms()
     assert 0.005 < ms_plain < ms_score < 5.0 and 0.001 < ms_an < 5.0
     c.profile(False)
+    # fnx_ctx_last_kernel: the route the dispatch took, not what an environment switch suggests
+    assert c.last_kernel(fennec_amd.PROF_MAIN) in ("blur_mfma_kernel", "blur_direct_kernel")
+    c.GaussianBlurSSIMFastBatch(d, 2.0)
+    assert "SCORE" in c.last_kernel(fennec_amd.PROF_MAIN)
+    c.GaussianBlur(d[0], 9.0); c.sync()                       # radius 27: beyond the matrix kernels
+    assert c.last_kernel(fennec_amd.PROF_MAIN).startswith("blur_pass_kernel")
+    assert c.last_kernel(fennec_amd.PROF_RESIZE) == ""
+    c.lanczosResize(d[0], 1920, 1080); c.sync()
+    assert c.last_kernel(fennec_amd.PROF_RESIZE).startswith("resize_")
+    with pytest.raises(fennec_amd.FennecError):
+        c.last_kernel(3)
     c.close()
 
 

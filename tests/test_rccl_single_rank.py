@@ -72,3 +72,8 @@ def test_bench_line_with_the_process_group_up():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["batch"]["summarize"]["Total"] == 24 and "RCCL" in line["batch"]["summarize"]["how"]
+    # the `dist` object: who took part, all-gathered over RCCL itself
+    d = line["dist"]
+    assert d["backend"].startswith("rccl") and d["world"] == 1 and d["devices_distinct"] is True
+    assert len(d["rccl_ranks_seen"]) == 1 and d["rccl_ranks_seen"][0]["rank"] == 0 and d["rccl_ranks_seen"][0]["device"] == 0
+    assert d["rccl_ranks_seen"][0]["pci"] and "queue" in d
