@@ -1120,6 +1120,88 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
             }
             nz0 = __builtin_amdgcn_readfirstlane(nz0);
             nz1 = __builtin_amdgcn_readfirstlane(nz1);
+            // The 2:1 form (NV == 4).  At an exact 2:1 ratio every output has the SAME twelve weights (its centre lies half way
+            // between two source pixels) and output 1 of a lane starts two pixels after output 0: W[i] for pixels 0..11, W[i - 2]
+            // for pixels 2..13, whatever the lane -- bar the few outputs at the image's edges whose tap lists are clamped.  A wave
+            // whose lanes agree (checked here against the staged table, bit for bit) runs its rows as straight-line code: the
+            // weights are scalar operands, no LDS read, no branch per tap, and the loop's loads run two rows ahead (the masked
+            // form below is a chain of small blocks the scheduler cannot overlap: PMC had it waiting 42 % of its wave-cycles).
+            // Lanes that disagree put their outputs on the workgroup's fix-up list (resize_exact_px, spread over all lanes).
+            constexpr int UT = 12, USH = 2;
+            bool uni = false;
+            uint64_t oddm = 0;
+            double W[UT] = {};
+            if constexpr (NV == 4) {
+                const uint64_t am = __ballot(active);
+                const int ref = __builtin_amdgcn_readfirstlane(__popcll(am) >> 1);
+#pragma unroll
+                for (int i = 0; i < UT; i++) {
+                    const double t = s_aw[i * 64 + ref];             // (one address for the wave: a broadcast)
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2loint(t)));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2hiint(t)));
+                    W[i] = __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+                }
+                bool same = true;
+#pragma unroll
+                for (int i = 0; i < NPX; i++) {
+                    const double e0 = i < UT ? W[i] : 0.0, e1 = (i >= USH && i < USH + UT) ? W[i - USH] : 0.0;
+                    same = same && s_aw[i * 64 + lane] == e0 && s_aw[(NPX + i) * 64 + lane] == e1;
+                }
+                oddm = __ballot(!same && active);
+                uni = __popcll(oddm) <= 6 && W[0] != 0.0;
+            }
+            if (uni) {                                              // wave-uniform
+                const bool odd = (oddm >> lane) & 1ull;
+                uint32_t tl = todo;                                 // rows whose loads have not been issued
+                auto next_row = [&](int fallback) {
+                    if (!tl) return fallback;
+                    const int yy = yw + __builtin_ctz(tl);
+                    tl &= tl - 1;
+                    return yy;
+                };
+                u32x4 ra[NV], rb[NV];
+                const int ya = next_row(yw);
+                load_row(ya, ra);
+                const int yb = next_row(ya);
+                load_row(yb, rb);
+                int ylast = yb;
+                while (todo) {
+                    const int y = yw + __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    u32x4 w[NV];
+#pragma unroll
+                    for (int q = 0; q < NV; q++) { w[q] = ra[q]; ra[q] = rb[q]; }
+                    ylast = next_row(ylast);
+                    load_row(ylast, rb);
+                    uint32_t andp = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < NV; q++) andp &= (w[q][0] & w[q][1]) & (w[q][2] & w[q][3]);
+                    uint32_t o0, o1;
+                    if (__all((andp >> 24) == 0xffu || !active)) {
+                        double rr0 = 0, gg0 = 0, bb0 = 0, rr1 = 0, gg1 = 0, bb1 = 0;
+#pragma unroll
+                        for (int i = 0; i < USH + UT; i++) {
+                            const uint32_t p = w[i / 4][i % 4];
+                            const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
+                            if (i < UT) { rr0 = rr0 + fr * W[i]; gg0 = gg0 + fg * W[i]; bb0 = bb0 + fb * W[i]; }
+                            if (i >= USH) { rr1 = rr1 + fr * W[i - USH]; gg1 = gg1 + fg * W[i - USH]; bb1 = bb1 + fb * W[i - USH]; }
+                        }
+                        o0 = clampF_fast64(rr0 * inv0) | (clampF_fast64(gg0 * inv0) << 8) | (clampF_fast64(bb0 * inv0) << 16) | ((ab & 0xffu) << 24);
+                        o1 = clampF_fast64(rr1 * inv1) | (clampF_fast64(gg1 * inv1) << 8) | (clampF_fast64(bb1 * inv1) << 16) | ((ab & 0xff00u) << 16);
+                    } else {
+                        o0 = resize_exact_px<false>(a, d0, y);
+                        o1 = resize_exact_px<false>(a, min(d0 + 1, a.nout - 1), y);
+                    }
+                    uint32_t *tp = trow + (y - r0) * RF_TW;
+                    if (!odd) {
+                        tp[0] = o0;
+                        tp[1] = o1;
+                    } else {                                        // (<= 6 lanes: within the list's bound of 7 lanes x 2 outputs per wave-row)
+                        s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(y - r0) << 8) | static_cast<uint32_t>(2 * lane);
+                        if (d0 + 1 < a.nout) s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(y - r0) << 8) | static_cast<uint32_t>(2 * lane + 1);
+                    }
+                }
+            }
             while (todo) {
                 const int y = yw + __builtin_ctz(todo);
                 todo &= todo - 1;
@@ -1289,8 +1371,54 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
             uint32_t and0 = 0xffffffffu, and1 = 0xffffffffu;
             uint32_t tmn = s_tm[0];
             const double2 *wrow = reinterpret_cast<const double2 *>(s_awv);
+            // The 2:1 form of the sweep (see phase 1): the group's four outputs have the same twelve weights, each two tmp rows
+            // further down -- 18 union rows, entry (i, j) = W[i - 2 j].  Checked against the staged table, then straight-line
+            // code with scalar weights (no masks, no weight reads).  Groups at the image's top and bottom keep the masked form.
+            constexpr int UT = 12, USH = 2;
+            bool uni = false;
+            if constexpr (NV == 4) {
+                if (nr == USH * (VG - 1) + UT && dense_rows == (1u << VG) - 1u) {   // wave-uniform
+                    bool same = true;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int idx = lane + 64 * k, i = idx >> 2, j = idx & 3, t = i - USH * j;
+                        if (idx < 68 * VG) {
+                            const double want = (t >= 0 && t < UT && i < nr) ? s_awv[t * VG] : 0.0;
+                            same = same && s_awv[idx] == want;
+                        }
+                    }
+                    uni = __all(same) && s_awv[0] != 0.0;
+                }
+            }
+            if (uni) {                                              // wave-uniform
+                double W[UT];
+#pragma unroll
+                for (int t = 0; t < UT; t++) {
+                    const double wv = s_awv[t * VG];
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2loint(wv)));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(__double2hiint(wv)));
+                    W[t] = __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+                }
+#pragma unroll
+                for (int i = 0; i < USH * (VG - 1) + UT; i++) {
+                    const u32x2 u = *reinterpret_cast<const u32x2 *>(tg + i * RF_TW);
+                    const uint32_t q0 = u[0], q1 = u[1];
+                    and0 &= q0; and1 &= q1;
+                    const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                    const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+#pragma unroll
+                    for (int j = 0; j < VG; j++) {
+                        const int t = i - USH * j;
+                        if (t >= 0 && t < UT) {
+                            const double aw = W[t];
+                            r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                            r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                        }
+                    }
+                }
+            }
 #pragma unroll 1
-            for (int i = 0; i < nr; i += 4) {
+            for (int i = uni ? nr : 0; i < nr; i += 4) {
                 u32x2 u[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) u[k] = *reinterpret_cast<const u32x2 *>(tg + min(i + k, nr - 1) * RF_TW);
