@@ -70,6 +70,7 @@ enum Slot {
     SLOT_JPEG_ENC, SLOT_JPEG_ENC2, SLOT_JPEG_LUT, SLOT_JPEG_ECS,   // jpeg.hip's entropy coder
     SLOT_FILE0, SLOT_FILE1, SLOT_FILE_SAMPLES,                     // host_api.cpp: fennec_CompressFileJPEG's images between its stages
     SLOT_JPEG_DEC, SLOT_JPEG_DEC_PLANES, SLOT_JPEG_DEC_IMG,        // jpeg_dec.hip: the decoder's work arrays, its planes, toNRGBARef's image
+    SLOT_AN_HASH0, SLOT_AN_HASH1,   // analyze.hip: the colour-set tables of this call and the next (the launch that uses one zeroes the other)
     SLOT_DONE,       // workgroup counters of the kernels that finish their own reduction (ssim.hip), zero between launches
     SLOT_COUNT
 };
@@ -170,6 +171,9 @@ struct fnx_ctx {
     // fnx_ctx_last_kernel: the kernel the last call of each class really launched (static strings), so that a report can
     // name the route the library took instead of inferring it from environment switches
     const char *route[8] = {"", "", "", "", "", "", "", ""};
+    // analyze.hip's single-launch form: which colour table the next call uses, and how many tables of each are not zero
+    int an_cur = 0;
+    int an_dirty[2] = {0, 0};
 };
 
 struct fnx_prepared {
@@ -371,7 +375,17 @@ int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, i
 int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
                    bool aligned16_ok, fnx_analysis *d_res);
 // flat Pix scan: *d_flags bit 0 = some alpha != 255, bit 1 = some pixel with r != g or g != b
+int launch_analyze_ready_words();
+int launch_analyze_one(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
+                       bool aligned16_ok, fnx_analysis *res, uint32_t *ready);
 int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags);
+// the same scan as ONE launch whose workgroups each write their flags (| 0x100) into their own word of host-visible memory
+// (h_slots: pinned, launch_scan_flags_slots(ctx) words set to 0xffffffff by the caller, who watches the first *nslots of
+// them change): no memset, no copy, no stream synchronisation
+int launch_scan_flags_slots(const fnx_ctx *ctx);
+int launch_scan_flags_direct(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *h_slots, int *nslots);
+int ssim_done_counters(fnx_ctx *ctx, unsigned **out);   // ssim.hip: zeroed "workgroups finished" words (see there)
+constexpr int DONE_SCAN = 2 * 4096 + 16;                // first of the 16 words of analyze.hip's scans
 // analyzeFormat's samples: pixels at row-major indices 0, step, 2 step, ... (nsamples of them) as packed NRGBA words
 int launch_sample_pixels(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, long long step, uint32_t *d_out, int nsamples);
 // applyPalette (+ palettedToNRGBA): palette = n x 4 host bytes (opaque); idx and/or quant may be null

@@ -975,7 +975,9 @@ __device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &
 
 // RMAX: the tile's rows.  64 (32 KB: three workgroups per CU) where a 2:1 downscale needs them; 32 (16 KB) for upscales,
 // whose V groups read few tmp rows: with the phase buffers sized by the window (NV = 2: 13 KB) four workgroups fit a CU.
-template <int NV, int RMAX>
+// FAST: the 2:1 forms of the exact loops (scalar weights, straight-line rows).  resize_fused_sparse_kernel, which wraps
+// the tile in a loop over the tiles resize_mfma_kernel handed back, is built without them: with them it spills 39 registers.
+template <int NV, int RMAX, bool FAST = true>
 __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, const int bx, const int by)
 {
     constexpr int HO = RG_HO, NPX = 4 * NV, VG = RG_VG;
@@ -1131,7 +1133,7 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
             bool uni = false;
             uint64_t oddm = 0;
             double W[UT] = {};
-            if constexpr (NV == 4) {
+            if constexpr (NV == 4 && FAST) {
                 const uint64_t am = __ballot(active);
                 const int ref = __builtin_amdgcn_readfirstlane(__popcll(am) >> 1);
 #pragma unroll
@@ -1150,7 +1152,119 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
                 oddm = __ballot(!same && active);
                 uni = __popcll(oddm) <= 6 && W[0] != 0.0;
             }
-            if (uni) {                                              // wave-uniform
+            // Four outputs per lane, two rows per wave instruction: lanes 0..31 take one row, lanes 32..63 the next, each lane
+            // the outputs of TWO adjacent groups (20 source pixels, of which 18 carry weight).  A source pixel is then
+            // converted once per four outputs instead of once per two: 108 + 288 instructions per 4 outputs against
+            // 2 x (84 + 144).  Needs the second group's window to start four pixels after the first (it does wherever the
+            // weights are uniform) and 20 readable pixels from the first window's start.
+            bool quad = false;
+            int s0q = 0;
+            if constexpr (NV == 4 && FAST) {
+                if (uni) {
+                    const int hl = lane & 31, gq = min(bx * 64 + 2 * hl, a.ngroups - 1), gq1 = min(gq + 1, a.ngroups - 1);
+                    s0q = a.s0[gq];
+                    const bool lane_odd = ((oddm >> (2 * hl)) & 3ull) != 0ull;
+                    // (a lane with an edge group in it is recomputed from the list: its 20 pixels need not all exist -- the loads clamp)
+                    const bool fits = lane_odd || (s0q + 20 <= a.srcN && (bx * 64 + 2 * hl + 1 >= a.ngroups || a.s0[gq1] == s0q + 4));
+                    quad = __all(fits) && a.srcN >= 20;
+                }
+            }
+            if (quad) {                                             // wave-uniform
+                const int hl = lane & 31, half = lane >> 5;
+                const int gA = bx * 64 + 2 * hl;
+                const bool actA = gA < a.ngroups, actB = gA + 1 < a.ngroups;
+                const bool oddA = (oddm >> (2 * hl)) & 1ull, oddB = (oddm >> (2 * hl + 1)) & 1ull;
+                const int dq = HO * min(gA, a.ngroups - 1);          // first output column of this lane (HO outputs per group)
+                double invq[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) invq[j] = a.inv[min(dq + j, a.nout - 1)];
+                const uint32_t abA = a.alpha[min(gA, a.ngroups - 1)], abB = a.alpha[min(gA + 1, a.ngroups - 1)];
+                auto load20 = [&](int y, u32x4 (&w)[5]) {
+                    const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) w[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(min(s0q + 4 * q, a.srcN - 4)));
+                };
+                // pairs of rows: (first set bit, second set bit) of what is left; a lone last row runs with its upper half idle
+                uint32_t tl = todo;
+                auto next_pair = [&](int &ylo, int &yhi, bool &has_hi) {
+                    if (!tl) { has_hi = false; return false; }
+                    ylo = yw + __builtin_ctz(tl);
+                    tl &= tl - 1;
+                    has_hi = tl != 0;
+                    yhi = has_hi ? yw + __builtin_ctz(tl) : ylo;
+                    if (has_hi) tl &= tl - 1;
+                    return true;
+                };
+                int yl0 = yw, yh0 = yw, yl1 = yw, yh1 = yw;
+                bool hh0 = false, hh1 = false;
+                u32x4 ra[5];                                        // the next pair's pixels (one pair = two rows ahead)
+                bool more0 = next_pair(yl0, yh0, hh0);
+                load20(half ? yh0 : yl0, ra);
+                uint32_t redo = 0;
+                while (more0) {
+                    const int y = half ? yh0 : yl0;
+                    const bool mine = half ? hh0 : true;             // (a lone row: the upper half computes it again and stores nothing)
+                    const int yl_now = yl0, yh_now = yh0;
+                    const bool hh_now = hh0;
+                    u32x4 w[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) w[q] = ra[q];
+                    const bool more1 = next_pair(yl1, yh1, hh1);
+                    if (more1) { yl0 = yl1; yh0 = yh1; hh0 = hh1; }
+                    more0 = more1;
+                    load20(half ? yh0 : yl0, ra);                   // (after the last pair: the same rows again, unused)
+                    uint32_t andp = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < 5; q++) andp &= (w[q][0] & w[q][1]) & (w[q][2] & w[q][3]);
+                    uint32_t o[4];
+                    if (!__all((andp >> 24) == 0xffu || !actA)) {   // a window that is not opaque: both rows go to the two-output form below
+                        redo |= 1u << (yl_now - yw);
+                        if (hh_now) redo |= 1u << (yh_now - yw);
+                        continue;
+                    }
+                    {
+                        double acc[4][3];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
+#pragma unroll
+                        for (int i = 0; i < 3 * USH + UT; i++) {
+                            const uint32_t p = w[i / 4][i % 4];
+                            const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int t = i - USH * j;
+                                if (t >= 0 && t < UT) {
+                                    acc[j][0] = acc[j][0] + fr * W[t]; acc[j][1] = acc[j][1] + fg * W[t]; acc[j][2] = acc[j][2] + fb * W[t];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t al = j < 2 ? ((abA >> (8 * j)) & 0xffu) : ((abB >> (8 * (j - 2))) & 0xffu);
+                            o[j] = clampF_fast64(acc[j][0] * invq[j]) | (clampF_fast64(acc[j][1] * invq[j]) << 8) |
+                                   (clampF_fast64(acc[j][2] * invq[j]) << 16) | (al << 24);
+                        }
+                    }
+                    if (mine) {
+                        uint32_t *tp = s_tile + (y - r0) * RF_TW + 4 * hl;
+                        if (!oddA && !oddB && actB) {
+                            *reinterpret_cast<u32x4 *>(tp) = (u32x4){o[0], o[1], o[2], o[3]};
+                        } else {
+                            // (edge groups, <= 6 of the wave's: their outputs go on the fix-up list -- at most 12 entries per
+                            // row, two rows per pass, within the list's bound of 14 per wave-row)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const bool act = j < 2 ? actA : actB, od = j < 2 ? oddA : oddB;
+                                if (!act) continue;
+                                if (!od) tp[j] = o[j];
+                                else if (dq + j < a.nout) s_fix[atomicAdd(&s_nfix, 1)] = (static_cast<uint32_t>(y - r0) << 8) | static_cast<uint32_t>(4 * hl + j);
+                            }
+                        }
+                    }
+                }
+                todo = redo;
+            }
+            if (uni && todo) {                                      // wave-uniform
                 const bool odd = (oddm >> lane) & 1ull;
                 uint32_t tl = todo;                                 // rows whose loads have not been issued
                 auto next_row = [&](int fallback) {
@@ -1376,7 +1490,7 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
             // code with scalar weights (no masks, no weight reads).  Groups at the image's top and bottom keep the masked form.
             constexpr int UT = 12, USH = 2;
             bool uni = false;
-            if constexpr (NV == 4) {
+            if constexpr (NV == 4 && FAST) {
                 if (nr == USH * (VG - 1) + UT && dense_rows == (1u << VG) - 1u) {   // wave-uniform
                     bool same = true;
 #pragma unroll
@@ -1498,7 +1612,7 @@ __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_sparse_k
     }
     for (int t = blockIdx.x; t < fa.cells; t += gridDim.x) {
         if (fa.todo[t] != fa.gen) continue;
-        resize_fused_tile<NV, RMAX>(fa, t % fa.gx, t / fa.gx);
+        resize_fused_tile<NV, RMAX, false>(fa, t % fa.gx, t / fa.gx);
         __syncthreads();
     }
 }

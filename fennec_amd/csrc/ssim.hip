@@ -367,8 +367,9 @@ __global__ __launch_bounds__(256) void box_tiled_multi_kernel(BoxMulti m)
 // "workgroups finished" counters of the kernels whose last workgroup takes the final sum itself: 2 x 4096 for the
 // marching SSIM kernels (one half per stream the ctx launches on), one more for MSSSIM's multi-level window launch.
 // Zero between launches (the last workgroup puts its counter back).
-constexpr int SSIM_DONE_WORDS = 2 * 4096 + 16;
-static int ssim_done_counters(fnx_ctx *ctx, unsigned **out)
+// Words DONE_SCAN .. + 15 belong to the single-launch scans of analyze.hip (isOpaque / isGrayscale).
+constexpr int SSIM_DONE_WORDS = 2 * 4096 + 32;
+int ssim_done_counters(fnx_ctx *ctx, unsigned **out)
 {
     const void *before = ctx->slot[SLOT_DONE].p;
     void *dn = nullptr;

@@ -1071,6 +1071,34 @@ def test_analyze_4k_device_batch_and_views(ctx, orc):
     assert (st["Width"], st["Height"], st["Entropy"]) == (0, 0, 0.0)
 
 
+def test_analyze_colour_tables_alternate_cleanly(orc):
+    """the single-launch Analyze keeps two colour tables per ctx: the launch that uses one clears the other.  Batches of
+    different sizes and single calls interleaved must each see an empty table (few-colour images count exactly)."""
+    import torch
+    c = fennec_amd.Context(0)
+    few = (synth.large_photo(640, 480, 1) & 0xC0) | np.array([0, 0, 0, 255], dtype=np.uint8)           # < 1024 colours
+    pal = np.ascontiguousarray(ANALYZE_IMAGES["palette_900x700"]())
+    noisy = [synth.noise_image(640, 480, 20 + k) for k in range(5)]
+    want_few, want_pal = orc.analyze(few), orc.analyze(pal)
+    assert want_few["unique_colors"] < 1024 and want_pal["unique_colors"] < 1024
+    d_noisy = [torch.from_numpy(i).cuda() for i in noisy]
+    d_few = [torch.from_numpy(few).cuda() for _ in range(2)]
+    torch.cuda.synchronize()
+    seq = [("b", d_noisy), ("s", few), ("s", pal), ("b", d_noisy[:2]), ("b", d_few), ("s", few), ("b", d_noisy), ("b", d_few), ("s", pal)]
+    for kind, x in seq * 2:
+        if kind == "s":
+            _check_analysis(c.analyze_raw(x), c.Analyze(x), want_few if x is few else want_pal)
+        else:
+            plan = c.plan_analyze_batch(x)
+            raw = plan.run()
+            for k in range(len(x)):
+                img = x[k].cpu().numpy()
+                want = orc.analyze(img)
+                assert c._analysis_dict(raw[k])["unique_colors"] == want["unique_colors"]
+                assert np.array_equal(np.array(raw[k].histogram[:], dtype=np.float64), want["histogram"])
+    c.close()
+
+
 def test_flat_scans_see_row_padding(ctx, orc):
     """isOpaque / isGrayscale walk the flat Pix slice (convert.go:66-84): padding counts."""
     base = synth.make_solid_image(64, 32, (9, 9, 9, 255))
@@ -1085,6 +1113,35 @@ def test_flat_scans_see_row_padding(ctx, orc):
     assert ctx.isOpaque(big) is True and ctx.isGrayscale(big) is False
     big[2159, 3839, 3] = 254
     assert ctx.isOpaque(big) is False
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (17, 1), (64, 64), (257, 129), (1021, 767), (3840, 2160)])
+def test_flat_scans_single_odd_pixel_anywhere(ctx, orc, w, h):
+    """the single-launch scan (its last workgroup reports, workgroups stop early once both flags are known): one pixel that
+    is not opaque / not grey at the first, the last and random positions, host images and device views at any alignment"""
+    import torch
+    rng = np.random.default_rng(w * 7919 + h)
+    grey = np.full((h, w, 4), 255, dtype=np.uint8)
+    grey[..., :3] = rng.integers(0, 256, size=(h, w, 1), dtype=np.uint8)
+    assert ctx.isOpaque(grey) is True and ctx.isGrayscale(grey) is True
+    spots = {(0, 0), (h - 1, w - 1)} | {(int(rng.integers(0, h)), int(rng.integers(0, w))) for _ in range(6)}
+    for (y, x) in sorted(spots):
+        a = grey.copy(); a[y, x, 3] = 254
+        assert ctx.isOpaque(a) is False and ctx.isGrayscale(a) is True, (y, x)
+        c = grey.copy(); c[y, x, int(rng.integers(0, 3))] ^= 1
+        assert ctx.isOpaque(c) is True and ctx.isGrayscale(c) is False, (y, x)
+        both = a.copy(); both[h - 1 - y, w - 1 - x, 1] ^= 0x80
+        assert ctx.isOpaque(both) is False and ctx.isGrayscale(both) is False
+        assert orc.is_opaque(a) is False and orc.is_grayscale(c) is False
+    # device-resident, flat and unaligned (a view starting one pixel in: 4-byte alignment only)
+    flat = torch.from_numpy(np.concatenate([grey.reshape(-1, 4), grey.reshape(-1, 4)[:1]])).cuda()
+    v = flat[1:1 + w * h].reshape(h, w, 4)
+    assert ctx.isOpaque(v) is True and ctx.isGrayscale(v) is True
+    flat[w * h, 3] = 7                               # the view's last pixel
+    torch.cuda.synchronize()
+    assert ctx.isOpaque(v) is False and ctx.isGrayscale(v) is True
+    for _ in range(3):                               # the counters go back to zero after every launch
+        assert ctx.isOpaque(grey) is True and ctx.isGrayscale(grey) is True
 
 
 # ------------------------------------------------------------------ applyPalette (targetsize.go:488-546), SURVEY 8(f).4
@@ -1193,6 +1250,8 @@ def test_ctx_profile_hook(ctx):
     assert 0.005 < ms_plain < ms_score < 5.0 and 0.001 < ms_an < 5.0
     c.profile(False)
     # fnx_ctx_last_kernel: the route the dispatch took, not what an environment switch suggests
+    assert c.last_kernel(fennec_amd.PROF_MAIN) in ("analyze_one_kernel", "analyze_pass_kernel")   # (Analyze shares the MAIN class)
+    c.GaussianBlurBatch(d, 2.0); c.sync()
     assert c.last_kernel(fennec_amd.PROF_MAIN) in ("blur_mfma_kernel", "blur_direct_kernel")
     c.GaussianBlurSSIMFastBatch(d, 2.0)
     assert "SCORE" in c.last_kernel(fennec_amd.PROF_MAIN)

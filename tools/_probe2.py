@@ -1,0 +1,13 @@
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fennec_amd
+from fennec_amd import synth
+ctx = fennec_amd.Context(0)
+imgs = [torch.from_numpy(synth.large_photo(3840, 2160, k)).cuda() for k in range(4)]
+torch.cuda.synchronize()
+for i in range(100): ctx.Analyze(imgs[i % 4])
+for i in range(5):
+    r = ctx.analyze_raw(imgs[i % 4])
+    pk = int(r["edge_total"])
+    print("stamps (us since tail start): bright loaded %.2f, sum %.2f, contrast loaded+computed %.2f, sum %.2f, stores acked %.2f" % tuple(((pk >> (12 * k)) & 0xfff) / 100.0 for k in range(5)))
