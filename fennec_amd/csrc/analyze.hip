@@ -410,7 +410,8 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
 // call (every lane clears a few words before it starts its own work).
 // ------------------------------------------------------------------------------------
 constexpr int AN1_T = 1024;
-constexpr int AN1_HB = 16;                     // histogram workgroups of the tail launch (16 bins each), + 1 for the rest
+constexpr int AN1_HB = 16;                     // histogram workgroups of the tail launch (16 bins each)
+constexpr int AN1_CW = 8;                      // + contrast workgroups: ONE CU's miss queue made 10 000 scattered samples a 20 us stage
 
 struct An1Args {
     PassArgs2 p;                               // G = pass workgroups per image
@@ -424,7 +425,8 @@ struct An1Args {
     uint32_t *count_part;                      // [n][CB + EB]
     unsigned *done;                            // [n], zero between launches
     fnx_analysis *res;                         // [n]
-    uint32_t *ready;                           // [n][AN1_HB + 1]: 1 once that workgroup's part of res[z] is complete
+    double *var_part;                          // [n][AN1_CW]: the contrast workgroups' sums (the caller adds them, in order)
+    uint32_t *ready;                           // [n][AN1_HB + AN1_CW]: 1 once that workgroup's part of the result is complete
 };
 
 __global__ __launch_bounds__(AN1_T) void analyze_one_kernel(An1Args a)
@@ -440,6 +442,8 @@ __global__ __launch_bounds__(AN1_T) void analyze_one_kernel(An1Args a)
         for (long long i = (static_cast<long long>(z) * NB + b) * AN1_T + tid; i < a.next_words; i += nthreads) a.hash_next[i] = 0ull;
     }
     if (tid == 0) s_flag = 0;
+    // (the sampled stages' workgroups come LAST in dispatch order: first, they took CUs from the pass -- 21.4 against 18.9 us)
+    const int SB = a.CB + a.EB;
     if (b < G) {                               // ---- the full pass
         for (int i = tid; i < 16 * AN_COPIES * 256; i += AN1_T) (&s_hist[0][0])[i] = 0;
         __syncthreads();
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(AN1_T) void analyze_one_kernel(An1Args a)
             a.p.bright_part[part] = t;
             a.p.flag_part[part] = s_flag;
         }
-    } else if (b < G + a.CB) {                 // ---- the sampled colour set
+    } else if (b - G < a.CB) {                 // ---- the sampled colour set
         const long long k = static_cast<long long>(b - G) * AN1_T + tid;
         bool fresh = false;
         if (k < a.color_samples) {
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(AN1_T) void analyze_one_kernel(An1Args a)
             }
         }
         const int c = __syncthreads_count(fresh);
-        if (tid == 0) a.count_part[static_cast<size_t>(z) * (a.CB + a.EB) + (b - G)] = c;
+        if (tid == 0) a.count_part[static_cast<size_t>(z) * SB + (b - G)] = c;
     } else {                                   // ---- Sobel edge count
         const int s = (b - G - a.CB) * AN1_T + tid;
         bool edge = false;
@@ -543,11 +547,11 @@ __global__ __launch_bounds__(AN1_T) void analyze_one_kernel(An1Args a)
             edge = sqrt(gx * gx + gy * gy) > 30.0;
         }
         const int c = __syncthreads_count(edge);
-        if (tid == 0) a.count_part[static_cast<size_t>(z) * (a.CB + a.EB) + (b - G)] = c;
+        if (tid == 0) a.count_part[static_cast<size_t>(z) * SB + (b - G)] = c;
     }
 }
 
-// The second (and last) launch of a call, AN1_HB + 1 workgroups per image: folds what analyze_one_kernel's workgroups left
+// The second (and last) launch of a call, AN1_HB + AN1_CW workgroups per image: folds what analyze_one_kernel's workgroups left
 // (a kernel boundary orders the two: no counter, no fence -- a "last workgroup" ticket on one word costs ~80 ns per
 // workgroup when every XCD contends for it, 30-80 us for this grid), then takes the stage that needs the mean.
 __global__ __launch_bounds__(AN1_T) void analyze_tail_kernel(An1Args a)
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(AN1_T) void analyze_tail_kernel(An1Args a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(&a.ready[z * (AN1_HB + 1) + hb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(&a.ready[z * (AN1_HB + AN1_CW) + hb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
 #ifdef FNX_DEVELOP
@@ -623,17 +627,20 @@ __global__ __launch_bounds__(AN1_T) void analyze_tail_kernel(An1Args a)
     const double mean = bright_sum / static_cast<double>(static_cast<long long>(a.p.w) * a.p.h);
     double v = 0.0;
     const int total = a.cnx * a.cny;
-    for (int s0 = tid; s0 < total; s0 += 10 * AN1_T) {              // ten independent loads in flight per lane: the whole grid in one trip
-        uint32_t px[10];
+    // this workgroup's slice of the grid (every contrast workgroup has taken the same brightness sum, in the same order)
+    const int cw = blockIdx.x - AN1_HB;
+    const int per = (total + AN1_CW - 1) / AN1_CW, lo = cw * per, hi = min(total, lo + per);
+    for (int s0 = lo + tid; s0 < hi; s0 += 2 * AN1_T) {             // two independent loads in flight per lane
+        uint32_t px[2];
 #pragma unroll
-        for (int e = 0; e < 10; e++) {
+        for (int e = 0; e < 2; e++) {
             const int s = s0 + e * AN1_T;
-            const int iy = s < total ? s / a.cnx : 0, ix = s < total ? s - iy * a.cnx : 0;
+            const int iy = s < hi ? s / a.cnx : 0, ix = s < hi ? s - iy * a.cnx : 0;
             px[e] = *(g_u32 *)(src + static_cast<size_t>(iy * a.cstep_y) * a.p.sstride + 4 * static_cast<size_t>(ix * a.cstep_x));
         }
 #pragma unroll
-        for (int e = 0; e < 10; e++) {
-            if (s0 + e * AN1_T < total) {
+        for (int e = 0; e < 2; e++) {
+            if (s0 + e * AN1_T < hi) {
                 const double d = lum601(px[e]) - mean;
                 v += d * d;
             }
@@ -644,15 +651,18 @@ __global__ __launch_bounds__(AN1_T) void analyze_tail_kernel(An1Args a)
     AN_STAMP(4);
     if (tid == 0) {
         auto put = [](auto *p, auto v) { __hip_atomic_store(p, static_cast<std::remove_reference_t<decltype(*p)>>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-        put(&r->bright_sum, bright_sum);
-        put(&r->variance_sum, var_sum);
-        put(&r->sample_count, static_cast<long long>(total));
-        put(&r->edge_count, static_cast<long long>(s_cnt[1]));
-        put(&r->edge_total, static_cast<long long>(a.enx) * a.eny);
-        put(&r->unique_colors, s_cnt[0]);
-        put(&r->has_alpha, static_cast<int>(s_flag & 1u));
-        put(&r->is_grayscale, (s_flag & 2u) ? 0 : 1);
-        put(&r->pad, 0);
+        put(&a.var_part[z * AN1_CW + cw], var_sum);
+        if (cw == 0) {
+            put(&r->bright_sum, bright_sum);
+            put(&r->variance_sum, 0.0);                             // (the caller's sum of var_part)
+            put(&r->sample_count, static_cast<long long>(total));
+            put(&r->edge_count, static_cast<long long>(s_cnt[1]));
+            put(&r->edge_total, static_cast<long long>(a.enx) * a.eny);
+            put(&r->unique_colors, s_cnt[0]);
+            put(&r->has_alpha, static_cast<int>(s_flag & 1u));
+            put(&r->is_grayscale, (s_flag & 2u) ? 0 : 1);
+            put(&r->pad, 0);
+        }
         // write-through stores, drained, then the ready word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef FNX_DEVELOP
@@ -665,15 +675,16 @@ __global__ __launch_bounds__(AN1_T) void analyze_tail_kernel(An1Args a)
         }
 #endif
     }
-    if (tid == 0) __hip_atomic_store(&a.ready[z * (AN1_HB + 1) + AN1_HB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(&a.ready[z * (AN1_HB + AN1_CW) + AN1_HB + cw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // n images -> res[n] (device or pinned host memory), ready[n * launch_analyze_ready_words()] (likewise; the caller sets
 // them to 0 and watches them all turn 1)
-int launch_analyze_ready_words() { return AN1_HB + 1; }
+int launch_analyze_ready_words() { return AN1_HB + AN1_CW; }
+int launch_analyze_var_parts() { return AN1_CW; }
 
 int launch_analyze_one(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
-                       bool aligned16_ok, fnx_analysis *res, uint32_t *ready)
+                       bool aligned16_ok, fnx_analysis *res, double *var_part, uint32_t *ready)
 {
     if (n <= 0) return FNX_OK;
     An1Args a{};
@@ -756,13 +767,14 @@ int launch_analyze_one(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *c
     { static const bool stamps = getenv("FNX_AN_STAMPS") != nullptr; if (stamps) a.done = reinterpret_cast<unsigned *>(res); }
 #endif
     a.res = res;
+    a.var_part = var_part;
     a.ready = ready;
     note_route(ctx, FNX_PROF_MAIN, "analyze_one_kernel");
     FNX_TRY(prof_begin(ctx));
     hipLaunchKernelGGL(analyze_one_kernel, dim3(G + a.CB + a.EB, n), dim3(AN1_T), 0, ctx->stream, a);
     FNX_HIP(hipGetLastError());
     FNX_TRY(prof_end(ctx));
-    hipLaunchKernelGGL(analyze_tail_kernel, dim3(AN1_HB + 1, n), dim3(AN1_T), 0, ctx->stream, a);
+    hipLaunchKernelGGL(analyze_tail_kernel, dim3(AN1_HB + AN1_CW, n), dim3(AN1_T), 0, ctx->stream, a);
     FNX_HIP(hipGetLastError());
     ctx->an_dirty[nxt] = 0;
     ctx->an_dirty[cur] = n;

@@ -1344,13 +1344,15 @@ static int analyze_direct(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
 {
     void *pin = nullptr;
     const size_t rbytes = (sizeof(fnx_analysis) * static_cast<size_t>(n) + 63) & ~size_t(63);
-    const int nr = n * launch_analyze_ready_words();
-    FNX_TRY(pinned_alloc(ctx, rbytes + sizeof(uint32_t) * static_cast<size_t>(nr), &pin));
+    const int nr = n * launch_analyze_ready_words(), nv = launch_analyze_var_parts();
+    const size_t vbytes = (sizeof(double) * static_cast<size_t>(n) * nv + 63) & ~size_t(63);
+    FNX_TRY(pinned_alloc(ctx, rbytes + vbytes + sizeof(uint32_t) * static_cast<size_t>(nr), &pin));
     fnx_analysis *hres = static_cast<fnx_analysis *>(pin);
-    volatile uint32_t *ready = reinterpret_cast<volatile uint32_t *>(static_cast<char *>(pin) + rbytes);
+    double *hvar = reinterpret_cast<double *>(static_cast<char *>(pin) + rbytes);
+    volatile uint32_t *ready = reinterpret_cast<volatile uint32_t *>(static_cast<char *>(pin) + rbytes + vbytes);
     for (int i = 0; i < nr; i++) ready[i] = 0u;
     std::atomic_thread_fence(std::memory_order_release);
-    FNX_TRY(launch_analyze_one(ctx, n, src, srcs, sstride, w, h, al, hres, const_cast<uint32_t *>(ready)));
+    FNX_TRY(launch_analyze_one(ctx, n, src, srcs, sstride, w, h, al, hres, hvar, const_cast<uint32_t *>(ready)));
     for (unsigned spin = 1;; spin++) {
         bool all = true;
         for (int i = 0; i < nr; i++)
@@ -1366,6 +1368,11 @@ static int analyze_direct(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t
     std::atomic_thread_fence(std::memory_order_acquire);
     for (int i = 0; i < nr; i++) FNX_REQUIRE(ready[i] == 1u, "Analyze: the launch finished without a result");
     std::memcpy(out, hres, sizeof(fnx_analysis) * static_cast<size_t>(n));
+    for (int i = 0; i < n; i++) {                                   // the contrast workgroups' sums, in order: bit-reproducible
+        double v = 0.0;
+        for (int k = 0; k < nv; k++) v += hvar[static_cast<size_t>(i) * nv + k];
+        out[i].variance_sum = v;
+    }
     return FNX_OK;
 }
 

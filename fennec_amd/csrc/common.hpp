@@ -376,8 +376,9 @@ int launch_analyze(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const
                    bool aligned16_ok, fnx_analysis *d_res);
 // flat Pix scan: *d_flags bit 0 = some alpha != 255, bit 1 = some pixel with r != g or g != b
 int launch_analyze_ready_words();
+int launch_analyze_var_parts();
 int launch_analyze_one(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *srcs, int sstride, int w, int h,
-                       bool aligned16_ok, fnx_analysis *res, uint32_t *ready);
+                       bool aligned16_ok, fnx_analysis *res, double *var_part, uint32_t *ready);
 int launch_scan_flags(fnx_ctx *ctx, const uint8_t *pix, size_t pix_len, uint32_t *d_flags);
 // the same scan as ONE launch whose workgroups each write their flags (| 0x100) into their own word of host-visible memory
 // (h_slots: pinned, launch_scan_flags_slots(ctx) words set to 0xffffffff by the caller, who watches the first *nslots of
