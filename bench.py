@@ -384,7 +384,7 @@ def main() -> int:
                        "in pinned host memory), both under the NEXT step's blur",
             "avg_ms": round(rest_ms, 4),
             "how": "step period minus the blur kernel's duration = the dispatch gap between consecutive blur launches (the tail's own "
-                   "kernels, ~45 + 40 us alone, run concurrently: profiles/r03_onepass_kernel_stats.csv)",
+                   "kernels, ~45 + 40 us alone, run concurrently: the newest profiles/*_onepass_kernel_stats.csv)",
         }
         if depth > 1:
             rest["note"] = "step period minus the (co-scheduled) blur kernel's duration: not a kernel time at this depth"
@@ -643,8 +643,8 @@ def other_configs(args, heavy_burst=None) -> dict:
         gc.disable()                            # step of config 3 (two host threads feeding four streams) is a 5-9 ms stall
         try:
             line = other_workload_line(a, embedded=True)
-            keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_step",
-                                        "step_ms", "gpu_stage", "result_sample") if k in line}
+            keep = {k: line[k] for k in ("metric", "value", "value_before_prewarm", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline",
+                                        "roofline_step", "step_ms", "gpu_stage", "result_sample") if k in line}
             keep["workload"] = line["config"]["workload"]
             keep["images_per_step"] = line["config"]["images_per_step_per_gpu"]
             keep["wall_s"] = round(time.perf_counter() - t0, 2)
@@ -1148,6 +1148,17 @@ def other_workload_line(args, embedded: bool = False):
         torch.cuda.synchronize()
 
     torch.cuda.synchronize()
+    cold = None
+    if wl in ("config3", "config4"):
+        # the same steps BEFORE this workload's own pre-warm: two steps for scratch growth, then eight timed
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        cold = units_per_step * 8 / (time.perf_counter() - t_c)
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.prewarm:      # untimed: GPU clock ramp, as in the config-2 path
         step()
@@ -1190,6 +1201,9 @@ def other_workload_line(args, embedded: bool = False):
         out["config"]["contexts_per_gpu"] = max(1, min(args.contexts, B))
         out["config"]["prewarm"] = f"{args.prewarm} s of untimed steps before the {args.warmup} warm-up steps (GPU clock ramp)"
         out["config"]["host_threads_per_gpu"] = max(1, min(args.threads or args.contexts, args.contexts, B))
+        out["value_before_prewarm"] = {"value": round(cold * world, 2), "unit": unit,
+                                       "note": "8 steps timed right after set-up (2 untimed steps for scratch growth), before this workload's own "
+                                               f"{args.prewarm} s pre-warm: what the clock governor's state costs; never `value`"}
         out["roofline_step"] = out["roofline"]
         S_img = 4.0 * W * H
         if wl == "config4":

@@ -14,7 +14,9 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"profile_{tag}")
-dst = os.path.join(root, "profiles")
+# FNX_PROFILES_DST: somewhere else (tools/collect_round.sh summarises ON the GPU box into gpurun_out/profiles_new/ and deletes
+# the raw counter files: a round's raw passes are > 64 MiB, more than gpurun merges back)
+dst = os.environ.get("FNX_PROFILES_DST") or os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
