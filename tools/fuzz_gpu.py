@@ -102,6 +102,7 @@ while time.time() < t_end:
           abs(a["bright_sum"] - wa["bright_sum"]) <= max(1e-12, w * h * 2.0 ** -53) * max(1.0, abs(wa["bright_sum"])) and
           abs(a["variance_sum"] - wa["variance_sum"]) <= 1e-9 * abs(wa["variance_sum"]) + 1e-6)
     case("analyze", ok, desc)
+    case("flat_scans", ctx.isOpaque(img) == orc.is_opaque(img) and ctx.isGrayscale(img) == orc.is_grayscale(img), desc)   # r5: the single-launch scan
     n = int(rng.integers(1, 257))
     pal = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
     pal[:, 3] = 255
