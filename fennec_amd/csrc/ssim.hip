@@ -1148,6 +1148,11 @@ __global__ __launch_bounds__(256, SMALL ? 5 : 1) void windowed_ssim_march_kernel
 // columns are 128 VGPRs, so this form runs 2 waves per SIMD -- the same windows in flight per SIMD as 4 one-column
 // waves, with the instruction-level parallelism inside the wave instead of between waves.
 // ------------------------------------------------------------------------------------
+// r5, measured and NOT taken: the milli-luminances are integers below 2^24 -- exact in fp32 -- so a lane's pixel pair can go
+// through the LDS as ONE float4 (a0, b0, a1, b1) and come back as five 16-byte reads instead of nine (17 LDS instructions per
+// wave-row instead of 22, 18 more conversions).  The model that asked for it -- 22 x 8 clocks x 8 resident waves = 1408 clocks
+// of the CU's one LDS pipe per row round against 1288 of VALU issue per SIMD -- was wrong: 135 us per 8K pair against 131.
+// The bound is a wave's chain write -> reads -> FMAs (the LDS round trip it cannot hide from itself), not the pipe.
 constexpr int WM2_COLS = 121;        // window columns per wave (128 pixel columns - 7)
 constexpr int WM2_LDSW = 72;         // entries per parity array: lane + 4, padded
 
@@ -1213,42 +1218,55 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
     // wave-uniform "if (i < nrows)" around every unrolled row the compiler cannot tell how many loads are in flight at the
     // joins and drains the queue (s_waitcnt vmcnt(0)) before each row's taps -- the four rows of prefetch were none
     // (8K pair: 135 -> 131 us; the one-column kernel keeps its loop: the same change costs its 96-register form 22 spills).
+    // r5: the march is software-pipelined by one row.  A row's luminances and its four LDS writes (with the wave barrier) are
+    // issued BEFORE the previous row's vertical pass and SSIM formula (~95 VALU instructions, which need none of it) instead of
+    // in front of its own reads: the row is in the LDS by the time its horizontal pass asks for it.  8K pair 134.6 -> 126 us (same
+    // box).  Sending the reads ahead too did not pay: all eighteen took 72 registers (256 with 62 spills), the nine second-moment
+    // taps alone (36) measured the same 126-127 us.  The loop is 145 VALU instructions per wave-row, 128 of them the separable
+    // window's FMAs: what is left is the fp64 rate.
+    auto stage = [&](const int i, auto pc) {                      // row i (i & 7 == pc): luminances into the wave's LDS row
+        constexpr int p = decltype(pc)::value;
+        const double va0 = lum_milli(qa[p % WM_PF][0]), va1 = lum_milli(qa[p % WM_PF][1]);
+        const double vb0 = lum_milli(qb[p % WM_PF][0]), vb1 = lum_milli(qb[p % WM_PF][1]);
+        qa[p % WM_PF] = *(g_u32x2 *)pa;                       // no branch around the loads (see the one-column kernel)
+        qb[p % WM_PF] = *(g_u32x2 *)pb;
+        if (i + WM_PF + 1 < nrows) {
+            pa += a.astride;
+            pb += a.bstride;
+        }
+        s_e1[lane] = make_double2(va0, vb0);
+        s_o1[lane] = make_double2(va1, vb1);
+        s_e2[lane] = make_double2(fma(vb0, vb0, va0 * va0), va0 * vb0);
+        s_o2[lane] = make_double2(fma(vb1, vb1, va1 * va1), va1 * vb1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto rowbody = [&](const int r, auto pc, auto guardc) {
         constexpr int p = decltype(pc)::value;
         const int i = r + p;
         if (decltype(guardc)::value && i >= nrows) return;        // wave-uniform
-            const double va0 = lum_milli(qa[p % WM_PF][0]), va1 = lum_milli(qa[p % WM_PF][1]);
-            const double vb0 = lum_milli(qb[p % WM_PF][0]), vb1 = lum_milli(qb[p % WM_PF][1]);
-            qa[p % WM_PF] = *(g_u32x2 *)pa;                   // no branch around the loads (see the one-column kernel)
-            qb[p % WM_PF] = *(g_u32x2 *)pb;
-            if (i + WM_PF + 1 < nrows) {
-                pa += a.astride;
-                pb += a.bstride;
-            }
-            s_e1[lane] = make_double2(va0, vb0);
-            s_o1[lane] = make_double2(va1, vb1);
-            s_e2[lane] = make_double2(fma(vb0, vb0, va0 * va0), va0 * vb0);
-            s_o2[lane] = make_double2(fma(vb1, vb1, va1 * va1), va1 * vb1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // pixel 2l + t: even t -> even[l + t / 2], odd t -> odd[l + t / 2].  Column 0's tap t is pixel 2l + t,
             // column 1's tap t is pixel 2l + 1 + t.
             double h00 = 0.0, h01 = 0.0, h02 = 0.0, h03 = 0.0, h10 = 0.0, h11 = 0.0, h12 = 0.0, h13 = 0.0;
+            double2 ru[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++) {                     // pixel 2l + q
-                const double2 u = (q & 1) ? s_o1[lane + q / 2] : s_e1[lane + q / 2];
+            for (int q = 0; q < 9; q++) ru[q] = (q & 1) ? s_o1[lane + q / 2] : s_e1[lane + q / 2];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {                     // pixel 2l + q: the second moments
                 const double2 v = (q & 1) ? s_o2[lane + q / 2] : s_e2[lane + q / 2];
-                if (q < 8) {
-                    const double c = a.col[q];
-                    h00 = fma(u.x, c, h00); h01 = fma(u.y, c, h01); h02 = fma(v.x, c, h02); h03 = fma(v.y, c, h03);
-                }
-                if (q >= 1) {
-                    const double c = a.col[q - 1];
-                    h10 = fma(u.x, c, h10); h11 = fma(u.y, c, h11); h12 = fma(v.x, c, h12); h13 = fma(v.y, c, h13);
-                }
+                if (q < 8) { const double c = a.col[q]; h02 = fma(v.x, c, h02); h03 = fma(v.y, c, h03); }
+                if (q >= 1) { const double c = a.col[q - 1]; h12 = fma(v.x, c, h12); h13 = fma(v.y, c, h13); }
             }
-            __builtin_amdgcn_wave_barrier();                  // the row is consumed before the next one overwrites it
+#pragma unroll
+            for (int q = 0; q < 9; q++) {                     // the first moments
+                const double2 u = ru[q];
+                if (q < 8) { const double c = a.col[q]; h00 = fma(u.x, c, h00); h01 = fma(u.y, c, h01); }
+                if (q >= 1) { const double c = a.col[q - 1]; h10 = fma(u.x, c, h10); h11 = fma(u.y, c, h11); }
+            }
+            // (this row's reads have been waited for by the FMAs above: the next row may overwrite it -- one wave, in-order LDS)
+            __builtin_amdgcn_wave_barrier();
+            stage(i + 1, std::integral_constant<int, (p + 1) & 7>{});   // (past the last row: the clamped loads again, never consumed)
 #pragma unroll
             for (int s = 0; s < 8; s++) {
                 const int k = (p - s) & 7;
@@ -1311,6 +1329,7 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
         rowbody(r, std::integral_constant<int, 4>{}, guardc); rowbody(r, std::integral_constant<int, 5>{}, guardc);
         rowbody(r, std::integral_constant<int, 6>{}, guardc); rowbody(r, std::integral_constant<int, 7>{}, guardc);
     };
+    stage(0, std::integral_constant<int, 0>{});
     int r = 0;
     for (; r + 8 <= nrows; r += 8) group(r, std::false_type{});
     if (r < nrows) group(r, std::true_type{});
