@@ -1,6 +1,5 @@
 set -u
 mkdir -p gpurun_out
-for rep in 1 2 3; do
-echo "== v2"; python tools/time_ssim.py 2>&1 | grep -v amdgpu | head -2
-echo "== v1"; FENNEC_HIP_LIB=$PWD/fennec_amd/libfennec_hip_ab.so python tools/time_ssim.py 2>&1 | grep -v amdgpu | head -2
-done
+bash tools/asan_run.sh > gpurun_out/asan_run.log 2>&1; echo "asan rc $?"; tail -6 gpurun_out/asan_run.log
+bash tools/tsan_run.sh > gpurun_out/tsan_run.log 2>&1; echo "tsan rc $?"; tail -12 gpurun_out/tsan_run.log
+ls gpurun_out | head -30

@@ -38,6 +38,11 @@ def worker(k):
                 out, q2, s2, st2, dims = c.jpeg_recompress(data, 0.94)   # the decoder's host side (parser, unstuffing) + its launches
                 assert dims == (w, h) and out[:2] == b"\xff\xd8"
                 assert 0 < v1 <= 1 and 0 < v2 <= 1 and 0 < v3 <= 1 and 1 <= q <= 100
+                # r5: results that arrive through watched pinned memory (Analyze's two launches, the flat scans' per-workgroup words)
+                st_d, st_h = c.Analyze(d), c.Analyze(img)
+                assert st_d["UniqueColors"] == st_h["UniqueColors"] and st_d["Width"] == w
+                assert c.isOpaque(d) is True and c.isGrayscale(img) is False
+                assert c.last_kernel(fennec_amd.PROF_RESIZE).startswith("resize_")
                 try:
                     c.lanczosResize(np.zeros((4, 4, 3), np.uint8), 2, 2)   # thread-local error text
                 except Exception:
