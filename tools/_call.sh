@@ -1,5 +1,5 @@
 set -u
 mkdir -p gpurun_out
-bash tools/asan_run.sh > gpurun_out/asan_run.log 2>&1; echo "asan rc $?"; tail -6 gpurun_out/asan_run.log
-bash tools/tsan_run.sh > gpurun_out/tsan_run.log 2>&1; echo "tsan rc $?"; tail -12 gpurun_out/tsan_run.log
-ls gpurun_out | head -30
+bash tools/collect_round.sh r05 > gpurun_out/collect_round.log 2>&1
+tail -12 gpurun_out/collect_round.log
+ls gpurun_out/profiles_new | head -60
