@@ -349,7 +349,9 @@ def main() -> int:
             # `achieved` / `peak` / `frac` price SURVEY 8(d)'s algorithmic bytes against the HBM peak (the contract of this object).
             # What the counters say BOUNDS the kernel is instruction issue: VALU + matrix + LDS instructions fill the SIMDs while
             # the measured HBM rate (hbm_frac_measured: counter bytes / launch time / peak) is well under the peak.
-            "bound": "issue (VALU + i8 MFMA + LDS), priced against hbm" if mfma else "valu, priced against hbm",
+            "bound": "valu",
+            "bound_detail": ("instruction issue: VALU + i8 MFMA + LDS instructions fill the SIMDs (committed SQ counters) while the measured HBM "
+                             "rate is hbm_frac_measured of the peak" if mfma else "VALU issue (fp32 FMA form)") + "; frac is priced against hbm",
             "roofline_priced_against": "hbm",
             "achieved": round(blur_gbs, 1),
             "peak": HBM_PEAK_GBS,
