@@ -346,6 +346,33 @@ def test_lanczos_resize_guard_kernels(ctx, orc, w, h, dw, dh):
         assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh))
 
 
+@pytest.mark.parametrize("dw,dh", [(960, 540), (961, 541), (130, 33), (64, 600), (1353, 517), (1920, 1080)])
+def test_lanczos_resize_two_to_one_exact_forms(ctx, orc, dw, dh):
+    """r5: at exactly 2:1 the exact (fp64, reference-order) loops of resize_fused_kernel have straight-line forms -- scalar weights,
+    four outputs per lane, two rows per wave instruction, the 18-row V sweep.  Content that sends every tile there (SURVEY 8(d)'s
+    ramp: all rounding ties), with what the forms must hand on: the image's edge groups (clamped tap lists), odd widths and heights
+    (a lone last row, a last group with one output), translucent pixels and patches (the general arithmetic), ramp / noise seams
+    (rows that stay fp32), and 2:1 on ONE axis only.  Bit-exact against the oracle; FNX_RESIZE_MFMA is left alone (the ramp is
+    handed back by the matrix kernel on the first call, and the ctx goes to resize_fused_kernel after it)."""
+    w, h = 2 * dw, 2 * dh
+    ramp = synth.large_photo(w, h, 3)
+    cases = [("ramp", ramp)]
+    one = ramp.copy(); one[h // 2, w // 3, 3] = 200
+    cases.append(("one translucent px", one))
+    patch = ramp.copy(); patch[h // 5: h // 5 + 40, : w // 7, 3] = 0; patch[-9:, -33:, 3] = 91
+    cases.append(("translucent patches at the edges", patch))
+    seam = _opaque(synth.noise_image(w, h, dw + dh, alpha=True)); seam[:, w // 2:] = ramp[:, w // 2:]; seam[: h // 3] = ramp[: h // 3]
+    cases.append(("noise / ramp seams", seam))
+    for name, img in cases:
+        for rep in range(2):                       # twice: the second call takes resize_fused_kernel straight away (the matrix kernel's cool-down)
+            assert np.array_equal(ctx.lanczosResize(img, dw, dh), orc.lanczos_resize(img, dw, dh, procs=8)), (name, rep)
+    # 2:1 on the x axis only / on the y axis only: one pass uniform, the other not
+    img = synth.large_photo(2 * dw, 3 * (dh // 2) + 7, 4)
+    assert np.array_equal(ctx.lanczosResize(img, dw, dh // 2 + 2), orc.lanczos_resize(img, dw, dh // 2 + 2, procs=8))
+    img = synth.large_photo(3 * (dw // 2) + 5, 2 * dh, 5)
+    assert np.array_equal(ctx.lanczosResize(img, dw // 2 + 3, dh), orc.lanczos_resize(img, dw // 2 + 3, dh, procs=8))
+
+
 def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
     """Random geometries, device views with odd strides: the guard kernels against the round-1 fp64 kernels
     (FNX_RESIZE_FP64=1), which follow the reference's operation order."""

@@ -1,6 +1,4 @@
 set -u
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q -k "resize or config3 or scan or flat" > gpurun_out/c13_tests.log 2>&1; echo "tests rc $?"; tail -2 gpurun_out/c13_tests.log
-python tools/time_resize.py soft 2>&1 | grep -v amdgpu
-python tools/fuzz_resize.py 90 11 2>&1 | tail -3
-./tools/time_ops_native 2>&1 | tail -2
+python -m pytest tests -m gpu -x -q > gpurun_out/c14_tests.log 2>&1; echo "tests rc $?"; tail -3 gpurun_out/c14_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
