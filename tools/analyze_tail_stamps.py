@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Phase stamps of analyze_tail_kernel's contrast workgroup (a DEVELOP build only: make -C fennec_amd/csrc BUILD=build_dev
+OUT=../libfennec_hip_dev.so DEVELOP=1; run with FENNEC_HIP_LIB=.../libfennec_hip_dev.so FNX_AN_STAMPS=1): the stamps come back in
+the edge_total field.  This is how round 5 found the 20 us single-CU contrast stage."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""isOpaque and Analyze one call at a time at 4K through the Python binding (run it under `rocprofv3 --kernel-trace --stats` for the
+kernels' own durations: scan_flags_direct_kernel, analyze_one_kernel, analyze_tail_kernel).  python tools/time_scan_analyze.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
