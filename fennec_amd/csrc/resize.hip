@@ -1165,7 +1165,8 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
                     s0q = a.s0[gq];
                     const bool lane_odd = ((oddm >> (2 * hl)) & 3ull) != 0ull;
                     // (a lane with an edge group in it is recomputed from the list: its 20 pixels need not all exist -- the loads clamp)
-                    const bool fits = lane_odd || (s0q + 20 <= a.srcN && (bx * 64 + 2 * hl + 1 >= a.ngroups || a.s0[gq1] == s0q + 4));
+                    const bool fits = lane_odd || bx * 64 + 2 * hl >= a.ngroups ||      // (lanes past the last group store nothing)
+                                      (s0q + 20 <= a.srcN && (bx * 64 + 2 * hl + 1 >= a.ngroups || a.s0[gq1] == s0q + 4));
                     quad = __all(fits) && a.srcN >= 20;
                 }
             }
