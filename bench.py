@@ -625,7 +625,8 @@ def other_configs(args, heavy_burst=None) -> dict:
     out = {}
     # (config 3's four worker streams jitter: 4 steps measured 59-83 k MP/s run to run, 40 steps 77-82 k)
     plan = [("config3", dict(batch=32, steps=40, warmup=3, contexts=4, threads=2)),
-            ("config4", dict(batch=4, steps=16, warmup=2, contexts=1, threads=1)),
+            ("config4", dict(batch=8, steps=16, warmup=2, contexts=1, threads=1)),     # (8 images per step as in `--workload config4`: with 4 the
+                                                                                        # three-deep result queue drains at every step boundary, 158 k against 165 k)
             ("config5", dict(batch=16, steps=3, warmup=1, contexts=1, threads=1, device_decode=True))]
     for wl, over in plan:
         a = copy.copy(args)
