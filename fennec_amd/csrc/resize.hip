@@ -977,7 +977,11 @@ __device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &
 // whose V groups read few tmp rows: with the phase buffers sized by the window (NV = 2: 13 KB) four workgroups fit a CU.
 // FAST: the 2:1 forms of the exact loops (scalar weights, straight-line rows).  resize_fused_sparse_kernel, which wraps
 // the tile in a loop over the tiles resize_mfma_kernel handed back, is built without them: with them it spills 39 registers.
-template <int NV, int RMAX, bool FAST = true>
+// DENSE: no fp32 form at all -- every tmp row and every output row goes straight to the exact loops (which are the
+// reference's arithmetic for any content: always right, slow where the fp32 form would have been proven).  For a plan whose
+// recent images came back tie-dense from the matrix kernel (its cool-down, see resize_fused): the kernel then carries
+// neither the fp32 weights nor the guard's packs, and its first rows are not computed twice.
+template <int NV, int RMAX, bool FAST = true, bool DENSE = false>
 __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, const int bx, const int by)
 {
     constexpr int HO = RG_HO, NPX = 4 * NV, VG = RG_VG;
@@ -1034,7 +1038,11 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
         for (int q = 0; q < NV; q++) w[q] = *(g_u32x4 *)(row + 4 * static_cast<size_t>(s0 + 4 * q));
     };
     // ---------------- phase 1: resizeH (resize.go:77-117) into the tile ----------------
-    if (yw < y1) {                                                  // wave-uniform
+    if constexpr (DENSE) {
+        if (yw < y1) exact_rows = (1u << (y1 - yw)) - 1u;
+        if (tid == 0) s_ndense = 4;
+    }
+    if (!DENSE && yw < y1) {                                        // wave-uniform
         u32x4 vn[NV], vm[NV];
         load_row(yw, vn);
         load_row(min(yw + 1, y1 - 1), vm);
@@ -1365,7 +1373,7 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
         }
     }
     __syncthreads();
-    const bool hinted = s_ndense >= 2;                              // wave-uniform
+    const bool hinted = DENSE || s_ndense >= 2;                     // wave-uniform
 
     // ---------------- phase 2: resizeV (resize.go:120-160) out of the tile ----------------
     float *s_wv = reinterpret_cast<float *>(s_u) + wave * (64 * VG);
@@ -1598,6 +1606,12 @@ template <int NV, int RMAX>
 __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(ResizeFusedArgs fa)
 {
     resize_fused_tile<NV, RMAX>(fa, blockIdx.x, blockIdx.y);
+}
+
+template <int NV, int RMAX>
+__global__ __launch_bounds__(256, 3) void resize_fused_dense_kernel(ResizeFusedArgs fa)
+{
+    resize_fused_tile<NV, RMAX, true, true>(fa, blockIdx.x, blockIdx.y);
 }
 
 // After resize_mfma_kernel: the tiles it handed back, and only those.  A fixed grid of workgroups walks the stamps (a launch
@@ -1997,6 +2011,12 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             ctx->rz_last_gen = 0;
         }
     }
+    // in the cool-down the plan's recent images were tie-dense (or translucent): the form without the fp32 passes (NV = 4: the
+    // 2:1 downscales whose exact loops have the straight-line forms)
+    static const bool dense_off = [] { const char *e = getenv("FNX_RF_DENSE"); return e && e[0] == '0'; }();   // A/B and tests
+    // (from the second cool-down in a row on -- mf_cool_len doubles each time the matrix kernel's retry comes back dense again --,
+    // so that one synthetic image in a stream of photographs does not send the next 64 of them through fp64 loops)
+    const bool dense_form = use_mf && ph->mf_cool > 0 && ph->mf_cool_len >= 128 && !low && ph->NV == 4 && !dense_off;
     if (use_mf && ph->mf_cool > 0) { ph->mf_cool--; use_mf = false; }
     if (use_mf) {
         const size_t cells = static_cast<size_t>(grid.x) * grid.y;
@@ -2056,6 +2076,12 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             default: hipLaunchKernelGGL((resize_fused_sparse_kernel<4, RF_RMAX>), sgrid, dim3(256), 0, ctx->stream, fa); break;
             }
         }
+        FNX_HIP(hipGetLastError());
+        return prof_end(ctx);
+    }
+    if (dense_form) {
+        note_route(ctx, FNX_PROF_RESIZE, "resize_fused_dense_kernel");
+        hipLaunchKernelGGL((resize_fused_dense_kernel<4, RF_RMAX>), grid, dim3(256), 0, ctx->stream, fa);
         FNX_HIP(hipGetLastError());
         return prof_end(ctx);
     }

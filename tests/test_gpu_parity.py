@@ -373,6 +373,31 @@ def test_lanczos_resize_two_to_one_exact_forms(ctx, orc, dw, dh):
     assert np.array_equal(ctx.lanczosResize(img, dw // 2 + 3, dh), orc.lanczos_resize(img, dw // 2 + 3, dh, procs=8))
 
 
+def test_lanczos_resize_dense_form_after_two_cool_downs(orc):
+    """r5: a plan whose images keep coming back tie-dense from the matrix kernel (two cool-downs in a row: ~66 calls) runs
+    resize_fused_dense_kernel -- no fp32 passes at all.  Every call on the way there, and the dense form itself on a ramp, a
+    ramp with translucent pixels and a noise image (which the dense form must still get right), equals the oracle."""
+    c = fennec_amd.Context(0)
+    w, h, dw, dh = 768, 400, 384, 200
+    ramp = synth.large_photo(w, h, 6)
+    want = orc.lanczos_resize(ramp, dw, dh)
+    seen = set()
+    for k in range(150):
+        got = c.lanczosResize(ramp, dw, dh)
+        seen.add(c.last_kernel(fennec_amd.PROF_RESIZE))
+        if k % 16 == 0 or k > 60:
+            assert np.array_equal(got, want), k
+    assert "resize_fused_dense_kernel" in seen and any(s.startswith("resize_mfma_kernel") for s in seen), seen
+    # still in the cool-down: other content through the dense form
+    holes = ramp.copy(); holes[h // 2: h // 2 + 9, 5: w // 2, 3] = 3; holes[0, 0, 3] = 254
+    noise = _opaque(synth.noise_image(w, h, 77, alpha=True))
+    for img in (holes, noise, ramp):
+        got = c.lanczosResize(img, dw, dh)
+        assert c.last_kernel(fennec_amd.PROF_RESIZE) in ("resize_fused_dense_kernel", "resize_mfma_kernel + resize_fused_sparse_kernel")
+        assert np.array_equal(got, orc.lanczos_resize(img, dw, dh))
+    c.close()
+
+
 def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
     """Random geometries, device views with odd strides: the guard kernels against the round-1 fp64 kernels
     (FNX_RESIZE_FP64=1), which follow the reference's operation order."""
