@@ -1233,13 +1233,23 @@ def other_workload_line(args, embedded: bool = False):
             # fused: reads S(4K), writes the 1080p result; two-pass: resizeH reads S(4K), writes the 1920 x 2160 intermediate
             abytes = S_img + S_img / 4 if fused else S_img + S_img / 2
             g = abytes / (ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": ("resize_fused_kernel<4> (lanczosResize 4K -> 1080p in one launch: resizeH into an LDS tile, resizeV out of it; "
+            # which form of the one-launch kernel the downscale takes in this workload: on SURVEY 8(d)'s ramp the plan is in its
+            # tie-dense cool-down from the 66th call on -- the committed profile of this same command says
+            # which kernel it launched
+            dense = committed_traffic_named("resize_fused_dense_kernel<4", "config3")
+            dense_file = source_file("traffic")
+            plain = committed_traffic_named("resize_fused_kernel<4", "config3")
+            plain_file = source_file("traffic")
+            use_dense = dense is not None
+            down_traffic, down_file = (dense, dense_file) if use_dense else (plain, plain_file)
+            out["roofline"] = {"kernel": (("resize_fused_dense_kernel<4> (a plan in its second tie-dense cool-down: the tile without fp32 passes)" if use_dense else "resize_fused_kernel<4>") +
+                                          " (lanczosResize 4K -> 1080p in one launch: resizeH into an LDS tile, resizeV out of it; "
                                           "the largest single kernel of the step)") if fused else
                                          "resize_h_guard_kernel<4> (resizeH of the 4K -> 1080p downscale: the largest single kernel of the step)",
                                "bound": "valu" if fused else "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
-                               "traffic": committed_traffic_named("resize_fused_kernel" if fused else "resize_h_guard_kernel", "config3"),
-                               "traffic_file": source_file("traffic"),
+                               "traffic": down_traffic if fused else committed_traffic_named("resize_h_guard_kernel", "config3"),
+                               "traffic_file": down_file if fused else source_file("traffic"),
                                "traffic_source": "the newest profiles/*config3*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4),
                                "launches_timed": len(kms[dom]),
