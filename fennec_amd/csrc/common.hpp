@@ -163,6 +163,7 @@ struct fnx_ctx {
     uint32_t rz_last_gen = 0;                // the last matrix launch whose report has not been read
     size_t rz_last_cells = 0;
     const fnx_resize_plan *rz_last_h = nullptr;
+    uint32_t d21_gen = 0;                    // resize_dense21_kernel's launches (rz_report[1] holds the last one that met translucent content)
     // fnx_ctx_profile: event pairs around the profiled kernel launches, oldest unread first
     static constexpr int PROF_DEPTH = 32;
     int prof = 0;                 // bit mask of FNX_PROF_* kernel classes being bracketed (0: off)

@@ -1614,6 +1614,169 @@ __global__ __launch_bounds__(256, 3) void resize_fused_dense_kernel(ResizeFusedA
     resize_fused_tile<NV, RMAX, true, true>(fa, blockIdx.x, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------
+// resize_dense21_kernel (r5): the exact 2:1 downscale of tie-dense content, and nothing else
+// ------------------------------------------------------------------------------------
+// What resize_fused_dense_kernel does for a plan in its tie-dense cool-down, as a kernel of its own: the straight-line forms
+// of the exact loops (four outputs per lane and two rows per wave instruction in the H pass, the 18-row sweep in the V pass)
+// with the twelve weights, 1 / sum and the alpha byte as kernel ARGUMENTS (the host has checked that every output but the
+// image's edge groups shares them: build_dense21) -- no weight tables, no staging, no fp32 form, no lists.  What does not
+// fit the form is recomputed per pixel from the tap lists, in the reference's order (resize_exact_px / _tile): the outputs
+// of "odd" groups (clamped tap lists at the image's edges) and every output whose window holds a pixel that is not opaque.
+// Tiles of up to 74 rows (eight V groups: 1.16 rows of H work per row used where the general kernel's 64 rows do 1.33, and two
+// groups for each wave), 42 KB of LDS, three workgroups per CU (four: twelve registers spilled, 47 us against 45).
+constexpr int D21_ROWS = 74, D21_NGMAX = 8;
+struct Dense21Args {
+    double wh[12], wv[12];           // aw = 255 w of the shared tap lists
+    double inv_h, inv_v;             // 1 / sum aw
+    uint32_t al_h, al_v;             // clampF(sum aw): the alpha byte of an opaque window
+    int base_h, base_v;              // first tap of output d: 2 d + base
+    const uint8_t *odd_h, *odd_v;    // per H group (2 outputs) / V group (4 outputs): 1 = not of the form
+    unsigned long long *heavy;       // host-mapped: a workgroup that redid more than an eighth of its tile per pixel leaves `gen`
+    unsigned gen;
+};
+
+#ifndef FNX_D21_OCC
+#define FNX_D21_OCC 3
+#endif
+__global__ __launch_bounds__(256, FNX_D21_OCC) void resize_dense21_kernel(ResizeFusedArgs fa, Dense21Args dn)
+{
+    constexpr int VG = RG_VG, UT = 12, USH = 2;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tile[D21_ROWS * RF_TW];
+    __shared__ uint16_t s_list[D21_ROWS * 32];                       // (row << 5 | lane): four outputs that await the per-pixel form
+    __shared__ unsigned s_nlist;
+    const ResizeGuardArgs &a = fa.h;
+    const ResizeGuardArgs &v = fa.v;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_nlist = 0;
+    const int gfirst = by * fa.ng, glast = min(gfirst + fa.ng, v.ngroups) - 1;
+    const int r0 = v.s0[gfirst], r1 = v.s0[glast] + v.cnt[glast];   // the tile's tmp rows (monotone tables: the host checks)
+    const int rpw = (r1 - r0 + 3) >> 2;
+    const int yw = r0 + wave * rpw, y1 = min(yw + rpw, r1);          // this wave's rows (<= 19)
+    __syncthreads();
+    // ---------------- phase 1: resizeH (resize.go:77-117), four outputs per lane, two rows per pass ----------------
+    {
+        const int hl = lane & 31, half = lane >> 5;
+        const int d0 = bx * RF_TW + 4 * hl;                          // this lane's first output column
+        const bool act = d0 < a.nout;
+        const int sx0 = 2 * d0 + dn.base_h;                          // the first of this lane's 18 tap pixels (20 are loaded)
+        const bool lane_odd = act && (dn.odd_h[min(d0 >> 1, a.ngroups - 1)] | dn.odd_h[min((d0 >> 1) + 1, a.ngroups)] | (d0 + 3 >= a.nout) |
+                                      (sx0 < 0) | (sx0 + 20 > a.srcN));
+        const int sx = clampi(sx0, 0, a.srcN - 20);                  // (an odd lane's 20 pixels need not be its own: it is redone)
+        auto load20 = [&](int y, u32x4 (&w)[5]) {
+            const uint8_t *row = a.src + static_cast<size_t>(y) * a.sstride + 4 * static_cast<size_t>(sx);
+#pragma unroll
+            for (int q = 0; q < 5; q++) w[q] = *(g_u32x4 *)(row + 16 * q);
+        };
+        const int npairs = (y1 - yw + 1) >> 1;                       // wave-uniform; <= 10
+        u32x4 ra[5];                                                 // the next pair's pixels (two pairs ahead: 12 registers spilled)
+        auto row_of = [&](int k) { return min(yw + 2 * min(k, max(npairs - 1, 0)) + half, max(y1 - 1, yw)); };
+        if (npairs > 0) load20(row_of(0), ra);
+        for (int k = 0; k < npairs; k++) {
+            const int y = yw + 2 * k + half;
+            const bool mine = y < y1;                                // (a lone last row: the upper half computes the row before it again)
+            u32x4 w[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) w[q] = ra[q];
+            load20(row_of(k + 1), ra);                               // one pair (two rows) ahead
+            uint32_t andp = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 5; q++) andp &= (w[q][0] & w[q][1]) & (w[q][2] & w[q][3]);
+            double acc[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3 * USH + UT; i++) {
+                const uint32_t p = w[i / 4][i % 4];
+                const double fr = u8_to_f64(p & 0xffu), fg = u8_to_f64((p >> 8) & 0xffu), fb = u8_to_f64((p >> 16) & 0xffu);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = i - USH * j;
+                    if (t >= 0 && t < UT) {
+                        acc[j][0] = acc[j][0] + fr * dn.wh[t]; acc[j][1] = acc[j][1] + fg * dn.wh[t]; acc[j][2] = acc[j][2] + fb * dn.wh[t];
+                    }
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                o[j] = clampF_fast64(acc[j][0] * dn.inv_h) | (clampF_fast64(acc[j][1] * dn.inv_h) << 8) |
+                       (clampF_fast64(acc[j][2] * dn.inv_h) << 16) | (dn.al_h << 24);
+            if (mine && act) {
+                *reinterpret_cast<u32x4 *>(s_tile + (min(y, y1 - 1) - r0) * RF_TW + 4 * hl) = o;
+                if (lane_odd || (andp >> 24) != 0xffu) s_list[atomicAdd(&s_nlist, 1u)] = static_cast<uint16_t>(((y - r0) << 5) | hl);
+            }
+        }
+    }
+    __syncthreads();
+    // the per-pixel form for what phase 1 could not take, one output per thread (a thread per lane's four took 70 us on the
+    // image's left and right tiles, where one lane of every row is on the list)
+    // (translucent content is all list: the host is told, and gives the plan's next calls to the general kernel)
+    if (tid == 0 && s_nlist > 4u * static_cast<unsigned>(r1 - r0))
+        __hip_atomic_store(dn.heavy, static_cast<unsigned long long>(dn.gen), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (unsigned e = tid, n = 4 * s_nlist; e < n; e += 256) {
+        const unsigned ent = s_list[e >> 2];
+        const int row = ent >> 5, col = 4 * (ent & 31u) + (e & 3u);
+        if (bx * RF_TW + col < a.nout) s_tile[row * RF_TW + col] = resize_exact_px<false>(a, bx * RF_TW + col, r0 + row);
+    }
+    __syncthreads();
+    // ---------------- phase 2: resizeV (resize.go:120-160) out of the tile ----------------
+    const int x = bx * RF_TW + 2 * lane;
+    const int ncol = x + 1 < v.other ? 2 : (x < v.other ? 1 : 0);
+    const bool st8 = ((reinterpret_cast<uintptr_t>(v.dst) | static_cast<uintptr_t>(v.dstride)) & 7u) == 0;
+    typedef __attribute__((address_space(1))) u32x2 g_u32x2w;
+    for (int gi = gfirst + wave; gi <= glast; gi += 4) {            // wave-uniform
+        const int y0 = gi * VG, sg = v.s0[gi];
+        const bool form = !dn.odd_v[gi] && v.cnt[gi] == USH * (VG - 1) + UT && y0 + VG <= v.nout && sg == 2 * y0 + dn.base_v;   // wave-uniform
+        uint32_t and0 = 0xffffffffu, and1 = 0xffffffffu;
+        double r[VG][6];
+        if (form) {
+#pragma unroll
+            for (int j = 0; j < VG; j++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) r[j][q] = 0.0;
+            const uint32_t *tg = s_tile + (sg - r0) * RF_TW + 2 * lane;
+#pragma unroll
+            for (int i = 0; i < USH * (VG - 1) + UT; i++) {
+                const u32x2 u = *reinterpret_cast<const u32x2 *>(tg + i * RF_TW);
+                const uint32_t q0 = u[0], q1 = u[1];
+                and0 &= q0; and1 &= q1;
+                const double f0 = u8_to_f64(q0 & 0xffu), f1 = u8_to_f64((q0 >> 8) & 0xffu), f2 = u8_to_f64((q0 >> 16) & 0xffu);
+                const double f3 = u8_to_f64(q1 & 0xffu), f4 = u8_to_f64((q1 >> 8) & 0xffu), f5 = u8_to_f64((q1 >> 16) & 0xffu);
+#pragma unroll
+                for (int j = 0; j < VG; j++) {
+                    const int t = i - USH * j;
+                    if (t >= 0 && t < UT) {
+                        const double aw = dn.wv[t];
+                        r[j][0] = r[j][0] + f0 * aw; r[j][1] = r[j][1] + f1 * aw; r[j][2] = r[j][2] + f2 * aw;
+                        r[j][3] = r[j][3] + f3 * aw; r[j][4] = r[j][4] + f4 * aw; r[j][5] = r[j][5] + f5 * aw;
+                    }
+                }
+            }
+        }
+        const bool q0ok = form && (and0 >> 24) == 0xffu, q1ok = form && (and1 >> 24) == 0xffu;
+#pragma unroll
+        for (int j = 0; j < VG; j++) {
+            const int y = y0 + j;
+            if (y >= v.nout || !ncol) continue;
+            uint8_t *dp = v.dst + static_cast<size_t>(y) * v.dstride + 4 * static_cast<size_t>(x);
+            uint32_t o0 = 0, o1 = 0;
+            if (form) {
+                o0 = clampF_fast64(r[j][0] * dn.inv_v) | (clampF_fast64(r[j][1] * dn.inv_v) << 8) | (clampF_fast64(r[j][2] * dn.inv_v) << 16) | (dn.al_v << 24);
+                o1 = clampF_fast64(r[j][3] * dn.inv_v) | (clampF_fast64(r[j][4] * dn.inv_v) << 8) | (clampF_fast64(r[j][5] * dn.inv_v) << 16) | (dn.al_v << 24);
+            }
+            if (q0ok && q1ok && ncol == 2 && st8) {
+                *(g_u32x2w *)dp = (u32x2){o0, o1};
+            } else {
+                *(g_u32w *)dp = q0ok ? o0 : resize_exact_px_tile(v, s_tile, r0, 2 * lane, y);
+                if (ncol == 2) *(g_u32w *)(dp + 4) = q1ok ? o1 : resize_exact_px_tile(v, s_tile, r0, 2 * lane + 1, y);
+            }
+        }
+    }
+}
+
 // After resize_mfma_kernel: the tiles it handed back, and only those.  A fixed grid of workgroups walks the stamps (a launch
 // of every tile's workgroup that looks and leaves took 4 us of an 18 us call); the first one also passes on to the host
 // how many of the matrix kernel's workgroups gave up (a hint for the next call with these tables: resize_fused's cool-down).
@@ -1666,6 +1829,9 @@ struct fnx_resize_plan {
     // guard form
     bool guard_ok = false;
     int HO = 0, NV = 0, ngroups = 0, npx = 0;
+    unsigned d21_fit = 0;            // vertical plans: bit ng = tiles of ng V groups hold at most D21_ROWS rows (resize_dense21_kernel)
+    bool d21_heavy = false;          // H plans: the last resize_dense21_kernel call met translucent content (until the matrix kernel's next try)
+    uint32_t d21_last_gen = 0;
     int fused_ng = 0, fused_ng32 = 0;   // vertical plans: V groups per 64-row / 32-row tile of resize_fused_kernel (0: not eligible)
     float guard = 0;
     const float *d_dense = nullptr;
@@ -1673,6 +1839,13 @@ struct fnx_resize_plan {
     const uint32_t *d_alpha = nullptr;
     const double *d_aw = nullptr, *d_inv = nullptr;
     fnx::RzMfTable mf;               // resize_mfma.hip: the matrix form (mf.ok: covered)
+    // resize_dense21_kernel (exact 2:1): the twelve weights aw = 255 w every interior output shares, 1 / sum aw, the alpha byte,
+    // and one flag per group (H: 2 outputs, V: 4) that says "not of that form" (clamped tap lists at the image's edges)
+    bool d21_ok = false;
+    double d21_w[12] = {}, d21_inv = 0;
+    uint32_t d21_alpha = 0;
+    int d21_base = 0;                // first tap of output d: 2 d + base
+    const uint8_t *d_odd = nullptr;
     int mf_cool = 0;                 // H plans: calls left to skip the matrix kernel (it handed most of an image back)
     int mf_cool_len = 32;            // half the length of the next such pause
 };
@@ -1703,9 +1876,44 @@ static bool resize_guard_disabled()
 
 // Host side of the guard form.  Returns false when the table is outside what the guard kernels cover
 // (gaps in the tap lists, windows too wide for the register matrix, a <= 0.5 somewhere, wild weights).
+// The 2:1 form of a plan (resize_dense21_kernel): is there ONE list of twelve weights that the outputs share, each output two
+// source pixels after the one before?  W, 1 / sum and the alpha byte are taken from the middle output; `odd[g]` marks the
+// groups (H: 2 outputs, V: 4) with an output that differs in any bit or lies elsewhere.  ok: at least three quarters match.
+static void build_dense21(const TapTable &t, int group, const std::vector<double> &invv, const std::vector<uint32_t> &abyte,
+                          fnx_resize_plan &p, std::vector<uint8_t> &odd)
+{
+    p.d21_ok = false;
+    odd.clear();
+    const int nout = t.nout, ng = (nout + group - 1) / group, dm = nout / 2;
+    if (nout < 2 * group || t.off[dm + 1] - t.off[dm] != 12) return;
+    const int base = t.idx[t.off[dm]] - 2 * dm;                     // first tap of output d: 2 d + base
+    p.d21_base = base;
+    for (int k = 0; k < 12; k++) p.d21_w[k] = 255.0 * t.wt[t.off[dm] + k];
+    p.d21_inv = invv[dm];
+    p.d21_alpha = abyte[dm];
+    if (p.d21_w[0] == 0.0) return;
+    auto like = [&](int d) {
+        if (d >= nout) return false;
+        const int t0 = t.off[d];
+        if (t.off[d + 1] - t0 != 12 || t.idx[t0] != 2 * d + base || invv[d] != p.d21_inv || abyte[d] != p.d21_alpha) return false;
+        for (int k = 0; k < 12; k++)
+            if (255.0 * t.wt[t0 + k] != p.d21_w[k]) return false;
+        return true;
+    };
+    odd.assign(ng, 0);
+    int nodd = 0;
+    for (int g = 0; g < ng; g++) {
+        bool all = true;
+        for (int j = 0; j < group; j++) all = all && like(g * group + j);
+        odd[g] = all ? 0 : 1;
+        nodd += odd[g];
+    }
+    p.d21_ok = 4 * nodd <= ng;
+}
+
 static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_plan &p, std::vector<float> &dense,
                         std::vector<int32_t> &s0v, std::vector<int32_t> &cntv, std::vector<uint32_t> &alphav,
-                        std::vector<double> &awv, std::vector<double> &invv)
+                        std::vector<double> &awv, std::vector<double> &invv, std::vector<uint8_t> &odd)
 {
     const int nout = t.nout;
     if (p.contig_taps <= 0) return false;
@@ -1828,6 +2036,15 @@ static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_p
         };
         p.fused_ng = groups_that_fit(RF_RMAX);
         p.fused_ng32 = groups_that_fit(32);
+        p.d21_fit = 0;
+        for (int cand = 1; mono && cand <= D21_NGMAX; cand++) {
+            bool fits = true;
+            for (int g0 = 0; g0 < ng && fits; g0 += cand) {
+                const int gl = std::min(g0 + cand, ng) - 1;
+                if (s0v[gl] + cntv[gl] - s0v[g0] > D21_ROWS) fits = false;
+            }
+            if (fits) p.d21_fit |= 1u << cand;
+        }
     }
     // the bound of the header comment
     const double top = 255.0 * smax + 1.0;
@@ -1839,6 +2056,7 @@ static bool build_guard(const TapTable &t, int srcN, bool vertical, fnx_resize_p
     if (static_cast<double>(gf) < G) gf = std::nextafterf(gf, 1.0f);
     p.guard = gf;
     (void)srcN;
+    build_dense21(t, vertical ? RG_VG : RG_HO, invv, abyte, p, odd);
     return true;
 }
 
@@ -1890,16 +2108,17 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
     std::vector<int32_t> s0v, cntv;
     std::vector<uint32_t> alphav;
     std::vector<double> awv, invv;
-    p->guard_ok = build_guard(t, srcN, vertical, *p, dense, s0v, cntv, alphav, awv, invv);
-    if (!p->guard_ok) { dense.clear(); s0v.clear(); cntv.clear(); alphav.clear(); awv.clear(); invv.clear(); }
+    std::vector<uint8_t> odd;
+    p->guard_ok = build_guard(t, srcN, vertical, *p, dense, s0v, cntv, alphav, awv, invv, odd);
+    if (!p->guard_ok) { dense.clear(); s0v.clear(); cntv.clear(); alphav.clear(); awv.clear(); invv.clear(); odd.clear(); p->d21_ok = false; }
     // one blob: wt | off | idx | dense | s0 | cnt | alpha | aw | inv, each 16-byte aligned
     auto al16 = [](size_t n) { return (n + 15) & ~size_t(15); };
     const size_t b_wt = al16(sizeof(double) * std::max(ntaps, 1)), b_off = al16(sizeof(int32_t) * (t.nout + 1)),
                  b_idx = al16(sizeof(int32_t) * std::max(ntaps, 1)), b_dense = al16(sizeof(float) * dense.size()),
                  b_s0 = al16(sizeof(int32_t) * s0v.size()), b_cnt = al16(sizeof(int32_t) * cntv.size()),
                  b_alpha = al16(sizeof(uint32_t) * alphav.size()), b_aw = al16(sizeof(double) * awv.size()),
-                 b_inv = al16(sizeof(double) * invv.size());
-    const size_t total = b_wt + b_off + b_idx + b_dense + b_s0 + b_cnt + b_alpha + b_aw + b_inv + 16;
+                 b_inv = al16(sizeof(double) * invv.size()), b_odd = al16(odd.size() + 64);   // (+ 64: lanes past the last group read on)
+    const size_t total = b_wt + b_off + b_idx + b_dense + b_s0 + b_cnt + b_alpha + b_aw + b_inv + b_odd + 16;
     std::vector<unsigned char> host(total, 0);
     size_t o = 0;
     std::memcpy(host.data() + o, t.wt, sizeof(double) * ntaps); const size_t o_wt = o; o += b_wt;
@@ -1916,7 +2135,10 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
     if (!awv.empty()) std::memcpy(host.data() + o, awv.data(), sizeof(double) * awv.size());
     const size_t o_aw = o; o += b_aw;
     if (!invv.empty()) std::memcpy(host.data() + o, invv.data(), sizeof(double) * invv.size());
-    const size_t o_inv = o;
+    const size_t o_inv = o; o += b_inv;
+    std::memset(host.data() + o, 1, b_odd);                          // (what lies past the last group is "odd")
+    if (!odd.empty()) std::memcpy(host.data() + o, odd.data(), odd.size());
+    const size_t o_odd = o;
     FNX_HIP(hipMalloc(&p->blob, total));
     // synchronous copy: the host vector dies with this call (plans are built once per table and ctx)
     hipError_t e = hipMemcpy(p->blob, host.data(), total, hipMemcpyHostToDevice);
@@ -1935,6 +2157,7 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
     p->d_alpha = reinterpret_cast<const uint32_t *>(base + o_alpha);
     p->d_aw = reinterpret_cast<const double *>(base + o_aw);
     p->d_inv = reinterpret_cast<const double *>(base + o_inv);
+    p->d_odd = base + o_odd;
     if (p->guard_ok) (void)resize_mfma_build(t, srcN, vertical, invv.data(), &p->mf);
     p->last_use = tick++;
     *out = p.get();
@@ -2018,7 +2241,13 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     // so that one synthetic image in a stream of photographs does not send the next 64 of them through fp64 loops)
     const bool dense_form = use_mf && ph->mf_cool > 0 && ph->mf_cool_len >= 128 && !low && ph->NV == 4 && !dense_off;
     if (use_mf && ph->mf_cool > 0) { ph->mf_cool--; use_mf = false; }
+    if (ph->d21_last_gen != 0 && ctx->rz_report &&
+        static_cast<uint32_t>(*reinterpret_cast<volatile unsigned long long *>(ctx->rz_report + 1)) == ph->d21_last_gen) {
+        ph->d21_heavy = true;
+        ph->d21_last_gen = 0;
+    }
     if (use_mf) {
+        ph->d21_heavy = false;
         const size_t cells = static_cast<size_t>(grid.x) * grid.y;
         if (cells + 2 > ctx->rz_todo_cap) {
             FNX_HIP(hipStreamSynchronize(ctx->stream));
@@ -2031,8 +2260,8 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             ctx->rz_gen = 0;
         }
         if (!ctx->rz_report) {
-            FNX_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->rz_report), sizeof(unsigned long long), hipHostMallocMapped));
-            *ctx->rz_report = 0;
+            FNX_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->rz_report), 2 * sizeof(unsigned long long), hipHostMallocMapped));
+            ctx->rz_report[0] = ctx->rz_report[1] = 0;               // [1]: resize_dense21_kernel's word
         }
         if (++ctx->rz_gen == 0) {                                   // 2^32 calls later: start the stamps over
             FNX_HIP(hipMemsetAsync(ctx->rz_todo, 0, sizeof(uint32_t) * ctx->rz_todo_cap, ctx->stream));
@@ -2076,6 +2305,42 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             default: hipLaunchKernelGGL((resize_fused_sparse_kernel<4, RF_RMAX>), sgrid, dim3(256), 0, ctx->stream, fa); break;
             }
         }
+        FNX_HIP(hipGetLastError());
+        return prof_end(ctx);
+    }
+    static const bool d21_off = [] { const char *e = getenv("FNX_RF_DENSE21"); return e && e[0] == '0'; }();   // A/B and tests
+    if (dense_form && ph->d21_ok && pv->d21_ok && srcW >= 20 && !d21_off && !ph->d21_heavy && ctx->rz_report && (pv->d21_fit & 2u)) {
+        // V groups per tile: the count whose busiest CU has least to do.  A CU's workgroups share its SIMDs, so its time goes
+        // with (workgroups on it) x (instructions of a workgroup's longest wave: ~534 per pair of tmp rows, ~1100 per V group)
+        int ng21 = 1;
+        double best = 0;
+        for (int cand = 1; cand <= D21_NGMAX; cand++) {
+            if (!(pv->d21_fit >> cand & 1u)) continue;
+            const double wgs = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand);
+            const int rows = 2 * RG_VG * cand + 10, pairs = ((rows + 3) / 4 + 1) / 2;
+            const double cost = std::ceil(wgs / ctx->num_cus) * (534.0 * pairs + 1100.0 * ((cand + 3) / 4));
+            if (best == 0 || cost < best) { best = cost; ng21 = cand; }
+        }
+        if (const char *e = getenv("FNX_RF_NG21")) {                 // experiments
+            const int want = atoi(e);
+            if (want >= 1 && want <= D21_NGMAX && (pv->d21_fit >> want & 1u)) ng21 = want;
+        }
+        fa.ng = ng21;
+        const dim3 grid21(gx, (pv->ngroups + ng21 - 1) / ng21);
+        Dense21Args dn{};
+        for (int k = 0; k < 12; k++) { dn.wh[k] = ph->d21_w[k]; dn.wv[k] = pv->d21_w[k]; }
+        dn.inv_h = ph->d21_inv; dn.inv_v = pv->d21_inv;
+        dn.al_h = ph->d21_alpha; dn.al_v = pv->d21_alpha;
+        dn.base_h = ph->d21_base; dn.base_v = pv->d21_base;
+        dn.odd_h = ph->d_odd; dn.odd_v = pv->d_odd;
+        void *dev_report = nullptr;
+        FNX_HIP(hipHostGetDevicePointer(&dev_report, ctx->rz_report, 0));
+        dn.heavy = static_cast<unsigned long long *>(dev_report) + 1;
+        if (++ctx->d21_gen == 0) ctx->d21_gen = 1;
+        dn.gen = ctx->d21_gen;
+        ph->d21_last_gen = ctx->d21_gen;
+        note_route(ctx, FNX_PROF_RESIZE, "resize_dense21_kernel");
+        hipLaunchKernelGGL(resize_dense21_kernel, grid21, dim3(256), 0, ctx->stream, fa, dn);
         FNX_HIP(hipGetLastError());
         return prof_end(ctx);
     }

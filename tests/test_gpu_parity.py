@@ -387,13 +387,13 @@ def test_lanczos_resize_dense_form_after_two_cool_downs(orc):
         seen.add(c.last_kernel(fennec_amd.PROF_RESIZE))
         if k % 16 == 0 or k > 60:
             assert np.array_equal(got, want), k
-    assert "resize_fused_dense_kernel" in seen and any(s.startswith("resize_mfma_kernel") for s in seen), seen
+    assert ("resize_dense21_kernel" in seen or "resize_fused_dense_kernel" in seen) and any(s.startswith("resize_mfma_kernel") for s in seen), seen
     # still in the cool-down: other content through the dense form
     holes = ramp.copy(); holes[h // 2: h // 2 + 9, 5: w // 2, 3] = 3; holes[0, 0, 3] = 254
     noise = _opaque(synth.noise_image(w, h, 77, alpha=True))
     for img in (holes, noise, ramp):
         got = c.lanczosResize(img, dw, dh)
-        assert c.last_kernel(fennec_amd.PROF_RESIZE) in ("resize_fused_dense_kernel", "resize_mfma_kernel + resize_fused_sparse_kernel")
+        assert c.last_kernel(fennec_amd.PROF_RESIZE) in ("resize_dense21_kernel", "resize_fused_dense_kernel", "resize_mfma_kernel + resize_fused_sparse_kernel")
         assert np.array_equal(got, orc.lanczos_resize(img, dw, dh))
     c.close()
 
