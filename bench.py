@@ -1236,13 +1236,17 @@ def other_workload_line(args, embedded: bool = False):
             # which form of the one-launch kernel the downscale takes in this workload: on SURVEY 8(d)'s ramp the plan is in its
             # tie-dense cool-down from the 66th call on -- the committed profile of this same command says
             # which kernel it launched
-            dense = committed_traffic_named("resize_fused_dense_kernel<4", "config3")
-            dense_file = source_file("traffic")
-            plain = committed_traffic_named("resize_fused_kernel<4", "config3")
-            plain_file = source_file("traffic")
-            use_dense = dense is not None
-            down_traffic, down_file = (dense, dense_file) if use_dense else (plain, plain_file)
-            out["roofline"] = {"kernel": (("resize_fused_dense_kernel<4> (a plan in its second tie-dense cool-down: the tile without fp32 passes)" if use_dense else "resize_fused_kernel<4>") +
+            down_traffic, down_file, down_name = None, None, "resize_fused_kernel<4>"
+            for pat, label in (("resize_dense21_kernel", "resize_dense21_kernel (a plan in its second tie-dense cool-down: the exact 2:1 form, "
+                                                         "weights as kernel arguments, 74-row tiles)"),
+                               ("resize_fused_dense_kernel<4", "resize_fused_dense_kernel<4> (a plan in its second tie-dense cool-down: "
+                                                               "the tile without fp32 passes)"),
+                               ("resize_fused_kernel<4", "resize_fused_kernel<4>")):
+                t = committed_traffic_named(pat, "config3")
+                if t is not None:
+                    down_traffic, down_file, down_name = t, source_file("traffic"), label
+                    break
+            out["roofline"] = {"kernel": (down_name +
                                           " (lanczosResize 4K -> 1080p in one launch: resizeH into an LDS tile, resizeV out of it; "
                                           "the largest single kernel of the step)") if fused else
                                          "resize_h_guard_kernel<4> (resizeH of the 4K -> 1080p downscale: the largest single kernel of the step)",
