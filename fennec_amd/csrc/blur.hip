@@ -846,7 +846,8 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
 constexpr int NHEAD = 260 + 257 * 8;   // uint32 words at the head of the table blob: magic[c] (c <= 256, padded to 260), tiedown[8 c + w]
 static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH, int th_fixed = 0)
 {
-    if (radius < 1 || radius > SCORE_RMAX || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
+    // (th_fixed: the matrix-pipe kernels' tile, whose rows do not depend on the radius -- radii up to 14 since r5)
+    if (radius < 1 || radius > (th_fixed ? 14 : SCORE_RMAX) || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
         h >= (1 << 24))
         return false;
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
@@ -909,7 +910,7 @@ static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int ds
         };
         for (int x0 = 0; x0 < w; x0 += 64) nbx = std::max(nbx, span(bx, x0, std::min(w, x0 + 64)));
         for (int y0 = 0; y0 < h; y0 += th) nby = std::max(nby, span(by, y0, std::min(h, y0 + th)));
-        if ((nbx + 1) * (nby + 1) <= SCORE_NBOX) break;
+        if ((nbx + 1) * (nby + 1) <= (th_fixed > 272 ? 2 * SCORE_NBOX : SCORE_NBOX)) break;   // (th_fixed > 272: the wide matrix kernel's long segments)
         th = 0;
     }
     if (!th) return false;
@@ -960,15 +961,20 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
                        uint8_t *planes, size_t plane, int dstW, int dstH)
 {
     if (n > 65535) return FNX_NOOP;   // grid.z
-    if (radius < 1 || radius > SCORE_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
     const bool exact = flags & FNX_BLUR_EXACT;
-    if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
-    // radius 7, 8: GaussianBlur alone runs on the matrix pipe (blur_mfma_wide_kernel), whose fast-mode bytes are not this
-    // file's fp32 kernel's: the one-pass form must return what the two calls return, so it leaves these radii to them
-    if (radius > 6 && blur_mfma_takes(kernel, radius, w, h, exact)) return FNX_NOOP;
-    const bool tall_pref = direct_tall(ctx, radius, n, w, h);
+    // radii 7 .. 14 (r5): GaussianBlur alone runs on the matrix pipe (blur_mfma_wide_kernel), whose fast-mode bytes are not this
+    // file's fp32 kernel's; the one-pass form must return what the two calls return, so it is that kernel's SCORE form or none
+    const bool wide = radius > 6 && blur_mfma_wide_scored_covers(kernel, radius, w, h, exact);
+    if (!wide) {
+        if (radius < 1 || radius > SCORE_RMAX) return FNX_NOOP;   // before any tile arithmetic (TH would be <= 0)
+        if (exact && !guard_kernel_ok(kernel, radius)) return FNX_NOOP;
+        if (radius > 6 && blur_mfma_takes(kernel, radius, w, h, exact)) return FNX_NOOP;
+    }
+    const bool tall_pref = wide ? false : direct_tall(ctx, radius, n, w, h);
     // the matrix-pipe kernel (blur_mfma.hip) where its table and its box geometry fit; its tile is 64 px x seg rows
-    const int seg = blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272, 3) : 0;
+    static const int wide_cap = [] { const char *e = getenv("FNX_MFMA_WIDE_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
+    const int seg = wide ? blur_mfma_segment(ctx, n, w, h, wide_cap, 2)
+                         : (blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272, 3) : 0);
     ScoreGeom &g = ctx->score_geom;
     if (!(g.w == w && g.h == h && g.dstW == dstW && g.dstH == dstH && g.radius == radius && g.tall_pref == tall_pref && g.seg == seg)) {
         g.w = w; g.h = h; g.dstW = dstW; g.dstH = dstH; g.radius = radius; g.tall_pref = tall_pref; g.seg = seg;
@@ -976,7 +982,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
         // where GaussianBlur alone runs on the matrix pipe but its one-pass geometry does not fit (boxes under 4 px: long side
         // 1843..2047), this file's fp32 kernel would return fast-mode bytes the two calls do not: the two calls take the step
         // (tools/fuzz_blur.py: 72 such shapes in 6 528)
-        g.ok = g.mfma || (seg == 0 && build_score_geom(g, w, h, radius, dstW, dstH));
+        g.ok = g.mfma || (!wide && seg == 0 && build_score_geom(g, w, h, radius, dstW, dstH));
     }
     if (!g.ok) return FNX_NOOP;
     const std::vector<int32_t> &map = g.map;
@@ -991,7 +997,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     FusedArgs fa{};
     fa.srcs = srcs; fa.dsts = dsts;
     fa.sstride = sstride; fa.dstride = dstride; fa.w = w; fa.h = h;
-    for (int i = 0; i < 2 * radius + 1; i++) {
+    for (int i = 0; i < 2 * radius + 1 && !wide; i++) {
         fa.wt[i] = static_cast<float>(kernel[i]);
         fa.wd[i] = kernel[i];
     }
@@ -1002,7 +1008,8 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     fa.slabs = static_cast<unsigned long long *>(slabs);
     int st;
     if (g.mfma) {
-        st = launch_blur_mfma_scored(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride, fa.bx, fa.by, fa.slabs, nbx, nby, th);
+        st = wide ? launch_blur_mfma_wide_scored(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride, fa.bx, fa.by, fa.slabs, nbx, nby, th)
+                  : launch_blur_mfma_scored(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride, fa.bx, fa.by, fa.slabs, nbx, nby, th);
         if (st == FNX_NOOP) return FNX_NOOP;   // (blur_mfma_covers said yes: not reached) the caller runs the two ops back to back
     } else {
         st = exact ? launch_direct_radius<true, true>(ctx, radius, n, fa, tall)

@@ -50,6 +50,7 @@ constexpr int MF_WT = 64 * MF_P + 256;   // ring bytes per wave: 64 byte columns
 constexpr int MF_SP = 352;           // pitch of a staged source row (19 chunks of 16 bytes): conflict-free as the A operand (tools/lds_conflicts.py)
 constexpr int MF_OP = 272;           // pitch of an output row in its stage
 constexpr int MF_SEG_SCORE = 272;    // most rows per workgroup with SCORE (row tables and box tables in LDS)
+constexpr int MF_SEG_SCORE_WIDE = 544;   // ... of blur_mfma_wide_kernel<2, ., SCORE>: two workgroups per CU either way (its ring and stages are 43 KB)
 
 struct MfmaArgs {
     const uint8_t *src;
@@ -525,14 +526,22 @@ __device__ __forceinline__ uint32_t mf_exact_u_n(const double *wd, const uint8_t
     return clampF_dev(acc);
 }
 
-template <int NKH, bool GUARD>
+// r5, SCORE (NKH = 2: radii 7 .. 14): SSIMFast's box sums of the source and of the blurred image in the same pass, exactly as
+// blur_mfma_kernel<SCORE> takes them -- two more matrix instructions per 16 x 16 px block and 4 + 4 LDS atomics; the strip's own
+// 16 px of a staged row start 4 RF bytes into the window (8-byte aligned: two 8-byte reads make the A operand).
+template <int NKH, bool GUARD, bool SCORE = false>
 __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
 {
     using C = MfWide<NKH>;
     constexpr int RF = C::RF, NC = C::NC, SP = C::SP, P = C::P, WT = C::WT, OP = MF_OP, NT = C::NT;
+    static_assert(!SCORE || (4 * RF) % 8 == 0, "the source-side A operand is read as two 8-byte halves");
     __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[2 * 16 * SP];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[2 * 16 * OP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowh[SCORE ? MF_SEG_SCORE_WIDE + 48 : 4];   // (see blur_mfma_kernel)
+    __shared__ __attribute__((aligned(16))) uint32_t s_rowv[SCORE ? MF_SEG_SCORE_WIDE + 16 : 4];
+    __shared__ uint32_t s_colbox[SCORE ? 64 : 1];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_box[];
 
     const int tile = xcd_tile(blockIdx.x, a.tiles);
     if (tile < 0) return;
@@ -577,17 +586,66 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
     const int o_r = orow * OP + 16 * och;
     const int xo = x0 + 4 * och;
 
+    // ---- SCORE set-up (blur_mfma_kernel's, with the wide frame's row offset) ----
+    v4i bbox = {0, 0, 0, 0}, sbox = {0, 0, 0, 0};
+    uint32_t coln = 0;
+    const int slabn = SCORE ? (a.nbx + 1) * (a.nby + 1) : 0;
+    uint32_t *tbl_s = s_box, *tbl_b = s_box + 4 * slabn;
+    auto score_setup = [&]() {
+        for (int e = tid; e < 8 * slabn; e += 256) s_box[e] = 0;
+        const int rowbytes = 16 * (a.nbx + 1);
+        const int b0y = a.by[y0];
+        for (int u = tid; u < 16 * NI; u += 256) {                  // staged row u = tile row u - RF
+            const int t = u - RF;
+            const int v = (t >= 0 && t < a.seg && y0 + t < a.h) ? a.by[y0 + t] : -1;
+            s_rowh[u] = rowbytes * ((v >= 0 && b0y >= 0) ? v - b0y : a.nby);
+        }
+        for (int t = tid; t < 16 * NJ; t += 256) {
+            const int v = (t < a.seg && y0 + t < a.h) ? a.by[y0 + t] : -1;
+            s_rowv[t] = rowbytes * ((v >= 0 && b0y >= 0) ? v - b0y : a.nby);
+        }
+        if (tid < 64) {
+            const int b0x = a.bx[x0], v = x0 + tid < a.w ? a.bx[x0 + tid] : -1;
+            s_colbox[tid] = (v >= 0 && b0x >= 0) ? v - b0x : 255u;
+        }
+        __syncthreads();
+        uint32_t first = 255u;
+        for (int i = 0; i < 16; i++) first = min(first, s_colbox[16 * wave + i]);
+        const int slot = r / 3, ch = r - 3 * slot;
+        int cnt = 0;
+        for (int i = 0; i < 16; i++) cnt += (r < 15 && s_colbox[16 * wave + i] == first + slot) ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool in = r < 15 && first != 255u && s_colbox[16 * wave + 4 * g + e] == first + slot;
+            bbox[e] = in ? (1 << (8 * ch)) : 0;
+        }
+        const int seed = 128 * cnt;
+        sbox = (v4i){seed, seed, seed, seed};
+        const uint32_t bc = (r < 15 && first != 255u && cnt > 0) ? first + slot : static_cast<uint32_t>(a.nbx);
+        coln = 16u * bc + 4u * (r < 15 ? ch : 3);
+    };
+
     auto stage_write = [&](const u32x4 (&d)[2], int buf) {
         uint8_t *sb = s_stage + buf * 16 * SP;
         *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
         if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
     };
-    auto hset = [&](int buf, int slot) {
+    auto hset = [&](int s, int buf, int slot) {
         const uint8_t *sbuf = s_stage + buf * 16 * SP;
         const uint8_t *sb = sbuf + st_r;
         v4i c2[4], c1[4], c0[4];
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) { c2[qq] = zero; c1[qq] = zero; c0[qq] = sh; }
+        if constexpr (SCORE) {   // source side of the box sums: the strip's own 16 px of these 16 staged rows
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(sb + 4 * RF), hi = *reinterpret_cast<const u32x2 *>(sb + 4 * RF + 8);
+            const v4i A = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+            const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
+            const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowh + 16 * s + 4 * g);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_s) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
 #pragma unroll
         for (int kk = 0; kk < NKH; kk++)
 #pragma unroll
@@ -709,7 +767,18 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                         if (lane == L) op[4 * q + i] = static_cast<uint8_t>(e);
                     }
                 }
+                if constexpr (SCORE) o = *reinterpret_cast<const u32x4 *>(op);       // the box sums are those of the exact image
             }
+        }
+        if constexpr (SCORE) {   // blurred side: lane (row r, chunk g) holds 4 px of row r -- an A operand as it is
+            const u32x4 os = o ^ 0x80808080u;
+            const v4i A = {(int)os[0], (int)os[1], (int)os[2], (int)os[3]};
+            const v4i cb = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, bbox, sbox, 0, 0, 0);
+            const u32x4 ro = *reinterpret_cast<const u32x4 *>(s_rowv + 16 * j + 4 * g);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl_b) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
 
@@ -753,13 +822,14 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
         __builtin_amdgcn_sched_barrier(0);
         hload(1, rb);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SCORE) score_setup();
         auto step = [&](int s, u32x4 (&d)[2], auto part) {
             constexpr int par = decltype(part)::value;
             if (s < NI) stage_write(d, par);
             if (XEDGE) { if (s + 2 < NI) hload(s + 2, d); } else hload(min(s + 2, NI - 1), d);
             if (s >= 5 && s - 5 < NJ) out_store(s - 5, par);
             __syncthreads();
-            if (s < NI) hset(par, s & 3);
+            if (s < NI) hset(s, par, s & 3);
             if (s >= 3 && s - 3 < NJ) vset(s - 3, par);
         };
 #pragma unroll 1
@@ -769,6 +839,15 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
         }
     };
     if (xedge) march(std::true_type{}); else march(std::false_type{});
+
+    if constexpr (SCORE) {   // the tile's slab (blur_mfma_kernel's)
+        __syncthreads();
+        unsigned long long *slab = a.slabs + (static_cast<size_t>(z) * a.tiles + tile) * 2 * slabn;
+        for (int e = tid; e < 2 * slabn; e += 256) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(s_box + 4 * e);
+            slab[e] = static_cast<unsigned long long>(v.x | (v.y << 16)) | (static_cast<unsigned long long>(v.z) << 32);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -945,8 +1024,8 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
 }
 
 // blur_mfma_wide_kernel's table: BH[NKH][3][64] x 16 bytes | BV[3][64] x 16 bytes | 2 RF + 1 fp64 weights, centred
-template <int NKH>
-static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights &q, const double *kernel, int radius, bool exact)
+template <int NKH, bool SCORE = false>
+static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights &q, const double *kernel, int radius, bool exact, size_t lds = 0)
 {
     using C = MfWide<NKH>;
     constexpr int RF = C::RF;
@@ -983,9 +1062,15 @@ static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights
     dim3 grid(8 * ((ma.tiles + 7) / 8), n);
     LaunchEvents ev;
     FNX_TRY(prof_bind(ctx, FNX_PROF_MAIN, &ev));
-    note_route(ctx, FNX_PROF_MAIN, exact ? "blur_mfma_wide_kernel<GUARD>" : "blur_mfma_wide_kernel");
-    if (exact) hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, true>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
-    else hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, false>), grid, dim3(256), 0, ctx->stream, ev.start, ev.stop, 0, ma);
+    if constexpr (SCORE) {               // (launch_mfma_cfg: the step's tail on the ctx's second stream waits for this event)
+        if (!ev.stop) ev.stop = ctx->ev_blur[ctx->parity];
+        ctx->blur_done = ev.stop;
+        note_route(ctx, FNX_PROF_MAIN, exact ? "blur_mfma_wide_kernel<SCORE, GUARD>" : "blur_mfma_wide_kernel<SCORE>");
+    } else {
+        note_route(ctx, FNX_PROF_MAIN, exact ? "blur_mfma_wide_kernel<GUARD>" : "blur_mfma_wide_kernel");
+    }
+    if (exact) hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, true, SCORE>), grid, dim3(256), lds, ctx->stream, ev.start, ev.stop, 0, ma);
+    else hipExtLaunchKernelGGL((blur_mfma_wide_kernel<NKH, false, SCORE>), grid, dim3(256), lds, ctx->stream, ev.start, ev.stop, 0, ma);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
 }
@@ -1039,6 +1124,34 @@ int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
     ma.bx = bx; ma.by = by; ma.slabs = slabs; ma.nbx = nbx; ma.nby = nby;
     const size_t lds = sizeof(uint32_t) * 8 * static_cast<size_t>(nbx + 1) * (nby + 1);
     return exact ? launch_mfma_cfg<true, true>(ctx, n, ma, lds) : launch_mfma_cfg<true, false>(ctx, n, ma, lds);
+}
+
+// radii 7 .. 14 (r5): the same through blur_mfma_wide_kernel<2, ., SCORE>
+bool blur_mfma_wide_scored_covers(const double *kernel, int radius, int w, int h, bool exact)
+{
+    if (radius > MfWide<2>::RF || (exact && !blur_mfma_exact_enabled())) return false;
+    return blur_mfma_wide_covers(kernel, radius, w, h);
+}
+int launch_blur_mfma_wide_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
+                                 int radius, int flags, uint8_t *const *dsts, int dstride, const int32_t *bx, const int32_t *by,
+                                 unsigned long long *slabs, int nbx, int nby, int seg)
+{
+    const bool exact = flags & FNX_BLUR_EXACT;
+    if (!blur_mfma_wide_scored_covers(kernel, radius, w, h, exact) || seg > MF_SEG_SCORE_WIDE) return FNX_NOOP;
+    MfmaWeights q;
+    mfma_quantise(kernel, radius, &q, MF_RWIDE);
+    const long long gq = exact ? static_cast<long long>(std::ceil(q.err255)) + 2 : 0;
+    if (gq > (1 << 20)) return FNX_NOOP;
+    MfmaArgs ma{};
+    ma.srcs = srcs; ma.dsts = dsts;
+    ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
+    ma.seed_h = static_cast<int>((1u << 23) + static_cast<uint32_t>(gq));
+    ma.seed_v = static_cast<int>((1u << 23) + (1u << 31) + static_cast<uint32_t>(gq));
+    ma.thr = static_cast<int>(2 * gq);
+    ma.seg = seg;
+    ma.bx = bx; ma.by = by; ma.slabs = slabs; ma.nbx = nbx; ma.nby = nby;
+    const size_t lds = sizeof(uint32_t) * 8 * static_cast<size_t>(nbx + 1) * (nby + 1);
+    return launch_mfma_wide<2, true>(ctx, n, ma, q, kernel, radius, exact, lds);
 }
 
 }  // namespace fnx

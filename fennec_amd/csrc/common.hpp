@@ -286,6 +286,10 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
 int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
                             int radius, int flags, uint8_t *const *dsts, int dstride, const int32_t *bx, const int32_t *by,
                             unsigned long long *slabs, int nbx, int nby, int seg);
+bool blur_mfma_wide_scored_covers(const double *kernel, int radius, int w, int h, bool exact);
+int launch_blur_mfma_wide_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
+                                 int radius, int flags, uint8_t *const *dsts, int dstride, const int32_t *bx, const int32_t *by,
+                                 unsigned long long *slabs, int nbx, int nby, int seg);
 int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, uint8_t *dst,
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,

@@ -820,6 +820,44 @@ def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
     _one_pass_case(ctx, orc, [synth.large_photo(500, 300, 2)], 2.0)
 
 
+@pytest.mark.parametrize("sigma,radius", [(2.3, 7), (2.6, 8), (3.0, 9), (4.0, 12), (4.6, 14)])
+def test_blur_ssimfast_one_pass_wide_radii(ctx, orc, sigma, radius):
+    """r5: radii 7 .. 14 take the one-pass form too (blur_mfma_wide_kernel<2, ., SCORE>): the images are the two-call route's
+    bit for bit (fast and exact), the exact ones are the oracle's, the scores are SSIMFast of what came back; shapes with
+    edge strips, short last segments and a translucent image."""
+    import torch
+    imgs = [synth.large_photo(3840, 2160, 11), synth.noise_image(3840, 2160, 12, alpha=True)]
+    for exact in (False, True):
+        _one_pass_case(ctx, orc, imgs, sigma, exact=exact, check_oracle=(0, 1))
+    d = [torch.from_numpy(imgs[1]).cuda()]
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=True)
+    assert "blur_mfma_wide_kernel<SCORE" in ctx.last_kernel(1), ctx.last_kernel(1)      # the route the library took
+    want = orc.gaussian_blur(imgs[1], sigma, procs=16)
+    assert np.array_equal(outs[0].cpu().numpy(), want)
+    assert abs(ss[0] - orc.ssim_fast(imgs[1], want, procs=16)) <= SSIM_TOL
+    for w, h in ((3001, 2005), (2560, 1440), (4099, 2817), (7680, 4320), (2900, 700)):
+        _one_pass_case(ctx, orc, [synth.noise_image(w, h, w + radius, alpha=True), synth.large_photo(w, h, 2)], sigma,
+                       exact=(w & 1) == 1, check_oracle=(0,))
+
+
+def test_blur_ssimfast_one_pass_wide_exact_ties(ctx, orc):
+    """the guarded wide kernel's SCORE form where whole tiles sit on rounding boundaries (dyadic kernel, stripes): the box sums
+    must be those of the patched image"""
+    import torch
+    k = _binomial(10)
+    w, h = 2048, 1200
+    cols = np.zeros((h, w, 4), np.uint8); cols[:, 1::2, :3] = 1; cols[..., 3] = 255
+    mixed = synth.noise_image(w, h, 77, alpha=True); mixed[300:900, 500:1500, :3] &= 1
+    imgs = [cols, mixed]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    outs, ss = ctx.GaussianBlurSSIMFastBatch(d, 1.0, exact=True, kernel=k)
+    for i, img in enumerate(imgs):
+        want = orc.gaussian_blur(img, 1.0, kernel=k, procs=8)
+        assert np.array_equal(outs[i].cpu().numpy(), want), i
+        assert abs(ss[i] - orc.ssim_fast(img, want, procs=8)) <= SSIM_TOL, i
+
+
 def test_reference_named_blur_is_exact_for_host_images(orc):
     """fennec_GaussianBlur (the drop-in mirror): bit-exact for host images, fast kernel for device tensors."""
     import torch
@@ -1234,6 +1272,58 @@ def test_apply_palette_device_and_extremes(ctx, orc):
     assert np.array_equal(gi, orc.apply_palette(img, bw)[0]) and gi.max() <= 1
     with pytest.raises(fennec_amd.FennecError):
         ctx.applyPalette(img, np.array([[1, 2, 3, 200]], dtype=np.uint8))      # translucent palette entry
+
+
+def _clustered_palette(n, seed):
+    """entries crowded around a few centres (what medianCut makes of a photograph): long candidate lists, many near ties"""
+    rng = np.random.default_rng(seed)
+    centres = rng.integers(0, 256, size=(max(1, n // 24), 3))
+    pal = np.clip(centres[rng.integers(0, len(centres), size=n)] + rng.integers(-6, 7, size=(n, 3)), 0, 255).astype(np.uint8)
+    pal = np.concatenate([pal, np.full((n, 1), 255, np.uint8)], axis=1)
+    if n > 5:
+        pal[n - 1] = pal[2]                 # a duplicate far behind its twin
+    return pal
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+@pytest.mark.parametrize("kind,n", [("random", 256), ("random", 17), ("clustered", 256), ("clustered", 100), ("corner", 256), ("one", 1)])
+def test_apply_palette_grid_form(ctx, orc, monkeypatch, kind, n, mode):
+    """the grid of candidate lists (palette.hip, r5) against the walk over the whole palette: random, crowded (cells with more
+    than 31 candidates take the marked path) and degenerate palettes; photo-like, noise and grey-ramp pixels; odd sizes"""
+    import subprocess, sys, json, os
+    # the mode is read once per process: a child per mode
+    code = f"""
+import numpy as np, sys, json
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})
+import fennec_amd
+from fennec_amd import synth
+from oracle import oracle as orc
+orc.build()
+import test_gpu_parity as t
+kind, n = {kind!r}, {n}
+if kind == "random": pal = t._palette(n, 100 + n)
+elif kind == "clustered": pal = t._clustered_palette(n, n)
+elif kind == "corner":
+    rng = np.random.default_rng(3); pal = rng.integers(0, 12, size=(n, 4), dtype=np.uint8); pal[:, 3] = 255
+else: pal = np.array([[9, 200, 77, 255]], dtype=np.uint8)
+ctx = fennec_amd.Context(0)
+bad = 0
+imgs = [synth.make_test_image(701, 397), synth.noise_image(515, 333, 7, alpha=True)]
+ramp = np.zeros((64, 1024, 4), np.uint8); ramp[..., :3] = (np.arange(1024) // 4)[None, :, None]; ramp[..., 3] = 255
+imgs.append(ramp)
+dark = (synth.noise_image(300, 200, 9) // 20).astype(np.uint8); dark[..., 3] = 255
+imgs.append(dark)
+for img in imgs:
+    wi, wq = orc.apply_palette(img, pal)
+    gi, gq = ctx.applyPalette(img, pal)
+    bad += int(not (np.array_equal(gi, wi) and np.array_equal(gq, wq)))
+print(json.dumps({{"bad": bad}}))
+"""
+    env = dict(os.environ, FNX_PALETTE_GRID=mode)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["bad"] == 0
 
 
 # ------------------------------------------------------------------ decoded JPEG planes -> NRGBA, SURVEY 8(f).1
