@@ -480,12 +480,20 @@ __global__ __launch_bounds__(256, GUARD ? 3 : 1) void blur_mfma_kernel(MfmaArgs 
 // NKH = 2, 3, 4).  V: v_mfma_i32_16x16x64_i8 over a 64-row window (16 + 2 RF <= 64), the ring holds four 16-row slots, a V
 // set runs three steps behind its first H set.  Same stages, same barrier per step, same exactness argument (the guard
 // distance grows with the tap count: G ~ 3e-4 at 45 taps).  Plain blur only (the one-pass SSIMFast form stops at radius 6).
+// r5: radii 25 .. 62 (sigma <= 20.67; the generic passes took 410 .. 820 us per 4K image from sigma = 8.4 on).  NKH = 5 .. 8 H
+// chunks, and the V window as NKV = 2 / 3 chained 64-row instructions over a ring of NS = 4 NKV slots: 16 + 2 RF <= 64 NKV rows,
+// a V set runs NS - 1 steps behind its first H set, its store two more.  NKV = 1 is the kernel as it was.
 template <int NKH> struct MfWide {
-    static constexpr int RF = (8 * NKH - 2) < 24 ? (8 * NKH - 2) : 24;   // frame radius: taps sit centred in it
+    static constexpr int NKV = NKH <= 4 ? 1 : (NKH <= 7 ? 2 : 3);         // 64-row chunks of the V window
+    static constexpr int RFH = 8 * NKH - 2, RFV = 32 * NKV - 8;
+    static constexpr int RF = RFH < RFV ? RFH : RFV;                      // frame radius: taps sit centred in it (24 at NKH = 4)
     static constexpr int NC = 16 + RF / 2;                                // 16-byte chunks of a staged row: px x0 - RF .. x0 + 63 + RF
+    static constexpr int NL = (16 * NC + 255) / 256;                      // chunk loads per lane and H set
     static constexpr int SP = 16 * NC + 48;                               // staged row pitch, conflict-free as the A operand (tools/lds_conflicts.py)
     static constexpr int NT = 2 * RF + 1;
-    static constexpr int P = 80;                                          // ring: 64 rows + 16 per byte column
+    static constexpr int NS = 4 * NKV;                                    // ring slots of 16 rows
+    static constexpr int RING = 16 * NS;
+    static constexpr int P = RING + 16;                                   // ring: RING rows + 16 per byte column (= 16 mod 32)
     static constexpr int WT = 64 * P + 256;
 };
 
@@ -498,12 +506,12 @@ __device__ __noinline__ uint32_t mf_exact_h_n(const uint8_t *p, const double *wd
     for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[4 * t] ^ 0x80u) * wd[t];
     return clampF_dev(acc);
 }
-template <int NT>
+template <int NT, int RING = 64>
 __device__ __noinline__ uint32_t mf_exact_v_n(const uint8_t *p, int ring0, const double *wd)
 {
     double acc = 0;
 #pragma unroll 15
-    for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[(ring0 + t) & 63] ^ 0x80u) * wd[t];
+    for (int t = 0; t < NT; t++) acc = acc + u8_to_f64(p[static_cast<unsigned>(ring0 + t) % static_cast<unsigned>(RING)] ^ 0x80u) * wd[t];
     return clampF_dev(acc);
 }
 
@@ -530,11 +538,13 @@ __device__ __forceinline__ uint32_t mf_exact_u_n(const double *wd, const uint8_t
 // blur_mfma_kernel<SCORE> takes them -- two more matrix instructions per 16 x 16 px block and 4 + 4 LDS atomics; the strip's own
 // 16 px of a staged row start 4 RF bytes into the window (8-byte aligned: two 8-byte reads make the A operand).
 template <int NKH, bool GUARD, bool SCORE = false>
-__global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
+__global__ __launch_bounds__(256, MfWide<NKH>::NKV == 3 ? 1 : 2) void blur_mfma_wide_kernel(MfmaArgs a)   // (NKV = 3: 89 KB of LDS)
 {
     using C = MfWide<NKH>;
     constexpr int RF = C::RF, NC = C::NC, SP = C::SP, P = C::P, WT = C::WT, OP = MF_OP, NT = C::NT;
+    constexpr int NKV = C::NKV, NS = C::NS, RING = C::RING, NL = C::NL;
     static_assert(!SCORE || (4 * RF) % 8 == 0, "the source-side A operand is read as two 8-byte halves");
+    static_assert(!SCORE || NKV == 1, "the one-pass form is NKH = 2's");
     __shared__ __attribute__((aligned(16))) uint8_t s_t[4 * WT];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[2 * 16 * SP];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[2 * 16 * OP];
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, g = lane >> 4;
     const int NJ = min(a.seg, ((a.h - y0 + 15) >> 4) << 4) >> 4;
-    const int NI = NJ + 3;                                          // a V set reads the four H sets from its own on
+    const int NI = NJ + NS - 1;                                     // a V set reads the NS H sets from its own on
     const bool xedge = x0 - RF < 0 || x0 + 64 + RF > a.w;
 
     const v4i *tbh = reinterpret_cast<const v4i *>(a.tab);
@@ -563,8 +573,12 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
 #pragma unroll
         for (int l = 0; l < 3; l++) bh[kk][l] = tbh[(3 * kk + l) * 64 + lane];   // digits hi, mid, lo
     const v4i *tbv = tbh + 3 * NKH * 64;
-    const v4i bv2 = tbv[lane], bv1 = tbv[64 + lane], bv0 = tbv[128 + lane];
-    const double *wd = reinterpret_cast<const double *>(tbv + 192);
+    v4i bv[NKV][3];
+#pragma unroll
+    for (int c = 0; c < NKV; c++)
+#pragma unroll
+        for (int l = 0; l < 3; l++) bv[c][l] = tbv[(3 * c + l) * 64 + lane];                // digits hi, mid, lo
+    const double *wd = reinterpret_cast<const double *>(tbv + 3 * NKV * 64);
     const bool alane = (r & 3) == 3;
     const int seed_hl = alane ? (1 << 23) + 128 : a.seed_h;
     const v4i sh = {seed_hl, seed_hl, seed_hl, seed_hl}, sv = {a.seed_v, a.seed_v, a.seed_v, a.seed_v};
@@ -572,15 +586,21 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
     const uint32_t sel01 = alane ? 0x0c0c0400u : 0x0c0c0703u, sel23 = alane ? 0x04000c0cu : 0x07030c0cu;
 
     uint8_t *tw = s_t + wave * WT;
-    const int id1 = min(256 + tid, 16 * NC - 1);                    // (lanes past the last chunk fetch it again and drop it: see hload)
-    const int srow0 = tid / NC, sch0 = tid - NC * srow0, srow1 = id1 / NC, sch1 = id1 - NC * srow1;
-    const bool two = 256 + tid < 16 * NC;
-    const int st_w0 = srow0 * SP + 16 * sch0, st_w1 = srow1 * SP + 16 * sch1;
+    // chunk ids tid, 256 + tid, ...: (lanes past the last chunk fetch it again and drop it: see hload)
+    int srow[NL], sch[NL], st_w[NL];
+    bool have[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int id = min(256 * k + tid, 16 * NC - 1);
+        srow[k] = id / NC; sch[k] = id - NC * srow[k];
+        st_w[k] = srow[k] * SP + 16 * sch[k];
+        have[k] = 256 * k + tid < 16 * NC;
+    }
     const int st_r = r * SP + 64 * wave + 16 * g;                   // A operand of H set qq, K chunk kk: + 16 qq + 64 kk
     uint8_t *t_w = tw + r * P + 4 * g;                              // + (16 qq) P + 64 qq + 16 slot
     const int m4 = r >> 2, mi = r & 3;
-    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4;         // + 4 q P + 16 ((j + g) & 3)
-    const uint8_t *t_a = tw + (16 * g + 3) * P + 64 * g;            // + 4 q P + ((16 j + r + RF) & 63)
+    const uint8_t *t_r = tw + (16 * m4 + mi) * P + 64 * m4;         // + 4 q P + 16 ((j + 4 c + g) mod NS)
+    const uint8_t *t_a = tw + (16 * g + 3) * P + 64 * g;            // + 4 q P + ((16 j + r + RF) mod RING)
     const int o_w = r * OP + 64 * wave + 16 * g;
     const int orow = tid >> 4, och = tid & 15;
     const int o_r = orow * OP + 16 * och;
@@ -625,10 +645,12 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
         coln = 16u * bc + 4u * (r < 15 ? ch : 3);
     };
 
-    auto stage_write = [&](const u32x4 (&d)[2], int buf) {
+    auto stage_write = [&](const u32x4 (&d)[NL], int buf) {
         uint8_t *sb = s_stage + buf * 16 * SP;
-        *reinterpret_cast<u32x4 *>(sb + st_w0) = d[0] ^ 0x80808080u;
-        if (two) *reinterpret_cast<u32x4 *>(sb + st_w1) = d[1] ^ 0x80808080u;
+        *reinterpret_cast<u32x4 *>(sb + st_w[0]) = d[0] ^ 0x80808080u;
+#pragma unroll
+        for (int k = 1; k < NL; k++)
+            if (have[k]) *reinterpret_cast<u32x4 *>(sb + st_w[k]) = d[k] ^ 0x80808080u;
     };
     auto hset = [&](int s, int buf, int slot) {
         const uint8_t *sbuf = s_stage + buf * 16 * SP;
@@ -706,20 +728,26 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
         }
     };
     auto vset = [&](int j, int buf) {
-        v4i A[4];
         uint32_t al[4];
-        const int ro = 16 * ((j + g) & 3);
-        const int ra_ = (16 * j + r + RF) & 63;
-#pragma unroll
-        for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const v4i *>(t_r + (4 * q) * P + ro);
+        const int jm = static_cast<int>(static_cast<unsigned>(j) % static_cast<unsigned>(NS));   // (wave-uniform)
+        const int ra_ = static_cast<int>(static_cast<unsigned>(16 * jm + r + RF) % static_cast<unsigned>(RING));
 #pragma unroll
         for (int q = 0; q < 4; q++) al[q] = *(t_a + (4 * q) * P + ra_);
         v4i c2[4], c1[4], c0[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            c2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv2, zero, 0, 0, 0);
-            c1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv1, zero, 0, 0, 0);
-            c0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv0, sv, 0, 0, 0);
+        for (int q = 0; q < 4; q++) { c2[q] = zero; c1[q] = zero; c0[q] = sv; }
+#pragma unroll
+        for (int c = 0; c < NKV; c++) {
+            const int ro = 16 * static_cast<int>(static_cast<unsigned>(jm + 4 * c + g) % static_cast<unsigned>(NS));
+            v4i A[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) A[q] = *reinterpret_cast<const v4i *>(t_r + (4 * q) * P + ro);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                c2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv[c][0], c2[q], 0, 0, 0);
+                c1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv[c][1], c1[q], 0, 0, 0);
+                c0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[q], bv[c][2], c0[q], 0, 0, 0);
+            }
         }
         int u[4][3];
 #pragma unroll
@@ -751,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                     while (fl) {
                         const int b = __builtin_ctz(fl), q = b >> 2, i = b & 3;
                         fl &= fl - 1;
-                        op[4 * q + i] = static_cast<uint8_t>(mf_exact_v_n<NT>(tw + (16 * g + 4 * q + i) * P + 64 * g, 16 * j + r, wd));
+                        op[4 * q + i] = static_cast<uint8_t>(mf_exact_v_n<NT, RING>(tw + (16 * g + 4 * q + i) * P + 64 * g, 16 * jm + r, wd));
                     }
                 }
                 unsigned long long todo = NKH > 2 ? 0ull : __builtin_amdgcn_ballot_w64(fl != 0);
@@ -763,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                     while (flL) {
                         const int b = __builtin_ctz(flL), q = b >> 2, i = b & 3;
                         flL &= flL - 1;
-                        const uint32_t e = mf_exact_u_n<NT>(wd, tw + (16 * gL + 4 * q + i) * P + 64 * gL, 1, 16 * j + rL, 63);
+                        const uint32_t e = mf_exact_u_n<NT>(wd, tw + (16 * gL + 4 * q + i) * P + 64 * gL, 1, 16 * j + rL, 63);   // (NKH = 2: a 64-row ring)
                         if (lane == L) op[4 * q + i] = static_cast<uint8_t>(e);
                     }
                 }
@@ -785,20 +813,22 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
     auto march = [&](auto xedget) {
         constexpr bool XEDGE = decltype(xedget)::value;
         // (interior strips: both loads of every set from every lane, rows clamped per lane, no branch -- blur_mfma_kernel's hload)
-        auto hload = [&](int i, u32x4 (&d)[2]) {
+        auto hload = [&](int i, u32x4 (&d)[NL]) {
             const int ys = y0 - RF + 16 * i;
             if constexpr (!XEDGE) {
                 const uint8_t *sb = src + 4 * static_cast<ptrdiff_t>(x0 - RF);
-                const int ya = clampi(ys + srow0, 0, a.h - 1), yb = clampi(ys + srow1, 0, a.h - 1);
-                d[0] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(ya) * a.sstride + 16 * sch0);
-                d[1] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(yb) * a.sstride + 16 * sch1);
+#pragma unroll
+                for (int k = 0; k < NL; k++) {
+                    const int yk = clampi(ys + srow[k], 0, a.h - 1);
+                    d[k] = *(g_u32x4 *)(sb + static_cast<ptrdiff_t>(yk) * a.sstride + 16 * sch[k]);
+                }
             } else {
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (k == 1 && !two) break;
-                    const int y = clampi(ys + (k ? srow1 : srow0), 0, a.h - 1);
+                for (int k = 0; k < NL; k++) {
+                    if (k > 0 && !have[k]) break;
+                    const int y = clampi(ys + srow[k], 0, a.h - 1);
                     const uint8_t *rowp = src + static_cast<size_t>(y) * a.sstride;
-                    const int xc = x0 - RF + 4 * (k ? sch1 : sch0);
+                    const int xc = x0 - RF + 4 * sch[k];
 #pragma unroll
                     for (int e = 0; e < 4; e++) d[k][e] = ld_px(rowp, clampi(xc + e, 0, a.w - 1));
                 }
@@ -816,24 +846,24 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
                 }
             }
         };
-        // step s: [stage write of H set s | store of V set s-5]  barrier  [H set s -> ring slot s&3 | V set s-3 -> out stage s&1]
-        u32x4 ra[2], rb[2];
+        // step s: [stage write of H set s | store of V set s-NS-1]  barrier  [H set s -> ring slot s mod NS | V set s-NS+1 -> out stage s&1]
+        u32x4 ra[NL], rb[NL];
         hload(0, ra);
         __builtin_amdgcn_sched_barrier(0);
         hload(1, rb);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (SCORE) score_setup();
-        auto step = [&](int s, u32x4 (&d)[2], auto part) {
+        auto step = [&](int s, u32x4 (&d)[NL], auto part) {
             constexpr int par = decltype(part)::value;
             if (s < NI) stage_write(d, par);
             if (XEDGE) { if (s + 2 < NI) hload(s + 2, d); } else hload(min(s + 2, NI - 1), d);
-            if (s >= 5 && s - 5 < NJ) out_store(s - 5, par);
+            if (s >= NS + 1 && s - (NS + 1) < NJ) out_store(s - (NS + 1), par);
             __syncthreads();
-            if (s < NI) hset(s, par, s & 3);
-            if (s >= 3 && s - 3 < NJ) vset(s - 3, par);
+            if (s < NI) hset(s, par, static_cast<int>(static_cast<unsigned>(s) % static_cast<unsigned>(NS)));
+            if (s >= NS - 1 && s - (NS - 1) < NJ) vset(s - (NS - 1), par);
         };
 #pragma unroll 1
-        for (int s = 0; s < NJ + 5; s += 2) {
+        for (int s = 0; s < NJ + NS + 1; s += 2) {
             step(s, ra, std::integral_constant<int, 0>{});
             step(s + 1, rb, std::integral_constant<int, 1>{});
         }
@@ -855,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void blur_mfma_wide_kernel(MfmaArgs a)
 // ------------------------------------------------------------------------------------
 // Fixed-point form of a blur kernel: wq[k] = round(w[k] 2^24), the centre takes what is left of 2^24.
 // Returns false when the table is outside what the three-digit form or the error bound covers.
-constexpr int MF_RWIDE = 24;         // blur_mfma_wide_kernel: 16 + 2 R <= the 64 rows of one V instruction
+constexpr int MF_RWIDE = 62;         // blur_mfma_wide_kernel: 16 + 2 R <= the 64 NKV rows of its V window (NKH = 8: RF = 62)
 struct MfmaWeights {
     long long wq[2 * MF_RWIDE + 1];
     double err255;                // 255 * max(sum of the positive, sum of the negative wq[k] - w[k] 2^24): bound of |S - exact sum * 2^24|
@@ -1029,7 +1059,8 @@ static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights
 {
     using C = MfWide<NKH>;
     constexpr int RF = C::RF;
-    constexpr size_t words = (3 * NKH + 3) * 64 * 4 + 2 * ((C::NT + 7) / 8 * 8);   // (weights padded to whole s_load_dwordx16's)
+    constexpr int NKV = C::NKV;
+    constexpr size_t words = (3 * NKH + 3 * NKV) * 64 * 4 + 2 * ((C::NT + 7) / 8 * 8);   // (weights padded to whole s_load_dwordx16's)
     std::vector<uint32_t> tab(words, 0u);
     int8_t *bh = reinterpret_cast<int8_t *>(tab.data());
     int8_t *bv = bh + 3 * NKH * 64 * 16;
@@ -1045,14 +1076,15 @@ static int launch_mfma_wide(fnx_ctx *ctx, int n, MfmaArgs &ma, const MfmaWeights
                 if (ch == c && c == 3 && px == pj + RF) d[0] = 1;
                 for (int l = 0; l < 3; l++) bh[((3 * kk + (2 - l)) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
             }
-        for (int b = 0; b < 16; b++) {       // V: K index 16 kc + b = staged row of the set's 64; output row nn
-            const int t = 16 * kc + b - nn - off;
-            int d[3] = {0, 0, 0};
-            if (t >= 0 && t < nt) mfma_digits(q.wq[t], d);
-            for (int l = 0; l < 3; l++) bv[((2 - l) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
-        }
+        for (int c = 0; c < NKV; c++)
+            for (int b = 0; b < 16; b++) {   // V: K index 64 c + 16 kc + b = staged row of the set's 64 NKV; output row nn
+                const int t = 64 * c + 16 * kc + b - nn - off;
+                int d[3] = {0, 0, 0};
+                if (t >= 0 && t < nt) mfma_digits(q.wq[t], d);
+                for (int l = 0; l < 3; l++) bv[((3 * c + (2 - l)) * 64 + lane) * 16 + b] = static_cast<int8_t>(d[l]);
+            }
     }
-    memcpy(reinterpret_cast<double *>(tab.data() + (3 * NKH + 3) * 64 * 4) + off, kernel, sizeof(double) * nt);
+    memcpy(reinterpret_cast<double *>(tab.data() + (3 * NKH + 3 * NKV) * 64 * 4) + off, kernel, sizeof(double) * nt);
     void *dt = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab.data(), sizeof(uint32_t) * words, &dt));
     ma.tab = static_cast<const uint32_t *>(dt);
@@ -1096,6 +1128,12 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
         ma.seg = blur_mfma_segment(ctx, n, w, h, 544, 3);
         if (radius <= MfWide<2>::RF) return launch_mfma_wide<2>(ctx, n, ma, q, kernel, radius, exact);
         if (radius <= MfWide<3>::RF) return launch_mfma_wide<3>(ctx, n, ma, q, kernel, radius, exact);
+        if (radius > MfWide<4>::RF) {        // r5: 25 .. 62, the V window in two or three chained instructions
+            if (radius <= MfWide<5>::RF) return launch_mfma_wide<5>(ctx, n, ma, q, kernel, radius, exact);
+            if (radius <= MfWide<6>::RF) return launch_mfma_wide<6>(ctx, n, ma, q, kernel, radius, exact);
+            if (radius <= MfWide<7>::RF) return launch_mfma_wide<7>(ctx, n, ma, q, kernel, radius, exact);
+            return launch_mfma_wide<8>(ctx, n, ma, q, kernel, radius, exact);
+        }
         return launch_mfma_wide<4>(ctx, n, ma, q, kernel, radius, exact);
     }
     if (!blur_mfma_covers(kernel, radius, w, h)) return FNX_NOOP;

@@ -175,3 +175,44 @@ def test_one_pass_where_the_box_geometry_does_not_fit(ctx, orc, w, h):
             ref_ss = ctx.SSIMFastBatch(d, ref)
             for k in range(len(imgs)):
                 assert torch.equal(outs[k], ref[k]) and ss[k] == ref_ss[k]
+
+
+# ---- r5: radii 25 .. 62 (two / three chained 64-row V instructions, five to eight H chunks) ----
+@pytest.mark.parametrize("sigma", [8.1, 8.4, 10.0, 12.6, 12.7, 15.0, 15.4, 16.0, 18.0, 18.1, 19.0, 20.0, 20.6, 20.7, 22.0])
+def test_very_wide_radii(ctx, orc, sigma):
+    """radius 25 .. 62 on blur_mfma_wide_kernel<5 .. 8>: on both sides of every frame boundary (38 / 39, 46 / 47, 54 / 55, 62 / 63),
+    beyond 62 the generic passes; images shorter and narrower than the window, segment ends, an alpha plane"""
+    radius = int(np.ceil(3 * sigma))
+    for img in (synth.noise_image(517, 301, int(sigma * 10), alpha=True), synth.large_photo(1030, 620, 3), synth.noise_image(70, 41, 5, alpha=True)):
+        want = orc.gaussian_blur(img, sigma, procs=8)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want), (sigma, img.shape)
+        if radius <= 62:
+            assert "blur_mfma_wide_kernel" in ctx.last_kernel(1), ctx.last_kernel(1)
+        _close(ctx.GaussianBlur(img, sigma), want)
+
+
+@pytest.mark.parametrize("radius", [25, 31, 38, 39, 46, 47, 54, 55, 60, 62])
+def test_very_wide_every_sample_a_tie(ctx, orc, radius):
+    k = _binomial(radius)
+    w, h = 320, 240
+    cols = np.zeros((h, w, 4), np.uint8); cols[:, 1::2, :3] = 1; cols[..., 3] = 255
+    rows = np.zeros((h, w, 4), np.uint8); rows[1::2, :, :3] = 1; rows[..., 3] = 9
+    mixed = synth.noise_image(w, h, radius, alpha=True); mixed[40:200, 100:260, :3] &= 1
+    for img in (cols, rows, mixed):
+        assert np.array_equal(ctx.GaussianBlur(img, 1.0, exact=True, kernel=k), orc.gaussian_blur(img, 1.0, kernel=k, procs=4))
+
+
+def test_very_wide_4k_and_views(ctx, orc):
+    import torch
+    img = synth.noise_image(3840, 2160, 67, alpha=True)
+    for sigma in (10.0, 20.0):
+        want = orc.gaussian_blur(img, sigma, procs=32)
+        assert np.array_equal(ctx.GaussianBlur(img, sigma, exact=True), want)
+        _close(ctx.GaussianBlur(img, sigma), want)
+    big = torch.from_numpy(synth.noise_image(1500, 900, 21, alpha=True)).cuda()
+    view = big[7:7 + 700, 13:13 + 1201]                           # pitched, 4-byte aligned only
+    host = np.ascontiguousarray(view.cpu().numpy())
+    outs = ctx.GaussianBlurBatch([view, view], 13.0, exact=True)
+    want = orc.gaussian_blur(host, 13.0, procs=16)
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy(), want)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of GaussianBlur (the matrix-pipe kernels of csrc/blur_mfma.hip and everything they fall back to) against
 the oracle, on a GPU box: python tools/fuzz_blur.py [seconds] [seed].  Shapes on both sides of the 64-px / 16-row / segment
-boundaries, sigma 0.3 .. 8.6 (radius 1 .. 26), binomial (all-ties) tables of radius 1 .. 24, pitched device views, batches,
+boundaries, sigma 0.3 .. 21 (radius 1 .. 63), binomial (all-ties) tables of radius 1 .. 63, pitched device views, batches,
 and the one-pass SSIMFast form against the two-call route.  Every failure prints its reproducing seed / case."""
 import os
 import sys
@@ -73,10 +73,11 @@ while time.time() < t_end:
     desc = f"seed={seed} it={it} {w}x{h}"
     kernel = None
     if rng.integers(4) == 0:
-        kernel = binomial(int(rng.integers(1, 25)))
+        kernel = binomial(int(rng.integers(1, 25)) if rng.integers(3) else int(rng.integers(25, 64)))      # r5: 25 .. 62 on the matrix pipe too
         sigma, kd = 1.0, f" binomial R={(len(kernel) - 1) // 2}"
     else:
-        sigma = float(rng.choice([0.3, 0.5, 0.66, 0.8, 1.0, 1.34, 1.67, 2.0, 2.01, 2.67, 3.0, 4.66, 4.7, 6.0, 7.33, 7.4, 8.0, 8.1, 8.6]))
+        sigma = float(rng.choice([0.3, 0.5, 0.66, 0.8, 1.0, 1.34, 1.67, 2.0, 2.01, 2.67, 3.0, 4.66, 4.7, 6.0, 7.33, 7.4, 8.0, 8.1, 8.6,
+                                  10.0, 12.66, 12.7, 15.33, 15.4, 18.0, 18.1, 20.0, 20.66, 20.7, 21.0]))
         kd = f" sigma={sigma}"
     want = orc.gaussian_blur(img, sigma, kernel=kernel, procs=16)
     case("blur_exact", np.array_equal(ctx.GaussianBlur(img, sigma, exact=True, kernel=kernel), want), desc + kd)
