@@ -36,7 +36,11 @@ OPS = [
     ("GaussianBlur sigma=5 (R=15, exact)", lambda k: ctx.GaussianBlur(imgs[k], 5.0, exact=True), 2 * S, False),
     ("GaussianBlur sigma=5.3 (R=16, fast)", lambda k: ctx.GaussianBlur(imgs[k], 5.3), 2 * S, False),
     ("GaussianBlur sigma=5.3 (R=16, exact)", lambda k: ctx.GaussianBlur(imgs[k], 5.3, exact=True), 2 * S, False),
-    ("GaussianBlur sigma=6 (R=18, generic fp32)", lambda k: ctx.GaussianBlur(imgs[k], 6.0), 2 * S, False),
+    ("GaussianBlur sigma=6 (R=18, fast)", lambda k: ctx.GaussianBlur(imgs[k], 6.0), 2 * S, False),
+    ("GaussianBlur sigma=10 (R=30, fast)", lambda k: ctx.GaussianBlur(imgs[k], 10.0), 2 * S, False),
+    ("GaussianBlur sigma=10 (R=30, exact)", lambda k: ctx.GaussianBlur(imgs[k], 10.0, exact=True), 2 * S, False),
+    ("GaussianBlur sigma=20 (R=60, fast)", lambda k: ctx.GaussianBlur(imgs[k], 20.0), 2 * S, False),
+    ("GaussianBlur sigma=21 (R=63, generic fp32)", lambda k: ctx.GaussianBlur(imgs[k], 21.0), 2 * S, False),
     ("gaussianBlur3x3", lambda k: ctx.blur3x3(imgs[k]), 2 * S, False),
     ("Sharpen 0.5", lambda k: ctx.Sharpen(imgs[k], 0.5), 2 * S, False),
     ("AdaptiveSharpen 0.5", lambda k: ctx.AdaptiveSharpen(imgs[k], 0.5), 2 * S, False),
