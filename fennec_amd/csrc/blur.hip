@@ -1268,8 +1268,13 @@ int launch_blur(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *const *s
         case 8: return launch_exact<8>(ctx, n, ea);
         }
     }
-    if (radius < 1 || radius > FUSED_RMAX)
+    if (radius < 1 || radius > FUSED_RMAX) {
+        // what the matrix kernels leave (images under 64 x 32, radii past 62, a weight >= 0.49).  An fp32 accumulator's rounding grows
+        // with the tap count -- tools/fuzz_blur.py, seed 71: 0.4 % of the samples one LSB off at 127 taps, past the fast mode's
+        // 0.1 % -- so beyond 53 taps the fast mode takes the fp64 passes as well (the reference's own arithmetic, 28 % slower)
+        if (radius > 26) return launch_generic<double>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
         return launch_generic<float>(ctx, n, src, srcs, sstride, w, h, kernel, radius, dst, dsts, dstride);
+    }
     FusedArgs fa{};
     fa.src = src; fa.srcs = srcs; fa.dst = dst; fa.dsts = dsts;
     fa.sstride = sstride; fa.dstride = dstride; fa.w = w; fa.h = h;

@@ -216,3 +216,15 @@ def test_very_wide_4k_and_views(ctx, orc):
     want = orc.gaussian_blur(host, 13.0, procs=16)
     for o in outs:
         assert np.array_equal(o.cpu().numpy(), want)
+
+
+def test_generic_passes_past_53_taps_run_in_fp64(ctx, orc):
+    """what the matrix kernels leave at large radii (radius 63, images narrower than 64 px): an fp32 accumulator put 0.4 % of the
+    samples of few-colour images one LSB off at 127 taps (tools/fuzz_blur.py seed 71); the fast mode takes the fp64 passes there"""
+    few = synth.noise_image(829, 682, 11, alpha=True); few[..., :3] &= 0xF0
+    want = orc.gaussian_blur(few, 21.0, procs=16)
+    got = ctx.GaussianBlur(few, 21.0)
+    assert "double" in ctx.last_kernel(1), ctx.last_kernel(1)
+    assert np.array_equal(got, want)
+    narrow = synth.noise_image(61, 129, 12, alpha=True); narrow[..., :3] &= 0xF0
+    assert np.array_equal(ctx.GaussianBlur(narrow, 15.4), orc.gaussian_blur(narrow, 15.4, procs=4))
