@@ -1397,7 +1397,7 @@ def test_ctx_profile_hook(ctx):
     assert c.last_kernel(fennec_amd.PROF_MAIN) in ("blur_mfma_kernel", "blur_direct_kernel")
     c.GaussianBlurSSIMFastBatch(d, 2.0)
     assert "SCORE" in c.last_kernel(fennec_amd.PROF_MAIN)
-    c.GaussianBlur(d[0], 9.0); c.sync()                       # radius 27: beyond the matrix kernels
+    c.GaussianBlur(d[0], 21.5); c.sync()                      # radius 65: beyond the matrix kernels (r5: they take up to 62)
     assert c.last_kernel(fennec_amd.PROF_MAIN).startswith("blur_pass_kernel")
     assert c.last_kernel(fennec_amd.PROF_RESIZE) == ""
     c.lanczosResize(d[0], 1920, 1080); c.sync()

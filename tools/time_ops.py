@@ -40,7 +40,7 @@ OPS = [
     ("GaussianBlur sigma=10 (R=30, fast)", lambda k: ctx.GaussianBlur(imgs[k], 10.0), 2 * S, False),
     ("GaussianBlur sigma=10 (R=30, exact)", lambda k: ctx.GaussianBlur(imgs[k], 10.0, exact=True), 2 * S, False),
     ("GaussianBlur sigma=20 (R=60, fast)", lambda k: ctx.GaussianBlur(imgs[k], 20.0), 2 * S, False),
-    ("GaussianBlur sigma=21 (R=63, generic fp32)", lambda k: ctx.GaussianBlur(imgs[k], 21.0), 2 * S, False),
+    ("GaussianBlur sigma=21 (R=63, generic fp64)", lambda k: ctx.GaussianBlur(imgs[k], 21.0), 2 * S, False),
     ("gaussianBlur3x3", lambda k: ctx.blur3x3(imgs[k]), 2 * S, False),
     ("Sharpen 0.5", lambda k: ctx.Sharpen(imgs[k], 0.5), 2 * S, False),
     ("AdaptiveSharpen 0.5", lambda k: ctx.AdaptiveSharpen(imgs[k], 0.5), 2 * S, False),
