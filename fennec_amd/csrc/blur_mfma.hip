@@ -1201,7 +1201,7 @@ extern "C" int fnx_blur_fixed_point(const double *kernel, int radius, long long 
         return FNX_ERR_INVALID;
     }
     fnx::MfmaWeights q;
-    if (!fnx::mfma_quantise(kernel, radius, &q)) return FNX_NOOP;
+    if (!fnx::mfma_quantise(kernel, radius, &q, fnx::MF_RWIDE)) return FNX_NOOP;       // (r5: the wide kernels' radii 7 .. 62 too)
     for (int i = 0; i < 2 * radius + 1; i++) wq[i] = q.wq[i];
     *err255 = q.err255;
     return FNX_OK;

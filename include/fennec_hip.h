@@ -152,7 +152,7 @@ int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
  * sum sum kernel[k] * p[k] * 2^24 over bytes 0 <= p <= 255.  A sample
  * whose (sum + 2^23) mod 2^24 lies at least ceil(*err255) + 2 away from 0 and from 2^24 rounds to the same byte as the
  * reference's clampF of its fp64 chain; the others are recomputed in fp64 (FNX_BLUR_EXACT).  Host arithmetic only, no
- * device.  FNX_NOOP: the table is not that kernel's (radius outside 1..6, a negative or >= 0.49 weight, sum != 1). */
+ * device.  FNX_NOOP: the table is not the matrix kernels' (radius outside 1..62, a negative or >= 0.49 weight, sum != 1). */
 int fnx_blur_fixed_point(const double *kernel, int radius, long long *wq /* 2*radius+1 */, double *err255);
 /* gaussianBlur3x3 (effects.go:116-141). */
 int fnx_blur3x3(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
