@@ -846,8 +846,8 @@ static int launch_direct_radius(fnx_ctx *ctx, int radius, int n, FusedArgs &fa, 
 constexpr int NHEAD = 260 + 257 * 8;   // uint32 words at the head of the table blob: magic[c] (c <= 256, padded to 260), tiedown[8 c + w]
 static bool build_score_geom(fnx::ScoreGeom &g, int w, int h, int radius, int dstW, int dstH, int th_fixed = 0)
 {
-    // (th_fixed: the matrix-pipe kernels' tile, whose rows do not depend on the radius -- radii up to 14 since r5)
-    if (radius < 1 || radius > (th_fixed ? 14 : SCORE_RMAX) || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
+    // (th_fixed: the matrix-pipe kernels' tile, whose rows do not depend on the radius -- radii up to 24 since r5)
+    if (radius < 1 || radius > (th_fixed ? 24 : SCORE_RMAX) || w < dstW || h < dstH || dstW <= 0 || dstH <= 0 || w >= (1 << 24) ||
         h >= (1 << 24))
         return false;
     const double xr = static_cast<double>(w) / static_cast<double>(dstW);   // ssim.go:251-252
@@ -962,7 +962,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
 {
     if (n > 65535) return FNX_NOOP;   // grid.z
     const bool exact = flags & FNX_BLUR_EXACT;
-    // radii 7 .. 14 (r5): GaussianBlur alone runs on the matrix pipe (blur_mfma_wide_kernel), whose fast-mode bytes are not this
+    // radii 7 .. 24 (r5): GaussianBlur alone runs on the matrix pipe (blur_mfma_wide_kernel), whose fast-mode bytes are not this
     // file's fp32 kernel's; the one-pass form must return what the two calls return, so it is that kernel's SCORE form or none
     const bool wide = radius > 6 && blur_mfma_wide_scored_covers(kernel, radius, w, h, exact);
     if (!wide) {

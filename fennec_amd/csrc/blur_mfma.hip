@@ -1164,10 +1164,10 @@ int launch_blur_mfma_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
     return exact ? launch_mfma_cfg<true, true>(ctx, n, ma, lds) : launch_mfma_cfg<true, false>(ctx, n, ma, lds);
 }
 
-// radii 7 .. 14 (r5): the same through blur_mfma_wide_kernel<2, ., SCORE>
+// radii 7 .. 24 (r5): the same through blur_mfma_wide_kernel<2 / 3 / 4, ., SCORE>
 bool blur_mfma_wide_scored_covers(const double *kernel, int radius, int w, int h, bool exact)
 {
-    if (radius > MfWide<2>::RF || (exact && !blur_mfma_exact_enabled())) return false;
+    if (radius > MfWide<4>::RF || (exact && !blur_mfma_exact_enabled())) return false;      // (r5: 7 .. 14, then 15 .. 24)
     return blur_mfma_wide_covers(kernel, radius, w, h);
 }
 int launch_blur_mfma_wide_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel,
@@ -1189,7 +1189,9 @@ int launch_blur_mfma_wide_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs
     ma.seg = seg;
     ma.bx = bx; ma.by = by; ma.slabs = slabs; ma.nbx = nbx; ma.nby = nby;
     const size_t lds = sizeof(uint32_t) * 8 * static_cast<size_t>(nbx + 1) * (nby + 1);
-    return launch_mfma_wide<2, true>(ctx, n, ma, q, kernel, radius, exact, lds);
+    if (radius <= MfWide<2>::RF) return launch_mfma_wide<2, true>(ctx, n, ma, q, kernel, radius, exact, lds);
+    if (radius <= MfWide<3>::RF) return launch_mfma_wide<3, true>(ctx, n, ma, q, kernel, radius, exact, lds);
+    return launch_mfma_wide<4, true>(ctx, n, ma, q, kernel, radius, exact, lds);
 }
 
 }  // namespace fnx

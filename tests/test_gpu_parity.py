@@ -820,9 +820,9 @@ def test_blur_ssimfast_one_pass_radii_and_fallbacks(ctx, orc):
     _one_pass_case(ctx, orc, [synth.large_photo(500, 300, 2)], 2.0)
 
 
-@pytest.mark.parametrize("sigma,radius", [(2.3, 7), (2.6, 8), (3.0, 9), (4.0, 12), (4.6, 14)])
+@pytest.mark.parametrize("sigma,radius", [(2.3, 7), (2.6, 8), (3.0, 9), (4.0, 12), (4.6, 14), (4.7, 15), (6.0, 18), (7.3, 22), (7.4, 23), (8.0, 24)])
 def test_blur_ssimfast_one_pass_wide_radii(ctx, orc, sigma, radius):
-    """r5: radii 7 .. 14 take the one-pass form too (blur_mfma_wide_kernel<2, ., SCORE>): the images are the two-call route's
+    """r5: radii 7 .. 24 take the one-pass form too (blur_mfma_wide_kernel<2 / 3 / 4, ., SCORE>): the images are the two-call route's
     bit for bit (fast and exact), the exact ones are the oracle's, the scores are SSIMFast of what came back; shapes with
     edge strips, short last segments and a translucent image."""
     import torch
