@@ -99,7 +99,7 @@ while time.time() < t_end:
         case("batch_exact", all(np.array_equal(o.cpu().numpy(), orc.gaussian_blur(i, sigma, procs=8)) for i, o in zip(imgs, outs)), desc + kd + f" n={n}")
     if it % 7 == 0:                                 # one pass == two calls, on shapes that downsample
         bw, bh = int(rng.integers(600, 4200)), int(rng.integers(400, 2400))
-        sg = float(rng.choice([1.0, 1.5, 2.0, 2.6]))
+        sg = float(rng.choice([1.0, 1.5, 2.0, 2.6, 3.4, 4.6, 4.7, 6.0, 7.3, 7.4, 8.0, 9.0]))      # r5: radii 7 .. 24 run one pass too (27: two calls)
         imgs = [synth.noise_image(bw, bh, int(rng.integers(1 << 30)), alpha=True), synth.large_photo(bw, bh, 5)]
         d = [torch.from_numpy(i).cuda() for i in imgs]
         torch.cuda.synchronize()
