@@ -678,6 +678,10 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     from fennec_amd import batch as fbatch
     from fennec_amd import synth
 
+    # one process per GPU, its worker pool on the GPU's own NUMA node for the length of the job (restored below: the CPU baseline
+    # wants every core)
+    affinity_before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa_bound = fbatch.bind_to_device_numa(local_rank)
     n_items = args.batch_items
     n_files = max(1, min(args.batch_files, n_items))
     # 16 host threads per rank.  Round 2's kernels: 8 -> 12 -> 16 -> 24 threads measured 1 526 -> 1 944 -> 1 966 -> 1 548 images/s on
@@ -763,6 +767,8 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
         ref_rate = float(r0.item())
     for c in states.values():
         c.close()
+    if numa_bound and affinity_before is not None:
+        os.sched_setaffinity(0, affinity_before)
     total = n_items / elapsed
     return {
         "metric": "images/sec: CompressBatch 4K JPEG, SSIM-guided quality search",
@@ -776,6 +782,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
         "queue": "one dynamic queue for the job (store counter, chunks of 4 indices)" if world > 1 else "one rank: its own queue",
         "path": "fnx_jpeg_recompress per item: file bytes up, decoder + quality search + encoder on the device, new file down; no host codec",
         "host_threads_per_rank": workers, "host_decoded_items": host_dec,
+        "host_numa_binding": numa_bound or "none (one node, an affinity mask already set, or FENNEC_NO_NUMA_BIND=1)",
         "distinct_files": n_files, "file_bytes_mean": round(sum(len(f) for f in files) / n_files),
         "pcie_bytes": {"up": up, "down": down, "per_item_up": round(up / n_items), "per_item_down": round(down / n_items)},
         "summarize": {"Total": summ.Total, "Succeeded": summ.Succeeded, "Failed": summ.Failed, "TotalSaved": summ.TotalSaved,
