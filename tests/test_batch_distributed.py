@@ -211,3 +211,12 @@ def test_world_size_2_dynamic_queue_uneven_job_with_a_failing_item(orc, n_items,
         t, ok, bad, saved, avg = got[r][1]
         assert (t, ok, bad, saved) == (want["Total"], want["Succeeded"], want["Failed"], want["TotalSaved"])
         assert abs(avg - want["AvgSSIM"]) <= 1e-15 * 4
+
+
+def test_bind_to_device_numa_is_a_no_op_without_a_gpu():
+    """fennec_amd.batch.bind_to_device_numa: no device (this container) or no topology file -> None, the affinity mask untouched"""
+    import os
+    from fennec_amd import batch as fb
+    before = os.sched_getaffinity(0)
+    assert fb.bind_to_device_numa(0) is None
+    assert os.sched_getaffinity(0) == before
