@@ -321,7 +321,7 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
  * channel sums of boxDownsample (ssim.go:244-309) for both, and SSIMFast never re-reads either
  * full-size image (HBM traffic 2*S instead of 4*S).  Results are identical to the two separate
  * calls: the box sums are integers, everything after them is the same code.  Shapes the one-pass
- * kernel is not built for or does not win on (radius > 8, no downsample, a box-downsample ratio below
+ * kernel is not built for or does not win on (radius > 24, no downsample, a box-downsample ratio below
  * 3.6 or boxes above 256 px: long side under ~1850 px or over 8192 px; with FNX_BLUR_EXACT also a kernel
  * with negative taps or gain > 1) run the two ops back to back.  With FNX_BLUR_EXACT the blurred images
  * are bit-exact and the scores are computed from exactly those images.  The _enqueue form pairs with fnx_results_fetch. */
