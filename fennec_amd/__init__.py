@@ -189,6 +189,8 @@ def load_library() -> C.CDLL:
                                           C.POINTER(i)])
         _sig(L, "fnx_jpeg_roundtrip", i, [ctx, i] + img + [i, i, i] + img)
         _sig(L, "fnx_jpeg_decode", i, [ctx, _u8p, C.c_size_t, i, C.c_void_p, i, C.POINTER(i), C.POINTER(i)])
+        _sig(L, "fnx_jpeg_progressive_coefficients", i, [_u8p, C.c_size_t, C.POINTER(C.c_int16), C.c_size_t, C.POINTER(C.c_size_t),
+                                                        C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_recompress", i, [ctx, _u8p, C.c_size_t, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
                                             C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
@@ -610,6 +612,25 @@ class Context:
                     break
                 cap = n.value
         self._chk(rc, "fnx_jpeg_compress")
+
+    @staticmethod
+    def jpeg_progressive_coefficients(data: bytes):
+        """Host only (fnx_jpeg_progressive_coefficients): a progressive file's quantised coefficients over all its scans, as the
+        device's IDCT launch gets them -> (coef [blocks, 64] int16 in natural order, blocks MCU by MCU, (w, h), ratio)."""
+        L = load_library()
+        buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        nb, w, h, ratio = C.c_size_t(0), C.c_int(), C.c_int(), C.c_int()
+
+        def chk(rc):
+            if rc == FNX_ERR_UNSUPPORTED:
+                raise FennecUnsupported(L.fnx_last_error().decode())
+            if rc < 0:
+                raise FennecError(f"fnx_jpeg_progressive_coefficients failed ({rc}): {L.fnx_last_error().decode()}")
+        chk(L.fnx_jpeg_progressive_coefficients(buf.ctypes.data_as(_u8p), len(data), None, 0, C.byref(nb), C.byref(w), C.byref(h), C.byref(ratio)))
+        coef = np.empty((nb.value, 64), dtype=np.int16)
+        chk(L.fnx_jpeg_progressive_coefficients(buf.ctypes.data_as(_u8p), len(data), coef.ctypes.data_as(C.POINTER(C.c_int16)), nb.value,
+                                                C.byref(nb), C.byref(w), C.byref(h), C.byref(ratio)))
+        return coef, (w.value, h.value), ratio.value
 
     @staticmethod
     def jpeg_parse(data: bytes):

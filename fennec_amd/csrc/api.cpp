@@ -1283,6 +1283,22 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
     return finish(ctx, space, &d);
 }
 
+// host only: jpeg_prog.cpp's output as the tests and the sanitizer runs read it
+int fnx_jpeg_progressive_coefficients(const uint8_t *data, size_t n, int16_t *coef, size_t cap_blocks, size_t *blocks, int *w, int *h, int *ratio)
+{
+    FNX_REQUIRE(data != nullptr && blocks != nullptr && w != nullptr && h != nullptr && ratio != nullptr, "coefficient arguments");
+    JpegFile f;
+    FNX_TRY(jpeg_parse(data, n, &f));
+    if (!f.progressive) return jpeg_unsupported("a baseline file here (its scan is decoded on the device)");
+    const unsigned long long nblk = static_cast<unsigned long long>(f.mx) * f.my * f.nslots;
+    *blocks = static_cast<size_t>(nblk);
+    *w = f.w; *h = f.h; *ratio = f.ratio;
+    if (coef == nullptr) return FNX_OK;
+    FNX_REQUIRE(cap_blocks >= nblk, "coefficient capacity");
+    std::memset(coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk));
+    return jpeg_progressive_coefficients(data, n, &f, coef);
+}
+
 int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double target_ssim, const double *window, uint8_t *out, size_t cap,
                         size_t *nbytes, int *quality, double *ssim, int *steps, int *w, int *h)
 {

@@ -451,9 +451,13 @@ struct JpegFile {
     uint16_t q[3][64];           // per component, natural order
     size_t scan = 0;             // offset of the entropy-coded segment in the file
     int rounds = 0;              // cross-workgroup synchronisation rounds the decode took
+    bool progressive = false;    // SOF2: the scans are entropy-decoded on the host (jpeg_prog.cpp), the image is made on the device
     DecTables tab;
 };
 int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);
+// a progressive file's coefficients over all its scans into coef (zeroed by the caller; [mx my nslots][64] int16, blocks in the
+// order of an interleaved scan, natural order inside a block, DC as it is), the quantisation tables in force at EOI into f->q
+int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, int16_t *coef);
 int jpeg_unsupported(const char *what);     // set_error + FNX_ERR_UNSUPPORTED
 int jpeg_corrupt(const char *what);         // set_error + FNX_ERR_INVALID
 // the scan's bytes without the stuffing into dst (capacity: n - f.scan); *nbytes = what was written

@@ -450,6 +450,7 @@ struct IdctArgs {
     int stride[3], nbx[3], nblocks[3];
     int mx, nmcu, hy, vy, nc;            // MCUs per row, MCUs, Y blocks per MCU across / down, chroma components
     int ri;                              // MCUs per restart interval (the DC prediction starts over in each); 0: one interval
+    int abs_dc;                          // progressive files (jpeg_prog.cpp): coef[0] IS the DC, no prediction to undo
     uint16_t q[3][64];                   // natural order
 };
 
@@ -486,8 +487,10 @@ __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
         }
     }
     // the block's DC: the sum of its component's differences from the start of its restart interval up to it
-    const long long dsum = static_cast<long long>(a.dcsum[place] - a.dcsum[start]) + a.dcb[place] - 2048ll * (place - start + 1);
-    b[0] = static_cast<int32_t>(dsum) * static_cast<int32_t>(a.q[plane][0]);
+    if (!a.abs_dc) {
+        const long long dsum = static_cast<long long>(a.dcsum[place] - a.dcsum[start]) + a.dcb[place] - 2048ll * (place - start + 1);
+        b[0] = static_cast<int32_t>(dsum) * static_cast<int32_t>(a.q[plane][0]);
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++) idct8_row(b[8 * r], b[8 * r + 1], b[8 * r + 2], b[8 * r + 3], b[8 * r + 4], b[8 * r + 5], b[8 * r + 6], b[8 * r + 7]);
 #pragma unroll
@@ -512,9 +515,55 @@ constexpr int SCAN_PER_WG_D = 2048;
 
 // data (host): the file.  On return the planes (SLOT_JPEG_DEC_PLANES: Y, Cb, Cr back to back, MCU-padded) are
 // enqueued and *f describes them; the scan has been validated (one small read-back).
+// SOF2: every scan's entropy decoding on the host (jpeg_prog.cpp: why), the coefficients across PCIe at 2 bytes each, then the
+// same dequantisation + IDCT launch as a baseline file's
+static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride)
+{
+    const long long nmcu = static_cast<long long>(f->mx) * f->my;
+    const long long nblk_ll = nmcu * f->nslots;
+    if (nblk_ll >= (1ll << 30)) return jpeg_unsupported("a file this large");
+    // a first DC scan costs every block at least one bit: a header that promises more blocks than the file has bits is refused
+    // before anything is sized by it
+    if (8ull * n < static_cast<unsigned long long>(nblk_ll)) return jpeg_corrupt("the file is too short for the image's blocks");
+    const int nblk = static_cast<int>(nblk_ll);
+    const int ys = 8 * f->hy * f->mx, yh = 8 * f->vy * f->my, cs = 8 * f->mx, chh = 8 * f->my;
+    const size_t b_coef = sizeof(int16_t) * 64 * static_cast<size_t>(nblk);
+    void *pin = nullptr;
+    FNX_TRY(pinned_alloc(ctx, b_coef, &pin));
+    std::memset(pin, 0, b_coef);
+    FNX_TRY(jpeg_progressive_coefficients(data, n, f, static_cast<int16_t *>(pin)));
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    void *sc = nullptr, *pl = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC, al(b_coef), &sc));
+    const size_t b_y = al(static_cast<size_t>(ys) * yh), b_c = al(static_cast<size_t>(cs) * chh);
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_PLANES, b_y + 2 * b_c, &pl));
+    planes[0] = static_cast<uint8_t *>(pl);
+    planes[1] = planes[0] + b_y;
+    planes[2] = planes[1] + b_c;
+    *ystride = ys; *cstride = cs;
+    FNX_HIP(hipMemcpyAsync(sc, pin, b_coef, hipMemcpyHostToDevice, ctx->stream));
+    IdctArgs ia{};
+    ia.coef = static_cast<const int16_t *>(sc); ia.dcb = nullptr; ia.dcsum = nullptr;
+    for (int c = 0; c < 3; c++) {
+        ia.out[c] = planes[c];
+        ia.stride[c] = c ? cs : ys;
+        ia.nbx[c] = (c ? cs : ys) / 8;
+        ia.nblocks[c] = ia.nbx[c] * ((c ? chh : yh) / 8);
+        for (int k = 0; k < 64; k++) ia.q[c][k] = f->q[c][k];
+    }
+    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1; ia.ri = 0; ia.abs_dc = 1;
+    FNX_TRY(prof_begin(ctx, FNX_PROF_JPEG));
+    hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, f->ncomp), dim3(256), 0, ctx->stream, ia);
+    FNX_HIP(hipGetLastError());
+    FNX_TRY(prof_end(ctx));
+    f->rounds = 0;
+    return FNX_OK;
+}
+
 int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride)
 {
     FNX_TRY(jpeg_parse(data, n, f));
+    if (f->progressive) return jpeg_decode_planes_progressive(ctx, data, n, f, planes, ystride, cstride);
     void *pin = nullptr, *tpin = nullptr;
     const size_t cap = (n - f->scan + 64 + 63) & ~size_t(63);           // >= the scan + 4 words of zeros
     const long long nmcu0 = static_cast<long long>(f->mx) * f->my;
@@ -674,7 +723,7 @@ int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f,
         ia.nblocks[c] = ia.nbx[c] * ((c ? chh : yh) / 8);
         for (int k = 0; k < 64; k++) ia.q[c][k] = f->q[c][k];
     }
-    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1; ia.ri = f->ri;
+    ia.mx = f->mx; ia.nmcu = static_cast<int>(nmcu); ia.hy = f->hy; ia.vy = f->vy; ia.nc = f->ncomp - 1; ia.ri = f->ri; ia.abs_dc = 0;
     hipLaunchKernelGGL(jpeg_didct_kernel, dim3((ia.nblocks[0] + 255) / 256, f->ncomp), dim3(256), 0, ctx->stream, ia);
     FNX_HIP(hipGetLastError());
     // what the scan held: blocks finished inside the string, and the write pass's complaints

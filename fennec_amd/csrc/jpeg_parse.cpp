@@ -13,7 +13,7 @@ static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
 
 int jpeg_unsupported(const char *what)
 {
-    set_error("jpeg decode: %s is not handled on the device (baseline, 8 bit, 1 or 3 components, luminance factors 1 or 2, one scan)", what);
+    set_error("jpeg decode: %s is not handled on the device (baseline in one scan or progressive, 8 bit, 1 or 3 components, luminance factors 1, 2 or 4 across and 1 or 2 down)", what);
     return FNX_ERR_UNSUPPORTED;
 }
 
@@ -27,6 +27,9 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
 {
     if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return jpeg_corrupt("no SOI marker");
     bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
+    // what only a baseline scan minds (a progressive file's scans are decoded on the host, jpeg_prog.cpp, with tables of their own)
+    const char *baseline_only = nullptr;
+    f->progressive = false;
     uint8_t q[4][64];
     int ncomp = 0, comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
     std::memset(&f->tab, 0, sizeof(f->tab));
@@ -53,8 +56,9 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 have_q[tq] = true;
                 o += 65;
             }
-        } else if (m == 0xc0) {
+        } else if (m == 0xc0 || m == 0xc2) {
             if (have_sof) return jpeg_corrupt("two SOF segments");
+            f->progressive = m == 0xc2;
             if (sl < 6) return jpeg_corrupt("bad SOF segment");
             if (seg[0] != 8) return jpeg_unsupported("a sample precision other than 8 bits");
             if (seg[5] != 3 && seg[5] != 1) return jpeg_unsupported("a component count other than 1 and 3");
@@ -71,20 +75,24 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 if (comp_q[c] > 3) return jpeg_corrupt("bad quantisation table selector");
             }
             have_sof = true;
-        } else if (m == 0xc1 || m == 0xc2 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-            return jpeg_unsupported(m == 0xc2 ? "a progressive file" : "a frame type other than baseline");
+        } else if (m == 0xc1 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            return jpeg_unsupported("a frame type other than baseline and progressive");
         } else if (m == 0xcc) {
             return jpeg_unsupported("arithmetic coding");
         } else if (m == 0xc4) {
             size_t o = 0;
             while (o < sl) {
                 const int tc = seg[o] >> 4, th = seg[o] & 15;
-                if (tc > 1 || o + 17 > sl) return jpeg_corrupt("bad DHT segment");
-                if (th > 1) return jpeg_unsupported("a Huffman table selector above 1");
-                const int t = tc * 2 + th;
+                if (tc > 1 || th > 3 || o + 17 > sl) return jpeg_corrupt("bad DHT segment");
                 int total = 0;
                 for (int L = 1; L <= 16; L++) total += seg[o + L];
                 if (total > 256 || o + 17 + total > sl) return jpeg_corrupt("bad DHT segment");
+                if (th > 1) {                                             // (progressive files use up to four)
+                    if (!baseline_only) baseline_only = "a Huffman table selector above 1";
+                    o += 17 + total;
+                    continue;
+                }
+                const int t = tc * 2 + th;
                 std::memset(f->tab.fast[t], 0, sizeof(f->tab.fast[t]));
                 uint32_t code = 0;
                 int k = 0;
@@ -96,7 +104,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                         // T.81 C.2 keeps the all-ones code of every length unassigned, and the kernels lean on it: the 1-bits
                         // that pad the byte before a restart marker (and the string's last byte) can then never be a symbol.
                         // A table that assigns it is one the host codec gets to read.
-                        if (code + 1 == (1u << L)) return jpeg_unsupported("a Huffman table that assigns the all-ones code");
+                        if (code + 1 == (1u << L) && !baseline_only) baseline_only = "a Huffman table that assigns the all-ones code";
                         f->tab.value[t][k] = seg[o + 17 + k];
                         if (L <= DEC_FAST_BITS)
                             for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)
@@ -115,17 +123,6 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
         } else if (m == 0xda) {
             if (!have_sof) return jpeg_corrupt("SOS before SOF");
-            if (sl < 1 || seg[0] != ncomp) return jpeg_unsupported("a scan that does not hold all the frame's components");
-            if (sl < 1 + 2 * static_cast<size_t>(ncomp) + 3) return jpeg_corrupt("bad SOS segment");
-            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
-            for (int c = 0; c < ncomp; c++) {
-                if (seg[1 + 2 * c] != comp_id[c]) return jpeg_unsupported("scan components out of frame order");
-                td[c] = seg[2 + 2 * c] >> 4;
-                ta[c] = seg[2 + 2 * c] & 15;
-                if (td[c] > 1 || ta[c] > 1) return jpeg_unsupported("a Huffman table selector above 1");
-                if (!have_t[td[c]] || !have_t[2 + ta[c]]) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
-                if (!have_q[comp_q[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
-            }
             if (ncomp == 3 && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return jpeg_unsupported("an RGB file");
             if (ncomp == 1) {
                 // a one-component scan is not interleaved (T.81 A.2.2): one block per MCU whatever the factors say; image.Gray
@@ -141,8 +138,26 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 f->ratio = f->hy == 4 ? (f->vy == 2 ? 5 : 4) : f->hy == 2 ? (f->vy == 2 ? 2 : 1) : (f->vy == 2 ? 3 : 0);
             }
             f->ncomp = ncomp;
+            f->nslots = f->hy * f->vy + ncomp - 1;
+            f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
+            f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
+            if (f->progressive) {                                         // the scans are jpeg_progressive_coefficients' to read
+                f->scan = pos;
+                return FNX_OK;
+            }
+            if (baseline_only) return jpeg_unsupported(baseline_only);
+            if (sl < 1 || seg[0] != ncomp) return jpeg_unsupported("a scan that does not hold all the frame's components");
+            if (sl < 1 + 2 * static_cast<size_t>(ncomp) + 3) return jpeg_corrupt("bad SOS segment");
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
+                if (seg[1 + 2 * c] != comp_id[c]) return jpeg_unsupported("scan components out of frame order");
+                td[c] = seg[2 + 2 * c] >> 4;
+                ta[c] = seg[2 + 2 * c] & 15;
+                if (td[c] > 1 || ta[c] > 1) return jpeg_unsupported("a Huffman table selector above 1");
+                if (!have_t[td[c]] || !have_t[2 + ta[c]]) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                if (!have_q[comp_q[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
+            }
             const int ny = f->hy * f->vy;
-            f->nslots = ny + ncomp - 1;
             f->dcpack = f->acpack = 0;
             for (int s = 0; s < f->nslots; s++) {
                 const int c = s < ny ? 0 : s - ny + 1;
@@ -151,8 +166,6 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             }
             for (int c = 0; c < 3; c++)
                 for (int k = 0; k < 64; k++) f->q[c][k] = c < ncomp ? q[comp_q[c]][k] : 1;
-            f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
-            f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
             f->scan = pos + 2 + len;
             return FNX_OK;
         }

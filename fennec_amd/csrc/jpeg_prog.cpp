@@ -1,0 +1,356 @@
+// Progressive JPEG files (SOF2) for the device decoder: the entropy decoding of every scan on the host, into the block-major
+// coefficient array jpeg_didct_kernel reads (jpeg_dec.hip) -- the image is then made on the device like a baseline file's.
+//
+// Why the host: an AC refinement scan (T.81 G.1.2.3) reads one correction bit per coefficient that is ALREADY non-zero, so where
+// a symbol starts depends on the block's history over all earlier scans, not only on the bit string -- the self-synchronising
+// decoder of jpeg_dec.hip has no form for that.  What the device keeps: dequantisation, the IDCT, the colour conversion, and
+// everything behind them (the quality search reads the planes where they lie).  A progressive file therefore crosses PCIe as
+// 2 bytes per coefficient instead of 4 bytes per decoded pixel after a host decode, and the caller needs no host codec.
+//
+// Behaviour follows image/jpeg (reader.go, scan.go: processSOS, refine, refineNonZeroes, reconstructProgressiveImage) as
+// published -- restated from ITU T.81 Annex G, not from Go's source; bit-exact against the CPU restatement under oracle/
+// (tests/test_jpeg_progressive.py), which libjpeg's progressive files pin coefficient by coefficient:
+//   * coefficients are collected over all scans and dequantised once, with the tables in force at EOI;
+//   * a one-component frame is h = v = 1; an interleaved scan walks the frame's MCUs, a one-component scan its component's
+//     blocks in raster order, without data for blocks wholly outside the image;
+//   * image/jpeg counts FRAME MCUs between restart markers in every scan where T.81 counts the scan's own: the two agree only
+//     for components of one block per MCU, anything else with a restart interval is FNX_ERR_UNSUPPORTED (the host codec's call).
+// Not handled (FNX_ERR_UNSUPPORTED, as for baseline files): 12-bit samples, four components, arithmetic coding, chroma factors
+// other than 1 x 1, a component no scan mentions, coefficients beyond 16 bits.
+// Plain C++ with no device code: this file reads untrusted bytes and is part of the sanitizer builds (make asan / tsan).
+#include <cstring>
+#include <vector>
+#include "common.hpp"
+
+namespace fnx {
+
+namespace {
+
+const uint8_t UNZIG_P[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// MSB-first bits of an entropy-coded segment: 0xff 0x00 is one 0xff byte, any other 0xff ends the segment (the reader
+// stays in front of it and hands out zeros, counted: a scan that consumed one of them ran past its data)
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t acc = 0;
+    int cnt = 0, fake = 0;
+    BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+    inline void fill()
+    {
+        while (cnt <= 56) {
+            uint32_t b = 0;
+            if (p < end && *p != 0xff) b = *p++;
+            else if (p + 1 < end && p[1] == 0x00) { b = 0xff; p += 2; }
+            else fake += 8;
+            acc = (acc << 8) | b;
+            cnt += 8;
+        }
+    }
+    inline uint32_t peek16() { fill(); return static_cast<uint32_t>(acc >> (cnt - 16)) & 0xffffu; }
+    inline void skip(int nb) { cnt -= nb; }
+    inline uint32_t bits(int nb)                 // nb <= 16
+    {
+        if (nb == 0) return 0;
+        fill();
+        cnt -= nb;
+        return static_cast<uint32_t>(acc >> cnt) & ((1u << nb) - 1u);
+    }
+    inline uint32_t bit() { return bits(1); }
+    bool overran() const { return cnt < fake; }
+    void restart() { acc = 0; cnt = 0; fake = 0; }
+};
+
+struct HTab {
+    uint16_t fast[512];                          // 9 bits of look-ahead -> length << 8 | symbol; 0: a longer code
+    int32_t maxcode[17], valoff[17];             // per length: largest code (-1: none), value index of code 0
+    uint8_t val[256];
+    bool have = false;
+};
+
+inline int huff(BitReader &br, const HTab &t)
+{
+    const uint32_t look = br.peek16();
+    const uint16_t e = t.fast[look >> 7];
+    if (e) { br.skip(e >> 8); return e & 0xff; }
+    for (int L = 10; L <= 16; L++) {
+        const int32_t code = static_cast<int32_t>(look >> (16 - L));
+        if (code <= t.maxcode[L]) { br.skip(L); return t.val[t.valoff[L] + code]; }
+    }
+    return -1;
+}
+
+inline int32_t extend(BitReader &br, int s)          // T.81 F.2.2.1: s bits as a signed value
+{
+    if (s == 0) return 0;
+    const int32_t v = static_cast<int32_t>(br.bits(s));
+    return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+}
+
+struct Frame {
+    int w = 0, h = 0, ncomp = 0;
+    int id[3] = {0, 0, 0}, ch[3] = {1, 1, 1}, cv[3] = {1, 1, 1}, cq[3] = {0, 0, 0};
+    int hy = 1, vy = 1, mx = 0, my = 0, per = 1;
+};
+
+// where block (bx, by) of component c lies in the scan-ordered array jpeg_didct_kernel reads
+inline size_t block_at(const Frame &fr, int c, int bx, int by)
+{
+    if (c == 0) {
+        const size_t m = static_cast<size_t>(by / fr.vy) * fr.mx + bx / fr.hy;
+        return m * fr.per + (by % fr.vy) * fr.hy + bx % fr.hy;
+    }
+    return (static_cast<size_t>(by) * fr.mx + bx) * fr.per + fr.hy * fr.vy + c - 1;
+}
+
+inline bool put(int16_t *dst, int32_t v)
+{
+    *dst = static_cast<int16_t>(v);
+    return v == static_cast<int16_t>(v);
+}
+
+// refineNonZeroes: over coefficients zig .. ze of b; a non-zero one reads a correction bit; stops in front of the (nz + 1)-th
+// zero one (nz < 0: never)
+inline int refine_nonzeroes(BitReader &br, int16_t *b, int zig, int ze, int nz, int32_t delta, bool *ok)
+{
+    for (; zig <= ze; zig++) {
+        int16_t *p = b + UNZIG_P[zig];
+        if (*p == 0) {
+            if (nz == 0) break;
+            nz--;
+            continue;
+        }
+        if (!br.bit()) continue;
+        *ok = put(p, *p >= 0 ? *p + delta : *p - delta) && *ok;
+    }
+    return zig;
+}
+
+}  // namespace
+
+int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, int16_t *coef)
+{
+    Frame fr;
+    uint8_t q[4][64];
+    bool have_q[4] = {false, false, false, false}, seen[3] = {false, false, false};
+    std::vector<HTab> tabs(8);                   // [tc * 4 + th]
+    int ri = 0;
+    bool range_ok = true;
+    size_t pos = 2;
+    for (;;) {
+        if (pos + 2 > n) return jpeg_corrupt("the file ends before EOI");
+        if (data[pos] != 0xff) { pos++; continue; }                         // reader.go skips what lies between segments
+        const uint8_t m = data[pos + 1];
+        if (m == 0xff) { pos++; continue; }
+        if (m == 0x00 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
+        if (m == 0xd9) break;
+        if (pos + 4 > n) return jpeg_corrupt("the file ends inside a segment");
+        const size_t len = (static_cast<size_t>(data[pos + 2]) << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > n) return jpeg_corrupt("a segment runs past the end of the file");
+        const uint8_t *seg = data + pos + 4;
+        const size_t sl = len - 2;
+        if (m == 0xdb) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (pq != 0) return jpeg_unsupported("a 16-bit quantisation table");
+                if (tq > 3 || o + 65 > sl) return jpeg_corrupt("bad DQT segment");
+                for (int zig = 0; zig < 64; zig++) q[tq][UNZIG_P[zig]] = seg[o + 1 + zig];
+                have_q[tq] = true;
+                o += 65;
+            }
+        } else if (m == 0xc2) {
+            if (fr.ncomp != 0) return jpeg_corrupt("two SOF segments");
+            if (sl < 6 || seg[0] != 8 || (seg[5] != 1 && seg[5] != 3) || sl < 6 + 3 * static_cast<size_t>(seg[5]))
+                return jpeg_corrupt("bad SOF segment");                    // (jpeg_parse has let this frame through already)
+            fr.ncomp = seg[5];
+            fr.h = (seg[1] << 8) | seg[2];
+            fr.w = (seg[3] << 8) | seg[4];
+            for (int c = 0; c < fr.ncomp; c++) {
+                fr.id[c] = seg[6 + 3 * c];
+                fr.ch[c] = seg[7 + 3 * c] >> 4;
+                fr.cv[c] = seg[7 + 3 * c] & 15;
+                fr.cq[c] = seg[8 + 3 * c];
+            }
+            if (fr.ncomp == 1) fr.ch[0] = fr.cv[0] = 1;
+            fr.hy = fr.ch[0]; fr.vy = fr.cv[0];
+            fr.mx = f->mx; fr.my = f->my;
+            fr.per = fr.hy * fr.vy + fr.ncomp - 1;
+            if (fr.w != f->w || fr.h != f->h || fr.hy != f->hy || fr.vy != f->vy || fr.ncomp != f->ncomp || fr.per != f->nslots)
+                return jpeg_corrupt("the frame header changed between two readings");
+        } else if (m == 0xc0 || m == 0xc1 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8)) {
+            return jpeg_corrupt("a second frame header of another kind");
+        } else if (m == 0xc4) {
+            size_t o = 0;
+            while (o < sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || th > 3 || o + 17 > sl) return jpeg_corrupt("bad DHT segment");
+                HTab &t = tabs[4 * tc + th];
+                int total = 0;
+                for (int L = 1; L <= 16; L++) total += seg[o + L];
+                if (total > 256 || o + 17 + static_cast<size_t>(total) > sl) return jpeg_corrupt("bad DHT segment");
+                std::memset(t.fast, 0, sizeof(t.fast));
+                int32_t code = 0;
+                int k = 0;
+                for (int L = 1; L <= 16; L++) {
+                    const int cnt = seg[o + L];
+                    t.valoff[L] = k - code;
+                    if (code + cnt > (1 << L)) return jpeg_corrupt("a Huffman table with more codes than its lengths allow");
+                    for (int j = 0; j < cnt; j++, k++, code++) {
+                        t.val[k] = seg[o + 17 + k];
+                        if (L <= 9)
+                            for (int32_t x = code << (9 - L); x < ((code + 1) << (9 - L)); x++)
+                                t.fast[x] = static_cast<uint16_t>((L << 8) | t.val[k]);
+                    }
+                    t.maxcode[L] = cnt ? code - 1 : -1;
+                    code <<= 1;
+                }
+                t.have = true;
+                o += 17 + total;
+            }
+        } else if (m == 0xdd) {
+            if (sl < 2) return jpeg_corrupt("bad DRI segment");
+            ri = (seg[0] << 8) | seg[1];
+        } else if (m == 0xee) {
+            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
+        } else if (m == 0xda) {
+            if (fr.ncomp == 0) return jpeg_corrupt("SOS before SOF");
+            const int ns = sl >= 1 ? seg[0] : 0;
+            if (ns < 1 || ns > fr.ncomp || sl != 4 + 2 * static_cast<size_t>(ns)) return jpeg_corrupt("bad SOS segment");
+            int sc[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int i = 0; i < ns; i++) {
+                int c = -1;
+                for (int j = 0; j < fr.ncomp; j++) if (fr.id[j] == seg[1 + 2 * i]) c = j;
+                if (c < 0) return jpeg_corrupt("a scan names a component the frame does not hold");
+                for (int j = 0; j < i; j++) if (sc[j] == c) return jpeg_corrupt("a scan names a component twice");
+                sc[i] = c; td[i] = seg[2 + 2 * i] >> 4; ta[i] = seg[2 + 2 * i] & 15;
+                if (td[i] > 3 || ta[i] > 3) return jpeg_corrupt("bad Huffman table selector");
+            }
+            const int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if ((zs == 0 && ze != 0) || zs > ze || ze > 63) return jpeg_corrupt("bad spectral selection bounds");
+            if (zs != 0 && ns != 1) return jpeg_corrupt("progressive AC coefficients for more than one component");
+            if ((ah != 0 && ah != al + 1) || al > 13) return jpeg_corrupt("bad successive approximation values");
+            for (int i = 0; i < ns; i++) {
+                if (zs == 0 && ah == 0 && !tabs[td[i]].have) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                if (zs != 0 && !tabs[4 + ta[i]].have) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                seen[sc[i]] = true;
+            }
+            if (ri > 0 && ns == 1 && fr.ch[sc[0]] * fr.cv[sc[0]] > 1)
+                return jpeg_unsupported("a restart interval in a one-component scan of a component with several blocks per MCU");
+            BitReader br(data + pos + 2 + len, data + n);
+            const int32_t delta = 1 << al;
+            int32_t pred[3] = {0, 0, 0};
+            uint32_t eob_run = 0;
+            long long mcu = 0, block_count = 0;
+            const long long nmcu = static_cast<long long>(fr.mx) * fr.my;
+            int expected_rst = 0;
+            for (int my0 = 0; my0 < fr.my; my0++)
+                for (int mx0 = 0; mx0 < fr.mx; mx0++) {
+                    for (int i = 0; i < ns; i++) {
+                        const int c = sc[i], hi = fr.ch[c], vi = fr.cv[c];
+                        for (int j = 0; j < hi * vi; j++) {
+                            int bx, by;
+                            if (ns != 1) { bx = hi * mx0 + j % hi; by = vi * my0 + j / hi; }
+                            else {
+                                const int across = fr.mx * hi;
+                                bx = static_cast<int>(block_count % across);
+                                by = static_cast<int>(block_count / across);
+                                block_count++;
+                                // the component's own extent: ceil(w hi / hy) x ceil(h vi / vy) samples
+                                if (8ll * bx * fr.hy >= static_cast<long long>(fr.w) * hi || 8ll * by * fr.vy >= static_cast<long long>(fr.h) * vi) continue;
+                            }
+                            int16_t *b = coef + 64 * block_at(fr, c, bx, by);
+                            if (ah != 0) {                                       // refinement (G.1.2.1, G.1.2.3)
+                                if (zs == 0) {
+                                    if (br.bit()) range_ok = put(b, b[0] | delta) && range_ok;
+                                    continue;
+                                }
+                                const HTab &t = tabs[4 + ta[i]];
+                                int zig = zs;
+                                if (eob_run == 0) {
+                                    for (; zig <= ze; zig++) {
+                                        int32_t z = 0;
+                                        const int rs = huff(br, t);
+                                        if (rs < 0) return jpeg_corrupt("a scan holds a code outside its Huffman table");
+                                        const int v0 = rs >> 4, v1 = rs & 15;
+                                        if (v1 == 0) {
+                                            if (v0 != 15) {
+                                                eob_run = (1u << v0) | br.bits(v0);
+                                                break;
+                                            }
+                                        } else if (v1 == 1) {
+                                            z = br.bit() ? delta : -delta;
+                                        } else {
+                                            return jpeg_corrupt("a refinement scan holds a coefficient of more than one bit");
+                                        }
+                                        zig = refine_nonzeroes(br, b, zig, ze, v0, delta, &range_ok);
+                                        if (zig > ze) return jpeg_corrupt("a refinement scan runs past the end of its band");
+                                        if (z != 0) b[UNZIG_P[zig]] = static_cast<int16_t>(z);
+                                    }
+                                }
+                                if (eob_run > 0) {
+                                    eob_run--;
+                                    refine_nonzeroes(br, b, zig, ze, -1, delta, &range_ok);
+                                }
+                                continue;
+                            }
+                            int zig = zs;
+                            if (zig == 0) {                                      // DC, first pass (G.1.2.1)
+                                zig++;
+                                const int s = huff(br, tabs[td[i]]);
+                                if (s < 0 || s > 16) return jpeg_corrupt("a scan holds a code outside its Huffman table");
+                                pred[c] += extend(br, s);
+                                range_ok = put(b, pred[c] * delta) && range_ok && pred[c] >= -(1 << 20) && pred[c] <= (1 << 20);
+                                if (pred[c] < -(1 << 20) || pred[c] > (1 << 20)) pred[c] = 0;   // (refused below; keeps the product defined)
+                            }
+                            if (zig <= ze && eob_run > 0) eob_run--;
+                            else {                                               // AC, first pass (G.1.2.2)
+                                const HTab &t = tabs[4 + ta[i]];
+                                for (; zig <= ze; zig++) {
+                                    const int rs = huff(br, t);
+                                    if (rs < 0) return jpeg_corrupt("a scan holds a code outside its Huffman table");
+                                    const int v0 = rs >> 4, v1 = rs & 15;
+                                    if (v1 != 0) {
+                                        zig += v0;
+                                        if (zig > ze) break;
+                                        range_ok = put(b + UNZIG_P[zig], extend(br, v1) * delta) && range_ok;
+                                    } else {
+                                        if (v0 != 15) {
+                                            eob_run = ((1u << v0) | br.bits(v0)) - 1u;
+                                            break;
+                                        }
+                                        zig += 15;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (br.overran()) return jpeg_corrupt("a scan ends before its last block");
+                    mcu++;
+                    if (ri > 0 && mcu % ri == 0 && mcu < nmcu) {
+                        br.restart();
+                        if (br.p + 2 > br.end || br.p[0] != 0xff || br.p[1] != 0xd0 + expected_rst) return jpeg_corrupt("restart markers out of sequence");
+                        br.p += 2;
+                        expected_rst = (expected_rst + 1) & 7;
+                        pred[0] = pred[1] = pred[2] = 0;
+                        eob_run = 0;
+                    }
+                }
+            pos = static_cast<size_t>(br.p - data);                             // in front of the marker that ended the scan
+            continue;
+        }
+        pos += 2 + len;
+    }
+    if (fr.ncomp == 0) return jpeg_corrupt("EOI before any frame");
+    if (!range_ok) return jpeg_unsupported("coefficients beyond 16 bits");
+    for (int c = 0; c < fr.ncomp; c++) {
+        if (!seen[c]) return jpeg_unsupported("a component no scan mentions");
+        if (!have_q[fr.cq[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
+    }
+    for (int c = 0; c < 3; c++)
+        for (int k = 0; k < 64; k++) f->q[c][k] = c < fr.ncomp ? q[fr.cq[c]][k] : 1;
+    return FNX_OK;
+}
+
+}  // namespace fnx

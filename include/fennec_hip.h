@@ -259,14 +259,25 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
 /* SURVEY 8(f)2, third slice -- image.Decode of a JPEG source (batch.go:88-101 via io.go:60-95) on the device:
  * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
  * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all (host work: ctx may be
- * NULL and no device is touched).  Handled: baseline
- * (SOF0), 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one (image.Gray), one scan, with or without restart intervals; anything else returns
+ * NULL and no device is touched).  Handled: 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one
+ * (image.Gray), with or without restart intervals, as baseline (SOF0) in one scan or progressive (SOF2) in any number of
+ * scans; anything else returns
  * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
- * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Huffman decoding is parallel over
- * 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how
- * many rounds that takes.  Restated from ITU T.81 and Go's documented behaviour: bit-exact against the tests' CPU
- * restatement, parity with Go unpinned. */
+ * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Baseline: Huffman decoding is parallel
+ * over 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how
+ * many rounds that takes.  Progressive (r5): a refinement scan's bits depend on the coefficients of the scans before it, so
+ * the scans are entropy-decoded on the host (jpeg_prog.cpp) and the coefficients go up at 2 bytes each; dequantisation, IDCT
+ * and colour conversion are the device's as for baseline.  Restated from ITU T.81 and Go's documented behaviour (scan.go's
+ * refine / reconstructProgressiveImage): bit-exact against the tests' CPU restatement, parity with Go unpinned. */
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h);
+/* Host only (no ctx, no device): what fnx_jpeg_decode hands the device for a progressive (SOF2) file -- the quantised
+ * coefficients over all its scans (scan.go processSOS / refine as published).  coef: [*blocks][64] int16, blocks MCU by MCU
+ * in the order of an interleaved scan (Y blocks of the MCU row by row, then Cb, then Cr), natural (row-major) order inside a
+ * block, DC as it is.  *blocks, *w, *h, *ratio (image.YCbCrSubsampleRatio 0..5; -1: one component) are set whenever the
+ * frame parses; coef == NULL or cap_blocks < *blocks: nothing is decoded (FNX_OK / FNX_ERR_INVALID).  A baseline file:
+ * FNX_ERR_UNSUPPORTED (its scan is decoded on the device).  Exists for the CPU-side parity tests and the sanitizer runs. */
+int fnx_jpeg_progressive_coefficients(const uint8_t *data, size_t n, int16_t *coef, size_t cap_blocks, size_t *blocks, int *w, int *h,
+                                      int *ratio);
 /* CompressBatch's per-item body for a JPEG source in one call (batch.go:88-122 -> compress.go:21-87): decode `data`
  * on the device, run compressJPEGOptimal's quality search there and write the winner's file into `out` -- the file
  * bytes go up, the new file's bytes come down, no host codec.  Arguments as fnx_jpeg_compress; *w, *h: the image's

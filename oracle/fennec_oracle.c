@@ -1967,6 +1967,307 @@ static int32_t jr_receive_extend(jpeg_bitr *r, int s)
     return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
 }
 
+/* ---- progressive files (SOF2): scan.go's processSOS / refine / refineNonZeroes and reader.go's reconstructProgressiveImage
+ * as published (image/jpeg is a standard-library dependency, absent from /root/reference: restated from ITU T.81 Annex G and the
+ * package's documented behaviour; parity with Go unpinned like the rest of the codec).  What pins the ENTROPY side: libjpeg's
+ * progressive file of an image holds exactly the quantised coefficients of its baseline file of the same image and quality, and
+ * tests/test_jpeg_progressive.py asks this decoder for both.  image/jpeg's own choices kept here:
+ *   - coefficients of every scan are collected and dequantised once, at EOI, with the tables in force THEN;
+ *   - a one-component frame is h = v = 1 whatever the file says;
+ *   - an interleaved scan walks the frame's MCUs, a one-component scan walks the component's blocks in raster order and has no
+ *     data for blocks wholly outside the image;
+ *   - only the blocks that touch the image are reconstructed (bx * 8 * h0 / h < width ...): the MCU padding of a progressive
+ *     image's planes stays zero;
+ *   - the restart counter of image/jpeg counts FRAME MCUs in every scan where T.81 counts the scan's own (one block in a
+ *     one-component scan): the two only agree for components of one block per MCU, so a restart interval together with a
+ *     one-component scan of a component with more is refused here (-12) as it is by the product (the host codec's call). */
+static int jr_bits(jpeg_bitr *r, int nb)
+{
+    int v = 0;
+    for (int i = 0; i < nb; i++) v = (v << 1) | jr_bit(r);
+    return v;
+}
+
+/* refineNonZeroes (scan.go): passes over coefficients zig .. zig_end; every non-zero one reads a correction bit; stops in front
+ * of the (nz + 1)-th zero one (nz < 0: never).  b in zig-zag order. */
+static int jprog_refine_nonzeroes(jpeg_bitr *r, int32_t *b, int zig, int zig_end, int nz, int32_t delta)
+{
+    for (; zig <= zig_end; zig++) {
+        if (b[zig] == 0) {
+            if (nz == 0) break;
+            nz--;
+            continue;
+        }
+        if (!jr_bit(r)) continue;
+        if (b[zig] >= 0) b[zig] += delta; else b[zig] -= delta;
+    }
+    return zig;
+}
+
+/* refine (scan.go; T.81 G.1.2.2, G.1.2.3) */
+static int jprog_refine(jpeg_bitr *r, int32_t *b, const jpeg_dtab *h, int zs, int ze, int32_t delta, uint32_t *eob_run)
+{
+    if (zs == 0) {
+        if (jr_bit(r)) b[0] |= delta;
+        return r->bad ? -10 : 0;
+    }
+    int zig = zs;
+    if (*eob_run == 0) {
+        for (; zig <= ze; zig++) {
+            int32_t z = 0;
+            const int rs = jr_symbol(r, h);
+            if (r->bad) return -10;
+            const int v0 = rs >> 4, v1 = rs & 15;
+            if (v1 == 0) {
+                if (v0 != 15) {
+                    *eob_run = 1u << v0;
+                    if (v0 != 0) *eob_run |= (uint32_t)jr_bits(r, v0);
+                    break;
+                }
+            } else if (v1 == 1) {
+                z = jr_bit(r) ? delta : -delta;
+            } else {
+                return -10;                                                       /* "unexpected Huffman code" */
+            }
+            zig = jprog_refine_nonzeroes(r, b, zig, ze, v0, delta);
+            if (r->bad) return -10;
+            if (zig > ze) return -10;                                             /* "too many coefficients" */
+            if (z != 0) b[zig] = z;
+        }
+    }
+    if (*eob_run > 0) {
+        (*eob_run)--;
+        jprog_refine_nonzeroes(r, b, zig, ze, -1, delta);
+    }
+    return r->bad ? -10 : 0;
+}
+
+static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
+                                       int16_t *coef)
+{
+    uint8_t q[4][64];
+    jpeg_dtab dt[2][4];
+    int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    int ri = 0, W = 0, H = 0, ncomp = 0, comp_h[3] = {1, 1, 1}, comp_v[3] = {1, 1, 1}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
+    int hy = 1, vy = 1, mx = 0, my = 0, seen[3] = {0, 0, 0};
+    int32_t *cf[3] = {NULL, NULL, NULL};                                          /* per component: [my v][mx h] blocks of 64, zig-zag order */
+    int rc = -2;
+    long pos = 2;
+    for (;;) {
+        if (pos + 2 > n) { rc = -2; goto out; }
+        if (data[pos] != 0xff) { pos++; continue; }                               /* reader.go: bytes between segments are skipped */
+        const uint8_t m = data[pos + 1];
+        if (m == 0xff) { pos++; continue; }
+        if (m == 0x00 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
+        if (m == 0xd9) break;                                                     /* EOI */
+        if (pos + 4 > n) { rc = -2; goto out; }
+        const int len = (data[pos + 2] << 8) | data[pos + 3];
+        if (len < 2 || pos + 2 + len > n) { rc = -2; goto out; }
+        const uint8_t *seg = data + pos + 4;
+        const int sl = len - 2;
+        if (m == 0xdb) {
+            int o = 0;
+            while (o < sl) {
+                const int pq = seg[o] >> 4, tq = seg[o] & 15;
+                if (pq != 0 || tq > 3 || o + 65 > sl) { rc = -3; goto out; }
+                for (int zig = 0; zig < 64; zig++) q[tq][zig] = seg[o + 1 + zig];  /* kept in zig-zag order here */
+                have_q[tq] = 1;
+                o += 65;
+            }
+        } else if (m == 0xc2) {
+            if (ncomp != 0) { rc = -4; goto out; }
+            if (sl < 6 + 3 || seg[0] != 8 || (seg[5] != 3 && seg[5] != 1) || sl < 6 + 3 * seg[5]) { rc = -4; goto out; }
+            ncomp = seg[5];
+            H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4];
+            if (W <= 0 || H <= 0) { rc = -4; goto out; }
+            for (int c = 0; c < ncomp; c++) {
+                comp_id[c] = seg[6 + 3 * c]; comp_h[c] = seg[7 + 3 * c] >> 4; comp_v[c] = seg[7 + 3 * c] & 15; comp_q[c] = seg[8 + 3 * c];
+                if (comp_q[c] > 3) { rc = -4; goto out; }
+            }
+            if (ncomp == 1) { comp_h[0] = comp_v[0] = 1; }
+            else {
+                if (comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) { rc = -9; goto out; }
+                if (!(comp_h[0] == 1 || comp_h[0] == 2 || comp_h[0] == 4) || comp_v[0] < 1 || comp_v[0] > 2) { rc = -9; goto out; }
+            }
+            hy = comp_h[0]; vy = comp_v[0];
+            mx = (W + 8 * hy - 1) / (8 * hy); my = (H + 8 * vy - 1) / (8 * vy);
+            *wd = W; *ht = H;
+            *ratio = ncomp == 1 ? -1 : (hy == 4 ? (vy == 2 ? 5 : 4) : hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));
+            if (!yp) return 1;
+            for (int c = 0; c < ncomp; c++) {
+                cf[c] = (int32_t *)calloc((size_t)mx * comp_h[c] * my * comp_v[c] * 64, sizeof(int32_t));
+                if (!cf[c]) { rc = -20; goto out; }
+            }
+        } else if (m == 0xc0 || m == 0xc1 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8)) {
+            rc = -5; goto out;
+        } else if (m == 0xc4) {
+            int o = 0;
+            while (o < sl) {
+                const int tc = seg[o] >> 4, th = seg[o] & 15;
+                if (tc > 1 || th > 3 || o + 17 > sl) { rc = -6; goto out; }
+                jpeg_dtab *t = &dt[tc][th];
+                int total = 0, code = 0, k = 0;
+                for (int len2 = 1; len2 <= 16; len2++) {
+                    const int cnt = seg[o + len2];
+                    t->valptr[len2] = k;
+                    t->mincode[len2] = code;
+                    t->maxcode[len2] = cnt ? code + cnt - 1 : -1;
+                    code = (code + cnt) << 1;
+                    k += cnt;
+                    total += cnt;
+                }
+                if (total > 256 || o + 17 + total > sl) { rc = -6; goto out; }
+                for (int i = 0; i < total; i++) t->value[i] = seg[o + 17 + i];
+                have_t[tc][th] = 1;
+                o += 17 + total;
+            }
+        } else if (m == 0xdd) {
+            if (sl < 2) { rc = -2; goto out; }
+            ri = (seg[0] << 8) | seg[1];
+        } else if (m == 0xee) {
+            if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) { rc = -9; goto out; }
+        } else if (m == 0xda) {
+            if (ncomp == 0) { rc = -8; goto out; }
+            const int ns = sl >= 1 ? seg[0] : 0;
+            if (ns < 1 || ns > ncomp || sl != 4 + 2 * ns) { rc = -8; goto out; }
+            int sc[3], td[3], ta[3];
+            for (int i = 0; i < ns; i++) {
+                int c = -1;
+                for (int j = 0; j < ncomp; j++) if (comp_id[j] == seg[1 + 2 * i]) c = j;
+                if (c < 0) { rc = -8; goto out; }
+                for (int j = 0; j < i; j++) if (sc[j] == c) { rc = -8; goto out; }
+                sc[i] = c; td[i] = seg[2 + 2 * i] >> 4; ta[i] = seg[2 + 2 * i] & 15;
+                if (td[i] > 3 || ta[i] > 3) { rc = -8; goto out; }
+            }
+            const int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if ((zs == 0 && ze != 0) || zs > ze || ze > 63) { rc = -8; goto out; }   /* "bad spectral selection bounds" */
+            if (zs != 0 && ns != 1) { rc = -8; goto out; }                           /* AC scans hold one component */
+            if (ah != 0 && ah != al + 1) { rc = -8; goto out; }                      /* "bad successive approximation values" */
+            if (al > 13) { rc = -8; goto out; }
+            for (int i = 0; i < ns; i++) {
+                if (zs == 0 && ah == 0 && !have_t[0][td[i]]) { rc = -8; goto out; }
+                if (zs != 0 && !have_t[1][ta[i]]) { rc = -8; goto out; }
+                seen[sc[i]] = 1;
+            }
+            if (ri > 0 && ns == 1 && comp_h[sc[0]] * comp_v[sc[0]] > 1) { rc = -12; goto out; }
+            jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};
+            int32_t pred[3] = {0, 0, 0};
+            uint32_t eob_run = 0;
+            long mcu = 0, block_count = 0;
+            int expected_rst = 0;
+            for (int my0 = 0; my0 < my; my0++)
+                for (int mx0 = 0; mx0 < mx; mx0++) {
+                    for (int i = 0; i < ns; i++) {
+                        const int c = sc[i], hi = comp_h[c], vi = comp_v[c];
+                        for (int j = 0; j < hi * vi; j++) {
+                            int bx, by;
+                            if (ns != 1) { bx = hi * mx0 + j % hi; by = vi * my0 + j / hi; }
+                            else {
+                                const int qq = mx * hi;
+                                bx = (int)(block_count % qq); by = (int)(block_count / qq);
+                                block_count++;
+                                /* the component's own extent in samples: ceil(W hi / hy) across, ceil(H vi / vy) down */
+                                if ((long)bx * 8 * hy >= (long)W * hi || (long)by * 8 * vy >= (long)H * vi) continue;
+                            }
+                            int32_t *b = cf[c] + ((size_t)by * mx * hi + bx) * 64;
+                            if (ah != 0) {
+                                const int e = jprog_refine(&br, b, &dt[1][ta[i]], zs, ze, (int32_t)1 << al, &eob_run);
+                                if (e) { rc = e; goto out; }
+                                continue;
+                            }
+                            int zig = zs;
+                            if (zig == 0) {
+                                zig++;
+                                const int s = jr_symbol(&br, &dt[0][td[i]]);
+                                if (br.bad || s > 16) { rc = -10; goto out; }
+                                pred[c] += jr_receive_extend(&br, s);
+                                b[0] = pred[c] * ((int32_t)1 << al);
+                            }
+                            if (zig <= ze && eob_run > 0) eob_run--;
+                            else {
+                                for (; zig <= ze; zig++) {
+                                    const int rs = jr_symbol(&br, &dt[1][ta[i]]);
+                                    if (br.bad) { rc = -10; goto out; }
+                                    const int v0 = rs >> 4, v1 = rs & 15;
+                                    if (v1 != 0) {
+                                        zig += v0;
+                                        if (zig > ze) break;
+                                        b[zig] = jr_receive_extend(&br, v1) * ((int32_t)1 << al);
+                                    } else {
+                                        if (v0 != 15) {
+                                            eob_run = 1u << v0;
+                                            if (v0 != 0) eob_run |= (uint32_t)jr_bits(&br, v0);
+                                            eob_run--;
+                                            break;
+                                        }
+                                        zig += 15;
+                                    }
+                                }
+                            }
+                            if (br.bad) { rc = -10; goto out; }
+                        }
+                    }
+                    mcu++;
+                    if (ri > 0 && mcu % ri == 0 && mcu < (long)mx * my) {
+                        br.nbits = 0;
+                        if (br.pos + 2 > br.n || br.p[br.pos] != 0xff || br.p[br.pos + 1] != (uint8_t)(0xd0 + expected_rst)) { rc = -11; goto out; }
+                        br.pos += 2;
+                        expected_rst = (expected_rst + 1) & 7;
+                        pred[0] = pred[1] = pred[2] = 0;
+                        eob_run = 0;
+                    }
+                }
+            pos = (long)(br.p - data) + (long)br.pos;                             /* the next marker is looked for from here */
+            continue;
+        }
+        pos += 2 + len;
+    }
+    if (ncomp == 0) { rc = -4; goto out; }
+    /* reconstructProgressiveImage: dequantise with the tables as they stand now, idct.go's IDCT, level shift, clamp */
+    {
+        const int ys = 8 * hy * mx, cs = 8 * mx;
+        memset(yp, 0, (size_t)ys * 8 * vy * my);
+        if (ncomp == 3) { memset(cbp, 0, (size_t)cs * 8 * my); memset(crp, 0, (size_t)cs * 8 * my); }
+        for (int c = 0; c < ncomp; c++) {
+            if (!seen[c]) continue;                                               /* progCoeffs[i] == nil: the plane stays zero */
+            if (!have_q[comp_q[c]]) { rc = -8; goto out; }
+            const int hi = comp_h[c], vi = comp_v[c], stride = mx * hi;
+            uint8_t *plane = c == 0 ? yp : (c == 1 ? cbp : crp);
+            const int ps = c == 0 ? ys : cs;
+            for (int by = 0; (long)by * 8 * vy < (long)H * vi; by++)
+                for (int bx = 0; (long)bx * 8 * hy < (long)W * hi; bx++) {
+                    const int32_t *z = cf[c] + ((size_t)by * stride + bx) * 64;
+                    int32_t b[64];
+                    for (int zig = 0; zig < 64; zig++) {
+                        if (z[zig] > 32767 || z[zig] < -32768) { rc = -13; goto out; }   /* beyond what any 8-bit image's file holds */
+                        b[jpeg_unzig[zig]] = z[zig] * (int32_t)q[comp_q[c]][zig];
+                    }
+                    orc_jpeg_idct(b);
+                    for (int j = 0; j < 8; j++)
+                        for (int k = 0; k < 8; k++) {
+                            const int32_t s = b[8 * j + k];
+                            plane[(size_t)(8 * by + j) * ps + 8 * bx + k] = (uint8_t)(s < -128 ? 0 : (s > 127 ? 255 : s + 128));
+                        }
+                }
+        }
+        if (coef) {                                                               /* the baseline decoder's layout: MCU by MCU, zig-zag order */
+            size_t blk = 0;
+            for (int my0 = 0; my0 < my; my0++)
+                for (int mx0 = 0; mx0 < mx; mx0++)
+                    for (int c = 0; c < ncomp; c++)
+                        for (int j = 0; j < comp_h[c] * comp_v[c]; j++, blk++) {
+                            const int bx = comp_h[c] * mx0 + j % comp_h[c], by = comp_v[c] * my0 + j / comp_h[c];
+                            const int32_t *z = cf[c] + ((size_t)by * mx * comp_h[c] + bx) * 64;
+                            for (int k = 0; k < 64; k++) coef[64 * blk + k] = (int16_t)z[k];
+                        }
+        }
+        rc = 1;
+    }
+out:
+    for (int c = 0; c < 3; c++) free(cf[c]);
+    return rc;
+}
+
 /* Decodes `data` into MCU-padded planes (yp: ys x 8*vmax*my rows ...).  Returns 1, with *wd, *ht, *ratio
  * (image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0; -1: one component, image.Gray) set, or a negative
  * error.  Call with yp == NULL to learn the dims first. */
@@ -2004,7 +2305,9 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
             for (int c = 0; c < ncomp; c++) {
                 comp_id[c] = seg[6 + 3 * c]; comp_h[c] = seg[7 + 3 * c] >> 4; comp_v[c] = seg[7 + 3 * c] & 15; comp_q[c] = seg[8 + 3 * c];
             }
-        } else if (m == 0xc1 || m == 0xc2 || (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+        } else if (m == 0xc2) {
+            return orc_jpeg_decode_progressive(data, n, wd, ht, ratio, yp, cbp, crp, coef);
+        } else if (m == 0xc1 || (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
             return -5;                                                            /* not baseline */
         } else if (m == 0xc4) {                                                   /* DHT */
             int o = 0;

@@ -170,8 +170,7 @@ def test_segment_parser_answers_or_refuses_never_crashes():
     assert parse(_pil(src, quality=80, subsampling=1)) == (96, 64) and parse(_pil_grey(src, quality=80)) == (96, 64)
     assert parse(_as_440(_pil(src, quality=80, subsampling=1))) == (64, 96)
     assert parse(_pil(src, quality=80, restart_marker_blocks=2)) == (96, 64)
-    with pytest.raises(fennec_amd.FennecUnsupported):
-        parse(_pil(src, quality=80, progressive=True))
+    assert parse(_pil(src, quality=80, progressive=True)) == (96, 64)          # r5: progressive frames are taken (jpeg_prog.cpp)
     for hv in (0x41, 0x42):                                   # 4:1:1, 4:1:0: taken since r4 (the geometry is the header's)
         assert parse(_with_luma_factors(good[0], hv)) == (96, 64)
     for hv in (0x14, 0x31, 0x44, 0x24):                       # four down (image/jpeg refuses it too), three across
@@ -347,8 +346,10 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
     import fennec_amd
     from PIL import Image
     src = _photo(160, 120, 4)
+    # progressive files are decoded since r5 -- bar a restart interval over one-component scans of a component with several
+    # blocks per MCU (image/jpeg counts frame MCUs there, T.81 the scan's own: the host codec's call)
     with pytest.raises(fennec_amd.FennecUnsupported):
-        ctx.jpeg_decode(_pil(src, quality=80, progressive=True))
+        ctx.jpeg_decode(_pil(src, quality=80, progressive=True, subsampling=2, restart_marker_blocks=3))
     # restart markers: one missing, two swapped
     rs = _pil(src, quality=80, subsampling=2, restart_marker_blocks=3)
     i0, i1 = rs.index(b"\xff\xd0"), rs.index(b"\xff\xd1")
@@ -404,12 +405,13 @@ def test_gpu_recompress_is_decode_plus_compress(ctx):
 
 @pytest.mark.gpu
 def test_gpu_native_pool_over_jpeg_files(ctx):
-    """fennec_CompressBatchJPEG: the C++ pool with fnx_jpeg_recompress per item, against the per-item calls; a progressive file
-    in the batch comes back FNX_ERR_UNSUPPORTED and the python caller's host decode takes it from there."""
+    """fennec_CompressBatchJPEG: the C++ pool with fnx_jpeg_recompress per item, against the per-item calls; a file the device
+    does not take (a progressive 4:2:0 file with restart intervals: tests/test_jpeg_progressive.py) comes back FNX_ERR_UNSUPPORTED
+    and the python caller's host decode takes it from there."""
     from fennec_amd import batch
     files = [_pil(_photo(640 + 16 * k, 480 - 8 * k, k), quality=95 - k, subsampling=2 if k % 2 else 0) for k in range(9)]
     files.append(orc.jpeg_encode(_photo(333, 217, 3), 97))
-    files.insert(4, _pil(_photo(320, 200, 11), quality=90, progressive=True))
+    files.insert(4, _pil(_photo(320, 200, 11), quality=90, progressive=True, subsampling=2, restart_marker_blocks=4))
     res, outs, summ = batch.compress_batch_jpeg_native(files, 0.94, workers=4)
     assert [r.Index for r in res] == list(range(len(files))) and all(r.Err is None for r in res)
     assert [r.host_decoded for r in res] == [i == 4 for i in range(len(files))]

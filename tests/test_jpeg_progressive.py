@@ -1,0 +1,252 @@
+"""Progressive JPEG sources (SOF2) -- VERDICT r4 "missing" 3: image.Decode of CompressBatch's source (batch.go:88-101 ->
+io.go:60-95) takes whatever image/jpeg takes, and the device path used to refuse these files.
+
+The scans are entropy-decoded on the host (fennec_amd/csrc/jpeg_prog.cpp: a refinement scan's bits depend on the
+coefficients of the scans before it), the image is made on the device by the baseline path's IDCT and colour kernels.
+
+CPU (not gpu):
+  * what pins the checker's progressive entropy decoding: libjpeg's progressive file of an image holds exactly the quantised
+    coefficients of its baseline file of the same image and quality -- the oracle reads both and they must agree, coefficient
+    by coefficient (all four scan kinds, EOB runs, every subsampling, grey, restart intervals);
+  * the oracle's pixels of such a file within the IDCTs' tolerance of libjpeg's own decode;
+  * the product's host decoder (fnx_jpeg_progressive_coefficients) against the oracle's, exactly;
+  * what it must refuse, truncations and a few thousand random mutations (it reads untrusted bytes).
+GPU (-m gpu): fnx_jpeg_decode / fnx_jpeg_recompress of progressive files against the oracle, bit for bit.
+"""
+import io
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from test_jpeg_decode import _mutations, _photo, _pil, _pil_decode, _pil_grey
+
+ZIG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56,
+       57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+SIZES = [(203, 117), (16, 16), (17, 9), (1, 1), (8, 300), (640, 480)]
+
+
+def _flat(w, h):
+    a = np.full((h, w, 4), 255, dtype=np.uint8)
+    a[..., :3] = (40, 90, 200)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the checker
+@pytest.mark.parametrize("sub", [0, 1, 2])
+def test_oracle_progressive_coefficients_are_the_baseline_files(sub):
+    for (w, h) in SIZES:
+        src = _photo(w, h, w + sub)
+        for q in (35, 75, 96):
+            for opt in (False, True):
+                base = orc.jpeg_decode_planes(_pil(src, quality=q, subsampling=sub), with_coefficients=True)
+                prog = orc.jpeg_decode_planes(_pil(src, quality=q, subsampling=sub, progressive=True, optimize=opt), with_coefficients=True)
+                assert prog[:3] == base[:3] and np.array_equal(prog[-1], base[-1]), (w, h, sub, q, opt)
+                # same coefficients, same tables: the same planes inside the image (a progressive image's MCU padding beyond the
+                # blocks that touch the image stays zero in image/jpeg: reconstructProgressiveImage)
+                bw, bh = 8 * ((w + 7) // 8), 8 * ((h + 7) // 8)
+                assert np.array_equal(prog[3][:bh, :bw], base[3][:bh, :bw]) and np.array_equal(prog[4], base[4]) and np.array_equal(prog[5], base[5])
+                assert not prog[3][bh:].any() and not prog[3][:, bw:].any()
+    # a flat image (EOB runs as long as the image) and noise at quality 100 (long codes, dense refinement passes)
+    for src, q in ((_flat(333, 217), 90), (np.random.default_rng(3).integers(0, 256, (64, 80, 4), dtype=np.uint8), 100)):
+        base = orc.jpeg_decode_planes(_pil(src, quality=q, subsampling=sub), with_coefficients=True)
+        prog = orc.jpeg_decode_planes(_pil(src, quality=q, subsampling=sub, progressive=True), with_coefficients=True)
+        assert np.array_equal(prog[-1], base[-1])
+
+
+def test_oracle_progressive_grey_and_restart_intervals():
+    src = _photo(203, 117, 5)
+    base = orc.jpeg_decode_planes(_pil_grey(src, quality=80), with_coefficients=True)
+    for kw in (dict(), dict(restart_marker_blocks=3), dict(restart_marker_rows=1)):
+        prog = orc.jpeg_decode_planes(_pil_grey(src, quality=80, progressive=True, **kw), with_coefficients=True)
+        assert prog[2] == -1 and np.array_equal(prog[-1], base[-1]) and np.array_equal(prog[3], base[3]), kw
+    # 4:4:4: every component is one block per MCU -- image/jpeg's restart count and T.81's agree
+    base = orc.jpeg_decode_planes(_pil(src, quality=80, subsampling=0), with_coefficients=True)
+    for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=7), dict(restart_marker_rows=2)):
+        data = _pil(src, quality=80, subsampling=0, progressive=True, **kw)
+        assert b"\xff\xdd" in data and b"\xff\xd3" in data
+        assert np.array_equal(orc.jpeg_decode_planes(data, with_coefficients=True)[-1], base[-1]), kw
+    # 4:2:0 / 4:2:2 with a restart interval: refused (the header of orc_jpeg_decode_progressive says why)
+    for sub in (1, 2):
+        with pytest.raises(RuntimeError, match="-12"):
+            orc.jpeg_decode_planes(_pil(src, quality=80, subsampling=sub, progressive=True, restart_marker_blocks=3))
+
+
+@pytest.mark.parametrize("sub", [0, 2])
+def test_oracle_progressive_pixels_against_libjpeg(sub):
+    src = _photo(203, 117, 3)
+    data = _pil(src, quality=85, subsampling=sub, progressive=True)
+    got = orc.jpeg_decode(data)
+    d = np.abs(got[..., :3].astype(int) - _pil_decode(data).astype(int))
+    assert got.shape == (117, 203, 4) and (got[..., 3] == 255).all()
+    assert d.mean() < (1.6 if sub == 2 else 0.6) and np.percentile(d, 99) <= (12 if sub == 2 else 3)     # (as for baseline files)
+    assert np.array_equal(got, orc.jpeg_decode(_pil(src, quality=85, subsampling=sub)))
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the product's host decoder
+def _product_coefficients(data):
+    import fennec_amd
+    coef, dims, ratio = fennec_amd.Context.jpeg_progressive_coefficients(data)
+    return coef[:, ZIG], dims, ratio                         # natural order -> the oracle's zig-zag order
+
+
+def test_host_decoder_against_the_oracle():
+    for sub in (0, 1, 2):
+        for (w, h) in SIZES:
+            src = _photo(w, h, 7 * w + sub)
+            for q, opt in ((35, False), (88, True), (100, False)):
+                data = _pil(src, quality=q, subsampling=sub, progressive=True, optimize=opt)
+                want = orc.jpeg_decode_planes(data, with_coefficients=True)
+                got, dims, ratio = _product_coefficients(data)
+                assert dims == (w, h) and ratio == want[2] and np.array_equal(got, want[-1]), (sub, w, h, q)
+    src = _photo(203, 117, 5)
+    for data in (_pil_grey(src, quality=80, progressive=True), _pil_grey(src, quality=80, progressive=True, restart_marker_blocks=3),
+                 _pil(src, quality=80, subsampling=0, progressive=True, restart_marker_blocks=5), _pil(_flat(333, 217), quality=90, progressive=True),
+                 _pil(np.random.default_rng(3).integers(0, 256, (64, 80, 4), dtype=np.uint8), quality=100, progressive=True)):
+        want = orc.jpeg_decode_planes(data, with_coefficients=True)
+        got, dims, ratio = _product_coefficients(data)
+        assert ratio == want[2] and np.array_equal(got, want[-1])
+
+
+def test_host_decoder_refuses_and_reports():
+    import fennec_amd
+    src = _photo(96, 64, 1)
+    good = _pil(src, quality=80, subsampling=2, progressive=True)
+    with pytest.raises(fennec_amd.FennecUnsupported):                                  # a baseline file: the device's scan decoder's
+        fennec_amd.Context.jpeg_progressive_coefficients(_pil(src, quality=80))
+    with pytest.raises(fennec_amd.FennecUnsupported, match="restart"):
+        fennec_amd.Context.jpeg_progressive_coefficients(_pil(src, quality=80, subsampling=2, progressive=True, restart_marker_blocks=2))
+    i = good.index(b"\xff\xc2")
+    twelve = good[:i + 4] + b"\x0c" + good[i + 5:]
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        fennec_amd.Context.jpeg_progressive_coefficients(twelve)
+    for bad in (good[: len(good) // 2], good[:-2], good[: len(good) * 3 // 4] + b"\xff\xd9"):
+        with pytest.raises(fennec_amd.FennecError) as e:
+            fennec_amd.Context.jpeg_progressive_coefficients(bad)
+        assert not isinstance(e.value, fennec_amd.FennecUnsupported)
+    # successive approximation that does not follow on (Ah != Al + 1), a spectral band that runs backwards, AC for three components
+    s2 = good.index(b"\xff\xda", good.index(b"\xff\xda") + 2)                          # the second scan: Y, AC 1..5, Al = 2
+    assert good[s2 + 4] == 1 and good[s2 + 7] == 1 and good[s2 + 8] == 5
+    for patch in ((s2 + 9, 0x31), (s2 + 7, 9), (s2 + 8, 64)):
+        b = bytearray(good)
+        b[patch[0]] = patch[1]
+        with pytest.raises(fennec_amd.FennecError):
+            fennec_amd.Context.jpeg_progressive_coefficients(bytes(b))
+
+
+def test_host_decoder_on_damaged_files_agrees_with_the_checker_or_refuses():
+    """random bytes replaced anywhere behind the frame header: the host decoder answers or refuses, never crashes, and where both
+    it and the checker decode they hold the same coefficients"""
+    import fennec_amd
+    rng = np.random.default_rng(23)
+    src = _photo(120, 72, 2)
+    both = one = neither = 0
+    for g in (_pil(src, quality=85, subsampling=2, progressive=True), _pil(src, quality=70, subsampling=0, progressive=True, optimize=True),
+              _pil_grey(src, quality=90, progressive=True, restart_marker_blocks=4)):
+        lo = g.index(b"\xff\xc2") + 20
+        for c in _mutations(g, rng, 700, lo, len(g) - 2) + [g[:k] for k in range(lo, len(g), 37)]:
+            try:
+                want = orc.jpeg_decode_planes(c, with_coefficients=True)[-1]
+            except Exception:
+                want = None
+            try:
+                got = _product_coefficients(c)[0]
+            except fennec_amd.FennecError:
+                got = None
+            if got is not None and want is not None:
+                assert np.array_equal(got, want)
+                both += 1
+            elif got is None and want is None:
+                neither += 1
+            else:
+                one += 1
+    print(f"damaged progressive files: both decode {both}, one side only {one}, neither {neither}")
+    assert both > 200 and neither > 100
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ctx():
+    import fennec_amd
+    return fennec_amd.Context(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", [0, 1, 2])
+def test_gpu_decode_of_progressive_files(ctx, sub):
+    for (w, h) in SIZES + [(1920, 1080)]:
+        src = _photo(w, h, w + 3 * sub)
+        for q, opt in ((40, False), (92, True)):
+            data = _pil(src, quality=q, subsampling=sub, progressive=True, optimize=opt)
+            assert ctx.jpeg_decode_config(data) == (w, h)
+            got = ctx.jpeg_decode(data)
+            assert np.array_equal(got, orc.jpeg_decode(data)), (w, h, sub, q)
+            assert np.array_equal(got, orc.jpeg_decode(_pil(src, quality=q, subsampling=sub)))       # = the baseline file's image
+
+
+@pytest.mark.gpu
+def test_gpu_decode_progressive_grey_restart_4k_and_device_output(ctx):
+    import torch
+    src = _photo(203, 117, 5)
+    for data in (_pil_grey(src, quality=80, progressive=True), _pil_grey(src, quality=80, progressive=True, restart_marker_rows=1),
+                 _pil(src, quality=80, subsampling=0, progressive=True, restart_marker_blocks=5), _pil(_flat(333, 217), quality=90, progressive=True)):
+        assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data))
+    big = _pil(_photo(3840, 2160, 9), quality=90, subsampling=2, progressive=True)
+    want = orc.jpeg_decode(big)
+    assert np.array_equal(ctx.jpeg_decode(big), want)
+    t = ctx.jpeg_decode(big, device=True)
+    ctx.sync()
+    assert t.is_cuda and np.array_equal(t.cpu().numpy(), want)
+    # a baseline file right behind it on the same ctx (the scratch slots are shared)
+    base = _pil(_photo(640, 480, 1), quality=85, subsampling=2)
+    assert np.array_equal(ctx.jpeg_decode(base), orc.jpeg_decode(base))
+
+
+@pytest.mark.gpu
+def test_gpu_recompress_of_progressive_sources(ctx):
+    """CompressBatch's item body over a progressive source: decode + compressJPEGOptimal's search, no host codec"""
+    for (w, h, sub) in [(640, 480, 2), (333, 217, 0), (1283, 719, 1)]:
+        src = _photo(w, h, 7)
+        data = _pil(src, quality=93, subsampling=sub, progressive=True)
+        out, q, s, steps, dims = ctx.jpeg_recompress(data, 0.94)
+        assert dims == (w, h)
+        assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
+        assert (out, q, s, steps) == ctx.jpeg_recompress(_pil(src, quality=93, subsampling=sub), 0.94)[:4]
+    grey = _pil_grey(_photo(203, 117, 2), quality=91, progressive=True)
+    out, q, s, steps, dims = ctx.jpeg_recompress(grey, 0.94)
+    assert (out, q, s, steps) == ctx.jpeg_compress(orc.jpeg_decode(grey), 0.94)
+
+
+@pytest.mark.gpu
+def test_gpu_native_pool_takes_progressive_files(ctx):
+    from fennec_amd import batch
+    files = [_pil(_photo(320 + 16 * k, 200 + 8 * k, k), quality=92, subsampling=(0, 1, 2)[k % 3], progressive=bool(k % 2)) for k in range(6)]
+    res, outs, summ = batch.compress_batch_jpeg_native(files, 0.94, workers=3)
+    assert all(r.Err is None for r in res) and not any(r.host_decoded for r in res)
+    for r, f, data in zip(res, outs, files):
+        want, q, s, n = ctx.jpeg_compress(orc.jpeg_decode(data), 0.94)
+        assert (r.Quality, r.SSIM, r.steps) == (q, s, n) and f == want
+
+
+@pytest.mark.gpu
+def test_gpu_decode_of_damaged_progressive_files(ctx):
+    import fennec_amd
+    rng = np.random.default_rng(31)
+    g = _pil(_photo(200, 136, 2), quality=85, subsampling=2, progressive=True)
+    lo = g.index(b"\xff\xda") + 14
+    both = 0
+    for c in _mutations(g, rng, 150, lo, len(g) - 2):
+        try:
+            want = orc.jpeg_decode(c)
+        except Exception:
+            want = None
+        try:
+            got = ctx.jpeg_decode(c)
+        except fennec_amd.FennecError:
+            got = None
+        if got is not None and want is not None:
+            assert np.array_equal(got, want)
+            both += 1
+    assert both > 40
+    assert np.array_equal(ctx.jpeg_decode(g), orc.jpeg_decode(g))

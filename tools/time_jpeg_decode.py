@@ -28,6 +28,8 @@ for W, H in sizes:
     for label, data in (("libjpeg q=90 4:2:0", pil(photo, quality=90, subsampling=2)),
                         ("libjpeg q=75 4:2:0", pil(photo, quality=75, subsampling=2)),
                         ("libjpeg q=95 4:4:4", pil(photo, quality=95, subsampling=0)),
+                        ("libjpeg q=90 4:2:0 progressive", pil(photo, quality=90, subsampling=2, progressive=True)),
+                        ("libjpeg q=95 4:4:4 progressive", pil(photo, quality=95, subsampling=0, progressive=True)),
                         ("bench source (synth.make_test_image, q=90)", pil(synth.make_test_image(W, H), quality=90, subsampling=2))):
         t = ctx.jpeg_decode(data, device=True)
         ctx.sync()
