@@ -1295,6 +1295,7 @@ int fnx_jpeg_progressive_coefficients(const uint8_t *data, size_t n, int16_t *co
     *w = f.w; *h = f.h; *ratio = f.ratio;
     if (coef == nullptr) return FNX_OK;
     FNX_REQUIRE(cap_blocks >= nblk, "coefficient capacity");
+    if (8ull * n < nblk) return jpeg_corrupt("the file is too short for the image's blocks");       // (as fnx_jpeg_decode: before anything is sized by the header)
     std::memset(coef, 0, sizeof(int16_t) * 64 * static_cast<size_t>(nblk));
     return jpeg_progressive_coefficients(data, n, &f, coef);
 }
