@@ -576,6 +576,30 @@ def main() -> int:
                            "steps": args.steps, "warmup": args.warmup, "roofline_frac": round(4.0 * S * B / t_c / 1e9 / HBM_PEAK_GBS, 4),
                            "note": "fnx_gaussian_blur_batch then fnx_ssim_fast_batch on the same 32 images: the reference's two calls, "
                                    "4*S of HBM traffic per image; same protocol as the timed region, run after it"}
+        # (c) the same two calls with the hand-over flag: the blur call promises that the scoring call over the same pairs comes next
+        keep_plan = ctx.plan_blur_batch(srcs, SIGMA, outs=dsts, exact=exact, keep_box_sums=True)
+        plain_vals = np.array(ssim_plans[0].run())
+
+        def two_call_keep_steps(n):
+            for _ in range(n):
+                keep_plan.run()                                # fnx_gaussian_blur_batch(FNX_BLUR_KEEP_BOX_SUMS)
+                ssim_plans[0].enqueue()                        # fnx_ssim_fast_batch_enqueue: the kept box sums, no image read
+                vals[:] = ssim_plans[0].fetch()
+        t_k = time.perf_counter()
+        while time.perf_counter() - t_k < 0.1:
+            two_call_keep_steps(2)
+        two_call_keep_steps(args.warmup)
+        torch.cuda.synchronize()
+        t_k = time.perf_counter()
+        two_call_keep_steps(args.steps)
+        torch.cuda.synchronize()
+        t_k = (time.perf_counter() - t_k) / args.steps
+        out["two_call_keep"] = {"value": round(mp_per_image * B / t_k, 1), "unit": "MP/s", "ms_per_step": round(t_k * 1e3, 4),
+                                "steps": args.steps, "warmup": args.warmup, "roofline_frac": round(4.0 * S * B / t_k / 1e9 / HBM_PEAK_GBS, 4),
+                                "max_abs_diff_vs_plain_two_call": float(np.max(np.abs(vals - plain_vals))),
+                                "note": "the same two calls with FNX_BLUR_KEEP_BOX_SUMS on the blur: its kernel takes SSIMFast's box sums of "
+                                        "both sides as it passes, fnx_ssim_fast_batch reads neither image again (2*S of traffic, priced "
+                                        "against the path's 4*S like `value`); the caller promises the scoring call comes next"}
         ctx.profile(True)
     host0 = srcs[0].cpu().numpy() if rank == 0 else None
     if rank == 0 and not args.no_extras:

@@ -39,7 +39,7 @@ LIB_PATH = os.environ.get("FENNEC_HIP_LIB") or os.path.join(_HERE, "libfennec_hi
 
 FNX_OK, FNX_NOOP, FNX_EMPTY = 0, 1, 2
 FNX_HOST, FNX_DEVICE, FNX_DEVICE_SRC = 0, 1, 2
-FNX_BLUR_FAST, FNX_BLUR_EXACT = 0, 1
+FNX_BLUR_FAST, FNX_BLUR_EXACT, FNX_BLUR_KEEP_BOX_SUMS = 0, 1, 2
 PROF_MAIN, PROF_SSIM, PROF_RESIZE, PROF_FX, PROF_JPEG = 1, 2, 4, 8, 16
 
 _u8p = C.c_void_p
@@ -1002,9 +1002,11 @@ class Context:
             plan.run()
         return plan.outs
 
-    def plan_blur_batch(self, imgs, sigma: float, outs=None, exact: bool = False):
+    def plan_blur_batch(self, imgs, sigma: float, outs=None, exact: bool = False, keep_box_sums: bool = False):
         """Pre-marshal a batched blur (pointer tables, kernel) so that run() is one C call --
-        lets a caller bracket the launch tightly with events."""
+        lets a caller bracket the launch tightly with events.  keep_box_sums (FNX_BLUR_KEEP_BOX_SUMS): the caller's next call on
+        this ctx is the SSIMFast batch over (imgs[i], outs[i]) and nothing writes the images in between -- that call then reads
+        neither full-size image again."""
         views = self._batch_views(imgs)
         w, h, st = views[0].w, views[0].h, views[0].stride
         if outs is None:
@@ -1017,7 +1019,7 @@ class Context:
         dsts = (C.c_void_p * n)(*[v.ptr for v in oviews])
         radius, kernel = self.blurKernel(sigma)
         k, pk = _f64(kernel)
-        flags = FNX_BLUR_EXACT if exact else FNX_BLUR_FAST
+        flags = (FNX_BLUR_EXACT if exact else FNX_BLUR_FAST) | (FNX_BLUR_KEEP_BOX_SUMS if keep_box_sums else 0)
         ctx, lib, ost = self, self._lib, oviews[0].stride
 
         class _Plan:

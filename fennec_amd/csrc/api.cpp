@@ -284,6 +284,36 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
     const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
     void *dp[2];
     FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+    const bool keep = (flags & FNX_BLUR_KEEP_BOX_SUMS) != 0;
+    flags &= ~FNX_BLUR_KEEP_BOX_SUMS;
+    ctx->kept.valid = false;
+    int nw, nh;
+    if (keep && ssim_fast_dims(w, h, &nw, &nh) && nw >= 8 && nh >= 8) {
+        // the one-pass kernel (fnx_gaussian_blur_ssim_fast_batch's first half): the same blurred bytes, and the box planes of both
+        // sides into buffer set p.  The set stays this batch's until the scoring call -- or, if none comes, until the next
+        // one-pass launch on it, which waits for ev_tail[p] like any other.
+        const int p = ctx->parity;
+        const size_t plane = static_cast<size_t>(nw) * nh * 4;
+        void *t = nullptr;
+        FNX_TRY(scratch(ctx, p ? SLOT_PLANES1 : SLOT_PLANES0, plane * 2 * n + 16, &t));
+        if (ctx->tail_pending[p]) FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
+        const int st = launch_blur_scored(ctx, n, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel, radius, flags,
+                                          static_cast<uint8_t *const *>(dp[1]), dstride, static_cast<uint8_t *>(t), plane, nw, nh);
+        if (st < 0) return st;
+        if (st == FNX_OK) {
+            FNX_HIP(hipEventRecord(ctx->ev_tail[p], ctx->stream2));      // behind box_from_slabs_kernel
+            ctx->tail_pending[p] = true;
+            fnx_ctx::KeptBoxes &k = ctx->kept;
+            k.srcs.assign(srcs, srcs + n);
+            k.dsts.assign(dsts, dsts + n);
+            k.n = n; k.sstride = sstride; k.dstride = dstride; k.w = w; k.h = h; k.nw = nw; k.nh = nh; k.parity = p;
+            k.planes = static_cast<uint8_t *>(t); k.plane = plane;
+            k.seq = ctx->op_seq;
+            k.valid = true;
+            return FNX_OK;
+        }
+        // FNX_NOOP: a shape the one-pass kernel is not built for -- the plain blur, nothing kept
+    }
     return launch_blur(ctx, n, nullptr, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel,
                        radius, flags, nullptr, static_cast<uint8_t *const *>(dp[1]), dstride);
 }
@@ -482,6 +512,26 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
     FNX_TRY(result_slot_queued(ctx, n, &dres));
+    {   // the box planes a fnx_gaussian_blur_batch(FNX_BLUR_KEEP_BOX_SUMS) left for exactly this call?
+        fnx_ctx::KeptBoxes &k = ctx->kept;
+        bool use = k.valid && k.seq + 1 == ctx->op_seq && k.n == n && k.sstride == astride && k.dstride == bstride && k.w == w && k.h == h;
+        for (int i = 0; use && i < n; i++) use = as[i] == k.srcs[i] && bs[i] == k.dsts[i];
+        k.valid = false;
+        if (use) {
+            // fnx_gaussian_blur_ssim_fast_batch's second half, on the main stream behind the planes (box_from_slabs_kernel ran on
+            // the second one): neither full-size image is read again
+            const int p = k.parity;
+            FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
+            ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;
+            const int rc = launch_windowed_ssim(ctx, n, k.planes, k.nw * 4, k.plane, k.planes + k.plane * n, k.nw * 4, k.plane, k.nw, k.nh,
+                                                window, static_cast<const double *>(dwin), dres);
+            ctx->partial_slot = -1;
+            if (rc < 0) return rc;
+            ctx->tail_pending[p] = false;        // everything that read set p is now in front of whatever `stream` runs next
+            ctx->parity ^= 1;
+            return publish_results(ctx, dres, n);
+        }
+    }
     int nw, nh;
     bool al = !(astride & 15) && !(bstride & 15);
     for (int i = 0; i < n; i++) {

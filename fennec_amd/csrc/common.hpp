@@ -128,6 +128,18 @@ struct fnx_ctx {
     int ev_toggle = 0;           // fnx_ssim_enqueue alternates between the two hand-over events
     bool stream2_used = false;
     int partial_slot = -1;       // >= 0: launch_windowed_ssim takes its partial sums from this slot (one-pass tail)
+    // fnx_gaussian_blur_batch with FNX_BLUR_KEEP_BOX_SUMS (api.cpp): the boxDownsample planes of the batch's sources and blurred
+    // images, made by the blur's own pass, wait here for the fnx_ssim_fast_batch(_enqueue) that scores exactly these pairs --
+    // the very next call on the ctx (op_seq) or nothing
+    struct KeptBoxes {
+        bool valid = false;
+        unsigned long long seq = 0;
+        int n = 0, sstride = 0, dstride = 0, w = 0, h = 0, nw = 0, nh = 0, parity = 0;
+        std::vector<const uint8_t *> srcs, dsts;
+        uint8_t *planes = nullptr;
+        size_t plane = 0;
+    } kept;
+    unsigned long long op_seq = 0;     // exported calls bound to this ctx so far (bind)
     fnx::Scratch slot[fnx::SLOT_COUNT];
     fnx::TableCache tcache[fnx::SLOT_COUNT];
     // pinned host ring: tables going up, scalars coming down

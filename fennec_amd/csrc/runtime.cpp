@@ -115,6 +115,7 @@ int bind(fnx_ctx *ctx)
         return FNX_ERR_INVALID;
     }
     FNX_HIP(hipSetDevice(ctx->device));
+    ctx->op_seq++;
     return FNX_OK;
 }
 

@@ -133,6 +133,78 @@ def test_one_pass_equals_two_calls(ctx, orc, w, h):
                 assert np.array_equal(outs[0].cpu().numpy(), orc.gaussian_blur(imgs[0], 2.0, procs=16))
 
 
+@pytest.mark.parametrize("w,h", [(3840, 2160), (2560, 1440), (3000, 272 * 3 + 5)])
+def test_two_calls_with_kept_box_sums(ctx, orc, w, h):
+    """FNX_BLUR_KEEP_BOX_SUMS: fnx_gaussian_blur_batch runs the SCORE form and the fnx_ssim_fast_batch that
+    follows over the same pairs reads no image -- the same bytes and the same scores as the one-pass entry and as the plain two
+    calls; any other call in between, other pairs, or a shape the one-pass kernel does not take drops the sums."""
+    import torch
+    imgs = [synth.noise_image(w, h, w + 7 * h, alpha=True), synth.large_photo(w, h, 4), synth.large_photo(w, h, 9)]
+    d = [torch.from_numpy(i).cuda() for i in imgs]
+    outs = [torch.empty_like(t) for t in d]
+    other = [torch.empty_like(t) for t in d]
+    torch.cuda.synchronize()
+    for exact in (False, True):
+        for sigma in (2.0, 3.0):
+            keep = ctx.plan_blur_batch(d, sigma, outs=outs, exact=exact, keep_box_sums=True)
+            score = ctx.plan_ssim_fast_batch(d, outs)
+            keep.run()
+            assert "SCORE" in ctx.last_kernel(1)
+            got = score.run().copy()
+            assert ctx.last_kernel(2) == "windowed_ssim_march_kernel"                # the one-pass tail, not box_tiled + windowed_ssim
+            ctx.sync()
+            kept_bytes = [o.clone() for o in outs]
+            ref_outs, ref_ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=exact)
+            plain_outs = ctx.GaussianBlurBatch(d, sigma, exact=exact)
+            plain_ss = ctx.SSIMFastBatch(d, plain_outs)
+            assert ctx.last_kernel(2) != "windowed_ssim_march_kernel"
+            for k in range(len(imgs)):
+                assert torch.equal(kept_bytes[k], ref_outs[k]) and torch.equal(kept_bytes[k], plain_outs[k])
+                assert got[k] == ref_ss[k] == plain_ss[k]
+    assert abs(got[1] - orc.ssim_fast(imgs[1], kept_bytes[1].cpu().numpy(), procs=16)) <= 1e-9
+    # a call in between (here: the images change under a sync): the sums are dropped, the scores are those of the images as they are
+    keep = ctx.plan_blur_batch(d, 2.0, outs=outs, keep_box_sums=True)
+    score = ctx.plan_ssim_fast_batch(d, outs)
+    keep.run()
+    ctx.sync()
+    outs[0].copy_(d[0])
+    torch.cuda.synchronize()
+    got = score.run().copy()
+    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[0] == 1.0 and got[1] == plain_ss[1]
+    # other pairs than the blur's: dropped
+    ctx.plan_blur_batch(d, 2.0, outs=other, keep_box_sums=False).run()
+    keep.run()
+    got = ctx.plan_ssim_fast_batch(d, other).run().copy()
+    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[1] == plain_ss[1]
+    got = score.run().copy()                                                         # (and the kept set is gone for good)
+    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[1] == plain_ss[1]
+    # two kept blurs in a row, the second one consumed; then the enqueue / fetch form
+    keep.run(); keep.run()
+    got = score.run().copy()
+    assert ctx.last_kernel(2) == "windowed_ssim_march_kernel" and got[1] == plain_ss[1] and got[2] == plain_ss[2]
+    keep.run(); score.enqueue()
+    assert np.array_equal(score.fetch(), got)
+    # a subset of the batch is another batch
+    keep.run()
+    sub = ctx.plan_ssim_fast_batch(d[:2], outs[:2]).run().copy()
+    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and sub[1] == plain_ss[1]
+
+
+def test_kept_box_sums_on_shapes_without_a_one_pass_form(ctx):
+    import torch
+    for (w, h, sigma) in ((640, 480, 2.0), (3840, 2160, 9.0), (1700, 1000, 2.0)):   # no downsample; radius 27; a box ratio the one-pass form leaves
+        imgs = [synth.large_photo(w, h, 2), synth.noise_image(w, h, 5, alpha=True)]
+        d = [torch.from_numpy(i).cuda() for i in imgs]
+        outs = [torch.empty_like(t) for t in d]
+        torch.cuda.synchronize()
+        ctx.plan_blur_batch(d, sigma, outs=outs, keep_box_sums=True).run()
+        assert "SCORE" not in ctx.last_kernel(1)
+        got = ctx.plan_ssim_fast_batch(d, outs).run().copy()
+        ctx.sync()
+        want_outs = ctx.GaussianBlurBatch(d, sigma)
+        assert all(torch.equal(a, b) for a, b in zip(outs, want_outs)) and np.array_equal(got, ctx.SSIMFastBatch(d, want_outs))
+
+
 @pytest.mark.parametrize("sigma", [2.4, 3.0, 4.6, 4.7, 5.0, 6.0, 7.3, 7.4, 8.0, 8.1])
 def test_wide_radii(ctx, orc, sigma):
     """radius 8 .. 24 on blur_mfma_wide_kernel (two, three, four 64-byte K chunks per H set; 64-row V window), 25: blur.hip"""
