@@ -527,6 +527,7 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
                                                 window, static_cast<const double *>(dwin), dres);
             ctx->partial_slot = -1;
             if (rc < 0) return rc;
+            note_route(ctx, FNX_PROF_SSIM, "kept box planes + windowed SSIM");
             ctx->tail_pending[p] = false;        // everything that read set p is now in front of whatever `stream` runs next
             ctx->parity ^= 1;
             return publish_results(ctx, dres, n);

