@@ -15,7 +15,7 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:protect_shad
 # ASan's dlopen interceptor loses the caller's RUNPATH: torch finds its own libraries through LD_LIBRARY_PATH instead
 export LD_LIBRARY_PATH=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib'))"):${LD_LIBRARY_PATH:-}
 # libstdc++ beside the runtime: its __cxa_throw interceptor must find the real one (torch throws during CUDA init)
-LD_PRELOAD="$RT $(gcc -print-file-name=libstdc++.so)" timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_jpeg_roundtrip.py tests/test_jpeg_decode.py -x -q -m gpu \
+LD_PRELOAD="$RT $(gcc -print-file-name=libstdc++.so)" timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_jpeg_roundtrip.py tests/test_jpeg_decode.py tests/test_jpeg_progressive.py tests/test_blur_mfma_gpu.py -x -q -m gpu \
     -k "not 8k and not 4k and not config" "$@" > gpurun_out/asan_pytest.log 2>&1
 rc=$?
 tail -15 gpurun_out/asan_pytest.log; echo "pytest rc=$rc"; ls gpurun_out/asan_report* 2>/dev/null && head -60 gpurun_out/asan_report*

@@ -67,6 +67,20 @@ assert all(r.Err is None for r in nres) and nsumm.Succeeded == len(items)
 # ... over files (fennec_CompressBatchJPEG: decoder + search + encoder per item on the workers' contexts)
 jres, jfiles, jsumm = batch.compress_batch_jpeg_native(jpegs, workers=4)
 assert all(r.Err is None for r in jres) and jsumm.Succeeded == len(jpegs)
+# ... progressive files among them (r5: every worker runs the host-side scan decoder, jpeg_prog.cpp, for its own items)
+
+
+def _progressive(img, q):
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(img[..., :3]), "RGB").save(b, "JPEG", quality=q, subsampling=2, progressive=True)
+    return b.getvalue()
+
+
+mixed = [(_progressive(synth.large_photo(640, 480, k), 92) if k % 2 else jpegs[k]) for k in range(12)]
+pres, pfiles, psumm = batch.compress_batch_jpeg_native(mixed, workers=4)
+assert all(r.Err is None for r in pres) and psumm.Succeeded == len(mixed) and not any(r.host_decoded for r in pres)
 print("errors:", errs)
 print("done" if not errs else "FAILED")
 sys.exit(1 if errs else 0)
