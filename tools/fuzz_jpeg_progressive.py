@@ -70,7 +70,11 @@ while time.time() - t0 < budget:
     if (grey or sub == 0) and it % 3 == 0:        # restart intervals where image/jpeg's count and T.81's agree
         kw["restart_marker_blocks"] = int(rng.integers(1, 40))
     img = content(w, h)
-    data = pil(img, grey, **kw)
+    try:
+        data = pil(img, grey, **kw)
+    except OSError:                               # Pillow's encoder buffer: some small noisy images at high quality do not fit it
+        runs["encoder_refused"] = runs.get("encoder_refused", 0) + 1
+        continue
     desc = f"seed {seed} it {it}: {w}x{h} grey={grey} {kw}"
     try:
         want = orc.jpeg_decode(data)
