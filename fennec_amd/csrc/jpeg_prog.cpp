@@ -19,6 +19,7 @@
 // other than 1 x 1, a component no scan mentions, coefficients beyond 16 bits.
 // Plain C++ with no device code: this file reads untrusted bytes and is part of the sanitizer builds (make asan / tsan).
 #include <cstring>
+#include <new>
 #include <vector>
 #include "common.hpp"
 
@@ -153,7 +154,13 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
     uint8_t q[4][64];
     bool have_q[4] = {false, false, false, false}, seen[3] = {false, false, false};
     std::vector<HTab> tabs(8);                   // [tc * 4 + th]
-    std::vector<uint64_t> nzmask(static_cast<size_t>(f->mx) * f->my * f->nslots, 0);   // per block: its non-zero AC coefficients by zig-zag position
+    std::vector<uint64_t> nzmask;                // per block: its non-zero AC coefficients by zig-zag position
+    try {
+        nzmask.assign(static_cast<size_t>(f->mx) * f->my * f->nslots, 0);
+    } catch (const std::bad_alloc &) {
+        set_error("jpeg decode: no host memory for a progressive image of %d x %d", f->w, f->h);
+        return FNX_ERR_OOM;
+    }
     int ri = 0;
     bool range_ok = true;
     size_t pos = 2;
