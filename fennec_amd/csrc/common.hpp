@@ -463,7 +463,7 @@ struct JpegFile {
     uint16_t q[3][64];           // per component, natural order
     size_t scan = 0;             // offset of the entropy-coded segment in the file
     int rounds = 0;              // cross-workgroup synchronisation rounds the decode took
-    bool progressive = false;    // SOF2: the scans are entropy-decoded on the host (jpeg_prog.cpp), the image is made on the device
+    bool progressive = false;    // the scans are entropy-decoded on the host (jpeg_prog.cpp: SOF2, SOF1, sequential scans the device has no form for), the image is made on the device
     DecTables tab;
 };
 int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);

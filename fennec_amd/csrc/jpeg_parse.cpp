@@ -29,6 +29,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
     bool have_q[4] = {false, false, false, false}, have_t[4] = {false, false, false, false}, have_sof = false;
     // what only a baseline scan minds (a progressive file's scans are decoded on the host, jpeg_prog.cpp, with tables of their own)
     const char *baseline_only = nullptr;
+    bool sof1_or_2 = false, allones = false;
     f->progressive = false;
     uint8_t q[4][64];
     int ncomp = 0, comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
@@ -56,9 +57,10 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 have_q[tq] = true;
                 o += 65;
             }
-        } else if (m == 0xc0 || m == 0xc2) {
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
             if (have_sof) return jpeg_corrupt("two SOF segments");
-            f->progressive = m == 0xc2;
+            f->progressive = m != 0xc0;      // SOF2, and SOF1 (extended sequential: up to four tables per class): the host reads the scans
+            sof1_or_2 = m != 0xc0;
             if (sl < 6) return jpeg_corrupt("bad SOF segment");
             if (seg[0] != 8) return jpeg_unsupported("a sample precision other than 8 bits");
             if (seg[5] != 3 && seg[5] != 1) return jpeg_unsupported("a component count other than 1 and 3");
@@ -75,8 +77,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 if (comp_q[c] > 3) return jpeg_corrupt("bad quantisation table selector");
             }
             have_sof = true;
-        } else if (m == 0xc1 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-            return jpeg_unsupported("a frame type other than baseline and progressive");
+        } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+            return jpeg_unsupported("a frame type other than sequential and progressive Huffman coding");
         } else if (m == 0xcc) {
             return jpeg_unsupported("arithmetic coding");
         } else if (m == 0xc4) {
@@ -104,7 +106,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                         // T.81 C.2 keeps the all-ones code of every length unassigned, and the kernels lean on it: the 1-bits
                         // that pad the byte before a restart marker (and the string's last byte) can then never be a symbol.
                         // A table that assigns it is one the host codec gets to read.
-                        if (code + 1 == (1u << L) && !baseline_only) baseline_only = "a Huffman table that assigns the all-ones code";
+                        if (code + 1 == (1u << L)) allones = true;                 // (image/jpeg reads such a table: the host decodes the scan)
                         f->tab.value[t][k] = seg[o + 17 + k];
                         if (L <= DEC_FAST_BITS)
                             for (uint32_t x = code << (DEC_FAST_BITS - L); x < ((code + 1) << (DEC_FAST_BITS - L)); x++)
@@ -141,7 +143,17 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             f->nslots = f->hy * f->vy + ncomp - 1;
             f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
             f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);
+            // A baseline frame whose scan the device's decoder has no form for -- the components in scans of their own or out of
+            // frame order, a table that assigns the all-ones code -- is the host decoder's too (r5: jpeg_prog.cpp reads sequential
+            // scans as well).  A baseline file with table selectors above 1 stays refused: image/jpeg refuses it ("bad Th value").
+            if (!f->progressive && !baseline_only && sl >= 1 && seg[0] >= 1) {
+                bool host = allones || seg[0] < ncomp;
+                if (seg[0] == ncomp && sl >= 1 + 2 * static_cast<size_t>(ncomp))
+                    for (int c = 0; c < ncomp; c++) host = host || seg[1 + 2 * c] != comp_id[c];
+                f->progressive = host;
+            }
             if (f->progressive) {                                         // the scans are jpeg_progressive_coefficients' to read
+                if (!sof1_or_2 && baseline_only) return jpeg_unsupported(baseline_only);
                 f->scan = pos;
                 return FNX_OK;
             }

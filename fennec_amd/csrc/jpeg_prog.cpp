@@ -15,6 +15,8 @@
 //     blocks in raster order, without data for blocks wholly outside the image;
 //   * image/jpeg counts FRAME MCUs between restart markers in every scan where T.81 counts the scan's own: the two agree only
 //     for components of one block per MCU, anything else with a restart interval is FNX_ERR_UNSUPPORTED (the host codec's call).
+// r5, later: the SEQUENTIAL files the device's scan decoder has no form for are read here as well -- SOF1 (extended sequential),
+// components in scans of their own or out of frame order, a Huffman table that assigns the all-ones code.
 // Not handled (FNX_ERR_UNSUPPORTED, as for baseline files): 12-bit samples, four components, arithmetic coding, chroma factors
 // other than 1 x 1, a component no scan mentions, coefficients beyond 16 bits.
 // Plain C++ with no device code: this file reads untrusted bytes and is part of the sanitizer builds (make asan / tsan).
@@ -151,6 +153,11 @@ inline int refine_nonzeroes(BitReader &br, int16_t *b, uint64_t mask, int zig, i
 int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, int16_t *coef)
 {
     Frame fr;
+    // sequential frames (SOF0 / SOF1) whose scans the device's decoder has no form for come here too: processSOS is one function,
+    // with Ss, Se, Ah, Al fixed at 0, 63, 0, 0 whatever the scan header says (Table B.3), and a block is dequantised when its scan
+    // decodes it -- with the table in force then (qsnap), not at EOI
+    bool sequential = false;
+    uint8_t qsnap[3][64];
     uint8_t q[4][64];
     bool have_q[4] = {false, false, false, false}, seen[3] = {false, false, false};
     std::vector<HTab> tabs(8);                   // [tc * 4 + th]
@@ -186,8 +193,9 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                 have_q[tq] = true;
                 o += 65;
             }
-        } else if (m == 0xc2) {
+        } else if (m == 0xc2 || m == 0xc0 || m == 0xc1) {
             if (fr.ncomp != 0) return jpeg_corrupt("two SOF segments");
+            sequential = m != 0xc2;
             if (sl < 6 || seg[0] != 8 || (seg[5] != 1 && seg[5] != 3) || sl < 6 + 3 * static_cast<size_t>(seg[5]))
                 return jpeg_corrupt("bad SOF segment");                    // (jpeg_parse has let this frame through already)
             fr.ncomp = seg[5];
@@ -207,7 +215,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
             fr.per = fr.hy * fr.vy + fr.ncomp - 1;
             if (fr.w != f->w || fr.h != f->h || fr.hy != f->hy || fr.vy != f->vy || fr.ncomp != f->ncomp || fr.per != f->nslots)
                 return jpeg_corrupt("the frame header changed between two readings");
-        } else if (m == 0xc0 || m == 0xc1 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8)) {
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8) {
             return jpeg_corrupt("a second frame header of another kind");
         } else if (m == 0xc4) {
             size_t o = 0;
@@ -255,13 +263,19 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                 sc[i] = c; td[i] = seg[2 + 2 * i] >> 4; ta[i] = seg[2 + 2 * i] & 15;
                 if (td[i] > 3 || ta[i] > 3) return jpeg_corrupt("bad Huffman table selector");
             }
-            const int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
-            if ((zs == 0 && ze != 0) || zs > ze || ze > 63) return jpeg_corrupt("bad spectral selection bounds");
+            int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if (sequential) { zs = 0; ze = 63; ah = 0; al = 0; }
+            if ((zs == 0 && ze != 0 && !sequential) || zs > ze || ze > 63) return jpeg_corrupt("bad spectral selection bounds");
             if (zs != 0 && ns != 1) return jpeg_corrupt("progressive AC coefficients for more than one component");
             if ((ah != 0 && ah != al + 1) || al > 13) return jpeg_corrupt("bad successive approximation values");
             for (int i = 0; i < ns; i++) {
                 if (zs == 0 && ah == 0 && !tabs[td[i]].have) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
-                if (zs != 0 && !tabs[4 + ta[i]].have) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                if ((zs != 0 || sequential) && !tabs[4 + ta[i]].have) return jpeg_corrupt("the scan uses a Huffman table the file does not define");
+                if (sequential) {
+                    if (seen[sc[i]]) return jpeg_corrupt("a sequential file codes a component twice");
+                    if (!have_q[fr.cq[sc[i]]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
+                    std::memcpy(qsnap[sc[i]], q[fr.cq[sc[i]]], 64);
+                }
                 seen[sc[i]] = true;
             }
             if (ri > 0 && ns == 1 && fr.ch[sc[0]] * fr.cv[sc[0]] > 1)
@@ -376,10 +390,10 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
     if (!range_ok) return jpeg_unsupported("coefficients beyond 16 bits");
     for (int c = 0; c < fr.ncomp; c++) {
         if (!seen[c]) return jpeg_unsupported("a component no scan mentions");
-        if (!have_q[fr.cq[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
+        if (!sequential && !have_q[fr.cq[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
     }
     for (int c = 0; c < 3; c++)
-        for (int k = 0; k < 64; k++) f->q[c][k] = c < fr.ncomp ? q[fr.cq[c]][k] : 1;
+        for (int k = 0; k < 64; k++) f->q[c][k] = c < fr.ncomp ? (sequential ? qsnap[c][k] : q[fr.cq[c]][k]) : 1;
     return FNX_OK;
 }
 

@@ -2045,6 +2045,12 @@ static int jprog_refine(jpeg_bitr *r, int32_t *b, const jpeg_dtab *h, int zs, in
 static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
                                        int16_t *coef)
 {
+    /* Also the SEQUENTIAL files the one-scan decoder below does not read (r5): SOF0 / SOF1 frames whose components come in
+     * scans of their own, and SOF1 (extended sequential, 8 bit) altogether.  processSOS is the same function for them with
+     * Ss, Se, Ah, Al fixed at 0, 63, 0, 0 whatever the scan header says (Table B.3), and a block is dequantised when its scan
+     * decodes it -- with the table in force THEN (qsnap), not at EOI. */
+    int sequential = 0;
+    uint8_t qsnap[3][64];
     uint8_t q[4][64];
     jpeg_dtab dt[2][4];
     int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -2074,8 +2080,9 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                 have_q[tq] = 1;
                 o += 65;
             }
-        } else if (m == 0xc2) {
+        } else if (m == 0xc2 || m == 0xc0 || m == 0xc1) {
             if (ncomp != 0) { rc = -4; goto out; }
+            sequential = m != 0xc2;
             if (sl < 6 + 3 || seg[0] != 8 || (seg[5] != 3 && seg[5] != 1) || sl < 6 + 3 * seg[5]) { rc = -4; goto out; }
             ncomp = seg[5];
             H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4];
@@ -2098,7 +2105,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                 cf[c] = (int32_t *)calloc((size_t)mx * comp_h[c] * my * comp_v[c] * 64, sizeof(int32_t));
                 if (!cf[c]) { rc = -20; goto out; }
             }
-        } else if (m == 0xc0 || m == 0xc1 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8)) {
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8) {
             rc = -5; goto out;
         } else if (m == 0xc4) {
             int o = 0;
@@ -2139,14 +2146,20 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                 sc[i] = c; td[i] = seg[2 + 2 * i] >> 4; ta[i] = seg[2 + 2 * i] & 15;
                 if (td[i] > 3 || ta[i] > 3) { rc = -8; goto out; }
             }
-            const int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
-            if ((zs == 0 && ze != 0) || zs > ze || ze > 63) { rc = -8; goto out; }   /* "bad spectral selection bounds" */
+            int zs = seg[1 + 2 * ns], ze = seg[2 + 2 * ns], ah = seg[3 + 2 * ns] >> 4, al = seg[3 + 2 * ns] & 15;
+            if (sequential) { zs = 0; ze = 63; ah = 0; al = 0; }
+            if ((zs == 0 && ze != 0 && !sequential) || zs > ze || ze > 63) { rc = -8; goto out; }   /* "bad spectral selection bounds" */
             if (zs != 0 && ns != 1) { rc = -8; goto out; }                           /* AC scans hold one component */
             if (ah != 0 && ah != al + 1) { rc = -8; goto out; }                      /* "bad successive approximation values" */
             if (al > 13) { rc = -8; goto out; }
             for (int i = 0; i < ns; i++) {
                 if (zs == 0 && ah == 0 && !have_t[0][td[i]]) { rc = -8; goto out; }
-                if (zs != 0 && !have_t[1][ta[i]]) { rc = -8; goto out; }
+                if ((zs != 0 || sequential) && !have_t[1][ta[i]]) { rc = -8; goto out; }
+                if (sequential) {
+                    if (seen[sc[i]]) { rc = -8; goto out; }                          /* a sequential component has ONE scan */
+                    if (!have_q[comp_q[sc[i]]]) { rc = -8; goto out; }
+                    memcpy(qsnap[sc[i]], q[comp_q[sc[i]]], 64);
+                }
                 seen[sc[i]] = 1;
             }
             if (ri > 0 && ns == 1 && comp_h[sc[0]] * comp_v[sc[0]] > 1) { rc = -12; goto out; }
@@ -2230,7 +2243,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
         if (ncomp == 3) { memset(cbp, 0, (size_t)cs * 8 * my); memset(crp, 0, (size_t)cs * 8 * my); }
         for (int c = 0; c < ncomp; c++) {
             if (!seen[c]) continue;                                               /* progCoeffs[i] == nil: the plane stays zero */
-            if (!have_q[comp_q[c]]) { rc = -8; goto out; }
+            if (!sequential && !have_q[comp_q[c]]) { rc = -8; goto out; }
             const int hi = comp_h[c], vi = comp_v[c], stride = mx * hi;
             uint8_t *plane = c == 0 ? yp : (c == 1 ? cbp : crp);
             const int ps = c == 0 ? ys : cs;
@@ -2240,7 +2253,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                     int32_t b[64];
                     for (int zig = 0; zig < 64; zig++) {
                         if (z[zig] > 32767 || z[zig] < -32768) { rc = -13; goto out; }   /* beyond what any 8-bit image's file holds */
-                        b[jpeg_unzig[zig]] = z[zig] * (int32_t)q[comp_q[c]][zig];
+                        b[jpeg_unzig[zig]] = z[zig] * (int32_t)(sequential ? qsnap[c][zig] : q[comp_q[c]][zig]);
                     }
                     orc_jpeg_idct(b);
                     for (int j = 0; j < 8; j++)
@@ -2305,9 +2318,9 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
             for (int c = 0; c < ncomp; c++) {
                 comp_id[c] = seg[6 + 3 * c]; comp_h[c] = seg[7 + 3 * c] >> 4; comp_v[c] = seg[7 + 3 * c] & 15; comp_q[c] = seg[8 + 3 * c];
             }
-        } else if (m == 0xc2) {
+        } else if (m == 0xc2 || m == 0xc1) {
             return orc_jpeg_decode_progressive(data, n, wd, ht, ratio, yp, cbp, crp, coef);
-        } else if (m == 0xc1 || (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+        } else if (m >= 0xc5 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
             return -5;                                                            /* not baseline */
         } else if (m == 0xc4) {                                                   /* DHT */
             int o = 0;
@@ -2333,6 +2346,8 @@ ORC_API int orc_jpeg_decode_planes(const uint8_t *data, long n, int *wd, int *ht
         } else if (m == 0xdd) {
             if (sl >= 2) ri = (seg[0] << 8) | seg[1];                             /* MCUs per restart interval; 0: none */
         } else if (m == 0xda) {                                                   /* SOS */
+            if (ncomp != 0 && sl >= 1 && seg[0] >= 1 && seg[0] < ncomp)               /* the components in scans of their own */
+                return orc_jpeg_decode_progressive(data, n, wd, ht, ratio, yp, cbp, crp, coef);
             if (ncomp == 0 || sl < 1 + 2 * ncomp + 3 || seg[0] != ncomp) return -8;
             int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
             for (int c = 0; c < ncomp; c++) {

@@ -165,6 +165,86 @@ def test_host_decoder_on_damaged_files_agrees_with_the_checker_or_refuses():
     assert both > 200 and neither > 100
 
 
+# ------------------------------------------------------------------------------------------------ sequential files the device's scan decoder has no form for
+def _with_all_ones_code(data):
+    """the file's first AC table with one more (unused) symbol on the all-ones 16-bit code, which T.81's tables leave free: the
+    scan does not change, the device's parallel decoder (which leans on that code being free) must hand the file to the host"""
+    pos = 2
+    while True:
+        assert data[pos] == 0xFF
+        m, n = data[pos + 1], (data[pos + 2] << 8) | data[pos + 3]
+        if m == 0xC4:
+            seg, o = data[pos + 4:pos + 2 + n], 0
+            while o < len(seg):
+                total = sum(seg[o + 1:o + 17])
+                if seg[o] >> 4 == 1:
+                    kraft = sum(c << (16 - L) for L, c in enumerate(seg[o + 1:o + 17], 1))
+                    assert kraft == 65535 and 0xFB not in seg[o + 17:o + 17 + total]
+                    new = seg[:o + 16] + bytes([seg[o + 16] + 1]) + seg[o + 17:o + 17 + total] + b"\xfb" + seg[o + 17 + total:]
+                    return data[:pos + 2] + bytes([(n + 1) >> 8, (n + 1) & 255]) + new + data[pos + 2 + n:]
+                o += 17 + total
+        pos += 2 + n
+
+
+def _sequential_cases():
+    import jpeg_mini
+    src = _photo(203, 117, 3)
+    out = []
+    for (hy, vy) in ((1, 1), (2, 1), (2, 2), (4, 1), (1, 2), (4, 2)):
+        base = jpeg_mini.encode(src, hy, vy, 85)
+        for sof in (0xC0, 0xC1):
+            for order in ((0, 1, 2), (2, 0, 1)):
+                out.append((f"{hy}x{vy} sof={sof:#x} scans {order}", jpeg_mini.encode_scans(src, hy, vy, 85, sof=sof, order=order), base))
+        i = base.index(b"\xff\xc0")
+        out.append((f"{hy}x{vy} one scan, relabelled SOF1", base[:i] + b"\xff\xc1" + base[i + 2:], base))
+    out.append(("4:4:4 scans with restart intervals", jpeg_mini.encode_scans(src, 1, 1, 85, restart=5), jpeg_mini.encode(src, 1, 1, 85)))
+    libjpeg = _pil(src, quality=85, subsampling=2)
+    out.append(("libjpeg's file with the all-ones code assigned", _with_all_ones_code(libjpeg), libjpeg))
+    return out
+
+
+def test_oracle_reads_sequential_files_scan_by_scan():
+    """every component in a scan of its own (any order), SOF1, tables redefined between scans: the image of the one-scan file, and
+    libjpeg's reading of the same bytes within the IDCTs' tolerance"""
+    import jpeg_mini
+    for name, data, base in _sequential_cases():
+        got = orc.jpeg_decode(data)
+        assert np.array_equal(got, orc.jpeg_decode(base)), name
+        if "all-ones" in name:
+            continue                                          # (libjpeg refuses such a table outright; image/jpeg builds it)
+        d = np.abs(got[..., :3].astype(int) - _pil_decode(data).astype(int))
+        assert d.mean() < 1.3 and np.percentile(d, 99) <= 10, (name, d.mean())
+    # a DQT between the Cb and the Cr scan: a sequential block is dequantised when its scan decodes it (libjpeg agrees)
+    src = _photo(203, 117, 3)
+    data = jpeg_mini.encode_scans(src, 2, 2, 85, requant_between=True)
+    d = np.abs(orc.jpeg_decode(data)[..., :3].astype(int) - _pil_decode(data).astype(int))
+    assert d.mean() < 1.3 and np.percentile(d, 99) <= 10
+    with pytest.raises(RuntimeError, match="-12"):
+        orc.jpeg_decode(jpeg_mini.encode_scans(src, 2, 2, 85, restart=5))
+
+
+def test_host_decoder_reads_sequential_files():
+    import fennec_amd
+    import jpeg_mini
+    for name, data, base in _sequential_cases():
+        want = orc.jpeg_decode_planes(data, with_coefficients=True)
+        got, dims, ratio = _product_coefficients(data)
+        assert dims == (203, 117) and ratio == want[2] and np.array_equal(got, want[-1]), name
+        assert fennec_amd.Context.jpeg_parse(data) == (203, 117)
+    src = _photo(203, 117, 3)
+    with pytest.raises(fennec_amd.FennecUnsupported, match="restart"):
+        _product_coefficients(jpeg_mini.encode_scans(src, 2, 2, 85, restart=5))
+    # a component coded twice, a component never coded
+    data = jpeg_mini.encode_scans(src, 1, 1, 85)
+    scans = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    twice = bytearray(data)
+    twice[scans[1] + 5] = 1
+    with pytest.raises(fennec_amd.FennecError):
+        _product_coefficients(bytes(twice))
+    with pytest.raises(fennec_amd.FennecError):
+        _product_coefficients(data[:scans[2]] + b"\xff\xd9")
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -250,3 +330,18 @@ def test_gpu_decode_of_damaged_progressive_files(ctx):
             both += 1
     assert both > 20
     assert np.array_equal(ctx.jpeg_decode(g), orc.jpeg_decode(g))
+
+
+@pytest.mark.gpu
+def test_gpu_decode_of_sequential_files_read_scan_by_scan(ctx):
+    import jpeg_mini
+    for name, data, base in _sequential_cases():
+        got = ctx.jpeg_decode(data)
+        assert np.array_equal(got, orc.jpeg_decode(data)) and np.array_equal(got, ctx.jpeg_decode(base)), name
+    src = _photo(203, 117, 3)
+    for (hy, vy) in ((1, 1), (2, 2)):
+        data = jpeg_mini.encode_scans(src, hy, vy, 85, requant_between=True)
+        assert np.array_equal(ctx.jpeg_decode(data), orc.jpeg_decode(data))
+    big = jpeg_mini.encode_scans(_photo(1283, 719, 4), 2, 2, 90, sof=0xC1)
+    assert np.array_equal(ctx.jpeg_decode(big), orc.jpeg_decode(big))
+    assert ctx.jpeg_recompress(big, 0.94)[:4] == ctx.jpeg_compress(orc.jpeg_decode(big), 0.94)
