@@ -270,13 +270,14 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
  * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
  * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all (host work: ctx may be
  * NULL and no device is touched).  Handled: 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one
- * (image.Gray), with or without restart intervals, as baseline (SOF0) in one scan or progressive (SOF2) in any number of
- * scans; anything else returns
+ * (image.Gray), with or without restart intervals: baseline (SOF0), extended sequential (SOF1) and progressive (SOF2) frames in
+ * any number of scans; anything else (four components, 12 bit, arithmetic coding, lossless) returns
  * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
  * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Baseline: Huffman decoding is parallel
  * over 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how
  * many rounds that takes.  Progressive (r5): a refinement scan's bits depend on the coefficients of the scans before it, so
- * the scans are entropy-decoded on the host (jpeg_prog.cpp) and the coefficients go up at 2 bytes each; dequantisation, IDCT
+ * the scans are entropy-decoded on the host (jpeg_prog.cpp) and the coefficients go up at 2 bytes each -- as are the sequential
+ * files that decoder has no form for (SOF1, components in scans of their own, a table that assigns the all-ones code); dequantisation, IDCT
  * and colour conversion are the device's as for baseline.  Restated from ITU T.81 and Go's documented behaviour (scan.go's
  * refine / reconstructProgressiveImage): bit-exact against the tests' CPU restatement, parity with Go unpinned. */
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h);
