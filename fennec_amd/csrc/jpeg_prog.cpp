@@ -42,6 +42,18 @@ struct BitReader {
     BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
     inline void fill()
     {
+        if (cnt > 32) return;                    // a 16-bit code and a 16-bit value, or 32 correction bits, are there
+        if (p + 4 <= end) {                      // four bytes at once when none of them is 0xff
+            uint32_t w;
+            std::memcpy(&w, p, 4);
+            const uint32_t v = ~w;
+            if (!((v - 0x01010101u) & ~v & 0x80808080u)) {
+                acc = (acc << 32) | __builtin_bswap32(w);
+                cnt += 32;
+                p += 4;
+                return;
+            }
+        }
         while (cnt <= 56) {
             uint32_t b = 0;
             if (p < end && *p != 0xff) b = *p++;
