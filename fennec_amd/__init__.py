@@ -721,10 +721,12 @@ class Context:
         return q.value, v.value, st.value, rc == FNX_OK
 
     # -- effects.go ---------------------------------------------------------------------
-    def GaussianBlur(self, img, sigma: float, exact: bool | None = False, kernel=None):
+    def GaussianBlur(self, img, sigma: float, exact: bool | None = False, kernel=None, keep_box_sums: bool = False):
         """effects.go:146.  sigma <= 0 returns `img` itself (same pointer).  exact=False: fast fp32 kernel
         (<= 1 LSB on <= 0.1 % of samples); exact=True: bit-exact fp64 kernels; exact=None: what the
-        reference-named mirror fennec_GaussianBlur picks (exact for host images, fast for device tensors)."""
+        reference-named mirror fennec_GaussianBlur picks (exact for host images, fast for device tensors).
+        keep_box_sums (device tensors, FNX_BLUR_KEEP_BOX_SUMS): the next call on this ctx is SSIMFast(img, result) and nothing
+        writes either image in between -- that call then reads neither of them again."""
         if sigma <= 0:
             return img
         s = _Img(img)
@@ -741,7 +743,8 @@ class Context:
                     radius = (len(kernel) - 1) // 2
                 k, pk = _f64(kernel)
                 rc = self._lib.fnx_gaussian_blur(self._h, s.space, s.ptr, s.stride, s.w, s.h, pk, radius,
-                                                 FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, d.ptr, d.stride)
+                                                 (FNX_BLUR_EXACT if exact else FNX_BLUR_FAST) | (FNX_BLUR_KEEP_BOX_SUMS if keep_box_sums else 0),
+                                                 d.ptr, d.stride)
             self._chk(rc, "GaussianBlur")
         return dst
 

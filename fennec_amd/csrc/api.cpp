@@ -253,6 +253,9 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
 
 extern "C" {
 
+static int blur_batch_body(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel, int radius,
+                           int flags, uint8_t *const *dsts, int dstride);
+
 int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                       const double *kernel, int radius, int flags, uint8_t *dst, int dstride)
 {
@@ -263,6 +266,10 @@ int fnx_gaussian_blur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, 
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     if (w <= 0 || h <= 0) return FNX_OK;
     FNX_REQUIRE(space != FNX_DEVICE || src != dst, "dst aliases src (the blur is not in-place)");
+    ctx->kept.valid = false;
+    if ((flags & FNX_BLUR_KEEP_BOX_SUMS) && space == FNX_DEVICE && !(sstride & 3) && !(dstride & 3))   // a batch of one (fnx_ssim_fast consumes it)
+        return blur_batch_body(ctx, 1, &src, sstride, w, h, kernel, radius, flags, &dst, dstride);
+    flags &= ~FNX_BLUR_KEEP_BOX_SUMS;
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
@@ -276,6 +283,12 @@ int fnx_gaussian_blur_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int
                             uint8_t *const *dsts, int dstride)
 {
     FNX_ENTER(ctx);
+    return blur_batch_body(ctx, n, srcs, sstride, w, h, kernel, radius, flags, dsts, dstride);
+}
+
+static int blur_batch_body(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, const double *kernel, int radius,
+                           int flags, uint8_t *const *dsts, int dstride)
+{
     FNX_REQUIRE(n >= 0 && srcs && dsts && kernel && radius >= 0, "batch arguments");
     if (n == 0 || w <= 0 || h <= 0) return FNX_OK;
     FNX_REQUIRE(sstride >= 4 * w && dstride >= 4 * w && !(sstride & 3) && !(dstride & 3), "stride");
@@ -434,6 +447,33 @@ int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     return finish(ctx, space, &d);
 }
 
+// the box planes a blur with FNX_BLUR_KEEP_BOX_SUMS left for exactly this scoring call?  (Either way they are gone afterwards.)
+static bool kept_matches(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride, int w, int h)
+{
+    fnx_ctx::KeptBoxes &k = ctx->kept;
+    bool use = k.valid && k.seq + 1 == ctx->op_seq && k.n == n && k.sstride == astride && k.dstride == bstride && k.w == w && k.h == h;
+    for (int i = 0; use && i < n; i++) use = as[i] == k.srcs[i] && bs[i] == k.dsts[i];
+    k.valid = false;
+    return use;
+}
+
+// fnx_gaussian_blur_ssim_fast_batch's second half on the main stream, behind the planes (box_from_slabs_kernel ran on the second
+// one): neither full-size image is read again
+static int kept_score(fnx_ctx *ctx, int n, const double *window, const double *dwin, double *dres, bool batch_form)
+{
+    fnx_ctx::KeptBoxes &k = ctx->kept;
+    const int p = k.parity;
+    FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
+    if (batch_form) ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;    // (the one-pass entry's arithmetic; a single call keeps its own)
+    const int rc = launch_windowed_ssim(ctx, n, k.planes, k.nw * 4, k.plane, k.planes + k.plane * n, k.nw * 4, k.plane, k.nw, k.nh, window, dwin, dres);
+    ctx->partial_slot = -1;
+    if (rc < 0) return rc;
+    note_route(ctx, FNX_PROF_SSIM, "kept box planes + windowed SSIM");
+    ctx->tail_pending[p] = false;        // everything that read set p is now in front of whatever `stream` runs next
+    ctx->parity ^= 1;
+    return FNX_OK;
+}
+
 int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const uint8_t *b,
                   int bstride, int w, int h, const double *window, double *out)
 {
@@ -448,6 +488,12 @@ int fnx_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *a, int astride, const 
     }
     void *dwin = nullptr;
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    if (kept_matches(ctx, 1, &a, astride, &b, bstride, w, h) && space == FNX_DEVICE) {
+        double *dres;
+        FNX_TRY(result_slot(ctx, 1, &dres));
+        FNX_TRY(kept_score(ctx, 1, window, static_cast<const double *>(dwin), dres, false));
+        return result_wait(ctx, dres, out, 1);
+    }
     DevImg da, db;
     int nw, nh;
     if (!ssim_fast_dims(w, h, &nw, &nh) && (w < 8 || h < 8)) {   // pixelSSIM on the inputs themselves
@@ -512,26 +558,9 @@ int fnx_ssim_fast_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, i
     FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     double *dres;
     FNX_TRY(result_slot_queued(ctx, n, &dres));
-    {   // the box planes a fnx_gaussian_blur_batch(FNX_BLUR_KEEP_BOX_SUMS) left for exactly this call?
-        fnx_ctx::KeptBoxes &k = ctx->kept;
-        bool use = k.valid && k.seq + 1 == ctx->op_seq && k.n == n && k.sstride == astride && k.dstride == bstride && k.w == w && k.h == h;
-        for (int i = 0; use && i < n; i++) use = as[i] == k.srcs[i] && bs[i] == k.dsts[i];
-        k.valid = false;
-        if (use) {
-            // fnx_gaussian_blur_ssim_fast_batch's second half, on the main stream behind the planes (box_from_slabs_kernel ran on
-            // the second one): neither full-size image is read again
-            const int p = k.parity;
-            FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
-            ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;
-            const int rc = launch_windowed_ssim(ctx, n, k.planes, k.nw * 4, k.plane, k.planes + k.plane * n, k.nw * 4, k.plane, k.nw, k.nh,
-                                                window, static_cast<const double *>(dwin), dres);
-            ctx->partial_slot = -1;
-            if (rc < 0) return rc;
-            note_route(ctx, FNX_PROF_SSIM, "kept box planes + windowed SSIM");
-            ctx->tail_pending[p] = false;        // everything that read set p is now in front of whatever `stream` runs next
-            ctx->parity ^= 1;
-            return publish_results(ctx, dres, n);
-        }
+    if (kept_matches(ctx, n, as, astride, bs, bstride, w, h)) {
+        FNX_TRY(kept_score(ctx, n, window, static_cast<const double *>(dwin), dres, true));
+        return publish_results(ctx, dres, n);
     }
     int nw, nh;
     bool al = !(astride & 15) && !(bstride & 15);

@@ -119,6 +119,15 @@ int bind(fnx_ctx *ctx)
     return FNX_OK;
 }
 
+// for the calls that only look at the ctx or move it to another stream: they do not come between a blur that kept its box sums
+// and the scoring call (api.cpp: KeptBoxes) -- the binding's stream lending sits exactly there
+static int bind_quiet(fnx_ctx *ctx)
+{
+    const int rc = bind(ctx);
+    if (rc == FNX_OK) ctx->op_seq--;
+    return rc;
+}
+
 int scratch(fnx_ctx *ctx, Slot slot, size_t bytes, void **out)
 {
     Scratch &s = ctx->slot[slot];
@@ -470,7 +479,7 @@ int fnx_ctx_device(const fnx_ctx *ctx) { return ctx ? ctx->logical_device : -1; 
 
 int fnx_ctx_profile(fnx_ctx *ctx, int enable)
 {
-    FNX_TRY(bind(ctx));
+    FNX_TRY(bind_quiet(ctx));
     if (enable)
         for (auto &pair : ctx->prof_ev)
             for (auto &e : pair)
@@ -491,7 +500,7 @@ const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class)
 
 int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms)
 {
-    FNX_TRY(bind(ctx));
+    FNX_TRY(bind_quiet(ctx));
     FNX_REQUIRE(ms != nullptr && ctx->prof_count > 0, "no unread profiled kernel launch on this ctx");
     hipEvent_t *pair = ctx->prof_ev[ctx->prof_head];
     FNX_HIP(hipEventSynchronize(pair[1]));
@@ -521,13 +530,13 @@ static int switch_stream(fnx_ctx *ctx, hipStream_t ns)
 
 int fnx_ctx_use_stream(fnx_ctx *ctx, void *stream)
 {
-    FNX_TRY(bind(ctx));
+    FNX_TRY(bind_quiet(ctx));
     return switch_stream(ctx, static_cast<hipStream_t>(stream));
 }
 
 int fnx_ctx_use_own_stream(fnx_ctx *ctx)
 {
-    FNX_TRY(bind(ctx));
+    FNX_TRY(bind_quiet(ctx));
     return switch_stream(ctx, ctx->own_stream);
 }
 

@@ -75,12 +75,14 @@ extern "C" {
 #define FNX_BLUR_EXACT 1 /* bit-exact: fp32 with a rounding guard, fp64 in the reference's tap order for every
                             sample the guard cannot decide (and for kernels with negative taps or gain > 1) */
 
-/* fnx_gaussian_blur_batch only, OR-ed to either mode: "the next call on this ctx is fnx_ssim_fast_batch(_enqueue) over exactly
+/* fnx_gaussian_blur_batch (and fnx_gaussian_blur with FNX_DEVICE: a batch of one, scored by fnx_ssim_fast), OR-ed to either
+ * mode: "the next call on this ctx is fnx_ssim_fast_batch(_enqueue) over exactly
  * these (srcs[i], dsts[i]) pairs, and nothing writes the images in between".  The blur then runs as the one-pass kernel of
  * fnx_gaussian_blur_ssim_fast_batch -- same blurred bytes -- which also takes SSIMFast's boxDownsample sums (ssim.go:244-309)
  * of both sides, and that scoring call reads neither full-size image again: the reference's two calls (effects.go:146, then
  * ssim.go:48) at the one-pass traffic of 2 S instead of 4 S.  Scores are those of fnx_gaussian_blur_ssim_fast_batch (integer
- * box sums, then the same code).  Any other call on the ctx, other pointers, strides or dims: the sums are dropped and
+ * box sums, then the same code).  Any other call on the ctx (fnx_ctx_use_stream / _use_own_stream / _profile / _kernel_ms do not
+ * count), other pointers, strides or dims: the sums are dropped and
  * SSIMFast reads the images as always; shapes the one-pass kernel does not take run the plain blur.  The promise about
  * writes is the caller's: the library cannot see a store to device memory it was only lent. */
 #define FNX_BLUR_KEEP_BOX_SUMS 2

@@ -193,6 +193,30 @@ def test_two_calls_with_kept_box_sums(ctx, orc, w, h):
     assert not ctx.last_kernel(2).startswith("kept box planes") and sub[1] == plain_ss[1]
 
 
+def test_single_calls_with_kept_box_sums(ctx, orc):
+    """the per-image entry points (what a cgo caller holding device-resident images calls): fnx_gaussian_blur with the flag, then
+    fnx_ssim_fast -- through the binding, whose stream lending between the two does not count as a call in between"""
+    import torch
+    img = synth.large_photo(3840, 2160, 6)
+    d = torch.from_numpy(img).cuda()
+    torch.cuda.synchronize()
+    for exact in (False, True):
+        ref = ctx.GaussianBlur(d, 2.0, exact=exact)
+        ref_s = ctx.SSIMFast(d, ref)
+        assert not ctx.last_kernel(2).startswith("kept box planes")
+        out = ctx.GaussianBlur(d, 2.0, exact=exact, keep_box_sums=True)
+        assert "SCORE" in ctx.last_kernel(1)
+        s = ctx.SSIMFast(d, out)
+        assert ctx.last_kernel(2).startswith("kept box planes")
+        assert torch.equal(out, ref) and abs(s - ref_s) <= 1e-12
+    assert abs(s - orc.ssim_fast(img, out.cpu().numpy(), procs=16)) <= 1e-9
+    # scored against something else: dropped; a host image: the flag means nothing
+    out = ctx.GaussianBlur(d, 2.0, keep_box_sums=True)
+    assert ctx.SSIMFast(out, d) == ctx.SSIMFast(out, d) and not ctx.last_kernel(2).startswith("kept box planes")
+    small = synth.large_photo(640, 480, 1)
+    assert np.array_equal(ctx.GaussianBlur(small, 2.0, exact=True, keep_box_sums=True), ctx.GaussianBlur(small, 2.0, exact=True))
+
+
 def test_kept_box_sums_on_shapes_without_a_one_pass_form(ctx):
     import torch
     for (w, h, sigma) in ((640, 480, 2.0), (3840, 2160, 9.0), (1700, 1000, 2.0)):   # no downsample; radius 27; a box ratio the one-pass form leaves
