@@ -59,13 +59,17 @@ int main(int argc, char **argv)
         {"lanczosResize -> 1/2", [&](int k) { FK(fennec_lanczosResize(ctx, FNX_DEVICE, img[k], W * 4, W, H, out[k], (W / 2) * 4, W / 2, H / 2)); }, 1.25 * S, true},
         {"boxDownsample -> 512x288", [&](int k) { FK(fnx_box_downsample(ctx, FNX_DEVICE, img[k], W * 4, W, H, out[k], 512 * 4, 512, 288)); }, 1.0 * S, true},
         {"SSIMFast", [&](int k) { FK(fnx_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, blur[k], W * 4, W, H, win, &r)); }, 2.0 * S, false},
+        {"GaussianBlur + SSIMFast (2 calls)", [&](int k) { FK(fnx_gaussian_blur(ctx, FNX_DEVICE, img[k], W * 4, W, H, kern.data(), radius, 0, out[k], W * 4));
+                                                          FK(fnx_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, out[k], W * 4, W, H, win, &r)); }, 4.0 * S, false},
+        {"... with FNX_BLUR_KEEP_BOX_SUMS", [&](int k) { FK(fnx_gaussian_blur(ctx, FNX_DEVICE, img[k], W * 4, W, H, kern.data(), radius, FNX_BLUR_KEEP_BOX_SUMS, out[k], W * 4));
+                                                        FK(fnx_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, out[k], W * 4, W, H, win, &r)); }, 4.0 * S, false},
         {"SSIM (full resolution)", [&](int k) { FK(fnx_ssim(ctx, FNX_DEVICE, img[k], W * 4, blur[k], W * 4, W, H, win, &r)); }, 2.0 * S, false},
         {"MSSSIM", [&](int k) { FK(fnx_msssim(ctx, FNX_DEVICE, img[k], W * 4, blur[k], W * 4, W, H, win, &r, nullptr)); }, 3.33 * S, false},
         {"Analyze", [&](int k) { FK(fnx_analyze(ctx, FNX_DEVICE, img[k], W * 4, W, H, &an)); }, 1.0 * S, false},
         {"isOpaque", [&](int k) { FK(fnx_scan_flags(ctx, FNX_DEVICE, img[k], S, &fo, &fg)); }, 1.0 * S, false},
     };
     printf("%dx%d, device-resident, one C-ABI call at a time from a C++ host (launch + result latency included)\n", W, H);
-    printf("%-32s %9s %9s %8s %9s\n", "op", "us/call", "min us", "GB/s", "of 8 TB/s");
+    printf("%-34s %9s %9s %8s %9s\n", "op", "us/call", "min us", "GB/s", "of 8 TB/s");
     for (auto &op : ops) {
         double t0 = now();
         while (now() - t0 < 0.25) { op.fn(0); if (op.sync) FK(fnx_ctx_sync(ctx)); }
@@ -81,7 +85,7 @@ int main(int argc, char **argv)
         for (double t : ts) mean += t;
         mean /= n;
         const double mn = *std::min_element(ts.begin(), ts.end());
-        printf("%-32s %9.1f %9.1f %8.0f %9.3f\n", op.name, mean * 1e6, mn * 1e6, op.bytes / mean / 1e9, op.bytes / mean / 8e12);
+        printf("%-34s %9.1f %9.1f %8.0f %9.3f\n", op.name, mean * 1e6, mn * 1e6, op.bytes / mean / 1e9, op.bytes / mean / 8e12);
     }
     (void)r; (void)fo; (void)fg;
     fnx_ctx_destroy(ctx);
