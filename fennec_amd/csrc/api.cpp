@@ -304,18 +304,19 @@ static int blur_batch_body(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int 
     if (keep && ssim_fast_dims(w, h, &nw, &nh) && nw >= 8 && nh >= 8) {
         // the one-pass kernel (fnx_gaussian_blur_ssim_fast_batch's first half): the same blurred bytes, and the box planes of both
         // sides into buffer set p.  The set stays this batch's until the scoring call -- or, if none comes, until the next
-        // one-pass launch on it, which waits for ev_tail[p] like any other.
+        // one-pass launch on it (ordered behind this one on `stream`).
         const int p = ctx->parity;
         const size_t plane = static_cast<size_t>(nw) * nh * 4;
         void *t = nullptr;
         FNX_TRY(scratch(ctx, p ? SLOT_PLANES1 : SLOT_PLANES0, plane * 2 * n + 16, &t));
         if (ctx->tail_pending[p]) FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
+        ctx->boxes_on_main = true;               // blur, box planes and (next call) the windowed SSIM back to back on `stream`
         const int st = launch_blur_scored(ctx, n, static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, kernel, radius, flags,
                                           static_cast<uint8_t *const *>(dp[1]), dstride, static_cast<uint8_t *>(t), plane, nw, nh);
+        ctx->boxes_on_main = false;
         if (st < 0) return st;
         if (st == FNX_OK) {
-            FNX_HIP(hipEventRecord(ctx->ev_tail[p], ctx->stream2));      // behind box_from_slabs_kernel
-            ctx->tail_pending[p] = true;
+            ctx->tail_pending[p] = false;        // whatever read set p before is in front of this blur on `stream`, and so is all that follows
             fnx_ctx::KeptBoxes &k = ctx->kept;
             k.srcs.assign(srcs, srcs + n);
             k.dsts.assign(dsts, dsts + n);
@@ -457,19 +458,17 @@ static bool kept_matches(fnx_ctx *ctx, int n, const uint8_t *const *as, int astr
     return use;
 }
 
-// fnx_gaussian_blur_ssim_fast_batch's second half on the main stream, behind the planes (box_from_slabs_kernel ran on the second
-// one): neither full-size image is read again
+// fnx_gaussian_blur_ssim_fast_batch's second half, on the main stream right behind the planes (the kept form's box_from_slabs_kernel
+// ran there too): neither full-size image is read again
 static int kept_score(fnx_ctx *ctx, int n, const double *window, const double *dwin, double *dres, bool batch_form)
 {
     fnx_ctx::KeptBoxes &k = ctx->kept;
     const int p = k.parity;
-    FNX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[p], 0));
     if (batch_form) ctx->partial_slot = p ? SLOT_PART1 : SLOT_PART0;    // (the one-pass entry's arithmetic; a single call keeps its own)
     const int rc = launch_windowed_ssim(ctx, n, k.planes, k.nw * 4, k.plane, k.planes + k.plane * n, k.nw * 4, k.plane, k.nw, k.nh, window, dwin, dres);
     ctx->partial_slot = -1;
     if (rc < 0) return rc;
     note_route(ctx, FNX_PROF_SSIM, "kept box planes + windowed SSIM");
-    ctx->tail_pending[p] = false;        // everything that read set p is now in front of whatever `stream` runs next
     ctx->parity ^= 1;
     return FNX_OK;
 }

@@ -1016,9 +1016,15 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
                    : launch_direct_radius<true, false>(ctx, radius, n, fa, tall);
     }
     if (st < 0) return st;
-    // the rest of the step runs on the ctx's second stream, behind this blur (api.cpp: one-pass enqueue)
-    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->blur_done, 0));   // bound to the blur dispatch: no packet on `stream`
-    ctx->stream2_used = true;
+    // the rest of the step runs on the ctx's second stream, behind this blur (api.cpp: one-pass enqueue) -- or, for a blur that
+    // only KEEPS the box planes for the scoring call that follows (FNX_BLUR_KEEP_BOX_SUMS), right behind it on the same stream:
+    // there is no next blur to hide a tail under, and the two cross-stream hand-overs cost a per-image pair 25 us
+    hipStream_t box_stream = ctx->stream2;
+    if (ctx->boxes_on_main) box_stream = ctx->stream;
+    else {
+        FNX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->blur_done, 0));   // bound to the blur dispatch: no packet on `stream`
+        ctx->stream2_used = true;
+    }
 
     SlabArgs sa{};
     sa.slabs = fa.slabs; sa.dst = planes; sa.plane = plane;
@@ -1029,7 +1035,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     sa.image_slabs = static_cast<size_t>(tiles) * 2 * slabn;
     sa.n = n; sa.dstW = dstW; sa.dstH = dstH; sa.slabn = slabn;
     hipLaunchKernelGGL(box_from_slabs_kernel, dim3((dstW + 64 * BFS_BOXES - 1) / (64 * BFS_BOXES), (dstH + 3) / 4, n), dim3(256), 0,
-                       ctx->stream2, sa);
+                       box_stream, sa);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
 }

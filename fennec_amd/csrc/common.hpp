@@ -140,6 +140,7 @@ struct fnx_ctx {
         size_t plane = 0;
     } kept;
     unsigned long long op_seq = 0;     // exported calls bound to this ctx so far (bind)
+    bool boxes_on_main = false;        // launch_blur_scored: box_from_slabs_kernel on `stream` instead of `stream2` (the kept form)
     fnx::Scratch slot[fnx::SLOT_COUNT];
     fnx::TableCache tcache[fnx::SLOT_COUNT];
     // pinned host ring: tables going up, scalars coming down
