@@ -18,6 +18,8 @@ Two ways through the C ABI, bit-identical results (tests/test_gpu_parity.py::tes
 --pipeline one-pass (default) calls fnx_gaussian_blur_ssim_fast_batch, whose blur kernel also
 accumulates SSIMFast's boxDownsample sums, so neither full-size image is read a second time;
 --pipeline two-call calls fnx_gaussian_blur_batch then fnx_ssim_fast_batch, as the reference does.
+The default line carries both beside `value`: `two_call`, and `two_call_keep` -- the same two calls with
+FNX_BLUR_KEEP_BOX_SUMS on the blur, whose kernel then leaves the box sums of both sides for the scoring call.
 
 --depth 1 (default): one step at a time -- the blur kernel has the GPU to itself, which is what `roofline`
 describes.  --depth 2: two steps in flight; step s+1 is enqueued -- on a second context (= HIP stream), into a
