@@ -109,23 +109,11 @@ __device__ __forceinline__ uint32_t mf_exact_u(const double *wd, const uint8_t *
     return clampF_dev(acc);
 }
 
-// SCORE: a lane's four rows (4 g .. 4 g + 3) of one box column and channel go into at most two box rows wherever boxes are three
-// or more rows tall.  FNX_SCORE_PRESUM (experiment, CHANGELOG r5): add them up in the lane first -- one or two LDS atomics instead of
-// four, at the price of ~10 vector instructions.
+// SCORE: a lane's four rows (4 g .. 4 g + 3) of one box column and channel into the box table.  (Measured and dropped, r5: adding
+// the rows of one box row up in the lane first -- one or two atomics instead of four for ~10 more vector instructions: the fast form
+// unchanged at 21.5 us per image, the exact form 2 % slower; CHANGELOG r5.)
 __device__ __forceinline__ void mf_box_add4(uint32_t *tbl, const u32x4 ro, uint32_t coln, const v4i cb)
 {
-#ifdef FNX_SCORE_PRESUM
-    const bool two = (ro[1] == ro[0] || ro[1] == ro[3]) && (ro[2] == ro[0] || ro[2] == ro[3]);
-    if (__builtin_amdgcn_ballot_w64(!two) == 0) {
-        const uint32_t c0 = static_cast<uint32_t>(cb[0]), c1 = static_cast<uint32_t>(cb[1]), c2 = static_cast<uint32_t>(cb[2]), c3 = static_cast<uint32_t>(cb[3]);
-        const uint32_t a0 = c0 + (ro[1] == ro[0] ? c1 : 0u) + (ro[2] == ro[0] ? c2 : 0u) + (ro[3] == ro[0] ? c3 : 0u);
-        const uint32_t a1 = (c0 + c1 + c2 + c3) - a0;
-        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl) + ro[0] + coln), a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (ro[3] != ro[0])
-            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl) + ro[3] + coln), a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-    }
-#endif
 #pragma unroll
     for (int k = 0; k < 4; k++)
         __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(tbl) + ro[k] + coln), static_cast<uint32_t>(cb[k]),
