@@ -714,7 +714,7 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     # one GPU (the GPU runs 2-4 files' kernels side by side; past that the threads only contend for the interpreter lock); with
     # round 3's shorter GPU side of an item (no decoded / candidate images, the packed sync passes) 12 -> 16 -> 20 threads measure
     # 1 990-2 100 -> 2 410-2 440 -> 2 340 on one box
-    workers = args.workers or max(1, min(16, (os.cpu_count() or 8) // max(world, 1)))
+    workers = args.workers or max(1, min(16, host_cpus()[0] // max(world, 1)))
     target = fbatch.TARGET_SSIM["Balanced"]
     # the same file list on every rank (any rank may take any item)
     files = []
@@ -1137,7 +1137,7 @@ def other_workload_line(args, embedded: bool = False):
         srcs = synth.large_photo_batch(W, H, ks)
         jpegs = [fbatch.pillow_encode(s, 92) for s in srcs]          # "4096 synthetic 4K JPEGs", q=92 up front
         NI = len(jpegs)
-        workers = args.workers or max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))
+        workers = args.workers or max(1, min(8, host_cpus()[0] // max(world, 1)))
         alg = 2 * 4 * W * H * 6.0                                     # ~6 search steps x (H2D + read)
         gpu_stage = []          # seconds inside the C ABI per item (prepare + every against), all workers
         if args.device_decode:
@@ -1468,7 +1468,7 @@ def cpu_baseline_other(wl: str, W: int, H: int) -> dict:
     per-pixel work with fixed-size neighbourhoods, so MP/s carries over; the full 8K SSIM alone is ~10 s a pass)."""
     from oracle import oracle
     from fennec_amd import synth
-    cores = os.cpu_count() or 1
+    cores = host_cpus()[0]
     if wl == "config3":
         img = synth.large_photo(W, H, 0)
         n, t0 = 0, time.perf_counter()
@@ -1479,7 +1479,7 @@ def cpu_baseline_other(wl: str, W: int, H: int) -> dict:
             dt = time.perf_counter() - t0
             if dt > 12.0 or n >= 16:
                 break
-        return {"value": round(n * W * H / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+        return {"value": round(n * W * H / 1e6 / dt, 2), "unit": "MP/s", **_cores_fields(), "kind": "port",
                 "sample": f"{n} x (lanczosResize 4K -> 1080p + MSSSIM(4K, 1080p)) in {dt:.1f} s, oracle/fennec_oracle.c with procs={cores}"}
     cw, ch = 1920, 1080
     img = np.ascontiguousarray(synth.large_photo(W, H, 0)[:ch, :cw])
@@ -1491,7 +1491,7 @@ def cpu_baseline_other(wl: str, W: int, H: int) -> dict:
         dt = time.perf_counter() - t0
         if dt > 12.0 or n >= 64:
             break
-    return {"value": round(n * cw * ch / 1e6 / dt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+    return {"value": round(n * cw * ch / 1e6 / dt, 2), "unit": "MP/s", **_cores_fields(), "kind": "port",
             "sample": f"{n} x (AdaptiveSharpen(0.5) + full-resolution SSIM) of a {cw}x{ch} crop of the 8K image in {dt:.1f} s, "
                       f"oracle/fennec_oracle.c with procs={cores}"}
 
@@ -1503,7 +1503,7 @@ def cpu_baseline_config5(files, target: float) -> dict:
     interpreter lock), each item single-threaded.  A bounded sample: one item per worker, at most 32 workers."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
-    workers = max(1, min(32, os.cpu_count() or 1))
+    workers = max(1, min(32, host_cpus()[0]))
 
     def item(data):
         src = oracle.jpeg_decode(data)
@@ -1559,12 +1559,39 @@ def committed_traffic(kernel_substr: str, batch: int, scored: bool = False, exac
     return None
 
 
+def host_cpus():
+    """CPUs this process can really use: its affinity mask capped by the cgroup's CPU quota (cpu.max / cfs_quota_us).  The boxes of
+    this pool show 256 logical CPUs and a quota of 16: threads beyond the quota only add throttling stalls, and a baseline that
+    says "256 cores" there would describe a machine the job never had.  -> (usable, quota or None, visible)"""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except Exception:
+            pass
+    usable = visible if not quota else max(1, min(visible, int(quota + 0.999)))
+    return usable, quota, visible
+
+
+def _cores_fields():
+    usable, quota, visible = host_cpus()
+    return {"cores": usable, "cpus_visible": visible, "cpu_quota": None if quota is None else round(quota, 2)}
+
+
 def cpu_baseline(img: np.ndarray) -> dict:
     """The oracle (C restatement of the Go reference, same threading model: static row/column
     split over T threads, boxDownsample/toLuminance serial) timed on this box's host cores on a
     bounded sample of the same workload.  A reported baseline, not the optimisation target."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
+    cores = host_cpus()[0]
     n = 0
     t0 = time.perf_counter()
     while True:
@@ -1582,7 +1609,7 @@ def cpu_baseline(img: np.ndarray) -> dict:
     return {
         "value": round(n * W4K * H4K / 1e6 / dt, 2),
         "unit": "MP/s",
-        "cores": cores,
+        **_cores_fields(),
         "kind": "port",
         "sample": f"{n} x (4K GaussianBlur sigma=2 + SSIMFast) in {dt:.1f} s, oracle/fennec_oracle.c with procs={cores}",
         "value_1_thread": round(W4K * H4K / 1e6 / dt1, 2),
