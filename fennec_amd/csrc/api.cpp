@@ -1354,11 +1354,12 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
     FNX_TRY(check_img(dst, dstride, f.w, f.h, "dst"));
     DevOut d;
     FNX_TRY(stage_out(ctx, space, dst, dstride, f.w, f.h, SLOT_OUT, &d));
-    uint8_t *pl[3];
+    uint8_t *pl[4] = {nullptr, nullptr, nullptr, nullptr};
     int ys = 0, cs = 0;
     FNX_TRY(jpeg_decode_planes(ctx, data, n, &f, pl, &ys, &cs));
     const bool grey = f.ncomp == 1;
-    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, d.p, d.stride));
+    if (f.ncomp == 4) FNX_TRY(launch_cmyk_to_nrgba(ctx, pl, ys, f.adobe, f.w, f.h, d.p, d.stride));
+    else FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, d.p, d.stride));
     return finish(ctx, space, &d);
 }
 
@@ -1386,7 +1387,7 @@ int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double targ
     FNX_REQUIRE(data && window && nbytes && quality && ssim && w && h, "recompress arguments");
     *nbytes = 0;
     JpegFile f;
-    uint8_t *pl[3];
+    uint8_t *pl[4] = {nullptr, nullptr, nullptr, nullptr};
     int ys = 0, cs = 0;
     FNX_TRY(jpeg_decode_planes(ctx, data, n, &f, pl, &ys, &cs));
     *w = f.w; *h = f.h;
@@ -1409,7 +1410,8 @@ int fnx_jpeg_recompress(fnx_ctx *ctx, const uint8_t *data, size_t n, double targ
     uint8_t *img = static_cast<uint8_t *>(t);
     s.p = img;
     const bool grey = f.ncomp == 1;
-    FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, img, s.stride));
+    if (f.ncomp == 4) FNX_TRY(launch_cmyk_to_nrgba(ctx, pl, ys, f.adobe, f.w, f.h, img, s.stride));
+    else FNX_TRY(launch_ycbcr_to_nrgba(ctx, pl[0], ys, grey ? nullptr : pl[1], grey ? nullptr : pl[2], cs, grey ? 0 : f.ratio, f.w, f.h, img, s.stride));
     FNX_TRY(launch_jpeg_ycc(ctx, s.p, s.stride, f.w, f.h, orig.p[0], orig.p[1], orig.p[2]));
     FNX_TRY(jpeg_search_device(ctx, s, orig, f.w, f.h, target_ssim, window, quality, ssim, steps, &found));
     return jpeg_file_from_planes(ctx, orig, f.w, f.h, *quality, out, cap, nbytes);

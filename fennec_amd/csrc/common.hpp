@@ -414,6 +414,8 @@ int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, i
 // boxDownsample(toNRGBARef(planes)) without the image (ssim.hip); *done = false: not its case, convert and downsample instead
 int launch_box_downsample_ycc(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr, int cstride,
                               int ratio, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH, bool *done);
+// four planes of equal geometry (a four-component JPEG, reader.go applyBlack) -> toNRGBARef's image; adobe: the APP14 transform
+int launch_cmyk_to_nrgba(fnx_ctx *ctx, const uint8_t *const planes[4], int stride, int adobe, int w, int h, uint8_t *dst, int dstride);
 int launch_ycbcr_to_nrgba(fnx_ctx *ctx, const uint8_t *y, int ystride, const uint8_t *cb, const uint8_t *cr,
                           int cstride, int ratio, int w, int h, uint8_t *dst, int dstride);
 int launch_orient(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, int orient,
@@ -454,14 +456,15 @@ struct DecSyncTables {
 
 struct JpegFile {
     int w = 0, h = 0;
-    int ncomp = 3;               // 3: image.YCbCr; 1: image.Gray
+    int ncomp = 3;               // 3: image.YCbCr; 1: image.Gray; 4: image.CMYK (Adobe CMYK / YCbCrK, every component 1 x 1: the host route)
+    int adobe = -1;              // the APP14 segment's transform byte (-1: no such segment)
     int ratio = 0;               // image.YCbCrSubsampleRatio: 0 4:4:4, 1 4:2:2, 2 4:2:0, 3 4:4:0, 4 4:1:1, 5 4:1:0; -1: one component
     int hy = 1, vy = 1;          // Y blocks per MCU across / down
     int nslots = 3;              // blocks per MCU
     int ri = 0;                  // MCUs per restart interval (DRI); 0: none
     int mx = 0, my = 0;          // MCUs per row / column
     uint64_t dcpack = 0, acpack = 0;   // Huffman table of MCU slot s: (pack >> 4 s) & 15 (up to 4 x 2 + 2 slots)
-    uint16_t q[3][64];           // per component, natural order
+    uint16_t q[4][64];           // per component, natural order
     size_t scan = 0;             // offset of the entropy-coded segment in the file
     int rounds = 0;              // cross-workgroup synchronisation rounds the decode took
     bool progressive = false;    // the scans are entropy-decoded on the host (jpeg_prog.cpp: SOF2, SOF1, sequential scans the device has no form for), the image is made on the device
@@ -476,7 +479,7 @@ int jpeg_corrupt(const char *what);         // set_error + FNX_ERR_INVALID
 // the scan's bytes without the stuffing into dst (capacity: n - f.scan); *nbytes = what was written
 // rst: the byte offsets (in dst) at which restart intervals 1, 2, ... start
 int jpeg_unstuff(const uint8_t *data, size_t n, const JpegFile &f, uint8_t *dst, size_t *nbytes, std::vector<uint32_t> *rst);
-int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride);
+int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[4], int *ystride, int *cstride);
 int launch_scan(fnx_ctx *ctx, const uint32_t *in, unsigned long long *out, unsigned long long *totals, int n, unsigned long long *grand);
 
 }  // namespace fnx

@@ -446,12 +446,12 @@ struct IdctArgs {
     const int16_t *coef;
     const uint32_t *dcb;
     const unsigned long long *dcsum;     // exclusive prefix sum of dcb
-    uint8_t *out[3];
-    int stride[3], nbx[3], nblocks[3];
+    uint8_t *out[4];
+    int stride[4], nbx[4], nblocks[4];
     int mx, nmcu, hy, vy, nc;            // MCUs per row, MCUs, Y blocks per MCU across / down, chroma components
     int ri;                              // MCUs per restart interval (the DC prediction starts over in each); 0: one interval
     int abs_dc;                          // progressive files (jpeg_prog.cpp): coef[0] IS the DC, no prediction to undo
-    uint16_t q[3][64];                   // natural order
+    uint16_t q[4][64];                   // natural order (a fourth plane -- the black of a CMYK file -- only with abs_dc)
 };
 
 __global__ __launch_bounds__(256) void jpeg_didct_kernel(IdctArgs a)
@@ -517,7 +517,7 @@ constexpr int SCAN_PER_WG_D = 2048;
 // enqueued and *f describes them; the scan has been validated (one small read-back).
 // SOF2: every scan's entropy decoding on the host (jpeg_prog.cpp: why), the coefficients across PCIe at 2 bytes each, then the
 // same dequantisation + IDCT launch as a baseline file's
-static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride)
+static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[4], int *ystride, int *cstride)
 {
     const long long nmcu = static_cast<long long>(f->mx) * f->my;
     const long long nblk_ll = nmcu * f->nslots;
@@ -536,15 +536,16 @@ static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, siz
     void *sc = nullptr, *pl = nullptr;
     FNX_TRY(scratch(ctx, SLOT_JPEG_DEC, al(b_coef), &sc));
     const size_t b_y = al(static_cast<size_t>(ys) * yh), b_c = al(static_cast<size_t>(cs) * chh);
-    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_PLANES, b_y + 2 * b_c, &pl));
+    FNX_TRY(scratch(ctx, SLOT_JPEG_DEC_PLANES, b_y + 3 * b_c, &pl));
     planes[0] = static_cast<uint8_t *>(pl);
     planes[1] = planes[0] + b_y;
     planes[2] = planes[1] + b_c;
+    planes[3] = planes[2] + b_c;                  // (four components: all of one geometry, b_c == b_y)
     *ystride = ys; *cstride = cs;
     FNX_HIP(hipMemcpyAsync(sc, pin, b_coef, hipMemcpyHostToDevice, ctx->stream));
     IdctArgs ia{};
     ia.coef = static_cast<const int16_t *>(sc); ia.dcb = nullptr; ia.dcsum = nullptr;
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 4; c++) {
         ia.out[c] = planes[c];
         ia.stride[c] = c ? cs : ys;
         ia.nbx[c] = (c ? cs : ys) / 8;
@@ -560,7 +561,7 @@ static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, siz
     return FNX_OK;
 }
 
-int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[3], int *ystride, int *cstride)
+int jpeg_decode_planes(fnx_ctx *ctx, const uint8_t *data, size_t n, JpegFile *f, uint8_t *planes[4], int *ystride, int *cstride)
 {
     FNX_TRY(jpeg_parse(data, n, f));
     if (f->progressive) return jpeg_decode_planes_progressive(ctx, data, n, f, planes, ystride, cstride);

@@ -32,7 +32,8 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
     bool sof1_or_2 = false, allones = false;
     f->progressive = false;
     uint8_t q[4][64];
-    int ncomp = 0, comp_id[3] = {0, 0, 0}, comp_h[3] = {0, 0, 0}, comp_v[3] = {0, 0, 0}, comp_q[3] = {0, 0, 0};
+    int ncomp = 0, comp_id[4] = {0, 0, 0, 0}, comp_h[4] = {0, 0, 0, 0}, comp_v[4] = {0, 0, 0, 0}, comp_q[4] = {0, 0, 0, 0};
+    f->adobe = -1;
     std::memset(&f->tab, 0, sizeof(f->tab));
     f->ri = 0;
     size_t pos = 2;
@@ -63,7 +64,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             sof1_or_2 = m != 0xc0;
             if (sl < 6) return jpeg_corrupt("bad SOF segment");
             if (seg[0] != 8) return jpeg_unsupported("a sample precision other than 8 bits");
-            if (seg[5] != 3 && seg[5] != 1) return jpeg_unsupported("a component count other than 1 and 3");
+            if (seg[5] != 3 && seg[5] != 1 && seg[5] != 4) return jpeg_unsupported("a component count other than 1, 3 and 4");
             ncomp = seg[5];
             if (sl < 6 + 3 * static_cast<size_t>(ncomp)) return jpeg_corrupt("bad SOF segment");
             f->h = (seg[1] << 8) | seg[2];
@@ -122,11 +123,21 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             if (sl < 2) return jpeg_corrupt("bad DRI segment");
             f->ri = (seg[0] << 8) | seg[1];                               // MCUs per restart interval; 0: none
         } else if (m == 0xee) {
-            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
+            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0) f->adobe = seg[11];     // (judged at the scan: what it means depends on the component count)
         } else if (m == 0xda) {
             if (!have_sof) return jpeg_corrupt("SOS before SOF");
             if (ncomp == 3 && comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') return jpeg_unsupported("an RGB file");
-            if (ncomp == 1) {
+            if (ncomp == 3 && f->adobe >= 0 && f->adobe != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
+            if (ncomp == 4) {
+                // image.CMYK (reader.go applyBlack): Adobe CMYK or YCbCrK.  Of image/jpeg's two layouts the one every encoder writes
+                // -- all four components 1 x 1; without an APP14 segment image/jpeg refuses the file.  Always the host's scans.
+                for (int c = 0; c < 4; c++)
+                    if (comp_h[c] != 1 || comp_v[c] != 1) return jpeg_unsupported("a four-component file with subsampled components");
+                if (f->adobe < 0) return jpeg_unsupported("a four-component file without an Adobe segment (image/jpeg refuses it)");
+                if (baseline_only && !sof1_or_2) return jpeg_unsupported(baseline_only);
+                f->ratio = -2; f->hy = 1; f->vy = 1;
+                f->progressive = true;
+            } else if (ncomp == 1) {
                 // a one-component scan is not interleaved (T.81 A.2.2): one block per MCU whatever the factors say; image.Gray
                 f->ratio = -1; f->hy = 1; f->vy = 1;
             } else {

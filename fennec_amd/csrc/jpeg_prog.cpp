@@ -17,7 +17,8 @@
 //     for components of one block per MCU, anything else with a restart interval is FNX_ERR_UNSUPPORTED (the host codec's call).
 // r5, later: the SEQUENTIAL files the device's scan decoder has no form for are read here as well -- SOF1 (extended sequential),
 // components in scans of their own or out of frame order, a Huffman table that assigns the all-ones code.
-// Not handled (FNX_ERR_UNSUPPORTED, as for baseline files): 12-bit samples, four components, arithmetic coding, chroma factors
+// Four-component files (Adobe CMYK / YCbCrK, all components 1 x 1) are read here whatever their frame type.
+// Not handled (FNX_ERR_UNSUPPORTED, as for baseline files): 12-bit samples, arithmetic coding, chroma factors
 // other than 1 x 1, a component no scan mentions, coefficients beyond 16 bits.
 // Plain C++ with no device code: this file reads untrusted bytes and is part of the sanitizer builds (make asan / tsan).
 #include <cstring>
@@ -111,7 +112,7 @@ inline int32_t extend(BitReader &br, int s)          // T.81 F.2.2.1: s bits as 
 
 struct Frame {
     int w = 0, h = 0, ncomp = 0;
-    int id[3] = {0, 0, 0}, ch[3] = {1, 1, 1}, cv[3] = {1, 1, 1}, cq[3] = {0, 0, 0};
+    int id[4] = {0, 0, 0, 0}, ch[4] = {1, 1, 1, 1}, cv[4] = {1, 1, 1, 1}, cq[4] = {0, 0, 0, 0};
     int hy = 1, vy = 1, mx = 0, my = 0, per = 1;
     int lhy = 0, lvy = 0;                        // log2 of hy (1, 2, 4) and vy (1, 2): block_at runs once per block and scan
 };
@@ -169,9 +170,9 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
     // with Ss, Se, Ah, Al fixed at 0, 63, 0, 0 whatever the scan header says (Table B.3), and a block is dequantised when its scan
     // decodes it -- with the table in force then (qsnap), not at EOI
     bool sequential = false;
-    uint8_t qsnap[3][64];
+    uint8_t qsnap[4][64];
     uint8_t q[4][64];
-    bool have_q[4] = {false, false, false, false}, seen[3] = {false, false, false};
+    bool have_q[4] = {false, false, false, false}, seen[4] = {false, false, false, false};
     std::vector<HTab> tabs(8);                   // [tc * 4 + th]
     std::vector<uint64_t> nzmask;                // per block: its non-zero AC coefficients by zig-zag position
     try {
@@ -208,7 +209,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
         } else if (m == 0xc2 || m == 0xc0 || m == 0xc1) {
             if (fr.ncomp != 0) return jpeg_corrupt("two SOF segments");
             sequential = m != 0xc2;
-            if (sl < 6 || seg[0] != 8 || (seg[5] != 1 && seg[5] != 3) || sl < 6 + 3 * static_cast<size_t>(seg[5]))
+            if (sl < 6 || seg[0] != 8 || (seg[5] != 1 && seg[5] != 3 && seg[5] != 4) || sl < 6 + 3 * static_cast<size_t>(seg[5]))
                 return jpeg_corrupt("bad SOF segment");                    // (jpeg_parse has let this frame through already)
             fr.ncomp = seg[5];
             fr.h = (seg[1] << 8) | seg[2];
@@ -261,12 +262,12 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
             if (sl < 2) return jpeg_corrupt("bad DRI segment");
             ri = (seg[0] << 8) | seg[1];
         } else if (m == 0xee) {
-            if (sl >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) return jpeg_unsupported("an Adobe colour transform other than YCbCr");
+            // (jpeg_parse has judged the Adobe segment against the component count)
         } else if (m == 0xda) {
             if (fr.ncomp == 0) return jpeg_corrupt("SOS before SOF");
             const int ns = sl >= 1 ? seg[0] : 0;
             if (ns < 1 || ns > fr.ncomp || sl != 4 + 2 * static_cast<size_t>(ns)) return jpeg_corrupt("bad SOS segment");
-            int sc[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            int sc[4] = {0, 0, 0, 0}, td[4] = {0, 0, 0, 0}, ta[4] = {0, 0, 0, 0};
             for (int i = 0; i < ns; i++) {
                 int c = -1;
                 for (int j = 0; j < fr.ncomp; j++) if (fr.id[j] == seg[1 + 2 * i]) c = j;
@@ -294,7 +295,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                 return jpeg_unsupported("a restart interval in a one-component scan of a component with several blocks per MCU");
             BitReader br(data + pos + 2 + len, data + n);
             const int32_t delta = 1 << al;
-            int32_t pred[3] = {0, 0, 0};
+            int32_t pred[4] = {0, 0, 0, 0};
             uint32_t eob_run = 0;
             long long mcu = 0;
             int rbx = 0, rby = 0;                                                // a one-component scan's raster position
@@ -389,7 +390,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                         if (br.p + 2 > br.end || br.p[0] != 0xff || br.p[1] != 0xd0 + expected_rst) return jpeg_corrupt("restart markers out of sequence");
                         br.p += 2;
                         expected_rst = (expected_rst + 1) & 7;
-                        pred[0] = pred[1] = pred[2] = 0;
+                        pred[0] = pred[1] = pred[2] = pred[3] = 0;
                         eob_run = 0;
                     }
                 }
@@ -404,7 +405,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
         if (!seen[c]) return jpeg_unsupported("a component no scan mentions");
         if (!sequential && !have_q[fr.cq[c]]) return jpeg_corrupt("the frame uses a quantisation table the file does not define");
     }
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < 4; c++)
         for (int k = 0; k < 64; k++) f->q[c][k] = c < fr.ncomp ? (sequential ? qsnap[c][k] : q[fr.cq[c]][k]) : 1;
     return FNX_OK;
 }

@@ -2042,21 +2042,33 @@ static int jprog_refine(jpeg_bitr *r, int32_t *b, const jpeg_dtab *h, int zs, in
     return r->bad ? -10 : 0;
 }
 
+static int orc_jpeg_decode_scans(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
+                                 int16_t *coef, uint8_t *kp, int *adobe);
 static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
                                        int16_t *coef)
+{
+    return orc_jpeg_decode_scans(data, n, wd, ht, ratio, yp, cbp, crp, coef, NULL, NULL);
+}
+
+/* kp != NULL: four-component frames too (reader.go: the fourth component is the black plane, d.blackPix), all four at 1 x 1 --
+ * of image/jpeg's two layouts ([0x11 x 4], [0x22, 0x11, 0x11, 0x22]) the one every encoder writes; *adobe = the APP14 transform
+ * (-1: no Adobe segment, which applyBlack refuses).  *ratio = -2 for such a frame. */
+static int orc_jpeg_decode_scans(const uint8_t *data, long n, int *wd, int *ht, int *ratio, uint8_t *yp, uint8_t *cbp, uint8_t *crp,
+                                 int16_t *coef, uint8_t *kp, int *adobe)
 {
     /* Also the SEQUENTIAL files the one-scan decoder below does not read (r5): SOF0 / SOF1 frames whose components come in
      * scans of their own, and SOF1 (extended sequential, 8 bit) altogether.  processSOS is the same function for them with
      * Ss, Se, Ah, Al fixed at 0, 63, 0, 0 whatever the scan header says (Table B.3), and a block is dequantised when its scan
      * decodes it -- with the table in force THEN (qsnap), not at EOI. */
     int sequential = 0;
-    uint8_t qsnap[3][64];
+    uint8_t qsnap[4][64];
     uint8_t q[4][64];
+    int adobe_t = -1;
     jpeg_dtab dt[2][4];
     int have_q[4] = {0, 0, 0, 0}, have_t[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    int ri = 0, W = 0, H = 0, ncomp = 0, comp_h[3] = {1, 1, 1}, comp_v[3] = {1, 1, 1}, comp_q[3] = {0, 0, 0}, comp_id[3] = {0, 0, 0};
-    int hy = 1, vy = 1, mx = 0, my = 0, seen[3] = {0, 0, 0};
-    int32_t *cf[3] = {NULL, NULL, NULL};                                          /* per component: [my v][mx h] blocks of 64, zig-zag order */
+    int ri = 0, W = 0, H = 0, ncomp = 0, comp_h[4] = {1, 1, 1, 1}, comp_v[4] = {1, 1, 1, 1}, comp_q[4] = {0, 0, 0, 0}, comp_id[4] = {0, 0, 0, 0};
+    int hy = 1, vy = 1, mx = 0, my = 0, seen[4] = {0, 0, 0, 0};
+    int32_t *cf[4] = {NULL, NULL, NULL, NULL};                                          /* per component: [my v][mx h] blocks of 64, zig-zag order */
     int rc = -2;
     long pos = 2;
     for (;;) {
@@ -2083,7 +2095,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
         } else if (m == 0xc2 || m == 0xc0 || m == 0xc1) {
             if (ncomp != 0) { rc = -4; goto out; }
             sequential = m != 0xc2;
-            if (sl < 6 + 3 || seg[0] != 8 || (seg[5] != 3 && seg[5] != 1) || sl < 6 + 3 * seg[5]) { rc = -4; goto out; }
+            if (sl < 6 + 3 || seg[0] != 8 || (seg[5] != 3 && seg[5] != 1 && !(seg[5] == 4 && kp)) || sl < 6 + 3 * seg[5]) { rc = seg[5] == 4 ? -14 : -4; goto out; }
             ncomp = seg[5];
             H = (seg[1] << 8) | seg[2]; W = (seg[3] << 8) | seg[4];
             if (W <= 0 || H <= 0) { rc = -4; goto out; }
@@ -2092,14 +2104,16 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                 if (comp_q[c] > 3) { rc = -4; goto out; }
             }
             if (ncomp == 1) { comp_h[0] = comp_v[0] = 1; }
-            else {
+            else if (ncomp == 4) {
+                for (int c = 0; c < 4; c++) if (comp_h[c] != 1 || comp_v[c] != 1) { rc = -9; goto out; }
+            } else {
                 if (comp_h[1] != 1 || comp_v[1] != 1 || comp_h[2] != 1 || comp_v[2] != 1) { rc = -9; goto out; }
                 if (!(comp_h[0] == 1 || comp_h[0] == 2 || comp_h[0] == 4) || comp_v[0] < 1 || comp_v[0] > 2) { rc = -9; goto out; }
             }
             hy = comp_h[0]; vy = comp_v[0];
             mx = (W + 8 * hy - 1) / (8 * hy); my = (H + 8 * vy - 1) / (8 * vy);
             *wd = W; *ht = H;
-            *ratio = ncomp == 1 ? -1 : (hy == 4 ? (vy == 2 ? 5 : 4) : hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));
+            *ratio = ncomp == 4 ? -2 : ncomp == 1 ? -1 : (hy == 4 ? (vy == 2 ? 5 : 4) : hy == 2 ? (vy == 2 ? 2 : 1) : (vy == 2 ? 3 : 0));
             if (!yp) return 1;
             for (int c = 0; c < ncomp; c++) {
                 cf[c] = (int32_t *)calloc((size_t)mx * comp_h[c] * my * comp_v[c] * 64, sizeof(int32_t));
@@ -2132,12 +2146,15 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
             if (sl < 2) { rc = -2; goto out; }
             ri = (seg[0] << 8) | seg[1];
         } else if (m == 0xee) {
-            if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) { rc = -9; goto out; }
+            if (sl >= 12 && memcmp(seg, "Adobe", 5) == 0) {
+                adobe_t = seg[11];
+                if (!kp && seg[11] != 1) { rc = -9; goto out; }
+            }
         } else if (m == 0xda) {
             if (ncomp == 0) { rc = -8; goto out; }
             const int ns = sl >= 1 ? seg[0] : 0;
             if (ns < 1 || ns > ncomp || sl != 4 + 2 * ns) { rc = -8; goto out; }
-            int sc[3], td[3], ta[3];
+            int sc[4], td[4], ta[4];
             for (int i = 0; i < ns; i++) {
                 int c = -1;
                 for (int j = 0; j < ncomp; j++) if (comp_id[j] == seg[1 + 2 * i]) c = j;
@@ -2164,7 +2181,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
             }
             if (ri > 0 && ns == 1 && comp_h[sc[0]] * comp_v[sc[0]] > 1) { rc = -12; goto out; }
             jpeg_bitr br = {data + pos + 2 + len, (size_t)(n - (pos + 2 + len)), 0, 0, 0, 0};
-            int32_t pred[3] = {0, 0, 0};
+            int32_t pred[4] = {0, 0, 0, 0};
             uint32_t eob_run = 0;
             long mcu = 0, block_count = 0;
             int expected_rst = 0;
@@ -2226,7 +2243,7 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
                         if (br.pos + 2 > br.n || br.p[br.pos] != 0xff || br.p[br.pos + 1] != (uint8_t)(0xd0 + expected_rst)) { rc = -11; goto out; }
                         br.pos += 2;
                         expected_rst = (expected_rst + 1) & 7;
-                        pred[0] = pred[1] = pred[2] = 0;
+                        pred[0] = pred[1] = pred[2] = pred[3] = 0;
                         eob_run = 0;
                     }
                 }
@@ -2240,13 +2257,15 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
     {
         const int ys = 8 * hy * mx, cs = 8 * mx;
         memset(yp, 0, (size_t)ys * 8 * vy * my);
-        if (ncomp == 3) { memset(cbp, 0, (size_t)cs * 8 * my); memset(crp, 0, (size_t)cs * 8 * my); }
+        if (ncomp >= 3) { memset(cbp, 0, (size_t)cs * 8 * my); memset(crp, 0, (size_t)cs * 8 * my); }
+        if (ncomp == 4) memset(kp, 0, (size_t)ys * 8 * vy * my);
+        if (adobe) *adobe = adobe_t;
         for (int c = 0; c < ncomp; c++) {
             if (!seen[c]) continue;                                               /* progCoeffs[i] == nil: the plane stays zero */
             if (!sequential && !have_q[comp_q[c]]) { rc = -8; goto out; }
             const int hi = comp_h[c], vi = comp_v[c], stride = mx * hi;
-            uint8_t *plane = c == 0 ? yp : (c == 1 ? cbp : crp);
-            const int ps = c == 0 ? ys : cs;
+            uint8_t *plane = c == 0 ? yp : (c == 1 ? cbp : (c == 2 ? crp : kp));
+            const int ps = (c == 0 || c == 3) ? ys : cs;
             for (int by = 0; (long)by * 8 * vy < (long)H * vi; by++)
                 for (int bx = 0; (long)bx * 8 * hy < (long)W * hi; bx++) {
                     const int32_t *z = cf[c] + ((size_t)by * stride + bx) * 64;
@@ -2277,7 +2296,50 @@ static int orc_jpeg_decode_progressive(const uint8_t *data, long n, int *wd, int
         rc = 1;
     }
 out:
-    for (int c = 0; c < 3; c++) free(cf[c]);
+    for (int c = 0; c < 4; c++) free(cf[c]);
+    return rc;
+}
+
+/* toNRGBARef(jpeg.Decode(data)) of a four-component file (8 bit, every component 1 x 1), any frame type the scan-by-scan decoder
+ * reads.  reader.go applyBlack: without an Adobe segment the file is refused; transform 0 (CMYK): the stored samples are inverted,
+ * C, M, Y, K = 255 - s; any other transform (YCbCrK): the first three planes go through YCbCr -> RGB and stand for C, M, Y as
+ * they are (the RGB -> CMY inversion cancels the Adobe inversion), K = 255 - s.  Then convert.go:34-64 over image.CMYK:
+ * color.CMYK.RGBA() -- w = 0xffff - K * 0x101, r = (0xffff - C * 0x101) * w / 0xffff -- and the opaque branch's r >> 8.
+ * dst == NULL: the dimensions only.  Returns 1, or a negative error. */
+ORC_API int orc_jpeg_decode_cmyk(const uint8_t *data, long n, int *wd, int *ht, uint8_t *dst, int dstride)
+{
+    int ratio = 0, adobe = -1;
+    uint8_t dummy = 0;
+    int rc = orc_jpeg_decode_scans(data, n, wd, ht, &ratio, NULL, NULL, NULL, NULL, &dummy, NULL);
+    if (rc != 1 || ratio != -2) return rc == 1 ? -14 : rc;
+    if (!dst) return 1;
+    const int W = *wd, H = *ht, mx = (W + 7) / 8, my = (H + 7) / 8, ps = 8 * mx;
+    const size_t pb = (size_t)ps * 8 * my;
+    uint8_t *pl = (uint8_t *)malloc(4 * pb);
+    if (!pl) return -20;
+    rc = orc_jpeg_decode_scans(data, n, wd, ht, &ratio, pl, pl + pb, pl + 2 * pb, NULL, pl + 3 * pb, &adobe);
+    if (rc == 1 && adobe < 0) rc = -15;                        /* "4-component JPEG doesn't have Adobe APP14 metadata" */
+    for (int y = 0; rc == 1 && y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const size_t i = (size_t)y * ps + x;
+            uint32_t c, m, yy, k = 255u - pl[3 * pb + i];
+            if (adobe == 0) { c = 255u - pl[i]; m = 255u - pl[pb + i]; yy = 255u - pl[2 * pb + i]; }
+            else {                                                  /* color.YCbCrToRGB */
+                const int32_t y1 = (int32_t)pl[i] * 0x10101, cb1 = (int32_t)pl[pb + i] - 128, cr1 = (int32_t)pl[2 * pb + i] - 128;
+                int32_t r = y1 + 91881 * cr1, g = y1 - 22554 * cb1 - 46802 * cr1, b = y1 + 116130 * cb1;
+                r = ((uint32_t)r & 0xff000000u) == 0 ? r >> 16 : (r < 0 ? 0 : 255);
+                g = ((uint32_t)g & 0xff000000u) == 0 ? g >> 16 : (g < 0 ? 0 : 255);
+                b = ((uint32_t)b & 0xff000000u) == 0 ? b >> 16 : (b < 0 ? 0 : 255);
+                c = (uint32_t)r; m = (uint32_t)g; yy = (uint32_t)b;
+            }
+            const uint32_t w = 0xffffu - k * 0x101u;
+            uint8_t *o = dst + (size_t)y * dstride + 4 * x;
+            o[0] = (uint8_t)(((0xffffu - c * 0x101u) * w / 0xffffu) >> 8);
+            o[1] = (uint8_t)(((0xffffu - m * 0x101u) * w / 0xffffu) >> 8);
+            o[2] = (uint8_t)(((0xffffu - yy * 0x101u) * w / 0xffffu) >> 8);
+            o[3] = 0xff;
+        }
+    free(pl);
     return rc;
 }
 

@@ -523,8 +523,39 @@ def jpeg_decode_planes(data: bytes, with_coefficients: bool = False):
     return out + (coef,) if with_coefficients else out
 
 
+def jpeg_decode_cmyk(data: bytes) -> np.ndarray:
+    """toNRGBARef(jpeg.Decode(data)) of a four-component file (Adobe CMYK or YCbCrK, every component 1 x 1): orc_jpeg_decode_cmyk."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    L = lib()
+    L.orc_jpeg_decode_cmyk.restype = C.c_int
+    L.orc_jpeg_decode_cmyk.argtypes = [_u8p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int), _u8p, C.c_int]
+    w, h = C.c_int(), C.c_int()
+    rc = L.orc_jpeg_decode_cmyk(buf.ctypes.data_as(_u8p), len(data), C.byref(w), C.byref(h), None, 0)
+    if rc != 1:
+        raise RuntimeError(f"orc_jpeg_decode_cmyk: {rc}")
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    rc = L.orc_jpeg_decode_cmyk(buf.ctypes.data_as(_u8p), len(data), C.byref(w), C.byref(h), out.ctypes.data_as(_u8p), w.value * 4)
+    if rc != 1:
+        raise RuntimeError(f"orc_jpeg_decode_cmyk: {rc}")
+    return out
+
+
+def _jpeg_components(data: bytes) -> int:
+    pos = 2
+    while pos + 4 <= len(data) and data[pos] == 0xFF:
+        m, n = data[pos + 1], (data[pos + 2] << 8) | data[pos + 3]
+        if m in (0xC0, 0xC1, 0xC2):
+            return data[pos + 9] if pos + 9 < len(data) else 0
+        if m == 0xDA:
+            break
+        pos += 2 + n
+    return 0
+
+
 def jpeg_decode(data: bytes) -> np.ndarray:
     """toNRGBARef(jpeg.Decode(data)) for such a file."""
+    if _jpeg_components(data) == 4:
+        return jpeg_decode_cmyk(data)
     w, h, ratio, y, cb, cr = jpeg_decode_planes(data)
     full = ycbcr_to_nrgba(y, cb, cr, ratio)
     return np.ascontiguousarray(full[:h, :w])

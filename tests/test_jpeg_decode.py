@@ -178,8 +178,14 @@ def test_segment_parser_answers_or_refuses_never_crashes():
             parse(_with_luma_factors(good[0], hv))
     buf = io.BytesIO()
     Image.fromarray(src, "RGBA").convert("CMYK").save(buf, "JPEG")
-    with pytest.raises(fennec_amd.FennecUnsupported):
-        parse(buf.getvalue())
+    cmyk = buf.getvalue()
+    assert parse(cmyk) == (96, 64)                              # r5: four components with an Adobe segment are taken (the host's scans)
+    i = cmyk.index(b"\xff\xee")
+    with pytest.raises(fennec_amd.FennecUnsupported):          # ... without one image/jpeg refuses the file, and so does this parser
+        parse(cmyk[:i] + cmyk[i + 2 + ((cmyk[i + 2] << 8) | cmyk[i + 3]):])
+    i = good[0].index(b"\xff\xc0")
+    with pytest.raises(fennec_amd.FennecUnsupported):          # 12-bit samples
+        parse(good[0][:i + 4] + b"\x0c" + good[0][i + 5:])
     for junk in (b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"GIF89a" + good[0], b"\xff\xd8\xff\xd9", b"\xff\xd8" + b"\xff" * 64):
         with pytest.raises(fennec_amd.FennecError):
             parse(junk)
@@ -362,8 +368,10 @@ def test_gpu_decode_refuses_what_it_does_not_handle(ctx):
             ctx.jpeg_decode(_with_luma_factors(_pil(src, quality=80, subsampling=2), hv))
     buf = io.BytesIO()
     Image.fromarray(src, "RGBA").convert("CMYK").save(buf, "JPEG", quality=80)
-    with pytest.raises(fennec_amd.FennecUnsupported):
-        ctx.jpeg_decode_config(buf.getvalue())
+    cmyk = buf.getvalue()
+    i = cmyk.index(b"\xff\xee")
+    with pytest.raises(fennec_amd.FennecUnsupported):          # four components without an Adobe segment (r5: with one they decode)
+        ctx.jpeg_decode_config(cmyk[:i] + cmyk[i + 2 + ((cmyk[i + 2] << 8) | cmyk[i + 3]):])
     good = _pil(src, quality=80, subsampling=2)
     for bad in (good[: len(good) // 2], good[:-2], b"\x89PNG\r\n\x1a\n" + good, good[:300]):
         with pytest.raises(fennec_amd.FennecError) as e:

@@ -245,6 +245,60 @@ def test_host_decoder_reads_sequential_files():
         _product_coefficients(data[:scans[2]] + b"\xff\xd9")
 
 
+# ------------------------------------------------------------------------------------------------ four components (image.CMYK)
+def _cmyk_files():
+    """libjpeg's Adobe CMYK files (transform 0, every component 1 x 1) of an image, baseline / progressive / optimised, and each of
+    them relabelled YCbCrK (transform 2: the same scans, read as luminance, two chroma planes and black)"""
+    from PIL import Image
+    src = _photo(203, 117, 3)
+    im = Image.fromarray(np.ascontiguousarray(src[..., :3]), "RGB").convert("CMYK")
+    out = []
+    for kw in (dict(quality=90), dict(quality=90, progressive=True), dict(quality=60, optimize=True)):
+        b = io.BytesIO()
+        im.save(b, "JPEG", **kw)
+        d = b.getvalue()
+        i = d.index(b"Adobe")
+        assert d[i + 11] == 0
+        out.append((f"CMYK {kw}", d))
+        out.append((f"YCbCrK {kw}", d[:i + 11] + b"\x02" + d[i + 12:]))
+    return out
+
+
+def test_oracle_reads_four_component_files():
+    """against libjpeg's decode + Pillow's CMYK -> RGB ((255 - c)(255 - k) / 255, the same product color.CMYK.RGBA() takes in 16 bits):
+    within one level; the YCbCrK reading of the same scans decodes to another image"""
+    from PIL import Image
+    for name, d in _cmyk_files():
+        got = orc.jpeg_decode(d)
+        assert got.shape == (117, 203, 4) and (got[..., 3] == 255).all(), name
+        if name.startswith("CMYK"):
+            ref = np.asarray(Image.open(io.BytesIO(d)).convert("RGB")).astype(int)
+            diff = np.abs(got[..., :3].astype(int) - ref)
+            assert diff.max() <= 2 and diff.mean() < 0.1, (name, diff.max(), diff.mean())
+            cmyk = got
+        else:
+            # the same scans read as luminance, two chroma planes and black (no encoder here writes such a file: the structure only --
+            # another image than the CMYK reading's; the arithmetic is checked where the device meets the oracle)
+            assert not np.array_equal(got, cmyk)
+    with pytest.raises(RuntimeError):
+        d = _cmyk_files()[0][1]
+        i = d.index(b"\xff\xee")
+        orc.jpeg_decode(d[:i] + d[i + 2 + ((d[i + 2] << 8) | d[i + 3]):])            # no Adobe segment: refused
+
+
+def test_host_decoder_reads_four_component_files():
+    import fennec_amd
+    for name, d in _cmyk_files():
+        coef, dims, ratio = fennec_amd.Context.jpeg_progressive_coefficients(d)
+        assert dims == (203, 117) and ratio == -2 and coef.shape == (4 * 26 * 15, 64), name
+        assert fennec_amd.Context.jpeg_parse(d) == (203, 117)
+    d = _cmyk_files()[0][1]
+    i = d.index(b"\xff\xc0")
+    sub = d[:i + 11] + b"\x22" + d[i + 12:]                                          # the first component 2 x 2: not a layout this route takes
+    with pytest.raises(fennec_amd.FennecUnsupported):
+        fennec_amd.Context.jpeg_parse(sub)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -345,3 +399,19 @@ def test_gpu_decode_of_sequential_files_read_scan_by_scan(ctx):
     big = jpeg_mini.encode_scans(_photo(1283, 719, 4), 2, 2, 90, sof=0xC1)
     assert np.array_equal(ctx.jpeg_decode(big), orc.jpeg_decode(big))
     assert ctx.jpeg_recompress(big, 0.94)[:4] == ctx.jpeg_compress(orc.jpeg_decode(big), 0.94)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_of_four_component_files(ctx):
+    """image.CMYK sources: Adobe CMYK and YCbCrK, baseline / progressive / optimised tables -- the device image against the oracle's
+    bit for bit, the item body over such a source against decode + compress"""
+    for name, d in _cmyk_files():
+        want = orc.jpeg_decode(d)
+        assert np.array_equal(ctx.jpeg_decode(d), want), name
+        assert ctx.jpeg_recompress(d, 0.94)[:4] == ctx.jpeg_compress(want, 0.94), name
+    from PIL import Image
+    big = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(_photo(1283, 719, 4)[..., :3]), "RGB").convert("CMYK").save(big, "JPEG", quality=92, progressive=True)
+    assert np.array_equal(ctx.jpeg_decode(big.getvalue()), orc.jpeg_decode(big.getvalue()))
+    three = _pil(_photo(320, 200, 1), quality=85, subsampling=2)                       # and a three-component file right behind it
+    assert np.array_equal(ctx.jpeg_decode(three), orc.jpeg_decode(three))

@@ -17,6 +17,9 @@ for kw in (dict(subsampling=2, progressive=True), dict(subsampling=0, progressiv
            dict(subsampling=0, progressive=True, restart_marker_blocks=3), dict(subsampling=2), dict(subsampling=0, restart_marker_blocks=2)):
     Image.fromarray(img).save(f"{sys.argv[1]}/f{k}.jpg", "JPEG", **{"quality": 85, **kw}); k += 1
 Image.fromarray(img[..., 0]).save(f"{sys.argv[1]}/f{k}.jpg", "JPEG", quality=85, progressive=True, restart_marker_blocks=4)
+k += 1
+for kw in (dict(), dict(progressive=True)):
+    Image.fromarray(img).convert("CMYK").save(f"{sys.argv[1]}/f{k}.jpg", "JPEG", quality=85, **kw); k += 1
 P
 ASAN_OPTIONS=detect_leaks=1 "$T/fuzz" "${1:-20000}" "$T"/f*.jpg
 rm -rf "$T"
