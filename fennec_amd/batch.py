@@ -300,7 +300,7 @@ def jpeg_item_work_device_all(jpegs: Sequence[bytes], target_ssim: float = TARGE
                               decode: Callable[[bytes], np.ndarray] = pillow_decode, file_options: Optional[dict] = None):
     """The per-item body of CompressBatch with NO host codec (fnx_jpeg_recompress: SURVEY 8(f)2, third slice): the file's
     bytes go up, the decoder, the search and the encoder run on the device, the new file's bytes come down.  A file the
-    device decoder does not take (CMYK, 12-bit, a progressive 4:2:0 file with restart intervals: FennecUnsupported) is decoded on the host by
+    device decoder does not take (12-bit, arithmetic coding, a progressive 4:2:0 file with restart intervals: FennecUnsupported) is decoded on the host by
     THIS function -- the caller's choice, visible in the result's `host_decoded` -- and continues on the device (without
     file_options' stages: those belong to the device call)."""
     import time

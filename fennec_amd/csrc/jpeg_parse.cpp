@@ -13,7 +13,7 @@ static const uint8_t UNZIG_H[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
 
 int jpeg_unsupported(const char *what)
 {
-    set_error("jpeg decode: %s is not handled on the device (sequential or progressive Huffman coding, 8 bit, 1 or 3 components, luminance factors 1, 2 or 4 across and 1 or 2 down)", what);
+    set_error("jpeg decode: %s is not handled on the device (sequential or progressive Huffman coding, 8 bit, 1 or 3 components with luminance factors 1, 2 or 4 across and 1 or 2 down, or 4 at 1 x 1)", what);
     return FNX_ERR_UNSUPPORTED;
 }
 

@@ -741,7 +741,7 @@ func jpegCompressHIP(src *image.NRGBA, targetSSIM float64) (data []byte, quality
 }
 
 // jpegDecodeHIP is image.Decode + toNRGBARef for a JPEG file (io.go:60-95) on the device.  ok == false: the device was
-// not used, does not take this file (CMYK, 12-bit samples: FNX_ERR_UNSUPPORTED) or finds it damaged
+// not used, does not take this file (12-bit samples, arithmetic coding: FNX_ERR_UNSUPPORTED) or finds it damaged
 // (FNX_ERR_INVALID) -- in every such case the caller runs image.Decode as before, and what the reference says about a
 // damaged file (an error, or an image: its decoder forgives some damage the device's strict block accounting does not)
 // stays the reference's own answer.

@@ -272,9 +272,10 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
 /* SURVEY 8(f)2, third slice -- image.Decode of a JPEG source (batch.go:88-101 via io.go:60-95) on the device:
  * dst = toNRGBARef(jpeg.Decode(data)), *w x *h.  `data` is HOST memory (the file); dst is in `space`.  dst == NULL:
  * only the dimensions (jpeg.DecodeConfig) -- and whether the device decoder takes the file at all (host work: ctx may be
- * NULL and no device is touched).  Handled: 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0) or one
- * (image.Gray), with or without restart intervals: baseline (SOF0), extended sequential (SOF1) and progressive (SOF2) frames in
- * any number of scans; anything else (four components, 12 bit, arithmetic coding, lossless) returns
+ * NULL and no device is touched).  Handled: 8 bit, three components (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, 4:1:0), one
+ * (image.Gray) or four (image.CMYK: Adobe CMYK / YCbCrK with every component 1 x 1, reader.go applyBlack), with or without restart
+ * intervals: baseline (SOF0), extended sequential (SOF1) and progressive (SOF2) frames in
+ * any number of scans; anything else (12 bit, arithmetic coding, lossless) returns
  * FNX_ERR_UNSUPPORTED and the caller decodes on the host (an explicit answer, not a fallback inside the library).
  * FNX_ERR_INVALID: a scan that ends early or holds a code outside its Huffman table.  Baseline: Huffman decoding is parallel
  * over 1024-bit spans of the scan that synchronise with their neighbours (jpeg_dec.hip); the result does not depend on how
@@ -287,7 +288,7 @@ int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint
 /* Host only (no ctx, no device): what fnx_jpeg_decode hands the device for a progressive (SOF2) file -- the quantised
  * coefficients over all its scans (scan.go processSOS / refine as published).  coef: [*blocks][64] int16, blocks MCU by MCU
  * in the order of an interleaved scan (Y blocks of the MCU row by row, then Cb, then Cr), natural (row-major) order inside a
- * block, DC as it is.  *blocks, *w, *h, *ratio (image.YCbCrSubsampleRatio 0..5; -1: one component) are set whenever the
+ * block, DC as it is.  *blocks, *w, *h, *ratio (image.YCbCrSubsampleRatio 0..5; -1: one component; -2: four) are set whenever the
  * frame parses; coef == NULL or cap_blocks < *blocks: nothing is decoded (FNX_OK / FNX_ERR_INVALID).  A baseline file:
  * FNX_ERR_UNSUPPORTED (its scan is decoded on the device).  Exists for the CPU-side parity tests and the sanitizer runs. */
 int fnx_jpeg_progressive_coefficients(const uint8_t *data, size_t n, int16_t *coef, size_t cap_blocks, size_t *blocks, int *w, int *h,
