@@ -51,6 +51,12 @@ def content(w, h):
 def pil(img, grey, **kw):
     from PIL import Image
     b = io.BytesIO()
+    if kw.pop("cmyk", False):                     # four components (Adobe CMYK; `ycck`: the same scans relabelled YCbCrK)
+        ycck = kw.pop("ycck", False)
+        Image.fromarray(np.ascontiguousarray(img[..., :3]), "RGB").convert("CMYK").save(b, "JPEG", **kw)
+        d = b.getvalue()
+        i = d.index(b"Adobe")
+        return d[:i + 11] + (b"\x02" if ycck else b"\x00") + d[i + 12:]
     if grey:
         Image.fromarray(np.ascontiguousarray(img[..., 1]), "L").save(b, "JPEG", **kw)
     else:
@@ -69,9 +75,14 @@ while time.time() - t0 < budget:
         kw["subsampling"] = sub
     if (grey or sub == 0) and it % 3 == 0:        # restart intervals where image/jpeg's count and T.81's agree
         kw["restart_marker_blocks"] = int(rng.integers(1, 40))
+    if it % 11 == 0:                              # four components: any frame type goes the host's way
+        grey = False
+        kw = dict(quality=kw["quality"], progressive=bool(rng.integers(2)), optimize=kw["optimize"], cmyk=True, ycck=bool(rng.integers(2)))
+        if it % 2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 40))
     img = content(w, h)
     try:
-        data = pil(img, grey, **kw)
+        data = pil(img, grey, **dict(kw))
     except OSError:                               # Pillow's encoder buffer: some small noisy images at high quality do not fit it
         runs["encoder_refused"] = runs.get("encoder_refused", 0) + 1
         continue
@@ -79,8 +90,9 @@ while time.time() - t0 < budget:
     try:
         want = orc.jpeg_decode(data)
         case("decode", np.array_equal(ctx.jpeg_decode(data), want), desc)
-        coef = fennec_amd.Context.jpeg_progressive_coefficients(data)[0]
-        case("coefficients", np.array_equal(coef[:, ZIG], orc.jpeg_decode_planes(data, with_coefficients=True)[-1]), desc)
+        if not kw.get("cmyk"):
+            coef = fennec_amd.Context.jpeg_progressive_coefficients(data)[0]
+            case("coefficients", np.array_equal(coef[:, ZIG], orc.jpeg_decode_planes(data, with_coefficients=True)[-1]), desc)
         if it % 5 == 0 and w >= 16 and h >= 16:
             case("recompress", ctx.jpeg_recompress(data, 0.94)[:4] == ctx.jpeg_compress(want, 0.94), desc)
     except Exception as e:                        # noqa: BLE001
