@@ -1373,6 +1373,7 @@ int fnx_jpeg_progressive_coefficients(const uint8_t *data, size_t n, int16_t *co
     const unsigned long long nblk = static_cast<unsigned long long>(f.mx) * f.my * f.nslots;
     *blocks = static_cast<size_t>(nblk);
     *w = f.w; *h = f.h; *ratio = f.ratio;
+    if (nblk > static_cast<unsigned long long>(JPEG_HOST_MAX_BLOCKS)) return jpeg_unsupported("a host-decoded file of more than 4 M blocks (FNX_JPEG_HOST_MAX_BLOCKS)");
     if (coef == nullptr) return FNX_OK;
     FNX_REQUIRE(cap_blocks >= nblk, "coefficient capacity");
     if (8ull * n < nblk) return jpeg_corrupt("the file is too short for the image's blocks");       // (as fnx_jpeg_decode: before anything is sized by the header)

@@ -468,12 +468,20 @@ struct JpegFile {
     size_t scan = 0;             // offset of the entropy-coded segment in the file
     int rounds = 0;              // cross-workgroup synchronisation rounds the decode took
     bool progressive = false;    // the scans are entropy-decoded on the host (jpeg_prog.cpp: SOF2, SOF1, sequential scans the device has no form for), the image is made on the device
+    // the frame header as jpeg_parse read and judged it: jpeg_prog.cpp takes the frame from HERE and never reads a SOF segment
+    // itself (two readings of one file by two sets of marker rules was a heap overflow: ADVICE r5)
+    bool sof_sequential = false; // SOF0 / SOF1 (true) or SOF2 (false)
+    int comp_id[4] = {0, 0, 0, 0}, comp_h[4] = {1, 1, 1, 1}, comp_v[4] = {1, 1, 1, 1}, comp_q[4] = {0, 0, 0, 0};
     DecTables tab;
 };
 int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f);
 // a progressive file's coefficients over all its scans into coef (zeroed by the caller; [mx my nslots][64] int16, blocks in the
 // order of an interleaved scan, natural order inside a block, DC as it is), the quantisation tables in force at EOI into f->q
 int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, int16_t *coef);
+// the host route's size limit (FNX_JPEG_HOST_MAX_BLOCKS in the header): a block costs 128 bytes of pinned host memory + 8 of
+// mask before a single scan bit is validated, so a header may not promise more than this many (4 M blocks = 512 MB pinned:
+// 16K x 8K at 4:2:0, 8K x 8K at 4:4:4); above it FNX_ERR_UNSUPPORTED -- the host codec's call
+constexpr long long JPEG_HOST_MAX_BLOCKS = 1ll << 22;
 int jpeg_unsupported(const char *what);     // set_error + FNX_ERR_UNSUPPORTED
 int jpeg_corrupt(const char *what);         // set_error + FNX_ERR_INVALID
 // the scan's bytes without the stuffing into dst (capacity: n - f.scan); *nbytes = what was written

@@ -521,7 +521,7 @@ static int jpeg_decode_planes_progressive(fnx_ctx *ctx, const uint8_t *data, siz
 {
     const long long nmcu = static_cast<long long>(f->mx) * f->my;
     const long long nblk_ll = nmcu * f->nslots;
-    if (nblk_ll >= (1ll << 30)) return jpeg_unsupported("a file this large");
+    if (nblk_ll > JPEG_HOST_MAX_BLOCKS) return jpeg_unsupported("a host-decoded file of more than 4 M blocks (FNX_JPEG_HOST_MAX_BLOCKS)");
     // a first DC scan costs every block at least one bit: a header that promises more blocks than the file has bits is refused
     // before anything is sized by it
     if (8ull * n < static_cast<unsigned long long>(nblk_ll)) return jpeg_corrupt("the file is too short for the image's blocks");

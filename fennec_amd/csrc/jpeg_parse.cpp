@@ -60,6 +60,7 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
             }
         } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
             if (have_sof) return jpeg_corrupt("two SOF segments");
+            f->sof_sequential = m != 0xc2;
             f->progressive = m != 0xc0;      // SOF2, and SOF1 (extended sequential: up to four tables per class): the host reads the scans
             sof1_or_2 = m != 0xc0;
             if (sl < 6) return jpeg_corrupt("bad SOF segment");
@@ -151,6 +152,12 @@ int jpeg_parse(const uint8_t *data, size_t n, JpegFile *f)
                 f->ratio = f->hy == 4 ? (f->vy == 2 ? 5 : 4) : f->hy == 2 ? (f->vy == 2 ? 2 : 1) : (f->vy == 2 ? 3 : 0);
             }
             f->ncomp = ncomp;
+            for (int c = 0; c < 4; c++) {
+                f->comp_id[c] = comp_id[c]; f->comp_q[c] = comp_q[c];
+                // (one component: not interleaved, one block per MCU whatever the factors say)
+                f->comp_h[c] = c < ncomp && ncomp != 1 ? comp_h[c] : 1;
+                f->comp_v[c] = c < ncomp && ncomp != 1 ? comp_v[c] : 1;
+            }
             f->nslots = f->hy * f->vy + ncomp - 1;
             f->mx = (f->w + 8 * f->hy - 1) / (8 * f->hy);
             f->my = (f->h + 8 * f->vy - 1) / (8 * f->vy);

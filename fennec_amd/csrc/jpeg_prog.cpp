@@ -165,35 +165,68 @@ inline int refine_nonzeroes(BitReader &br, int16_t *b, uint64_t mask, int zig, i
 
 int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, int16_t *coef)
 {
+    // The frame is jpeg_parse's (f->comp_*, f->hy ...): this function never reads a SOF segment.  Up to the first SOS (f->scan)
+    // it walks the file by jpeg_parse's marker rules exactly -- every segment starts with a marker, anything that is not a
+    // stand-alone marker is length-prefixed, 0xff 0x00 included -- so what the sizes came from and what is decoded here are one
+    // reading of the file (with two sets of rules an 0xff 0x00 pseudo-segment hid a second frame header whose chroma
+    // factors indexed coef and nzmask at twice their size).  Behind the first scan it reads as reader.go does between segments.
     Frame fr;
+    fr.w = f->w; fr.h = f->h; fr.ncomp = f->ncomp;
+    if (fr.ncomp != 1 && fr.ncomp != 3 && fr.ncomp != 4) return jpeg_corrupt("bad component count");
+    for (int c = 0; c < fr.ncomp; c++) {
+        fr.id[c] = f->comp_id[c]; fr.ch[c] = f->comp_h[c]; fr.cv[c] = f->comp_v[c]; fr.cq[c] = f->comp_q[c];
+        if (fr.cq[c] < 0 || fr.cq[c] > 3) return jpeg_corrupt("bad quantisation table selector");
+        if (c > 0 && (fr.ch[c] != 1 || fr.cv[c] != 1)) return jpeg_unsupported("chroma factors other than 1 x 1");
+    }
+    if (fr.ncomp == 1) fr.ch[0] = fr.cv[0] = 1;
+    if (fr.ncomp == 4 && (fr.ch[0] != 1 || fr.cv[0] != 1)) return jpeg_unsupported("a four-component file with subsampled components");
+    fr.hy = fr.ch[0]; fr.vy = fr.cv[0];
+    if (!(fr.hy == 1 || fr.hy == 2 || fr.hy == 4) || !(fr.vy == 1 || fr.vy == 2)) return jpeg_unsupported("luminance factors other than 1, 2, 4 across and 1, 2 down");
+    fr.lhy = fr.hy == 4 ? 2 : fr.hy - 1; fr.lvy = fr.vy - 1;
+    fr.mx = f->mx; fr.my = f->my;
+    fr.per = fr.hy * fr.vy + fr.ncomp - 1;
+    if (fr.w <= 0 || fr.h <= 0 || fr.hy != f->hy || fr.vy != f->vy || fr.per != f->nslots ||
+        fr.mx != (fr.w + 8 * fr.hy - 1) / (8 * fr.hy) || fr.my != (fr.h + 8 * fr.vy - 1) / (8 * fr.vy))
+        return jpeg_corrupt("the frame does not describe the block array");
+    const size_t nblk_total = static_cast<size_t>(fr.mx) * fr.my * fr.per;      // what coef and nzmask hold
     // sequential frames (SOF0 / SOF1) whose scans the device's decoder has no form for come here too: processSOS is one function,
     // with Ss, Se, Ah, Al fixed at 0, 63, 0, 0 whatever the scan header says (Table B.3), and a block is dequantised when its scan
     // decodes it -- with the table in force then (qsnap), not at EOI
-    bool sequential = false;
+    const bool sequential = f->sof_sequential;
     uint8_t qsnap[4][64];
     uint8_t q[4][64];
     bool have_q[4] = {false, false, false, false}, seen[4] = {false, false, false, false};
     std::vector<HTab> tabs(8);                   // [tc * 4 + th]
     std::vector<uint64_t> nzmask;                // per block: its non-zero AC coefficients by zig-zag position
     try {
-        nzmask.assign(static_cast<size_t>(f->mx) * f->my * f->nslots, 0);
+        nzmask.assign(nblk_total, 0);
     } catch (const std::bad_alloc &) {
         set_error("jpeg decode: no host memory for a progressive image of %d x %d", f->w, f->h);
         return FNX_ERR_OOM;
     }
     int ri = 0;
-    bool range_ok = true;
+    bool range_ok = true, seen_sof = false;
     size_t pos = 2;
+    if (f->scan < 2 || f->scan + 4 > n) return jpeg_corrupt("no scan where the first reading found one");
     for (;;) {
         if (pos + 2 > n) return jpeg_corrupt("the file ends before EOI");
-        if (data[pos] != 0xff) { pos++; continue; }                         // reader.go skips what lies between segments
+        const bool header = pos < f->scan;                                  // jpeg_parse's rules up to the first SOS
+        if (data[pos] != 0xff) {
+            if (header) return jpeg_corrupt("a segment does not start with a marker");
+            pos++;                                                          // reader.go skips what lies between segments
+            continue;
+        }
         const uint8_t m = data[pos + 1];
         if (m == 0xff) { pos++; continue; }
-        if (m == 0x00 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
-        if (m == 0xd9) break;
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7) || (m == 0x00 && !header)) { pos += 2; continue; }
+        if (m == 0xd9) {
+            if (header) return jpeg_corrupt("EOI before any scan");
+            break;
+        }
         if (pos + 4 > n) return jpeg_corrupt("the file ends inside a segment");
         const size_t len = (static_cast<size_t>(data[pos + 2]) << 8) | data[pos + 3];
         if (len < 2 || pos + 2 + len > n) return jpeg_corrupt("a segment runs past the end of the file");
+        if (header && (pos + 2 + len > f->scan || m == 0xda)) return jpeg_corrupt("the two readings of the file's segments disagree");
         const uint8_t *seg = data + pos + 4;
         const size_t sl = len - 2;
         if (m == 0xdb) {
@@ -207,27 +240,9 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                 o += 65;
             }
         } else if (m == 0xc2 || m == 0xc0 || m == 0xc1) {
-            if (fr.ncomp != 0) return jpeg_corrupt("two SOF segments");
-            sequential = m != 0xc2;
-            if (sl < 6 || seg[0] != 8 || (seg[5] != 1 && seg[5] != 3 && seg[5] != 4) || sl < 6 + 3 * static_cast<size_t>(seg[5]))
-                return jpeg_corrupt("bad SOF segment");                    // (jpeg_parse has let this frame through already)
-            fr.ncomp = seg[5];
-            fr.h = (seg[1] << 8) | seg[2];
-            fr.w = (seg[3] << 8) | seg[4];
-            for (int c = 0; c < fr.ncomp; c++) {
-                fr.id[c] = seg[6 + 3 * c];
-                fr.ch[c] = seg[7 + 3 * c] >> 4;
-                fr.cv[c] = seg[7 + 3 * c] & 15;
-                fr.cq[c] = seg[8 + 3 * c];
-            }
-            if (fr.ncomp == 1) fr.ch[0] = fr.cv[0] = 1;
-            fr.hy = fr.ch[0]; fr.vy = fr.cv[0];
-            if (!(fr.hy == 1 || fr.hy == 2 || fr.hy == 4) || !(fr.vy == 1 || fr.vy == 2)) return jpeg_corrupt("the frame header changed between two readings");
-            fr.lhy = fr.hy == 4 ? 2 : fr.hy - 1; fr.lvy = fr.vy - 1;
-            fr.mx = f->mx; fr.my = f->my;
-            fr.per = fr.hy * fr.vy + fr.ncomp - 1;
-            if (fr.w != f->w || fr.h != f->h || fr.hy != f->hy || fr.vy != f->vy || fr.ncomp != f->ncomp || fr.per != f->nslots)
-                return jpeg_corrupt("the frame header changed between two readings");
+            // (the one frame header jpeg_parse read; its contents are in *f)
+            if (!header || seen_sof) return jpeg_corrupt("two SOF segments");
+            seen_sof = true;
         } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8) {
             return jpeg_corrupt("a second frame header of another kind");
         } else if (m == 0xc4) {
@@ -315,6 +330,7 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                                 if (8ll * bx * fr.hy >= static_cast<long long>(fr.w) * hi || 8ll * by * fr.vy >= static_cast<long long>(fr.h) * vi) continue;
                             }
                             const size_t blk = block_at(fr, c, bx, by);
+                            if (blk >= nblk_total) return jpeg_corrupt("a scan addresses a block outside the frame");
                             int16_t *b = coef + 64 * blk;
                             uint64_t &mask = nzmask[blk];
                             if (ah != 0) {                                       // refinement (G.1.2.1, G.1.2.3)
@@ -357,8 +373,12 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
                                 const int s = huff(br, tabs[td[i]]);
                                 if (s < 0 || s > 16) return jpeg_corrupt("a scan holds a code outside its Huffman table");
                                 pred[c] += extend(br, s);
-                                range_ok = put(b, pred[c] * delta) && range_ok && pred[c] >= -(1 << 20) && pred[c] <= (1 << 20);
-                                if (pred[c] < -(1 << 20) || pred[c] > (1 << 20)) pred[c] = 0;   // (refused below; keeps the product defined)
+                                // the prediction is range-checked BEFORE it is scaled, the product taken in 64 bits (2^20 * 2^13
+                                // does not fit 32: ADVICE r5 -- a wrapped product could pass for an in-range coefficient)
+                                if (pred[c] < -(1 << 20) || pred[c] > (1 << 20)) { range_ok = false; pred[c] = 0; }
+                                const long long dc = static_cast<long long>(pred[c]) * delta;
+                                if (dc < -32768 || dc > 32767) range_ok = false;
+                                b[0] = static_cast<int16_t>(dc);
                             }
                             if (zig <= ze && eob_run > 0) eob_run--;
                             else {                                               // AC, first pass (G.1.2.2)
@@ -399,7 +419,6 @@ int jpeg_progressive_coefficients(const uint8_t *data, size_t n, JpegFile *f, in
         }
         pos += 2 + len;
     }
-    if (fr.ncomp == 0) return jpeg_corrupt("EOI before any frame");
     if (!range_ok) return jpeg_unsupported("coefficients beyond 16 bits");
     for (int c = 0; c < fr.ncomp; c++) {
         if (!seen[c]) return jpeg_unsupported("a component no scan mentions");

@@ -283,7 +283,10 @@ int fnx_jpeg_quality_search(fnx_ctx *ctx, int space, const uint8_t *src, int sst
  * the scans are entropy-decoded on the host (jpeg_prog.cpp) and the coefficients go up at 2 bytes each -- as are the sequential
  * files that decoder has no form for (SOF1, components in scans of their own, a table that assigns the all-ones code); dequantisation, IDCT
  * and colour conversion are the device's as for baseline.  Restated from ITU T.81 and Go's documented behaviour (scan.go's
- * refine / reconstructProgressiveImage): bit-exact against the tests' CPU restatement, parity with Go unpinned. */
+ * refine / reconstructProgressiveImage): bit-exact against the tests' CPU restatement, parity with Go unpinned.
+ * The host route sizes 136 bytes of host memory per block from the frame header alone, so it takes at most
+ * FNX_JPEG_HOST_MAX_BLOCKS blocks (16K x 8K at 4:2:0); a header that promises more is FNX_ERR_UNSUPPORTED (the host codec's). */
+#define FNX_JPEG_HOST_MAX_BLOCKS (1 << 22)
 int fnx_jpeg_decode(fnx_ctx *ctx, const uint8_t *data, size_t n, int space, uint8_t *dst, int dstride, int *w, int *h);
 /* Host only (no ctx, no device): what fnx_jpeg_decode hands the device for a progressive (SOF2) file -- the quantised
  * coefficients over all its scans (scan.go processSOS / refine as published).  coef: [*blocks][64] int16, blocks MCU by MCU

@@ -36,6 +36,68 @@ static void one(const std::vector<uint8_t> &d)
     if (rc == 0) n_ok++; else if (rc == FNX_ERR_UNSUPPORTED) n_unsupported++; else n_invalid++;
 }
 
+// the starts of the segments in front of the first scan, as jpeg_parse walks them
+static std::vector<size_t> header_segments(const std::vector<uint8_t> &g, size_t *sof)
+{
+    std::vector<size_t> at;
+    *sof = 0;
+    size_t pos = 2;
+    while (pos + 4 <= g.size() && g[pos] == 0xff) {
+        const uint8_t m = g[pos + 1];
+        if (m == 0xff) { pos++; continue; }
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) { pos += 2; continue; }
+        at.push_back(pos);
+        if (m >= 0xc0 && m <= 0xc2) *sof = pos;
+        if (m == 0xda || m == 0xd9) break;
+        pos += 2 + ((static_cast<size_t>(g[pos + 2]) << 8) | g[pos + 3]);
+    }
+    return at;
+}
+
+// Structure-aware mutations (the byte mutator never produced the file that overflowed jpeg_prog.cpp):
+//   * an `ff 00 LL LL` pseudo-segment in front of a header segment -- one reader's length-prefixed segment, another's stuffed
+//     byte -- holding a copy of the file from its frame header on with other sampling factors / table selectors, or noise;
+//   * the real frame header's component bytes (factors, table selectors, ids, count) changed in place.
+static std::vector<uint8_t> structured(const std::vector<uint8_t> &g, std::mt19937_64 &rng)
+{
+    size_t sof = 0;
+    const std::vector<size_t> at = header_segments(g, &sof);
+    std::vector<uint8_t> c = g;
+    if (at.empty() || sof == 0 || sof + 10 > g.size()) return c;
+    const int ncomp = g[sof + 9];
+    auto twist = [&](std::vector<uint8_t> &v, size_t f) {          // f: offset of the frame header's marker in v
+        const int nm = 1 + static_cast<int>(rng() % 3);
+        for (int m = 0; m < nm; m++) {
+            const size_t cc = rng() % (ncomp > 0 ? ncomp : 1);
+            const size_t o = f + 10 + 3 * cc + rng() % 3;
+            if (o >= v.size()) continue;
+            static const uint8_t fac[] = {0x11, 0x22, 0x21, 0x12, 0x41, 0x42, 0x44, 0x14, 0x00, 0xff, 0x31};
+            switch ((o - f - 10) % 3) {
+            case 0: v[o] = static_cast<uint8_t>(rng()); break;                                   // id
+            case 1: v[o] = fac[rng() % sizeof fac]; break;                                       // factors
+            default: v[o] = (rng() & 1) ? static_cast<uint8_t>(rng() % 4) : static_cast<uint8_t>(rng()); break;   // tq
+            }
+        }
+        if (rng() % 8 == 0 && f + 9 < v.size()) v[f + 9] = static_cast<uint8_t>(1 + rng() % 4);  // component count
+    };
+    if (rng() % 3 == 0) { twist(c, sof); return c; }
+    std::vector<uint8_t> payload;
+    if (rng() % 4 == 0) {
+        payload.resize(1 + rng() % 300);
+        for (auto &b : payload) b = static_cast<uint8_t>(rng());
+    } else {
+        payload.assign(g.begin() + sof, g.end());
+        twist(payload, 0);
+        if (payload.size() > 0xfff0) payload.resize(0xfff0);
+    }
+    const size_t where = at[rng() % at.size()];
+    const size_t len = (rng() % 5 == 0) ? rng() % 0x10000 : payload.size() + 2;                   // mostly honest, sometimes not
+    std::vector<uint8_t> ins = {0xff, 0x00, static_cast<uint8_t>(len >> 8), static_cast<uint8_t>(len)};
+    ins.insert(ins.end(), payload.begin(), payload.end());
+    c.insert(c.begin() + where, ins.begin(), ins.end());
+    return c;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) { std::fprintf(stderr, "usage: %s iters file...\n", argv[0]); return 2; }
@@ -52,8 +114,9 @@ int main(int argc, char **argv)
         one(g);
         for (size_t cut = 0; cut < g.size(); cut += (cut < 700 ? 1 : 13)) one(std::vector<uint8_t>(g.begin(), g.begin() + cut));
         for (long it = 0; it < iters; it++) {
-            std::vector<uint8_t> c = g;
-            const int nm = 1 + static_cast<int>(rng() % 4);
+            const bool st = it % 3 == 2;
+            std::vector<uint8_t> c = st ? structured(g, rng) : g;
+            const int nm = st ? static_cast<int>(rng() % 2) : 1 + static_cast<int>(rng() % 4);
             for (int m = 0; m < nm; m++) {
                 const size_t at = 2 + rng() % (c.size() - 2);
                 switch (rng() % 4) {
