@@ -167,10 +167,21 @@ class _RankQueue:
             # CONTRACT: a rank that calls with an id k times must be matched by k calls on every other rank; a rank that
             # retries a batch on its own (an exception mid-job) must mint a NEW id on all ranks, or it would build 'x#2'
             # against the others' 'x#1' and drain that job alone.
-            use = _RankQueue._uses.pop(batch_id, 0) + 1
+            # The count lives in this process (newest _USES_CAP ids) and, once an id falls out of that window, in the job's
+            # store under (id, rank): forgetting it would restart the id at #1 on THIS rank only while ranks that still
+            # remember it build '#k' -- the very collision the count exists to prevent.  Ranks evict
+            # independently; the store copy makes what they evict irrelevant.
+            store0 = dist.PrefixStore("fennec_batch_uses", c10d._get_default_store())
+            rank = dist.get_rank(group)
+            use = _RankQueue._uses.pop(batch_id, None)
+            if use is None:
+                k = f"{batch_id}@r{rank}"
+                use = int(store0.get(k)) if store0.check([k]) else 0
+            use += 1
             _RankQueue._uses[batch_id] = use
-            while len(_RankQueue._uses) > _RankQueue._USES_CAP:     # ids are usually unique per job: forget the oldest
-                _RankQueue._uses.popitem(last=False)
+            while len(_RankQueue._uses) > _RankQueue._USES_CAP:     # ids are usually unique per job: park the oldest in the store
+                old_id, old_use = _RankQueue._uses.popitem(last=False)
+                store0.set(f"{old_id}@r{rank}", str(old_use))
             batch_id = f"{batch_id}#{use}"
         self.key = f"next_{batch_id}"
         self.store = dist.PrefixStore("fennec_batch_queue", c10d._get_default_store())

@@ -183,6 +183,43 @@ def _rank_main_small(rank, world, port, n_items, chunk, out_q):
     dist.destroy_process_group()
 
 
+def _rank_main_evict(rank, world, port, out_q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 0:
+        batch._RankQueue._USES_CAP = 2            # rank 0 forgets ids after two newer ones; rank 1 remembers everything
+    out = []
+    for name in ("A", "B", "C", "D", "A", "A", "B"):      # "A" comes back after rank 0 has evicted it
+        res = batch.compress_batch(9, _fake_work, lambda w: None, workers=2, rank=rank, world=world,
+                                   queue_mode="dynamic", chunk=2, batch_id=name)
+        out.append([r.Index for r in res])
+        dist.barrier()
+    out_q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_batch_id_use_counts_survive_a_rank_forgetting_them():
+    """the per-process window of batch-id use counts (newest 1024) restarted an evicted id at #1 on the rank that had
+    forgotten it while the others built #k -- two jobs' keys for one job.  The evicted count is parked in the store."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main_evict, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for j in range(7):
+        assert sorted(got[0][j] + got[1][j]) == list(range(9)), (j, got[0][j], got[1][j])       # ONE queue per job: every item exactly once
+
+
 @pytest.mark.parametrize("n_items,chunk", [(7, 4), (7, 1), (1, 4), (3, 8)])
 def test_world_size_2_dynamic_queue_uneven_job_with_a_failing_item(orc, n_items, chunk):
     """An uneven job: 7 items over 2 ranks in chunks of 4 (the second chunk is partial), item 3 fails (batch.go:100-106: the
