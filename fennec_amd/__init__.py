@@ -136,6 +136,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ctx_profile", i, [ctx, i])
         _sig(L, "fnx_ctx_kernel_ms", i, [ctx, C.POINTER(C.c_float)])
         _sig(L, "fnx_ctx_last_kernel", C.c_char_p, [ctx, i])
+        _sig(L, "fnx_ctx_set_form", i, [ctx, C.c_char_p, C.c_char_p])
         _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
         _sig(L, "fnx_free", i, [ctx, C.c_void_p])
         _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
@@ -345,6 +346,27 @@ class Context:
         if s is None:
             raise FennecError("fnx_ctx_last_kernel: bad class")
         return s.decode()
+
+    def set_form(self, name: str, value=None) -> None:
+        """fnx_ctx_set_form: which of several kernels that compute the same bytes this ctx takes (tests, A/B timing);
+        value None: the product's own choice again."""
+        v = None if value is None else str(value).encode()
+        self._chk(self._lib.fnx_ctx_set_form(self._h, name.encode(), v), "fnx_ctx_set_form")
+
+    def forms(self, **kw):
+        """`with ctx.forms(fx_stream=0, fx_pairs=1): ...` -- set_form for the block, defaults afterwards"""
+        ctx = self
+
+        class _Forms:
+            def __enter__(self_inner):
+                for k, v in kw.items():
+                    ctx.set_form(k, v)
+
+            def __exit__(self_inner, *exc):
+                for k in kw:
+                    ctx.set_form(k, None)
+                return False
+        return _Forms()
 
     @property
     def stream(self) -> int:

@@ -764,7 +764,7 @@ int launch_analyze_one(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *c
     a.count_part = static_cast<uint32_t *>(cp);
     a.done = nullptr;
 #ifdef FNX_DEVELOP
-    { static const bool stamps = getenv("FNX_AN_STAMPS") != nullptr; if (stamps) a.done = reinterpret_cast<unsigned *>(res); }
+    { static const bool stamps = dev_env("FNX_AN_STAMPS") != nullptr; if (stamps) a.done = reinterpret_cast<unsigned *>(res); }
 #endif
     a.res = res;
     a.var_part = var_part;

@@ -717,7 +717,7 @@ int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t 
     // not wait for them, so one kernel's last workgroups and the next one's first share the chip instead of each
     // launch draining it (three launch boundaries per image, ~5 us each, at 8K).  The partial sums use the tail's
     // own slot: other calls on `stream` may use SLOT_PARTIAL meanwhile.  a and b stay the caller's until the fetch.
-    static const bool same_stream = [] { const char *e = getenv("FNX_SSIM_ENQUEUE_INLINE"); return e && e[0] == '1'; }();
+    static const bool same_stream = [] { const char *e = dev_env("FNX_SSIM_ENQUEUE_INLINE"); return e && e[0] == '1'; }();
     if (same_stream) {
         FNX_TRY(launch_windowed_ssim(ctx, 1, a, astride, 0, b, bstride, 0, w, h, window, static_cast<const double *>(dwin), dres));
         return publish_results(ctx, dres, 1);
@@ -1434,7 +1434,7 @@ void fnx_prepared_free(fnx_ctx *ctx, fnx_prepared *p)
 // after them; this thread watches the words (FNX_ANALYZE_STAGED=1: the staged launches of rounds 1-4, A/B and tests).
 static bool analyze_staged()
 {
-    static const bool v = [] { const char *e = getenv("FNX_ANALYZE_STAGED"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char *e = dev_env("FNX_ANALYZE_STAGED"); return e && e[0] == '1'; }();
     return v;
 }
 

@@ -972,7 +972,7 @@ int launch_blur_scored(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstr
     }
     const bool tall_pref = wide ? false : direct_tall(ctx, radius, n, w, h);
     // the matrix-pipe kernel (blur_mfma.hip) where its table and its box geometry fit; its tile is 64 px x seg rows
-    static const int wide_cap = [] { const char *e = getenv("FNX_MFMA_WIDE_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
+    static const int wide_cap = [] { const char *e = dev_env("FNX_MFMA_WIDE_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
     const int seg = wide ? blur_mfma_segment(ctx, n, w, h, wide_cap, 2)
                          : (blur_mfma_covers(kernel, radius, w, h) && (!exact || blur_mfma_exact_enabled()) ? blur_mfma_segment(ctx, n, w, h, 272, 3) : 0);
     ScoreGeom &g = ctx->score_geom;

@@ -962,20 +962,20 @@ static void mfma_build_table(const MfmaWeights &q, int radius, uint32_t *tab)
 // 4K plain 18.7 us against 23.8, one-pass 26.4 against 29.2 per image
 bool blur_mfma_exact_enabled()
 {
-    static const bool on = [] { const char *e = getenv("FNX_BLUR_MFMA_EXACT"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = dev_env("FNX_BLUR_MFMA_EXACT"); return !(e && e[0] == '0'); }();
     return on;
 }
 
 bool blur_mfma_covers(const double *kernel, int radius, int w, int h)
 {
-    static const bool off = [] { const char *e = getenv("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char *e = dev_env("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
     if (off || w < 64 || h < 32) return false;
     MfmaWeights q;
     return mfma_quantise(kernel, radius, &q);
 }
 static bool blur_mfma_wide_covers(const double *kernel, int radius, int w, int h)
 {
-    static const bool off = [] { const char *e = getenv("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char *e = dev_env("FNX_BLUR_MFMA"); return e && e[0] == '0'; }();
     if (off || w < 64 || h < 32 || radius <= MF_RMAX) return false;
     MfmaWeights q;
     return mfma_quantise(kernel, radius, &q, MF_RWIDE);
@@ -1041,7 +1041,7 @@ static int mfma_prepare(fnx_ctx *ctx, const double *kernel, int radius, bool exa
     FNX_TRY(upload_table(ctx, SLOT_TABLE_MFMA, tab, sizeof(tab), &dt));
     ma->tab = static_cast<const uint32_t *>(dt);
 #ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): bits 1 / 2 / 4 skip the box sums -- wrong scores
-    { static const int dbg = [] { const char *e = getenv("FNX_MFMA_DBG"); return e ? atoi(e) : 0; }(); ma->dbg = dbg; }
+    { static const int dbg = [] { const char *e = dev_env("FNX_MFMA_DBG"); return e ? atoi(e) : 0; }(); ma->dbg = dbg; }
 #else
     ma->dbg = 0;
 #endif
@@ -1145,7 +1145,7 @@ int launch_blur_mfma(fnx_ctx *ctx, int n, const uint8_t *src, const uint8_t *con
     if (st != FNX_OK) return st;
     ma.src = src; ma.srcs = srcs; ma.dst = dst; ma.dsts = dsts;
     ma.sstride = sstride; ma.dstride = dstride; ma.w = w; ma.h = h;
-    static const int cap = [] { const char *e = getenv("FNX_MFMA_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
+    static const int cap = [] { const char *e = dev_env("FNX_MFMA_SEG"); return e ? atoi(e) : 544; }();   // development: rows per workgroup
     ma.seg = blur_mfma_segment(ctx, n, w, h, cap, exact ? 3 : 4);
     return exact ? launch_mfma_cfg<false, true>(ctx, n, ma, 0) : launch_mfma_cfg<false, false>(ctx, n, ma, 0);
 }

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -13,6 +14,36 @@
 namespace fnx {
 
 void set_error(const char *fmt, ...);
+
+// ---- what steers the library from outside (r6: VERDICT r5 item 7) ------------------------------------------------------
+// A release build reads FIVE environment names, each once, all listed in include/fennec_hip.h: FENNEC_HIP_DISABLE,
+// FENNEC_HIP_DEVICES (runtime.cpp: which devices), FNX_ROCTX, FNX_POOL_TRACE, FNX_JPEG_TRACE (tracing; no effect on results
+// or on which kernel runs).  Everything else:
+//   * kernel FORMS the tests must be able to reach on any image (a fallback kernel that the product only takes for rare
+//     tables, the two-pass twin of a fused launch ...) are a per-ctx selection, fnx_ctx_set_form (Form below) -- explicit,
+//     per context, no process-wide state;
+//   * development switches (tile sizes, priorities, thresholds, A/B of two correct kernels) exist in `make DEVELOP=1`
+//     builds only: dev_env() is getenv there and a constant nullptr in a release build, so the compiler drops the branch.
+#ifdef FNX_DEVELOP
+inline const char *dev_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *dev_env(const char *) { return nullptr; }
+#endif
+
+enum Form {
+    FORM_FX_STREAM = 0,      // "fx_stream":       "0" = effects.hip's tile kernel instead of the streaming one
+    FORM_FX_PAIRS,           // "fx_pairs":        "0" = the tile kernel's one-row form
+    FORM_FX_REF,             // "fx_ref":          "1" = the fp64 reference-order kernel (what tables outside the guard take)
+    FORM_RESIZE_MFMA,        // "resize_mfma":     "0" never / "1" downscales (default) / "2" wherever the tables allow; read when a plan is built
+    FORM_RESIZE_FP64,        // "resize_fp64":     "1" = the fp64 reference-order resize kernels (what tables outside the guard take)
+    FORM_RESIZE_FUSED,       // "resize_fused":    "0" = the two-pass kernels (what windows wider than the fused tile take)
+    FORM_MSSSIM_LEVELWISE,   // "msssim_levelwise":"1" = one SSIMFast + one halving per level
+    FORM_MSSSIM_NOFUSE0,     // "msssim_nofuse0":  "1" = level 0's boxes and halving as two reads
+    FORM_MSSSIM_FOLD,        // "msssim_fold":     "0" = a finish launch instead of the fold in the window kernel
+    FORM_MSSSIM_BOXFLY,      // "msssim_boxfly":   "1" = levels 1..4's boxes taken on the fly
+    FORM_PALETTE_GRID,       // "palette_grid":    "0" every image walks the whole palette / "1" every image takes the grid
+    FORM_COUNT
+};
 
 #define FNX_HIP(expr)                                                                      \
     do {                                                                                   \
@@ -185,6 +216,8 @@ struct fnx_ctx {
     // fnx_ctx_last_kernel: the kernel the last call of each class really launched (static strings), so that a report can
     // name the route the library took instead of inferring it from environment switches
     const char *route[8] = {"", "", "", "", "", "", "", ""};
+    // fnx_ctx_set_form: the kernel forms this ctx was told to take ("" = the product's own choice)
+    char form[fnx::FORM_COUNT][8] = {};
     // analyze.hip's single-launch form: which colour table the next call uses, and how many tables of each are not zero
     int an_cur = 0;
     int an_dirty[2] = {0, 0};
@@ -199,6 +232,10 @@ struct fnx_prepared {
 namespace fnx {
 
 int bind(fnx_ctx *ctx);
+// the ctx's selection for a kernel form (fnx_ctx_set_form), else -- DEVELOP builds only -- the environment variable of the
+// same name (FNX_ + upper case: the A/B scripts under tools/ and experiments/), else nullptr: the product's own choice
+const char *form_value(const fnx_ctx *ctx, Form f);
+int form_set(fnx_ctx *ctx, const char *name, const char *value);
 // roctx range around an exported op (runtime.cpp: FNX_ROCTX=1 turns them on; off they cost a load and a branch)
 class OpRange {
 public:
@@ -337,7 +374,7 @@ struct RzMfTable {
     const int32_t *meta = nullptr, *sbase = nullptr;
     const void *ex = nullptr;      // per output: the operands of the fp64 fix-ups
 };
-bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double *inv, RzMfTable *out);
+bool resize_mfma_build(const fnx_ctx *ctx, const TapTable &t, int srcN, bool vertical, const double *inv, RzMfTable *out);
 void resize_mfma_free(RzMfTable *t);
 // Launches the matrix kernel; regions it gives up are marked todo[tile] = gen for resize_fused_kernel's tiles
 // (old_tw x old_th output px, old_gx per row), which the caller launches next.

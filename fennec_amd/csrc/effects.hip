@@ -697,7 +697,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     a.src = src; a.dst = dst; a.sstride = sstride; a.dstride = dstride; a.w = w; a.h = h; a.amount = amount;
     a.vec_ok = aligned16(src, sstride) ? 1 : 0;
     bool march = true;
-    const char *force_ref = getenv("FNX_FX_REF");                // A/B and tests: "1" takes the fp64 reference-order kernel
+    const char *force_ref = form_value(ctx, FORM_FX_REF);                // A/B and tests: "1" takes the fp64 reference-order kernel
     if (MODE != FX_BLUR3) {
         int32_t tab[512];
         bool ties = false;
@@ -712,7 +712,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
                 float t32 = static_cast<float>(thr);
                 if (static_cast<double>(t32) > thr) t32 = std::nextafterf(t32, 0.0f);
                 a.flag_thr = t32;
-                const char *pe = getenv("FNX_FX_PAIRS");          // tile kernel, A/B and tests: "0" takes the one-row form
+                const char *pe = form_value(ctx, FORM_FX_PAIRS);          // tile kernel, A/B and tests: "0" takes the one-row form
                 a.pairs = pe ? atoi(pe) : 1;
             }
             a.amt32 = static_cast<float>(amount);
@@ -729,7 +729,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     // the tile kernels address the destination with 32-bit offsets
     if (static_cast<long long>(h) * dstride >= (1ll << 31)) march = false;
     FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
-    const char *stream_env = getenv("FNX_FX_STREAM");            // A/B and tests: "0" takes the tile kernel
+    const char *stream_env = form_value(ctx, FORM_FX_STREAM);            // A/B and tests: "0" takes the tile kernel
     const int stream_on = stream_env ? atoi(stream_env) : 1;
     if (march && stream_on && w < 65536 && h < 65536 && static_cast<long long>(h) * sstride < (1ll << 31)) {
         // one wave per (strip, segment); segments sized so that the launch is one round of resident waves
@@ -738,7 +738,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fx_stream_kernel<MODE>, 256, 0) != hipSuccess || nb < 1) nb = 4;
             return nb;
         }();
-        static const int rounds = [] { const char *e = getenv("FNX_FX_ROUNDS"); return e ? atoi(e) : 1; }();
+        static const int rounds = [] { const char *e = dev_env("FNX_FX_ROUNDS"); return e ? atoi(e) : 1; }();
         a.strips = (w + FXS_COLS - 1) / FXS_COLS;
         const long capacity = static_cast<long>(ctx->num_cus) * per_cu * 4 * rounds;
         int segs = static_cast<int>(capacity / a.strips);
@@ -751,7 +751,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     } else if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
         // FNX_FX_LDS_PAD=<bytes> of unused dynamic LDS: an A/B knob for workgroups per CU (8192 -> 4 instead of 5)
-        static const unsigned pad = [] { const char *e = getenv("FNX_FX_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+        static const unsigned pad = [] { const char *e = dev_env("FNX_FX_LDS_PAD"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
         hipLaunchKernelGGL((fx_march_kernel<MODE>), grid, dim3(256), pad, ctx->stream, a);
     } else {
         dim3 grid((w + FXR_TW - 1) / FXR_TW, (h + FXR_TH - 1) / FXR_TH);

@@ -251,11 +251,11 @@ __global__ __launch_bounds__(256) void apply_palette_grid_kernel(PalGridApply ga
     }
 }
 
-// FNX_PALETTE_GRID=0: every image walks the whole palette (A/B, tests); =1: every image takes the grid
-static int palette_grid_mode()
+// form "palette_grid" = "0": every image walks the whole palette (A/B, tests); "1": every image takes the grid
+static int palette_grid_mode(const fnx_ctx *ctx)
 {
-    static const int v = [] { const char *e = getenv("FNX_PALETTE_GRID"); return e ? atoi(e) : -1; }();
-    return v;
+    const char *e = form_value(ctx, FORM_PALETTE_GRID);
+    return e ? atoi(e) : -1;
 }
 
 // palette: n x 4 bytes r,g,b,a on the host (a must be 255: checked by the caller)
@@ -263,7 +263,7 @@ int launch_apply_palette(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, i
                          uint8_t *idx, int istride, uint8_t *quant, int qstride)
 {
     if (w <= 0 || h <= 0) return FNX_OK;
-    const int mode = palette_grid_mode();
+    const int mode = palette_grid_mode(ctx);
     if (mode == 1 || (mode != 0 && static_cast<long>(w) * h >= 262144L)) {
         std::vector<uint32_t> tab(256 + 512, 0u);                        // rgb[256] | pairs[256][2]
         for (int i = 0; i < 256; i++) {

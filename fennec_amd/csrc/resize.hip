@@ -1868,9 +1868,9 @@ void free_resize_plans(fnx_ctx *ctx)
     ctx->rz_last_gen = 0;
 }
 
-static bool resize_guard_disabled()
+static bool resize_guard_disabled(const fnx_ctx *ctx)
 {
-    const char *e = getenv("FNX_RESIZE_FP64");      // A/B and tests: "1" keeps the round-1 fp64 kernels
+    const char *e = form_value(ctx, FORM_RESIZE_FP64);      // A/B and tests: "1" keeps the round-1 fp64 kernels
     return e && e[0] == '1';
 }
 
@@ -2158,7 +2158,7 @@ static int get_resize_plan(fnx_ctx *ctx, const TapTable &t, int srcN, bool verti
     p->d_aw = reinterpret_cast<const double *>(base + o_aw);
     p->d_inv = reinterpret_cast<const double *>(base + o_inv);
     p->d_odd = base + o_odd;
-    if (p->guard_ok) (void)resize_mfma_build(t, srcN, vertical, invv.data(), &p->mf);
+    if (p->guard_ok) (void)resize_mfma_build(ctx, t, srcN, vertical, invv.data(), &p->mf);
     p->last_use = tick++;
     *out = p.get();
     ctx->rplans.push_back(p.release());
@@ -2179,9 +2179,9 @@ static void launch_h_guard(fnx_ctx *ctx, const ResizeGuardArgs &ga, dim3 grid)
 int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
                  uint8_t *dst, int dstride)
 {
-    const char *fe = getenv("FNX_RESIZE_FUSED");                     // "0": A/B and tests (the two-pass kernels)
+    const char *fe = form_value(ctx, FORM_RESIZE_FUSED);                     // "0": A/B and tests (the two-pass kernels)
     const bool off = (fe && fe[0] == '0') || (fe && fe[0] == '2' && th.nout < srcW);   // "2": upscales only (experiments)
-    if (off || resize_guard_disabled() || th.nout <= 0 || tv.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_NOOP;
+    if (off || resize_guard_disabled(ctx) || th.nout <= 0 || tv.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_NOOP;
     fnx_resize_plan *ph = nullptr, *pv = nullptr;
     FNX_TRY(get_resize_plan(ctx, th, srcW, false, &ph));
     FNX_TRY(get_resize_plan(ctx, tv, srcH, true, &pv));
@@ -2201,7 +2201,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     // workgroups is (810 workgroups on 768 slots take two rounds, 675 one): among the counts from what the tile holds
     // down to half of it (more groups = less row halo in phase 1), the one whose rounds are fullest.
     const int gx = (ph->ngroups + 63) / 64;
-    static const bool no32 = [] { const char *e = getenv("FNX_RF_NO32"); return e && e[0] == '1'; }();   // experiments
+    static const bool no32 = [] { const char *e = dev_env("FNX_RF_NO32"); return e && e[0] == '1'; }();   // experiments
     const bool low = !no32 && ph->NV <= 2 && pv->fused_ng32 >= 8;
     const int ngmax = low ? pv->fused_ng32 : pv->fused_ng;
     int ng = ngmax;
@@ -2214,7 +2214,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             if (fill > best + 0.02) { best = fill; ng = cand; }
         }
     }
-    if (const char *e = getenv("FNX_RF_NG")) ng = std::max(1, std::min(ngmax, atoi(e)));   // experiments
+    if (const char *e = dev_env("FNX_RF_NG")) ng = std::max(1, std::min(ngmax, atoi(e)));   // experiments
     fa.ng = ng;
     const dim3 grid(gx, (pv->ngroups + ng - 1) / ng);
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
@@ -2222,7 +2222,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     // or tie-dense regions).  When it gave up most of an image -- the count comes back through host-mapped memory, read
     // here one call later -- the next 64 .. 4096 calls with this H plan skip it: a heuristic about cost, both kernels are exact.
     bool use_mf = ph->mf.ok && pv->mf.ok;
-    static const bool adapt = [] { const char *e = getenv("FNX_RM_ADAPT"); return !(e && e[0] == '0'); }();
+    static const bool adapt = [] { const char *e = dev_env("FNX_RM_ADAPT"); return !(e && e[0] == '0'); }();
     if (use_mf && adapt && ctx->rz_report && ctx->rz_last_gen != 0) {
         const unsigned long long repv = *reinterpret_cast<volatile unsigned long long *>(ctx->rz_report);
         if (static_cast<uint32_t>(repv >> 32) == ctx->rz_last_gen) {
@@ -2236,7 +2236,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     }
     // in the cool-down the plan's recent images were tie-dense (or translucent): the form without the fp32 passes (NV = 4: the
     // 2:1 downscales whose exact loops have the straight-line forms)
-    static const bool dense_off = [] { const char *e = getenv("FNX_RF_DENSE"); return e && e[0] == '0'; }();   // A/B and tests
+    static const bool dense_off = [] { const char *e = dev_env("FNX_RF_DENSE"); return e && e[0] == '0'; }();   // A/B and tests
     // (from the second cool-down in a row on -- mf_cool_len doubles each time the matrix kernel's retry comes back dense again --,
     // so that one synthetic image in a stream of photographs does not send the next 64 of them through fp64 loops)
     const bool dense_form = use_mf && ph->mf_cool > 0 && ph->mf_cool_len >= 128 && !low && ph->NV == 4 && !dense_off;
@@ -2282,7 +2282,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         ctx->rz_last_cells = static_cast<size_t>(mf_wgs);
         ctx->rz_last_h = ph;
 #ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): "2" stops before the handed-back tiles are redone
-        static const char *const rm_stats = getenv("FNX_RM_STATS");
+        static const char *const rm_stats = dev_env("FNX_RM_STATS");
         if (const char *e = rm_stats) {                              // how many tiles came back
             std::vector<uint32_t> cells_h(cells);
             FNX_HIP(hipStreamSynchronize(ctx->stream));
@@ -2308,7 +2308,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         FNX_HIP(hipGetLastError());
         return prof_end(ctx);
     }
-    static const bool d21_off = [] { const char *e = getenv("FNX_RF_DENSE21"); return e && e[0] == '0'; }();   // A/B and tests
+    static const bool d21_off = [] { const char *e = dev_env("FNX_RF_DENSE21"); return e && e[0] == '0'; }();   // A/B and tests
     if (dense_form && ph->d21_ok && pv->d21_ok && srcW >= 20 && !d21_off && !ph->d21_heavy && ctx->rz_report && (pv->d21_fit & 2u)) {
         // V groups per tile: the count whose busiest CU has least to do.  A CU's workgroups share its SIMDs, so its time goes
         // with (workgroups on it) x (instructions of a workgroup's longest wave: ~534 per pair of tmp rows, ~1100 per V group)
@@ -2321,7 +2321,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             const double cost = std::ceil(wgs / ctx->num_cus) * (534.0 * pairs + 1100.0 * ((cand + 3) / 4));
             if (best == 0 || cost < best) { best = cost; ng21 = cand; }
         }
-        if (const char *e = getenv("FNX_RF_NG21")) {                 // experiments
+        if (const char *e = dev_env("FNX_RF_NG21")) {                 // experiments
             const int want = atoi(e);
             if (want >= 1 && want <= D21_NGMAX && (pv->d21_fit >> want & 1u)) ng21 = want;
         }
@@ -2374,7 +2374,7 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
     FNX_TRY(get_resize_plan(ctx, t, vertical ? srcH : srcW, vertical, &p));
     const int other = vertical ? srcW : srcH;
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
-    if (p->guard_ok && !resize_guard_disabled() && (!vertical || other >= RG_VPX)) {
+    if (p->guard_ok && !resize_guard_disabled(ctx) && (!vertical || other >= RG_VPX)) {
         ResizeGuardArgs ga{};
         ga.src = src; ga.dst = dst; ga.sstride = sstride; ga.dstride = dstride;
         ga.srcN = vertical ? srcH : srcW; ga.nout = t.nout; ga.other = other;
@@ -2397,7 +2397,7 @@ int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *s
             int rows = 16;
             const int gx = (p->ngroups + 63) / 64;
             while (rows > 2 && static_cast<long>(gx) * ((other + 4 * rows - 1) / (4 * rows)) < 2L * ctx->num_cus) rows >>= 1;
-            if (const char *e = getenv("FNX_RH_ROWS")) rows = std::max(1, std::min(16, atoi(e)));   // experiments
+            if (const char *e = dev_env("FNX_RH_ROWS")) rows = std::max(1, std::min(16, atoi(e)));   // experiments
             ga.rows = rows;
             const dim3 grid(gx, (other + 4 * rows - 1) / (4 * rows));
             if (hint) {

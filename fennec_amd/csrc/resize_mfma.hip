@@ -435,9 +435,9 @@ static void rm_digits(long long v, int d[3])
 }
 
 // 0: never, 1: downscales (the default), 2: wherever the tables allow
-static int resize_mfma_mode()
+static int resize_mfma_mode(const fnx_ctx *ctx)
 {
-    const char *e = getenv("FNX_RESIZE_MFMA");
+    const char *e = form_value(ctx, FORM_RESIZE_MFMA);
     return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
 }
 
@@ -449,10 +449,10 @@ void resize_mfma_free(RzMfTable *t)
 
 // The matrix form of one tap table; false (nothing allocated): outside what the kernel covers.
 // `inv`: 1 / a per output as the guard form computed it (resize.hip: build_guard, a = sum of 255 w in tap order).
-bool resize_mfma_build(const TapTable &t, int srcN, bool vertical, const double *inv, RzMfTable *out)
+bool resize_mfma_build(const fnx_ctx *ctx, const TapTable &t, int srcN, bool vertical, const double *inv, RzMfTable *out)
 {
     *out = RzMfTable();
-    const int mode = resize_mfma_mode();
+    const int mode = resize_mfma_mode(ctx);
     const int nout = t.nout;
     if (mode == 0 || nout < 16 || srcN < 16) return false;
     if (mode == 1 && 4 * srcN < 5 * nout) return false;              // (the header's last paragraph)
@@ -670,7 +670,7 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
             if (cand == 1 || cost < best * 0.98) { best = cost; segj = cand; }
         }
     }
-    if (const char *e = getenv("FNX_RM_SEG")) segj = std::max(1, std::min(RM_MAXJ, atoi(e)));   // experiments
+    if (const char *e = dev_env("FNX_RM_SEG")) segj = std::max(1, std::min(RM_MAXJ, atoi(e)));   // experiments
     a.segj = segj;
     a.tiles = a.tiles_x * ((a.nvg + segj - 1) / segj);
     const size_t lds = static_cast<size_t>(lds_of(segj));
@@ -683,7 +683,7 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
     a.sh_h = h.S - 16; a.sh_v = v.S - 16;
     a.exh = static_cast<const RmEx *>(h.ex); a.exv = static_cast<const RmEx *>(v.ex);
 #ifdef FNX_DEVELOP                     // a development build only (make DEVELOP=1): no fix-ups, results may be off by one
-    { static const bool nofix = getenv("FNX_RM_NOFIX") != nullptr; if (nofix) a.thr_h = a.thr_v = 0; }
+    { static const bool nofix = dev_env("FNX_RM_NOFIX") != nullptr; if (nofix) a.thr_h = a.thr_v = 0; }
 #endif
     a.todo = todo; a.gave_up = gave_up; a.gen = gen; a.old_tw = old_tw; a.old_th = old_th; a.old_gx = old_gx;
     const dim3 grid(8 * ((a.tiles + 7) / 8));

@@ -98,6 +98,36 @@ OpRange::~OpRange()
     if (on_) g_roctx_pop();
 }
 
+static const char *const FORM_NAMES[FORM_COUNT] = {"fx_stream", "fx_pairs", "fx_ref", "resize_mfma", "resize_fp64", "resize_fused",
+                                                   "msssim_levelwise", "msssim_nofuse0", "msssim_fold", "msssim_boxfly", "palette_grid"};
+
+const char *form_value(const fnx_ctx *ctx, Form f)
+{
+    if (ctx && ctx->form[f][0]) return ctx->form[f];
+#ifdef FNX_DEVELOP
+    char name[40] = "FNX_";
+    size_t k = 4;
+    for (const char *p = FORM_NAMES[f]; *p && k + 1 < sizeof(name); p++) name[k++] = static_cast<char>(*p >= 'a' && *p <= 'z' ? *p - 32 : *p);
+    name[k] = 0;
+    return std::getenv(name);
+#else
+    return nullptr;
+#endif
+}
+
+int form_set(fnx_ctx *ctx, const char *name, const char *value)
+{
+    for (int f = 0; f < FORM_COUNT; f++) {
+        if (std::strcmp(name, FORM_NAMES[f]) != 0) continue;
+        if (value && std::strlen(value) >= sizeof(ctx->form[f])) { set_error("fnx_ctx_set_form: value too long"); return FNX_ERR_INVALID; }
+        std::memset(ctx->form[f], 0, sizeof(ctx->form[f]));
+        if (value) std::strcpy(ctx->form[f], value);
+        return FNX_OK;
+    }
+    set_error("fnx_ctx_set_form: no kernel form called '%s'", name);
+    return FNX_ERR_INVALID;
+}
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)
@@ -423,7 +453,7 @@ int fnx_ctx_create(int device, fnx_ctx **out)
         // the tail stream.  FNX_TAIL_PRIO=low|high moves it to the end of the device's priority range (experiments)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const char *pe = getenv("FNX_TAIL_PRIO");
+        const char *pe = dev_env("FNX_TAIL_PRIO");
         int prio = (least + greatest) / 2;
         if (pe && pe[0] == 'l') prio = least;
         if (pe && pe[0] == 'h') prio = greatest;
@@ -488,6 +518,12 @@ int fnx_ctx_profile(fnx_ctx *ctx, int enable)
     ctx->prof_head = ctx->prof_count = 0;      // (re-)enabling forgets unread launches
     ctx->prof_open = -1;
     return FNX_OK;
+}
+
+int fnx_ctx_set_form(fnx_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx || !name) { fnx::set_error("fnx_ctx_set_form: null argument"); return FNX_ERR_INVALID; }
+    return fnx::form_set(ctx, name, value);
 }
 
 const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class)

@@ -319,7 +319,7 @@ int launch_box_downsample_ycc(fnx_ctx *ctx, const uint8_t *y, int ystride, const
                               int ratio, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH, bool *done)
 {
     *done = false;
-    static const bool off = [] { const char *e = getenv("FNX_BOX_YCC"); return e && e[0] == '0'; }();   // A/B and tests
+    static const bool off = [] { const char *e = dev_env("FNX_BOX_YCC"); return e && e[0] == '0'; }();   // A/B and tests
     if (off || !cb || !cr || ratio < 0 || ratio > 5 || srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_OK;
     static const int xs[6] = {0, 1, 1, 0, 2, 2}, ys[6] = {0, 0, 1, 1, 0, 1};
     BoxYccArgs ya{};
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial,
 // FNX_SSIM_TILED=1 keeps the tile kernels (A/B measurements); default: the marching kernel
 static bool ssim_use_tiled()
 {
-    static const bool v = [] { const char *e = getenv("FNX_SSIM_TILED"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char *e = dev_env("FNX_SSIM_TILED"); return e && e[0] == '1'; }();
     return v;
 }
 
@@ -1365,7 +1365,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     // the marching kernel needs long column segments to pay for its serial row walk (~0.45 us per row per
     // wave): single small planes (one SSIMFast, the MSSSIM levels) keep the tile kernels, 2-5 us a launch
     // against ~19.  FNX_SSIM_MARCH_MIN overrides the window count from which it takes over (experiments).
-    static const long march_min = [] { const char *e = getenv("FNX_SSIM_MARCH_MIN"); return e ? atol(e) : 1500000L; }();
+    static const long march_min = [] { const char *e = dev_env("FNX_SSIM_MARCH_MIN"); return e ? atol(e) : 1500000L; }();
     const bool march = sep && !ssim_use_tiled() && static_cast<long>(ww) * wh * n >= march_min;
     // tile kernels (FNX_SSIM_TILED=1, and the 64-tap kernel for tables that are not rank-1)
     const bool big = sep && static_cast<long>(ww) * wh * n >= 4L * 1024 * ctx->num_cus;
@@ -1373,7 +1373,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
     int tiles_x = 0, tiles = 0;
     MarchArgs ma{};
     // the two-column form (2 waves per SIMD) once ONE image has a round of such waves to fill the chip with
-    static const long march2_min = [] { const char *e = getenv("FNX_SSIM_MARCH2_MIN"); return e ? atol(e) : 4000000L; }();
+    static const long march2_min = [] { const char *e = dev_env("FNX_SSIM_MARCH2_MIN"); return e ? atol(e) : 4000000L; }();
     // (per image: a batch of small planes -- the one-pass tail under the next blur -- keeps the one-column form, whose
     // 104-VGPR waves fit into the gaps the blur's workgroups leave; 202-VGPR waves wait for two of them to retire)
     const bool march2 = march && static_cast<long>(ww) * wh >= march2_min;
@@ -1383,7 +1383,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         // rows (row halo (S + 7) / S <= 1.22)
         const int cols = march2 ? WM2_COLS : WM_COLS;
         ma.strips = (ww + cols - 1) / cols;
-        static const long m2_per_cu = [] { const char *e = getenv("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 8L; }();   // experiments
+        static const long m2_per_cu = [] { const char *e = dev_env("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 8L; }();   // experiments
         const long target = (march2 ? m2_per_cu : 16L) * ctx->num_cus;
         long segs = target / (static_cast<long>(n) * ma.strips);
         const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
@@ -1419,7 +1419,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         for (int i = 0; i < 8; i++) { ma.col[i] = sa.col[i]; ma.row[i] = sa.row[i]; }
         // the image's last workgroup takes the mean itself (no finish launch).  Counters: 2 x 4096, one half per
         // stream the ctx launches on (a scored tail on the second stream may run beside a call on the first)
-        static const bool nofold = [] { const char *e = getenv("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
+        static const bool nofold = [] { const char *e = dev_env("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
         if (!defer && !nofold && n <= 4096) {
             unsigned *dn = nullptr;
             FNX_TRY(ssim_done_counters(ctx, &dn));
@@ -1428,7 +1428,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
             ma.count = have ? static_cast<double>(ww) * static_cast<double>(wh) : 0.0;
             folded = true;
         }
-        static const int prio = [] { const char *e = getenv("FNX_SSIM_PRIO"); return e ? atoi(e) : 1; }();
+        static const int prio = [] { const char *e = dev_env("FNX_SSIM_PRIO"); return e ? atoi(e) : 1; }();
         ma.prio = prio;
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
         note_route(ctx, FNX_PROF_SSIM, march2 ? "windowed_ssim_march2_kernel" : "windowed_ssim_march_kernel");
@@ -1441,7 +1441,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
-        static const bool nofold = [] { const char *e = getenv("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
+        static const bool nofold = [] { const char *e = dev_env("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
         if (!big && !defer && !nofold && n <= 4096) {
             unsigned *dn = nullptr;
             FNX_TRY(ssim_done_counters(ctx, &dn));
@@ -1682,7 +1682,7 @@ static bool fast_dims(int w, int h, int *nw, int *nh)
 int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                         int nweights, const double *h_window, double *d_out, int *nlev)
 {
-    const char *lvw = getenv("FNX_MSSSIM_LEVELWISE");             // "1": A/B and tests
+    const char *lvw = form_value(ctx, FORM_MSSSIM_LEVELWISE);             // "1": A/B and tests
     if ((lvw && lvw[0] == '1') || nweights < 1 || nweights > WS_MAXJOBS) return FNX_NOOP;
     WinSepArgs proto{};
     if (!window_rank1(h_window, proto.col, proto.row)) return FNX_NOOP;
@@ -1737,7 +1737,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
     bool fuse0 = false;
     BoxHalveArgs bh{};
     if (nl > 0 && down[0]) {
-        const char *nf = getenv("FNX_MSSSIM_NOFUSE0");            // "1": A/B and tests (two reads of level 0, as in round 2)
+        const char *nf = form_value(ctx, FORM_MSSSIM_NOFUSE0);            // "1": A/B and tests (two reads of level 0, as in round 2)
         const bool nofuse = nf && nf[0] == '1';
         BoxArgs &ba = bh.b;
         ba.xRatio = static_cast<double>(lw[0]) / static_cast<double>(pw[0]);      // ssim.go:251-252
@@ -1796,7 +1796,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         // by the window kernel's tile load itself -- no plane is written, no launch has to finish first
         {
             const double xr = static_cast<double>(lw[i]) / static_cast<double>(pw[i]), yr = static_cast<double>(lh[i]) / static_cast<double>(ph[i]);
-            const char *nb_env = getenv("FNX_MSSSIM_BOXFLY");        // "1": on.  Off by default: one launch fewer and 5 us off a single
+            const char *nb_env = form_value(ctx, FORM_MSSSIM_BOXFLY);        // "1": on.  Off by default: one launch fewer and 5 us off a single
                                                                      // 4K call, but the window kernel then finishes every staged pixel's
                                                                      // box 1.75 times over (tile halos) and config 3's four streams
                                                                      // measured 68 k MP/s against 72 k
@@ -1859,7 +1859,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
     // FNX_MSSSIM_FOLD=1: each level's last workgroup takes the level's mean itself instead of the separate finish launch.
     // Off by default: the write-through stores and counters cost what the launch costs (a single 4K call 75 us against
     // 71, config 3 the same within its noise); kept, with its test, as the measured alternative.
-    const char *nf_env = getenv("FNX_MSSSIM_FOLD");
+    const char *nf_env = form_value(ctx, FORM_MSSSIM_FOLD);
     const bool fold = nf_env && nf_env[0] == '1';
     if (fold) {
         unsigned *dn = nullptr;

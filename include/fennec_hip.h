@@ -38,6 +38,16 @@
  *     untouched); negative = error, text via fnx_last_error().  There is NO
  *     CPU fallback inside this library: without a usable GPU every op fails
  *     with FNX_ERR_NO_DEVICE.
+ *   - Environment: a release build reads exactly these names, each once --
+ *       FENNEC_HIP_DISABLE=1    no device is used (fnx_device_count() == 0)
+ *       FENNEC_HIP_DEVICES=0,2  which HIP devices, in which order
+ *       FNX_ROCTX=1             a roctx range per exported call (tracing)
+ *       FNX_POOL_TRACE=1        per-item wall times of the C++ batch pools on stderr
+ *       FNX_JPEG_TRACE=1        the device decoder's pass counts on stderr
+ *     None of them changes a result or the kernel a call takes.  Which kernel
+ *     FORM a ctx takes where several compute the same bytes is a per-ctx
+ *     selection (fnx_ctx_set_form); development switches exist only in
+ *     `make DEVELOP=1` builds.
  */
 #ifndef FENNEC_HIP_H
 #define FENNEC_HIP_H
@@ -138,6 +148,19 @@ int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
  * argument): which of the routes the dispatch took (matrix pipe, direct, generic; fused, two-pass ...).  Reporting
  * only: bench.py names its roofline kernel with it.  No reference counterpart. */
 const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class);
+/* Kernel-form selection of ONE ctx, for tests and A/B timing: every form computes the same bytes as the default, the
+ * selection only says which kernel does it, so that a fallback the product takes for rare tables (the fp64
+ * reference-order kernels, the two-pass twin of a fused launch ...) can be run on any image and compared.  name / value:
+ *   "fx_stream" "0"        effects.hip's tile kernel instead of the streaming kernel
+ *   "fx_pairs" "0"         the tile kernel's one-row form
+ *   "fx_ref" "1"           the fp64 reference-order effects kernel
+ *   "resize_mfma" "0|1|2"  matrix-pipe resize never / downscales (default) / wherever the tables allow (read when a plan is built)
+ *   "resize_fp64" "1"      the fp64 reference-order resize kernels
+ *   "resize_fused" "0"     the two-pass resize kernels
+ *   "msssim_levelwise" "1", "msssim_nofuse0" "1", "msssim_fold" "0", "msssim_boxfly" "1"   MSSSIM's launch structure
+ *   "palette_grid" "0|1"   applyPalette: whole-palette walk for every image / the candidate grid for every image
+ * value NULL: back to the default.  Unknown name or a value longer than 7 characters: FNX_ERR_INVALID.  No reference counterpart. */
+int fnx_ctx_set_form(fnx_ctx *ctx, const char *name, const char *value);
 
 /* Device memory on the ctx's device (for FNX_DEVICE callers). */
 int fnx_malloc(fnx_ctx *ctx, size_t bytes, void **dptr);

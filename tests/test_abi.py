@@ -55,6 +55,37 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in text.replace("no CPU", ""), os.path.join(dirpath, f)
 
 
+RELEASE_ENV = {"FENNEC_HIP_DISABLE", "FENNEC_HIP_DEVICES", "FNX_ROCTX", "FNX_POOL_TRACE", "FNX_JPEG_TRACE"}
+
+
+def test_release_build_reads_five_environment_names():
+    """a release build reads the five names include/fennec_hip.h lists and no other.  Every other
+    switch goes through dev_env() (getenv only under -DFNX_DEVELOP) or is a per-ctx kernel-form selection (fnx_ctx_set_form)."""
+    import re
+    csrc = os.path.join(ROOT, "fennec_amd", "csrc")
+    seen = set()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        text = re.sub(r"#ifdef FNX_DEVELOP.*?#e(?:lse|ndif)", "", text, flags=re.S)      # development-only blocks
+        for m in re.finditer(r"(?<![_a-z])(?:std::)?getenv\(\s*(\"[A-Z0-9_]+\"|[a-z_]+)\s*\)", text):
+            seen.add(m.group(1).strip('"'))
+    assert seen == RELEASE_ENV, seen ^ RELEASE_ENV
+    header = open(os.path.join(ROOT, "include", "fennec_hip.h")).read()
+    for name in RELEASE_ENV:
+        assert name in header, name
+    # and the shipped library holds no other FNX_ / FENNEC_ environment name as a string
+    blob = open(fennec_amd.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"(?<![A-Z0-9_])(?:FNX|FENNEC)_[A-Z0-9_]{3,}(?![A-Za-z0-9_])", blob))
+    allowed = RELEASE_ENV | {n for n in names if n.startswith(("FNX_ERR", "FNX_BLUR_", "FNX_HOST", "FNX_DEVICE", "FNX_PROF", "FNX_JPEG_HOST_MAX"))}
+    assert names <= allowed, sorted(names - allowed)
+
+
+def test_set_form_needs_a_ctx_and_a_known_name(lib):
+    assert lib.fnx_ctx_set_form(None, b"fx_ref", b"1") == fennec_amd.FNX_ERR_INVALID
+
+
 def test_table_generators_match_oracle(lib, orc):
     assert np.array_equal(fennec_amd.gaussianKernel(), orc.gaussian_kernel())
     for s in (0.3, 1.0, 2.0, 2.5, 20.0):

@@ -22,8 +22,20 @@ BLUR_FAST_MAX_FRAC = 1e-3
 
 
 @pytest.fixture(scope="module")
-def ctx():
+def _module_ctx():
     return fennec_amd.Context(0)
+
+
+FORM_NAMES = ("fx_stream", "fx_pairs", "fx_ref", "resize_mfma", "resize_fp64", "resize_fused", "msssim_levelwise",
+              "msssim_nofuse0", "msssim_fold", "msssim_boxfly", "palette_grid")
+
+
+@pytest.fixture()
+def ctx(_module_ctx):
+    """the module's ctx; whatever kernel forms a test selected (fnx_ctx_set_form) are back at their defaults after it"""
+    yield _module_ctx
+    for name in FORM_NAMES:
+        _module_ctx.set_form(name, None)
 
 
 IMAGES = {
@@ -174,8 +186,8 @@ def test_fx_kernel_forms(ctx, orc, monkeypatch, form, w, h):
     """Round 3: the streaming kernel (a wave marches down a strip of 62 columns) and both forms of the tile kernel
     (paired rows on v_pk_* with the fract boundary test; one row at a time with the second pack) against the
     oracle -- sizes around the strip width, the segment length and the tile."""
-    monkeypatch.setenv("FNX_FX_STREAM", "1" if form == "stream" else "0")
-    monkeypatch.setenv("FNX_FX_PAIRS", "0" if form == "tile_rows" else "1")
+    ctx.set_form("fx_stream", "1" if form == "stream" else "0")
+    ctx.set_form("fx_pairs", "0" if form == "tile_rows" else "1")
     soft = _soft_image(orc, w, h, 3 * w + h)
     hard = synth.large_photo(w, h, 5)
     for img in (soft, hard):
@@ -189,7 +201,7 @@ def test_fx_kernel_forms(ctx, orc, monkeypatch, form, w, h):
 def test_fx_kernel_forms_4k_and_views(ctx, orc, monkeypatch, form):
     """The same at 4K (many segments per strip) and on strided device views (the flat-copy pass runs behind either form)."""
     import torch
-    monkeypatch.setenv("FNX_FX_STREAM", "1" if form == "stream" else "0")
+    ctx.set_form("fx_stream", "1" if form == "stream" else "0")
     img = _soft_image(orc, 3840, 2160, 11)
     assert np.array_equal(ctx.AdaptiveSharpen(img, 0.5), orc.adaptive_sharpen(img, 0.5, procs=32))
     assert np.array_equal(ctx.Sharpen(img, 0.5), orc.sharpen(img, 0.5, procs=32))
@@ -205,7 +217,7 @@ def test_fx_kernel_forms_4k_and_views(ctx, orc, monkeypatch, form):
 
 def test_sharpen_amounts_against_reference_order_kernel(ctx, orc, monkeypatch):
     """Kernel-level amounts outside what the reference ever passes (and an unaligned strided view): the marching
-    kernels against the round-1 fp64 kernel, which follows the reference's operation order (FNX_FX_REF=1)."""
+    kernels against the round-1 fp64 kernel, which follows the reference's operation order (form "fx_ref" = 1)."""
     import torch
     soft = _soft_image(orc, 333, 217, 5)
     big = torch.from_numpy(np.ascontiguousarray(np.pad(soft, ((0, 0), (3, 2), (0, 0))))).cuda()
@@ -214,17 +226,17 @@ def test_sharpen_amounts_against_reference_order_kernel(ctx, orc, monkeypatch):
     amounts = [0.1, 1.0, 1.5, 2.0, 2.5, 3.0, 7.99, 8.5, 40.0, -0.5] + list(rng.uniform(0.01, 8.0, 6))
     for adaptive in (False, True):
         for amt in amounts:
-            monkeypatch.delenv("FNX_FX_REF", raising=False)
+            ctx.set_form("fx_ref", None)
             got = ctx.sharpen_amount(soft, amt, adaptive)
             got_view = ctx.sharpen_amount(view, amt, adaptive).cpu().numpy()
-            monkeypatch.setenv("FNX_FX_REF", "1")
+            ctx.set_form("fx_ref", "1")
             want = ctx.sharpen_amount(soft, amt, adaptive)
             want_view = ctx.sharpen_amount(view, amt, adaptive).cpu().numpy()
             assert np.array_equal(got, want), (adaptive, amt)
             # a SubImage's border follows the reference's flat copy(dst.Pix, img.Pix) (test_subimage_flat_pix_copies_gpu)
             assert np.array_equal(got_view, want_view), (adaptive, amt, "view")
             assert np.array_equal(got_view[1:-1, 1:-1], want[1:-1, 1:-1]), (adaptive, amt, "view interior")
-    monkeypatch.delenv("FNX_FX_REF", raising=False)
+    ctx.set_form("fx_ref", None)
 
 
 @pytest.mark.parametrize("geom", [(20, 10, 4, 8, 6, 12), (160, 120, 5, 8, 80, 128), (700, 300, 7, 13, 280, 611), (33, 17, 0, 0, 17, 9)])
@@ -352,7 +364,7 @@ def test_lanczos_resize_two_to_one_exact_forms(ctx, orc, dw, dh):
     four outputs per lane, two rows per wave instruction, the 18-row V sweep.  Content that sends every tile there (SURVEY 8(d)'s
     ramp: all rounding ties), with what the forms must hand on: the image's edge groups (clamped tap lists), odd widths and heights
     (a lone last row, a last group with one output), translucent pixels and patches (the general arithmetic), ramp / noise seams
-    (rows that stay fp32), and 2:1 on ONE axis only.  Bit-exact against the oracle; FNX_RESIZE_MFMA is left alone (the ramp is
+    (rows that stay fp32), and 2:1 on ONE axis only.  Bit-exact against the oracle; the "resize_mfma" form is left alone (the ramp is
     handed back by the matrix kernel on the first call, and the ctx goes to resize_fused_kernel after it)."""
     w, h = 2 * dw, 2 * dh
     ramp = synth.large_photo(w, h, 3)
@@ -400,7 +412,7 @@ def test_lanczos_resize_dense_form_after_two_cool_downs(orc):
 
 def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
     """Random geometries, device views with odd strides: the guard kernels against the round-1 fp64 kernels
-    (FNX_RESIZE_FP64=1), which follow the reference's operation order."""
+    (form "resize_fp64" = 1), which follow the reference's operation order."""
     import torch
     rng = np.random.default_rng(3)
     for _ in range(24):
@@ -412,12 +424,12 @@ def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
         pad = int(rng.integers(0, 3))
         big = torch.from_numpy(np.ascontiguousarray(np.pad(img, ((0, 0), (pad, 3 - pad), (0, 0))))).cuda()
         view = big[:, pad: pad + w]
-        monkeypatch.delenv("FNX_RESIZE_FP64", raising=False)
+        ctx.set_form("resize_fp64", None)
         got = ctx.lanczosResize(img, dw, dh)
         got_view = ctx.lanczosResize(view, dw, dh).cpu().numpy()
-        monkeypatch.setenv("FNX_RESIZE_FP64", "1")
+        ctx.set_form("resize_fp64", "1")
         want = ctx.lanczosResize(img, dw, dh)
-        monkeypatch.delenv("FNX_RESIZE_FP64", raising=False)
+        ctx.set_form("resize_fp64", None)
         assert np.array_equal(got, want), (w, h, dw, dh)
         assert np.array_equal(got_view, want), (w, h, dw, dh, "view")
 
@@ -427,7 +439,7 @@ def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
                                        (3840, 2160, 1920, 1080), (2048, 70, 929, 151), (9, 9, 4, 20)])
 def test_lanczos_resize_one_launch_vs_two_pass(ctx, orc, monkeypatch, w, h, dw, dh):
     """r3: resize_fused_kernel (resizeH into an LDS tile, resizeV out of it: windows of <= 16 source pixels) against the
-    two-pass kernels (FNX_RESIZE_FUSED=0) and, below 4K, the oracle -- noise, SURVEY 8(d)'s ramp (dense exact ties at 2:1),
+    two-pass kernels (form "resize_fused" = 0) and, below 4K, the oracle -- noise, SURVEY 8(d)'s ramp (dense exact ties at 2:1),
     two-level stripes (ties in both passes), a translucent patch (the general arithmetic from the tile), odd widths (the
     last H group has one output), tiles with fewer V groups than the tile holds, host arrays and strided device views."""
     import torch
@@ -444,14 +456,14 @@ def test_lanczos_resize_one_launch_vs_two_pass(ctx, orc, monkeypatch, w, h, dw, 
     for k, img in enumerate((noise, ramp, stripes, holes, soft)):
         if big and k in (2, 4):
             continue
-        monkeypatch.delenv("FNX_RESIZE_FUSED", raising=False)
+        ctx.set_form("resize_fused", None)
         got = ctx.lanczosResize(img, dw, dh)
         pad = 1 + k % 3
         view = torch.from_numpy(np.ascontiguousarray(np.pad(img, ((0, 0), (pad, 4 - pad), (0, 0))))).cuda()[:, pad: pad + w]
         got_view = ctx.lanczosResize(view, dw, dh).cpu().numpy()
-        monkeypatch.setenv("FNX_RESIZE_FUSED", "0")
+        ctx.set_form("resize_fused", "0")
         two = ctx.lanczosResize(img, dw, dh)
-        monkeypatch.delenv("FNX_RESIZE_FUSED", raising=False)
+        ctx.set_form("resize_fused", None)
         assert np.array_equal(got, two) and np.array_equal(got_view, two), (k, w, h, dw, dh)
         if not big or k == 3:                                  # at 4K the oracle checks the translucent-patch image only
             assert np.array_equal(got, orc.lanczos_resize(img, dw, dh, procs=32 if big else 8)), (k, w, h, dw, dh)
@@ -608,36 +620,36 @@ def test_msssim_levels(ctx, orc):
                                  (1200, 720), (1360, 752), (752, 1360), (528, 16 * 35)])
 def test_msssim_fused_levels(ctx, orc, monkeypatch, w, h):
     """The five-launch MSSSIM (one-pass 2 x 2 pyramid, multi-job box and window launches) against the level-by-level
-    loop (FNX_MSSSIM_LEVELWISE=1) and the oracle: per level and combined.  Shapes that are not divisible by 2^levels
+    loop (form "msssim_levelwise" = 1) and the oracle: per level and combined.  Shapes that are not divisible by 2^levels
     (1000 x 600) or too thin take the loop either way."""
     import torch
     a = synth.large_photo(w, h, 2)
     b = orc.gaussian_blur(a, 1.1)
     b[h // 3: h // 2, w // 4: w // 2, :3] //= 2
     da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
-    monkeypatch.delenv("FNX_MSSSIM_LEVELWISE", raising=False)
+    ctx.set_form("msssim_levelwise", None)
     got, lv = ctx.msssim_levels(da, db)
     got_h, lv_h = ctx.msssim_levels(a, b)
-    monkeypatch.setenv("FNX_MSSSIM_LEVELWISE", "1")
+    ctx.set_form("msssim_levelwise", "1")
     ref, lv_ref = ctx.msssim_levels(da, db)
-    monkeypatch.delenv("FNX_MSSSIM_LEVELWISE", raising=False)
+    ctx.set_form("msssim_levelwise", None)
     # r3: level 0 read once (box_halve_kernel: its planes and level 1 in one pass) against the two-read form -- the same
     # integer arithmetic, so the values are identical, odd box edges (1200 / 512, 1360 / 512 ...) included
-    monkeypatch.setenv("FNX_MSSSIM_NOFUSE0", "1")
+    ctx.set_form("msssim_nofuse0", "1")
     two, lv_two = ctx.msssim_levels(da, db)
-    monkeypatch.delenv("FNX_MSSSIM_NOFUSE0", raising=False)
+    ctx.set_form("msssim_nofuse0", None)
     assert two == got and np.array_equal(lv_two, lv, equal_nan=True)
     # r3: the means taken by each level's last workgroup against the separate finish launch, and (opt-in) boxes of <= 5 x 5
     # pixels taken in the window kernel's tile load against planes written by the box kernel: the same bytes, the same sums
     # in the same order
-    monkeypatch.setenv("FNX_MSSSIM_FOLD", "1")                # (off by default: see launch_msssim_fused)
+    ctx.set_form("msssim_fold", "1")                # (off by default: see launch_msssim_fused)
     old, lv_old = ctx.msssim_levels(da, db)
     old2, lv_old2 = ctx.msssim_levels(da, db)                 # (the folded finish leaves its counters at zero)
-    monkeypatch.delenv("FNX_MSSSIM_FOLD", raising=False)
+    ctx.set_form("msssim_fold", None)
     assert old == got and np.array_equal(lv_old, lv, equal_nan=True) and old2 == got
-    monkeypatch.setenv("FNX_MSSSIM_BOXFLY", "1")              # (off by default: see launch_msssim_fused)
+    ctx.set_form("msssim_boxfly", "1")              # (off by default: see launch_msssim_fused)
     fly, lv_fly = ctx.msssim_levels(da, db)
-    monkeypatch.delenv("FNX_MSSSIM_BOXFLY", raising=False)
+    ctx.set_form("msssim_boxfly", None)
     assert fly == got and np.array_equal(lv_fly, lv, equal_nan=True)
     want, wl = orc.msssim(a, b, per_level=True, procs=8)
     assert np.array_equal(np.isnan(lv), np.isnan(wl)) and np.array_equal(np.isnan(lv_ref), np.isnan(wl))
@@ -1287,43 +1299,32 @@ def _clustered_palette(n, seed):
 
 @pytest.mark.parametrize("mode", ["1", "0"])
 @pytest.mark.parametrize("kind,n", [("random", 256), ("random", 17), ("clustered", 256), ("clustered", 100), ("corner", 256), ("one", 1)])
-def test_apply_palette_grid_form(ctx, orc, monkeypatch, kind, n, mode):
+def test_apply_palette_grid_form(ctx, orc, kind, n, mode):
     """the grid of candidate lists (palette.hip, r5) against the walk over the whole palette: random, crowded (cells with more
     than 31 candidates take the marked path) and degenerate palettes; photo-like, noise and grey-ramp pixels; odd sizes"""
-    import subprocess, sys, json, os
-    # the mode is read once per process: a child per mode
-    code = f"""
-import numpy as np, sys, json
-sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
-sys.path.insert(0, {repr(os.path.dirname(os.path.abspath(__file__)))})
-import fennec_amd
-from fennec_amd import synth
-from oracle import oracle as orc
-orc.build()
-import test_gpu_parity as t
-kind, n = {kind!r}, {n}
-if kind == "random": pal = t._palette(n, 100 + n)
-elif kind == "clustered": pal = t._clustered_palette(n, n)
-elif kind == "corner":
-    rng = np.random.default_rng(3); pal = rng.integers(0, 12, size=(n, 4), dtype=np.uint8); pal[:, 3] = 255
-else: pal = np.array([[9, 200, 77, 255]], dtype=np.uint8)
-ctx = fennec_amd.Context(0)
-bad = 0
-imgs = [synth.make_test_image(701, 397), synth.noise_image(515, 333, 7, alpha=True)]
-ramp = np.zeros((64, 1024, 4), np.uint8); ramp[..., :3] = (np.arange(1024) // 4)[None, :, None]; ramp[..., 3] = 255
-imgs.append(ramp)
-dark = (synth.noise_image(300, 200, 9) // 20).astype(np.uint8); dark[..., 3] = 255
-imgs.append(dark)
-for img in imgs:
-    wi, wq = orc.apply_palette(img, pal)
-    gi, gq = ctx.applyPalette(img, pal)
-    bad += int(not (np.array_equal(gi, wi) and np.array_equal(gq, wq)))
-print(json.dumps({{"bad": bad}}))
-"""
-    env = dict(os.environ, FNX_PALETTE_GRID=mode)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert json.loads(out.stdout.strip().splitlines()[-1])["bad"] == 0
+    if kind == "random":
+        pal = _palette(n, 100 + n)
+    elif kind == "clustered":
+        pal = _clustered_palette(n, n)
+    elif kind == "corner":
+        rng = np.random.default_rng(3)
+        pal = rng.integers(0, 12, size=(n, 4), dtype=np.uint8)
+        pal[:, 3] = 255
+    else:
+        pal = np.array([[9, 200, 77, 255]], dtype=np.uint8)
+    imgs = [synth.make_test_image(701, 397), synth.noise_image(515, 333, 7, alpha=True)]
+    ramp = np.zeros((64, 1024, 4), np.uint8)
+    ramp[..., :3] = (np.arange(1024) // 4)[None, :, None]
+    ramp[..., 3] = 255
+    imgs.append(ramp)
+    dark = (synth.noise_image(300, 200, 9) // 20).astype(np.uint8)
+    dark[..., 3] = 255
+    imgs.append(dark)
+    ctx.set_form("palette_grid", mode)           # (a per-ctx selection since r6: no child process per mode)
+    for k, img in enumerate(imgs):
+        wi, wq = orc.apply_palette(img, pal)
+        gi, gq = ctx.applyPalette(img, pal)
+        assert np.array_equal(gi, wi) and np.array_equal(gq, wq), (kind, n, mode, k)
 
 
 # ------------------------------------------------------------------ decoded JPEG planes -> NRGBA, SURVEY 8(f).1

@@ -1,6 +1,6 @@
 """csrc/resize_mfma.hip (lanczosResize on the i8 matrix pipe: planar channels, fixed-point weights under a rounding guard,
 fp64 fix-ups, regions it cannot take handed back to resize_fused_sparse_kernel) against the oracle, bit for bit.
-FNX_RESIZE_MFMA=2 sends every table the kernel covers through it (the default keeps it to downscales); shapes on both sides
+The "resize_mfma" form = 2 (fnx_ctx_set_form) sends every table the kernel covers through it (the default keeps it to downscales); shapes on both sides
 of its boundaries (64-column strips, 16-row groups and slots, ratios at the edge of the 64-px / 64-row windows, strips that
 would stick out of the row), content it must hand back (translucent patches, tie-dense ramps and stripes, all of it or a
 corner), pitched device views, and the cool-down after a call that was mostly handed back."""
@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()
-def mctx(monkeypatch):
-    monkeypatch.setenv("FNX_RESIZE_MFMA", "2")       # read when a resize plan is built: a ctx of its own, plans of its own
-    return fennec_amd.Context(0)
+def mctx():
+    c = fennec_amd.Context(0)
+    c.set_form("resize_mfma", 2)                     # read when a resize plan is built: a ctx of its own, plans of its own
+    return c
 
 
 def _opaque(img):
@@ -99,8 +100,8 @@ def test_default_policy_and_cool_down(orc):
     assert np.array_equal(ctx.lanczosResize(photo, 2 * w, 2 * h), orc.lanczos_resize(photo, 2 * w, 2 * h, procs=8))
 
 
-def test_switched_off(monkeypatch, orc):
-    monkeypatch.setenv("FNX_RESIZE_MFMA", "0")
+def test_switched_off(orc):
     ctx = fennec_amd.Context(0)
+    ctx.set_form("resize_mfma", 0)
     img = _photo(640, 480, 9)
     assert np.array_equal(ctx.lanczosResize(img, 320, 240), orc.lanczos_resize(img, 320, 240, procs=8))

@@ -21,6 +21,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 orc.build()
 ctx = fennec_amd.Context(0)
+ctx.set_form("resize_mfma", os.environ["FNX_RESIZE_MFMA"])     # (r6: a per-ctx kernel-form selection; the variable is this tool's own)
 fails, it, t0 = 0, 0, time.time()
 
 
