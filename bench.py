@@ -117,6 +117,9 @@ def main() -> int:
                          "alone and `roofline` describes it; 2: step s+1 is enqueued (on a second context = stream, into "
                          "a second set of destinations) before step s's results are fetched (+7 %%; the default line "
                          "reports that rate as `pipelined`)")
+    ap.add_argument("--ssim-mode", default="fast", choices=["fast", "exact"],
+                    help="config 4's full-resolution SSIM: fast = FNX_SSIM_FAST (fp32 moments, |delta| <= 1e-6: SURVEY Appendix A's tolerance for "
+                         "fp32-moment paths), exact = the default of the library (fp64 moments, <= 1e-9); the other one is reported beside it")
     ap.add_argument("--blur-mode", default="fast", choices=["fast", "exact"],
                     help="fast (default): 24-bit fixed-point weights on the i8 matrix pipe, exact integer sums: <= 1 LSB on "
                          "<= 0.001 %% of samples (north_star allows a stated tolerance; the bar is 0.1 %%); exact: the same sums "
@@ -673,7 +676,7 @@ def other_configs(args, heavy_burst=None) -> dict:
         try:
             line = other_workload_line(a, embedded=True)
             keep = {k: line[k] for k in ("metric", "value", "value_before_prewarm", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline",
-                                        "roofline_step", "step_ms", "gpu_stage", "result_sample") if k in line}
+                                        "roofline_step", "step_ms", "gpu_stage", "result_sample", "ssim_mode", "other_ssim_mode") if k in line}
             keep["workload"] = line["config"]["workload"]
             keep["images_per_step"] = line["config"]["images_per_step_per_gpu"]
             keep["wall_s"] = round(time.perf_counter() - t0, 2)
@@ -951,7 +954,7 @@ def _pooled_queue_step(fennec_amd, device, ctx0, n_items, submit, drain, nctx, n
 
 DTYPES = {   # the arithmetic each workload's hot kernels compute in (not a precision claim: every integer output is bit-exact)
     "config3": "u8 (fp32 FMA resize under a rounding guard + fp64 reference-order fix-ups; integer box sums; fp64 SSIM moments)",
-    "config4": "u8 (integer Sobel + fp32 AdaptiveSharpen under a rounding guard + fp64 fix-ups; integer milli-luminance, fp64 SSIM moments)",
+    "config4": "u8 (integer Sobel + fp32 AdaptiveSharpen under a rounding guard + fp64 fix-ups: bit-exact; integer milli-luminance, SSIM moments fp32 (--ssim-mode fast, the default of this line) or fp64)",
     "config5": "u8 / int32 (Go image/jpeg's integer DCT, quantisation and Huffman arithmetic; integer box sums; fp64 SSIM moments)",
     "analyze": "u8 -> fp64 luminance sums, integer histogram",
     "palette": "u8 / u32 integer distances",
@@ -1059,9 +1062,15 @@ def other_workload_line(args, embedded: bool = False):
             if c is ctx and prof_on[0]:
                 kms["windowed_ssim"].append(c.kernel_ms())
 
+        ssim_fast = [getattr(args, "ssim_mode", "fast") == "fast"]
+        mode_of = {}
+
         def submit4(c, i, out):
             """AdaptiveSharpen (async) + fnx_ssim_enqueue per image, results fetched QD images behind."""
             pend = pend4.setdefault(id(c), [])
+            if mode_of.get(id(c)) != ssim_fast[0]:
+                c.set_ssim_mode(ssim_fast[0])
+                mode_of[id(c)] = ssim_fast[0]
             sharp = c.AdaptiveSharpen(imgs[i], 0.5)
             c.ssim_enqueue(imgs[i], sharp)
             pend.append((i, sharp))
@@ -1215,6 +1224,33 @@ def other_workload_line(args, embedded: bool = False):
     if wl in ("config3", "config4"):
         prof_on[0] = False
         ctx.profile(0)
+    other_mode = None
+    if wl == "config4":
+        # the same steps in the OTHER arithmetic of full-resolution SSIM (fp64 moments when the line is the fp32 form and vice
+        # versa), right after the timed region, same protocol, half the steps; never `value`
+        kms_main = list(kms["windowed_ssim"])
+        name_main = ctx.last_kernel(fennec_amd.PROF_SSIM)
+        ssim_fast[0] = not ssim_fast[0]
+        for _ in range(2):
+            vals_o = step()
+        kms["windowed_ssim"].clear()
+        ctx.profile(prof_mask)
+        prof_on[0] = True
+        n_o = max(4, args.steps // 2)
+        barrier()
+        t_o = time.perf_counter()
+        for _ in range(n_o):
+            vals_o = step()
+        barrier()
+        dt_o = time.perf_counter() - t_o
+        prof_on[0] = False
+        ctx.profile(0)
+        other_mode = {"mode": "fast" if ssim_fast[0] else "exact", "value": round(units_per_step * world * n_o / dt_o, 2), "unit": unit, "steps": n_o,
+                      "ms_per_step": round(dt_o / n_o * 1e3, 4), "kernel": ctx.last_kernel(fennec_amd.PROF_SSIM),
+                      "avg_launch_ms": round(float(np.mean(kms["windowed_ssim"])), 4) if kms["windowed_ssim"] else None,
+                      "result_sample": float(vals_o[0]), "delta_vs_line": float(vals_o[0]) - float(vals[0])}
+        ssim_fast[0] = not ssim_fast[0]
+        kms["windowed_ssim"][:] = kms_main
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1248,16 +1284,24 @@ def other_workload_line(args, embedded: bool = False):
             g = abytes / (ms * 1e-3) / 1e9
             # the kernel is fp64-VALU bound: 4 moments x 8 taps x 2 passes of fp64 FMA per window
             win = float(W - 8) * float(H - 8)
-            out["roofline"] = {"kernel": "windowed_ssim_march2_kernel (full-resolution SSIM of one 8K pair, two pixel columns per lane, luminance fused)",
+            fastk = name_main == "windowed_ssim_march2f_kernel"
+            out["ssim_mode"] = ("fast: FNX_SSIM_FAST, fp32 moments in the cancellation-free form, |delta| <= 1e-6 (SURVEY Appendix A), measured <= 6e-8"
+                                if fastk else "exact: fp64 moments, |delta| <= 1e-9 (the library's default)")
+            out["other_ssim_mode"] = other_mode
+            out["roofline"] = {"kernel": f"{name_main} (full-resolution SSIM of one 8K pair, two pixel columns per lane, luminance fused"
+                                         + (", fp32 moments)" if fastk else ", fp64 moments)"),
                                "bound": "valu", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(g / HBM_PEAK_GBS, 4),
-                               "traffic": committed_traffic_named("windowed_ssim_march2_kernel", "config4"),
+                               "traffic": committed_traffic_named(name_main, "config4"),
                                "traffic_file": source_file("traffic"),
                                "traffic_source": "the newest profiles/*config4*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": len(kms["windowed_ssim"]),
-                               "fp64_fma_floor_ms": round(win * 64 / 39.3e12 * 1e3, 4),
-                               "note": "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown); "
-                                       "bytes are SURVEY 8(d)'s 2*S per pair"}
+                               "fma_floor_ms": round(win * 64 / (78.6e12 if fastk else 39.3e12) * 1e3, 4),
+                               "note": ("bound by instruction issue: 64 FMA per window -- the floor shown is at 78.6 T fp32 FMA/s, which needs "
+                                        "packed instructions AND more than two waves per SIMD; at two, every VALU instruction costs a quad-cycle "
+                                        "(experiments/ssimf/pkrate.hip)" if fastk else
+                                        "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown)")
+                                       + "; bytes are SURVEY 8(d)'s 2*S per pair"}
         else:
             means = {k: float(np.mean(v)) for k, v in kms.items() if v}
             fused = "resize_fused_down" in kms

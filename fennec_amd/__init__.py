@@ -137,6 +137,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_ctx_kernel_ms", i, [ctx, C.POINTER(C.c_float)])
         _sig(L, "fnx_ctx_last_kernel", C.c_char_p, [ctx, i])
         _sig(L, "fnx_ctx_set_form", i, [ctx, C.c_char_p, C.c_char_p])
+        _sig(L, "fnx_ctx_set_ssim_mode", i, [ctx, i])
         _sig(L, "fnx_malloc", i, [ctx, C.c_size_t, C.POINTER(C.c_void_p)])
         _sig(L, "fnx_free", i, [ctx, C.c_void_p])
         _sig(L, "fnx_upload", i, [ctx, C.c_void_p, i, C.c_void_p, i, i, i])
@@ -346,6 +347,10 @@ class Context:
         if s is None:
             raise FennecError("fnx_ctx_last_kernel: bad class")
         return s.decode()
+
+    def set_ssim_mode(self, fast: bool) -> None:
+        """fnx_ctx_set_ssim_mode: fp32 moments (<= 1e-6) instead of fp64 (<= 1e-9) for full-resolution SSIM planes"""
+        self._chk(self._lib.fnx_ctx_set_ssim_mode(self._h, 1 if fast else 0), "fnx_ctx_set_ssim_mode")
 
     def set_form(self, name: str, value=None) -> None:
         """fnx_ctx_set_form: which of several kernels that compute the same bytes this ctx takes (tests, A/B timing);

@@ -216,6 +216,7 @@ struct fnx_ctx {
     // fnx_ctx_last_kernel: the kernel the last call of each class really launched (static strings), so that a report can
     // name the route the library took instead of inferring it from environment switches
     const char *route[8] = {"", "", "", "", "", "", "", ""};
+    int ssim_mode = 0;           // fnx_ctx_set_ssim_mode: FNX_SSIM_EXACT (fp64 moments) / FNX_SSIM_FAST (fp32 moments for full-resolution planes)
     // fnx_ctx_set_form: the kernel forms this ctx was told to take ("" = the product's own choice)
     char form[fnx::FORM_COUNT][8] = {};
     // analyze.hip's single-launch form: which colour table the next call uses, and how many tables of each are not zero

@@ -520,6 +520,13 @@ int fnx_ctx_profile(fnx_ctx *ctx, int enable)
     return FNX_OK;
 }
 
+int fnx_ctx_set_ssim_mode(fnx_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != FNX_SSIM_EXACT && mode != FNX_SSIM_FAST)) { fnx::set_error("fnx_ctx_set_ssim_mode: bad argument"); return FNX_ERR_INVALID; }
+    ctx->ssim_mode = mode;
+    return FNX_OK;
+}
+
 int fnx_ctx_set_form(fnx_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx || !name) { fnx::set_error("fnx_ctx_set_form: null argument"); return FNX_ERR_INVALID; }

@@ -958,6 +958,9 @@ struct MarchArgs {
     unsigned *done;               // [n] workgroups finished, zero before and after the launch
     double count;
     int prio;                     // march2: alternate the wave's priority by progress (A/B knob FNX_SSIM_PRIO)
+    // the fp32 form (windowed_ssim_march2f_kernel): col[] rounded to fp32; row[] * 2^-10 (first moments) and * 2^-20 (second
+    // moments) -- exact scalings: the moments come out in units of milli-luminance / 1024, whose squares stay far inside fp32
+    float colf[8], rowf1[8], rowf2[8];
 };
 
 // exact integer milli-luminance: 299 R + 587 G + 114 B  (255 + 44, 255 + 255 + 77, 114)
@@ -1338,6 +1341,236 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
     march_finish(a, z, item, items, val, s_red, &s_last);
 }
 
+// ------------------------------------------------------------------------------------
+// r6: the two-column march with fp32 moments -- the FAST mode of full-resolution SSIM (fnx_ctx_set_ssim_mode(FNX_SSIM_FAST);
+// "<= 1e-6 for fp32-moment fast paths"; the default stays the fp64 kernel above, <= 1e-9).
+//
+// fp64 FMAs issue at the plain fp32 rate on this part and v_pk_fma_f32 does two fp32 FMAs per lane in the same slot, so the
+// window's 64 FMAs per pixel become 32 instructions.  What makes fp32 ENOUGH is the formulation, not the type:
+//   * the moments are taken of x = A - 127500, y = B - 127500 (exact integers in fp32) and of d = x - y (exact);
+//   * with  S = E[x^2 + y^2] - mx^2 - my^2 (= sigma_aa + sigma_bb),  Vd = E[d^2] - (mx - my)^2 (= Var(a - b))  the window's
+//     value (ssim.go:150-155) is   [1 - (mx - my)^2 / (muA^2 + muB^2 + C1)] * [1 - Vd / (S + C2)]   -- identically, since
+//     2 sigma_ab = S - Vd and 2 muA muB = muA^2 + muB^2 - (muA - muB)^2.  The cancellation-prone S (an fp32 E[x^2] minus
+//     an fp32 mean^2: absolute error ~1e-7 E[x^2]) now only scales a term that VANISHES where the images agree: its error
+//     reaches the result multiplied by Vd / (S + C2)^2.  Identical images give exactly 1, as in the reference.
+// Measured against the oracle on SURVEY's ramp, photograph-like, noise, dark, bright and unrelated pairs: |delta| <= 3e-7 on
+// the image's mean (tests/test_gpu_parity.py::test_ssim_fast_moments*); the same expression in fp64 is within 1e-13.
+// Layout: lane l owns pixels 2l, 2l + 1 (as the fp64 kernel); an LDS entry is ONE float4 per pixel (x, y, x^2 + y^2, d^2) in
+// an even and an odd array (16-byte reads at a 16-byte lane stride); (x, y) and (x^2 + y^2, d^2) are the packed pairs of
+// every FMA, so no operand is ever shuffled.  Rings: 2 columns x 8 windows x 2 pairs = 64 VGPRs: three waves per SIMD.
+// Two consecutive windows of a column share ONE division (P / Q as in the fp64 kernel; denominators <= 4e9 in these units).
+// The lane's sum is kept in fp32 over eight rows of (1 - value) and added into an fp64 total per group.
+// ------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// (299 R + 587 G + 114 B) - c as an exact fp32 integer: the dot products start from -c mod 2^32 (negc)
+__device__ __forceinline__ float lum_milli_centred(uint32_t p, uint32_t negc)
+{
+    uint32_t i = __builtin_amdgcn_udot4(p, 0x00004d00u, negc, false);
+    i = __builtin_amdgcn_udot4(p, 0x0000ff2cu, i, false);
+    i = __builtin_amdgcn_udot4(p, 0x0072ffffu, i, false);
+    return static_cast<float>(static_cast<int32_t>(i));
+}
+
+#ifndef WMF_PF_N
+#define WMF_PF_N 4
+#endif
+constexpr int WMF_PF = WMF_PF_N;       // pixel rows in flight per lane (divides 8)
+template <int WPS, bool PRE>
+__global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 s_row[4][2 * WM2_LDSW];   // per wave: even pixels, odd pixels
+    __shared__ double s_red[4];
+    __shared__ int s_last;
+    const int z = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    const int items = a.strips * a.segs;
+    double val = 0.0;
+    if (item < items) {                                           // wave-uniform
+    const int seg = item / a.strips, strip = item - seg * a.strips;
+    const int ww = a.w - 8, wh = a.h - 8;
+    const int wy0 = seg * a.seg_rows;
+    const int nwin = min(a.seg_rows, wh - wy0);
+    const int wx = strip * WM2_COLS + 2 * lane;
+    const bool live0 = 2 * lane < WM2_COLS && wx < ww, live1 = 2 * lane + 1 < WM2_COLS && wx + 1 < ww;
+    const int px = min(wx, a.w - 2);                              // (see the fp64 kernel)
+    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    f32x4 *s_e = s_row[wave], *s_o = s_e + WM2_LDSW;
+    if (lane < WM2_LDSW - 64) {
+        s_e[64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s_o[64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int nrows = nwin + 7;
+    f32x2 m0a[8], m0q[8], m1a[8], m1q[8];                         // rings: column 0 / 1, (mx, my) and (E[x^2 + y^2], E[d^2])
+#pragma unroll
+    for (int s = 0; s < 8; s++) m0a[s] = m0q[s] = m1a[s] = m1q[s] = (f32x2){0.f, 0.f};
+    typedef __attribute__((address_space(1))) const u32x2 g_u32x2;
+    // The centre c: the mean milli-luminance of three rows of both images as this WAVE sees them (first, middle and last
+    // pixel row of its segment, 128 columns), an integer.  Any constant gives the same moments in exact arithmetic; one near
+    // the strip's level keeps |x|, |y| -- and with them the rounding of E[x^2 + y^2] against mx^2 + my^2, the one
+    // cancellation the form has left -- as small as the content allows (a bright flat region against a noisy copy of itself
+    // was 3.6e-6 off with the fixed centre 127500 and is exact to 1e-8 with this one).
+    uint32_t csum = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const size_t rr = static_cast<size_t>(k == 0 ? 0 : (k == 1 ? (nrows - 1) / 2 : nrows - 1));
+        const u32x2 sa = *(g_u32x2 *)(pa + rr * a.astride), sb = *(g_u32x2 *)(pb + rr * a.bstride);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            csum = __builtin_amdgcn_udot4(sa[e], 0x00004d00u, csum, false); csum = __builtin_amdgcn_udot4(sa[e], 0x0000ff2cu, csum, false);
+            csum = __builtin_amdgcn_udot4(sa[e], 0x0072ffffu, csum, false);
+            csum = __builtin_amdgcn_udot4(sb[e], 0x00004d00u, csum, false); csum = __builtin_amdgcn_udot4(sb[e], 0x0000ff2cu, csum, false);
+            csum = __builtin_amdgcn_udot4(sb[e], 0x0072ffffu, csum, false);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off, 64);          // <= 768 x 255000 < 2^28
+    const uint32_t centre = __builtin_amdgcn_readfirstlane(csum) / 768u;
+    const uint32_t negc = 0u - centre;
+    u32x2 qa[WMF_PF], qb[WMF_PF];
+#pragma unroll
+    for (int k = 0; k < WMF_PF; k++) {
+        const int rr = min(k, nrows - 1);
+        qa[k] = *(g_u32x2 *)(pa + static_cast<size_t>(rr) * a.astride);
+        qb[k] = *(g_u32x2 *)(pb + static_cast<size_t>(rr) * a.bstride);
+    }
+    pa += static_cast<size_t>(min(WMF_PF, nrows - 1)) * a.astride;
+    pb += static_cast<size_t>(min(WMF_PF, nrows - 1)) * a.bstride;
+    // units: milli-luminance / 1024
+    const float CU = static_cast<float>(centre) * (1.0f / 1024.0f);    // exact: an integer below 2^18 times 2^-10
+    constexpr float C1U = 6.5025e6f / 1048576.0f, C2U = 58.5225e6f / 1048576.0f;
+    float acc0 = 0.f, acc1 = 0.f;                                 // sum of (1 - value) over the current group of rows
+    double tot0 = 0.0, tot1 = 0.0;
+    float P0 = 0.f, Q0 = 1.f, P1 = 0.f, Q1 = 1.f;                 // the window of the row before, not yet divided
+
+    auto stage = [&](const int i, auto pc) {
+        constexpr int p = decltype(pc)::value;
+        const float x0 = lum_milli_centred(qa[p % WMF_PF][0], negc), x1 = lum_milli_centred(qa[p % WMF_PF][1], negc);
+        const float y0 = lum_milli_centred(qb[p % WMF_PF][0], negc), y1 = lum_milli_centred(qb[p % WMF_PF][1], negc);
+        qa[p % WMF_PF] = *(g_u32x2 *)pa;                       // no branch around the loads (see the one-column kernel)
+        qb[p % WMF_PF] = *(g_u32x2 *)pb;
+        if (i + WMF_PF + 1 < nrows) {
+            pa += a.astride;
+            pb += a.bstride;
+        }
+        const float d0 = x0 - y0, d1 = x1 - y1;
+        s_e[lane] = (f32x4){x0, y0, fmaf(y0, y0, x0 * x0), d0 * d0};
+        s_o[lane] = (f32x4){x1, y1, fmaf(y1, y1, x1 * x1), d1 * d1};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    f32x4 tap[9];                                                 // the staged row as this lane's window sees it: pixels 2l .. 2l + 8
+    auto fetch = [&]() {
+#pragma unroll
+        for (int q = 0; q < 9; q++) tap[q] = (q & 1) ? s_o[lane + q / 2] : s_e[lane + q / 2];
+        __builtin_amdgcn_wave_barrier();                          // (the next stage() overwrites the row: after these reads, in order)
+    };
+    // numerator and denominator of (1 - value): value = (t1 - md2)(den2 - vd) / (t1 den2)
+    auto numden = [&](const f32x2 A, const f32x2 B, float &num, float &den) {
+        const f32x2 SQ = A * A;
+        const f32x2 AB = A + (f32x2){CU, CU};
+        const float md = A.x - A.y;
+        const float t1 = fmaf(AB.x, AB.x, fmaf(AB.y, AB.y, C1U));
+        const float md2 = md * md;
+        const float den2 = ((B.x + C2U) - SQ.x) - SQ.y;
+        const float vd = B.y - md2;
+        // 1 - (t1 - md2)(den2 - vd) / (t1 den2) = (md2 den2 + vd (t1 - md2)) / (t1 den2): no cancellation left in the quotient
+        num = fmaf(md2, den2, vd * (t1 - md2));
+        den = t1 * den2;
+    };
+    auto quot = [&](float num, float den) {
+        float rc = __builtin_amdgcn_rcpf(den);
+        rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
+        return num * rc;
+    };
+    // FIRST: the segment's first eight rows (the ring fills: only p == 7 completes a window; nrows >= 8 always).  GUARD: the
+    // segment's last, partial group.  The groups in between are straight-line code without a branch (see the fp64 kernel).
+    auto rowbody = [&](const int r, auto pc, auto guardc, auto firstc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr bool GUARD = decltype(guardc)::value, FIRST = decltype(firstc)::value;
+        const int i = r + p;
+        if (GUARD && i >= nrows) return;                          // wave-uniform
+        // rows stay rows: without this fence the scheduler pulls the luminances of all WMF_PF prefetched rows to the front of
+        // the group and waits for the NEWEST load (s_waitcnt vmcnt(0) once per row: the four rows of prefetch become one)
+        __builtin_amdgcn_sched_barrier(0);
+        // the row's nine entries were read at the END of the row before (tap[]): the LDS round trip runs under that row's
+        // vertical pass and formula instead of in front of this row's FMAs (36 registers; the fp64 kernel has no room for it)
+        f32x2 h0a = {0.f, 0.f}, h0q = {0.f, 0.f}, h1a = {0.f, 0.f}, h1q = {0.f, 0.f};
+        if (!PRE) fetch();
+#pragma unroll
+        for (int q = 0; q < 9; q++) {                             // pixel 2l + q: column 0's tap q, column 1's tap q - 1
+            const f32x4 v = tap[q];
+            const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+            if (q < 8) {
+                const f32x2 c = {a.colf[q], a.colf[q]};
+                h0a = __builtin_elementwise_fma(lo, c, h0a);
+                h0q = __builtin_elementwise_fma(hi, c, h0q);
+            }
+            if (q >= 1) {
+                const f32x2 c = {a.colf[q - 1], a.colf[q - 1]};
+                h1a = __builtin_elementwise_fma(lo, c, h1a);
+                h1q = __builtin_elementwise_fma(hi, c, h1q);
+            }
+        }
+        stage(i + 1, std::integral_constant<int, (p + 1) & 7>{});   // (tap[] holds row i: the LDS row is free)
+        if (PRE) fetch();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int k = (p - s) & 7;
+            const f32x2 r1 = {a.rowf1[k], a.rowf1[k]}, r2 = {a.rowf2[k], a.rowf2[k]};
+            if (k == 0) {
+                m0a[s] = h0a * r1; m0q[s] = h0q * r2; m1a[s] = h1a * r1; m1q[s] = h1q * r2;
+            } else {
+                m0a[s] = __builtin_elementwise_fma(h0a, r1, m0a[s]); m0q[s] = __builtin_elementwise_fma(h0q, r2, m0q[s]);
+                m1a[s] = __builtin_elementwise_fma(h1a, r1, m1a[s]); m1q[s] = __builtin_elementwise_fma(h1q, r2, m1q[s]);
+            }
+        }
+        if (FIRST && p != 7) return;
+        const int s = (p + 1) & 7;
+        float n0, d0, n1, d1;
+        numden(m0a[s], m0q[s], n0, d0);
+        numden(m1a[s], m1q[s], n1, d1);
+        if (FIRST) {
+            acc0 += quot(n0, d0);
+            acc1 += quot(n1, d1);
+        } else if ((p & 1) == 0) {
+            // (a full group ends on an odd p: only the guarded group can end on an even one)
+            if (GUARD && i == nrows - 1) {                        // wave-uniform: the segment's last row has no partner
+                acc0 += quot(n0, d0);
+                acc1 += quot(n1, d1);
+            } else {
+                P0 = n0; Q0 = d0; P1 = n1; Q1 = d1;
+            }
+        } else {
+            acc0 += quot(fmaf(P0, d0, n0 * Q0), Q0 * d0);
+            acc1 += quot(fmaf(P1, d1, n1 * Q1), Q1 * d1);
+        }
+    };
+    auto group = [&](const int r, auto guardc, auto firstc) {
+        rowbody(r, std::integral_constant<int, 0>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 1>{}, guardc, firstc);
+        rowbody(r, std::integral_constant<int, 2>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 3>{}, guardc, firstc);
+        rowbody(r, std::integral_constant<int, 4>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 5>{}, guardc, firstc);
+        rowbody(r, std::integral_constant<int, 6>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 7>{}, guardc, firstc);
+        tot0 += static_cast<double>(acc0); tot1 += static_cast<double>(acc1);
+        acc0 = acc1 = 0.f;
+    };
+    stage(0, std::integral_constant<int, 0>{});
+    if (PRE) fetch();
+    group(0, std::false_type{}, std::true_type{});
+    int r = 8;
+    for (; r + 8 <= nrows; r += 8) group(r, std::false_type{}, std::false_type{});
+    if (r < nrows) group(r, std::true_type{}, std::false_type{});
+    // the lane's windows: nwin each of value 1 - (1 - value)
+    val = (live0 ? static_cast<double>(nwin) - tot0 : 0.0) + (live1 ? static_cast<double>(nwin) - tot1 : 0.0);
+    }
+    march_finish(a, z, item, items, val, s_red, &s_last);
+}
+
 // one workgroup per image pair: fixed-order sum of the tile partials, then / count
 __global__ __launch_bounds__(256) void ssim_finish_kernel(const double *partial, int tiles, double count, double *out)
 {
@@ -1383,7 +1616,9 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         // rows (row halo (S + 7) / S <= 1.22)
         const int cols = march2 ? WM2_COLS : WM_COLS;
         ma.strips = (ww + cols - 1) / cols;
-        static const long m2_per_cu = [] { const char *e = dev_env("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 8L; }();   // experiments
+        static const long m2_env = [] { const char *e = dev_env("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 0L; }();   // experiments
+        static const long mf_wps = [] { const char *e = dev_env("FNX_SSIM_F_WAVES"); return e ? atol(e) : 2L; }();
+        const long m2_per_cu = m2_env ? m2_env : (ctx->ssim_mode == FNX_SSIM_FAST ? 4L * mf_wps : 8L);
         const long target = (march2 ? m2_per_cu : 16L) * ctx->num_cus;
         long segs = target / (static_cast<long>(n) * ma.strips);
         const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
@@ -1432,7 +1667,19 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         ma.prio = prio;
         FNX_TRY(prof_begin(ctx, FNX_PROF_SSIM));
         note_route(ctx, FNX_PROF_SSIM, march2 ? "windowed_ssim_march2_kernel" : "windowed_ssim_march_kernel");
-        if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        const bool fast = march2 && ctx->ssim_mode == FNX_SSIM_FAST;
+        if (fast) {
+            for (int i = 0; i < 8; i++) {
+                ma.colf[i] = static_cast<float>(sa.col[i]);
+                ma.rowf1[i] = static_cast<float>(sa.row[i] * (1.0 / 1024.0));
+                ma.rowf2[i] = static_cast<float>(sa.row[i] * (1.0 / 1048576.0));
+            }
+            note_route(ctx, FNX_PROF_SSIM, "windowed_ssim_march2f_kernel");
+            static const int wps = [] { const char *e = dev_env("FNX_SSIM_F_WAVES"); return e ? atoi(e) : 2; }();   // development: waves per SIMD
+            if (wps == 4) hipLaunchKernelGGL((windowed_ssim_march2f_kernel<4, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+            else if (wps == 3) hipLaunchKernelGGL((windowed_ssim_march2f_kernel<3, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+            else hipLaunchKernelGGL((windowed_ssim_march2f_kernel<2, true>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+        } else if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else if (ctx->partial_slot >= 0) hipLaunchKernelGGL(windowed_ssim_march_kernel<true>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else hipLaunchKernelGGL(windowed_ssim_march_kernel<false>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         FNX_HIP(hipGetLastError());

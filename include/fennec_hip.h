@@ -148,6 +148,17 @@ int fnx_ctx_kernel_ms(fnx_ctx *ctx, float *ms);
  * argument): which of the routes the dispatch took (matrix pipe, direct, generic; fused, two-pass ...).  Reporting
  * only: bench.py names its roofline kernel with it.  No reference counterpart. */
 const char *fnx_ctx_last_kernel(fnx_ctx *ctx, int prof_class);
+/* Arithmetic of the windowed statistics of FULL-RESOLUTION SSIM (ssim.go:24-43, 110-148: planes of 4 M windows and more --
+ * fnx_ssim, fnx_ssim_enqueue, fennec_SSIM on large images; SSIMFast / MSSSIM planes are <= 512 px and always exact):
+ *   FNX_SSIM_EXACT (default)  fp64 moments, |result - reference| <= 1e-9 (measured ~1e-12)
+ *   FNX_SSIM_FAST             fp32 moments of centred luminances in a cancellation-free form of the same expression,
+ *                             |result - reference| <= 1e-6 (SURVEY.md Appendix A's tolerance for fp32-moment paths;
+ *                             measured <= 3e-7), identical images still give exactly 1.  About 1.5 x the throughput.
+ * The analogue of FNX_BLUR_FAST / FNX_BLUR_EXACT; a property of the ctx because the SSIM entry points keep the reference's
+ * argument lists.  The Go shim leaves the default. */
+#define FNX_SSIM_EXACT 0
+#define FNX_SSIM_FAST 1
+int fnx_ctx_set_ssim_mode(fnx_ctx *ctx, int mode);
 /* Kernel-form selection of ONE ctx, for tests and A/B timing: every form computes the same bytes as the default, the
  * selection only says which kernel does it, so that a fallback the product takes for rare tables (the fp64
  * reference-order kernels, the two-pass twin of a fused launch ...) can be run on any image and compared.  name / value:

@@ -943,7 +943,110 @@ def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
     s = ctx.SSIM(img, sharp)
     assert 0.0 < s < 1.0 and ctx.SSIM(img, img) == 1.0
     # r4: the full 8K pair against the oracle (33 M windows, ~30 s of host time on 64 threads): config 4 at its own size
-    assert abs(s - orc.ssim(img, sharp, procs=64)) <= SSIM_TOL
+    want = orc.ssim(img, sharp, procs=64)
+    assert abs(s - want) <= SSIM_TOL
+    # r6: the fp32-moment mode (FNX_SSIM_FAST, windowed_ssim_march2f_kernel) at config 4's own size: SURVEY Appendix A's
+    # tolerance for fp32-moment paths is 1e-6; identical images still give exactly 1
+    ctx.set_ssim_mode(True)
+    try:
+        fast = ctx.SSIM(img, sharp)
+        assert ctx.last_kernel(fennec_amd.PROF_SSIM) == "windowed_ssim_march2f_kernel"
+        assert abs(fast - want) <= SSIM_FAST_TOL, (fast, want)
+        assert ctx.SSIM(img, img) == 1.0
+    finally:
+        ctx.set_ssim_mode(False)
+    assert ctx.SSIM(img, sharp) == s                       # (and the default is the fp64 kernel again)
+
+
+SSIM_FAST_TOL = 1e-6
+
+
+def _photo_like(w, h, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 97.0) * np.cos(y / 61.0) + rng.normal(0, 4, x.shape) for _ in range(3)] + [np.full(x.shape, 255.0)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", ["ramp_sharpen", "ramp_blur", "noise_blur", "unrelated", "photo_blur", "bright_blur", "dark_blur",
+                                  "flat_noisy", "half_bright_half_dark", "translucent", "strided_views"])
+def test_ssim_fast_moments(ctx, orc, case):
+    """FNX_SSIM_FAST against the oracle on planes of 4.4 M windows (the two-column marching kernel's range): the fp32
+    cancellation-free form [1 - md^2 / (muA^2 + muB^2 + C1)] [1 - Var(a - b) / (sigma_aa + sigma_bb + C2)] about a per-wave
+    centre.  Content chosen against it: a bright flat image against a noisy copy (E[x^2] >> the variances), unrelated images
+    (the Var(a - b) term at full weight), levels that change inside a wave's segment (the centre fits neither half), alpha
+    (ignored by toLuminance), pitched device views.  |delta| <= 1e-6 (measured <= 6e-8); the exact mode is checked beside it."""
+    import torch
+    w, h = 2600, 1700
+    rng = np.random.default_rng(11)
+    ramp = synth.large_photo(w, h, 1)
+    if case == "ramp_sharpen":
+        a, b = ramp, orc.adaptive_sharpen(ramp, 0.5, procs=16)
+    elif case == "ramp_blur":
+        a, b = ramp, orc.gaussian_blur(ramp, 2.0, procs=16)
+    elif case == "noise_blur":
+        a = synth.noise_image(w, h, 3)
+        b = orc.gaussian_blur(a, 1.2, procs=16)
+    elif case == "unrelated":
+        a, b = ramp, synth.noise_image(w, h, 3)
+    elif case == "photo_blur":
+        a = _photo_like(w, h, 2)
+        b = orc.gaussian_blur(a, 2.0, procs=16)
+    elif case == "bright_blur":
+        a = np.clip(_photo_like(w, h, 2).astype(int) // 8 + 224, 0, 255).astype(np.uint8)
+        a[..., 3] = 255
+        b = orc.gaussian_blur(a, 1.0, procs=16)
+    elif case == "dark_blur":
+        a = (_photo_like(w, h, 2) // 16).astype(np.uint8)
+        a[..., 3] = 255
+        b = orc.gaussian_blur(a, 1.0, procs=16)
+    elif case == "flat_noisy":
+        a = np.full((h, w, 4), 250, np.uint8)
+        a[..., 3] = 255
+        b = a.copy()
+        b[..., :3] = np.clip(250 + rng.integers(-6, 6, (h, w, 3)), 0, 255)
+    elif case == "half_bright_half_dark":
+        a = np.full((h, w, 4), 255, np.uint8)
+        yy = np.arange(h)[:, None]
+        a[..., :3] = np.where((yy // 37) % 2 == 0, 252, 3)[..., None]        # bands shorter than a wave's segment
+        a[:, w // 2:, :3] = 255 - a[:, w // 2:, :3]
+        b = a.copy()
+        b[..., :3] = np.clip(a[..., :3].astype(int) + rng.integers(-5, 6, (h, w, 3)), 0, 255)
+    elif case == "translucent":
+        a = synth.noise_image(w, h, 5, alpha=True)
+        b = orc.gaussian_blur(a, 0.8, procs=16)
+        b[..., 3] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        a = _photo_like(w, h, 4)
+        b = orc.gaussian_blur(a, 1.5, procs=16)
+    want = orc.ssim(a, b, procs=32)
+    if case == "strided_views":
+        pa = torch.from_numpy(np.ascontiguousarray(np.pad(a, ((0, 0), (2, 1), (0, 0))))).cuda()[:, 2: 2 + w]
+        pb = torch.from_numpy(np.ascontiguousarray(np.pad(b, ((0, 0), (1, 3), (0, 0))))).cuda()[:, 1: 1 + w]
+        xa, xb = pa, pb
+    else:
+        xa, xb = a, b
+    exact = ctx.SSIM(xa, xb)
+    assert abs(exact - want) <= SSIM_TOL
+    ctx.set_ssim_mode(True)
+    try:
+        fast = ctx.SSIM(xa, xb)
+        assert ctx.last_kernel(fennec_amd.PROF_SSIM) == "windowed_ssim_march2f_kernel"
+        assert abs(fast - want) <= SSIM_FAST_TOL, (case, fast, want, fast - want)
+        # through the enqueue form (config 4's flow) the same number
+        da, db = (xa, xb) if case == "strided_views" else (torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+        ctx.ssim_enqueue(da, db)
+        assert ctx.fetch_result() == fast
+        # planes below the two-column kernel's range keep the fp64 kernels whatever the mode
+        small_a, small_b = np.ascontiguousarray(a[:600, :800]), np.ascontiguousarray(b[:600, :800])
+        assert abs(ctx.SSIM(small_a, small_b) - orc.ssim(small_a, small_b, procs=8)) <= SSIM_TOL
+    finally:
+        ctx.set_ssim_mode(False)
+
+
+def test_ssim_mode_argument(ctx):
+    with pytest.raises(fennec_amd.FennecError):
+        ctx._chk(ctx._lib.fnx_ctx_set_ssim_mode(ctx._h, 7), "fnx_ctx_set_ssim_mode")
 
 
 # ------------------------------------------------------------------ fused blur kernel: every radius, odd shapes
