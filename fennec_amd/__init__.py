@@ -196,6 +196,7 @@ def load_library() -> C.CDLL:
         _sig(L, "fnx_jpeg_recompress", i, [ctx, _u8p, C.c_size_t, d, _f64p, _u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i), _f64p,
                                             C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
+        _sig(L, "fnx_gaussian_blur_ssim_fast", i, [ctx, i] + img + [i, i, _f64p, i, i] + img + [_f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
@@ -774,6 +775,27 @@ class Context:
                                                  d.ptr, d.stride)
             self._chk(rc, "GaussianBlur")
         return dst
+
+    def GaussianBlurSSIMFast(self, img, sigma: float, exact: bool = True, window=None, out=None):
+        """GaussianBlur(img, sigma) and SSIMFast(img, blurred) in ONE call (fnx_gaussian_blur_ssim_fast): a host image crosses
+        PCIe once each way.  -> (blurred, ssim); the bytes and the score of the two separate calls.  out: the image to write
+        (same kind and size as img) instead of a new one."""
+        if sigma <= 0:
+            raise FennecError("GaussianBlurSSIMFast: sigma <= 0 (GaussianBlur would return the image itself)")
+        s = _Img(img)
+        dst = s.like(s.w, s.h) if out is None else out
+        d = _Img(dst)
+        if (d.w, d.h, d.space) != (s.w, s.h, s.space):
+            raise FennecError("GaussianBlurSSIMFast: out must be an image of img's size in img's memory space")
+        radius, kernel = self.blurKernel(sigma)
+        k, pk = _f64(kernel)
+        wk, pw = _f64(self.gaussianKernel() if window is None else window)
+        out = C.c_double()
+        with self._ordered(img, dst):
+            self._chk(self._lib.fnx_gaussian_blur_ssim_fast(self._h, s.space, s.ptr, s.stride, s.w, s.h, pk, radius,
+                                                            FNX_BLUR_EXACT if exact else FNX_BLUR_FAST, d.ptr, d.stride, pw, C.byref(out)),
+                      "GaussianBlurSSIMFast")
+        return dst, float(out.value)
 
     def blur3x3(self, img):
         """effects.go:116 gaussianBlur3x3.  A strided / cropped view is a Go SubImage here (as for Sharpen / AdaptiveSharpen):

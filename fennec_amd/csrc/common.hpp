@@ -290,6 +290,7 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
               DevOut *out);
 // Copy a staged output back (if host) and synchronise when `space` is host.
 int finish(fnx_ctx *ctx, int space, DevOut *out);
+int finish_enqueue(fnx_ctx *ctx, int space, DevOut *out);   // the copy back without the wait
 // fnx_ctx_profile hooks: bracket the launch of a profiled kernel (no-ops when profiling is off)
 // Events carried by ONE dispatch (hipExtLaunchKernelGGL's startEvent / stopEvent): they ride on the kernel packet's own
 // completion signal, so neither costs a barrier packet on the stream.  hipEventRecord before and after a launch is two

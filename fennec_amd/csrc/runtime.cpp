@@ -291,8 +291,10 @@ int stage_in(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, in
     int pitch = pitch16(w);
     void *d = nullptr;
     FNX_TRY(scratch(ctx, slot, size_t(pitch) * h + 16, &d));
-    FNX_HIP(hipMemcpy2DAsync(d, pitch, src, sstride, size_t(w) * 4, h, hipMemcpyHostToDevice,
-                             ctx->stream));
+    // a tight image (image.NewNRGBA: stride = 4 w) goes up as ONE linear copy: the runtime's 2-D path for pageable memory
+    // stages row by row
+    if (sstride == pitch) FNX_HIP(hipMemcpyAsync(d, src, size_t(pitch) * h, hipMemcpyHostToDevice, ctx->stream));
+    else FNX_HIP(hipMemcpy2DAsync(d, pitch, src, sstride, size_t(w) * 4, h, hipMemcpyHostToDevice, ctx->stream));
     out->p = static_cast<const uint8_t *>(d);
     out->stride = pitch;
     return FNX_OK;
@@ -354,11 +356,22 @@ int stage_out(fnx_ctx *ctx, int space, uint8_t *dst, int dstride, int w, int h, 
 int finish(fnx_ctx *ctx, int space, DevOut *out)
 {
     if (space == FNX_DEVICE) return FNX_OK;
-    if (out && out->host && out->w > 0 && out->h > 0) {
-        FNX_HIP(hipMemcpy2DAsync(out->host, out->hstride, out->p, out->stride, size_t(out->w) * 4,
-                                 out->h, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    FNX_TRY(finish_enqueue(ctx, space, out));
     FNX_HIP(hipStreamSynchronize(ctx->stream));
+    return FNX_OK;
+}
+
+// the copy back of a staged output, enqueued on the ctx's stream without waiting for it
+int finish_enqueue(fnx_ctx *ctx, int space, DevOut *out)
+{
+    if (space == FNX_DEVICE) return FNX_OK;
+    if (out && out->host && out->w > 0 && out->h > 0) {
+        if (out->hstride == out->stride)
+            FNX_HIP(hipMemcpyAsync(out->host, out->p, size_t(out->stride) * out->h, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            FNX_HIP(hipMemcpy2DAsync(out->host, out->hstride, out->p, out->stride, size_t(out->w) * 4,
+                                     out->h, hipMemcpyDeviceToHost, ctx->stream));
+    }
     return FNX_OK;
 }
 

@@ -388,6 +388,14 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
  * 3.6 or boxes above 256 px: long side under ~1850 px or over 8192 px; with FNX_BLUR_EXACT also a kernel
  * with negative taps or gain > 1) run the two ops back to back.  With FNX_BLUR_EXACT the blurred images
  * are bit-exact and the scores are computed from exactly those images.  The _enqueue form pairs with fnx_results_fetch. */
+/* The same for ONE image in either space: dst = GaussianBlur(src) and *ssim = SSIMFast(src, dst) -- bytes and score those of
+ * fnx_gaussian_blur followed by fnx_ssim_fast.  With FNX_HOST the image crosses PCIe ONCE each way (source up, blurred
+ * image down: 2 x 33 MB at 4K); the two separate calls upload the source twice and the blurred image once more
+ * (4 x 33 MB), and PCIe is all a host-space call costs (0.6 ms per 33 MB against 20 us of kernels).  What the cgo
+ * shim's GaussianBlurScored calls.  Blocking; requires an empty result FIFO. */
+int fnx_gaussian_blur_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
+                                const double *kernel, int radius, int flags, uint8_t *dst, int dstride,
+                                const double *window /* 64 */, double *ssim);
 int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride,
                                       int w, int h, const double *kernel, int radius, int flags,
                                       uint8_t *const *dsts, int dstride, const double *window,

@@ -958,6 +958,42 @@ def test_config4_8k_adaptive_sharpen_ssim(ctx, orc):
     assert ctx.SSIM(img, sharp) == s                       # (and the default is the fp64 kernel again)
 
 
+def test_gaussian_blur_ssim_fast_one_call(ctx, orc):
+    """r6: fnx_gaussian_blur_ssim_fast -- GaussianBlur + SSIMFast(src, blurred) of one image in one call (a host image
+    crosses PCIe once each way): the bytes and the score of the two separate calls, host arrays (tight and pitched), device
+    tensors, sizes on both sides of the one-pass kernel's range and pixelSSIM's."""
+    import torch
+    for (w, h, sigma) in [(3840, 2160, 2.0), (2048, 1536, 1.2), (640, 480, 2.0), (1920, 1080, 3.0), (5, 5, 1.0), (7, 300, 0.8), (517, 389, 2.0)]:
+        img = synth.large_photo(w, h, w % 7)
+        for exact in (True, False):
+            want_b = ctx.GaussianBlur(img, sigma, exact=exact)
+            want_s = ctx.SSIMFast(img, want_b)
+            got_b, got_s = ctx.GaussianBlurSSIMFast(img, sigma, exact=exact)
+            assert np.array_equal(got_b, want_b) and got_s == want_s, (w, h, sigma, exact)
+        if w * h <= 2048 * 1536:
+            ob = orc.gaussian_blur(img, sigma, procs=8)
+            got_b, got_s = ctx.GaussianBlurSSIMFast(img, sigma)
+            assert np.array_equal(got_b, ob) and abs(got_s - orc.ssim_fast(img, ob)) <= SSIM_TOL
+        want_b = ctx.GaussianBlur(img, sigma, exact=True)
+        if w >= 8 and h >= 8:        # (below that SSIMFast is pixelSSIM, which walks the FLAT Pix slices: a pitched source against a tight result is the reference's panic)
+            pitched = np.ascontiguousarray(np.pad(img, ((0, 0), (1, 2), (0, 0))))[:, 1: 1 + w]      # a host view with row padding
+            got_b, got_s = ctx.GaussianBlurSSIMFast(pitched, sigma)
+            assert np.array_equal(got_b, want_b) and got_s == ctx.SSIMFast(img, want_b)
+            reuse = np.empty_like(img)
+            rb, rs = ctx.GaussianBlurSSIMFast(img, sigma, out=reuse)
+            assert rb is reuse and np.array_equal(reuse, want_b) and rs == got_s
+        d = torch.from_numpy(img).cuda()
+        db, ds = ctx.GaussianBlurSSIMFast(d, sigma)
+        ctx.sync()
+        assert np.array_equal(db.cpu().numpy(), want_b) and ds == ctx.SSIMFast(img, want_b)
+    # an enqueued result waiting in the FIFO: the blocking call refuses instead of mixing results up
+    d = torch.from_numpy(synth.large_photo(3840, 2160, 1)).cuda()
+    ctx.ssim_enqueue(d, d)
+    with pytest.raises(fennec_amd.FennecError):
+        ctx.GaussianBlurSSIMFast(d, 2.0)
+    assert ctx.fetch_result() == 1.0
+
+
 SSIM_FAST_TOL = 1e-6
 
 
