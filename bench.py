@@ -1050,6 +1050,7 @@ def other_workload_line(args, embedded: bool = False):
         # tells which: down-scale first, then MSSSIM's implicit up-scale.
         ctx.profile(fennec_amd.PROF_RESIZE)
         _small = ctx.lanczosResize(imgs[0], W // 2, H // 2)
+        small0 = _small
         ctx.MSSSIM(imgs[0], _small)
         _n = 0
         while True:
@@ -1327,7 +1328,10 @@ def other_workload_line(args, embedded: bool = False):
         out["roofline_step"] = out["roofline"]
         S_img = 4.0 * W * H
         if wl == "config4":
-            ms = float(np.mean(kms["windowed_ssim"]))
+            ms_flow = float(np.mean(kms["windowed_ssim"]))   # in the workload's flow: AdaptiveSharpen of the next image runs beside it
+            sharp0 = ctx.AdaptiveSharpen(imgs[0], 0.5)
+            ctx.set_ssim_mode(ssim_fast[0])
+            ms = kernel_alone_ms(ctx, lambda: ctx.SSIM(imgs[0], sharp0), fennec_amd.PROF_SSIM)
             abytes = 2.0 * S_img                      # SSIM reads both full-size images once
             g = abytes / (ms * 1e-3) / 1e9
             # the kernel is fp64-VALU bound: 4 moments x 8 taps x 2 passes of fp64 FMA per window
@@ -1343,18 +1347,26 @@ def other_workload_line(args, embedded: bool = False):
                                "traffic": committed_traffic_named(name_main, "config4"),
                                "traffic_file": source_file("traffic"),
                                "traffic_source": "the newest profiles/*config4*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
-                               "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": len(kms["windowed_ssim"]),
+                               "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4), "launches_timed": 9,
+                               "avg_launch_ms_is": "the kernel ALONE (one call at a time after the timed region): what `achieved`, `frac`, `traffic` and "
+                                                   "`hbm_frac_measured` are all about -- one collection, one context",
+                               "avg_launch_ms_in_flow": round(ms_flow, 4), "launches_timed_in_flow": len(kms["windowed_ssim"]),
                                "fma_floor_ms": round(win * 64 / (78.6e12 if fastk else 39.3e12) * 1e3, 4),
                                "note": ("bound by instruction issue: 64 FMA per window -- the floor shown is at 78.6 T fp32 FMA/s, which needs "
                                         "packed instructions AND more than two waves per SIMD; at two, every VALU instruction costs a quad-cycle "
                                         "(experiments/ssimf/pkrate.hip)" if fastk else
                                         "bound in practice by fp64 VALU issue + LDS (64 fp64 FMA per window at 39.3 T FMA/s is the floor shown)")
                                        + "; bytes are SURVEY 8(d)'s 2*S per pair"}
+            tr4 = out["roofline"]["traffic"]
+            out["roofline"]["hbm_frac_measured"] = round(tr4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr4 else None
         else:
             means = {k: float(np.mean(v)) for k, v in kms.items() if v}
             fused = "resize_fused_down" in kms
             dom = "resize_fused_down" if fused else next(iter(kms))
-            ms = means.get(dom, float("nan"))
+            ms_flow = means.get(dom, float("nan"))     # in the workload's flow: the other worker streams' kernels run beside it
+            # the same downscale alone, the plan in the state the workload left it in (on the ramp: its tie-dense cool-down)
+            ms = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(imgs[0], 1920, 1080), fennec_amd.PROF_RESIZE)
+            ms_up_alone = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(small0, W, H), fennec_amd.PROF_RESIZE) if small0 is not None else None
             # fused: reads S(4K), writes the 1080p result; two-pass: resizeH reads S(4K), writes the 1920 x 2160 intermediate
             abytes = S_img + S_img / 4 if fused else S_img + S_img / 2
             g = abytes / (ms * 1e-3) / 1e9
@@ -1381,12 +1393,18 @@ def other_workload_line(args, embedded: bool = False):
                                "traffic_file": down_file if fused else source_file("traffic"),
                                "traffic_source": "the newest profiles/*config3*_traffic.json (named in traffic_file): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (committed, not measured in this run)",
                                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(ms, 4),
-                               "launches_timed": len(kms[dom]),
-                               "resize_kernels_ms": {k: round(v, 4) for k, v in means.items()},
+                               "launches_timed": 9,
+                               "avg_launch_ms_is": "the kernel ALONE (one call at a time after the timed region, the plan in the state the workload left): "
+                                                   "what `achieved`, `frac`, `traffic` and `hbm_frac_measured` are all about -- one collection, one context",
+                               "avg_launch_ms_in_flow": round(ms_flow, 4), "launches_timed_in_flow": len(kms[dom]),
+                               "upscale_alone_ms": round(ms_up_alone, 4) if ms_up_alone else None,
+                               "resize_kernels_ms_in_flow": {k: round(v, 4) for k, v in means.items()},
                                "note": "SURVEY 8(d)'s synthetic ramp makes every output of the 2:1 downscale an exact rounding tie, so this "
                                        "kernel runs its fp64 reference-order loops (VALU-bound); the step is 7-9 kernels per image (1-2 launches "
                                        "per resize, level 0 + level 1 in one pass, pyramid, boxes, windows, finish): see roofline_step for the "
                                        "whole step against SURVEY 8(d)'s 193.4 MB"}
+            tr3 = out["roofline"]["traffic"]
+            out["roofline"]["hbm_frac_measured"] = round(tr3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr3 else None
             if rank == 0:
                 out["roofline"]["photo_like"] = resize_photo_like(ctx, W, H)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1517,6 +1535,30 @@ def committed_traffic_named(kernel_substr: str, tag: str):
         except Exception:
             continue
     return None
+
+
+def kernel_alone_ms(ctx, fn, mask, reps=9, warm_s=0.15):
+    """The profiled kernel(s) of ONE call at a time with nothing else on the device (the call's stream drained between calls):
+    the duration a single-context rocprofv3 collection sees, and the one its counter traffic belongs with."""
+    import fennec_amd
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        fn()
+        ctx.sync()
+    ctx.profile(mask)
+    ts = []
+    for _ in range(reps):
+        fn()
+        ctx.sync()
+        t = 0.0
+        while True:
+            try:
+                t += ctx.kernel_ms()
+            except fennec_amd.FennecError:
+                break
+        ts.append(t)
+    ctx.profile(0)
+    return float(np.mean(ts))
 
 
 def resize_photo_like(ctx, W, H):
