@@ -148,7 +148,8 @@ def main() -> int:
                          "codec decodes the source and encodes the winner only")
     ap.add_argument("--no-batch", action="store_true", help="skip the `batch` object (CompressBatch images/s over --batch-items 4K JPEGs)")
     ap.add_argument("--batch-items", type=int, default=4096, help="items of the `batch` job (BASELINE config 5: 4096)")
-    ap.add_argument("--batch-files", type=int, default=64, help="distinct synthetic 4K JPEG files the items cycle through")
+    ap.add_argument("--batch-files", type=int, default=512,
+                    help="distinct synthetic 4K JPEG files the items cycle through (256 distinct images x 2 qualities; 3.2 GB of host memory)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5", "analyze", "palette", "scale-search"],
                     help="BASELINE.json config to run; config2 (default) is the headline metric")
     args = ap.parse_args()
@@ -770,12 +771,16 @@ def batch_metric(args, rank, world, local_rank, red_dev, ctx0) -> dict:
     # the same file list on every rank (any rank may take any item)
     files = []
     nimg = (n_files + 1) // 2
-    for k, img in zip(range(nimg), synth.large_photo_batch(W4K, H4K, range(nimg))):
-        d = torch.from_numpy(img).cuda()
+    base = torch.from_numpy(synth.large_photo(W4K, H4K, 0)).cuda()
+    for k in range(nimg):
+        # large_photo(w, h, k) = large_photo(w, h, 0) + a per-channel salt mod 256 (synth.large_photo_batch): uint8 wrap-around on the device
+        salt = torch.tensor([(17 * k) % 256, (31 * k) % 256, (5 * k) % 256, 0], dtype=torch.uint8, device=base.device)
+        d = base + salt
         for q in (92, 85):
             if len(files) < n_files:
                 files.append(ctx0.jpeg_encode(d, q))
         del d
+    del base
     states = {}
 
     def make_state(wid):
