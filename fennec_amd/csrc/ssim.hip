@@ -1406,9 +1406,12 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
         s_o[64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int nrows = nwin + 7;
-    f32x2 m0a[8], m0q[8], m1a[8], m1q[8];                         // rings: column 0 / 1, (mx, my) and (E[x^2 + y^2], E[d^2])
+    // rings, each entry the pair (column 0, column 1): mx, my, E[x^2 + y^2], E[d^2].  The horizontal pass pairs QUANTITIES
+    // (an LDS entry is (x, y, x^2 + y^2, d^2) of one pixel); its four results are transposed once per row (v_pk_mov) so that
+    // the vertical pass and the whole window formula run on column pairs with no operand shuffled again.
+    f32x2 rmx[8], rmy[8], rms[8], rmd[8];
 #pragma unroll
-    for (int s = 0; s < 8; s++) m0a[s] = m0q[s] = m1a[s] = m1q[s] = (f32x2){0.f, 0.f};
+    for (int s = 0; s < 8; s++) rmx[s] = rmy[s] = rms[s] = rmd[s] = (f32x2){0.f, 0.f};
     typedef __attribute__((address_space(1))) const u32x2 g_u32x2;
     // The centre c: the mean milli-luminance of three rows of both images as this WAVE sees them (first, middle and last
     // pixel row of its segment, 128 columns), an integer.  Any constant gives the same moments in exact arithmetic; one near
@@ -1444,9 +1447,9 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
     // units: milli-luminance / 1024
     const float CU = static_cast<float>(centre) * (1.0f / 1024.0f);    // exact: an integer below 2^18 times 2^-10
     constexpr float C1U = 6.5025e6f / 1048576.0f, C2U = 58.5225e6f / 1048576.0f;
-    float acc0 = 0.f, acc1 = 0.f;                                 // sum of (1 - value) over the current group of rows
+    f32x2 acc = {0.f, 0.f};                                       // sum of (1 - value) over the current group of rows, per column
     double tot0 = 0.0, tot1 = 0.0;
-    float P0 = 0.f, Q0 = 1.f, P1 = 0.f, Q1 = 1.f;                 // the window of the row before, not yet divided
+    f32x2 PP = {0.f, 0.f}, QQ = {1.f, 1.f};                       // the windows of the row before, not yet divided
 
     auto stage = [&](const int i, auto pc) {
         constexpr int p = decltype(pc)::value;
@@ -1471,22 +1474,24 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
         for (int q = 0; q < 9; q++) tap[q] = (q & 1) ? s_o[lane + q / 2] : s_e[lane + q / 2];
         __builtin_amdgcn_wave_barrier();                          // (the next stage() overwrites the row: after these reads, in order)
     };
-    // numerator and denominator of (1 - value): value = (t1 - md2)(den2 - vd) / (t1 den2)
-    auto numden = [&](const f32x2 A, const f32x2 B, float &num, float &den) {
-        const f32x2 SQ = A * A;
-        const f32x2 AB = A + (f32x2){CU, CU};
-        const float md = A.x - A.y;
-        const float t1 = fmaf(AB.x, AB.x, fmaf(AB.y, AB.y, C1U));
-        const float md2 = md * md;
-        const float den2 = ((B.x + C2U) - SQ.x) - SQ.y;
-        const float vd = B.y - md2;
+    // numerator and denominator of (1 - value) of the two columns' windows: value = (t1 - md2)(den2 - vd) / (t1 den2)
+    auto numden = [&](const f32x2 MX, const f32x2 MY, const f32x2 M2, const f32x2 M3, f32x2 &num, f32x2 &den) {
+        const f32x2 cu = {CU, CU}, c1 = {C1U, C1U}, c2 = {C2U, C2U};
+        const f32x2 sq = __builtin_elementwise_fma(MY, MY, MX * MX);              // mx^2 + my^2
+        const f32x2 ma = MX + cu, mb = MY + cu;
+        const f32x2 t1 = __builtin_elementwise_fma(ma, ma, __builtin_elementwise_fma(mb, mb, c1));
+        const f32x2 md = MX - MY;
+        const f32x2 md2 = md * md;
+        const f32x2 den2 = (M2 + c2) - sq;
+        const f32x2 vd = M3 - md2;
         // 1 - (t1 - md2)(den2 - vd) / (t1 den2) = (md2 den2 + vd (t1 - md2)) / (t1 den2): no cancellation left in the quotient
-        num = fmaf(md2, den2, vd * (t1 - md2));
+        num = __builtin_elementwise_fma(md2, den2, vd * (t1 - md2));
         den = t1 * den2;
     };
-    auto quot = [&](float num, float den) {
-        float rc = __builtin_amdgcn_rcpf(den);
-        rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
+    auto quot = [&](const f32x2 num, const f32x2 den) {
+        f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const f32x2 one = {1.0f, 1.0f};
+        rc = __builtin_elementwise_fma(__builtin_elementwise_fma(-den, rc, one), rc, rc);
         return num * rc;
     };
     // FIRST: the segment's first eight rows (the ring fills: only p == 7 completes a window; nrows >= 8 always).  GUARD: the
@@ -1520,36 +1525,35 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
         }
         stage(i + 1, std::integral_constant<int, (p + 1) & 7>{});   // (tap[] holds row i: the LDS row is free)
         if (PRE) fetch();
+        // quantity pairs -> column pairs (two v_pk_mov_b32 per 2 x 2 transpose)
+        const f32x2 hx = __builtin_shufflevector(h0a, h1a, 0, 2), hy = __builtin_shufflevector(h0a, h1a, 1, 3);
+        const f32x2 hs = __builtin_shufflevector(h0q, h1q, 0, 2), hd = __builtin_shufflevector(h0q, h1q, 1, 3);
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const int k = (p - s) & 7;
             const f32x2 r1 = {a.rowf1[k], a.rowf1[k]}, r2 = {a.rowf2[k], a.rowf2[k]};
             if (k == 0) {
-                m0a[s] = h0a * r1; m0q[s] = h0q * r2; m1a[s] = h1a * r1; m1q[s] = h1q * r2;
+                rmx[s] = hx * r1; rmy[s] = hy * r1; rms[s] = hs * r2; rmd[s] = hd * r2;
             } else {
-                m0a[s] = __builtin_elementwise_fma(h0a, r1, m0a[s]); m0q[s] = __builtin_elementwise_fma(h0q, r2, m0q[s]);
-                m1a[s] = __builtin_elementwise_fma(h1a, r1, m1a[s]); m1q[s] = __builtin_elementwise_fma(h1q, r2, m1q[s]);
+                rmx[s] = __builtin_elementwise_fma(hx, r1, rmx[s]); rmy[s] = __builtin_elementwise_fma(hy, r1, rmy[s]);
+                rms[s] = __builtin_elementwise_fma(hs, r2, rms[s]); rmd[s] = __builtin_elementwise_fma(hd, r2, rmd[s]);
             }
         }
         if (FIRST && p != 7) return;
         const int s = (p + 1) & 7;
-        float n0, d0, n1, d1;
-        numden(m0a[s], m0q[s], n0, d0);
-        numden(m1a[s], m1q[s], n1, d1);
+        f32x2 nn, dd;
+        numden(rmx[s], rmy[s], rms[s], rmd[s], nn, dd);
         if (FIRST) {
-            acc0 += quot(n0, d0);
-            acc1 += quot(n1, d1);
+            acc += quot(nn, dd);
         } else if ((p & 1) == 0) {
             // (a full group ends on an odd p: only the guarded group can end on an even one)
             if (GUARD && i == nrows - 1) {                        // wave-uniform: the segment's last row has no partner
-                acc0 += quot(n0, d0);
-                acc1 += quot(n1, d1);
+                acc += quot(nn, dd);
             } else {
-                P0 = n0; Q0 = d0; P1 = n1; Q1 = d1;
+                PP = nn; QQ = dd;
             }
         } else {
-            acc0 += quot(fmaf(P0, d0, n0 * Q0), Q0 * d0);
-            acc1 += quot(fmaf(P1, d1, n1 * Q1), Q1 * d1);
+            acc += quot(__builtin_elementwise_fma(PP, dd, nn * QQ), QQ * dd);
         }
     };
     auto group = [&](const int r, auto guardc, auto firstc) {
@@ -1557,8 +1561,8 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
         rowbody(r, std::integral_constant<int, 2>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 3>{}, guardc, firstc);
         rowbody(r, std::integral_constant<int, 4>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 5>{}, guardc, firstc);
         rowbody(r, std::integral_constant<int, 6>{}, guardc, firstc); rowbody(r, std::integral_constant<int, 7>{}, guardc, firstc);
-        tot0 += static_cast<double>(acc0); tot1 += static_cast<double>(acc1);
-        acc0 = acc1 = 0.f;
+        tot0 += static_cast<double>(acc.x); tot1 += static_cast<double>(acc.y);
+        acc = (f32x2){0.f, 0.f};
     };
     stage(0, std::integral_constant<int, 0>{});
     if (PRE) fetch();
