@@ -117,6 +117,9 @@ def main() -> int:
                          "alone and `roofline` describes it; 2: step s+1 is enqueued (on a second context = stream, into "
                          "a second set of destinations) before step s's results are fetched (+7 %%; the default line "
                          "reports that rate as `pipelined`)")
+    ap.add_argument("--config3-chunk", type=int, default=4,
+                    help="config 3: images per batched call (fnx_lanczos_resize_batch + fennec_MSSSIM_batch_enqueue: one set of resize "
+                         "launches per chunk); 1 = one call per image as in rounds 2-5")
     ap.add_argument("--ssim-mode", default="fast", choices=["fast", "exact"],
                     help="config 4's full-resolution SSIM: fast = FNX_SSIM_FAST (fp32 moments, |delta| <= 1e-6: SURVEY Appendix A's tolerance for "
                          "fp32-moment paths), exact = the default of the library (fp64 moments, <= 1e-9); the other one is reported beside it")
@@ -1094,7 +1097,40 @@ def other_workload_line(args, embedded: bool = False):
                 fetch3(c, out)
 
         prof_on = [False]
-        step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), submit3, drain3, args.contexts, args.threads)
+        CH = max(1, min(getattr(args, "config3_chunk", 8), len(imgs)))
+        if CH > 1:
+            # r6: a worker's images go through the batched entry points CH at a time -- ONE set of resize launches per chunk and
+            # direction (a 4K resize alone is ~700 workgroups: one under-filled round), one FIFO entry per chunk
+            nch = (len(imgs) + CH - 1) // CH
+            chunks = [imgs[k * CH:(k + 1) * CH] for k in range(nch)]
+            small_bufs = [[torch.empty((H // 2, W // 2, 4), dtype=torch.uint8, device="cuda") for _ in ch] for ch in chunks]
+            QDC = 2                                          # chunks in flight per context
+
+            def fetch3c(c, out):
+                ci, _ = pend3[id(c)].pop(0)
+                out[ci] = c.fetch_results(len(chunks[ci]))
+                if c is ctx and prof_on[0]:
+                    for k in kms:
+                        kms[k].append(c.kernel_ms())
+
+            def submit3c(c, ci, out):
+                pend = pend3.setdefault(id(c), [])
+                smalls = c.lanczosResizeBatch(chunks[ci], W // 2, H // 2, outs=small_bufs[ci])
+                c.msssim_batch_enqueue(chunks[ci], smalls)   # ssim.go:320-322: the smalls go back to 4K in one batched resize
+                pend.append((ci, smalls))
+                if len(pend) > QDC:
+                    fetch3c(c, out)
+
+            def drain3c(c, out):
+                while pend3.get(id(c)):
+                    fetch3c(c, out)
+
+            step_chunks = _pooled_queue_step(fennec_amd, local_rank, ctx, nch, submit3c, drain3c, args.contexts, args.threads)
+
+            def step():
+                return [v for part in step_chunks() for v in part]
+        else:
+            step = _pooled_queue_step(fennec_amd, local_rank, ctx, len(imgs), submit3, drain3, args.contexts, args.threads)
         prof_mask = fennec_amd.PROF_RESIZE
         metric, unit, units_per_step = "megapixels/sec: 4K -> 1920x1080 Lanczos-3 downscale + MS-SSIM", "MP/s", B * W * H / 1e6
         name = "config3: 4K lanczosResize(1920x1080) + MSSSIM(4K, 1080p)"
@@ -1325,6 +1361,9 @@ def other_workload_line(args, embedded: bool = False):
     }
     if wl in ("config3", "config4"):
         out["config"]["contexts_per_gpu"] = max(1, min(args.contexts, B))
+        if wl == "config3":
+            out["config"]["calls"] = (f"batched: fnx_lanczos_resize_batch + fennec_MSSSIM_batch_enqueue, {CH} images per call" if CH > 1
+                                      else "one lanczosResize + one MSSSIM_enqueue per image")
         out["config"]["prewarm"] = f"{args.prewarm} s of untimed steps before the {args.warmup} warm-up steps (GPU clock ramp)"
         out["config"]["host_threads_per_gpu"] = max(1, min(args.threads or args.contexts, args.contexts, B))
         out["value_before_prewarm"] = {"value": round(cold * world, 2), "unit": unit,
@@ -1370,8 +1409,16 @@ def other_workload_line(args, embedded: bool = False):
             dom = "resize_fused_down" if fused else next(iter(kms))
             ms_flow = means.get(dom, float("nan"))     # in the workload's flow: the other worker streams' kernels run beside it
             # the same downscale alone, the plan in the state the workload left it in (on the ramp: its tie-dense cool-down)
-            ms = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(imgs[0], 1920, 1080), fennec_amd.PROF_RESIZE)
-            ms_up_alone = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(small0, W, H), fennec_amd.PROF_RESIZE) if small0 is not None else None
+            if CH > 1:
+                ups = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(CH)]
+                ms = kernel_alone_ms(ctx, lambda: ctx.lanczosResizeBatch(chunks[0], 1920, 1080, outs=small_bufs[0]), fennec_amd.PROF_RESIZE) / CH
+                ms_up_alone = kernel_alone_ms(ctx, lambda: ctx.lanczosResizeBatch(small_bufs[0], W, H, outs=ups), fennec_amd.PROF_RESIZE) / CH
+                del ups
+                ms_flow /= CH
+                means = {k: v / CH for k, v in means.items()}
+            else:
+                ms = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(imgs[0], 1920, 1080), fennec_amd.PROF_RESIZE)
+                ms_up_alone = kernel_alone_ms(ctx, lambda: ctx.lanczosResize(small0, W, H), fennec_amd.PROF_RESIZE) if small0 is not None else None
             # fused: reads S(4K), writes the 1080p result; two-pass: resizeH reads S(4K), writes the 1920 x 2160 intermediate
             abytes = S_img + S_img / 4 if fused else S_img + S_img / 2
             g = abytes / (ms * 1e-3) / 1e9
@@ -1403,6 +1450,8 @@ def other_workload_line(args, embedded: bool = False):
                                                    "what `achieved`, `frac`, `traffic` and `hbm_frac_measured` are all about -- one collection, one context",
                                "avg_launch_ms_in_flow": round(ms_flow, 4), "launches_timed_in_flow": len(kms[dom]),
                                "upscale_alone_ms": round(ms_up_alone, 4) if ms_up_alone else None,
+                               "images_per_launch": CH,
+                               "per": "image (a launch holds images_per_launch of them: durations and bytes are the launch's divided by that)",
                                "resize_kernels_ms_in_flow": {k: round(v, 4) for k, v in means.items()},
                                "note": "SURVEY 8(d)'s synthetic ramp makes every output of the 2:1 downscale an exact rounding tie, so this "
                                        "kernel runs its fp64 reference-order loops (VALU-bound); the step is 7-9 kernels per image (1-2 launches "

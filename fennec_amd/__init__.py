@@ -197,6 +197,11 @@ def load_library() -> C.CDLL:
                                             C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast", i, [ctx, i] + img + [i, i, _f64p, i, i] + img + [_f64p, _f64p])
+        _sig(L, "fnx_msssim_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
+        _sig(L, "fennec_MSSSIM_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.POINTER(C.c_void_p), i, i, i])
+        _sig(L, "fnx_lanczos_resize_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p,
+                                                C.POINTER(C.c_void_p), i, i, i])
+        _sig(L, "fennec_lanczosResizeBatch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.POINTER(C.c_void_p), i, i, i])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch", i,
              [ctx, i, C.POINTER(C.c_void_p), i, i, i, _f64p, i, i, C.POINTER(C.c_void_p), i, _f64p, _f64p])
         _sig(L, "fnx_gaussian_blur_ssim_fast_batch_enqueue", i,
@@ -503,6 +508,28 @@ class Context:
         with self._ordered(img1, img2):
             self._chk(self._lib.fennec_MSSSIM_enqueue(self._h, a.ptr, a.stride, a.w, a.h, b.ptr, b.stride, b.w, b.h),
                       "fennec_MSSSIM_enqueue")
+
+    def msssim_batch_enqueue(self, imgs1, imgs2):
+        """fennec_MSSSIM_batch_enqueue: n device pairs (every imgs1[i] of one size, every imgs2[i] of one size) as ONE FIFO
+        entry; the imgs2 are resized to imgs1's dims by one batched lanczosResize when the dims differ.  fetch_results(n)."""
+        va, vb = [_Img(t) for t in imgs1], [_Img(t) for t in imgs2]
+        n = len(va)
+        if n == 0 or n != len(vb) or any(v.space != FNX_DEVICE for v in va + vb):
+            raise FennecError("msssim_batch_enqueue takes two equally long, non-empty lists of device tensors")
+        a0, b0 = va[0], vb[0]
+        if any((v.w, v.h, v.stride) != (a0.w, a0.h, a0.stride) for v in va) or any((v.w, v.h, v.stride) != (b0.w, b0.h, b0.stride) for v in vb):
+            raise FennecError("every image of a side must share width, height and stride")
+        pa = (C.c_void_p * n)(*[v.ptr for v in va])
+        pb = (C.c_void_p * n)(*[v.ptr for v in vb])
+        with self._ordered(*imgs1, *imgs2):
+            self._chk(self._lib.fennec_MSSSIM_batch_enqueue(self._h, n, pa, a0.stride, a0.w, a0.h, pb, b0.stride, b0.w, b0.h),
+                      "fennec_MSSSIM_batch_enqueue")
+
+    def fetch_results(self, n: int) -> np.ndarray:
+        """The oldest FIFO entry's n values (fnx_results_fetch)."""
+        out = np.empty(n, dtype=np.float64)
+        self._chk(self._lib.fnx_results_fetch(self._h, n, out.ctypes.data_as(_f64p)), "fnx_results_fetch")
+        return out
 
     def fetch_result(self) -> float:
         """The oldest enqueued scalar result (fnx_results_fetch)."""
@@ -847,6 +874,30 @@ class Context:
             self._chk(self._lib.fennec_lanczosResize(self._h, space, s.ptr, s.stride, s.w, s.h, d.ptr,
                                                      d.stride, dstW, dstH), "lanczosResize")
         return dst
+
+    def lanczosResizeBatch(self, imgs, dstW: int, dstH: int, outs=None):
+        """n same-sized device images through ONE set of launches (fennec_lanczosResizeBatch): the bytes of n lanczosResize
+        calls; enqueued (sync() or a later blocking call waits)."""
+        views = [_Img(t) for t in imgs]
+        if not views or any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("lanczosResizeBatch takes a non-empty list of device tensors")
+        v0 = views[0]
+        if any((v.w, v.h, v.stride) != (v0.w, v0.h, v0.stride) for v in views):
+            raise FennecError("every image of a batch must share width, height and stride")
+        if v0.w <= 0 or v0.h <= 0 or dstW <= 0 or dstH <= 0:
+            return [v0.like(0, 0) for _ in views]
+        if outs is None:
+            outs = [v0.like(dstW, dstH) for _ in views]
+        ov = [_Img(t) for t in outs]
+        if len(ov) != len(views) or any((o.w, o.h, o.stride, o.space) != (dstW, dstH, ov[0].stride, FNX_DEVICE) for o in ov):
+            raise FennecError("outs must hold one device image of dstW x dstH per input, all of one stride")
+        n = len(views)
+        srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+        dsts = (C.c_void_p * n)(*[v.ptr for v in ov])
+        with self._ordered(*imgs, *outs):
+            self._chk(self._lib.fennec_lanczosResizeBatch(self._h, n, srcs, v0.stride, v0.w, v0.h, dsts, ov[0].stride, dstW, dstH),
+                      "lanczosResizeBatch")
+        return outs
 
     def smartResize(self, img, maxW: int, maxH: int):
         """resize.go:12.  Returns `img` itself when it already fits."""

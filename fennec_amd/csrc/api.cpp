@@ -186,6 +186,7 @@ int publish_results(fnx_ctx *ctx, const double *pinned, int n)
     q.pinned = pinned;
     q.n = n;
     q.nraw = 0;
+    q.nimg = 1;
     q.tail_parity = -1;
     ctx->res_count++;
     return FNX_OK;
@@ -247,6 +248,37 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
     FNX_TRY(resize_pass(ctx, false, th, s.p, s.stride, srcW, srcH, static_cast<uint8_t *>(tmp), tp, &hint));
     FNX_TRY(resize_pass(ctx, true, tv, static_cast<const uint8_t *>(tmp), tp, dstW, srcH, d.p, d.stride, &hint));
     return finish(ctx, space, &d);
+}
+
+// n same-geometry device images through ONE set of launches where resize_fused applies (every launch then holds n images'
+// workgroups: a 4K call alone is 700 workgroups for 768-1024 slots -- one under-filled round), else image by image
+int lanczos_resize_tables_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                                const TapTable &th, const TapTable &tv, uint8_t *const *dsts, int dstride, int dstW, int dstH)
+{
+    FNX_ENTER(ctx);
+    FNX_REQUIRE(n >= 0 && (n == 0 || (srcs && dsts)), "batch arguments");
+    if (n == 0) return FNX_OK;
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
+        FNX_TRY(check_img(srcs[i], sstride, srcW, srcH, "src"));
+        FNX_TRY(check_img(dsts[i], dstride, dstW, dstH, "dst"));
+    }
+    if (n > 1 && !(srcW == dstW && srcH == dstH)) {
+        const void *hosts[2] = {srcs, dsts};
+        const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+        void *dp[2];
+        FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+        const int rc = resize_fused(ctx, th, tv, srcs[0], sstride, srcW, srcH, dsts[0], dstride, n,
+                                    static_cast<const uint8_t *const *>(dp[0]), static_cast<uint8_t *const *>(dp[1]));
+        if (rc < 0) return rc;
+        if (rc != FNX_NOOP) return FNX_OK;
+    }
+    for (int i = 0; i < n; i++) {
+        const int rc = lanczos_resize_tables(ctx, FNX_DEVICE, srcs[i], sstride, srcW, srcH, th, tv, dsts[i], dstride, dstW, dstH);
+        if (rc < 0) return rc;
+    }
+    return FNX_OK;
 }
 
 }  // namespace fnx
@@ -431,6 +463,15 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
     return fnx::lanczos_resize_tables(ctx, space, src, sstride, srcW, srcH, th, tv, dst, dstride, dstW, dstH);
 }
 
+int fnx_lanczos_resize_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                             const int32_t *offH, const int32_t *idxH, const double *wH,
+                             const int32_t *offV, const int32_t *idxV, const double *wV,
+                             uint8_t *const *dsts, int dstride, int dstW, int dstH)
+{
+    const TapTable th{offH, idxH, wH, dstW, 0}, tv{offV, idxV, wV, dstH, 0};
+    return fnx::lanczos_resize_tables_batch(ctx, n, srcs, sstride, srcW, srcH, th, tv, dsts, dstride, dstW, dstH);
+}
+
 // ---- ssim.go -----------------------------------------------------------------------
 int fnx_box_downsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
                        int srcH, uint8_t *dst, int dstride, int dstW, int dstH)
@@ -527,9 +568,11 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out)
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(ctx->res_count > 0 && n <= ctx->res_q[ctx->res_head].n, "no enqueued results of that size on this ctx");
     fnx_ctx::Pending &q = ctx->res_q[ctx->res_head];            // oldest unfetched batch
-    if (q.nraw > 0) {                                            // an enqueued MSSSIM: levels -> the weighted product
-        FNX_TRY(poll_results(q.pinned, q.nraw, [&] { return hipEventQuery(q.ev); }));
-        out[0] = msssim_combine(q.pinned, q.weights, q.nraw);
+    if (q.nraw > 0) {                                            // enqueued MSSSIMs: levels -> the weighted product, image by image
+        for (int i = 0; i < n; i++) {
+            FNX_TRY(poll_results(q.pinned + 5 * i, q.nraw, [&] { return hipEventQuery(q.ev); }));
+            out[i] = msssim_combine(q.pinned + 5 * i, q.weights, q.nraw);
+        }
     } else {
         FNX_TRY(poll_results(q.pinned, n, [&] { return hipEventQuery(q.ev); }));
         std::memcpy(out, q.pinned, sizeof(double) * size_t(n));
@@ -916,6 +959,33 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
     fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
     FNX_TRY(publish_results(ctx, dres, 1));
     q.nraw = nlev;
+    for (int i = 0; i < 5; i++) q.weights[i] = weights[i];
+    return FNX_OK;
+}
+
+int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride,
+                             int w, int h, const double *window)
+{
+    FNX_ENTER(ctx);
+    FNX_REQUIRE(n >= 0 && (n == 0 || (as && bs)) && window != nullptr && w > 0 && h > 0, "batch arguments");
+    if (n == 0) return FNX_OK;
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(as[i] && bs[i], "null image in batch");
+        FNX_TRY(check_img(as[i], astride, w, h, "a"));
+        FNX_TRY(check_img(bs[i], bstride, w, h, "b"));
+    }
+    FNX_TRY(can_enqueue(ctx));
+    double weights[5];
+    const int nweights = msssim_weights(w, h, weights);
+    double *dres;
+    FNX_TRY(result_slot_queued(ctx, 5 * n, &dres));
+    int nlev = 0;
+    for (int i = 0; i < n; i++)      // (every image has the same levels: the dims decide)
+        FNX_TRY(msssim_levels_device(ctx, as[i], w * 4, bs[i], w * 4, w, h, nweights, window, dres + 5 * i, &nlev));   // toNRGBA: flat (see fnx_msssim)
+    fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
+    FNX_TRY(publish_results(ctx, dres, n));
+    q.nraw = nlev;
+    q.nimg = n;
     for (int i = 0; i < 5; i++) q.weights[i] = weights[i];
     return FNX_OK;
 }

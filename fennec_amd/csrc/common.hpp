@@ -189,6 +189,7 @@ struct fnx_ctx {
         // fnx_msssim_enqueue: the slots hold `nraw` per-level SSIMFast values and the fetch returns ONE number,
         // exp(sum weights[i] log(max(level i, 1e-10))) (ssim.go:344-352); nraw == 0: the values as they are
         int nraw = 0;
+        int nimg = 1;          // fnx_msssim_batch_enqueue: that many images, five slots each, `nraw` of them written; the fetch returns nimg numbers
         double weights[5] = {0, 0, 0, 0, 0};
         int tail_parity = -1;  // one-pass batches: the buffer set (slabs, planes, partials) this batch's tail reads,
         unsigned long long tail_gen = 0;   // and which use of that set it was
@@ -359,8 +360,10 @@ struct ResizeHint {
 int resize_pass(fnx_ctx *ctx, bool vertical, const TapTable &t, const uint8_t *src, int sstride, int srcW, int srcH,
                 uint8_t *dst, int dstride, ResizeHint *hint = nullptr);
 // both passes in one launch (the uint8 intermediate in LDS); FNX_NOOP when the tables are outside its reach
+// nimg > 1: a batch of same-geometry images in one set of launches (blockIdx.z / .y = image); d_srcs / d_dsts are DEVICE arrays
+// of their pointers (src / dst are then ignored)
 int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
-                 uint8_t *dst, int dstride);
+                 uint8_t *dst, int dstride, int nimg = 1, const uint8_t *const *d_srcs = nullptr, uint8_t *const *d_dsts = nullptr);
 void free_resize_plans(fnx_ctx *ctx);
 // resize_mfma.hip: lanczosResize on the i8 matrix pipe (opaque images, ratios up to ~2.3).  One tap table in matrix form:
 struct RzMfTable {
@@ -382,10 +385,13 @@ void resize_mfma_free(RzMfTable *t);
 // (old_tw x old_th output px, old_gx per row), which the caller launches next.
 int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
                        const uint8_t *src, int sstride, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH,
-                       uint32_t *todo, unsigned *gave_up, uint32_t gen, int old_tw, int old_th, int old_gx, int *workgroups);
+                       uint32_t *todo, unsigned *gave_up, uint32_t gen, int old_tw, int old_th, int old_gx, int *workgroups,
+                       int nimg = 1, const uint8_t *const *d_srcs = nullptr, uint8_t *const *d_dsts = nullptr, uint32_t todo_stride = 0);
 // lanczosResize (resize.go:37-53) with both tables given: the body of fnx_lanczos_resize
 int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
                           const TapTable &th, const TapTable &tv, uint8_t *dst, int dstride, int dstW, int dstH);
+int lanczos_resize_tables_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                                const TapTable &th, const TapTable &tv, uint8_t *const *dsts, int dstride, int dstW, int dstH);
 // contig_taps: resize_contiguous_taps() of the (host) H table -- most taps of any output when every
 // output's tap indices are consecutive, else 0
 int launch_resize_h(fnx_ctx *ctx, const uint8_t *src, int sstride, int srcW, int srcH,

@@ -271,6 +271,27 @@ int fennec_MSSSIM_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, int aw, i
     return fnx_msssim_enqueue(ctx, a, astride, rb, rbs, aw, ah, ssim_window());
 }
 
+int fennec_MSSSIM_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, int aw, int ah,
+                                const uint8_t *const *bs, int bstride, int bw, int bh)
+{
+    FNX_ENTER(ctx);
+    if (n < 0 || aw <= 0 || ah <= 0 || bw <= 0 || bh <= 0 || (n > 0 && (!as || !bs))) {
+        set_error("invalid argument: MSSSIM_batch_enqueue takes non-empty device images");
+        return FNX_ERR_INVALID;
+    }
+    if (n == 0) return FNX_OK;
+    if (aw == bw && ah == bh) return fnx_msssim_batch_enqueue(ctx, n, as, astride, bs, bstride, aw, ah, ssim_window());
+    // ssim.go:320-322 for the whole batch: every b resized to a's dims in ONE set of launches, n images side by side in the slot
+    const size_t img = (static_cast<size_t>(aw) * ah * 4 + 255) & ~size_t(255);
+    void *d = nullptr;
+    FNX_TRY(scratch(ctx, SLOT_TMP3, img * n + 16, &d));
+    std::vector<uint8_t *> ups(static_cast<size_t>(n));
+    for (int i = 0; i < n; i++) ups[i] = static_cast<uint8_t *>(d) + img * i;
+    const auto pth = make_taps(aw, bw), ptv = make_taps(ah, bh);
+    FNX_TRY(lanczos_resize_tables_batch(ctx, n, bs, bstride, bw, bh, pth->table(aw), ptv->table(ah), ups.data(), aw * 4, aw, ah));
+    return fnx_msssim_batch_enqueue(ctx, n, as, astride, const_cast<const uint8_t *const *>(ups.data()), aw * 4, aw, ah, ssim_window());
+}
+
 int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                         double sigma, uint8_t *dst, int dstride)
 {
@@ -320,6 +341,22 @@ int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
     const Taps &th = *pth, &tv = *ptv;
     return lanczos_resize_tables(ctx, space, src, sstride, srcW, srcH, th.table(dstW), tv.table(dstH), dst, dstride,
                                  dstW, dstH);
+}
+
+int fennec_lanczosResizeBatch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                              uint8_t *const *dsts, int dstride, int dstW, int dstH)
+{
+    if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;
+    if (srcW == dstW && srcH == dstH) {
+        for (int i = 0; i < n; i++) {
+            const int rc = fnx_lanczos_resize(ctx, FNX_DEVICE, srcs ? srcs[i] : nullptr, sstride, srcW, srcH, nullptr, nullptr, nullptr, nullptr,
+                                              nullptr, nullptr, dsts ? dsts[i] : nullptr, dstride, dstW, dstH);
+            if (rc < 0) return rc;
+        }
+        return FNX_OK;
+    }
+    const auto pth = make_taps(dstW, srcW), ptv = make_taps(dstH, srcH);
+    return lanczos_resize_tables_batch(ctx, n, srcs, sstride, srcW, srcH, pth->table(dstW), ptv->table(dstH), dsts, dstride, dstW, dstH);
 }
 
 int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,

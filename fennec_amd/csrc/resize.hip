@@ -956,7 +956,20 @@ struct ResizeFusedArgs {
     int cells, gx;                   // tiles, tiles per row
     unsigned *counter;               // resize_mfma_kernel's workgroups that gave up (zeroed again by the reader)
     unsigned long long *report;      // host-mapped: gen << 32 | that count
+    // a batch of same-geometry images (fnx_lanczos_resize_batch): device arrays of their pointers; the kernels' third grid
+    // dimension is the image (resize_fused_sparse_kernel: the second), `todo` holds `cells` stamps per image
+    const uint8_t *const *srcs;
+    uint8_t *const *dsts;
 };
+
+// the image of this workgroup (batched launches); z = its index
+__device__ __forceinline__ void resize_pick_image(ResizeFusedArgs &fa, unsigned z)
+{
+    if (fa.srcs) {
+        fa.h.src = fa.srcs[z];
+        fa.v.dst = fa.dsts[z];
+    }
+}
 
 // one output of resizeV exactly as the reference computes it (resize.go:137-156), its taps read from the tile
 __device__ __forceinline__ uint32_t resize_exact_px_tile(const ResizeGuardArgs &v, const uint32_t *tile, int r0, int col, int y)
@@ -1605,12 +1618,14 @@ __device__ __forceinline__ void resize_fused_tile(const ResizeFusedArgs &fa, con
 template <int NV, int RMAX>
 __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_kernel(ResizeFusedArgs fa)
 {
+    resize_pick_image(fa, blockIdx.z);
     resize_fused_tile<NV, RMAX>(fa, blockIdx.x, blockIdx.y);
 }
 
 template <int NV, int RMAX>
 __global__ __launch_bounds__(256, 3) void resize_fused_dense_kernel(ResizeFusedArgs fa)
 {
+    resize_pick_image(fa, blockIdx.z);
     resize_fused_tile<NV, RMAX, true, true>(fa, blockIdx.x, blockIdx.y);
 }
 
@@ -1645,6 +1660,7 @@ __global__ __launch_bounds__(256, FNX_D21_OCC) void resize_dense21_kernel(Resize
     __shared__ __attribute__((aligned(16))) uint32_t s_tile[D21_ROWS * RF_TW];
     __shared__ uint16_t s_list[D21_ROWS * 32];                       // (row << 5 | lane): four outputs that await the per-pixel form
     __shared__ unsigned s_nlist;
+    resize_pick_image(fa, blockIdx.z);
     const ResizeGuardArgs &a = fa.h;
     const ResizeGuardArgs &v = fa.v;
     const int bx = blockIdx.x, by = blockIdx.y;
@@ -1783,13 +1799,15 @@ __global__ __launch_bounds__(256, FNX_D21_OCC) void resize_dense21_kernel(Resize
 template <int NV, int RMAX>
 __global__ __launch_bounds__(256, RMAX <= 32 ? 4 : 3) void resize_fused_sparse_kernel(ResizeFusedArgs fa)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         // how many of resize_mfma_kernel's workgroups gave up (it has finished: stream order), for the host's next call
         const unsigned total = atomicExch(fa.counter, 0u);
         *reinterpret_cast<volatile unsigned long long *>(fa.report) = (static_cast<unsigned long long>(fa.gen) << 32) | total;
     }
+    resize_pick_image(fa, blockIdx.y);
+    const uint32_t *todo = fa.todo + static_cast<size_t>(blockIdx.y) * fa.cells;        // (a batch: `cells` stamps per image)
     for (int t = blockIdx.x; t < fa.cells; t += gridDim.x) {
-        if (fa.todo[t] != fa.gen) continue;
+        if (todo[t] != fa.gen) continue;
         resize_fused_tile<NV, RMAX, false>(fa, t % fa.gx, t / fa.gx);
         __syncthreads();
     }
@@ -2177,8 +2195,9 @@ static void launch_h_guard(fnx_ctx *ctx, const ResizeGuardArgs &ga, dim3 grid)
 // lanczosResize in one launch (resize_fused_kernel) when both tables take the guard form, the H windows fit the
 // register matrix and the V windows a tile.  FNX_NOOP: not covered -- the caller runs the two passes.
 int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uint8_t *src, int sstride, int srcW, int srcH,
-                 uint8_t *dst, int dstride)
+                 uint8_t *dst, int dstride, int nimg, const uint8_t *const *d_srcs, uint8_t *const *d_dsts)
 {
+    const unsigned nz = static_cast<unsigned>(nimg > 1 ? nimg : 1);
     const char *fe = form_value(ctx, FORM_RESIZE_FUSED);                     // "0": A/B and tests (the two-pass kernels)
     const bool off = (fe && fe[0] == '0') || (fe && fe[0] == '2' && th.nout < srcW);   // "2": upscales only (experiments)
     if (off || resize_guard_disabled(ctx) || th.nout <= 0 || tv.nout <= 0 || srcW <= 0 || srcH <= 0) return FNX_NOOP;
@@ -2187,6 +2206,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     FNX_TRY(get_resize_plan(ctx, tv, srcH, true, &pv));
     if (!ph->guard_ok || !pv->guard_ok || ph->NV > 4 || pv->fused_ng < 1 || th.nout < 2) return FNX_NOOP;
     ResizeFusedArgs fa{};
+    fa.srcs = nz > 1 ? d_srcs : nullptr; fa.dsts = nz > 1 ? d_dsts : nullptr;
     ResizeGuardArgs &h = fa.h, &v = fa.v;
     h.src = src; h.sstride = sstride; h.srcN = srcW; h.nout = th.nout; h.other = srcH;
     h.ngroups = ph->ngroups; h.npx = ph->npx; h.guard = ph->guard;
@@ -2209,14 +2229,14 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         const double slots = (low ? 4.0 : 3.0) * ctx->num_cus;
         double best = -1.0;
         for (int cand = ngmax; cand >= std::max(2, ngmax / 2); cand--) {
-            const double rounds = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand) / slots;
+            const double rounds = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand) * nz / slots;
             const double fill = rounds / std::ceil(rounds);
             if (fill > best + 0.02) { best = fill; ng = cand; }
         }
     }
     if (const char *e = dev_env("FNX_RF_NG")) ng = std::max(1, std::min(ngmax, atoi(e)));   // experiments
     fa.ng = ng;
-    const dim3 grid(gx, (pv->ngroups + ng - 1) / ng);
+    const dim3 grid(gx, (pv->ngroups + ng - 1) / ng, nz);
     FNX_TRY(prof_begin(ctx, FNX_PROF_RESIZE));
     // The matrix kernel first (resize_mfma.hip); resize_fused_sparse_kernel then redoes the tiles it gave up (translucent
     // or tie-dense regions).  When it gave up most of an image -- the count comes back through host-mapped memory, read
@@ -2249,14 +2269,14 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
     if (use_mf) {
         ph->d21_heavy = false;
         const size_t cells = static_cast<size_t>(grid.x) * grid.y;
-        if (cells + 2 > ctx->rz_todo_cap) {
+        if (cells * nz + 2 > ctx->rz_todo_cap) {
             FNX_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->rz_todo) FNX_HIP(hipFree(ctx->rz_todo));
             ctx->rz_todo = nullptr;
             ctx->rz_todo_cap = 0;
-            FNX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->rz_todo), sizeof(uint32_t) * (cells + 2)));
-            FNX_HIP(hipMemsetAsync(ctx->rz_todo, 0, sizeof(uint32_t) * (cells + 2), ctx->stream));
-            ctx->rz_todo_cap = cells + 2;
+            FNX_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->rz_todo), sizeof(uint32_t) * (cells * nz + 2)));
+            FNX_HIP(hipMemsetAsync(ctx->rz_todo, 0, sizeof(uint32_t) * (cells * nz + 2), ctx->stream));
+            ctx->rz_todo_cap = cells * nz + 2;
             ctx->rz_gen = 0;
         }
         if (!ctx->rz_report) {
@@ -2269,7 +2289,8 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         }
         int mf_wgs = 0;
         FNX_TRY(resize_mfma_launch(ctx, ph->mf, pv->mf, src, sstride, srcW, srcH, dst, dstride, th.nout, tv.nout,
-                                   ctx->rz_todo + 2, ctx->rz_todo, ctx->rz_gen, 64 * RG_HO, RG_VG * ng, static_cast<int>(grid.x), &mf_wgs));
+                                   ctx->rz_todo + 2, ctx->rz_todo, ctx->rz_gen, 64 * RG_HO, RG_VG * ng, static_cast<int>(grid.x), &mf_wgs,
+                                   static_cast<int>(nz), d_srcs, d_dsts, static_cast<uint32_t>(cells)));
         fa.todo = ctx->rz_todo + 2;
         fa.gen = ctx->rz_gen;
         fa.cells = static_cast<int>(cells);
@@ -2295,7 +2316,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         }
 #endif
         note_route(ctx, FNX_PROF_RESIZE, "resize_mfma_kernel + resize_fused_sparse_kernel");
-        const dim3 sgrid(static_cast<unsigned>(std::min<size_t>(cells, static_cast<size_t>(2) * ctx->num_cus)));
+        const dim3 sgrid(static_cast<unsigned>(std::min<size_t>(cells, static_cast<size_t>(2) * ctx->num_cus)), nz);
         if (low) {
             hipLaunchKernelGGL((resize_fused_sparse_kernel<2, 32>), sgrid, dim3(256), 0, ctx->stream, fa);
         } else {
@@ -2316,7 +2337,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
         double best = 0;
         for (int cand = 1; cand <= D21_NGMAX; cand++) {
             if (!(pv->d21_fit >> cand & 1u)) continue;
-            const double wgs = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand);
+            const double wgs = static_cast<double>(gx) * ((pv->ngroups + cand - 1) / cand) * nz;
             const int rows = 2 * RG_VG * cand + 10, pairs = ((rows + 3) / 4 + 1) / 2;
             const double cost = std::ceil(wgs / ctx->num_cus) * (534.0 * pairs + 1100.0 * ((cand + 3) / 4));
             if (best == 0 || cost < best) { best = cost; ng21 = cand; }
@@ -2326,7 +2347,7 @@ int resize_fused(fnx_ctx *ctx, const TapTable &th, const TapTable &tv, const uin
             if (want >= 1 && want <= D21_NGMAX && (pv->d21_fit >> want & 1u)) ng21 = want;
         }
         fa.ng = ng21;
-        const dim3 grid21(gx, (pv->ngroups + ng21 - 1) / ng21);
+        const dim3 grid21(gx, (pv->ngroups + ng21 - 1) / ng21, nz);
         Dense21Args dn{};
         for (int k = 0; k < 12; k++) { dn.wh[k] = ph->d21_w[k]; dn.wv[k] = pv->d21_w[k]; }
         dn.inv_h = ph->d21_inv; dn.inv_v = pv->d21_inv;

@@ -93,6 +93,10 @@ struct RzMfArgs {
     const RmEx *exh, *exv;               // per output: the reference's own operands for the fp64 fix-ups
     uint32_t *todo;
     unsigned *gave_up;                   // + 1 per workgroup that hands its region back
+    // a batch of same-geometry images (blockIdx.y = image): device arrays of their pointers, and the images' spacing in `todo`
+    const uint8_t *const *srcs;
+    uint8_t *const *dsts;
+    uint32_t todo_stride;
     uint32_t gen;
     int old_tw, old_th, old_gx;
 };
@@ -170,6 +174,11 @@ __global__ __launch_bounds__(256, 3) void resize_mfma_kernel(RzMfArgs a)
     v4i *s_vmat = reinterpret_cast<v4i *>(s_out + 2 * 16 * OP);
     uint8_t *s_stage = reinterpret_cast<uint8_t *>(s_vmat + a.segj * 192);
 
+    if (a.srcs) {                                                  // a batch: this workgroup's image
+        a.src = a.srcs[blockIdx.y];
+        a.dst = a.dsts[blockIdx.y];
+        a.todo += static_cast<size_t>(blockIdx.y) * a.todo_stride;
+    }
     const int tile = xcd_tile(blockIdx.x, a.tiles);
     if (tile < 0) return;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -644,9 +653,11 @@ bool resize_mfma_build(const fnx_ctx *ctx, const TapTable &t, int srcN, bool ver
 
 int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
                        const uint8_t *src, int sstride, int srcW, int srcH, uint8_t *dst, int dstride, int dstW, int dstH,
-                       uint32_t *todo, unsigned *gave_up, uint32_t gen, int old_tw, int old_th, int old_gx, int *workgroups)
+                       uint32_t *todo, unsigned *gave_up, uint32_t gen, int old_tw, int old_th, int old_gx, int *workgroups,
+                       int nimg, const uint8_t *const *d_srcs, uint8_t *const *d_dsts, uint32_t todo_stride)
 {
     RzMfArgs a{};
+    a.srcs = nimg > 1 ? d_srcs : nullptr; a.dsts = nimg > 1 ? d_dsts : nullptr; a.todo_stride = todo_stride;
     a.src = src; a.dst = dst; a.sstride = sstride; a.dstride = dstride;
     a.srcW = srcW; a.srcH = srcH; a.dstW = dstW; a.dstH = dstH;
     a.tiles_x = (dstW + 63) / 64;
@@ -664,7 +675,7 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
         for (int cand = 1; cand <= std::min(a.nvg, RM_MAXJ); cand++) {
             const int occ = std::max(1, std::min(3, (160 * 1024) / (lds_of(cand) + 1024)));
             const long slots = static_cast<long>(occ) * ctx->num_cus;
-            const long wgs = static_cast<long>(a.tiles_x) * ((a.nvg + cand - 1) / cand);
+            const long wgs = static_cast<long>(a.tiles_x) * ((a.nvg + cand - 1) / cand) * std::max(1, nimg);
             const double iters = std::max(cand * spg, static_cast<double>(cand)) + 4.0;
             const double cost = static_cast<double>((wgs + slots - 1) / slots) * iters;
             if (cand == 1 || cost < best * 0.98) { best = cost; segj = cand; }
@@ -686,8 +697,8 @@ int resize_mfma_launch(fnx_ctx *ctx, const RzMfTable &h, const RzMfTable &v,
     { static const bool nofix = dev_env("FNX_RM_NOFIX") != nullptr; if (nofix) a.thr_h = a.thr_v = 0; }
 #endif
     a.todo = todo; a.gave_up = gave_up; a.gen = gen; a.old_tw = old_tw; a.old_th = old_th; a.old_gx = old_gx;
-    const dim3 grid(8 * ((a.tiles + 7) / 8));
-    *workgroups = a.tiles;
+    const dim3 grid(8 * ((a.tiles + 7) / 8), std::max(1, nimg));
+    *workgroups = a.tiles * std::max(1, nimg);
     if (16 * a.NC <= 512) hipLaunchKernelGGL((resize_mfma_kernel<2>), grid, dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL((resize_mfma_kernel<3>), grid, dim3(256), lds, ctx->stream, a);
     FNX_HIP(hipGetLastError());

@@ -230,6 +230,15 @@ int fnx_lanczos_resize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride,
                        int srcH, const int32_t *offH, const int32_t *idxH, const double *wH,
                        const int32_t *offV, const int32_t *idxV, const double *wV,
                        uint8_t *dst, int dstride, int dstW, int dstH);
+/* lanczosResize of n same-geometry DEVICE images (srcs / dsts: host arrays of device pointers) with one tap-table pair: the
+ * bytes of n fnx_lanczos_resize calls, enqueued as ONE set of launches where the one-launch kernels apply (a 4K resize
+ * alone is ~700 workgroups on 768-1024 resident slots: one under-filled round; a batch fills the machine and pays the
+ * launch, the plan look-up and the tails once).  Other tables (windows wider than the fused tile, tables outside the
+ * rounding guard) run image by image.  CompressBatch workers that resize many same-sized frames (fennec.go:127-129). */
+int fnx_lanczos_resize_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                             const int32_t *offH, const int32_t *idxH, const double *wH,
+                             const int32_t *offV, const int32_t *idxV, const double *wV,
+                             uint8_t *const *dsts, int dstride, int dstW, int dstH);
 
 /* ---- ssim.go ---------------------------------------------------------- */
 /* boxDownsample (ssim.go:244-309). */
@@ -376,6 +385,11 @@ int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t 
  * the FIFO and fnx_results_fetch(ctx, 1, &v) combines them (exp of the weighted log sum, on the host as in fnx_msssim). */
 int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                        const double *window /* 64 */);
+/* n such pairs of ONE geometry as one FIFO entry: fnx_results_fetch(ctx, n, v) returns the n values in order (any k <= n of
+ * them; the entry is consumed either way).  What a worker scoring a batch of frames calls instead of n enqueues: one FIFO
+ * slot, one result event, and -- through fennec_MSSSIM_batch_enqueue -- ONE batched resize for the pairs whose dims differ. */
+int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride,
+                             int w, int h, const double *window /* 64 */);
 
 /* dsts[i] = GaussianBlur(srcs[i]) AND out[i] = SSIMFast(srcs[i], dsts[i]) -- the pair of calls
  * the reference makes whenever it scores a processed image against its source (effects.go:146
@@ -509,6 +523,10 @@ int fennec_MSSSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw
  * dims first when they differ (ssim.go:320-322); fnx_results_fetch(ctx, 1, &v) returns the value. */
 int fennec_MSSSIM_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, int aw, int ah, const uint8_t *b, int bstride,
                           int bw, int bh);
+/* ... of n device pairs (every a of aw x ah, every b of bw x bh): the b's are resized to the a's dims by ONE batched
+ * lanczosResize (fnx_lanczos_resize_batch) when the dims differ, ssim.go:320-322; results as fnx_msssim_batch_enqueue's. */
+int fennec_MSSSIM_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, int aw, int ah,
+                                const uint8_t *const *bs, int bstride, int bw, int bh);
 int fennec_GaussianBlur(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                         double sigma, uint8_t *dst, int dstride);                 /* effects.go:146;
                         FNX_HOST: FNX_BLUR_EXACT (bit-exact; the call is PCIe-bound anyway),
@@ -521,6 +539,8 @@ int fennec_ApplyOrientation(fnx_ctx *ctx, int space, const uint8_t *src, int sst
                             int h, int orient, uint8_t *dst, int dstride);        /* exif.go:178 */
 int fennec_lanczosResize(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
                          int srcH, uint8_t *dst, int dstride, int dstW, int dstH); /* resize.go:37 */
+int fennec_lanczosResizeBatch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int srcW, int srcH,
+                              uint8_t *const *dsts, int dstride, int dstW, int dstH);   /* resize.go:37 x n (device images) */
 int fennec_boxDownsample(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW,
                          int srcH, uint8_t *dst, int dstride, int dstW, int dstH); /* ssim.go:244 */
 

@@ -410,6 +410,86 @@ def test_lanczos_resize_dense_form_after_two_cool_downs(orc):
     c.close()
 
 
+def _photo_soft(w, h, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 90 * np.sin(x / (31.0 + c)) * np.cos(y / (23.0 + 2 * c)) + rng.normal(0, 5, x.shape) for c in range(3)] + [np.full(x.shape, 255.0)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,dw,dh", [(3840, 2160, 1920, 1080), (1920, 1080, 3840, 2160), (1280, 720, 853, 480), (640, 480, 320, 240),
+                                       (517, 389, 233, 800), (2048, 70, 929, 151), (300, 200, 300, 200), (64, 64, 7, 5)])
+def test_lanczos_resize_batch(ctx, orc, w, h, dw, dh):
+    """r6: fnx_lanczos_resize_batch -- n same-geometry device images through one set of launches (the matrix kernel + its
+    hand-backs, the one-launch kernel, the exact 2:1 form: each with the image as a grid dimension) against the same images one
+    call at a time, and -- below 4K -- the oracle.  A batch mixes what the routes hand to each other: photograph-like images
+    (the matrix kernel keeps them), SURVEY 8(d)'s ramp (every tile handed back; after enough of them the plan's cool-down
+    takes the dense forms), an image with a translucent patch, noise."""
+    import torch
+    ramp = synth.large_photo(w, h, 3)
+    holes = _photo_soft(w, h, 5)
+    holes[h // 3: h // 2 + 1, w // 4: w // 2 + 1, 3] = 17
+    imgs = [_photo_soft(w, h, 1), ramp, holes, _opaque(synth.noise_image(w, h, 9, alpha=True)), _photo_soft(w, h, 2), synth.large_photo(w, h, 8)]
+    c = fennec_amd.Context(0)                                    # a ctx of its own: plans without history
+    try:
+        want = [c.lanczosResize(im, dw, dh) for im in imgs]
+        if w * h < 3000 * 2000:
+            for k in (0, 1, 2):
+                assert np.array_equal(want[k], orc.lanczos_resize(imgs[k], dw, dh, procs=8)), k
+        dev = [torch.from_numpy(im).cuda() for im in imgs]
+        c2 = fennec_amd.Context(0)
+        for rep in range(3):                                     # (the ramps push the plan into its cool-down between repetitions)
+            got = c2.lanczosResizeBatch(dev, dw, dh)
+            c2.sync()
+            for k, (g, wnt) in enumerate(zip(got, want)):
+                assert np.array_equal(g.cpu().numpy(), wnt), (rep, k, w, h, dw, dh)
+        # a batch of ramps only, many times: the dense / 2:1 forms with the image dimension
+        ramps = [torch.from_numpy(synth.large_photo(w, h, s)).cuda() for s in range(4)]
+        wr = [c.lanczosResize(synth.large_photo(w, h, s), dw, dh) for s in range(4)]
+        for rep in range(70 if w * h <= 1280 * 720 else 6):
+            got = c2.lanczosResizeBatch(ramps, dw, dh)
+        c2.sync()
+        for k in range(4):
+            assert np.array_equal(got[k].cpu().numpy(), wr[k]), ("ramps", k)
+        # pitched views and a batch of one
+        big = torch.from_numpy(np.ascontiguousarray(np.pad(imgs[0], ((0, 0), (2, 2), (0, 0))))).cuda()
+        views = [big[:, 2: 2 + w], torch.from_numpy(np.ascontiguousarray(np.pad(imgs[1], ((0, 0), (2, 2), (0, 0))))).cuda()[:, 2: 2 + w]]
+        if (w, h) != (dw, dh):                                   # (equal dims are the reference's FLAT copy of Pix, resize.go:45-49: rows only for tight images)
+            got = c2.lanczosResizeBatch(views, dw, dh)
+            c2.sync()
+            assert np.array_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[1].cpu().numpy(), want[1])
+        one = c2.lanczosResizeBatch([dev[2]], dw, dh)
+        c2.sync()
+        assert np.array_equal(one[0].cpu().numpy(), want[2])
+        c2.close()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("w,h,bw,bh", [(3840, 2160, 1920, 1080), (1024, 768, 1024, 768), (1000, 600, 500, 300), (640, 480, 320, 240)])
+def test_msssim_batch_enqueue(ctx, orc, w, h, bw, bh):
+    """r6: fennec_MSSSIM_batch_enqueue -- n pairs as one FIFO entry, the b sides resized by ONE batched lanczosResize where the
+    dims differ (ssim.go:320-322): every value equals the single enqueue's and MSSSIM's, and -- below 4K -- the oracle's."""
+    import torch
+    n = 5
+    A = [synth.large_photo(w, h, k) for k in range(n)]
+    B = [orc.gaussian_blur(synth.large_photo(bw, bh, k), 0.9 + 0.2 * k, procs=8) for k in range(n)]
+    da, db = [torch.from_numpy(x).cuda() for x in A], [torch.from_numpy(x).cuda() for x in B]
+    want = [ctx.MSSSIM(da[k], db[k]) for k in range(n)]
+    ctx.msssim_batch_enqueue(da, db)
+    got = ctx.fetch_results(n)
+    assert list(got) == want
+    ctx.msssim_enqueue(da[2], db[2])
+    ctx.msssim_batch_enqueue(da[:3], db[:3])                   # two entries in the FIFO, fetched in order; a partial fetch of the second
+    assert ctx.fetch_result() == want[2]
+    assert list(ctx.fetch_results(2)) == want[:2]
+    if w * h < 3000 * 2000:
+        for k in (0, n - 1):
+            assert abs(want[k] - orc.msssim(A[k], B[k], procs=8)) <= SSIM_TOL
+    with pytest.raises(fennec_amd.FennecError):
+        ctx.fetch_results(1)                                   # nothing left
+
+
 def test_lanczos_resize_guard_vs_fp64_kernels(ctx, orc, monkeypatch):
     """Random geometries, device views with odd strides: the guard kernels against the round-1 fp64 kernels
     (form "resize_fp64" = 1), which follow the reference's operation order."""
