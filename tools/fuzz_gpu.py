@@ -96,6 +96,35 @@ while time.time() < t_end:
     case("ssim", abs(ctx.SSIM(img, other) - orc.ssim(img, other, procs=8)) <= SSIM_TOL, desc)
     case("ssim_fast", abs(ctx.SSIMFast(img, other) - orc.ssim_fast(img, other, procs=8)) <= SSIM_TOL, desc)
     case("msssim", abs(ctx.MSSSIM(img, other) - orc.msssim(img, other, procs=8)) <= SSIM_TOL, desc)
+    # r6: the one-call GaussianBlur + SSIMFast (host image: one crossing each way), the batched resize and MSSSIM entry points
+    # (the image as a grid dimension), and -- on planes large enough for the two-column marching kernel -- FNX_SSIM_FAST
+    gb, gs = ctx.GaussianBlurSSIMFast(img, sigma, exact=True)
+    case("blur_ssim_one_call", np.array_equal(gb, want) and (min(w, h) < 1 or abs(gs - orc.ssim_fast(img, want, procs=8)) <= SSIM_TOL), desc + f" sigma={sigma}")
+    if it % 3 == 0:
+        import torch
+        nb = int(rng.integers(2, 6))
+        batch = [img] + [rand_image(w, h) for _ in range(nb - 1)]
+        dev = [torch.from_numpy(b).cuda() for b in batch]
+        got = ctx.lanczosResizeBatch(dev, fw, fh)
+        ctx.sync()
+        case("resize_batch", all(np.array_equal(g.cpu().numpy(), orc.lanczos_resize(b, fw, fh, procs=8)) for g, b in zip(got, batch)), desc + f" x{nb} -> {fw}x{fh}")
+        if w >= 16 and h >= 16:
+            smalls = ctx.lanczosResizeBatch(dev, max(8, w // 2), max(8, h // 2))
+            ctx.msssim_batch_enqueue(dev, smalls)
+            gm = ctx.fetch_results(nb)
+            wm = [orc.msssim(b, s_.cpu().numpy(), procs=8) for b, s_ in zip(batch, smalls)]
+            case("msssim_batch", all(abs(g - w_) <= SSIM_TOL for g, w_ in zip(gm, wm)), desc + f" x{nb}")
+    if it % 16 == 0:
+        bw2, bh2 = int(rng.integers(2100, 2700)), int(rng.integers(2000, 2400))
+        big, big2 = rand_image(bw2, bh2), None
+        big2 = ctx.GaussianBlur(big, float(rng.choice([0.8, 1.5, 2.5]))) if rng.integers(2) else rand_image(bw2, bh2)
+        wbig = orc.ssim(big, big2, procs=16)
+        ctx.set_ssim_mode(True)
+        try:
+            fbig = ctx.SSIM(big, big2)
+        finally:
+            ctx.set_ssim_mode(False)
+        case("ssim_fast_moments", abs(fbig - wbig) <= 1e-6 and abs(ctx.SSIM(big, big2) - wbig) <= SSIM_TOL, desc + f" big {bw2}x{bh2} delta {fbig - wbig:+.2e}")
     a, wa = ctx.analyze_raw(img), orc.analyze(img)
     ok = (np.array_equal(a["histogram"].astype(np.float64), wa["histogram"]) and
           all(a[k] == wa[k] for k in ("has_alpha", "is_grayscale", "unique_colors", "sample_count", "edge_count", "edge_total")) and
