@@ -1526,8 +1526,11 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
         stage(i + 1, std::integral_constant<int, (p + 1) & 7>{});   // (tap[] holds row i: the LDS row is free)
         if (PRE) fetch();
         // quantity pairs -> column pairs (two v_pk_mov_b32 per 2 x 2 transpose)
-        const f32x2 hx = __builtin_shufflevector(h0a, h1a, 0, 2), hy = __builtin_shufflevector(h0a, h1a, 1, 3);
-        const f32x2 hs = __builtin_shufflevector(h0q, h1q, 0, 2), hd = __builtin_shufflevector(h0q, h1q, 1, 3);
+        f32x2 hx, hy, hs, hd;
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(hx) : "v"(h0a), "v"(h1a));      // (h0a.x, h1a.x)
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(hy) : "v"(h0a), "v"(h1a));      // (h0a.y, h1a.y)
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(hs) : "v"(h0q), "v"(h1q));
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(hd) : "v"(h0q), "v"(h1q));
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const int k = (p - s) & 7;

@@ -43,6 +43,19 @@ def worker(k):
                 assert st_d["UniqueColors"] == st_h["UniqueColors"] and st_d["Width"] == w
                 assert c.isOpaque(d) is True and c.isGrayscale(img) is False
                 assert c.last_kernel(fennec_amd.PROF_RESIZE).startswith("resize_")
+                # r6: the one-call blur + score on a host image, the batched resize / MSSSIM entry points (pointer tables, one FIFO
+                # entry for the batch), the per-ctx mode and form selections
+                hb, hs = c.GaussianBlurSSIMFast(img, 2.0)
+                assert np.array_equal(hb, c.GaussianBlur(img, 2.0, exact=True)) and 0 < hs <= 1
+                ds = [d, torch.from_numpy(synth.large_photo(w, h, k + r + 1)).cuda(), sharp]
+                smalls = c.lanczosResizeBatch(ds, w // 2, h // 2)
+                c.msssim_batch_enqueue(ds, smalls)
+                vb = c.fetch_results(3)
+                assert all(0 < x <= 1 for x in vb) and abs(vb[0] - v1) <= 1e-12
+                c.set_ssim_mode(bool(r & 1))
+                c.set_form("resize_fused", "0" if r % 3 == 0 else None)
+                assert np.array_equal(c.lanczosResize(d, w // 2, h // 2).cpu().numpy(), small.cpu().numpy())
+                c.set_form("resize_fused", None)
                 try:
                     c.lanczosResize(np.zeros((4, 4, 3), np.uint8), 2, 2)   # thread-local error text
                 except Exception:
