@@ -980,7 +980,26 @@ int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int 
     double *dres;
     FNX_TRY(result_slot_queued(ctx, 5 * n, &dres));
     int nlev = 0;
-    for (int i = 0; i < n; i++)      // (every image has the same levels: the dims decide)
+    bool batched = false;
+    if (n > 1) {
+        // the five launches of the fused form with the image as a grid dimension of each (ssim.hip); shapes it does not cover
+        // (odd dims, a pair that is not 16-byte aligned, the non-default forms) take the loop below
+        bool al = true;
+        for (int i = 0; i < n; i++) al = al && !(reinterpret_cast<uintptr_t>(as[i]) & 15) && !(reinterpret_cast<uintptr_t>(bs[i]) & 15);
+        if (al) {
+            const void *hosts[2] = {as, bs};
+            const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+            void *dp[2];
+            FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+            void *dwin = nullptr;
+            FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+            const int rc = launch_msssim_fused(ctx, as[0], w * 4, bs[0], w * 4, w, h, nweights, window, dres, &nlev, n,
+                                               static_cast<const uint8_t *const *>(dp[0]), static_cast<const uint8_t *const *>(dp[1]));
+            if (rc < 0) return rc;
+            batched = rc == FNX_OK;
+        }
+    }
+    for (int i = 0; i < n && !batched; i++)      // (every image has the same levels: the dims decide)
         FNX_TRY(msssim_levels_device(ctx, as[i], w * 4, bs[i], w * 4, w, h, nweights, window, dres + 5 * i, &nlev));   // toNRGBA: flat (see fnx_msssim)
     fnx_ctx::Pending &q = ctx->res_q[(ctx->res_head + ctx->res_count) % fnx_ctx::RES_DEPTH];
     FNX_TRY(publish_results(ctx, dres, n));

@@ -427,11 +427,12 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
                          const double *h_window, const double *d_window, double *d_out,
                          SsimDeferred *defer = nullptr, int defer_out_index = 0);
-int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out);
+int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out, int nimg = 1, size_t part_img = 0, int out_img = 0);
 // MSSSIM's levels in five launches (ssim.hip); FNX_NOOP (nothing launched) for shapes it does not cover.
 // d_out[i] = SSIMFast of level i; *nlev = levels the reference's loop visits.
 int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
-                        int nweights, const double *h_window, double *d_out, int *nlev);
+                        int nweights, const double *h_window, double *d_out, int *nlev,
+                        int nimg = 1, const uint8_t *const *d_as = nullptr, const uint8_t *const *d_bs = nullptr);
 int launch_pixel_ssim(fnx_ctx *ctx, const uint8_t *a, const uint8_t *b, int w, int h,
                       size_t pix_len, double *d_out);
 // Analyze's device side (analyze.hip): n images -> d_res[n]; aligned16_ok: every base pointer is 16-byte aligned

@@ -93,13 +93,16 @@ __device__ __forceinline__ void box_trip(const uint8_t *q, int sstride, uint32_t
     }
 }
 
+// src_off / dst_off: byte offsets added to the job's source and destination (a batched launch's image; kernel arguments are
+// never written to -- a store through a dynamic index would move the whole argument block into scratch memory)
 template <bool VEC>
-__device__ __forceinline__ void box_tiled_body(const BoxArgs &a, const int bx, const int by, const int z)
+__device__ __forceinline__ void box_tiled_body(const BoxArgs &a, const int bx, const int by, const int z, const size_t src_off = 0,
+                                               const size_t dst_off = 0)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
     const bool second = z >= a.nimg;
     const int zi = second ? z - a.nimg : z;
-    const uint8_t *src = second ? (a.srcs_b ? a.srcs_b[zi] : a.src_b) : (a.srcs ? a.srcs[zi] : a.src);
+    const uint8_t *src = (second ? (a.srcs_b ? a.srcs_b[zi] : a.src_b) : (a.srcs ? a.srcs[zi] : a.src)) + src_off;
     const int sstride = second ? a.sstride_b : a.sstride;
     const int dy = by;
     const int dx_lo = bx * a.seg;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void box_tiled_body(const BoxArgs &a, const int bx, c
             }
         }
         const int count = (sy1 - sy0) * (sx1 - sx0);
-        uint8_t *dimg = a.dst + a.dst_image_bytes * z;
+        uint8_t *dimg = a.dst + dst_off + a.dst_image_bytes * z;
         *reinterpret_cast<uint32_t *>(dimg + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) =
             box_finish(r, g, b, al, count);
     }
@@ -355,13 +358,18 @@ constexpr int BOX_MAXJOBS = 4;
 struct BoxMulti {
     BoxArgs job[BOX_MAXJOBS];
     int gx[BOX_MAXJOBS], gy[BOX_MAXJOBS];
+    // a batch (blockIdx.z = 2 (image * njobs + job) + side): sources in the ctx's pyramid scratch (`src_img` bytes per image),
+    // planes in its plane scratch (`dst_img`); njobs == 0: one pair
+    int njobs;
+    size_t src_img, dst_img;
 };
 
 __global__ __launch_bounds__(256) void box_tiled_multi_kernel(BoxMulti m)
 {
-    const int j = blockIdx.z >> 1;
+    const int jz = blockIdx.z >> 1;
+    const int img = m.njobs ? jz / m.njobs : 0, j = m.njobs ? jz - img * m.njobs : jz;
     if (static_cast<int>(blockIdx.x) >= m.gx[j] || static_cast<int>(blockIdx.y) >= m.gy[j]) return;
-    box_tiled_body<true>(m.job[j], blockIdx.x, blockIdx.y, blockIdx.z & 1);
+    box_tiled_body<true>(m.job[j], blockIdx.x, blockIdx.y, blockIdx.z & 1, m.src_img * img, m.dst_img * img);
 }
 
 // "workgroups finished" counters of the kernels whose last workgroup takes the final sum itself: 2 x 4096 for the
@@ -734,6 +742,10 @@ struct WinSepMulti {
     int njobs;
     int out_index[WS_MAXJOBS];
     double windows[WS_MAXJOBS];
+    // a batch (blockIdx.y = image * nlev + job; out == nullptr): each job's a_image_bytes / b_image_bytes is the spacing of its
+    // planes between images, the partial sums of image i lie part_img doubles behind image i - 1's; nlev == 0: one pair
+    int nlev;
+    size_t part_img;
 };
 
 __device__ __forceinline__ double finish_sum_256(const double *p, int tiles, double *s_red);
@@ -742,12 +754,13 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep_multi_kernel(WinSepMult
 {
     __shared__ double s_fin[4];
     __shared__ int s_last;
-    const WinSepArgs &a = m.job[blockIdx.y];
+    const int img = m.nlev ? blockIdx.y / m.nlev : 0, jb = m.nlev ? blockIdx.y - img * m.nlev : blockIdx.y;
+    const WinSepArgs &a = m.job[jb];
     if (static_cast<int>(blockIdx.x) >= a.tiles) return;
     // (ONE instantiation of the body: its LDS arrays are per instantiation, and two of them halved the kernel's occupancy)
-    const double t = ssim_sep_body<WSS_TY, 256, false>(a, blockIdx.x, 0);
+    const double t = ssim_sep_body<WSS_TY, 256, false>(a, blockIdx.x, img);
     if (!m.out) {
-        if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+        if (threadIdx.x == 0) a.partial[m.part_img * img + blockIdx.x] = t;
         return;
     }
     if (threadIdx.x == 0) {
@@ -1745,6 +1758,8 @@ struct PyrArgs {
     int sstride[2];
     int w, h, nl;            // level-0 dims, number of halvings (1..4)
     uint8_t *lv[2][4];       // [side][k - 1]: level k, tight (w >> k) x (h >> k)
+    // a batch (blockIdx.z = 2 image + side): every pointer above lies in the ctx's pyramid scratch, `img_bytes` per image
+    size_t img_bytes;
 };
 
 __device__ __forceinline__ uint32_t quad_mean(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11)
@@ -1758,15 +1773,16 @@ __device__ __forceinline__ uint32_t quad_mean(uint32_t p00, uint32_t p01, uint32
 __global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
 {
     __shared__ uint32_t s_l1[8][64], s_l2[4][32], s_l3[2][16];
-    const int side = blockIdx.z, tid = threadIdx.x;
+    const int side = blockIdx.z & 1, tid = threadIdx.x;
     const int bx = blockIdx.x, by = blockIdx.y;
+    const size_t io = a.img_bytes * (blockIdx.z >> 1);              // a batch's image (0 for a single pair); added where a pointer is USED
     {
         const int lx = tid & 31, ly = tid >> 5;
         const int x = bx * 128 + 4 * lx, y = by * 16 + 2 * ly;
         u32x4 r0 = {0, 0, 0, 0}, r1 = r0;
         const bool in = x < a.w && y < a.h;                        // w % 4 == 0, h % 2 == 0
         if (in) {
-            const uint8_t *p = a.src[side] + static_cast<size_t>(y) * a.sstride[side] + 4 * static_cast<size_t>(x);
+            const uint8_t *p = a.src[side] + io + static_cast<size_t>(y) * a.sstride[side] + 4 * static_cast<size_t>(x);
             r0 = ld16_stream(p);
             r1 = ld16_stream(p + a.sstride[side]);
         }
@@ -1775,7 +1791,7 @@ __global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
         s_l1[ly][2 * lx + 1] = q1;
         if (in) {
             const int w1 = a.w >> 1;
-            *reinterpret_cast<u32x2 *>(a.lv[side][0] + (static_cast<size_t>(by * 8 + ly) * w1 + bx * 64 + 2 * lx) * 4) = (u32x2){q0, q1};
+            *reinterpret_cast<u32x2 *>(a.lv[side][0] + io + (static_cast<size_t>(by * 8 + ly) * w1 + bx * 64 + 2 * lx) * 4) = (u32x2){q0, q1};
         }
     }
     if (a.nl < 2) return;
@@ -1785,7 +1801,7 @@ __global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
         const uint32_t q = quad_mean(s_l1[2 * ly][2 * lx], s_l1[2 * ly][2 * lx + 1], s_l1[2 * ly + 1][2 * lx], s_l1[2 * ly + 1][2 * lx + 1]);
         s_l2[ly][lx] = q;
         const int X = bx * 32 + lx, Y = by * 4 + ly, w2 = a.w >> 2;
-        if (X < w2 && Y < (a.h >> 2)) *reinterpret_cast<uint32_t *>(a.lv[side][1] + (static_cast<size_t>(Y) * w2 + X) * 4) = q;
+        if (X < w2 && Y < (a.h >> 2)) *reinterpret_cast<uint32_t *>(a.lv[side][1] + io + (static_cast<size_t>(Y) * w2 + X) * 4) = q;
     }
     if (a.nl < 3) return;
     __syncthreads();
@@ -1794,14 +1810,14 @@ __global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
         const uint32_t q = quad_mean(s_l2[2 * ly][2 * lx], s_l2[2 * ly][2 * lx + 1], s_l2[2 * ly + 1][2 * lx], s_l2[2 * ly + 1][2 * lx + 1]);
         s_l3[ly][lx] = q;
         const int X = bx * 16 + lx, Y = by * 2 + ly, w3 = a.w >> 3;
-        if (X < w3 && Y < (a.h >> 3)) *reinterpret_cast<uint32_t *>(a.lv[side][2] + (static_cast<size_t>(Y) * w3 + X) * 4) = q;
+        if (X < w3 && Y < (a.h >> 3)) *reinterpret_cast<uint32_t *>(a.lv[side][2] + io + (static_cast<size_t>(Y) * w3 + X) * 4) = q;
     }
     if (a.nl < 4) return;
     __syncthreads();
     if (tid < 8) {
         const uint32_t q = quad_mean(s_l3[0][2 * tid], s_l3[0][2 * tid + 1], s_l3[1][2 * tid], s_l3[1][2 * tid + 1]);
         const int X = bx * 8 + tid, Y = by, w4 = a.w >> 4;
-        if (X < w4 && Y < (a.h >> 4)) *reinterpret_cast<uint32_t *>(a.lv[side][3] + (static_cast<size_t>(Y) * w4 + X) * 4) = q;
+        if (X < w4 && Y < (a.h >> 4)) *reinterpret_cast<uint32_t *>(a.lv[side][3] + io + (static_cast<size_t>(Y) * w4 + X) * 4) = q;
     }
 }
 
@@ -1817,6 +1833,10 @@ __global__ __launch_bounds__(256) void pyramid_halve_kernel(PyrArgs a)
 struct BoxHalveArgs {
     BoxArgs b;
     uint8_t *l1[2];      // level 1 of side a / b, tight (srcW / 2) x (srcH / 2)
+    // a batch (blockIdx.z = 2 image + side): the level-0 images by pointer (device arrays), planes and level 1 in the ctx's
+    // scratch at `planes_img` / `l1_img` bytes per image
+    const uint8_t *const *srcs_a, *const *srcs_b;
+    size_t planes_img, l1_img;
 };
 
 template <int NP>
@@ -1853,8 +1873,9 @@ __global__ __launch_bounds__(256) void box_halve_kernel(BoxHalveArgs h)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_col[BOX_CHUNKS * 4 * 2];
     const BoxArgs &a = h.b;
-    const int side = blockIdx.z;                     // 0: a, 1: b (one pair per launch)
-    const uint8_t *src = side ? a.src_b : a.src;
+    const int side = blockIdx.z & 1;                 // 0: a, 1: b
+    const int img = blockIdx.z >> 1;                 // (0: one pair per launch)
+    const uint8_t *src = h.srcs_a ? (side ? h.srcs_b : h.srcs_a)[img] : (side ? a.src_b : a.src);
     const int sstride = side ? a.sstride_b : a.sstride;
     const int dy = blockIdx.y;
     const int dx_lo = blockIdx.x * a.seg;
@@ -1873,7 +1894,7 @@ __global__ __launch_bounds__(256) void box_halve_kernel(BoxHalveArgs h)
         const bool top_ok = (sy0 & 1) == 0, bot_ok = (sy1 & 1) == 0;
         const int l1stride = (a.srcW >> 1) * 4;
         const uint8_t *q = src + static_cast<size_t>(e0) * sstride + 4 * static_cast<size_t>(x);
-        uint8_t *l1p = h.l1[side] + static_cast<size_t>(e0 >> 1) * l1stride + 2 * static_cast<size_t>(x);
+        uint8_t *l1p = h.l1[side] + h.l1_img * img + static_cast<size_t>(e0 >> 1) * l1stride + 2 * static_cast<size_t>(x);
         int left = (e1 - e0) >> 1;
         bool first = true;
         // up to five pairs (every box of <= 8 rows, odd edges included) in ONE trip: all of a lane's loads in flight
@@ -1915,7 +1936,7 @@ __global__ __launch_bounds__(256) void box_halve_kernel(BoxHalveArgs h)
             }
         }
         const int count = (sy1 - sy0) * (sx1 - sx0);
-        uint8_t *dimg = a.dst + a.dst_image_bytes * side;
+        uint8_t *dimg = a.dst + h.planes_img * img + a.dst_image_bytes * side;
         *reinterpret_cast<uint32_t *>(dimg + static_cast<size_t>(dy) * a.dstride + 4 * static_cast<size_t>(dx)) =
             box_finish(r, g, b, al, count);
     }
@@ -1934,9 +1955,14 @@ static bool fast_dims(int w, int h, int *nw, int *nh)
     return false;
 }
 
+// nimg > 1: a batch of same-geometry pairs in the SAME five launches (the image is a grid dimension of each; d_as / d_bs are
+// device arrays of the level-0 pointers, a / b then only stand for their alignment); d_out holds five slots per image.
+// Only the default form is batched (level 0 read once, planes written by the box kernels, the separate finish launch).
 int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
-                        int nweights, const double *h_window, double *d_out, int *nlev)
+                        int nweights, const double *h_window, double *d_out, int *nlev,
+                        int nimg, const uint8_t *const *d_as, const uint8_t *const *d_bs)
 {
+    const unsigned nz = static_cast<unsigned>(nimg > 1 ? nimg : 1);
     const char *lvw = form_value(ctx, FORM_MSSSIM_LEVELWISE);             // "1": A/B and tests
     if ((lvw && lvw[0] == '1') || nweights < 1 || nweights > WS_MAXJOBS) return FNX_NOOP;
     WinSepArgs proto{};
@@ -1959,8 +1985,9 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
             off_lv[sd][k - 1] = total;
             total += (static_cast<size_t>(lw[k]) * lh[k] * 4 + 15) & ~size_t(15);
         }
+    const size_t pyr_img = (total + 255) & ~size_t(255);                  // per image of a batch
     void *pyr = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_TMP0, total + 16, &pyr));
+    FNX_TRY(scratch(ctx, SLOT_TMP0, pyr_img * nz + 16, &pyr));
     int pw[5], ph[5];
     bool down[5];
     size_t off_pl[5] = {}, ptotal = 0;
@@ -1973,10 +2000,11 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
             ptotal += 2 * ((static_cast<size_t>(pw[i]) * ph[i] * 4 + 15) & ~size_t(15));
         }
     }
+    const size_t planes_img = (ptotal + 255) & ~size_t(255);
     void *planes = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_TMP2, ptotal + 16, &planes));
+    FNX_TRY(scratch(ctx, SLOT_TMP2, planes_img * nz + 16, &planes));
     void *part = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES * nz, &part));
 
     const uint8_t *la[5], *lb[5];
     int ls[5];
@@ -2003,6 +2031,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
                             static_cast<int>(static_cast<double>(pw[0]) * ba.xRatio) >= lw[0];
         fuse0 = !nofuse && tiled && covers && (lw[1] & 3) == 0 && (lh[0] & 1) == 0;
     }
+    if (nz > 1 && !fuse0) return FNX_NOOP;                       // (the batch is the default form's)
     if (fuse0) {
         BoxArgs &ba = bh.b;
         const size_t plane = (static_cast<size_t>(pw[0]) * ph[0] * 4 + 15) & ~size_t(15);
@@ -2014,14 +2043,16 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         int seg = static_cast<int>((4 * BOX_CHUNKS - 8) / ba.xRatio);
         ba.seg = seg > 256 ? 256 : (seg < 1 ? 1 : seg);
         bh.l1[0] = lvp[0][0]; bh.l1[1] = lvp[1][0];
-        hipLaunchKernelGGL(box_halve_kernel, dim3((pw[0] + ba.seg - 1) / ba.seg, ph[0], 2), dim3(256), 0, ctx->stream, bh);
+        if (nz > 1) { bh.srcs_a = d_as; bh.srcs_b = d_bs; bh.planes_img = planes_img; bh.l1_img = pyr_img; }
+        hipLaunchKernelGGL(box_halve_kernel, dim3((pw[0] + ba.seg - 1) / ba.seg, ph[0], 2 * nz), dim3(256), 0, ctx->stream, bh);
         FNX_HIP(hipGetLastError());
         if (nl > 1) {
             PyrArgs pa{};
             pa.src[0] = lvp[0][0]; pa.src[1] = lvp[1][0]; pa.sstride[0] = pa.sstride[1] = lw[1] * 4;
             pa.w = lw[1]; pa.h = lh[1]; pa.nl = nl - 1;
+            pa.img_bytes = pyr_img;
             for (int k = 2; k <= nl; k++) { pa.lv[0][k - 2] = lvp[0][k - 1]; pa.lv[1][k - 2] = lvp[1][k - 1]; }
-            hipLaunchKernelGGL(pyramid_halve_kernel, dim3((lw[1] + 127) / 128, (lh[1] + 15) / 16, 2), dim3(256), 0, ctx->stream, pa);
+            hipLaunchKernelGGL(pyramid_halve_kernel, dim3((lw[1] + 127) / 128, (lh[1] + 15) / 16, 2 * nz), dim3(256), 0, ctx->stream, pa);
             FNX_HIP(hipGetLastError());
         }
     } else if (nl > 0) {
@@ -2055,7 +2086,7 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
                                                                      // 4K call, but the window kernel then finishes every staged pixel's
                                                                      // box 1.75 times over (tile halos) and config 3's four streams
                                                                      // measured 68 k MP/s against 72 k
-            if ((nb_env && nb_env[0] == '1') && i > 0 && lw[i] >= pw[i] && lh[i] >= ph[i] &&
+            if (nz == 1 && (nb_env && nb_env[0] == '1') && i > 0 && lw[i] >= pw[i] && lh[i] >= ph[i] &&
                 (static_cast<int>(xr) + 1) * (static_cast<int>(yr) + 1) <= 25) {
                 onfly[i] = true;
                 continue;
@@ -2083,7 +2114,8 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         nb++;
     }
     if (nb > 0) {
-        hipLaunchKernelGGL(box_tiled_multi_kernel, dim3(gx, gy, 2 * nb), dim3(256), 0, ctx->stream, bm);
+        if (nz > 1) { bm.njobs = nb; bm.src_img = pyr_img; bm.dst_img = planes_img; }
+        hipLaunchKernelGGL(box_tiled_multi_kernel, dim3(gx, gy, 2 * nb * nz), dim3(256), 0, ctx->stream, bm);
         FNX_HIP(hipGetLastError());
     }
     // the window sums of every level: one launch
@@ -2094,6 +2126,13 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
         WinSepArgs &wa = wm.job[i];
         wa = proto;
         wa.a = sa[i]; wa.b = sb[i]; wa.astride = sas[i]; wa.bstride = sbs[i]; wa.a_image_bytes = wa.b_image_bytes = 0;
+        if (nz > 1) {
+            // a batch: a level's operands are either its planes (plane scratch) or the level itself (pyramid scratch) -- never the
+            // caller's level-0 images, whose planes box_halve_kernel wrote (fuse0)
+            const bool in_planes = down[i];
+            if (!in_planes && i == 0) return FNX_NOOP;
+            wa.a_image_bytes = wa.b_image_bytes = in_planes ? planes_img : pyr_img;
+        }
         wa.w = pw[i]; wa.h = ph[i];
         if (onfly[i]) {
             wa.boxed = std::max(static_cast<int>(static_cast<double>(lw[i]) / static_cast<double>(pw[i])),
@@ -2115,7 +2154,8 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
     // Off by default: the write-through stores and counters cost what the launch costs (a single 4K call 75 us against
     // 71, config 3 the same within its noise); kept, with its test, as the measured alternative.
     const char *nf_env = form_value(ctx, FORM_MSSSIM_FOLD);
-    const bool fold = nf_env && nf_env[0] == '1';
+    const bool fold = nz == 1 && nf_env && nf_env[0] == '1';
+    if (nz > 1) { wm.nlev = levels; wm.part_img = SSIM_DEFER_DOUBLES; }
     if (fold) {
         unsigned *dn = nullptr;
         FNX_TRY(ssim_done_counters(ctx, &dn));
@@ -2125,9 +2165,9 @@ int launch_msssim_fused(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8
             wm.windows[i] = defer.item[i].windows;
         }
     }
-    hipLaunchKernelGGL(windowed_ssim_sep_multi_kernel, dim3(maxt, levels), dim3(256), 0, ctx->stream, wm);
+    hipLaunchKernelGGL(windowed_ssim_sep_multi_kernel, dim3(maxt, levels * nz), dim3(256), 0, ctx->stream, wm);
     FNX_HIP(hipGetLastError());
-    if (!fold) FNX_TRY(launch_ssim_finish_deferred(ctx, defer, d_out));
+    if (!fold) FNX_TRY(launch_ssim_finish_deferred(ctx, defer, d_out, static_cast<int>(nz), nz > 1 ? SSIM_DEFER_DOUBLES : 0, nz > 1 ? 5 : 0));
     *nlev = levels;
     return FNX_OK;
 }
@@ -2137,6 +2177,8 @@ struct FinishMulti {
     int tiles[8], out_index[8];
     double windows[8];
     double *out;
+    size_t part_img;             // a batch (blockIdx.y = image): partial sums part_img doubles apart, results out_img apart
+    int out_img;
 };
 
 // ssim_finish_kernel for several independent reductions: workgroup z finishes item z
@@ -2144,7 +2186,7 @@ __global__ __launch_bounds__(256) void ssim_finish_multi_kernel(FinishMulti f)
 {
     __shared__ double s_red[4];
     const int z = blockIdx.x;
-    const double *p = f.partial[z];
+    const double *p = f.partial[z] + f.part_img * blockIdx.y;
     const int tiles = f.tiles[z];
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i = threadIdx.x;
@@ -2155,15 +2197,16 @@ __global__ __launch_bounds__(256) void ssim_finish_multi_kernel(FinishMulti f)
     for (int e = 0; i < tiles; i += 256, e++) acc[e] += p[i];
     const double v = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     const double t = block_sum_256(v, s_red);
-    if (threadIdx.x == 0) f.out[f.out_index[z]] = f.windows[z] > 0 ? t / f.windows[z] : 1.0;
+    if (threadIdx.x == 0) f.out[f.out_index[z] + f.out_img * blockIdx.y] = f.windows[z] > 0 ? t / f.windows[z] : 1.0;
 }
 
-int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out)
+int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out, int nimg, size_t part_img, int out_img)
 {
     if (d.count == 0) return FNX_OK;
     void *part = nullptr;
-    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * SSIM_DEFER_DOUBLES, &part));
+    FNX_TRY(scratch(ctx, SLOT_PARTIAL, sizeof(double) * std::max(SSIM_DEFER_DOUBLES, part_img * static_cast<size_t>(nimg)), &part));
     FinishMulti f{};
+    f.part_img = part_img; f.out_img = out_img;
     for (int i = 0; i < d.count; i++) {
         f.partial[i] = static_cast<const double *>(part) + d.item[i].offset;
         f.tiles[i] = d.item[i].tiles;
@@ -2171,7 +2214,7 @@ int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_o
         f.windows[i] = d.item[i].windows;
     }
     f.out = d_out;
-    hipLaunchKernelGGL(ssim_finish_multi_kernel, dim3(d.count), dim3(256), 0, ctx->stream, f);
+    hipLaunchKernelGGL(ssim_finish_multi_kernel, dim3(d.count, nimg), dim3(256), 0, ctx->stream, f);
     FNX_HIP(hipGetLastError());
     return FNX_OK;
 }
