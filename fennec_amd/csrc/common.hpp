@@ -31,7 +31,7 @@ inline const char *dev_env(const char *) { return nullptr; }
 #endif
 
 enum Form {
-    FORM_FX_STREAM = 0,      // "fx_stream":       "0" = effects.hip's tile kernel, "1" = its one-pixel-per-lane streaming kernel
+    FORM_FX_STREAM = 0,      // "fx_stream":       "0" = effects.hip's tile kernel instead of the streaming one
     FORM_FX_PAIRS,           // "fx_pairs":        "0" = the tile kernel's one-row form
     FORM_FX_REF,             // "fx_ref":          "1" = the fp64 reference-order kernel (what tables outside the guard take)
     FORM_RESIZE_MFMA,        // "resize_mfma":     "0" never / "1" downscales (default) / "2" wherever the tables allow; read when a plan is built

@@ -611,187 +611,6 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------
-// r6: AdaptiveSharpen's streaming form with TWO pixels per lane and no LDS in the loop.
-// ------------------------------------------------------------------------------------
-// fx_stream_kernel<FX_ADAPTIVE> is instruction-bound (~90 % VALU-busy at 72 instructions per pixel): per pixel it pays a lane's
-// whole row overhead -- six LDS writes / reads and their waits for the two neighbours, the row's scalar bookkeeping and three
-// branches -- and runs its fp32 chain one sample per instruction.  Here a lane owns pixels (2 l, 2 l + 1) of a strip of 128:
-//   * the pair's inner neighbours are the lane's own registers; the outer ones (left of pixel 0: lane l - 1's pixel 1, right of
-//     pixel 1: lane l + 1's pixel 0) come through DPP wave shifts (wave_shr:1 / wave_shl:1 cross the 16-lane rows on gfx950,
-//     experiments/dpp/dpp_probe.hip): six v_mov_dpp per pair instead of twelve LDS operations and a wave barrier;
-//   * the fp32 chain of the two samples runs as v_pk_* (fx_march_kernel's paired form, with columns for rows): same operations
-//     in the same order per sample, same guard, same boundary test (fract(acc) >= 1 - 2 G flags the sample);
-//   * 126 outputs per wave (lane 0's pixel 0 and lane 63's pixel 1 are taps only): column halo 128 / 126 instead of 64 / 62.
-// Everything else is fx_stream_kernel's: clamped loads FXS_PF rows ahead without a branch around them, the three-row ring of
-// horizontal sums, borders and alpha copied from the source, flagged samples recomputed at the end of the segment in fp64 in the
-// reference's order from the source image, saturated samples (e == 1 for certain) by table.  Bit-exact by the same proof.
-constexpr int FXS2_COLS = 126;
-
-__device__ __forceinline__ uint32_t dpp_from_right(uint32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1: lane i <- lane i + 1
-__device__ __forceinline__ uint32_t dpp_from_left(uint32_t v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }    // wave_shr:1: lane i <- lane i - 1
-
-__global__ __launch_bounds__(256, 4) void fx_stream2_kernel(FxArgs a)
-{
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    __shared__ int16_t s_tab[512];
-    __shared__ uint32_t s_fix[4][FXS_FIX];
-    __shared__ int s_nfix[4];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (a.use_table) {
-        s_tab[tid] = static_cast<int16_t>(a.rtab[tid]);
-        s_tab[256 + tid] = static_cast<int16_t>(a.rtab[256 + tid]);
-    }
-    if (tid < 4) s_nfix[tid] = 0;
-    __syncthreads();                                                     // the only barrier
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= a.strips * a.segs) return;                               // wave-uniform
-    const int seg = item / a.strips, strip = item - seg * a.strips;
-    const int xa = strip * FXS2_COLS - 1 + 2 * lane;                     // the lane's pixels: xa, xa + 1
-    int x[2];
-    uint32_t xoff[2], xo[2];
-    bool mine[2], xborder[2];
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        x[e] = xa + e;
-        xoff[e] = 4u * static_cast<uint32_t>(clampi(x[e], 0, a.w - 1));     // clamped reads: see the tile kernel
-        xo[e] = 4u * static_cast<uint32_t>(x[e]);                            // (only lanes with 0 <= x < w store)
-        xborder[e] = x[e] <= 0 || x[e] >= a.w - 1;
-    }
-    mine[0] = lane >= 1 && x[0] < a.w;                                   // lane 0's first and lane 63's second pixel are taps only
-    mine[1] = lane <= 62 && x[1] < a.w;
-    const int y0 = seg * a.seg_rows;
-    const int nout = min(a.seg_rows, a.h - y0), nrows = nout + 2;        // rows y0 - 1 .. y0 + nout
-    auto load_row = [&](int r, int e) {                                  // r is wave-uniform: a scalar row base + one VGPR
-        const int yy = clampi(y0 - 1 + min(r, nrows - 1), 0, a.h - 1);
-        return *(g_u32 *)(a.src + (static_cast<uint32_t>(yy) * static_cast<uint32_t>(a.sstride) + xoff[e]));
-    };
-    uint32_t q[FXS_PF][2];
-#pragma unroll
-    for (int k = 0; k < FXS_PF; k++) { q[k][0] = load_row(k, 0); q[k][1] = load_row(k, 1); }
-    uint32_t hrb[3][2], hga[3][2], crb[3][2], cga[3][2];
-    int32_t dxr[3][2], sxr[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int e = 0; e < 2; e++) hrb[k][e] = hga[k][e] = crb[k][e] = cga[k][e] = 0u, dxr[k][e] = sxr[k][e] = 0;
-    const float seed = 0.5f - a.guard;
-    const v2f seed2 = {seed, seed};
-    const float amt = __builtin_canonicalizef(a.amt32), thr = a.flag_thr;
-    const v2f k2 = {a.k32, a.k32};
-    const bool use_table = a.use_table != 0;
-    // per-pixel forms of the amount and of the saturation bound: the image's border columns are copies of the source
-    const v2f amt2 = {xborder[0] ? 0.0f : amt, xborder[1] ? 0.0f : amt};
-    const float sat0 = xborder[0] ? __builtin_inff() : 1.6000016e11f, sat1 = xborder[1] ? __builtin_inff() : 1.6000016e11f;
-
-    for (int r0 = 0; r0 < nrows; r0 += 6) {
-#pragma unroll
-        for (int p = 0; p < 6; p++) {
-            const int r = r0 + p;
-            if (r < nrows) {                                             // wave-uniform
-                const int k = p % 3;
-                const uint32_t p0 = q[p % FXS_PF][0], p1 = q[p % FXS_PF][1];
-                q[p % FXS_PF][0] = load_row(r + FXS_PF, 0);              // no branch around the loads
-                q[p % FXS_PF][1] = load_row(r + FXS_PF, 1);
-                const uint32_t rb0 = p0 & 0x00ff00ffu, ga0 = ga_fields(p0), rb1 = p1 & 0x00ff00ffu, ga1 = ga_fields(p1);
-                const uint32_t l0 = lum_milli_u32(p0), l1 = lum_milli_u32(p1);
-                // the pair's outer neighbours: left of pixel 0 = lane l - 1's pixel 1, right of pixel 1 = lane l + 1's pixel 0
-                const uint32_t rbL = dpp_from_left(rb1), gaL = dpp_from_left(ga1), lL = dpp_from_left(l1);
-                const uint32_t rbR = dpp_from_right(rb0), gaR = dpp_from_right(ga0), lR = dpp_from_right(l0);
-                hrb[k][0] = rbL + rb1 + 2 * rb0; hga[k][0] = gaL + ga1 + 2 * ga0;
-                hrb[k][1] = rb0 + rbR + 2 * rb1; hga[k][1] = ga0 + gaR + 2 * ga1;
-                crb[k][0] = rb0; cga[k][0] = ga0; crb[k][1] = rb1; cga[k][1] = ga1;
-                dxr[k][0] = static_cast<int32_t>(l1) - static_cast<int32_t>(lL);
-                sxr[k][0] = static_cast<int32_t>(lL) + static_cast<int32_t>(l1) + 2 * static_cast<int32_t>(l0);
-                dxr[k][1] = static_cast<int32_t>(lR) - static_cast<int32_t>(l0);
-                sxr[k][1] = static_cast<int32_t>(l0) + static_cast<int32_t>(lR) + 2 * static_cast<int32_t>(l1);
-                if (r >= 2) {
-                    // output row yo: its three rows are ring entries T (yo - 1), M (yo), B (yo + 1) = the newest
-                    const int T = (p + 1) % 3, M = (p + 2) % 3, B = p % 3;
-                    const int yo = y0 + r - 2;
-                    const uint32_t c0 = crb[M][0] | (cga[M][0] << 8), c1 = crb[M][1] | (cga[M][1] << 8);
-                    uint32_t out0 = c0, out1 = c1;                       // borders and alpha are copies of the source (effects.go:68,120)
-                    bool flag0 = false, flag1 = false;
-                    if (yo >= 1 && yo < a.h - 1) {                       // wave-uniform
-                        const uint32_t brb0 = (hrb[T][0] + hrb[B][0] + 2 * hrb[M][0] + 0x00080008u) >> 4;
-                        const uint32_t bga0 = (hga[T][0] + hga[B][0] + 2 * hga[M][0] + 0x00080008u) >> 4;
-                        const uint32_t brb1 = (hrb[T][1] + hrb[B][1] + 2 * hrb[M][1] + 0x00080008u) >> 4;
-                        const uint32_t bga1 = (hga[T][1] + hga[B][1] + 2 * hga[M][1] + 0x00080008u) >> 4;
-                        const v2f gx = {static_cast<float>(dxr[T][0] + dxr[B][0] + 2 * dxr[M][0]), static_cast<float>(dxr[T][1] + dxr[B][1] + 2 * dxr[M][1])};
-                        const v2f gy = {static_cast<float>(sxr[B][0] - sxr[T][0]), static_cast<float>(sxr[B][1] - sxr[T][1])};
-                        const v2f m2 = __builtin_elementwise_fma(gy, gy, gx * gx);
-                        const v2f sq = {__builtin_amdgcn_sqrtf(m2.x), __builtin_amdgcn_sqrtf(m2.y)};
-                        const v2f tk = sq * k2;
-                        v2f t;                                           // min(amount, amount * |Sobel| / 400000); 0 on the image's border columns
-                        asm("v_min_f32 %0, %1, %2" : "=v"(t.x) : "v"(tk.x), "v"(amt2.x));
-                        asm("v_min_f32 %0, %1, %2" : "=v"(t.y) : "v"(tk.y), "v"(amt2.y));
-                        auto chan = [&](float o0, float o1, float b0, float b1) {
-                            const v2f f = {o0, o1}, bl = {b0, b1};
-                            return __builtin_elementwise_fma(t, f - bl, f + seed2);
-                        };
-                        const v2f ar = chan(ubyte_f32<0>(crb[M][0]), ubyte_f32<0>(crb[M][1]), ubyte_f32<0>(brb0), ubyte_f32<0>(brb1));
-                        const v2f ag = chan(ubyte_f32<0>(cga[M][0]), ubyte_f32<0>(cga[M][1]), ubyte_f32<0>(bga0), ubyte_f32<0>(bga1));
-                        const v2f ab = chan(ubyte_f32<2>(crb[M][0]), ubyte_f32<2>(crb[M][1]), ubyte_f32<2>(brb0), ubyte_f32<2>(brb1));
-                        const float f0 = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar.x), __builtin_amdgcn_fractf(ag.x)), __builtin_amdgcn_fractf(ab.x));
-                        const float f1 = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar.y), __builtin_amdgcn_fractf(ag.y)), __builtin_amdgcn_fractf(ab.y));
-                        fp32_round_toward_zero();
-                        out0 = pk8(ab.x, 2, pk8(ag.x, 1, pk8(ar.x, 0, cga[M][0] << 8)));
-                        out1 = pk8(ab.y, 2, pk8(ag.y, 1, pk8(ar.y, 0, cga[M][1] << 8)));
-                        fp32_round_nearest();
-                        flag0 = f0 >= thr; flag1 = f1 >= thr;
-                        if (use_table) {                                 // e == 1 for certain: exact by table
-                            auto tab = [&](uint32_t crbv, uint32_t cgav, uint32_t brb, uint32_t bga) {
-                                const int br = brb & 0xffu, bg = bga & 0xffu, bb = (brb >> 16) & 0xffu;
-                                const int o_r = crbv & 0xffu, o_g = cgav & 0xffu, o_b = (crbv >> 16) & 0xffu;
-                                const int vr = clampi(o_r + s_tab[o_r - br + 255], 0, 255), vg = clampi(o_g + s_tab[o_g - bg + 255], 0, 255),
-                                          vb = clampi(o_b + s_tab[o_b - bb + 255], 0, 255);
-                                return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | ((cgav << 8) & 0xff000000u);
-                            };
-                            if (m2.x > sat0) { out0 = tab(crb[M][0], cga[M][0], brb0, bga0); flag0 = false; }
-                            if (m2.y > sat1) { out1 = tab(crb[M][1], cga[M][1], brb1, bga1); flag1 = false; }
-                        }
-                        // (a border column runs with amount 0 -- acc = orig + 0.5 - G packs to orig and never flags)
-                        flag0 = flag0 && mine[0]; flag1 = flag1 && mine[1];
-                        if (flag0 || flag1) {
-                            if (flag0) {
-                                const int e = atomicAdd(&s_nfix[wave], 1);
-                                if (e < FXS_FIX) s_fix[wave][e] = (static_cast<uint32_t>(yo) << 16) | static_cast<uint32_t>(x[0]);
-                            }
-                            if (flag1) {
-                                const int e = atomicAdd(&s_nfix[wave], 1);
-                                if (e < FXS_FIX) s_fix[wave][e] = (static_cast<uint32_t>(yo) << 16) | static_cast<uint32_t>(x[1]);
-                            }
-                        }
-                    }
-                    const uint32_t rowo = static_cast<uint32_t>(yo) * static_cast<uint32_t>(a.dstride);
-                    if (mine[0] && !flag0) *(g_u32w *)(a.dst + (rowo + xo[0])) = out0;
-                    if (mine[1] && !flag1) *(g_u32w *)(a.dst + (rowo + xo[1])) = out1;
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // a list that overflowed (an amount / image that flags nearly everything): every interior sample of the segment
-    const int nfix = s_nfix[wave];
-    const bool over = nfix > FXS_FIX;
-    const int total = over ? nout * FXS2_COLS : nfix;
-    for (int e = lane; e < total; e += 64) {
-        int fx, fy;
-        if (over) {
-            fy = y0 + e / FXS2_COLS;
-            fx = strip * FXS2_COLS + (e - (e / FXS2_COLS) * FXS2_COLS);
-        } else {
-            const uint32_t ent = s_fix[wave][e];
-            fx = static_cast<int>(ent & 0xffffu);
-            fy = static_cast<int>(ent >> 16);
-        }
-        if (fx >= 1 && fy >= 1 && fx < a.w - 1 && fy < a.h - 1) fx_fix_from_source(a, fx, fy);
-    }
-}
-
 // R[d + 255] = floor(fl(amount * d) + 0.5), d in [-255, 255].  false: some product is within 1e-6 of a
 // half-integer without being one (the sum's fp64 rounding could then decide), or the table would not fit.
 // *ties: some product IS a half-integer (only the guard's statistics care).
@@ -928,29 +747,7 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
         if (a.seg_rows < 16) a.seg_rows = h < 16 ? h : 16;
         a.segs = (h + a.seg_rows - 1) / a.seg_rows;
         const int items = a.strips * a.segs;
-        // AdaptiveSharpen: the two-pixel-per-lane form (fx_stream2_kernel) unless the ctx asked for the one-pixel kernel
-        // ("fx_stream" = "1": A/B and tests) or the image is narrower than one of its strips
-        bool two = false;
-        if constexpr (MODE == FX_ADAPTIVE) two = !(stream_env && stream_env[0] == '1') && w >= 128;
-        if (two) {
-            static const int per_cu2 = [] {
-                int nb = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fx_stream2_kernel, 256, 0) != hipSuccess || nb < 1) nb = 4;
-                return nb;
-            }();
-            a.strips = (w + FXS2_COLS - 1) / FXS2_COLS;
-            const long cap2 = static_cast<long>(ctx->num_cus) * per_cu2 * 4 * rounds;
-            int segs2 = static_cast<int>(cap2 / a.strips);
-            segs2 = segs2 < 1 ? 1 : segs2;
-            a.seg_rows = (h + segs2 - 1) / segs2;
-            if (a.seg_rows < 16) a.seg_rows = h < 16 ? h : 16;
-            a.segs = (h + a.seg_rows - 1) / a.seg_rows;
-            note_route(ctx, FNX_PROF_FX, "fx_stream2_kernel");
-            hipLaunchKernelGGL(fx_stream2_kernel, dim3((a.strips * a.segs + 3) / 4), dim3(256), 0, ctx->stream, a);
-        } else {
-            note_route(ctx, FNX_PROF_FX, "fx_stream_kernel");
-            hipLaunchKernelGGL((fx_stream_kernel<MODE>), dim3((items + 3) / 4), dim3(256), 0, ctx->stream, a);
-        }
+        hipLaunchKernelGGL((fx_stream_kernel<MODE>), dim3((items + 3) / 4), dim3(256), 0, ctx->stream, a);
     } else if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
         // FNX_FX_LDS_PAD=<bytes> of unused dynamic LDS: an A/B knob for workgroups per CU (8192 -> 4 instead of 5)

@@ -162,8 +162,7 @@ int fnx_ctx_set_ssim_mode(fnx_ctx *ctx, int mode);
 /* Kernel-form selection of ONE ctx, for tests and A/B timing: every form computes the same bytes as the default, the
  * selection only says which kernel does it, so that a fallback the product takes for rare tables (the fp64
  * reference-order kernels, the two-pass twin of a fused launch ...) can be run on any image and compared.  name / value:
- *   "fx_stream" "0|1"      effects.hip's tile kernel / its one-pixel-per-lane streaming kernel (default: AdaptiveSharpen of images
- *                          from 128 px wide takes the two-pixel-per-lane streaming kernel, everything else the one-pixel one)
+ *   "fx_stream" "0"        effects.hip's tile kernel instead of the streaming kernel
  *   "fx_pairs" "0"         the tile kernel's one-row form
  *   "fx_ref" "1"           the fp64 reference-order effects kernel
  *   "resize_mfma" "0|1|2"  matrix-pipe resize never / downscales (default) / wherever the tables allow (read when a plan is built)

@@ -180,17 +180,13 @@ def test_sharpen_adaptive_guarded_kernels(ctx, orc, w, h):
             assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), ("adaptive", s)
 
 
-@pytest.mark.parametrize("form", ["stream2", "stream", "tile_pairs", "tile_rows"])
-@pytest.mark.parametrize("w,h", [(64, 24), (62, 16), (63, 17), (125, 100), (200, 150), (1000, 37), (3, 3), (2, 9), (9, 2), (1, 1), (4, 700), (517, 389),
-                                 (126, 40), (127, 33), (128, 19), (129, 50), (252, 31), (253, 64), (254, 18), (380, 200)])
+@pytest.mark.parametrize("form", ["stream", "tile_pairs", "tile_rows"])
+@pytest.mark.parametrize("w,h", [(64, 24), (62, 16), (63, 17), (125, 100), (200, 150), (1000, 37), (3, 3), (2, 9), (9, 2), (1, 1), (4, 700), (517, 389)])
 def test_fx_kernel_forms(ctx, orc, monkeypatch, form, w, h):
     """Round 3: the streaming kernel (a wave marches down a strip of 62 columns) and both forms of the tile kernel
     (paired rows on v_pk_* with the fract boundary test; one row at a time with the second pack) against the
     oracle -- sizes around the strip width, the segment length and the tile."""
-    # r6: "stream2" = the default (AdaptiveSharpen of images from 128 px wide: two pixels per lane, neighbours through DPP;
-    # strips of 126 columns -- the sizes around 126 / 128 / 252); "stream" = the one-pixel-per-lane streaming kernel
-    if form != "stream2":
-        ctx.set_form("fx_stream", "1" if form == "stream" else "0")
+    ctx.set_form("fx_stream", "1" if form == "stream" else "0")
     ctx.set_form("fx_pairs", "0" if form == "tile_rows" else "1")
     soft = _soft_image(orc, w, h, 3 * w + h)
     hard = synth.large_photo(w, h, 5)
@@ -201,12 +197,11 @@ def test_fx_kernel_forms(ctx, orc, monkeypatch, form, w, h):
             assert np.array_equal(ctx.AdaptiveSharpen(img, s), orc.adaptive_sharpen(img, s)), ("adaptive", s)
 
 
-@pytest.mark.parametrize("form", ["stream2", "stream", "tile_pairs"])
+@pytest.mark.parametrize("form", ["stream", "tile_pairs"])
 def test_fx_kernel_forms_4k_and_views(ctx, orc, monkeypatch, form):
     """The same at 4K (many segments per strip) and on strided device views (the flat-copy pass runs behind either form)."""
     import torch
-    if form != "stream2":
-        ctx.set_form("fx_stream", "1" if form == "stream" else "0")
+    ctx.set_form("fx_stream", "1" if form == "stream" else "0")
     img = _soft_image(orc, 3840, 2160, 11)
     assert np.array_equal(ctx.AdaptiveSharpen(img, 0.5), orc.adaptive_sharpen(img, 0.5, procs=32))
     assert np.array_equal(ctx.Sharpen(img, 0.5), orc.sharpen(img, 0.5, procs=32))
