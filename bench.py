@@ -1431,7 +1431,7 @@ def other_workload_line(args, embedded: bool = False):
                                ("resize_fused_dense_kernel<4", "resize_fused_dense_kernel<4> (a plan in its second tie-dense cool-down: "
                                                                "the tile without fp32 passes)"),
                                ("resize_fused_kernel<4", "resize_fused_kernel<4>")):
-                t = committed_traffic_named(pat, "config3")
+                t = committed_traffic_named(pat, "config3", per_image=True)
                 if t is not None:
                     down_traffic, down_file, down_name = t, source_file("traffic"), label
                     break
@@ -1575,8 +1575,9 @@ def committed_valu_issue(kernel_substr: str, launch_ms: float, scored: bool = Fa
     return None
 
 
-def committed_traffic_named(kernel_substr: str, tag: str):
-    """HBM bytes per launch of a kernel from profiles/*<tag>*_traffic.json (see committed_traffic); None if absent."""
+def committed_traffic_named(kernel_substr: str, tag: str, per_image: bool = False):
+    """HBM bytes per launch of a kernel from profiles/*<tag>*_traffic.json (see committed_traffic); None if absent.
+    per_image: divided by the file's images_per_launch (config 3's batched launches hold several images)."""
     import glob
     _SOURCES["traffic"] = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{tag}*_traffic.json")), reverse=True):   # r05 before r04 ...
@@ -1585,7 +1586,7 @@ def committed_traffic_named(kernel_substr: str, tag: str):
             for k, v in t["kernels"].items():
                 if kernel_substr in k:
                     _SOURCES["traffic"] = os.path.relpath(p, ROOT)
-                    return float(v["hbm_bytes_per_launch"])
+                    return float(v["hbm_bytes_per_launch"]) / (max(1, int(t.get("images_per_launch", 1))) if per_image else 1)
         except Exception:
             continue
     return None

@@ -17,7 +17,7 @@ collect() {   # tag, bench flags, images per launch
 }
 STEPS=10 collect ${R}_onepass "" 32
 collect ${R}_config4 "--workload config4" 1
-collect ${R}_config3 "--workload config3 --contexts 1" 1
+collect ${R}_config3 "--workload config3 --contexts 1" 4      # (r6: 4 images per batched call, bench.py --config3-chunk)
 # the resize kernels config 3's default line does not show: photograph-like content takes resize_mfma_kernel +
 # resize_fused_sparse_kernel; one PMC pass set over tools/time_resize.py on both kinds of content
 for kind in ramp soft; do
