@@ -1160,6 +1160,26 @@ def test_ssim_fast_moments(ctx, orc, case):
         ctx.set_ssim_mode(False)
 
 
+@pytest.mark.parametrize("w,h", [(40, 150000), (200000, 40), (2057, 2003)])
+def test_ssim_fast_moments_odd_geometry(ctx, orc, w, h):
+    """FNX_SSIM_FAST on planes that are one strip wide (every lane past column 32 idle), one segment tall, and of odd size
+    (the last strip's idle columns, the last segment's partial group of rows): <= 1e-6 against the oracle, the fp64 kernel <= 1e-9."""
+    a = synth.noise_image(w, h, 17)
+    a[..., :3] = (a[..., :3] // 3) + 80
+    b = a.copy()
+    rng = np.random.default_rng(4)
+    b[..., :3] = np.clip(b[..., :3].astype(int) + rng.integers(-9, 10, (h, w, 3)), 0, 255)
+    want = orc.ssim(a, b, procs=32)
+    assert abs(ctx.SSIM(a, b) - want) <= SSIM_TOL
+    ctx.set_ssim_mode(True)
+    try:
+        fast = ctx.SSIM(a, b)
+        assert ctx.last_kernel(fennec_amd.PROF_SSIM) == "windowed_ssim_march2f_kernel"
+        assert abs(fast - want) <= SSIM_FAST_TOL, (w, h, fast - want)
+    finally:
+        ctx.set_ssim_mode(False)
+
+
 def test_ssim_mode_argument(ctx):
     with pytest.raises(fennec_amd.FennecError):
         ctx._chk(ctx._lib.fnx_ctx_set_ssim_mode(ctx._h, 7), "fnx_ctx_set_ssim_mode")
