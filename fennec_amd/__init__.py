@@ -197,6 +197,9 @@ def load_library() -> C.CDLL:
                                             C.POINTER(i), C.POINTER(i), C.POINTER(i)])
         _sig(L, "fnx_jpeg_quality_search", i, [ctx, i] + img + [i, i, d, _f64p, C.POINTER(i), _f64p, C.POINTER(i)])
         _sig(L, "fnx_gaussian_blur_ssim_fast", i, [ctx, i] + img + [i, i, _f64p, i, i] + img + [_f64p, _f64p])
+        _sig(L, "fnx_ssim_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
+        _sig(L, "fnx_sharpen_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.c_double, C.POINTER(C.c_void_p), i])
+        _sig(L, "fnx_adaptive_sharpen_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.c_double, C.POINTER(C.c_void_p), i])
         _sig(L, "fnx_msssim_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, C.POINTER(C.c_void_p), i, i, i, _f64p])
         _sig(L, "fennec_MSSSIM_batch_enqueue", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, C.POINTER(C.c_void_p), i, i, i])
         _sig(L, "fnx_lanczos_resize_batch", i, [ctx, i, C.POINTER(C.c_void_p), i, i, i, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p,
@@ -524,6 +527,44 @@ class Context:
         with self._ordered(*imgs1, *imgs2):
             self._chk(self._lib.fennec_MSSSIM_batch_enqueue(self._h, n, pa, a0.stride, a0.w, a0.h, pb, b0.stride, b0.w, b0.h),
                       "fennec_MSSSIM_batch_enqueue")
+
+    def ssim_batch_enqueue(self, imgs1, imgs2, window=None):
+        """fnx_ssim_batch_enqueue: SSIM of n same-sized device pairs in one launch; fetch_results(n)."""
+        va, vb = [_Img(t) for t in imgs1], [_Img(t) for t in imgs2]
+        n = len(va)
+        if n == 0 or n != len(vb) or any(v.space != FNX_DEVICE for v in va + vb):
+            raise FennecError("ssim_batch_enqueue takes two equally long, non-empty lists of device tensors")
+        a0, b0 = va[0], vb[0]
+        if any((v.w, v.h, v.stride) != (a0.w, a0.h, a0.stride) for v in va) or any((v.w, v.h, v.stride) != (a0.w, a0.h, b0.stride) for v in vb):
+            raise FennecError("every image of a batch must share width and height, and every image of a side its stride")
+        pa = (C.c_void_p * n)(*[v.ptr for v in va])
+        pb = (C.c_void_p * n)(*[v.ptr for v in vb])
+        k, pk = _f64(self.gaussianKernel() if window is None else window)
+        with self._ordered(*imgs1, *imgs2):
+            self._chk(self._lib.fnx_ssim_batch_enqueue(self._h, n, pa, a0.stride, pb, b0.stride, a0.w, a0.h, pk), "fnx_ssim_batch_enqueue")
+
+    def sharpen_batch(self, imgs, strength: float, adaptive: bool = False, outs=None):
+        """Sharpen / AdaptiveSharpen (effects.go:10 / :49) of n same-sized device images in one launch (fnx_*_sharpen_batch);
+        strength <= 0 or images under 3 x 3 come back as they are, as from the single calls.  Enqueued."""
+        views = [_Img(t) for t in imgs]
+        if not views or any(v.space != FNX_DEVICE for v in views):
+            raise FennecError("sharpen_batch takes a non-empty list of device tensors")
+        v0 = views[0]
+        if any((v.w, v.h, v.stride) != (v0.w, v0.h, v0.stride) for v in views):
+            raise FennecError("every image of a batch must share width, height and stride")
+        if strength <= 0 or v0.w < 3 or v0.h < 3:
+            return list(imgs)
+        amount = 1.0 + min(strength, 1.0) * (2.0 if adaptive else 1.5)
+        if outs is None:
+            outs = [v0.like(v0.w, v0.h) for _ in views]
+        ov = [_Img(t) for t in outs]
+        n = len(views)
+        srcs = (C.c_void_p * n)(*[v.ptr for v in views])
+        dsts = (C.c_void_p * n)(*[v.ptr for v in ov])
+        fn = self._lib.fnx_adaptive_sharpen_batch if adaptive else self._lib.fnx_sharpen_batch
+        with self._ordered(*imgs, *outs):
+            self._chk(fn(self._h, n, srcs, v0.stride, v0.w, v0.h, C.c_double(amount), dsts, ov[0].stride), "sharpen_batch")
+        return outs
 
     def fetch_results(self, n: int) -> np.ndarray:
         """The oldest FIFO entry's n values (fnx_results_fetch)."""

@@ -417,6 +417,45 @@ int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstrid
     return sharpen_common(ctx, true, space, src, sstride, w, h, amount, dst, dstride);
 }
 
+// n same-geometry device images in ONE launch of the streaming kernel (tight images); anything else image by image
+static int sharpen_batch_common(fnx_ctx *ctx, bool adaptive, int n, const uint8_t *const *srcs, int sstride, int w, int h, double amount,
+                                uint8_t *const *dsts, int dstride)
+{
+    FNX_ENTER(ctx);
+    FNX_REQUIRE(n >= 0 && (n == 0 || (srcs && dsts)), "batch arguments");
+    if (n == 0) return FNX_OK;
+    FNX_REQUIRE(w >= 3 && h >= 3, "sharpen needs w,h >= 3 (the reference returns the input below that)");
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(srcs[i] && dsts[i] && srcs[i] != dsts[i], "null image in batch, or dst aliases src");
+        FNX_TRY(check_img(srcs[i], sstride, w, h, "src"));
+        FNX_TRY(check_img(dsts[i], dstride, w, h, "dst"));
+    }
+    if (n > 1) {
+        const void *hosts[2] = {srcs, dsts};
+        const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+        void *dp[2];
+        FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+        const int rc = launch_sharpen_batch(ctx, adaptive, n, srcs[0], static_cast<const uint8_t *const *>(dp[0]), sstride, w, h, amount,
+                                            dsts[0], static_cast<uint8_t *const *>(dp[1]), dstride);
+        if (rc < 0) return rc;
+        if (rc != FNX_NOOP) return FNX_OK;
+    }
+    for (int i = 0; i < n; i++) FNX_TRY(launch_sharpen(ctx, adaptive, srcs[i], sstride, w, h, amount, dsts[i], dstride));
+    return FNX_OK;
+}
+
+int fnx_sharpen_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, double amount,
+                      uint8_t *const *dsts, int dstride)
+{
+    return sharpen_batch_common(ctx, false, n, srcs, sstride, w, h, amount, dsts, dstride);
+}
+
+int fnx_adaptive_sharpen_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, double amount,
+                               uint8_t *const *dsts, int dstride)
+{
+    return sharpen_batch_common(ctx, true, n, srcs, sstride, w, h, amount, dsts, dstride);
+}
+
 // ---- resize ------------------------------------------------------------------------
 int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int srcW, int srcH,
                  const int32_t *offset, const int32_t *index, const double *weight,
@@ -961,6 +1000,49 @@ int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_
     q.nraw = nlev;
     for (int i = 0; i < 5; i++) q.weights[i] = weights[i];
     return FNX_OK;
+}
+
+// n same-geometry device pairs scored by ONE launch of the window kernel (the image is its second grid dimension), on the
+// ctx's second stream like fnx_ssim_enqueue; one FIFO entry of n values
+int fnx_ssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride,
+                           int w, int h, const double *window)
+{
+    FNX_ENTER(ctx);
+    FNX_REQUIRE(n >= 0 && (n == 0 || (as && bs)) && window != nullptr && w > 0 && h > 0, "batch arguments");
+    if (n == 0) return FNX_OK;
+    for (int i = 0; i < n; i++) {
+        FNX_REQUIRE(as[i] && bs[i], "null image in batch");
+        FNX_TRY(check_img(as[i], astride, w, h, "a"));
+        FNX_TRY(check_img(bs[i], bstride, w, h, "b"));
+    }
+    FNX_TRY(can_enqueue(ctx));
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
+    double *dres;
+    FNX_TRY(result_slot_queued(ctx, n, &dres));
+    if (w < 8 || h < 8) {   // ssim.go:35-37: pixelSSIM, pair by pair
+        FNX_REQUIRE(pix_len(w, h, bstride) >= pix_len(w, h, astride), "b.Pix shorter than a.Pix (the reference would panic)");
+        for (int i = 0; i < n; i++) FNX_TRY(launch_pixel_ssim(ctx, as[i], bs[i], w, h, pix_len(w, h, astride), dres + i));
+        return publish_results(ctx, dres, n);
+    }
+    const void *hosts[2] = {as, bs};
+    const size_t sizes[2] = {sizeof(void *) * size_t(n), sizeof(void *) * size_t(n)};
+    void *dp[2];
+    FNX_TRY(upload_tables(ctx, SLOT_PTRS, hosts, sizes, 2, dp));
+    hipEvent_t ev = ctx->ev_blur[ctx->ev_toggle];                 // (see fnx_ssim_enqueue)
+    FNX_HIP(hipEventRecord(ev, ctx->stream));
+    FNX_HIP(hipStreamWaitEvent(ctx->stream2, ev, 0));
+    ctx->stream2_used = true;
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->stream2;
+    ctx->partial_slot = SLOT_PART0;
+    int rc = launch_windowed_ssim(ctx, n, as[0], astride, 0, bs[0], bstride, 0, w, h, window, static_cast<const double *>(dwin), dres, nullptr, 0,
+                                  static_cast<const uint8_t *const *>(dp[0]), static_cast<const uint8_t *const *>(dp[1]));
+    if (rc >= 0) rc = publish_results(ctx, dres, n);
+    ctx->partial_slot = -1;
+    ctx->stream = main_stream;
+    ctx->ev_toggle ^= 1;
+    return rc;
 }
 
 int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride,

@@ -347,6 +347,8 @@ int launch_blur3x3(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, 
                    int dstride);
 int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride, int w, int h,
                    double amount, uint8_t *dst, int dstride);
+int launch_sharpen_batch(fnx_ctx *ctx, bool adaptive, int n, const uint8_t *src0, const uint8_t *const *d_srcs, int sstride, int w, int h,
+                         double amount, uint8_t *dst0, uint8_t *const *d_dsts, int dstride);
 // One pass of lanczosResize through the ctx's plan cache: guard-exact fp32 kernels where the table allows,
 // the fp64 kernels otherwise.  vertical == false: dst is t.nout x srcH; true: dst is srcW x t.nout.
 // `hint` (optional) carries the H pass's per-workgroup verdicts to the V pass of the same lanczosResize call: where
@@ -426,7 +428,8 @@ struct SsimDeferred {
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
                          const double *h_window, const double *d_window, double *d_out,
-                         SsimDeferred *defer = nullptr, int defer_out_index = 0);
+                         SsimDeferred *defer = nullptr, int defer_out_index = 0,
+                         const uint8_t *const *d_as = nullptr, const uint8_t *const *d_bs = nullptr);   // device pointer arrays: image z = d_as[z] / d_bs[z]
 int launch_ssim_finish_deferred(fnx_ctx *ctx, const SsimDeferred &d, double *d_out, int nimg = 1, size_t part_img = 0, int out_img = 0);
 // MSSSIM's levels in five launches (ssim.hip); FNX_NOOP (nothing launched) for shapes it does not cover.
 // d_out[i] = SSIMFast of level i; *nlev = levels the reference's loop visits.

@@ -49,6 +49,9 @@ struct FxArgs {
     int vec_ok;            // src base and stride 16-byte aligned
     int strips, segs, seg_rows;   // streaming form: per image strips x segs wave-sized items of seg_rows output rows
     int pairs;             // AdaptiveSharpen: interior tiles take the paired-row form (FNX_FX_PAIRS=0: the one-row form, A/B)
+    // a batch of same-geometry tight images (fx_stream_kernel's blockIdx.y = image): device arrays of their pointers
+    const uint8_t *const *srcs;
+    uint8_t *const *dsts;
 };
 
 // ------------------------------------------------------------------------------------
@@ -473,6 +476,10 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
         s_tab[256 + tid] = static_cast<int16_t>(a.rtab[256 + tid]);
     }
     if (tid < 4) s_nfix[tid] = 0;
+    if (a.srcs) {                                                        // a batch: this workgroup's image
+        a.src = a.srcs[blockIdx.y];
+        a.dst = a.dsts[blockIdx.y];
+    }
     __syncthreads();                                                     // the only barrier
     const int item = blockIdx.x * 4 + wave;
     if (item >= a.strips * a.segs) return;                               // wave-uniform
@@ -688,12 +695,16 @@ __global__ __launch_bounds__(256) void fx_flat_kernel(FxArgs a)
     }
 }
 
+// nimg > 1: a batch of same-geometry TIGHT images in one launch of the streaming kernel (d_srcs / d_dsts: device arrays of their
+// pointers); FNX_NOOP -- nothing launched -- where that kernel does not apply (the caller then goes image by image)
 template <int MODE>
 static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h, double amount,
-                     uint8_t *dst, int dstride)
+                     uint8_t *dst, int dstride, int nimg = 1, const uint8_t *const *d_srcs = nullptr, uint8_t *const *d_dsts = nullptr)
 {
     if (w <= 0 || h <= 0) return FNX_OK;
+    const unsigned nz = static_cast<unsigned>(nimg > 1 ? nimg : 1);
     FxArgs a{};
+    if (nz > 1) { a.srcs = d_srcs; a.dsts = d_dsts; }
     a.src = src; a.dst = dst; a.sstride = sstride; a.dstride = dstride; a.w = w; a.h = h; a.amount = amount;
     a.vec_ok = aligned16(src, sstride) ? 1 : 0;
     bool march = true;
@@ -728,10 +739,12 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
     if (force_ref && force_ref[0] == '1') march = false;
     // the tile kernels address the destination with 32-bit offsets
     if (static_cast<long long>(h) * dstride >= (1ll << 31)) march = false;
-    FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
     const char *stream_env = form_value(ctx, FORM_FX_STREAM);            // A/B and tests: "0" takes the tile kernel
     const int stream_on = stream_env ? atoi(stream_env) : 1;
-    if (march && stream_on && w < 65536 && h < 65536 && static_cast<long long>(h) * sstride < (1ll << 31)) {
+    const bool streams = march && stream_on && w < 65536 && h < 65536 && static_cast<long long>(h) * sstride < (1ll << 31);
+    if (nz > 1 && (!streams || sstride != w * 4)) return FNX_NOOP;       // (a SubImage's flat-copy pass is per image)
+    FNX_TRY(prof_begin(ctx, FNX_PROF_FX));
+    if (streams) {
         // one wave per (strip, segment); segments sized so that the launch is one round of resident waves
         static const int per_cu = [] {
             int nb = 0;
@@ -741,13 +754,13 @@ static int launch_fx(fnx_ctx *ctx, const uint8_t *src, int sstride, int w, int h
         static const int rounds = [] { const char *e = dev_env("FNX_FX_ROUNDS"); return e ? atoi(e) : 1; }();
         a.strips = (w + FXS_COLS - 1) / FXS_COLS;
         const long capacity = static_cast<long>(ctx->num_cus) * per_cu * 4 * rounds;
-        int segs = static_cast<int>(capacity / a.strips);
+        int segs = static_cast<int>(capacity / (static_cast<long>(a.strips) * nz));
         segs = segs < 1 ? 1 : segs;
         a.seg_rows = (h + segs - 1) / segs;
         if (a.seg_rows < 16) a.seg_rows = h < 16 ? h : 16;
         a.segs = (h + a.seg_rows - 1) / a.seg_rows;
         const int items = a.strips * a.segs;
-        hipLaunchKernelGGL((fx_stream_kernel<MODE>), dim3((items + 3) / 4), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((fx_stream_kernel<MODE>), dim3((items + 3) / 4, nz), dim3(256), 0, ctx->stream, a);
     } else if (march) {
         dim3 grid((w + FX_TW - 1) / FX_TW, (h + FX_TH - 1) / FX_TH);
         // FNX_FX_LDS_PAD=<bytes> of unused dynamic LDS: an A/B knob for workgroups per CU (8192 -> 4 instead of 5)
@@ -776,6 +789,15 @@ int launch_sharpen(fnx_ctx *ctx, bool adaptive, const uint8_t *src, int sstride,
 {
     return adaptive ? launch_fx<FX_ADAPTIVE>(ctx, src, sstride, w, h, amount, dst, dstride)
                     : launch_fx<FX_SHARPEN>(ctx, src, sstride, w, h, amount, dst, dstride);
+}
+
+// n same-geometry tight device images in one launch (d_srcs / d_dsts: device pointer arrays; src0 / dst0: the first pair, for
+// the alignment the kernel form depends on); FNX_NOOP where the streaming kernel does not apply
+int launch_sharpen_batch(fnx_ctx *ctx, bool adaptive, int n, const uint8_t *src0, const uint8_t *const *d_srcs, int sstride, int w, int h,
+                         double amount, uint8_t *dst0, uint8_t *const *d_dsts, int dstride)
+{
+    return adaptive ? launch_fx<FX_ADAPTIVE>(ctx, src0, sstride, w, h, amount, dst0, dstride, n, d_srcs, d_dsts)
+                    : launch_fx<FX_SHARPEN>(ctx, src0, sstride, w, h, amount, dst0, dstride, n, d_srcs, d_dsts);
 }
 
 }  // namespace fnx

@@ -441,9 +441,16 @@ int launch_box_downsample_pair(fnx_ctx *ctx, int n, const uint8_t *src, const ui
 // ------------------------------------------------------------------------------------
 constexpr int WS_TX = 32, WS_TY = 8;   // windows per workgroup (one per thread)
 
+// image z of a batched launch: by pointer array (separately allocated images: fnx_ssim_batch_enqueue) or at a fixed spacing
+__device__ __forceinline__ const uint8_t *batch_img(const uint8_t *base, const uint8_t *const *ptrs, size_t image_bytes, int z)
+{
+    return ptrs ? ptrs[z] : base + image_bytes * z;
+}
+
 struct WinArgs {
     const uint8_t *a;
     const uint8_t *b;
+    const uint8_t *const *as, *const *bs;    // non-null: image z is as[z] / bs[z]
     size_t a_image_bytes, b_image_bytes;
     int astride, bstride, w, h;
     int tiles_x, tiles;    // per image pair
@@ -460,8 +467,8 @@ __global__ __launch_bounds__(256) void windowed_ssim_kernel(WinArgs a)
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     // window (wx0+i, wy0+j) covers pixels [wx0+i, wx0+i+8) x [wy0+j, wy0+j+8): centre (x,y)=(wx+4,wy+4)
     const int wx0 = tx * WS_TX, wy0 = ty * WS_TY;
-    const uint8_t *A = a.a + a.a_image_bytes * z;
-    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const uint8_t *A = batch_img(a.a, a.as, a.a_image_bytes, z);
+    const uint8_t *B = batch_img(a.b, a.bs, a.b_image_bytes, z);
     const int tid = threadIdx.x;
     if (tid < 64) s_k[tid] = a.window[tid];
     for (int i = tid; i < LH * LW; i += 256) {
@@ -514,6 +521,7 @@ constexpr int WSS_TX = 32, WSS_TY = 16;   // windows per workgroup (256 lanes, 2
 struct WinSepArgs {
     const uint8_t *a;
     const uint8_t *b;
+    const uint8_t *const *as, *const *bs;    // non-null: image z is as[z] / bs[z]
     size_t a_image_bytes, b_image_bytes;
     int astride, bstride, w, h;
     int tiles_x, tiles;
@@ -590,8 +598,8 @@ __device__ __forceinline__ double ssim_sep_body(const WinSepArgs &a, const int t
     __shared__ double s_red[NTHR / 64];
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int wx0 = tx * WSS_TX, wy0 = ty * TY;
-    const uint8_t *A = a.a + a.a_image_bytes * z;
-    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const uint8_t *A = batch_img(a.a, a.as, a.a_image_bytes, z);
+    const uint8_t *B = batch_img(a.b, a.bs, a.b_image_bytes, z);
     const int tid = threadIdx.x;
     if (!a.boxed) {        // (its own loop: with the boxed form inside it the plain loads were no longer issued together -- 9.4 -> 13.9 us per 4K MSSSIM)
         for (int i = tid; i < LH * LW; i += NTHR) {
@@ -829,8 +837,8 @@ __global__ __launch_bounds__(256) void windowed_ssim_sep24_kernel(WinSepArgs a)
     const int tile = blockIdx.x;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int wx0 = tx * TX, wy0 = ty * W24_TY;
-    const uint8_t *A = a.a + a.a_image_bytes * z;
-    const uint8_t *B = a.b + a.b_image_bytes * z;
+    const uint8_t *A = batch_img(a.a, a.as, a.a_image_bytes, z);
+    const uint8_t *B = batch_img(a.b, a.bs, a.b_image_bytes, z);
     const int tid = threadIdx.x;
     for (int i = tid; i < LUM; i += NTHR) {
         const int ly = i / LW, lx = i - ly * LW;
@@ -960,6 +968,7 @@ constexpr int WM_PF = 4;             // pixel rows in flight per lane (divides t
 struct MarchArgs {
     const uint8_t *a;
     const uint8_t *b;
+    const uint8_t *const *as, *const *bs;    // non-null: image z is as[z] / bs[z]
     size_t a_image_bytes, b_image_bytes;
     int astride, bstride, w, h;
     int strips, segs, seg_rows;   // per image: strips x segs wave-sized work items, seg_rows window rows each
@@ -1065,8 +1074,8 @@ __global__ __launch_bounds__(256, SMALL ? 5 : 1) void windowed_ssim_march_kernel
     const int wx = strip * WM_COLS + lane;
     const bool live = lane < WM_COLS && wx < ww;
     const int px = min(wx, a.w - 1);
-    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
-    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    const uint8_t *pa = batch_img(a.a, a.as, a.a_image_bytes, z) + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = batch_img(a.b, a.bs, a.b_image_bytes, z) + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
     double2 *s_p1 = s_row[wave], *s_p2 = s_row[wave] + WM_LDSW;
     if (lane < WM_LDSW - 64) {                                    // the pad entries lanes 57..63 read: finite, unused
         s_p1[64 + lane] = make_double2(0.0, 0.0);
@@ -1194,8 +1203,8 @@ __global__ __launch_bounds__(256, 2) void windowed_ssim_march2_kernel(MarchArgs 
     // the pixel pair (px, px + 1), one 8-byte load (4-byte aligned).  Columns past w - 2 are taps of no live window
     // (the image's last column is never sampled, ssim.go:110-111): such lanes re-read the last pair
     const int px = min(wx, a.w - 2);
-    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
-    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    const uint8_t *pa = batch_img(a.a, a.as, a.a_image_bytes, z) + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = batch_img(a.b, a.bs, a.b_image_bytes, z) + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
     double2 *s_e1 = s_row[wave], *s_o1 = s_e1 + WM2_LDSW, *s_e2 = s_o1 + WM2_LDSW, *s_o2 = s_e2 + WM2_LDSW;
     if (lane < WM2_LDSW - 64) {                                   // the entries lanes 60..63 read past lane 63: finite, unused
         s_e1[64 + lane] = make_double2(0.0, 0.0); s_o1[64 + lane] = make_double2(0.0, 0.0);
@@ -1411,8 +1420,8 @@ __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchAr
     const int wx = strip * WM2_COLS + 2 * lane;
     const bool live0 = 2 * lane < WM2_COLS && wx < ww, live1 = 2 * lane + 1 < WM2_COLS && wx + 1 < ww;
     const int px = min(wx, a.w - 2);                              // (see the fp64 kernel)
-    const uint8_t *pa = a.a + a.a_image_bytes * z + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
-    const uint8_t *pb = a.b + a.b_image_bytes * z + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
+    const uint8_t *pa = batch_img(a.a, a.as, a.a_image_bytes, z) + static_cast<size_t>(wy0) * a.astride + 4 * static_cast<size_t>(px);
+    const uint8_t *pb = batch_img(a.b, a.bs, a.b_image_bytes, z) + static_cast<size_t>(wy0) * a.bstride + 4 * static_cast<size_t>(px);
     f32x4 *s_e = s_row[wave], *s_o = s_e + WM2_LDSW;
     if (lane < WM2_LDSW - 64) {
         s_e[64 + lane] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1610,7 +1619,7 @@ static bool ssim_use_tiled()
 int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, size_t a_image_bytes,
                          const uint8_t *b, int bstride, size_t b_image_bytes, int w, int h,
                          const double *h_window, const double *d_window, double *d_out,
-                         SsimDeferred *defer, int defer_out_index)
+                         SsimDeferred *defer, int defer_out_index, const uint8_t *const *d_as, const uint8_t *const *d_bs)
 {
     const int ww = w - 8, wh = h - 8;     // window grid
     const bool have = ww > 0 && wh > 0;
@@ -1669,7 +1678,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         FNX_TRY(scratch(ctx, ps, sizeof(double) * (static_cast<size_t>(tiles) * n + 2), &part));
     }
     if (march) {
-        ma.a = a; ma.b = b; ma.a_image_bytes = a_image_bytes; ma.b_image_bytes = b_image_bytes;
+        ma.a = a; ma.b = b; ma.as = d_as; ma.bs = d_bs; ma.a_image_bytes = a_image_bytes; ma.b_image_bytes = b_image_bytes;
         ma.astride = astride; ma.bstride = bstride; ma.w = w; ma.h = h;
         ma.partial = static_cast<double *>(part);
         for (int i = 0; i < 8; i++) { ma.col[i] = sa.col[i]; ma.row[i] = sa.row[i]; }
@@ -1706,7 +1715,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         FNX_HIP(hipGetLastError());
         FNX_TRY(prof_end(ctx));
     } else if (sep) {
-        sa.a = a; sa.b = b; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
+        sa.a = a; sa.b = b; sa.as = d_as; sa.bs = d_bs; sa.a_image_bytes = a_image_bytes; sa.b_image_bytes = b_image_bytes;
         sa.astride = astride; sa.bstride = bstride; sa.w = w; sa.h = h;
         sa.tiles_x = tiles_x; sa.tiles = tiles; sa.partial = static_cast<double *>(part);
         static const bool nofold = [] { const char *e = dev_env("FNX_SSIM_NOFOLD"); return e && e[0] == '1'; }();
@@ -1724,7 +1733,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         FNX_HIP(hipGetLastError());
     } else if (have) {
         WinArgs wa{};
-        wa.a = a; wa.b = b; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
+        wa.a = a; wa.b = b; wa.as = d_as; wa.bs = d_bs; wa.a_image_bytes = a_image_bytes; wa.b_image_bytes = b_image_bytes;
         wa.astride = astride; wa.bstride = bstride; wa.w = w; wa.h = h; wa.window = d_window;
         wa.tiles_x = tiles_x; wa.tiles = tiles; wa.partial = static_cast<double *>(part);
         note_route(ctx, FNX_PROF_SSIM, "windowed_ssim_kernel");

@@ -211,6 +211,14 @@ int fnx_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w,
  * (effects.go:93-112), amount = 1+2*strength; requires w,h >= 3. */
 int fnx_adaptive_sharpen(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                          double amount, uint8_t *dst, int dstride);
+/* Sharpen / AdaptiveSharpen bodies of n same-geometry DEVICE images (srcs / dsts: host arrays of device pointers, dst != src):
+ * the bytes of n single calls, one launch of the streaming kernel for tight images (stride == 4 w; the image is its second
+ * grid dimension), image by image otherwise.  Frames below 8K do not fill the machine alone (a 1080p image is 2 000 waves of
+ * 12 rows each); enqueued, no wait. */
+int fnx_sharpen_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, double amount,
+                      uint8_t *const *dsts, int dstride);
+int fnx_adaptive_sharpen_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs, int sstride, int w, int h, double amount,
+                               uint8_t *const *dsts, int dstride);
 
 /* ---- resize.go -------------------------------------------------------- */
 /* Lanczos tap table in CSR form: taps of output d are
@@ -381,6 +389,11 @@ int fnx_results_fetch(fnx_ctx *ctx, int n, double *out /* n, host */);
  * crosses to the host instead of draining the stream at every call. */
 int fnx_ssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,
                      const double *window /* 64 */);
+/* SSIM of n device-resident pairs of ONE geometry: one launch of the window kernel with the image as a grid dimension,
+ * one FIFO entry of n values (fnx_results_fetch(ctx, n, v)).  For frames smaller than 8K, where one pair does not fill the
+ * machine (a 1080p pair is 500 waves).  Honours fnx_ctx_set_ssim_mode like fnx_ssim_enqueue. */
+int fnx_ssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int astride, const uint8_t *const *bs, int bstride,
+                           int w, int h, const double *window /* 64 */);
 /* MSSSIM (ssim.go:313-365, equal dims) of ONE device-resident pair, enqueued the same way: the per-level values wait in
  * the FIFO and fnx_results_fetch(ctx, 1, &v) combines them (exp of the weighted log sum, on the host as in fnx_msssim). */
 int fnx_msssim_enqueue(fnx_ctx *ctx, const uint8_t *a, int astride, const uint8_t *b, int bstride, int w, int h,

@@ -1180,6 +1180,55 @@ def test_ssim_fast_moments_odd_geometry(ctx, orc, w, h):
         ctx.set_ssim_mode(False)
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (640, 480), (2600, 1700), (100, 37), (5, 5)])
+def test_ssim_and_sharpen_batches(ctx, orc, w, h):
+    """r6: fnx_ssim_batch_enqueue and fnx_(adaptive_)sharpen_batch -- n same-geometry device images in ONE launch (the image is a
+    grid dimension of the window / streaming kernel; separately allocated images by pointer array): every value and every
+    byte equals the single call's, and -- for the smaller sizes -- the oracle's.  Pitched views take the per-image path."""
+    import torch
+    n = 5
+    A = [synth.large_photo(w, h, k) for k in range(n)]
+    da = [torch.from_numpy(x).cuda() for x in A]
+    for adaptive in (True, False):
+        if w < 3 or h < 3:
+            continue
+        outs = ctx.sharpen_batch(da, 0.5, adaptive=adaptive)
+        ctx.sync()
+        for k in range(n):
+            want = ctx.AdaptiveSharpen(A[k], 0.5) if adaptive else ctx.Sharpen(A[k], 0.5)
+            assert np.array_equal(outs[k].cpu().numpy(), want), (adaptive, k)
+            if w * h <= 700 * 500 and k == 0:
+                assert np.array_equal(want, orc.adaptive_sharpen(A[k], 0.5) if adaptive else orc.sharpen(A[k], 0.5))
+    B = [ctx.GaussianBlur(x, 0.8 + 0.3 * k) for k, x in enumerate(A)]
+    db = [torch.from_numpy(x).cuda() for x in B]
+    want = [ctx.SSIM(A[k], B[k]) for k in range(n)]
+    ctx.ssim_batch_enqueue(da, db)
+    got = ctx.fetch_results(n)
+    # (a batch cuts the planes into other segments than a single call does: the window values are the same, the order their
+    # sum is taken in is not -- 1e-13, against the 1e-9 bar)
+    assert np.max(np.abs(got - np.array(want))) <= 1e-12
+    if w * h <= 700 * 500:
+        assert abs(want[1] - orc.ssim(A[1], B[1], procs=8)) <= SSIM_TOL
+    if w >= 8 and h >= 8:
+        # pitched device views: the SSIM batch reads rows by stride; the sharpen batch goes image by image (the flat-copy pass)
+        pa = [torch.from_numpy(np.ascontiguousarray(np.pad(x, ((0, 0), (1, 2), (0, 0))))).cuda()[:, 1: 1 + w] for x in A[:2]]
+        ctx.ssim_batch_enqueue(pa, db[:2])
+        assert np.max(np.abs(ctx.fetch_results(2) - np.array(want[:2]))) <= 1e-12
+        vo = ctx.sharpen_batch(pa, 0.5, adaptive=True)
+        ctx.sync()
+        for k in range(2):
+            assert np.array_equal(vo[k].cpu().numpy(), ctx.AdaptiveSharpen(pa[k], 0.5).cpu().numpy())
+    if w * h >= 2600 * 1700:                                  # the fp32-moment mode through the batch
+        ctx.set_ssim_mode(True)
+        try:
+            ctx.ssim_batch_enqueue(da[:2], db[:2])
+            gf = ctx.fetch_results(2)
+            assert ctx.last_kernel(fennec_amd.PROF_SSIM) == "windowed_ssim_march2f_kernel"
+            assert all(abs(g - x) <= SSIM_FAST_TOL for g, x in zip(gf, want[:2]))
+        finally:
+            ctx.set_ssim_mode(False)
+
+
 def test_ssim_mode_argument(ctx):
     with pytest.raises(fennec_amd.FennecError):
         ctx._chk(ctx._lib.fnx_ctx_set_ssim_mode(ctx._h, 7), "fnx_ctx_set_ssim_mode")

@@ -108,6 +108,15 @@ while time.time() < t_end:
         got = ctx.lanczosResizeBatch(dev, fw, fh)
         ctx.sync()
         case("resize_batch", all(np.array_equal(g.cpu().numpy(), orc.lanczos_resize(b, fw, fh, procs=8)) for g, b in zip(got, batch)), desc + f" x{nb} -> {fw}x{fh}")
+        if w >= 3 and h >= 3:
+            ad = bool(rng.integers(2))
+            sh = ctx.sharpen_batch(dev, st, adaptive=ad)
+            ctx.sync()
+            case("sharpen_batch", all(np.array_equal(g.cpu().numpy(), (orc.adaptive_sharpen if ad else orc.sharpen)(b, st, procs=4)) for g, b in zip(sh, batch)),
+                 desc + f" x{nb} s={st} adaptive={ad}")
+            ctx.ssim_batch_enqueue(dev, sh)
+            gsb = ctx.fetch_results(nb)
+            case("ssim_batch", all(abs(g - orc.ssim(b, s_.cpu().numpy(), procs=8)) <= SSIM_TOL for g, b, s_ in zip(gsb, batch, sh)), desc + f" x{nb}")
         if w >= 16 and h >= 16:
             smalls = ctx.lanczosResizeBatch(dev, max(8, w // 2), max(8, h // 2))
             ctx.msssim_batch_enqueue(dev, smalls)
