@@ -744,35 +744,40 @@ int fnx_gaussian_blur_ssim_fast_batch(fnx_ctx *ctx, int n, const uint8_t *const 
 }
 
 // GaussianBlur + SSIMFast(src, blurred) of ONE image: what fnx_gaussian_blur followed by fnx_ssim_fast compute, with the image
-// crossing PCIe once each way when it lives in host memory (the two calls upload the source twice and the blurred image once)
+// crossing PCIe once each way when it lives in host memory (the two calls upload the source twice and the blurred image once).
+// The two kernels' launches back to back on the ctx's stream, on the staged copies: for one image the time is the link's (host
+// space) or two launch latencies (device space), not HBM traffic -- the one-pass kernel and its second-stream tail are the
+// BATCH entry's (a first version went through them: 82 us per device-space call against 53 for this form).
 int fnx_gaussian_blur_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h, const double *kernel,
                                 int radius, int flags, uint8_t *dst, int dstride, const double *window, double *ssim)
 {
-    FNX_TRY(bind(ctx));
+    FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(kernel != nullptr && radius >= 0 && window != nullptr && ssim != nullptr, "blur kernel / window / ssim");
     FNX_TRY(check_img(src, sstride, w, h, "src"));
     FNX_TRY(check_img(dst, dstride, w, h, "dst"));
     FNX_REQUIRE(w > 0 && h > 0, "dims");
-    FNX_REQUIRE(ctx->res_count == 0, "enqueued batches are waiting for fnx_results_fetch: fetch them before a blocking call");
     flags &= ~FNX_BLUR_KEEP_BOX_SUMS;
-    if (w < 8 || h < 8 || (sstride & 3) || (dstride & 3)) {
-        // pixelSSIM's sizes (ssim.go:61-63) and byte-pitched images: the two calls as they are
+    ctx->kept.valid = false;
+    int nw, nh;
+    if (!ssim_fast_dims(w, h, &nw, &nh) && (w < 8 || h < 8)) {
+        // pixelSSIM's sizes (ssim.go:61-63, the FLAT Pix slices): the two calls as they are
         FNX_TRY(fnx_gaussian_blur(ctx, space, src, sstride, w, h, kernel, radius, flags, dst, dstride));
         return fnx_ssim_fast(ctx, space, src, sstride, dst, dstride, w, h, window, ssim);
     }
+    FNX_REQUIRE(space != FNX_DEVICE || src != dst, "dst aliases src (the blur is not in-place)");
+    void *dwin = nullptr;
+    FNX_TRY(upload_table(ctx, SLOT_TABLE0, window, sizeof(double) * 64, &dwin));
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, w, h, SLOT_IN_A, &s));
     FNX_TRY(stage_out(ctx, space, dst, dstride, w, h, SLOT_OUT, &d));
-    const uint8_t *sp = s.p;
-    uint8_t *dp = d.p;
-    FNX_REQUIRE(sp != dp, "dst aliases src (the blur is not in-place)");
-    // the one-pass kernel where it applies, else the two kernels back to back -- on device memory either way
-    FNX_TRY(fnx_gaussian_blur_ssim_fast_batch_enqueue(ctx, 1, &sp, s.stride, w, h, kernel, radius, flags, &dp, d.stride, window));
-    // the blurred image starts back while the score's tail (boxes, windows: the ctx's second stream) is still running
-    FNX_TRY(finish_enqueue(ctx, space, &d));
-    FNX_TRY(fnx_results_fetch(ctx, 1, ssim));
+    FNX_TRY(launch_blur(ctx, 1, s.p, nullptr, s.stride, w, h, kernel, radius, flags, d.p, nullptr, d.stride));
+    double *dres;
+    FNX_TRY(result_slot(ctx, 1, &dres));
+    FNX_TRY(ssim_fast_device(ctx, 1, s.p, nullptr, s.stride, d.p, nullptr, d.stride, w, h, window, static_cast<const double *>(dwin), dres));
+    FNX_TRY(finish_enqueue(ctx, space, &d));                     // the blurred image starts back behind the score's kernels
+    FNX_TRY(result_wait(ctx, dres, ssim, 1));
     if (space != FNX_DEVICE) FNX_HIP(hipStreamSynchronize(ctx->stream));
     return FNX_OK;
 }

@@ -418,8 +418,9 @@ int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int 
 /* The same for ONE image in either space: dst = GaussianBlur(src) and *ssim = SSIMFast(src, dst) -- bytes and score those of
  * fnx_gaussian_blur followed by fnx_ssim_fast.  With FNX_HOST the image crosses PCIe ONCE each way (source up, blurred
  * image down: 2 x 33 MB at 4K); the two separate calls upload the source twice and the blurred image once more
- * (4 x 33 MB), and PCIe is all a host-space call costs (0.6 ms per 33 MB against 20 us of kernels).  What the cgo
- * shim's GaussianBlurScored calls.  Blocking; requires an empty result FIFO. */
+ * (4 x 33 MB), and PCIe is all a host-space call costs (0.6 ms per 33 MB against 40 us of kernels).  What the cgo
+ * shim's GaussianBlurScored calls.  Blocking (the two kernels back to back on the ctx's stream; batches of device images
+ * take fnx_gaussian_blur_ssim_fast_batch, whose one-pass kernel also halves the HBM traffic). */
 int fnx_gaussian_blur_ssim_fast(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int w, int h,
                                 const double *kernel, int radius, int flags, uint8_t *dst, int dstride,
                                 const double *window /* 64 */, double *ssim);

@@ -63,6 +63,7 @@ int main(int argc, char **argv)
                                                           FK(fnx_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, out[k], W * 4, W, H, win, &r)); }, 4.0 * S, false},
         {"... with FNX_BLUR_KEEP_BOX_SUMS", [&](int k) { FK(fnx_gaussian_blur(ctx, FNX_DEVICE, img[k], W * 4, W, H, kern.data(), radius, FNX_BLUR_KEEP_BOX_SUMS, out[k], W * 4));
                                                         FK(fnx_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, out[k], W * 4, W, H, win, &r)); }, 4.0 * S, false},
+        {"GaussianBlur + SSIMFast (1 call, r6)", [&](int k) { FK(fnx_gaussian_blur_ssim_fast(ctx, FNX_DEVICE, img[k], W * 4, W, H, kern.data(), radius, 0, out[k], W * 4, win, &r)); }, 4.0 * S, false},
         {"SSIM (full resolution)", [&](int k) { FK(fnx_ssim(ctx, FNX_DEVICE, img[k], W * 4, blur[k], W * 4, W, H, win, &r)); }, 2.0 * S, false},
         {"MSSSIM", [&](int k) { FK(fnx_msssim(ctx, FNX_DEVICE, img[k], W * 4, blur[k], W * 4, W, H, win, &r, nullptr)); }, 3.33 * S, false},
         {"Analyze", [&](int k) { FK(fnx_analyze(ctx, FNX_DEVICE, img[k], W * 4, W, H, &an)); }, 1.0 * S, false},
