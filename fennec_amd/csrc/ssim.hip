@@ -1396,10 +1396,7 @@ __device__ __forceinline__ float lum_milli_centred(uint32_t p, uint32_t negc)
     return static_cast<float>(static_cast<int32_t>(i));
 }
 
-#ifndef WMF_PF_N
-#define WMF_PF_N 4
-#endif
-constexpr int WMF_PF = WMF_PF_N;       // pixel rows in flight per lane (divides 8)
+constexpr int WMF_PF = 4;              // pixel rows in flight per lane (divides 8; 2 and 8 measured the same)
 template <int WPS, bool PRE>
 __global__ __launch_bounds__(256, WPS) void windowed_ssim_march2f_kernel(MarchArgs a)
 {
@@ -1647,8 +1644,7 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
         const int cols = march2 ? WM2_COLS : WM_COLS;
         ma.strips = (ww + cols - 1) / cols;
         static const long m2_env = [] { const char *e = dev_env("FNX_SSIM_M2_WAVES"); return e ? atol(e) : 0L; }();   // experiments
-        static const long mf_wps = [] { const char *e = dev_env("FNX_SSIM_F_WAVES"); return e ? atol(e) : 2L; }();
-        const long m2_per_cu = m2_env ? m2_env : (ctx->ssim_mode == FNX_SSIM_FAST ? 4L * mf_wps : 8L);
+        const long m2_per_cu = m2_env ? m2_env : 8L;                // (both two-column kernels run two waves per SIMD)
         const long target = (march2 ? m2_per_cu : 16L) * ctx->num_cus;
         long segs = target / (static_cast<long>(n) * ma.strips);
         const long max_segs = wh / 32 > 0 ? wh / 32 : 1;
@@ -1705,10 +1701,8 @@ int launch_windowed_ssim(fnx_ctx *ctx, int n, const uint8_t *a, int astride, siz
                 ma.rowf2[i] = static_cast<float>(sa.row[i] * (1.0 / 1048576.0));
             }
             note_route(ctx, FNX_PROF_SSIM, "windowed_ssim_march2f_kernel");
-            static const int wps = [] { const char *e = dev_env("FNX_SSIM_F_WAVES"); return e ? atoi(e) : 2; }();   // development: waves per SIMD
-            if (wps == 4) hipLaunchKernelGGL((windowed_ssim_march2f_kernel<4, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
-            else if (wps == 3) hipLaunchKernelGGL((windowed_ssim_march2f_kernel<3, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
-            else hipLaunchKernelGGL((windowed_ssim_march2f_kernel<2, true>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
+            // (two waves per SIMD, the next row's taps read ahead: the three- and four-wave builds spill inside the loop, CHANGELOG r6)
+            hipLaunchKernelGGL((windowed_ssim_march2f_kernel<2, true>), dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         } else if (march2) hipLaunchKernelGGL(windowed_ssim_march2_kernel, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else if (ctx->partial_slot >= 0) hipLaunchKernelGGL(windowed_ssim_march_kernel<true>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
         else hipLaunchKernelGGL(windowed_ssim_march_kernel<false>, dim3((tiles + 3) / 4, n), dim3(256), 0, ctx->stream, ma);
