@@ -213,7 +213,7 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, dstH, "dst"));
-    if (srcW == dstW && srcH == dstH) {   // flat copy of Pix (resize.go:45-49)
+    if (srcW == dstW && srcH == dstH) {   // flat copy of Pix (resize.go:45-49): no tables
         const size_t sl = pix_len(srcW, srcH, sstride), dl = pix_len(dstW, dstH, dstride);
         const size_t nbytes = sl < dl ? sl : dl;
         if (space == FNX_HOST) {
@@ -226,6 +226,7 @@ int lanczos_resize_tables(fnx_ctx *ctx, int space, const uint8_t *src, int sstri
         }
         return FNX_OK;
     }
+    FNX_REQUIRE(th.off && th.idx && th.wt && tv.off && tv.idx && tv.wt, "tap table is null");
     DevImg s;
     DevOut d;
     FNX_TRY(stage_in(ctx, space, src, sstride, srcW, srcH, SLOT_IN_A, &s));
@@ -259,6 +260,7 @@ int lanczos_resize_tables_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs,
     FNX_REQUIRE(n >= 0 && (n == 0 || (srcs && dsts)), "batch arguments");
     if (n == 0) return FNX_OK;
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
+    FNX_REQUIRE((srcW == dstW && srcH == dstH) || (th.off && th.idx && th.wt && tv.off && tv.idx && tv.wt), "tap table is null");
     for (int i = 0; i < n; i++) {
         FNX_REQUIRE(srcs[i] && dsts[i], "null image in batch");
         FNX_TRY(check_img(srcs[i], sstride, srcW, srcH, "src"));
@@ -464,6 +466,7 @@ int fnx_resize_h(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstW > 0, "dims");
+    FNX_REQUIRE(offset && index && weight, "tap table is null");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, dstW, srcH, "dst"));
     DevImg s;
@@ -482,6 +485,7 @@ int fnx_resize_v(fnx_ctx *ctx, int space, const uint8_t *src, int sstride, int s
     FNX_ENTER(ctx);
     FNX_TRY(check_space_io(space));
     FNX_REQUIRE(srcW > 0 && srcH > 0 && dstH > 0, "dims");
+    FNX_REQUIRE(offset && index && weight, "tap table is null");
     FNX_TRY(check_img(src, sstride, srcW, srcH, "src"));
     FNX_TRY(check_img(dst, dstride, srcW, dstH, "dst"));
     DevImg s;

@@ -1917,3 +1917,75 @@ def test_ssim_two_column_march_against_oracle(ctx, orc):
     va, vb = da[:, 1:w + 1], db[:, 1:w + 1]
     want = orc.ssim(np.ascontiguousarray(a[:, 1:w + 1]), np.ascontiguousarray(b[:, 1:w + 1]), procs=64)
     assert abs(ctx.SSIM(va, vb) - want) <= SSIM_TOL
+
+
+@pytest.mark.gpu
+def test_batch_entry_points_refuse_bad_arguments(orc):
+    """round 6's batch entry points through the raw C ABI: negative counts, null arrays, a null image among the images, null
+    tap tables and a full result FIFO come back as errors with a message (never a crash); n = 0 is a no-op; the ctx stays usable"""
+    import ctypes as C
+    import torch
+    lib = fennec_amd.load_library()
+    c = fennec_amd.Context(0)
+    W, H = 96, 64
+    a = [torch.from_numpy(synth.large_photo(W, H, k)).cuda() for k in range(2)]
+    b = [torch.from_numpy(synth.noise_image(W, H, 3 + k)).cuda() for k in range(2)]
+    o = [torch.empty_like(x) for x in a]
+    small = [torch.empty((H // 2, W // 2, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])  # noqa: E731
+    none = C.POINTER(C.c_void_p)()
+    win = np.ascontiguousarray(orc.gaussian_kernel(8, 1.5), dtype=np.float64)
+    f64 = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    i32 = lambda x: x.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    pa, pb, po, ps = arr(a), arr(b), arr(o), arr(small)
+    bad = []
+
+    def refused(rc, what):
+        if rc >= 0 or not lib.fnx_last_error():
+            bad.append(what)
+
+    # sharpen / AdaptiveSharpen batches
+    refused(lib.fnx_sharpen_batch(c._h, -1, pa, 4 * W, W, H, 0.5, po, 4 * W), "sharpen n = -1")
+    refused(lib.fnx_sharpen_batch(c._h, 2, none, 4 * W, W, H, 0.5, po, 4 * W), "sharpen null srcs")
+    refused(lib.fnx_adaptive_sharpen_batch(c._h, 2, arr([a[0], None]), 4 * W, W, H, 0.5, po, 4 * W), "adaptive null image")
+    refused(lib.fnx_sharpen_batch(c._h, 2, pa, 4 * W, W, H, 0.5, pa, 4 * W), "sharpen dst aliases src")
+    refused(lib.fnx_sharpen_batch(c._h, 2, pa, 4 * W - 4, W, H, 0.5, po, 4 * W), "sharpen stride below a row")
+    assert lib.fnx_sharpen_batch(c._h, 0, none, 4 * W, W, H, 0.5, none, 4 * W) == 0
+    # SSIM / MSSSIM batches
+    refused(lib.fnx_ssim_batch_enqueue(c._h, -2, pa, 4 * W, pb, 4 * W, W, H, f64(win)), "ssim n = -2")
+    refused(lib.fnx_ssim_batch_enqueue(c._h, 2, pa, 4 * W, none, 4 * W, W, H, f64(win)), "ssim null bs")
+    refused(lib.fnx_ssim_batch_enqueue(c._h, 2, pa, 4 * W, pb, 4 * W, W, H, None), "ssim null window")
+    refused(lib.fnx_msssim_batch_enqueue(c._h, 2, arr([None, a[1]]), 4 * W, pb, 4 * W, W, H, f64(win)), "msssim null image")
+    refused(lib.fnx_msssim_batch_enqueue(c._h, 2, pa, 4 * W, pb, 4 * W, 0, H, f64(win)), "msssim w = 0")
+    # lanczosResize batch: tables
+    th, tv = orc.precompute_weights(W // 2, W), orc.precompute_weights(H // 2, H)
+    offh, idxh, wh = (np.ascontiguousarray(th[0], np.int32), np.ascontiguousarray(th[1], np.int32), np.ascontiguousarray(th[2], np.float64))
+    offv, idxv, wv = (np.ascontiguousarray(tv[0], np.int32), np.ascontiguousarray(tv[1], np.int32), np.ascontiguousarray(tv[2], np.float64))
+    ok = lib.fnx_lanczos_resize_batch(c._h, 2, pa, 4 * W, W, H, i32(offh), i32(idxh), f64(wh), i32(offv), i32(idxv), f64(wv), ps, 2 * W, W // 2, H // 2)
+    assert ok == 0, lib.fnx_last_error()
+    c.sync()
+    for k in range(2):
+        assert np.array_equal(small[k].cpu().numpy(), orc.lanczos_resize(a[k].cpu().numpy(), W // 2, H // 2))
+    refused(lib.fnx_lanczos_resize_batch(c._h, 2, pa, 4 * W, W, H, None, i32(idxh), f64(wh), i32(offv), i32(idxv), f64(wv), ps, 2 * W, W // 2, H // 2),
+            "resize null offH")
+    refused(lib.fnx_lanczos_resize_batch(c._h, 2, pa, 4 * W, W, H, i32(offh), i32(idxh), f64(wh), i32(offv), i32(idxv), None, ps, 2 * W, W // 2, H // 2),
+            "resize null wV")
+    refused(lib.fnx_lanczos_resize_batch(c._h, 2, pa, 4 * W, W, H, i32(offh), i32(idxh), f64(wh), i32(offv), i32(idxv), f64(wv), none, 2 * W, W // 2, H // 2),
+            "resize null dsts")
+    refused(lib.fnx_lanczos_resize_batch(c._h, -1, pa, 4 * W, W, H, i32(offh), i32(idxh), f64(wh), i32(offv), i32(idxv), f64(wv), ps, 2 * W, W // 2, H // 2),
+            "resize n = -1")
+    refused(lib.fnx_lanczos_resize(c._h, 1, a[0].data_ptr(), 4 * W, W, H, None, None, None, None, None, None, small[0].data_ptr(), 2 * W, W // 2, H // 2),
+            "single resize null tables")
+    assert not bad, bad
+    # a full FIFO: the fifth unfetched batch is refused, the four before it are intact
+    want = [orc.ssim(x.cpu().numpy(), y.cpu().numpy()) for x, y in zip(a, b)]
+    for _ in range(4):
+        assert lib.fnx_ssim_batch_enqueue(c._h, 2, pa, 4 * W, pb, 4 * W, W, H, f64(win)) == 0, lib.fnx_last_error()
+    assert lib.fnx_ssim_batch_enqueue(c._h, 2, pa, 4 * W, pb, 4 * W, W, H, f64(win)) < 0
+    assert b"fnx_results_fetch" in lib.fnx_last_error()
+    for _ in range(4):
+        got = c.fetch_results(2)
+        assert np.allclose(got, want, rtol=0, atol=1e-12)
+    # and the ctx still works
+    assert np.array_equal(c.Sharpen(a[0], 0.5).cpu().numpy(), orc.sharpen(a[0].cpu().numpy(), 0.5))
+    c.close()
