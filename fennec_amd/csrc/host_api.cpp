@@ -103,6 +103,7 @@ extern "C" {
 
 void fennec_gaussianKernel(int size, double sigma, double *kernel)
 {   // ssim.go:223-241
+    if (!kernel) return;
     const int half = size / 2;
     double sum = 0;
     int idx = 0;
@@ -160,14 +161,14 @@ int fennec_precomputeWeights(int dstSize, int srcSize, int32_t *offset, int32_t 
             double w = fennec_lanczosKernel((double(s) - center) / filterScale);
             if (w != 0) {
                 wsum += w;
-                if (index) {
+                if (index && weight) {
                     index[total] = s;
                     weight[total] = w;
                 }
                 total++;
             }
         }
-        if (wsum != 0 && index)
+        if (wsum != 0 && index && weight)
             for (int i = first; i < total; i++) weight[i] /= wsum;
     }
     if (offset) offset[dstSize] = total;
@@ -176,6 +177,10 @@ int fennec_precomputeWeights(int dstSize, int srcSize, int32_t *offset, int32_t 
 
 int fennec_smartResizeDims(int srcW, int srcH, int maxW, int maxH, int *dstW, int *dstH)
 {   // resize.go:12-32
+    if (!dstW || !dstH) {
+        fnx::set_error("invalid argument: fennec_smartResizeDims: dstW / dstH is null");
+        return FNX_ERR_INVALID;
+    }
     if (maxW <= 0) maxW = srcW;
     if (maxH <= 0) maxH = srcH;
     *dstW = srcW;
@@ -189,6 +194,10 @@ int fennec_smartResizeDims(int srcW, int srcH, int maxW, int maxH, int *dstW, in
 
 int fennec_ssimFastDims(int w, int h, int *newW, int *newH)
 {   // ssim.go:52-56
+    if (!newW || !newH) {
+        fnx::set_error("invalid argument: fennec_ssimFastDims: newW / newH is null");
+        return FNX_ERR_INVALID;
+    }
     *newW = w;
     *newH = h;
     if (w > 512 || h > 512) {
@@ -371,6 +380,7 @@ double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
 {   // batch.go:140-158
     int64_t succeeded = 0, nfailed = 0, saved = 0;
     double ssimSum = 0;
+    if (!failed || !has_result || !original_size || !compressed_size || !ssim) n = 0;   // (a summary of nothing, not a crash)
     for (int i = 0; i < n; i++) {
         if (failed[i]) {
             nfailed++;
@@ -382,10 +392,12 @@ double fennec_Summarize(int n, const int32_t *failed, const int32_t *has_result,
             ssimSum += ssim[i];
         }
     }
-    out4[0] = n;
-    out4[1] = succeeded;
-    out4[2] = nfailed;
-    out4[3] = saved;
+    if (out4) {
+        out4[0] = n > 0 ? n : 0;
+        out4[1] = succeeded;
+        out4[2] = nfailed;
+        out4[3] = saved;
+    }
     return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
 }
 
@@ -675,6 +687,7 @@ double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t
 {   // batch.go:140-158
     int64_t succeeded = 0, nfailed = 0, saved = 0;
     double ssimSum = 0;
+    if (!results) n = 0;
     for (int i = 0; i < n; i++) {
         if (results[i].failed) {
             nfailed++;
@@ -686,7 +699,7 @@ double fennec_SummarizeResults(int n, const fennec_BatchResult *results, int64_t
             ssimSum += results[i].ssim;
         }
     }
-    out4[0] = n; out4[1] = succeeded; out4[2] = nfailed; out4[3] = saved;
+    if (out4) { out4[0] = n > 0 ? n : 0; out4[1] = succeeded; out4[2] = nfailed; out4[3] = saved; }
     return succeeded > 0 ? ssimSum / double(succeeded) : 0.0;
 }
 

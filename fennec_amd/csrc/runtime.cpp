@@ -627,6 +627,7 @@ int fnx_upload(fnx_ctx *ctx, void *dptr, int dstride, const void *host, int hstr
 {
     FNX_TRY(bind(ctx));
     if (w <= 0 || h <= 0) return FNX_OK;
+    FNX_REQUIRE(dptr && host && dstride >= 4 * w && hstride >= 4 * w, "upload: null pointer or a stride below 4 * w");
     FNX_HIP(hipMemcpy2DAsync(dptr, dstride, host, hstride, size_t(w) * 4, h, hipMemcpyHostToDevice,
                              ctx->stream));
     FNX_HIP(hipStreamSynchronize(ctx->stream));
@@ -637,6 +638,7 @@ int fnx_download(fnx_ctx *ctx, void *host, int hstride, const void *dptr, int ds
 {
     FNX_TRY(bind(ctx));
     if (w <= 0 || h <= 0) return FNX_OK;
+    FNX_REQUIRE(dptr && host && dstride >= 4 * w && hstride >= 4 * w, "download: null pointer or a stride below 4 * w");
     FNX_HIP(hipMemcpy2DAsync(host, hstride, dptr, dstride, size_t(w) * 4, h, hipMemcpyDeviceToHost,
                              ctx->stream));
     FNX_HIP(hipStreamSynchronize(ctx->stream));

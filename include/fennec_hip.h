@@ -522,9 +522,9 @@ double fennec_lanczosKernel(double x);
  * resizeH/resizeV do; returns the tap count; index/weight may be NULL to size. */
 int fennec_precomputeWeights(int dstSize, int srcSize, int32_t *offset, int32_t *index,
                              double *weight);
-/* smartResize's dims (resize.go:12-32): returns 0 if the image already fits. */
+/* smartResize's dims (resize.go:12-32): returns 0 if the image already fits (negative: a NULL out pointer). */
 int fennec_smartResizeDims(int srcW, int srcH, int maxW, int maxH, int *dstW, int *dstH);
-/* SSIMFast's downsample dims (ssim.go:52-56): returns 1 if it downsamples. */
+/* SSIMFast's downsample dims (ssim.go:52-56): returns 1 if it downsamples (negative: a NULL out pointer). */
 int fennec_ssimFastDims(int w, int h, int *newW, int *newH);
 
 int fennec_SSIM(fnx_ctx *ctx, int space, const uint8_t *a, int astride, int aw, int ah,

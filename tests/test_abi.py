@@ -110,6 +110,24 @@ def test_dims_helpers_match_oracle(lib, orc):
         assert (bool(r), nw.value, nh.value) == orc.smart_resize_dims(*args)
 
 
+def test_host_helpers_survive_null_pointers(lib):
+    """the pure host helpers of the fennec_* layer (no ctx, no GPU) with NULL where a pointer is expected: an error or a
+    no-op, never a dereference"""
+    C = ctypes
+    assert lib.fennec_smartResizeDims(4000, 3000, 1920, 1080, None, None) < 0 and lib.fnx_last_error()
+    assert lib.fennec_ssimFastDims(3840, 2160, None, None) < 0
+    lib.fennec_gaussianKernel(8, 1.5, None)
+    n = lib.fennec_precomputeWeights(50, 100, None, None, None)
+    off = np.zeros(51, np.int32)
+    idx = np.zeros(n, np.int32)
+    assert lib.fennec_precomputeWeights(50, 100, off.ctypes.data_as(C.POINTER(C.c_int32)), idx.ctypes.data_as(C.POINTER(C.c_int32)), None) == n
+    assert off[50] == n
+    out4 = (C.c_int64 * 4)(7, 7, 7, 7)
+    assert fennec_amd.load_library().fennec_Summarize(3, None, None, None, None, None, out4) == 0.0 and list(out4) == [0, 0, 0, 0]
+    assert lib.fennec_SummarizeResults(3, None, out4) == 0.0
+    assert lib.fennec_SummarizeResults(0, None, None) == 0.0
+
+
 def test_summarize_matches_oracle(orc):
     rng = np.random.default_rng(3)
     n = 257
