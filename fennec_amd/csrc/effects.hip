@@ -458,7 +458,9 @@ __device__ __forceinline__ void fx_fix_from_source(const FxArgs &a, int px, int 
 // kernel's one-row form with the boundary test of its paired form (same guard, same proof).  Flagged samples go to a
 // per-wave list and are recomputed at the end of the segment -- in fp64, in the reference's order, from the source.
 constexpr int FXS_COLS = 62;
-constexpr int FXS_PF = 6;                  // rows in flight per lane; the unroll is lcm(PF, 3 ring phases, 2 LDS slots)
+constexpr int FXS_PF = 6;                  // rows in flight per lane; the unroll is lcm(PF, 2 LDS slots).  (Eight registers, so that a row's
+                                           // pixel stays where it was loaded while it is the next row's centre, and an eight-row unroll:
+                                           // 74 us against 65 at 8K.)
 constexpr int FXS_LW = 68;
 constexpr int FXS_FIX = 64;
 
@@ -498,10 +500,13 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
     uint32_t q[FXS_PF];
 #pragma unroll
     for (int k = 0; k < FXS_PF; k++) q[k] = load_row(k);
-    uint32_t hrb[3], hga[3], crb[3], cga[3];
-    int32_t dxr[3], sxr[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) hrb[k] = hga[k] = crb[k] = cga[k] = 0u, dxr[k] = sxr[k] = 0;
+    // Vertical [1 2 1] over the horizontal sums h of rows T, M, B (B = the newest) as two PAIR sums, (h[T] + h[M]) + (h[M] + h[B]):
+    // the older pair is last row's newer one, so a row costs two adds per word where the three-entry ring took a shift, an add
+    // and an add3; the +8 of the rounding rides in as +2 per h.  Same for the Sobel column differences; the row sums need the
+    // entry two rows back only.  The centre pixel (row M) is last row's source word as it was loaded: its bytes are the
+    // channels' floats (v_cvt_f32_ubyteN), its alpha the byte the packs leave alone, and the whole word the copy a border gets.
+    uint32_t hl_rb = 0u, hl_ga = 0u, pl_rb = 0u, pl_ga = 0u, px_m = 0u;   // h[M], h[T] + h[M], the source pixel of row M
+    int32_t dl = 0, pdl = 0, sl1 = 0, sl2 = 0;                              // dx[M], dx[T] + dx[M], sx[M], sx[T]
     const float seed = 0.5f - a.guard;
     const float amt = __builtin_canonicalizef(a.amt32), k32 = a.k32, thr = a.flag_thr;
     const bool use_table = a.use_table != 0;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
         for (int p = 0; p < 6; p++) {
             const int r = r0 + p;
             if (r < nrows) {                                             // wave-uniform
-                const int k = p % 3, slot = p & 1;
+                const int slot = p & 1;
                 const uint32_t px = q[p % FXS_PF];
                 q[p % FXS_PF] = load_row(r + FXS_PF);                    // no branch around the load
                 const uint32_t rb = px & 0x00ff00ffu, ga = ga_fields(px);
@@ -522,35 +527,34 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
                 sw[slot][1][lane + 1] = ga;
                 uint32_t lum = 0;
                 if constexpr (MODE == FX_ADAPTIVE) {
-                    lum = lum_milli_u32(px);
+                    lum = lum_milli_u32(px);                    // (two v_dot2_u32_u16 on the spread fields measured SLOWER: 69 against 65 us at 8K)
                     sw[slot][2][lane + 1] = lum;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                hrb[k] = sw[slot][0][lane] + sw[slot][0][lane + 2] + 2 * rb;
-                hga[k] = sw[slot][1][lane] + sw[slot][1][lane + 2] + 2 * ga;
-                crb[k] = rb;
-                cga[k] = ga;
+                const uint32_t h_rb = sw[slot][0][lane] + sw[slot][0][lane + 2] + (2 * rb + 0x00020002u);
+                const uint32_t h_ga = sw[slot][1][lane] + sw[slot][1][lane + 2] + (2 * ga + 0x00020002u);
+                const uint32_t p_rb = hl_rb + h_rb, p_ga = hl_ga + h_ga;
+                const uint32_t srb = pl_rb + p_rb, sga = pl_ga + p_ga;   // 16 x the blur + 8 per field (<= 4088)
+                int32_t d_new = 0, pd = 0, s_new = 0;
                 if constexpr (MODE == FX_ADAPTIVE) {
                     const int32_t l = static_cast<int32_t>(sw[slot][2][lane]), rr = static_cast<int32_t>(sw[slot][2][lane + 2]);
-                    dxr[k] = rr - l;
-                    sxr[k] = l + rr + 2 * static_cast<int32_t>(lum);
+                    d_new = rr - l;
+                    pd = dl + d_new;
+                    s_new = l + rr + 2 * static_cast<int32_t>(lum);
                 }
                 if (r >= 2) {
-                    // output row yo: its three tile rows are ring entries T (yo - 1), M (yo), B (yo + 1) = the newest
-                    const int T = (p + 1) % 3, M = (p + 2) % 3, B = p % 3;
+                    // output row yo = the row before the newest: T (yo - 1), M (yo), B (yo + 1)
                     const int yo = y0 + r - 2;
-                    const uint32_t c = crb[M] | (cga[M] << 8);
+                    const uint32_t c = px_m;
                     uint32_t out = c;                                    // borders and alpha are copies of the source (effects.go:68,120)
                     bool flagged = false;
                     if (yo >= 1 && yo < a.h - 1) {                       // wave-uniform
-                        const uint32_t srb = hrb[T] + hrb[B] + 2 * hrb[M] + 0x00080008u;
-                        const uint32_t sga = hga[T] + hga[B] + 2 * hga[M] + 0x00080008u;
                         const uint32_t brb = srb >> 4, bga = sga >> 4;   // blurred R | B << 16 (bytes 0, 2), blurred G in byte 0
                         auto tab = [&]() {
                             const int br = brb & 0xffu, bg = bga & 0xffu, bb = (brb >> 16) & 0xffu;
-                            const int o_r = crb[M] & 0xffu, o_g = cga[M] & 0xffu, o_b = (crb[M] >> 16) & 0xffu;
+                            const int o_r = c & 0xffu, o_g = (c >> 8) & 0xffu, o_b = (c >> 16) & 0xffu;
                             const int vr = clampi(o_r + s_tab[o_r - br + 255], 0, 255), vg = clampi(o_g + s_tab[o_g - bg + 255], 0, 255),
                                       vb = clampi(o_b + s_tab[o_b - bb + 255], 0, 255);
                             return static_cast<uint32_t>(vr) | (static_cast<uint32_t>(vg) << 8) | (static_cast<uint32_t>(vb) << 16) | (c & 0xff000000u);
@@ -561,18 +565,18 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
                         } else if constexpr (MODE == FX_SHARPEN) {
                             v = tab();
                         } else {
-                            const float gx = static_cast<float>(dxr[T] + dxr[B] + 2 * dxr[M]);
-                            const float gy = static_cast<float>(sxr[B] - sxr[T]);
+                            const float gx = static_cast<float>(pdl + pd);   // dx[T] + 2 dx[M] + dx[B]
+                            const float gy = static_cast<float>(s_new - sl2);
                             const float m2 = fmaf(gy, gy, gx * gx);
                             float t;                                     // min(amount, amount * |Sobel| / 400000); 0 on the image's border columns
                             asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(__builtin_amdgcn_sqrtf(m2) * k32), "v"(amt_lane));
-                            const float fr = ubyte_f32<0>(crb[M]), fg = ubyte_f32<0>(cga[M]), fb = ubyte_f32<2>(crb[M]);
+                            const float fr = ubyte_f32<0>(c), fg = ubyte_f32<1>(c), fb = ubyte_f32<2>(c);
                             const float ar = fmaf(t, fr - ubyte_f32<0>(brb), fr + seed);
                             const float ag = fmaf(t, fg - ubyte_f32<0>(bga), fg + seed);
                             const float ab = fmaf(t, fb - ubyte_f32<2>(brb), fb + seed);
                             const float fmx = fmaxf(fmaxf(__builtin_amdgcn_fractf(ar), __builtin_amdgcn_fractf(ag)), __builtin_amdgcn_fractf(ab));
                             fp32_round_toward_zero();
-                            v = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, cga[M] << 8)));
+                            v = pk8(ab, 2, pk8(ag, 1, pk8(ar, 0, c)));       // (byte 3 stays: the source's alpha)
                             fp32_round_nearest();
                             flagged = fmx >= thr;
                             if (use_table && m2 > sat_lane) {            // e == 1 for certain: exact by table
@@ -592,6 +596,8 @@ __global__ __launch_bounds__(256, 8) void fx_stream_kernel(FxArgs a)
                     }
                     if (mine && !flagged) *(g_u32w *)(a.dst + (static_cast<uint32_t>(yo) * static_cast<uint32_t>(a.dstride) + xo)) = out;
                 }
+                hl_rb = h_rb; hl_ga = h_ga; pl_rb = p_rb; pl_ga = p_ga; px_m = px;
+                if constexpr (MODE == FX_ADAPTIVE) { dl = d_new; pdl = pd; sl2 = sl1; sl1 = s_new; }
             }
         }
     }
