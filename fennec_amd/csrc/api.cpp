@@ -258,6 +258,7 @@ int lanczos_resize_tables_batch(fnx_ctx *ctx, int n, const uint8_t *const *srcs,
 {
     FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && (n == 0 || (srcs && dsts)), "batch arguments");
+    FNX_REQUIRE(n <= FNX_BATCH_MAX, "more than FNX_BATCH_MAX (65535) images in one batch call: the image is a grid dimension");
     if (n == 0) return FNX_OK;
     if (srcW <= 0 || srcH <= 0 || dstW <= 0 || dstH <= 0) return FNX_EMPTY;   // resize.go:41-43
     FNX_REQUIRE((srcW == dstW && srcH == dstH) || (th.off && th.idx && th.wt && tv.off && tv.idx && tv.wt), "tap table is null");
@@ -425,6 +426,7 @@ static int sharpen_batch_common(fnx_ctx *ctx, bool adaptive, int n, const uint8_
 {
     FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && (n == 0 || (srcs && dsts)), "batch arguments");
+    FNX_REQUIRE(n <= FNX_BATCH_MAX, "more than FNX_BATCH_MAX (65535) images in one batch call: the image is a grid dimension");
     if (n == 0) return FNX_OK;
     FNX_REQUIRE(w >= 3 && h >= 3, "sharpen needs w,h >= 3 (the reference returns the input below that)");
     for (int i = 0; i < n; i++) {
@@ -1018,6 +1020,7 @@ int fnx_ssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int as
 {
     FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && (n == 0 || (as && bs)) && window != nullptr && w > 0 && h > 0, "batch arguments");
+    FNX_REQUIRE(n <= FNX_BATCH_MAX, "more than FNX_BATCH_MAX (65535) images in one batch call: the image is a grid dimension");
     if (n == 0) return FNX_OK;
     for (int i = 0; i < n; i++) {
         FNX_REQUIRE(as[i] && bs[i], "null image in batch");
@@ -1059,6 +1062,7 @@ int fnx_msssim_batch_enqueue(fnx_ctx *ctx, int n, const uint8_t *const *as, int 
 {
     FNX_ENTER(ctx);
     FNX_REQUIRE(n >= 0 && (n == 0 || (as && bs)) && window != nullptr && w > 0 && h > 0, "batch arguments");
+    FNX_REQUIRE(n <= FNX_BATCH_MAX, "more than FNX_BATCH_MAX (65535) images in one batch call: the image is a grid dimension");
     if (n == 0) return FNX_OK;
     for (int i = 0; i < n; i++) {
         FNX_REQUIRE(as[i] && bs[i], "null image in batch");

@@ -71,6 +71,9 @@ extern "C" {
 #define FNX_ERR_OOM (-4)
 #define FNX_ERR_UNSUPPORTED (-5) /* fnx_jpeg_decode / fnx_jpeg_recompress: a file the device decoder does not handle; decode it on the host */
 
+/* most images one *_batch / *_batch_enqueue call of round 6 takes (the image is a grid dimension of the launch) */
+#define FNX_BATCH_MAX 65535
+
 #define FNX_HOST 0
 #define FNX_DEVICE 1
 /* image -> image ops only (blur, blur3x3, sharpen, resize, box downsample, orient): the source is device

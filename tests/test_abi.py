@@ -78,7 +78,7 @@ def test_release_build_reads_five_environment_names():
     # and the shipped library holds no other FNX_ / FENNEC_ environment name as a string
     blob = open(fennec_amd.LIB_PATH, "rb").read()
     names = set(m.decode() for m in re.findall(rb"(?<![A-Z0-9_])(?:FNX|FENNEC)_[A-Z0-9_]{3,}(?![A-Za-z0-9_])", blob))
-    allowed = RELEASE_ENV | {n for n in names if n.startswith(("FNX_ERR", "FNX_BLUR_", "FNX_HOST", "FNX_DEVICE", "FNX_PROF", "FNX_JPEG_HOST_MAX"))}
+    allowed = RELEASE_ENV | {n for n in names if n.startswith(("FNX_ERR", "FNX_BLUR_", "FNX_HOST", "FNX_DEVICE", "FNX_PROF", "FNX_JPEG_HOST_MAX", "FNX_BATCH_MAX"))}
     assert names <= allowed, sorted(names - allowed)
 
 

@@ -1951,6 +1951,9 @@ def test_batch_entry_points_refuse_bad_arguments(orc):
     refused(lib.fnx_sharpen_batch(c._h, 2, pa, 4 * W, W, H, 0.5, pa, 4 * W), "sharpen dst aliases src")
     refused(lib.fnx_sharpen_batch(c._h, 2, pa, 4 * W - 4, W, H, 0.5, po, 4 * W), "sharpen stride below a row")
     assert lib.fnx_sharpen_batch(c._h, 0, none, 4 * W, W, H, 0.5, none, 4 * W) == 0
+    many = (C.c_void_p * 65536)(*([a[0].data_ptr()] * 65536))           # one more than FNX_BATCH_MAX: refused before anything is read
+    refused(lib.fnx_sharpen_batch(c._h, 65536, many, 4 * W, W, H, 0.5, many, 4 * W), "sharpen n = 65536")
+    refused(lib.fnx_ssim_batch_enqueue(c._h, 65536, many, 4 * W, many, 4 * W, W, H, f64(win)), "ssim n = 65536")
     # SSIM / MSSSIM batches
     refused(lib.fnx_ssim_batch_enqueue(c._h, -2, pa, 4 * W, pb, 4 * W, W, H, f64(win)), "ssim n = -2")
     refused(lib.fnx_ssim_batch_enqueue(c._h, 2, pa, 4 * W, none, 4 * W, W, H, f64(win)), "ssim null bs")
